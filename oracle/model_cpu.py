@@ -1,0 +1,102 @@
+"""CPU restatement of LidarCenterNet (team_code_transfuser/model.py:538-805) and of the training
+step of Engine.train (train.py:295-318).  TEST INFRASTRUCTURE / CPU baseline.
+
+``backbone_module`` lets the authoring-container tests plug in the reference's own
+TransfuserBackbone (imported unmodified) instead of oracle.transfuser_cpu.
+"""
+import numpy as np
+import torch
+from torch import nn
+import torch.nn.functional as F
+
+from . import transfuser_cpu
+from .centernet import LidarCenterNetHead
+
+
+class LidarCenterNet(nn.Module):
+    def __init__(self, config, device='cpu', backbone='transFuser', image_architecture='regnety_032',
+                 lidar_architecture='regnety_032', use_velocity=True, backbone_module=None, make_net=None):
+        super().__init__()
+        self.config = config
+        self.pred_len = config.pred_len
+        self.use_target_point_image = config.use_target_point_image
+        self.gru_concat_target_point = config.gru_concat_target_point
+        assert not config.use_point_pillars, "pillars: see oracle/pillars.py"
+        tf = backbone_module or transfuser_cpu
+        assert backbone == 'transFuser'
+        kw = {} if backbone_module is not None else dict(make_net=make_net)
+        self._model = tf.TransfuserBackbone(config, image_architecture, lidar_architecture, use_velocity=use_velocity, **kw)
+        if config.multitask:
+            self.seg_decoder = tf.SegDecoder(config, config.perception_output_features)
+            self.depth_decoder = tf.DepthDecoder(config, config.perception_output_features)
+        ch = config.channel
+        self.pred_bev = nn.Sequential(nn.Conv2d(ch, ch, 3, 1, 1), nn.ReLU(inplace=True), nn.Conv2d(ch, 3, 1))
+        self.head = LidarCenterNetHead(ch, ch, 1, train_cfg=config)
+        self.join = nn.Sequential(nn.Linear(512, 256), nn.ReLU(inplace=True), nn.Linear(256, 128), nn.ReLU(inplace=True),
+                                  nn.Linear(128, 64), nn.ReLU(inplace=True))
+        self.decoder = nn.GRUCell(input_size=4 if self.gru_concat_target_point else 2, hidden_size=config.gru_hidden_size)
+        self.output = nn.Linear(config.gru_hidden_size, 3)
+
+    def forward_gru(self, z, target_point):  # model.py:611-646
+        z = self.join(z)
+        x = torch.zeros(z.shape[0], 2, dtype=z.dtype)
+        tp = target_point.clone()
+        tp[:, 1] *= -1
+        wps = []
+        for _ in range(self.pred_len):
+            x_in = torch.cat([x, tp], dim=1) if self.gru_concat_target_point else x
+            z = self.decoder(x_in, z)
+            x = self.output(z)[:, :2] + x
+            wps.append(x)
+        pred_wp = torch.stack(wps, dim=1)
+        shift = torch.zeros_like(pred_wp)
+        shift[:, :, 0] = self.config.lidar_pos[0]
+        return pred_wp - shift
+
+    def forward(self, rgb, lidar_bev, ego_waypoint, target_point, target_point_image, ego_vel, bev, label, depth, semantic,
+                num_points=None, save_path=None, bev_points=None, cam_points=None):  # model.py:733-805
+        if self.use_target_point_image:
+            lidar_bev = torch.cat((lidar_bev, target_point_image), dim=1)
+        features, grid, fused = self._model(rgb, lidar_bev, ego_vel)
+        pred_wp = self.forward_gru(fused, target_point)
+        cfg = self.config
+        pred_bev = F.interpolate(self.pred_bev(features[0]), (cfg.bev_resolution_height, cfg.bev_resolution_width),
+                                 mode='bilinear', align_corners=True)
+        loss = dict(loss_wp=torch.mean(torch.abs(pred_wp - ego_waypoint)),
+                    loss_bev=F.cross_entropy(pred_bev, bev, weight=pred_bev.new_tensor([1., 1., 3.])).mean())
+        preds = self.head.forward_single(features[0])
+        loss.update(self.head.loss(preds, label, torch.zeros_like(label[:, :, 0]), label.sum(dim=-1) == 0.))
+        if cfg.multitask:
+            loss['loss_depth'] = cfg.ls_depth * F.l1_loss(self.depth_decoder(grid), depth).mean()
+            loss['loss_semantic'] = cfg.ls_seg * F.cross_entropy(self.seg_decoder(grid), semantic).mean()
+        else:
+            loss['loss_depth'] = torch.zeros_like(loss['loss_wp'])
+            loss['loss_semantic'] = torch.zeros_like(loss['loss_wp'])
+        self._last = dict(pred_wp=pred_wp, pred_bev=pred_bev, preds=preds, features=features, grid=grid, fused=fused)
+        return loss
+
+
+def total_loss(losses, config):
+    """train.py:307-311."""
+    w = dict(zip(config.detailed_losses, config.detailed_losses_weights))
+    total = torch.tensor(0.0)
+    for k, v in losses.items():
+        total = total + w[k] * v
+    return total
+
+
+def train_step(model, optimizer, batch, config):
+    """One iteration of Engine.train (train.py:304-316)."""
+    optimizer.zero_grad(set_to_none=True)
+    losses = model(batch['rgb'], batch['lidar'], ego_waypoint=batch['ego_waypoint'], target_point=batch['target_point'],
+                   target_point_image=batch['target_point_image'], ego_vel=batch['ego_vel'].reshape(-1, 1), bev=batch['bev'],
+                   label=batch['label'], depth=batch['depth'], semantic=batch['semantic'])
+    loss = total_loss(losses, config)
+    loss.backward()
+    optimizer.step()
+    return loss.detach(), {k: v.detach() for k, v in losses.items()}
+
+
+def make_optimizer(model, lr=1e-4):
+    """train.py:142: AdamW, torch defaults (betas .9/.999, eps 1e-8, weight_decay 0.01)."""
+    return torch.optim.AdamW(model.parameters(), lr=lr)

@@ -1,0 +1,21 @@
+"""Minimal ``timm`` stand-in so the reference's transfuser.py (transfuser.py:5,380,442) imports
+unmodified in the authoring container.  Test infrastructure; resolves through oracle.regnet."""
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..", ".."))
+from oracle import regnet as _regnet  # noqa: E402
+
+_REGISTRY = {}
+
+
+def register(name, fn):
+    _REGISTRY[name] = fn
+
+
+def create_model(architecture, pretrained=False, **kw):
+    if architecture in _REGISTRY:
+        return _REGISTRY[architecture]()
+    if architecture == "regnety_032":
+        return _regnet.regnety_032()  # pretrained weights need network: seeded random init instead
+    raise ValueError("timm shim only provides regnety_032 (+registered test nets), got %r" % architecture)

@@ -1,0 +1,224 @@
+"""CPU fp32 restatement of team_code_transfuser/transfuser.py (TEST INFRASTRUCTURE).
+
+Pinned in the authoring container against the reference's own module imported unmodified
+(tests/test_oracle_pinning.py, fixtures from tests/golden/make_golden.py).  Parameter names
+are the reference's, so a reference state_dict loads with strict=True.
+"""
+import math
+import torch
+from torch import nn
+import torch.nn.functional as F
+
+from . import regnet
+
+
+def normalize_imagenet(x):
+    """transfuser.py:419-428."""
+    mean = x.new_tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+    std = x.new_tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    return (x / 255.0 - mean) / std
+
+
+class SelfAttention(nn.Module):
+    """transfuser.py:491-527: separate k/q/v Linear, 4 heads, softmax(qk^T/sqrt(hs)), no mask."""
+
+    def __init__(self, c, n_head, attn_pdrop, resid_pdrop):
+        super().__init__()
+        self.key = nn.Linear(c, c)
+        self.query = nn.Linear(c, c)
+        self.value = nn.Linear(c, c)
+        self.attn_drop = nn.Dropout(attn_pdrop)
+        self.resid_drop = nn.Dropout(resid_pdrop)
+        self.proj = nn.Linear(c, c)
+        self.n_head = n_head
+
+    def forward(self, x):
+        B, T, C = x.shape
+        hs = C // self.n_head
+        split = lambda t: t.view(B, T, self.n_head, hs).transpose(1, 2)
+        k, q, v = split(self.key(x)), split(self.query(x)), split(self.value(x))
+        att = self.attn_drop(F.softmax((q @ k.transpose(-2, -1)) * (1.0 / math.sqrt(hs)), dim=-1))
+        y = (att @ v).transpose(1, 2).contiguous().view(B, T, C)
+        return self.resid_drop(self.proj(y))
+
+
+class Block(nn.Module):
+    """transfuser.py:530-549 (MLP activation is ReLU)."""
+
+    def __init__(self, c, n_head, block_exp, attn_pdrop, resid_pdrop):
+        super().__init__()
+        self.ln1 = nn.LayerNorm(c)
+        self.ln2 = nn.LayerNorm(c)
+        self.attn = SelfAttention(c, n_head, attn_pdrop, resid_pdrop)
+        self.mlp = nn.Sequential(nn.Linear(c, block_exp * c), nn.ReLU(True), nn.Linear(block_exp * c, c),
+                                 nn.Dropout(resid_pdrop))
+
+    def forward(self, x):
+        x = x + self.attn(self.ln1(x))
+        return x + self.mlp(self.ln2(x))
+
+
+class GPT(nn.Module):
+    """transfuser.py:284-366, incl. quirk Q1 (raw view back to NCHW at :363-364)."""
+
+    def __init__(self, n_embd, config, use_velocity):
+        super().__init__()
+        self.n_embd = n_embd
+        self.n_img = config.img_vert_anchors * config.img_horz_anchors
+        self.n_lid = config.lidar_vert_anchors * config.lidar_horz_anchors
+        self.pos_emb = nn.Parameter(torch.zeros(1, self.n_img + self.n_lid, n_embd))
+        self.use_velocity = use_velocity
+        if use_velocity:
+            self.vel_emb = nn.Linear(1, n_embd)
+        self.drop = nn.Dropout(config.embd_pdrop)
+        self.blocks = nn.Sequential(*[Block(n_embd, config.n_head, config.block_exp, config.attn_pdrop, config.resid_pdrop)
+                                      for _ in range(config.n_layer)])
+        self.ln_f = nn.LayerNorm(n_embd)
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                m.weight.data.normal_(mean=config.gpt_linear_layer_init_mean, std=config.gpt_linear_layer_init_std)
+                m.bias.data.zero_()
+            elif isinstance(m, nn.LayerNorm):
+                m.bias.data.zero_()
+                m.weight.data.fill_(config.gpt_layer_norm_init_weight)
+
+    def forward(self, img, lid, velocity):
+        B = lid.shape[0]
+        ih, iw = img.shape[2:]
+        lh, lw = lid.shape[2:]
+        tok = torch.cat((img.flatten(2).transpose(1, 2), lid.flatten(2).transpose(1, 2)), dim=1)
+        x = self.pos_emb + tok
+        if self.use_velocity:
+            x = x + self.vel_emb(velocity).unsqueeze(1)
+        x = self.ln_f(self.blocks(self.drop(x)))
+        # Q1: (hw, C) token memory is reinterpreted as (C, h, w) WITHOUT permuting back
+        return (x[:, :self.n_img].contiguous().view(B, -1, ih, iw),
+                x[:, self.n_img:].contiguous().view(B, -1, lh, lw))
+
+
+class _Trunk(nn.Module):
+    """The reference's re-labelled timm trunk (transfuser.py:383-393, 445-455).
+
+    The aliases are real attributes (so state_dict carries the duplicate keys the reference
+    checkpoints carry).  ``lidar=True`` reproduces LidarEncoder's conv1 swap + ``del stem.conv``.
+    """
+
+    def __init__(self, net, in_channels=None):
+        super().__init__()
+        net.fc = None
+        net.conv1 = net.stem.conv
+        net.bn1 = net.stem.bn
+        net.act1 = nn.Sequential()
+        net.maxpool = nn.Sequential()
+        for i in range(1, 5):
+            setattr(net, "layer%d" % i, getattr(net, "s%d" % i))
+        net.global_pool = nn.AdaptiveAvgPool2d(1)
+        net.head = nn.Sequential()
+        if in_channels is not None:
+            old = net.conv1
+            net.conv1 = nn.Conv2d(in_channels, old.out_channels, old.kernel_size, old.stride, old.padding, bias=False)
+            del net.stem.conv
+        self.net = net
+
+
+class ImageCNN(nn.Module):
+    def __init__(self, make_net):
+        super().__init__()
+        self.normalize = True
+        self.features = _Trunk(make_net()).net
+
+
+class LidarEncoder(nn.Module):
+    def __init__(self, make_net, in_channels):
+        super().__init__()
+        self._model = _Trunk(make_net(), in_channels).net
+
+
+class TransfuserBackbone(nn.Module):
+    """transfuser.py:7-211."""
+
+    def __init__(self, config, image_architecture='regnety_032', lidar_architecture='regnety_032', use_velocity=True,
+                 make_net=None):
+        super().__init__()
+        self.config = config
+        make_net = make_net or regnet.regnety_032
+        self.avgpool_img = nn.AdaptiveAvgPool2d((config.img_vert_anchors, config.img_horz_anchors))
+        self.avgpool_lidar = nn.AdaptiveAvgPool2d((config.lidar_vert_anchors, config.lidar_horz_anchors))
+        self.image_encoder = ImageCNN(make_net)
+        in_ch = config.num_features[-1] if config.use_point_pillars else 2 * config.lidar_seq_len
+        if config.use_target_point_image:
+            in_ch += 1
+        self.lidar_encoder = LidarEncoder(make_net, in_ch)
+        chs = [f['num_chs'] for f in self.image_encoder.features.feature_info]
+        for i in range(1, 5):
+            setattr(self, "transformer%d" % i, GPT(chs[i], config, use_velocity))
+        pf = config.perception_output_features
+        if chs[4] != pf:
+            self.change_channel_conv_image = nn.Conv2d(chs[4], pf, (1, 1))
+            self.change_channel_conv_lidar = nn.Conv2d(chs[4], pf, (1, 1))
+        else:
+            self.change_channel_conv_image = nn.Sequential()
+            self.change_channel_conv_lidar = nn.Sequential()
+        ch = config.bev_features_chanels
+        self.relu = nn.ReLU(inplace=True)
+        self.upsample = nn.Upsample(scale_factor=config.bev_upsample_factor, mode='bilinear', align_corners=False)
+        self.up_conv5 = nn.Conv2d(ch, ch, (1, 1))
+        self.up_conv4 = nn.Conv2d(ch, ch, (1, 1))
+        self.up_conv3 = nn.Conv2d(ch, ch, (1, 1))
+        self.c5_conv = nn.Conv2d(pf, ch, (1, 1))
+
+    def top_down(self, x):
+        p5 = self.relu(self.c5_conv(x))
+        p4 = self.relu(self.up_conv5(self.upsample(p5)))
+        p3 = self.relu(self.up_conv4(self.upsample(p4)))
+        p2 = self.relu(self.up_conv3(self.upsample(p3)))
+        return p2, p3, p4, p5
+
+    def forward(self, image, lidar, velocity):
+        im, li = self.image_encoder.features, self.lidar_encoder._model
+        x = im.bn1(im.conv1(normalize_imagenet(image)))
+        y = li.bn1(li.conv1(lidar))
+        for i in range(1, 5):
+            x = getattr(im, "layer%d" % i)(x)
+            y = getattr(li, "layer%d" % i)(y)
+            fx, fy = getattr(self, "transformer%d" % i)(self.avgpool_img(x), self.avgpool_lidar(y), velocity)
+            x = x + F.interpolate(fx, size=x.shape[2:], mode='bilinear', align_corners=False)
+            y = y + F.interpolate(fy, size=y.shape[2:], mode='bilinear', align_corners=False)
+        x = self.change_channel_conv_image(x)
+        y = self.change_channel_conv_lidar(y)
+        fused = torch.flatten(im.global_pool(x), 1) + torch.flatten(li.global_pool(y), 1)
+        return self.top_down(y), x, fused
+
+
+def _decoder(config, latent, out_ch):
+    c1, c2, c3 = config.deconv_channel_num_1, config.deconv_channel_num_2, config.deconv_channel_num_3
+    conv = lambda a, b: nn.Conv2d(a, b, 3, 1, 1)
+    return (nn.Sequential(conv(latent, c1), nn.ReLU(True), conv(c1, c2), nn.ReLU(True)),
+            nn.Sequential(conv(c2, c3), nn.ReLU(True), conv(c3, c3), nn.ReLU(True)),
+            nn.Sequential(conv(c3, c3), nn.ReLU(True), conv(c3, out_ch)))
+
+
+class SegDecoder(nn.Module):
+    """transfuser.py:214-246."""
+
+    def __init__(self, config, latent_dim=512):
+        super().__init__()
+        self.config = config
+        self.deconv1, self.deconv2, self.deconv3 = _decoder(config, latent_dim, config.num_class)
+
+    def forward(self, x):
+        x = F.interpolate(self.deconv1(x), scale_factor=self.config.deconv_scale_factor_1, mode='bilinear', align_corners=False)
+        x = F.interpolate(self.deconv2(x), scale_factor=self.config.deconv_scale_factor_2, mode='bilinear', align_corners=False)
+        return self.deconv3(x)
+
+
+class DepthDecoder(SegDecoder):
+    """transfuser.py:249-281: same trunk, 1 output channel, sigmoid + squeeze."""
+
+    def __init__(self, config, latent_dim=512):
+        nn.Module.__init__(self)
+        self.config = config
+        self.deconv1, self.deconv2, self.deconv3 = _decoder(config, latent_dim, 1)
+
+    def forward(self, x):
+        return torch.sigmoid(super().forward(x)).squeeze(1)
