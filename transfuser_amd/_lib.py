@@ -1,0 +1,81 @@
+"""ctypes binding of libtransfuser_hip.so (the C ABI declared in include/transfuser_hip.h).
+
+The product path has NO fallback: if the HIP library is missing, or a tensor is not on a GPU,
+the call raises.  ``_install_test_backend`` exists only for tests/emu (the same kernel sources
+compiled for the host against a fiber emulator) and is never called from the package.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtransfuser_hip.so")
+
+_lib = None
+_test_backend = False
+
+c_f = ctypes.c_float
+c_i = ctypes.c_int
+c_l = ctypes.c_int64
+c_p = ctypes.c_void_p
+
+
+class GemmDesc(ctypes.Structure):
+    _fields_ = [("a", c_p), ("b", c_p), ("c", c_p), ("bias", c_p), ("res", c_p),
+                ("m", c_i), ("n", c_i), ("k", c_i), ("a_trans", c_i), ("b_trans", c_i),
+                ("lda", c_l), ("ldb", c_l), ("ldc", c_l), ("ldres", c_l),
+                ("batch", c_i), ("inner", c_i),
+                ("sa_outer", c_l), ("sa_inner", c_l), ("sb_outer", c_l), ("sb_inner", c_l), ("sc_outer", c_l), ("sc_inner", c_l),
+                ("alpha", c_f), ("relu", c_i), ("accumulate", c_i)]
+
+
+class ConvGeom(ctypes.Structure):
+    _fields_ = [(n, c_i) for n in ("B", "Hi", "Wi", "Cin", "Ho", "Wo", "Cout", "ksize", "stride", "pad", "groups")]
+
+
+def _declare(lib):
+    lib.tf_last_error.restype = ctypes.c_char_p
+    lib.tf_version.restype = c_i
+    return lib
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("transfuser_amd: %s not found - build it with `python -m transfuser_amd.build` "
+                               "(hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
+        _lib = _declare(ctypes.CDLL(LIB_PATH))
+    return _lib
+
+
+def _install_test_backend(cdll):
+    """tests/emu only: route the C ABI to the host-emulated build of the same kernels."""
+    global _lib, _test_backend
+    _lib = _declare(cdll)
+    _test_backend = True
+
+
+def is_test_backend():
+    return _test_backend
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise RuntimeError("transfuser_hip %s failed (%d): %s" % (what, rc, load().tf_last_error().decode()))
+
+
+def stream_of(t):
+    if t.is_cuda:
+        return c_p(torch.cuda.current_stream(t.device).cuda_stream)
+    if not _test_backend:
+        raise RuntimeError("transfuser_amd ops need GPU tensors (got device %s); there is no CPU path" % t.device)
+    return c_p(0)
+
+
+def ptr(t):
+    if t is None:
+        return c_p(0)
+    assert t.dtype in (torch.float32, torch.int32, torch.int64, torch.uint8), t.dtype
+    return c_p(t.data_ptr())

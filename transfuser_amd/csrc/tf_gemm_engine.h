@@ -1,0 +1,389 @@
+// fp32 MFMA implicit-GEMM engine for gfx950 (v_mfma_f32_32x32x2_f32: exact f32, 157 TF peak).
+//
+//   C[z](i, j) (op)= alpha * sum_k A[z](i, k) * B[z](k, j)  (+ bias[j]) (+ res(i, j)) (relu)
+//
+// One kernel template serves every dense contraction on the TransFuser training path
+// (SURVEY.md section 2.2 rows K1/K2/K3/K9/K10 and their dgrad/wgrad): the operands are described by
+// *loader* structs that map a logical (row, col) - col contiguous in memory - to an address
+// (plain strided matrices, NHWC im2col gathers for 3x3/1x1/strided/grouped convolutions, the
+// transposed gather of conv dgrad, channels-last weights).  Each operand is either "KC" (rows =
+// i or j, cols = k: needs a transpose on its way into LDS) or "IC" (rows = k, cols = i or j:
+// copied straight).  LDS tiles are K-major ([BK][BM+4]) so an MFMA operand fetch is a
+// conflict-free ds_read_b32 (lanes 0-31 consecutive, lanes 32-63 the next k row).
+//
+// Tile: BM x BN x 16, 256 threads = 4 waves, each wave owns (BM/WAVES_M) x (BN/WAVES_N) as
+// 32x32 MFMA tiles.  Global->register prefetch of tile t+1 is issued before the MFMAs of tile
+// t and written to the other LDS buffer after them: one barrier per K tile.
+#pragma once
+#include "tf_common.h"
+
+namespace tf {
+
+constexpr int GEMM_BK = 16;
+constexpr int GEMM_PAD = 4;
+
+__device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+// ---------------------------------------------------------------- loaders
+struct PlainRow { const float* p; };
+
+// X(r, c) = p[r*ld + c], r < rows, c < cols.  Batch z -> p + (z / inner) * s_outer + (z % inner) * s_inner.
+struct PlainOp {
+    const float* p; long ld; int rows, cols, vec; long s_outer, s_inner; int inner;
+    typedef PlainRow Row;
+    __device__ __forceinline__ void set_batch(int z) { p += (long)(z / inner) * s_outer + (long)(z % inner) * s_inner; }
+    __device__ __forceinline__ Row row(int r) const { Row w; w.p = (r < rows) ? p + (long)r * ld : nullptr; return w; }
+    __device__ __forceinline__ float4 load(const Row& w, int c) const {
+        if (!w.p || c >= cols) return f4zero();
+        if (vec) return *reinterpret_cast<const float4*>(w.p + c);
+        float4 v = f4zero();
+        v.x = w.p[c];
+        if (c + 1 < cols) v.y = w.p[c + 1];
+        if (c + 2 < cols) v.z = w.p[c + 2];
+        if (c + 3 < cols) v.w = w.p[c + 3];
+        return v;
+    }
+};
+
+// Conv weight in channels-last physical order W[co][tap][ci] seen as rows = (tap, co), cols = ci
+// (the B operand of dgrad).  Batch z = group.
+struct WDgradOp {
+    const float* w; int taps, Cog, Cig, rows, cols, vec; long gstride;
+    typedef PlainRow Row;
+    __device__ __forceinline__ void set_batch(int z) { w += (long)z * gstride; }
+    __device__ __forceinline__ Row row(int k) const {
+        Row r; r.p = nullptr;
+        if (k < rows) { int tap = k / Cog; int co = k - tap * Cog; r.p = w + ((long)co * taps + tap) * Cig; }
+        return r;
+    }
+    __device__ __forceinline__ float4 load(const Row& r, int c) const {
+        if (!r.p || c >= cols) return f4zero();
+        if (vec) return *reinterpret_cast<const float4*>(r.p + c);
+        float4 v = f4zero();
+        v.x = r.p[c];
+        if (c + 1 < cols) v.y = r.p[c + 1];
+        if (c + 2 < cols) v.z = r.p[c + 2];
+        if (c + 3 < cols) v.w = r.p[c + 3];
+        return v;
+    }
+};
+
+struct ConvRow { long base; int h0, w0, ok; };
+
+// im2col view of an NHWC tensor X (B, Hi, Wi, Ct): rows = output pixels (b, oh, ow), cols = (tap, ci)
+// with ci fastest in [0, Cg).  Batch z = group (channel offset z*Cg).
+struct Im2colOp {
+    const float* x; int Hi, Wi, Ct, Ho, Wo, ks, stride, pad, Cg, rows, cols, vec, coff;
+    typedef ConvRow Row;
+    __device__ __forceinline__ void set_batch(int z) { coff += z * Cg; }
+    __device__ __forceinline__ Row row(int r) const {
+        Row w; w.ok = r < rows; w.base = 0; w.h0 = 0; w.w0 = 0;
+        if (w.ok) {
+            int ow = r % Wo; int t = r / Wo; int oh = t % Ho; int b = t / Ho;
+            w.base = (long)b * Hi * Wi; w.h0 = oh * stride - pad; w.w0 = ow * stride - pad;
+        }
+        return w;
+    }
+    __device__ __forceinline__ float at(const Row& w, int c) const {
+        if (c >= cols) return 0.f;
+        int tap = c / Cg; int ci = c - tap * Cg; int kh = tap / ks; int kw = tap - kh * ks;
+        int ih = w.h0 + kh, iw = w.w0 + kw;
+        if ((unsigned)ih >= (unsigned)Hi || (unsigned)iw >= (unsigned)Wi) return 0.f;
+        return x[(w.base + (long)ih * Wi + iw) * Ct + coff + ci];
+    }
+    __device__ __forceinline__ float4 load(const Row& w, int c) const {
+        if (!w.ok || c >= cols) return f4zero();
+        if (vec) {
+            int tap = c / Cg; int ci = c - tap * Cg; int kh = tap / ks; int kw = tap - kh * ks;
+            int ih = w.h0 + kh, iw = w.w0 + kw;
+            if ((unsigned)ih >= (unsigned)Hi || (unsigned)iw >= (unsigned)Wi) return f4zero();
+            return *reinterpret_cast<const float4*>(x + (w.base + (long)ih * Wi + iw) * Ct + coff + ci);
+        }
+        return make_float4(at(w, c), at(w, c + 1), at(w, c + 2), at(w, c + 3));
+    }
+};
+
+// Transposed gather for conv dgrad: dY NHWC (B, Ho, Wo, Ct); rows = INPUT pixels (b, ih, iw),
+// cols = (tap, co), co fastest in [0, Cg).  Element = dY[b, (ih+pad-kh)/s, (iw+pad-kw)/s, co] if divisible.
+struct Im2colTOp {
+    const float* dy; int Hi, Wi, Ct, Ho, Wo, ks, stride, pad, Cg, rows, cols, vec, coff;
+    typedef ConvRow Row;
+    __device__ __forceinline__ void set_batch(int z) { coff += z * Cg; }
+    __device__ __forceinline__ Row row(int r) const {
+        Row w; w.ok = r < rows; w.base = 0; w.h0 = 0; w.w0 = 0;
+        if (w.ok) {
+            int iw = r % Wi; int t = r / Wi; int ih = t % Hi; int b = t / Hi;
+            w.base = (long)b * Ho * Wo; w.h0 = ih + pad; w.w0 = iw + pad;
+        }
+        return w;
+    }
+    __device__ __forceinline__ const float* addr(const Row& w, int c) const {
+        int tap = c / Cg; int co = c - tap * Cg; int kh = tap / ks; int kw = tap - kh * ks;
+        int th = w.h0 - kh, tw = w.w0 - kw;
+        if (th < 0 || tw < 0) return nullptr;
+        int oh = th, ow = tw;
+        if (stride != 1) {
+            oh = th / stride; ow = tw / stride;
+            if (oh * stride != th || ow * stride != tw) return nullptr;
+        }
+        if (oh >= Ho || ow >= Wo) return nullptr;
+        return dy + (w.base + (long)oh * Wo + ow) * Ct + coff + co;
+    }
+    __device__ __forceinline__ float at(const Row& w, int c) const {
+        if (c >= cols) return 0.f;
+        const float* p = addr(w, c);
+        return p ? *p : 0.f;
+    }
+    __device__ __forceinline__ float4 load(const Row& w, int c) const {
+        if (!w.ok || c >= cols) return f4zero();
+        if (vec) {
+            const float* p = addr(w, c);
+            return p ? *reinterpret_cast<const float4*>(p) : f4zero();
+        }
+        return make_float4(at(w, c), at(w, c + 1), at(w, c + 2), at(w, c + 3));
+    }
+};
+
+// ---------------------------------------------------------------- epilogue
+struct GemmEpi {
+    float* C; long ldc; long sc_outer, sc_inner; int inner;
+    const float* bias; long sbias;   // per-column bias; batch z adds z*sbias
+    const float* res; long ldres;    // residual with C's batch strides
+    float alpha; int relu; int mode; // mode 0: store, 1: +=, 2: atomicAdd
+};
+
+// ---------------------------------------------------------------- kernel
+template <int R, bool KC>
+struct TileMap {  // float4 slots of an operand tile (R outer x BK reduction), spread over 256 threads
+    static constexpr int kSlots = R * GEMM_BK / 4;
+    static constexpr int kPerThread = (kSlots + 255) / 256;
+};
+
+template <int BM, int BN, int WAVES_M, class LA, bool A_KC, class LB, bool B_KC>
+__global__ void __launch_bounds__(256) gemm_kernel(LA la, LB lb, GemmEpi ep, int M, int N, int K, int tiles_m, int tiles_n,
+                                                   int kchunk) {
+    constexpr int BK = GEMM_BK;
+    constexpr int WAVES_N = 4 / WAVES_M;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    static_assert(WM % 32 == 0 && WN % 32 == 0 && TM >= 1 && TN >= 1, "wave tile must be 32x32 multiples");
+    constexpr int NLA = TileMap<BM, A_KC>::kPerThread, NLB = TileMap<BN, B_KC>::kPerThread;
+
+    __shared__ __attribute__((aligned(16))) float As[2][BK][BM + GEMM_PAD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN + GEMM_PAD];
+
+    const int tid = threadIdx.x;
+    const int z = blockIdx.z;
+    la.set_batch(z);
+    lb.set_batch(z);
+
+    // XCD-aware, bijective block -> tile map: the 8 XCDs (private L2 each) get contiguous tile
+    // ranges; inside a range tn is fastest so neighbouring tiles share the A row panel.
+    int tile;
+    {
+        const int nt = tiles_m * tiles_n, bid = blockIdx.x;
+        const int q = nt >> 3, r = nt & 7, xcd = bid & 7, loc = bid >> 3;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int i0 = (tile / tiles_n) * BM, j0 = (tile % tiles_n) * BN;
+    const int kbeg = blockIdx.y * kchunk;
+    const int kend = (kbeg + kchunk < K) ? kbeg + kchunk : K;
+    const int nkt = (kend - kbeg + BK - 1) / BK;
+
+    // KC operands: a thread's rows are fixed over the K loop -> resolve them once
+    typename LA::Row arow[NLA];
+    typename LB::Row brow[NLB];
+    if (A_KC) {
+#pragma unroll
+        for (int p = 0; p < NLA; ++p) arow[p] = la.row(i0 + ((tid + p * 256) >> 2));
+    }
+    if (B_KC) {
+#pragma unroll
+        for (int p = 0; p < NLB; ++p) brow[p] = lb.row(j0 + ((tid + p * 256) >> 2));
+    }
+
+    float4 ra[NLA], rb[NLB];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int p = 0; p < NLA; ++p) {
+            const int f = tid + p * 256;
+            if (A_KC) {
+                ra[p] = (f < BM * 4) ? la.load(arow[p], k0 + (f & 3) * 4 < kend ? k0 + (f & 3) * 4 : 0x3fffffff) : f4zero();
+            } else {
+                const int kr = f / (BM / 4), cq = f - kr * (BM / 4);
+                ra[p] = (kr < BK && k0 + kr < kend) ? la.load(la.row(k0 + kr), i0 + cq * 4) : f4zero();
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < NLB; ++p) {
+            const int f = tid + p * 256;
+            if (B_KC) {
+                rb[p] = (f < BN * 4) ? lb.load(brow[p], k0 + (f & 3) * 4 < kend ? k0 + (f & 3) * 4 : 0x3fffffff) : f4zero();
+            } else {
+                const int kr = f / (BN / 4), cq = f - kr * (BN / 4);
+                rb[p] = (kr < BK && k0 + kr < kend) ? lb.load(lb.row(k0 + kr), j0 + cq * 4) : f4zero();
+            }
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < NLA; ++p) {
+            const int f = tid + p * 256;
+            if (A_KC) {
+                if (f < BM * 4) {
+                    const int r = f >> 2, kq = (f & 3) * 4;
+                    As[buf][kq + 0][r] = ra[p].x; As[buf][kq + 1][r] = ra[p].y;
+                    As[buf][kq + 2][r] = ra[p].z; As[buf][kq + 3][r] = ra[p].w;
+                }
+            } else {
+                const int kr = f / (BM / 4), cq = f - kr * (BM / 4);
+                if (kr < BK) *reinterpret_cast<float4*>(&As[buf][kr][cq * 4]) = ra[p];
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < NLB; ++p) {
+            const int f = tid + p * 256;
+            if (B_KC) {
+                if (f < BN * 4) {
+                    const int r = f >> 2, kq = (f & 3) * 4;
+                    Bs[buf][kq + 0][r] = rb[p].x; Bs[buf][kq + 1][r] = rb[p].y;
+                    Bs[buf][kq + 2][r] = rb[p].z; Bs[buf][kq + 3][r] = rb[p].w;
+                }
+            } else {
+                const int kr = f / (BN / 4), cq = f - kr * (BN / 4);
+                if (kr < BK) *reinterpret_cast<float4*>(&Bs[buf][kr][cq * 4]) = rb[p];
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wm0 = (wave % WAVES_M) * WM, wn0 = (wave / WAVES_M) * WN;
+
+    if (nkt > 0) {
+        fetch(kbeg);
+        stash(0);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < nkt;
+        if (more) fetch(kbeg + (kt + 1) * BK);
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int t = 0; t < TM; ++t) a[t] = As[cur][kk * 2 + hi][wm0 + t * 32 + l31];
+#pragma unroll
+            for (int t = 0; t < TN; ++t) b[t] = Bs[cur][kk * 2 + hi][wn0 + t * 32 + l31];
+#pragma unroll
+            for (int t = 0; t < TM; ++t)
+#pragma unroll
+                for (int u = 0; u < TN; ++u) mfma_32x32x2(a[t], b[u], acc[t][u]);
+        }
+        if (more) stash(cur ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: lane holds column j of 16 rows per 32x32 tile
+    const long cz = (long)(z / ep.inner) * ep.sc_outer + (long)(z % ep.inner) * ep.sc_inner;
+    float* C = ep.C + cz;
+    const float* res = ep.res ? ep.res + cz : nullptr;
+    const float* bias = ep.bias ? ep.bias + (long)z * ep.sbias : nullptr;
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+        for (int u = 0; u < TN; ++u) {
+            const int j = j0 + wn0 + u * 32 + l31;
+            if (j >= N) continue;
+            const float bj = bias ? bias[j] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = i0 + wm0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (i >= M) continue;
+                float v = ep.alpha * acc[t][u][r] + bj;
+                if (res) v += res[(long)i * ep.ldres + j];
+                if (ep.relu) v = fmaxf(v, 0.f);
+                float* dst = C + (long)i * ep.ldc + j;
+                if (ep.mode == 0) *dst = v;
+                else if (ep.mode == 1) *dst += v;
+                else atomicAdd(dst, v);
+            }
+        }
+}
+
+// ---------------------------------------------------------------- host dispatch
+struct GemmPlan { int bm, bn, splitk; };
+
+// Heuristic tile choice: smallest BN that covers N with the least padding, BM=64 when the grid
+// would not fill the 256 CUs, split-K (atomic epilogue) for skinny outputs with deep reductions.
+inline GemmPlan plan_gemm(int M, int N, int K, int batch, bool allow_splitk) {
+    GemmPlan p;
+    if (N <= 32) p.bn = 32;
+    else if (N <= 64) p.bn = 64;
+    else if (N <= 96) p.bn = 96;
+    else {
+        // padding waste of 128-wide vs 96-wide column tiles
+        const long w128 = (long)cdiv(N, 128) * 128, w96 = (long)cdiv(N, 96) * 96;
+        p.bn = (w96 < w128) ? 96 : 128;
+    }
+    p.bm = 128;
+    const long t128 = (long)cdiv(M, 128) * cdiv(N, p.bn) * batch;
+    if (p.bn == 128 || p.bn == 64) {
+        if (t128 < 384 && M > 64) p.bm = 64;  // more, smaller tiles when the chip would be under-filled
+    }
+    p.splitk = 1;
+    if (allow_splitk) {
+        const long tiles = (long)cdiv(M, p.bm) * cdiv(N, p.bn) * batch;
+        const int ktiles = cdiv(K, GEMM_BK);
+        if (tiles < 512 && ktiles >= 16) {
+            long want = (1024 + tiles - 1) / tiles;
+            long maxs = ktiles / 8;
+            if (want > maxs) want = maxs;
+            if (want < 1) want = 1;
+            p.splitk = (int)want;
+        }
+    }
+    return p;
+}
+
+template <int BM, int BN, int WAVES_M, class LA, bool A_KC, class LB, bool B_KC>
+inline void launch_cfg(const LA& la, const LB& lb, const GemmEpi& ep, int M, int N, int K, int batch, int splitk, void* stream) {
+    const int tiles_m = cdiv(M, BM), tiles_n = cdiv(N, BN);
+    int kchunk = cdiv(cdiv(K, splitk), GEMM_BK) * GEMM_BK;
+    if (kchunk < GEMM_BK) kchunk = GEMM_BK;
+    const int nsplit = cdiv(K, kchunk);
+    dim3 grid(tiles_m * tiles_n, nsplit > 0 ? nsplit : 1, batch);
+    TF_LAUNCH((gemm_kernel<BM, BN, WAVES_M, LA, A_KC, LB, B_KC>), grid, dim3(256), stream, la, lb, ep, M, N, K, tiles_m, tiles_n,
+              kchunk);
+}
+
+template <class LA, bool A_KC, class LB, bool B_KC>
+inline int launch_gemm(const LA& la, const LB& lb, GemmEpi ep, int M, int N, int K, int batch, bool allow_splitk, void* stream,
+                       const char* what) {
+    if (M <= 0 || N <= 0 || batch <= 0) return 0;
+    // split-K only for pure accumulations (weight gradients into the grad arena): atomic epilogue
+    GemmPlan p = plan_gemm(M, N, K, batch, allow_splitk && ep.mode == 1 && !ep.bias && !ep.res && !ep.relu);
+    if (p.splitk > 1) ep.mode = 2;
+#define TF_CFG(BM_, BN_, WM_) launch_cfg<BM_, BN_, WM_, LA, A_KC, LB, B_KC>(la, lb, ep, M, N, K, batch, p.splitk, stream)
+    if (p.bm == 128) {
+        if (p.bn == 32) TF_CFG(128, 32, 4);
+        else if (p.bn == 64) TF_CFG(128, 64, 2);
+        else if (p.bn == 96) TF_CFG(128, 96, 4);
+        else TF_CFG(128, 128, 2);
+    } else {
+        if (p.bn == 64) TF_CFG(64, 64, 2);
+        else TF_CFG(64, 128, 1);
+    }
+#undef TF_CFG
+    return launch_status(what);
+}
+
+}  // namespace tf
