@@ -55,6 +55,100 @@ int tf_conv2d_fwd_f32(const tf_conv_geom* g, const float* x, const float* w, con
 int tf_conv2d_dgrad_f32(const tf_conv_geom* g, const float* dy, const float* w, float* dx, int accumulate, void* stream);
 int tf_conv2d_wgrad_f32(const tf_conv_geom* g, const float* dy, const float* x, float* dw, int accumulate, void* stream);
 
+/* Stem convolutions reading the NCHW model inputs directly (Cin <= 4, no bias, NHWC output):
+ * channels [0,C0) from s0, [C0,C0+C1) from s1 - the torch.cat of model.py:741-742 is never
+ * materialised; normalize != 0 folds normalize_imagenet (transfuser.py:419-428, K17) into the load.
+ * Replaces features.conv1 / _model.conv1 (transfuser.py:136,140,475-478). */
+int tf_stem_conv_fwd_f32(const tf_conv_geom* g, const float* s0, int C0, const float* s1, int C1, int normalize, const float* w, float* y, void* stream);
+int tf_stem_conv_wgrad_f32(const tf_conv_geom* g, const float* dy, const float* s0, int C0, const float* s1, int C1, int normalize, float* dw,
+                           int accumulate, void* stream);
+
+/* ---- row-wise normalisation ------------------------------------------------------------------ */
+
+/* nn.LayerNorm (transfuser.py:319,535-536).  bwd: dgamma/dbeta are ACCUMULATED (may be NULL). */
+int tf_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, int rows, int C, float eps, void* stream);
+int tf_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx, int dx_accumulate,
+                         float* dgamma, float* dbeta, int rows, int C, void* stream);
+/* F.softmax over attention rows (transfuser.py:520), in place; bwd turns dP into dS in place. */
+int tf_softmax_fwd_f32(float* s, int rows, int n, int ld, void* stream);
+int tf_softmax_bwd_f32(const float* p, float* dp, int rows, int n, int ld, void* stream);
+
+/* ---- per-channel reductions / BatchNorm / Squeeze-Excite ------------------------------------- */
+
+/* scratch every reduction entry point needs (one buffer per stream is enough) */
+long tf_workspace_bytes(void);
+/* timm BatchNormAct2d on NHWC (rows = B*H*W): y = bn(x) (+res) (relu); training uses batch statistics
+ * and updates the running buffers (momentum, unbiased var).  bwd accumulates dgamma/dbeta. */
+int tf_bn_fwd_f32(const float* x, int rows, int C, const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
+                  float eps, const float* res, int relu, float* y, float* save_mean, float* save_invstd, float* ws, int training, void* stream);
+int tf_bn_bwd_f32(const float* dz, const float* z, const float* x, int rows, int C, const float* gamma, const float* save_mean, const float* save_invstd,
+                  float* dx, float* dres, float* dgamma, float* dbeta, float* ws, void* stream);
+/* out[seg][c] (+)= scale * sum_rows x (* [mask > 0]): SE squeeze / global average pool
+ * (transfuser.py:203-205), bias gradients, pos_emb gradient. */
+int tf_colsum_f32(const float* x, const float* mask, int nseg, int rows_per_seg, int C, float scale, float* out, int accumulate, float* ws, void* stream);
+/* timm SEModule excite: y = x * sigmoid(gate[b][c]) and its two backward pieces. */
+int tf_se_scale_fwd_f32(const float* x, const float* gate, float* y, int B, int HW, int C, void* stream);
+int tf_se_scale_bwd_gate_f32(const float* dy, const float* x, const float* gate, float* dgate, int B, int HW, int C, float* ws, void* stream);
+int tf_se_scale_bwd_x_f32(const float* dy, const float* gate, const float* dmean, float* dx, int B, int HW, int C, int accumulate, void* stream);
+
+/* ---- resampling ------------------------------------------------------------------------------ */
+
+/* AdaptiveAvgPool2d((oh,ow)) of an NHWC map written straight into rows [tok_off, tok_off+oh*ow) of the
+ * (B, T_total, C) token matrix, + pos_emb (+ per-sample vector): transfuser.py:150-151,346-357. */
+int tf_pool_tokens_fwd_f32(const float* x, int B, int H, int W, int C, int oh, int ow, const float* pos, const float* bvec, float* tok, int T_total,
+                           int tok_off, void* stream);
+int tf_pool_tokens_bwd_f32(const float* dtok, int B, int H, int W, int C, int oh, int ow, int T_total, int tok_off, float* dx, int accumulate, void* stream);
+
+/* F.interpolate(mode='bilinear') with explicit element strides for input and output (any layout):
+ * y = up(x) (+ add);  bwd is a gather (no atomics).  transfuser.py:103,154-157,241,243; model.py:760. */
+typedef struct {
+    int B, C, Hi, Wi, Ho, Wo;
+    int64_t sb_i, sc_i, sh_i, sw_i;
+    int64_t sb_o, sc_o, sh_o, sw_o;
+    int align_corners;
+} tf_bilinear_desc;
+int tf_bilinear_fwd_f32(const tf_bilinear_desc* d, const float* x, float* y, const float* add, void* stream);
+int tf_bilinear_bwd_f32(const tf_bilinear_desc* d, const float* dy, float* dx, int accumulate, void* stream);
+
+/* ---- losses ---------------------------------------------------------------------------------- */
+
+/* F.cross_entropy(logits, target, weight=class_w) (model.py:763,783) over NHWC logits (rows, C <= 16):
+ * loss = sum w_y nll / sum w_y; dlogits = w_y (softmax - onehot) (multiply by g * (*inv_wsum) later). */
+int tf_ce_fwd_f32(const float* logits, const int64_t* target, const float* class_w, int64_t rows, int C, float* dlogits, float* loss, float* inv_wsum,
+                  float* ws, void* stream);
+/* mean |f(pred) - target| with f = identity / sigmoid (model.py:765,784); dpred un-scaled. */
+int tf_l1_fwd_f32(const float* pred, const float* target, int64_t n, int use_sigmoid, float* dpred, float* loss, float* ws, void* stream);
+/* x *= (*a_dev) * (*b_dev) * mult (device scalars optional) */
+int tf_scale_dev_f32(float* x, int64_t n, const float* a_dev, const float* b_dev, float mult, void* stream);
+/* LidarCenterNetHead.get_targets (model.py:285-374) in one launch, no host sync.
+ * tgtf (B,fh,fw,8) = [heatmap, wh_w, wh_h, off_x, off_y, yaw_res, velocity, weight]; tgti (B,fh,fw,2) = [yaw_class, brake]; cnt[b] = #(heatmap == 1) */
+int tf_centernet_targets_f32(const float* label, int B, int nbox, int fh, int fw, float ratio_w, float ratio_h, int num_dir_bins, float* tgtf,
+                             int32_t* tgti, int32_t* cnt, void* stream);
+/* LidarCenterNetHead.loss (model.py:150-248) with mmdet 2.25 semantics; pred (B,fh,fw,9+bins) =
+ * [hm logit, wh(2), offset(2), yaw_class(bins), yaw_res, velocity, brake(2)]; losses[7] in the order
+ * center_heatmap, wh, offset, yaw_class, yaw_res, velocity, brake. */
+int tf_centernet_loss_fwd_f32(const float* pred, const float* tgtf, const int32_t* tgti, const int32_t* cnt, int B, int fh, int fw, int num_dir_bins,
+                              float* losses, float* ws, void* stream);
+int tf_centernet_loss_bwd_f32(const float* pred, const float* tgtf, const int32_t* tgti, const int32_t* cnt, const float* gup, int B, int fh, int fw,
+                              int num_dir_bins, float* dpred, void* stream);
+
+/* ---- elementwise / recurrent / optimiser / data ----------------------------------------------- */
+int tf_relu_mask_f32(const float* dy, const float* y, float* out, int64_t n, void* stream);
+int tf_axpby_f32(const float* a, const float* b, float* out, float alpha, float beta, int64_t n, void* stream);
+/* nn.Dropout with a counter-based RNG keyed by (*seed_dev, site, index); calling it on dy with the
+ * same key is the backward (transfuser.py:311,504-505,542). */
+int tf_dropout_f32(const float* x, float* y, int64_t n, const uint32_t* seed_dev, uint32_t site, float p, void* stream);
+/* nn.GRUCell gate math (model.py:601,631); the four matmuls go through tf_gemm_f32. */
+int tf_gru_gates_fwd_f32(const float* gi, const float* gh, const float* h, float* hnew, float* rzn, int B, int H, void* stream);
+int tf_gru_gates_bwd_f32(const float* dhnew, const float* rzn, const float* gh, const float* h, float* dgi, float* dgh, float* dh, int B, int H, void* stream);
+/* torch.optim.AdamW (train.py:142) over a flat arena in one launch; state_dev = {step, lr} floats
+ * on the device (step is advanced by the call, so a captured hipGraph replays correctly). */
+int tf_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, float* state_dev, float beta1, float beta2, float eps, float weight_decay,
+                 void* stream);
+/* lidar_to_histogram_features (data.py:446-470): points (B, max_points, stride>=3) f32 -> (B,2,256,256),
+ * integer-exact; num_points may be NULL. */
+int tf_lidar_hist_f32(const float* points, const int32_t* num_points, int B, int max_points, int point_stride, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

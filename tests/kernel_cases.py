@@ -1,0 +1,402 @@
+"""Shared op-level parity checks: HIP kernel (through transfuser_amd.ops) vs a plain PyTorch fp32
+reference / the CPU oracle on the same seeded inputs.  ``dev`` is "cpu" for the emulated build
+(tests/test_kernels_emu.py) and "cuda" for the real MI355X run (tests/test_kernels_gpu.py).
+Tolerances: fp32, 1e-3 per north_star (most ops are far tighter); integer outputs exact."""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from transfuser_amd import ops
+
+TOL = 1e-3
+
+
+def close(a, b, tol=TOL, what=""):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = (a - b).abs().max().item() if a.numel() else 0.0
+    scale = max(1.0, b.abs().max().item() if b.numel() else 1.0)
+    assert err <= tol * scale, "%s: max err %.3e (scale %.3e)" % (what, err, scale)
+
+
+def R(*shape, seed=None, dev="cpu", scale=1.0):
+    g = torch.Generator().manual_seed(abs(hash((shape, seed))) % (2 ** 31))
+    return (torch.randn(*shape, generator=g) * scale).to(dev)
+
+
+# ---------------------------------------------------------------- GEMM
+GEMM_CASES = [(100, 72, 72), (130, 216, 40), (70, 24, 100), (33, 300, 18), (200, 90, 64), (1, 3, 64), (257, 129, 33), (10, 192, 4)]
+
+
+def check_gemm(dev, m, n, k):
+    x, w, b, r = R(m, k, dev=dev), R(n, k, dev=dev), R(n, dev=dev), R(m, n, dev=dev)
+    y = ops.linear_fwd(x, w, b, relu=True, res=r)
+    close(y, torch.relu(x @ w.t() + b + r), what="linear_fwd")
+    dy = R(m, n, seed=1, dev=dev)
+    close(ops.linear_dgrad(dy, w), dy @ w, what="linear_dgrad")
+    dw0 = R(n, k, seed=2, dev=dev)
+    dw = ops.linear_wgrad(dy, x, dw0.clone(), accumulate=True)
+    close(dw, dw0 + dy.t() @ x, what="linear_wgrad")
+    # strided views (fused qkv buffer)
+    big = R(m, 3 * n, seed=3, dev=dev)
+    close(ops.linear_dgrad(big[:, n:2 * n], w), big[:, n:2 * n] @ w, what="dgrad strided")
+
+
+BATCHED_GEMM_CASES = [(2, 4, 174, 18), (1, 4, 174, 54), (1, 2, 50, 144), (1, 4, 174, 378 // 7)]
+
+
+def check_attention(dev, B, nh, T, hs):
+    """The five batched GEMMs + softmax of one attention layer (transfuser.py:510-527) on a fused qkv buffer."""
+    C = nh * hs
+    qkv = R(B, T, 3 * C, dev=dev, scale=0.5)
+    Tp = (T + 3) // 4 * 4
+    att = torch.zeros(B * nh, T, Tp, device=dev)
+    alpha = 1.0 / math.sqrt(hs)
+    q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+    sa = (T * 3 * C, hs)
+    ops.gemm(q, k, att, T, T, hs, 3 * C, 3 * C, Tp, alpha=alpha, batch=B * nh, inner=nh, sa=sa, sb=sa, sc=(nh * T * Tp, T * Tp))
+    ops.softmax_fwd_(att, B * nh * T, T, Tp)
+    y = torch.empty(B, T, C, device=dev)
+    ops.gemm(att, v, y, T, hs, T, Tp, 3 * C, C, b_trans=True, batch=B * nh, inner=nh, sa=(nh * T * Tp, T * Tp), sb=sa, sc=(T * C, hs))
+    qh, kh, vh = [t.reshape(B, T, nh, hs).transpose(1, 2) for t in (q, k, v)]
+    pr = F.softmax((qh @ kh.transpose(-2, -1)) * alpha, dim=-1)
+    ref = (pr @ vh).transpose(1, 2).reshape(B, T, C)
+    close(att[:, :, :T].reshape(B, nh, T, T), pr, what="att probs")
+    close(y, ref, what="att out")
+    # backward GEMMs
+    dy = R(B, T, C, seed=5, dev=dev)
+    dqkv = torch.zeros_like(qkv)
+    datt = torch.zeros_like(att)
+    ops.gemm(dy, v, datt, T, T, hs, C, 3 * C, Tp, batch=B * nh, inner=nh, sa=(T * C, hs), sb=sa, sc=(nh * T * Tp, T * Tp))  # dP = dY V^T
+    ops.gemm(att, dy, dqkv[..., 2 * C:], T, hs, T, Tp, C, 3 * C, a_trans=True, b_trans=True, batch=B * nh, inner=nh,
+             sa=(nh * T * Tp, T * Tp), sb=(T * C, hs), sc=sa)  # dV = P^T dY
+    ops.softmax_bwd_(att, datt, B * nh * T, T, Tp)
+    ops.gemm(datt, k, dqkv[..., :C], T, hs, T, Tp, 3 * C, 3 * C, b_trans=True, alpha=alpha, batch=B * nh, inner=nh,
+             sa=(nh * T * Tp, T * Tp), sb=sa, sc=sa)  # dQ = dS K
+    ops.gemm(datt, q, dqkv[..., C:2 * C], T, hs, T, Tp, 3 * C, 3 * C, a_trans=True, b_trans=True, alpha=alpha, batch=B * nh, inner=nh,
+             sa=(nh * T * Tp, T * Tp), sb=sa, sc=sa)  # dK = dS^T Q
+    qr = qkv.clone().requires_grad_(True)
+    q2, k2, v2 = [t.reshape(B, T, nh, hs).transpose(1, 2) for t in (qr[..., :C], qr[..., C:2 * C], qr[..., 2 * C:])]
+    out = (F.softmax((q2 @ k2.transpose(-2, -1)) * alpha, dim=-1) @ v2).transpose(1, 2).reshape(B, T, C)
+    out.backward(dy)
+    close(dqkv, qr.grad, what="attention grads")
+
+
+# ---------------------------------------------------------------- conv
+CONV_CASES = [(2, 10, 12, 32, 32, 3, 1, 1), (2, 11, 13, 48, 48, 3, 2, 2), (1, 9, 9, 72, 72, 3, 1, 3), (2, 8, 8, 32, 72, 1, 2, 1),
+              (2, 6, 7, 64, 7, 3, 1, 1), (2, 5, 22, 64, 128, 3, 1, 1), (2, 16, 16, 64, 64, 1, 1, 1), (1, 7, 5, 216, 216, 3, 2, 9)]
+
+
+def cl(w):
+    """(Cout, Cin/g, kh, kw) weight in channels_last memory format (what our parameters use)."""
+    return w.contiguous(memory_format=torch.channels_last) if w.shape[2] > 1 or w.shape[3] > 1 else w.contiguous()
+
+
+def check_conv(dev, B, Hi, Wi, Cin, Cout, ks, stride, groups):
+    x = R(B, Cin, Hi, Wi, dev=dev).requires_grad_(True)
+    w = (R(Cout, Cin // groups, ks, ks, dev=dev) * 0.1).requires_grad_(True)
+    b = R(Cout, dev=dev)
+    y = torch.relu(F.conv2d(x, w, b, stride, ks // 2, 1, groups))
+    dy = R(*y.shape, seed=1, dev=dev)
+    gx, gw = torch.autograd.grad(y, [x, w], dy)
+    xh = x.detach().permute(0, 2, 3, 1).contiguous()
+    wh = cl(w.detach())
+    yh = ops.conv_fwd(xh, wh, b, stride, None, groups, relu=True)
+    close(yh.permute(0, 3, 1, 2), y, what="conv fwd")
+    dyh = ops.relu_mask(dy.permute(0, 2, 3, 1).contiguous(), yh)
+    dxh = ops.conv_dgrad(dyh, wh, xh.shape, stride, None, groups)
+    close(dxh.permute(0, 3, 1, 2), gx, what="conv dgrad")
+    dw = torch.zeros_like(wh)
+    ops.conv_wgrad(dyh, xh, dw, stride, None, groups)
+    close(dw, gw, what="conv wgrad")
+    db = ops.colsum(dy.permute(0, 2, 3, 1).contiguous(), 1, dyh.numel() // Cout, Cout, mask=yh)
+    close(db[0], (dy * (y > 0)).sum((0, 2, 3)), what="bias grad")
+
+
+def check_stem(dev, B, H, W):
+    rgb = torch.randint(0, 256, (B, 3, H, W), generator=torch.Generator().manual_seed(0)).float().to(dev)
+    w = (R(32, 3, 3, 3, dev=dev) * 0.2).requires_grad_(True)
+    mean = torch.tensor([0.485, 0.456, 0.406], device=dev).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225], device=dev).view(1, 3, 1, 1)
+    y = F.conv2d((rgb / 255.0 - mean) / std, w, None, 2, 1)
+    dy = R(*y.shape, seed=1, dev=dev)
+    (gw,) = torch.autograd.grad(y, [w], dy)
+    wh = cl(w.detach())
+    yh = ops.stem_conv_fwd(rgb, None, wh, True)
+    close(yh.permute(0, 3, 1, 2), y, what="stem fwd")
+    dw = torch.zeros_like(wh)
+    ops.stem_conv_wgrad(dy.permute(0, 2, 3, 1).contiguous(), rgb, None, dw, True)
+    close(dw, gw, what="stem wgrad")
+    # lidar stem: 2-channel histogram + 1-channel target point image, never concatenated
+    l0, l1 = torch.rand(B, 2, H, H, device=dev), torch.rand(B, 1, H, H, device=dev)
+    w2 = (R(32, 3, 3, 3, seed=3, dev=dev) * 0.2)
+    y2 = F.conv2d(torch.cat((l0, l1), 1), w2, None, 2, 1)
+    close(ops.stem_conv_fwd(l0, l1, cl(w2), False).permute(0, 3, 1, 2), y2, what="lidar stem fwd")
+
+
+# ---------------------------------------------------------------- norms
+def check_layernorm(dev, rows, C):
+    x = R(rows, C, dev=dev).requires_grad_(True)
+    g, b = (R(C, seed=1, dev=dev) * 0.3 + 1).requires_grad_(True), R(C, seed=2, dev=dev).requires_grad_(True)
+    y = F.layer_norm(x, (C,), g, b, 1e-5)
+    dy = R(rows, C, seed=3, dev=dev)
+    gx, gg, gb = torch.autograd.grad(y, [x, g, b], dy)
+    yh, mean, rstd = ops.layernorm_fwd(x.detach(), g.detach(), b.detach())
+    close(yh, y, what="ln fwd")
+    dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    dx = ops.layernorm_bwd(dy, x.detach(), g.detach(), mean, rstd, dg, db)
+    close(dx, gx, what="ln dx")
+    close(dg, gg, what="ln dgamma")
+    close(db, gb, what="ln dbeta")
+
+
+def check_softmax(dev, rows, n, ld):
+    s = R(rows, ld, dev=dev)
+    ref = F.softmax(s[:, :n], dim=-1)
+    p = ops.softmax_fwd_(s.clone(), rows, n, ld)
+    close(p[:, :n], ref, what="softmax fwd")
+    dp = R(rows, ld, seed=1, dev=dev)
+    sr = s[:, :n].clone().requires_grad_(True)
+    (gs,) = torch.autograd.grad(F.softmax(sr, dim=-1), [sr], dp[:, :n])
+    close(ops.softmax_bwd_(p, dp.clone(), rows, n, ld)[:, :n], gs, what="softmax bwd")
+
+
+def check_bn(dev, B, H, W, C, relu, with_res):
+    x = (R(B, C, H, W, dev=dev) * 2 + 0.7).requires_grad_(True)
+    g, b = (R(C, seed=1, dev=dev) * 0.3 + 1).requires_grad_(True), R(C, seed=2, dev=dev).requires_grad_(True)
+    res = R(B, C, H, W, seed=4, dev=dev).requires_grad_(True) if with_res else None
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    y = F.batch_norm(x, rm, rv, g, b, True, 0.1, 1e-5)
+    if with_res:
+        y = y + res
+    if relu:
+        y = torch.relu(y)
+    dy = R(B, C, H, W, seed=3, dev=dev)
+    grads = torch.autograd.grad(y, [x, g, b] + ([res] if with_res else []), dy)
+    nhwc = lambda t: t.detach().permute(0, 2, 3, 1).contiguous()
+    rm2, rv2 = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    yh, sm, si = ops.bn_fwd(nhwc(x), g.detach(), b.detach(), rm2, rv2, nhwc(res) if with_res else None, relu, True)
+    close(yh.permute(0, 3, 1, 2), y, what="bn fwd")
+    close(rm2, rm, what="running mean")
+    close(rv2, rv, what="running var")
+    dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    dx, dres = ops.bn_bwd(nhwc(dy), yh if relu else None, nhwc(x), g.detach(), sm, si, dg, db, want_dres=with_res)
+    close(dx.permute(0, 3, 1, 2), grads[0], what="bn dx")
+    close(dg, grads[1], what="bn dgamma")
+    close(db, grads[2], what="bn dbeta")
+    if with_res:
+        close(dres.permute(0, 3, 1, 2), grads[3], what="bn dres")
+
+
+def check_bn_eval(dev):
+    B, H, W, C = 2, 4, 5, 24
+    x = R(B, C, H, W, dev=dev)
+    g, b = R(C, seed=1, dev=dev) * 0.3 + 1, R(C, seed=2, dev=dev)
+    rm, rv = R(C, seed=5, dev=dev), torch.rand(C, device=dev) + 0.5
+    y = torch.relu(F.batch_norm(x, rm.clone(), rv.clone(), g, b, False, 0.1, 1e-5))
+    yh, _, _ = ops.bn_fwd(x.permute(0, 2, 3, 1).contiguous(), g, b, rm, rv, None, True, False)
+    close(yh.permute(0, 3, 1, 2), y, what="bn eval")
+
+
+def check_colsum(dev):
+    x = R(3, 50, 72, dev=dev)
+    close(ops.colsum(x, 3, 50, 72, scale=1 / 50.0), x.mean(1), what="colsum mean")
+    x2 = R(1000, 7, dev=dev)
+    acc = R(1, 7, seed=1, dev=dev)
+    close(ops.colsum(x2, 1, 1000, 7, out=acc.clone(), accumulate=True), acc + x2.sum(0, keepdim=True), what="colsum acc")
+    x3 = R(4, 33, 1512, dev=dev)
+    close(ops.colsum(x3, 4, 33, 1512), x3.sum(1), what="colsum wide")
+
+
+def check_se(dev, B, H, W, C):
+    x = R(B, H, W, C, dev=dev).requires_grad_(True)
+    gate = R(B, C, seed=1, dev=dev).requires_grad_(True)
+    y = x * torch.sigmoid(gate).view(B, 1, 1, C)
+    dy = R(B, H, W, C, seed=2, dev=dev)
+    gx, gg = torch.autograd.grad(y, [x, gate], dy)
+    close(ops.se_scale_fwd(x.detach(), gate.detach()), y, what="se fwd")
+    close(ops.se_scale_bwd_gate(dy, x.detach(), gate.detach()), gg, what="se dgate")
+    dmean = R(B, C, seed=3, dev=dev)
+    dx = ops.se_scale_bwd_x(dy, gate.detach(), dmean, x.shape)
+    close(dx, gx + dmean.view(B, 1, 1, C) / (H * W), what="se dx")
+    dx2 = ops.se_scale_bwd_x(None, None, dmean, x.shape)
+    close(dx2, (dmean.view(B, 1, 1, C) / (H * W)).expand(B, H, W, C), what="gap bwd")
+
+
+# ---------------------------------------------------------------- resampling
+def check_pool_tokens(dev, B, H, W, C, oh, ow):
+    x = R(B, C, H, W, dev=dev).requires_grad_(True)
+    T = oh * ow + 7
+    pos = R(T, C, seed=1, dev=dev)
+    pooled = F.adaptive_avg_pool2d(x, (oh, ow))
+    ref = pooled.flatten(2).transpose(1, 2) + pos[3:3 + oh * ow]
+    tok = torch.zeros(B, T, C, device=dev)
+    ops.pool_tokens_fwd(x.detach().permute(0, 2, 3, 1).contiguous(), oh, ow, pos, tok, 3)
+    close(tok[:, 3:3 + oh * ow], ref, what="pool tokens fwd")
+    dtok = R(B, T, C, seed=2, dev=dev)
+    (gx,) = torch.autograd.grad(ref, [x], dtok[:, 3:3 + oh * ow])
+    dx = ops.pool_tokens_bwd(dtok, (B, H, W, C), oh, ow, 3)
+    close(dx.permute(0, 3, 1, 2), gx, what="pool tokens bwd")
+
+
+BILINEAR_CASES = [(2, 12, 5, 22, 40, 176, False, False), (2, 8, 8, 8, 64, 64, False, False), (1, 6, 5, 22, 64, 176, False, False),
+                  (2, 4, 8, 8, 16, 16, True, False), (1, 3, 16, 16, 40, 40, True, True), (2, 8, 5, 22, 5, 22, False, False),
+                  (1, 5, 8, 22, 16, 44, False, False)]
+
+
+def check_bilinear(dev, B, C, Hi, Wi, Ho, Wo, in_nhwc, align):
+    x = R(B, C, Hi, Wi, dev=dev).requires_grad_(True)
+    y = F.interpolate(x, size=(Ho, Wo), mode='bilinear', align_corners=align)
+    add = R(B, Ho, Wo, C, seed=1, dev=dev)
+    xin = x.detach().permute(0, 2, 3, 1).contiguous() if in_nhwc else x.detach().contiguous()
+    yh = ops.bilinear_fwd(xin, B, C, Hi, Wi, Ho, Wo, in_nhwc, True, align, add=add)
+    close(yh, y.permute(0, 2, 3, 1) + add, what="bilinear fwd")
+    dy = R(B, C, Ho, Wo, seed=2, dev=dev)
+    (gx,) = torch.autograd.grad(y, [x], dy)
+    dx = ops.bilinear_bwd(dy.permute(0, 2, 3, 1).contiguous(), B, C, Hi, Wi, Ho, Wo, in_nhwc, True, align)
+    close(dx.permute(0, 3, 1, 2) if in_nhwc else dx, gx, what="bilinear bwd")
+
+
+# ---------------------------------------------------------------- losses
+def check_ce(dev, rows, C, weighted):
+    lg = R(rows, C, dev=dev).requires_grad_(True)
+    tgt = torch.randint(0, C, (rows,), generator=torch.Generator().manual_seed(1)).to(dev)
+    cw = torch.tensor([1., 1., 3.], device=dev) if weighted else None
+    ref = F.cross_entropy(lg, tgt, weight=cw)
+    (gl,) = torch.autograd.grad(ref, [lg])
+    loss, dl, inv = ops.ce_fwd(lg.detach(), tgt, cw)
+    close(loss, ref, what="ce loss")
+    g = torch.tensor([0.7], device=dev)
+    ops.scale_dev_(dl, g, inv, 1.0)
+    close(dl, 0.7 * gl, what="ce grad")
+
+
+def check_l1(dev, n, sig):
+    p = R(n, dev=dev).requires_grad_(True)
+    t = torch.rand(n, device=dev)
+    ref = F.l1_loss(torch.sigmoid(p) if sig else p, t)
+    (gp,) = torch.autograd.grad(ref, [p])
+    loss, dp = ops.l1_fwd(p.detach(), t, sig)
+    close(loss, ref, what="l1 loss")
+    close(dp, gp, what="l1 grad")
+
+
+def check_gru(dev, B, H):
+    cell = torch.nn.GRUCell(4, H).to(dev)
+    x, h = R(B, 4, dev=dev), R(B, H, seed=1, dev=dev).requires_grad_(True)
+    hn = cell(x, h)
+    dhn = R(B, H, seed=2, dev=dev)
+    gi = (x @ cell.weight_ih.t() + cell.bias_ih).detach().requires_grad_(True)
+    gh = (h @ cell.weight_hh.t() + cell.bias_hh).detach().requires_grad_(True)
+    h2 = h.detach().clone().requires_grad_(True)
+    r = torch.sigmoid(gi[:, :H] + gh[:, :H]); z = torch.sigmoid(gi[:, H:2 * H] + gh[:, H:2 * H])
+    n = torch.tanh(gi[:, 2 * H:] + r * gh[:, 2 * H:])
+    ref = (1 - z) * n + z * h2
+    close(ref, hn, what="gru formula")
+    ggi, ggh, gh2 = torch.autograd.grad(ref, [gi, gh, h2], dhn)
+    hh, rzn = ops.gru_gates_fwd(gi.detach(), gh.detach(), h.detach())
+    close(hh, hn, what="gru fwd")
+    dgi, dgh, dh = ops.gru_gates_bwd(dhn, rzn, gh.detach(), h.detach())
+    close(dgi, ggi, what="gru dgi"); close(dgh, ggh, what="gru dgh"); close(dh, gh2, what="gru dh")
+
+
+def check_misc(dev):
+    a, b = R(1000, dev=dev), R(1000, seed=1, dev=dev)
+    close(ops.axpby(a, b, 2.0, -0.5), 2 * a - 0.5 * b, what="axpby")
+    close(ops.relu_mask(a, b), a * (b > 0), what="relu mask")
+    seed = torch.tensor([1234], dtype=torch.int32, device=dev)
+    x = torch.ones(100000, device=dev)
+    y = ops.dropout(x, seed, 3, 0.1)
+    keep = (y != 0).float().mean().item()
+    assert abs(keep - 0.9) < 0.01, keep
+    close(y[y != 0], torch.full_like(y[y != 0], 1 / 0.9), what="dropout scale")
+    assert torch.equal(y, ops.dropout(x, seed, 3, 0.1)), "dropout mask must be reproducible (backward regenerates it)"
+    assert not torch.equal(y, ops.dropout(x, seed, 4, 0.1))
+
+
+def check_adamw(dev, n):
+    p = torch.nn.Parameter(R(n, dev=dev))
+    opt = torch.optim.AdamW([p], lr=1e-2)
+    mine = p.detach().clone()
+    m, v = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    state = torch.tensor([0.0, 1e-2], device=dev)
+    for it in range(3):
+        g = R(n, seed=10 + it, dev=dev)
+        p.grad = g.clone()
+        opt.step()
+        ops.adamw_(mine, g, m, v, state)
+    close(mine, p, tol=1e-5, what="adamw")
+    assert state[0].item() == 3.0
+
+
+def check_hist(dev, B, N):
+    from oracle import hist
+    rng = np.random.default_rng(0)
+    pts = np.stack([rng.uniform(-20, 20, (B, N)), rng.uniform(-36, 4, (B, N)), rng.uniform(-4, 1, (B, N)), rng.uniform(0, 1, (B, N))], -1).astype(np.float32)
+    pts[0, :40, 0] = 16.0; pts[0, 40:80, 1] = 0.0; pts[0, 80:120, 0] = -16.0; pts[0, 120:160, 1] = -32.0; pts[0, 160:200, 2] = -2.3
+    pts[1, :500, :2] = np.round(pts[1, :500, :2] * 8) / 8   # points exactly on bin edges
+    pts[1, 500:520] = pts[1, 500]                            # > 5 hits in one bin (clipping)
+    npts = torch.tensor([N, N - 777], dtype=torch.int32)
+    out = ops.lidar_hist(torch.from_numpy(pts).to(dev), npts.to(dev)).cpu().numpy()
+    for b in range(B):
+        ref = hist.lidar_to_histogram_features(pts[b, :int(npts[b])])
+        assert np.array_equal(out[b], ref), "H1 histogram must be bit-exact (sample %d: %d bins differ)" % (b, (out[b] != ref).sum())
+
+
+# ---------------------------------------------------------------- CenterNet targets + losses vs the oracle
+def synthetic_labels(B, seed=0, crowded=False):
+    rng = np.random.default_rng(seed)
+    label = torch.zeros(B, 20, 7)
+    for b in range(B):
+        k = int(rng.integers(0, 9)) if not crowded else 20
+        if b == 0:
+            k = max(k, 3)
+        if k:
+            label[b, :k, 0:2] = torch.from_numpy(rng.uniform(1, 254, (k, 2))).float()
+            label[b, :k, 2:4] = torch.from_numpy(rng.uniform(8, 40, (k, 2))).float()
+            label[b, :k, 4] = torch.from_numpy(rng.uniform(-math.pi, math.pi, k)).float()
+            label[b, :k, 5] = torch.from_numpy(rng.uniform(0, 8, k)).float()
+            label[b, :k, 6] = torch.from_numpy(rng.integers(0, 2, k)).float()
+    label[0, 1, 0:2] = label[0, 0, 0:2] + 0.5   # two boxes landing in the same cell (later one wins)
+    label[0, 2, 0:2] = torch.tensor([2.0, 253.0])  # splat clipped by the map border
+    return label
+
+
+def check_centernet(dev, B, crowded=False):
+    from oracle.centernet import LidarCenterNetHead
+    from transfuser_amd.config import GlobalConfig
+    cfg = GlobalConfig()
+    head = LidarCenterNetHead(64, 64, 1, cfg)
+    label = synthetic_labels(B, 0, crowded)
+    fh = fw = 64
+    tgt, af = head.get_targets(label, torch.zeros_like(label[:, :, 0]), label.sum(-1) == 0., (B, 1, fh, fw))
+    tgtf, tgti, cnt = ops.centernet_targets(label.to(dev), fh, fw, fw / 256.0, fh / 256.0, cfg.num_dir_bins)
+    tf_, ti = tgtf.cpu(), tgti.cpu()
+    assert int(cnt.sum()) == int(tgt['center_heatmap_target'].eq(1).sum()), "avg_factor count"
+    close(tf_[..., 0], tgt['center_heatmap_target'][:, 0], tol=1e-6, what="heatmap target")
+    assert torch.equal(tf_[..., 0] == 1, tgt['center_heatmap_target'][:, 0] == 1)
+    close(tf_[..., 1:3], tgt['wh_target'].permute(0, 2, 3, 1), tol=1e-6, what="wh target")
+    close(tf_[..., 3:5], tgt['offset_target'].permute(0, 2, 3, 1), tol=1e-6, what="offset target")
+    close(tf_[..., 5], tgt['yaw_res_target'][:, 0], tol=1e-6, what="yaw res target")
+    close(tf_[..., 6], tgt['velocity_target'][:, 0], tol=1e-6, what="velocity target")
+    assert torch.equal(tf_[..., 7], tgt['wh_offset_target_weight'][:, 0]), "weight map (index scatter) must be exact"
+    assert torch.equal(ti[..., 0].long(), tgt['yaw_class_target']), "yaw class (integer) must be exact"
+    assert torch.equal(ti[..., 1].long(), tgt['brake_target']), "brake (integer) must be exact"
+    # losses + gradients
+    P = 9 + cfg.num_dir_bins
+    pred = (R(B, fh, fw, P, dev="cpu") * 1.5).requires_grad_(True)
+    nchw = lambda a, b_: pred[..., a:b_].permute(0, 3, 1, 2)
+    nb = cfg.num_dir_bins
+    preds = (nchw(0, 1).sigmoid(), nchw(1, 3), nchw(3, 5), nchw(5, 5 + nb), nchw(5 + nb, 6 + nb), nchw(6 + nb, 7 + nb), nchw(7 + nb, 9 + nb))
+    ref = head.loss(preds, label, torch.zeros_like(label[:, :, 0]), label.sum(-1) == 0.)
+    names = ['loss_center_heatmap', 'loss_wh', 'loss_offset', 'loss_yaw_class', 'loss_yaw_res', 'loss_velocity', 'loss_brake']
+    losses = ops.centernet_loss_fwd(pred.detach().to(dev), tgtf, tgti, cnt, nb)
+    for i, k in enumerate(names):
+        close(losses[i], ref[k], what=k)
+    gup = torch.tensor([1.0, 0.2, 0.2, 0.2, 0.2, 0.5, 0.3])
+    total = sum(gup[i] * ref[k] for i, k in enumerate(names))
+    (gp,) = torch.autograd.grad(total, [pred])
+    dpred = ops.centernet_loss_bwd(pred.detach().to(dev), tgtf, tgti, cnt, gup.to(dev), nb)
+    close(dpred, gp, tol=1e-4, what="centernet dpred")

@@ -1,0 +1,89 @@
+"""CPU checks of the HIP kernel sources, compiled for the host against the fiber emulator
+(tests/emu).  Each op is compared with a plain PyTorch fp32 reference.  The same comparisons
+run on the real GPU in tests/test_kernels_gpu.py (shared case lists in tests/kernel_cases.py)."""
+import pytest
+import torch
+
+import kernel_cases as kc
+
+
+@pytest.fixture(autouse=True)
+def _backend(emu_backend):
+    yield
+
+
+@pytest.mark.parametrize("case", kc.GEMM_CASES, ids=str)
+def test_gemm(case):
+    kc.check_gemm("cpu", *case)
+
+
+@pytest.mark.parametrize("case", kc.BATCHED_GEMM_CASES, ids=str)
+def test_attention_gemms(case):
+    kc.check_attention("cpu", *case)
+
+
+@pytest.mark.parametrize("case", kc.CONV_CASES, ids=str)
+def test_conv(case):
+    kc.check_conv("cpu", *case)
+
+
+def test_stem_conv():
+    kc.check_stem("cpu", 2, 12, 20)
+
+
+@pytest.mark.parametrize("case", [(37, 72), (9, 216), (5, 1512)], ids=str)
+def test_layernorm(case):
+    kc.check_layernorm("cpu", *case)
+
+
+def test_softmax():
+    kc.check_softmax("cpu", 23, 174, 176)
+
+
+@pytest.mark.parametrize("case", [(2, 6, 7, 72, True, True), (1, 5, 5, 216, False, False), (3, 4, 4, 32, True, False), (2, 3, 5, 7, False, True)], ids=str)
+def test_batchnorm(case):
+    kc.check_bn("cpu", *case)
+
+
+def test_bn_eval():
+    kc.check_bn_eval("cpu")
+
+
+def test_colsum_and_se():
+    kc.check_colsum("cpu")
+    kc.check_se("cpu", 3, 5, 6, 72)
+
+
+@pytest.mark.parametrize("case", [(2, 40, 44, 24, 5, 22), (2, 16, 16, 8, 8, 8), (1, 13, 9, 4, 5, 4), (2, 5, 22, 12, 5, 22)], ids=str)
+def test_pool_tokens(case):
+    kc.check_pool_tokens("cpu", *case)
+
+
+@pytest.mark.parametrize("case", kc.BILINEAR_CASES, ids=str)
+def test_bilinear(case):
+    kc.check_bilinear("cpu", *case)
+
+
+def test_losses():
+    kc.check_ce("cpu", 300, 7, False)
+    kc.check_ce("cpu", 257, 3, True)
+    kc.check_l1("cpu", 1000, True)
+    kc.check_l1("cpu", 80, False)
+
+
+def test_gru_and_misc():
+    kc.check_gru("cpu", 5, 64)
+    kc.check_misc("cpu")
+
+
+def test_adamw():
+    kc.check_adamw("cpu", 1003)
+
+
+def test_lidar_hist():
+    kc.check_hist("cpu", 2, 3000)
+
+
+@pytest.mark.parametrize("case", [(3, False), (2, True)], ids=str)
+def test_centernet_targets_and_losses(case):
+    kc.check_centernet("cpu", *case)

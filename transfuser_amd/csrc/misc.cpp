@@ -1,0 +1,183 @@
+// Small elementwise kernels, GRU gates, multi-tensor AdamW, LiDAR histogram.
+#include "tf_common.h"
+#include "../../include/transfuser_hip.h"
+
+using namespace tf;
+
+namespace {
+
+inline int ew_blocks(long n, int cap = 4096) {
+    long b = (n + 255) / 256;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+// out = dy * [y > 0]
+__global__ void __launch_bounds__(256) relu_mask_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ out, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = (y[i] > 0.f) ? dy[i] : 0.f;
+}
+// out = alpha * a + beta * b (b optional)
+__global__ void __launch_bounds__(256) axpby_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, float alpha,
+                                                    float beta, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = alpha * a[i] + (b ? beta * b[i] : 0.f);
+}
+// dropout with our counter-based RNG: y = keep ? x / (1-p) : 0 ; same call regenerates the mask in backward
+__global__ void __launch_bounds__(256) dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long n, const uint32_t* __restrict__ seed,
+                                                      uint32_t site, uint32_t thresh, float keep_scale) {
+    const uint32_t sd = *seed;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+        y[i] = dropout_keep(sd, site, (uint32_t)i, thresh) ? x[i] * keep_scale : 0.f;
+}
+
+// nn.GRUCell gates (model.py:601,631; torch gate order r, z, n):
+//   r = s(gi_r + gh_r), z = s(gi_z + gh_z), n = tanh(gi_n + r * gh_n), h' = (1 - z) * n + z * h
+__global__ void __launch_bounds__(256) gru_gates_fwd_kernel(const float* __restrict__ gi, const float* __restrict__ gh, const float* __restrict__ h,
+                                                            float* __restrict__ hnew, float* __restrict__ rzn, int B, int H) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * H) return;
+    const int b = i / H, j = i - b * H;
+    const float* a = gi + (long)b * 3 * H;
+    const float* c = gh + (long)b * 3 * H;
+    const float r = 1.f / (1.f + expf(-(a[j] + c[j])));
+    const float z = 1.f / (1.f + expf(-(a[H + j] + c[H + j])));
+    const float n = tanhf(a[2 * H + j] + r * c[2 * H + j]);
+    hnew[i] = (1.f - z) * n + z * h[i];
+    float* s = rzn + (long)b * 3 * H;
+    s[j] = r; s[H + j] = z; s[2 * H + j] = n;
+}
+// dgi, dgh (B,3H), dh_direct (B,H) = dh' * z
+__global__ void __launch_bounds__(256) gru_gates_bwd_kernel(const float* __restrict__ dhn, const float* __restrict__ rzn, const float* __restrict__ gh,
+                                                            const float* __restrict__ h, float* __restrict__ dgi, float* __restrict__ dgh,
+                                                            float* __restrict__ dh, int B, int H) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * H) return;
+    const int b = i / H, j = i - b * H;
+    const float* s = rzn + (long)b * 3 * H;
+    const float r = s[j], z = s[H + j], n = s[2 * H + j];
+    const float g = dhn[i];
+    const float dn_pre = g * (1.f - z) * (1.f - n * n);
+    const float dz_pre = g * (h[i] - n) * z * (1.f - z);
+    const float ghn = gh[(long)b * 3 * H + 2 * H + j];
+    const float dr_pre = dn_pre * ghn * r * (1.f - r);
+    float* a = dgi + (long)b * 3 * H;
+    float* c = dgh + (long)b * 3 * H;
+    a[j] = dr_pre; a[H + j] = dz_pre; a[2 * H + j] = dn_pre;
+    c[j] = dr_pre; c[H + j] = dz_pre; c[2 * H + j] = dn_pre * r;
+    dh[i] = g * z;
+}
+
+// torch.optim.AdamW (train.py:142: lr 1e-4, betas (.9,.999), eps 1e-8, weight_decay 0.01, decoupled),
+// ONE launch over the flat parameter arena.  state[0] = step (float), state[1] = lr; the step is
+// advanced by adamw_tick_kernel so a captured graph replays correctly.
+__global__ void adamw_tick_kernel(float* state) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) state[0] += 1.f;
+}
+__global__ void __launch_bounds__(256) adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                    long n4, long n, const float* __restrict__ state, float b1, float b2, float eps, float wd) {
+    const float step = state[0], lr = state[1];
+    const float bc1 = 1.f - powf(b1, step), bc2 = 1.f - powf(b2, step);
+    const float step_size = lr / bc1, inv_sq_bc2 = 1.f / sqrtf(bc2), decay = 1.f - lr * wd;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        float4 pp = reinterpret_cast<float4*>(p)[i], gg = reinterpret_cast<const float4*>(g)[i];
+        float4 mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+        float* P = &pp.x; float* G = &gg.x; float* M = &mm.x; float* V = &vv.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            P[k] *= decay;
+            M[k] = b1 * M[k] + (1.f - b1) * G[k];
+            V[k] = b2 * V[k] + (1.f - b2) * G[k] * G[k];
+            P[k] -= step_size * (M[k] / (sqrtf(V[k]) * inv_sq_bc2 + eps));
+        }
+        reinterpret_cast<float4*>(p)[i] = pp;
+        reinterpret_cast<float4*>(m)[i] = mm;
+        reinterpret_cast<float4*>(v)[i] = vv;
+    }
+    // tail
+    for (long i = n4 * 4 + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        float P = p[i] * decay, G = g[i];
+        float M = b1 * m[i] + (1.f - b1) * G, V = b2 * v[i] + (1.f - b2) * G * G;
+        p[i] = P - step_size * (M / (sqrtf(V) * inv_sq_bc2 + eps));
+        m[i] = M; v[i] = V;
+    }
+}
+
+// LiDAR -> 2-bin BEV histogram (data.py:446-470), integer-exact:
+//   valid iff -16 <= x <= 16 and -32 <= y <= 0; xbin = min(floor(8x) + 128, 255), ybin = min(floor(8y) + 256, 255)
+//   channel = (z <= -2.3) ? 1 : 0;  out[c][ybin][255 - xbin] = min(count, 5) / 5
+// One block owns a slab of HIST_ROWS output rows of one sample, scans the sample's points (L2
+// resident) and counts into LDS integer bins, then writes its slab with coalesced stores: no
+// global atomics, no zero-fill pass, bit-reproducible.
+constexpr int HIST_ROWS = 8;
+__global__ void __launch_bounds__(256) lidar_hist_kernel(const float* __restrict__ pts, const int32_t* __restrict__ npts, int max_pts, int stride,
+                                                         float* __restrict__ out) {
+    __shared__ int bins[2][HIST_ROWS][256];
+    const int b = blockIdx.y, slab = blockIdx.x, tid = threadIdx.x;
+    for (int i = tid; i < 2 * HIST_ROWS * 256; i += 256) (&bins[0][0][0])[i] = 0;
+    __syncthreads();
+    const int n = npts ? (npts[b] < max_pts ? npts[b] : max_pts) : max_pts;
+    const float* p = pts + (long)b * max_pts * stride;
+    const int y0 = slab * HIST_ROWS;
+    for (int i = tid; i < n; i += 256) {
+        const float x = p[(long)i * stride], y = p[(long)i * stride + 1], z = p[(long)i * stride + 2];
+        if (!(x >= -16.f && x <= 16.f && y >= -32.f && y <= 0.f)) continue;
+        int xb = (int)floorf(x * 8.f) + 128; if (xb > 255) xb = 255;
+        int yb = (int)floorf(y * 8.f) + 256; if (yb > 255) yb = 255;
+        const int r = yb - y0;
+        if (r < 0 || r >= HIST_ROWS) continue;
+        atomicAdd(&bins[(z <= -2.3f) ? 1 : 0][r][255 - xb], 1);
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * HIST_ROWS * 256; i += 256) {
+        const int c = i / (HIST_ROWS * 256), r = (i / 256) % HIST_ROWS, col = i % 256;
+        const int cnt = bins[c][r][col];
+        out[(((long)b * 2 + c) * 256 + (y0 + r)) * 256 + col] = (float)(cnt < 5 ? cnt : 5) / 5.0f;
+    }
+}
+
+}  // namespace
+
+extern "C" int tf_relu_mask_f32(const float* dy, const float* y, float* out, int64_t n, void* stream) {
+    TF_REQUIRE(dy && y && out && n >= 0, "tf_relu_mask_f32: bad arguments");
+    if (n == 0) return 0;
+    TF_LAUNCH(relu_mask_kernel, dim3(ew_blocks(n)), dim3(256), stream, dy, y, out, (long)n);
+    return launch_status("tf_relu_mask_f32");
+}
+extern "C" int tf_axpby_f32(const float* a, const float* b, float* out, float alpha, float beta, int64_t n, void* stream) {
+    TF_REQUIRE(a && out && n >= 0, "tf_axpby_f32: bad arguments");
+    if (n == 0) return 0;
+    TF_LAUNCH(axpby_kernel, dim3(ew_blocks(n)), dim3(256), stream, a, b, out, alpha, beta, (long)n);
+    return launch_status("tf_axpby_f32");
+}
+extern "C" int tf_dropout_f32(const float* x, float* y, int64_t n, const uint32_t* seed_dev, uint32_t site, float p, void* stream) {
+    TF_REQUIRE(x && y && seed_dev && n >= 0 && p >= 0.f && p < 1.f, "tf_dropout_f32: bad arguments");
+    if (n == 0) return 0;
+    const uint32_t thresh = (uint32_t)((double)p * 4294967296.0);
+    TF_LAUNCH(dropout_kernel, dim3(ew_blocks(n)), dim3(256), stream, x, y, (long)n, seed_dev, site, thresh, 1.f / (1.f - p));
+    return launch_status("tf_dropout_f32");
+}
+extern "C" int tf_gru_gates_fwd_f32(const float* gi, const float* gh, const float* h, float* hnew, float* rzn, int B, int H, void* stream) {
+    TF_REQUIRE(gi && gh && h && hnew && rzn && B > 0 && H > 0, "tf_gru_gates_fwd_f32: bad arguments");
+    TF_LAUNCH(gru_gates_fwd_kernel, dim3(cdiv((long)B * H, 256)), dim3(256), stream, gi, gh, h, hnew, rzn, B, H);
+    return launch_status("tf_gru_gates_fwd_f32");
+}
+extern "C" int tf_gru_gates_bwd_f32(const float* dhnew, const float* rzn, const float* gh, const float* h, float* dgi, float* dgh, float* dh, int B, int H,
+                                    void* stream) {
+    TF_REQUIRE(dhnew && rzn && gh && h && dgi && dgh && dh && B > 0 && H > 0, "tf_gru_gates_bwd_f32: bad arguments");
+    TF_LAUNCH(gru_gates_bwd_kernel, dim3(cdiv((long)B * H, 256)), dim3(256), stream, dhnew, rzn, gh, h, dgi, dgh, dh, B, H);
+    return launch_status("tf_gru_gates_bwd_f32");
+}
+extern "C" int tf_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, float* state_dev, float beta1, float beta2, float eps,
+                            float weight_decay, void* stream) {
+    TF_REQUIRE(p && g && m && v && state_dev && n >= 0, "tf_adamw_f32: bad arguments");
+    TF_REQUIRE(aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v), "tf_adamw_f32: arenas must be 16-byte aligned");
+    TF_LAUNCH(adamw_tick_kernel, dim3(1), dim3(64), stream, state_dev);
+    if (n > 0) TF_LAUNCH(adamw_kernel, dim3(ew_blocks(n / 4 + 1, 8192)), dim3(256), stream, p, g, m, v, (long)(n / 4), (long)n, (const float*)state_dev,
+                         beta1, beta2, eps, weight_decay);
+    return launch_status("tf_adamw_f32");
+}
+extern "C" int tf_lidar_hist_f32(const float* points, const int32_t* num_points, int B, int max_points, int point_stride, float* out, void* stream) {
+    TF_REQUIRE(points && out && B > 0 && max_points >= 0 && point_stride >= 3, "tf_lidar_hist_f32: bad arguments");
+    TF_LAUNCH(lidar_hist_kernel, dim3(256 / HIST_ROWS, B), dim3(256), stream, points, num_points, max_points, point_stride, out);
+    return launch_status("tf_lidar_hist_f32");
+}

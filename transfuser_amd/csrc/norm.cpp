@@ -1,0 +1,186 @@
+// Row-wise normalisation kernels (HBM-bound): LayerNorm fwd/bwd, attention softmax fwd/bwd.
+// One wave64 per row, float4 traffic, reductions by cross-lane shuffles only.
+#include "tf_common.h"
+#include "../../include/transfuser_hip.h"
+
+using namespace tf;
+
+// ------------------------------------------------------------------ LayerNorm
+// transfuser.py:319,535-536 (nn.LayerNorm, eps 1e-5): y = (x - mean) * rstd * gamma + beta.
+// mean / biased variance two-pass (second pass hits L1/L2), matches torch within fp32 roundoff.
+__global__ void __launch_bounds__(256) layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ y,
+                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out, int rows,
+                                                            int C, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const bool live = row < rows;  // whole wave shares the predicate
+    const float* xr = x + (long)(live ? row : 0) * C;
+    float s = 0.f;
+    if (live)
+        for (int c = lane; c < C; c += 64) s += xr[c];
+    s = wave_sum(s);
+    const float mean = s / (float)C;
+    float q = 0.f;
+    if (live)
+        for (int c = lane; c < C; c += 64) { float d = xr[c] - mean; q += d * d; }
+    q = wave_sum(q);
+    const float rstd = 1.0f / sqrtf(q / (float)C + eps);
+    if (!live) return;
+    float* yr = y + (long)row * C;
+    for (int c = lane; c < C; c += 64) yr[c] = (xr[c] - mean) * rstd * gamma[c] + beta[c];
+    if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma
+__global__ void __launch_bounds__(256) layernorm_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                               const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                               const float* __restrict__ rstd, float* __restrict__ dx, int rows, int C,
+                                                               int accumulate) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const bool live = row < rows;
+    const long o = (long)(live ? row : 0) * C;
+    const float m = live ? mean[row] : 0.f, rs = live ? rstd[row] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+    if (live)
+        for (int c = lane; c < C; c += 64) {
+            float g = dy[o + c] * gamma[c];
+            s1 += g;
+            s2 += g * ((x[o + c] - m) * rs);
+        }
+    s1 = wave_sum(s1) / (float)C;
+    s2 = wave_sum(s2) / (float)C;
+    if (!live) return;
+    for (int c = lane; c < C; c += 64) {
+        float g = dy[o + c] * gamma[c];
+        float xh = (x[o + c] - m) * rs;
+        float v = rs * (g - s1 - xh * s2);
+        if (accumulate) dx[o + c] += v; else dx[o + c] = v;
+    }
+}
+
+// dgamma[c] += sum_rows dy * xhat ; dbeta[c] += sum_rows dy.  Block = 64 columns x 4 row-lanes,
+// each block reduces a chunk of rows, then one atomic per column per block.
+__global__ void __launch_bounds__(256) layernorm_bwd_dw_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int C,
+                                                               int rows_per_block) {
+    __shared__ float sg[4][64], sb[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int ry = threadIdx.x >> 6;
+    const int r0 = blockIdx.y * rows_per_block;
+    int r1 = r0 + rows_per_block;
+    if (r1 > rows) r1 = rows;
+    float ag = 0.f, ab = 0.f;
+    if (c < C)
+        for (int r = r0 + ry; r < r1; r += 4) {
+            float d = dy[(long)r * C + c];
+            ag += d * ((x[(long)r * C + c] - mean[r]) * rstd[r]);
+            ab += d;
+        }
+    sg[ry][threadIdx.x & 63] = ag;
+    sb[ry][threadIdx.x & 63] = ab;
+    __syncthreads();
+    if (ry == 0 && c < C) {
+        const int l = threadIdx.x;
+        atomicAdd(&dgamma[c], (sg[0][l] + sg[1][l]) + (sg[2][l] + sg[3][l]));
+        atomicAdd(&dbeta[c], (sb[0][l] + sb[1][l]) + (sb[2][l] + sb[3][l]));
+    }
+}
+
+extern "C" int tf_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, int rows,
+                                    int C, float eps, void* stream) {
+    TF_REQUIRE(x && gamma && beta && y && mean && rstd && rows >= 0 && C > 0, "tf_layernorm_fwd_f32: bad arguments");
+    if (rows == 0) return 0;
+    TF_LAUNCH(layernorm_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), stream, x, gamma, beta, y, mean, rstd, rows, C, eps);
+    return launch_status("tf_layernorm_fwd_f32");
+}
+
+extern "C" int tf_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx,
+                                    int dx_accumulate, float* dgamma, float* dbeta, int rows, int C, void* stream) {
+    TF_REQUIRE(dy && x && gamma && mean && rstd && dx && rows >= 0 && C > 0, "tf_layernorm_bwd_f32: bad arguments");
+    if (rows == 0) return 0;
+    TF_LAUNCH(layernorm_bwd_dx_kernel, dim3(cdiv(rows, 4)), dim3(256), stream, dy, x, gamma, mean, rstd, dx, rows, C, dx_accumulate);
+    if (dgamma && dbeta) {
+        const int rpb = 64;
+        TF_LAUNCH(layernorm_bwd_dw_kernel, dim3(cdiv(C, 64), cdiv(rows, rpb)), dim3(256), stream, dy, x, mean, rstd, dgamma, dbeta, rows,
+                  C, rpb);
+    }
+    return launch_status("tf_layernorm_bwd_f32");
+}
+
+// ------------------------------------------------------------------ softmax (attention rows)
+// transfuser.py:520-521: att = softmax(q k^T / sqrt(hs)); the 1/sqrt(hs) lives in the GEMM alpha.
+// Row length n <= 64 * SM_MAXV (T = 174 here); row stride ld >= n.  In place.
+constexpr int SM_MAXV = 8;
+
+__global__ void __launch_bounds__(256) softmax_fwd_kernel(float* __restrict__ s, int rows, int n, int ld) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const bool live = row < rows;
+    float* p = s + (long)(live ? row : 0) * ld;
+    float v[SM_MAXV];
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int i = 0; i < SM_MAXV; ++i) {
+        const int c = lane + i * 64;
+        v[i] = (live && c < n) ? p[c] : -3.0e38f;
+        mx = fmaxf(mx, v[i]);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < SM_MAXV; ++i) {
+        const int c = lane + i * 64;
+        v[i] = (live && c < n) ? expf(v[i] - mx) : 0.f;
+        sum += v[i];
+    }
+    sum = wave_sum(sum);
+    if (!live) return;
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int i = 0; i < SM_MAXV; ++i) {
+        const int c = lane + i * 64;
+        if (c < n) p[c] = v[i] * inv;
+    }
+}
+
+// In: p = probabilities, dp = dL/dp.  Out (in place in dp): dL/ds = p * (dp - sum(dp * p)).
+__global__ void __launch_bounds__(256) softmax_bwd_kernel(const float* __restrict__ p, float* __restrict__ dp, int rows, int n, int ld) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const bool live = row < rows;
+    const long o = (long)(live ? row : 0) * ld;
+    float y[SM_MAXV], g[SM_MAXV];
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < SM_MAXV; ++i) {
+        const int c = lane + i * 64;
+        const bool ok = live && c < n;
+        y[i] = ok ? p[o + c] : 0.f;
+        g[i] = ok ? dp[o + c] : 0.f;
+        dot += y[i] * g[i];
+    }
+    dot = wave_sum(dot);
+    if (!live) return;
+#pragma unroll
+    for (int i = 0; i < SM_MAXV; ++i) {
+        const int c = lane + i * 64;
+        if (c < n) dp[o + c] = y[i] * (g[i] - dot);
+    }
+}
+
+extern "C" int tf_softmax_fwd_f32(float* s, int rows, int n, int ld, void* stream) {
+    TF_REQUIRE(s && rows >= 0 && n > 0 && n <= 64 * SM_MAXV && ld >= n, "tf_softmax_fwd_f32: bad arguments (n=%d)", n);
+    if (rows == 0) return 0;
+    TF_LAUNCH(softmax_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), stream, s, rows, n, ld);
+    return launch_status("tf_softmax_fwd_f32");
+}
+
+extern "C" int tf_softmax_bwd_f32(const float* p, float* dp, int rows, int n, int ld, void* stream) {
+    TF_REQUIRE(p && dp && rows >= 0 && n > 0 && n <= 64 * SM_MAXV && ld >= n, "tf_softmax_bwd_f32: bad arguments (n=%d)", n);
+    if (rows == 0) return 0;
+    TF_LAUNCH(softmax_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), stream, p, dp, rows, n, ld);
+    return launch_status("tf_softmax_bwd_f32");
+}

@@ -1,0 +1,404 @@
+// Column reductions over NHWC activations + the per-channel elementwise passes that go with them
+// (HBM-bound; SURVEY.md section 2.2 rows K4 BatchNorm, K5 Squeeze-Excite, global pools, bias gradients).
+//
+// Reduction skeleton: a (rows x C) row-major matrix is cut into column tiles of CTV vectors and
+// row chunks; a block's 256 threads form (256/CTV) row lanes x CTV vector columns, so every
+// wave reads whole contiguous row segments (coalesced float4), accumulates in registers,
+// combines its row lanes through LDS and writes ONE partial per (chunk, column) to a workspace;
+// a tiny finalize kernel sums the chunk partials in a fixed order (deterministic, no atomics).
+#include "tf_common.h"
+#include "../../include/transfuser_hip.h"
+
+using namespace tf;
+
+namespace {
+
+template <int V> struct vecf { float v[V]; };
+template <int V> __device__ __forceinline__ vecf<V> ldv(const float* p) {
+    vecf<V> r;
+    if (V == 4) { float4 t = *reinterpret_cast<const float4*>(p); r.v[0] = t.x; r.v[1 % V] = t.y; r.v[2 % V] = t.z; r.v[3 % V] = t.w; }
+    else r.v[0] = *p;
+    return r;
+}
+template <int V> __device__ __forceinline__ void stv(float* p, const vecf<V>& a) {
+    if (V == 4) *reinterpret_cast<float4*>(p) = make_float4(a.v[0], a.v[1 % V], a.v[2 % V], a.v[3 % V]);
+    else *p = a.v[0];
+}
+
+constexpr int kMaxChunks = 64;
+constexpr long kWsFloats = 4L << 20;  // 16 MiB workspace (floats), see tf_workspace_bytes()
+
+struct RedPlan { int V, CTV, coltiles, rpp, nchunks, rows_per_chunk; };
+
+inline RedPlan plan_reduce(int rows, int C, int nseg, int nacc, bool allow_vec = true) {
+    RedPlan p;
+    p.V = (allow_vec && C % 4 == 0) ? 4 : 1;
+    const int cv = C / p.V;
+    int ctv = 1;
+    for (int d = 1; d <= 64 && d <= cv; ++d)
+        if (cv % d == 0) ctv = d;
+    p.CTV = ctv;
+    p.coltiles = cv / ctv;
+    p.rpp = 256 / ctv;
+    int want = 1024 / (p.coltiles * nseg);
+    if (want < 1) want = 1;
+    if (want > kMaxChunks) want = kMaxChunks;
+    int maxc = cdiv(rows, p.rpp * 4);
+    if (maxc < 1) maxc = 1;
+    if (want > maxc) want = maxc;
+    while ((long)nseg * want * nacc * C > kWsFloats / 2 && want > 1) --want;
+    p.rows_per_chunk = cdiv(rows, want);
+    p.nchunks = cdiv(rows, p.rows_per_chunk);
+    return p;
+}
+
+// ---- functors: eval(global_row, c, out[NACC]) ------------------------------------------------
+template <int V> struct SumF {
+    const float* x; int C;
+    __device__ __forceinline__ void eval(long row, int c, vecf<V>* o) const { o[0] = ldv<V>(x + row * C + c); }
+};
+template <int V> struct BnStatF {  // shifted moments: d = x - K[c]
+    const float* x; const float* K; int C;
+    __device__ __forceinline__ void eval(long row, int c, vecf<V>* o) const {
+        vecf<V> a = ldv<V>(x + row * C + c), k = ldv<V>(K + c);
+#pragma unroll
+        for (int i = 0; i < V; ++i) { float d = a.v[i] - k.v[i]; o[0].v[i] = d; o[1].v[i] = d * d; }
+    }
+};
+template <int V> struct BnBwdF {  // g = dz * [z > 0]; (g, g * xhat)
+    const float* dz; const float* z; const float* x; const float* mean; const float* invstd; int C;
+    __device__ __forceinline__ void eval(long row, int c, vecf<V>* o) const {
+        vecf<V> g = ldv<V>(dz + row * C + c), a = ldv<V>(x + row * C + c), m = ldv<V>(mean + c), s = ldv<V>(invstd + c);
+        if (z) { vecf<V> zz = ldv<V>(z + row * C + c);
+#pragma unroll
+            for (int i = 0; i < V; ++i) if (!(zz.v[i] > 0.f)) g.v[i] = 0.f; }
+#pragma unroll
+        for (int i = 0; i < V; ++i) { o[0].v[i] = g.v[i]; o[1].v[i] = g.v[i] * ((a.v[i] - m.v[i]) * s.v[i]); }
+    }
+};
+template <int V> struct MulF {  // dy * x (SE gate gradient), optional relu mask y on dy
+    const float* dy; const float* x; int C;
+    __device__ __forceinline__ void eval(long row, int c, vecf<V>* o) const {
+        vecf<V> a = ldv<V>(dy + row * C + c), b = ldv<V>(x + row * C + c);
+#pragma unroll
+        for (int i = 0; i < V; ++i) o[0].v[i] = a.v[i] * b.v[i];
+    }
+};
+template <int V> struct MaskSumF {  // dy * [y > 0] (bias gradient behind a fused bias+ReLU epilogue)
+    const float* dy; const float* y; int C;
+    __device__ __forceinline__ void eval(long row, int c, vecf<V>* o) const {
+        vecf<V> a = ldv<V>(dy + row * C + c);
+        if (y) { vecf<V> b = ldv<V>(y + row * C + c);
+#pragma unroll
+            for (int i = 0; i < V; ++i) if (!(b.v[i] > 0.f)) a.v[i] = 0.f; }
+        o[0] = a;
+    }
+};
+
+template <int V, int NACC, class F>
+__global__ void __launch_bounds__(256) colreduce_kernel(F f, int rows_per_seg, int C, int CTV, int rows_per_chunk, float* __restrict__ ws) {
+    __shared__ __attribute__((aligned(16))) float red[NACC][256][V];
+    const int tid = threadIdx.x;
+    const int rpp = 256 / CTV;
+    const int cq = tid % CTV, rl = tid / CTV;
+    const int c = (blockIdx.x * CTV + cq) * V;
+    const int seg = blockIdx.z, chunk = blockIdx.y;
+    const int r0 = chunk * rows_per_chunk;
+    int r1 = r0 + rows_per_chunk;
+    if (r1 > rows_per_seg) r1 = rows_per_seg;
+    vecf<V> acc[NACC];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+        for (int i = 0; i < V; ++i) acc[a].v[i] = 0.f;
+    if (rl < rpp) {
+        const long base = (long)seg * rows_per_seg;
+        for (int r = r0 + rl; r < r1; r += rpp) {
+            vecf<V> o[NACC];
+            f.eval(base + r, c, o);
+#pragma unroll
+            for (int a = 0; a < NACC; ++a)
+#pragma unroll
+                for (int i = 0; i < V; ++i) acc[a].v[i] += o[a].v[i];
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+        for (int i = 0; i < V; ++i) red[a][tid][i] = acc[a].v[i];
+    __syncthreads();
+    if (rl == 0) {
+        const int nch = gridDim.y;
+#pragma unroll
+        for (int a = 0; a < NACC; ++a) {
+            vecf<V> t;
+#pragma unroll
+            for (int i = 0; i < V; ++i) t.v[i] = 0.f;
+            for (int j = 0; j < rpp; ++j)
+#pragma unroll
+                for (int i = 0; i < V; ++i) t.v[i] += red[a][j * CTV + cq][i];
+            stv<V>(ws + (((long)seg * nch + chunk) * NACC + a) * C + c, t);
+        }
+    }
+}
+
+template <int NACC, class F4, class F1>
+inline void launch_reduce(const RedPlan& p, const F4& f4, const F1& f1, int rows_per_seg, int C, int nseg, float* ws, void* stream) {
+    dim3 grid(p.coltiles, p.nchunks, nseg);
+    if (p.V == 4) TF_LAUNCH((colreduce_kernel<4, NACC, F4>), grid, dim3(256), stream, f4, rows_per_seg, C, p.CTV, p.rows_per_chunk, ws);
+    else TF_LAUNCH((colreduce_kernel<1, NACC, F1>), grid, dim3(256), stream, f1, rows_per_seg, C, p.CTV, p.rows_per_chunk, ws);
+}
+
+// ---- finalize kernels --------------------------------------------------------------------------
+// out[seg][c] (+)= scale * sum_chunks ws[seg][chunk][0][c]
+__global__ void colsum_finalize_kernel(const float* __restrict__ ws, float* __restrict__ out, int C, int nch, int nseg, float scale, int accumulate) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nseg * C) return;
+    const int seg = i / C, c = i - seg * C;
+    float s = 0.f;
+    for (int j = 0; j < nch; ++j) s += ws[((long)seg * nch + j) * C + c];
+    s *= scale;
+    if (accumulate) out[i] += s; else out[i] = s;
+}
+
+// BN training statistics (torch BatchNorm2d train mode: biased var for normalisation, unbiased for
+// running_var, momentum 0.1, eps 1e-5 - timm BatchNormAct2d).  coef = [scale | shift] (2*C).
+__global__ void bn_fwd_finalize_kernel(const float* __restrict__ ws, const float* __restrict__ K, const float* __restrict__ gamma,
+                                       const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
+                                       float* __restrict__ save_mean, float* __restrict__ save_invstd, float* __restrict__ coef, int C, int nch,
+                                       float n, float momentum, float eps) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float s1 = 0.f, s2 = 0.f;
+    for (int j = 0; j < nch; ++j) { s1 += ws[((long)j * 2 + 0) * C + c]; s2 += ws[((long)j * 2 + 1) * C + c]; }
+    const float dm = s1 / n;
+    const float mean = K[c] + dm;
+    float var = s2 / n - dm * dm;
+    if (var < 0.f) var = 0.f;
+    const float invstd = 1.0f / sqrtf(var + eps);
+    save_mean[c] = mean;
+    save_invstd[c] = invstd;
+    const float sc = gamma[c] * invstd;
+    coef[c] = sc;
+    coef[C + c] = beta[c] - mean * sc;
+    if (rmean) {
+        rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+        const float unb = (n > 1.f) ? var * (n / (n - 1.f)) : var;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * unb;
+    }
+}
+__global__ void bn_eval_coef_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ rmean,
+                                    const float* __restrict__ rvar, float* __restrict__ coef, int C, float eps) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float sc = gamma[c] / sqrtf(rvar[c] + eps);
+    coef[c] = sc;
+    coef[C + c] = beta[c] - rmean[c] * sc;
+}
+// dgamma += sum g*xhat, dbeta += sum g; dx = A*g + Bc*x + Cc  (coef = [A | Bc | Cc])
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ ws, const float* __restrict__ gamma, const float* __restrict__ mean,
+                                       const float* __restrict__ invstd, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                       float* __restrict__ coef, int C, int nch, float n) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float sg = 0.f, sgx = 0.f;
+    for (int j = 0; j < nch; ++j) { sg += ws[((long)j * 2 + 0) * C + c]; sgx += ws[((long)j * 2 + 1) * C + c]; }
+    if (dgamma) dgamma[c] += sgx;
+    if (dbeta) dbeta[c] += sg;
+    const float A = gamma[c] * invstd[c];
+    const float Bc = -A * invstd[c] * (sgx / n);
+    coef[c] = A;
+    coef[C + c] = Bc;
+    coef[2 * C + c] = -A * (sg / n) - Bc * mean[c];
+}
+// dgate_pre[b][c] = (sum_hw dy*x) * s * (1 - s), s = sigmoid(gate)
+__global__ void se_bwd_finalize_kernel(const float* __restrict__ ws, const float* __restrict__ gate, float* __restrict__ dgate, int C, int nch, int nseg) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nseg * C) return;
+    const int seg = i / C, c = i - seg * C;
+    float s = 0.f;
+    for (int j = 0; j < nch; ++j) s += ws[((long)seg * nch + j) * C + c];
+    const float sg = 1.f / (1.f + expf(-gate[i]));
+    dgate[i] = s * sg * (1.f - sg);
+}
+
+// ---- per-channel elementwise passes (grid-stride over vectors) ------------------------------------
+template <int V>
+__global__ void __launch_bounds__(256) bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ coef, const float* __restrict__ res,
+                                                       float* __restrict__ y, long nvec, int C, int relu) {
+    const int cv = C / V;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % cv) * V;
+        vecf<V> a = ldv<V>(x + i * V), s = ldv<V>(coef + c), t = ldv<V>(coef + C + c);
+        vecf<V> r;
+        if (res) r = ldv<V>(res + i * V);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            float v = a.v[k] * s.v[k] + t.v[k];
+            if (res) v += r.v[k];
+            if (relu) v = fmaxf(v, 0.f);
+            a.v[k] = v;
+        }
+        stv<V>(y + i * V, a);
+    }
+}
+template <int V>
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ z, const float* __restrict__ x,
+                                                           const float* __restrict__ coef, float* __restrict__ dx, float* __restrict__ dres,
+                                                           long nvec, int C) {
+    const int cv = C / V;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % cv) * V;
+        vecf<V> g = ldv<V>(dz + i * V), a = ldv<V>(x + i * V), A = ldv<V>(coef + c), Bc = ldv<V>(coef + C + c), Cc = ldv<V>(coef + 2 * C + c);
+        if (z) { vecf<V> zz = ldv<V>(z + i * V);
+#pragma unroll
+            for (int k = 0; k < V; ++k) if (!(zz.v[k] > 0.f)) g.v[k] = 0.f; }
+        if (dres) stv<V>(dres + i * V, g);
+#pragma unroll
+        for (int k = 0; k < V; ++k) a.v[k] = A.v[k] * g.v[k] + Bc.v[k] * a.v[k] + Cc.v[k];
+        stv<V>(dx + i * V, a);
+    }
+}
+// y = x * sigmoid(gate[b][c])
+template <int V>
+__global__ void __launch_bounds__(256) se_scale_kernel(const float* __restrict__ x, const float* __restrict__ gate, float* __restrict__ y, long nvec,
+                                                       int C, long vec_per_b) {
+    const int cv = C / V;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % cv) * V;
+        const long b = i / vec_per_b;
+        vecf<V> a = ldv<V>(x + i * V), g = ldv<V>(gate + b * C + c);
+#pragma unroll
+        for (int k = 0; k < V; ++k) a.v[k] = a.v[k] * (1.f / (1.f + expf(-g.v[k])));
+        stv<V>(y + i * V, a);
+    }
+}
+// dx (+)= dy * sigmoid(gate[b][c]) + dmean[b][c] * inv_hw      (either term optional)
+template <int V>
+__global__ void __launch_bounds__(256) se_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ gate, const float* __restrict__ dmean,
+                                                           float* __restrict__ dx, long nvec, int C, long vec_per_b, float inv_hw, int accumulate) {
+    const int cv = C / V;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % cv) * V;
+        const long b = i / vec_per_b;
+        vecf<V> o;
+#pragma unroll
+        for (int k = 0; k < V; ++k) o.v[k] = 0.f;
+        if (dy) {
+            vecf<V> a = ldv<V>(dy + i * V), g = ldv<V>(gate + b * C + c);
+#pragma unroll
+            for (int k = 0; k < V; ++k) o.v[k] = a.v[k] * (1.f / (1.f + expf(-g.v[k])));
+        }
+        if (dmean) {
+            vecf<V> m = ldv<V>(dmean + b * C + c);
+#pragma unroll
+            for (int k = 0; k < V; ++k) o.v[k] += m.v[k] * inv_hw;
+        }
+        if (accumulate) { vecf<V> p = ldv<V>(dx + i * V);
+#pragma unroll
+            for (int k = 0; k < V; ++k) o.v[k] += p.v[k]; }
+        stv<V>(dx + i * V, o);
+    }
+}
+
+inline int ew_blocks(long nvec) {
+    long b = (nvec + 255) / 256;
+    if (b > 4096) b = 4096;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace
+
+extern "C" long tf_workspace_bytes(void) { return kWsFloats * 4; }
+
+// BatchNorm2d forward on NHWC (rows = B*H*W).  training: batch statistics (+ running update);
+// eval: running statistics.  y = bn(x) (+res) (relu).  ws: tf_workspace_bytes() scratch.
+extern "C" int tf_bn_fwd_f32(const float* x, int rows, int C, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                             float momentum, float eps, const float* res, int relu, float* y, float* save_mean, float* save_invstd, float* ws,
+                             int training, void* stream) {
+    TF_REQUIRE(x && gamma && beta && y && ws && rows > 0 && C > 0, "tf_bn_fwd_f32: bad arguments");
+    float* coef = ws + kWsFloats / 2;
+    if (training) {
+        TF_REQUIRE(save_mean && save_invstd, "tf_bn_fwd_f32: training needs save_mean/save_invstd");
+        RedPlan p = plan_reduce(rows, C, 1, 2);
+        BnStatF<4> f4{x, x, C};  // shift K = first row of x
+        BnStatF<1> f1{x, x, C};
+        launch_reduce<2>(p, f4, f1, rows, C, 1, ws, stream);
+        TF_LAUNCH(bn_fwd_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), stream, (const float*)ws, x, gamma, beta, running_mean, running_var,
+                  save_mean, save_invstd, coef, C, p.nchunks, (float)rows, momentum, eps);
+    } else {
+        TF_REQUIRE(running_mean && running_var, "tf_bn_fwd_f32: eval needs running statistics");
+        TF_LAUNCH(bn_eval_coef_kernel, dim3(cdiv(C, 256)), dim3(256), stream, gamma, beta, (const float*)running_mean, (const float*)running_var,
+                  coef, C, eps);
+    }
+    const bool v4 = (C % 4 == 0) && aligned16(x) && aligned16(y) && (!res || aligned16(res));
+    const long n = (long)rows * C;
+    if (v4) TF_LAUNCH(bn_apply_kernel<4>, dim3(ew_blocks(n / 4)), dim3(256), stream, x, (const float*)coef, res, y, n / 4, C, relu);
+    else TF_LAUNCH(bn_apply_kernel<1>, dim3(ew_blocks(n)), dim3(256), stream, x, (const float*)coef, res, y, n, C, relu);
+    return launch_status("tf_bn_fwd_f32");
+}
+
+// BatchNorm2d backward (training statistics).  dz: grad of the (post-residual, post-ReLU) output;
+// z: that output when a ReLU followed (mask) else NULL.  dgamma/dbeta are ACCUMULATED.
+extern "C" int tf_bn_bwd_f32(const float* dz, const float* z, const float* x, int rows, int C, const float* gamma, const float* save_mean,
+                             const float* save_invstd, float* dx, float* dres, float* dgamma, float* dbeta, float* ws, void* stream) {
+    TF_REQUIRE(dz && x && gamma && save_mean && save_invstd && dx && ws && rows > 0 && C > 0, "tf_bn_bwd_f32: bad arguments");
+    float* coef = ws + kWsFloats / 2;
+    RedPlan p = plan_reduce(rows, C, 1, 2);
+    BnBwdF<4> f4{dz, z, x, save_mean, save_invstd, C};
+    BnBwdF<1> f1{dz, z, x, save_mean, save_invstd, C};
+    launch_reduce<2>(p, f4, f1, rows, C, 1, ws, stream);
+    TF_LAUNCH(bn_bwd_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), stream, (const float*)ws, gamma, save_mean, save_invstd, dgamma, dbeta, coef,
+              C, p.nchunks, (float)rows);
+    const bool v4 = (C % 4 == 0) && aligned16(dz) && aligned16(x) && aligned16(dx) && (!z || aligned16(z)) && (!dres || aligned16(dres));
+    const long n = (long)rows * C;
+    if (v4) TF_LAUNCH(bn_bwd_apply_kernel<4>, dim3(ew_blocks(n / 4)), dim3(256), stream, dz, z, x, (const float*)coef, dx, dres, n / 4, C);
+    else TF_LAUNCH(bn_bwd_apply_kernel<1>, dim3(ew_blocks(n)), dim3(256), stream, dz, z, x, (const float*)coef, dx, dres, n, C);
+    return launch_status("tf_bn_bwd_f32");
+}
+
+// out[seg][c] (+)= scale * sum over the segment's rows of x (* [mask > 0]).  Uses: SE squeeze /
+// global average pool (scale = 1/HW, nseg = B), bias gradients (nseg = 1, mask = ReLU output).
+extern "C" int tf_colsum_f32(const float* x, const float* mask, int nseg, int rows_per_seg, int C, float scale, float* out, int accumulate,
+                             float* ws, void* stream) {
+    TF_REQUIRE(x && out && ws && nseg > 0 && rows_per_seg > 0 && C > 0, "tf_colsum_f32: bad arguments");
+    RedPlan p = plan_reduce(rows_per_seg, C, nseg, 1, aligned16(x) && (!mask || aligned16(mask)));
+    MaskSumF<4> f4{x, mask, C};
+    MaskSumF<1> f1{x, mask, C};
+    launch_reduce<1>(p, f4, f1, rows_per_seg, C, nseg, ws, stream);
+    TF_LAUNCH(colsum_finalize_kernel, dim3(cdiv((long)nseg * C, 256)), dim3(256), stream, (const float*)ws, out, C, p.nchunks, nseg, scale, accumulate);
+    return launch_status("tf_colsum_f32");
+}
+
+// Squeeze-Excite scale (timm SEModule): y = x * sigmoid(gate[b][c]); x: (B, HW, C), gate: (B, C) pre-sigmoid.
+extern "C" int tf_se_scale_fwd_f32(const float* x, const float* gate, float* y, int B, int HW, int C, void* stream) {
+    TF_REQUIRE(x && gate && y && B > 0 && HW > 0 && C > 0, "tf_se_scale_fwd_f32: bad arguments");
+    const long n = (long)B * HW * C;
+    if (C % 4 == 0 && aligned16(x) && aligned16(y) && aligned16(gate))
+        TF_LAUNCH(se_scale_kernel<4>, dim3(ew_blocks(n / 4)), dim3(256), stream, x, gate, y, n / 4, C, (long)HW * C / 4);
+    else
+        TF_LAUNCH(se_scale_kernel<1>, dim3(ew_blocks(n)), dim3(256), stream, x, gate, y, n, C, (long)HW * C);
+    return launch_status("tf_se_scale_fwd_f32");
+}
+// dgate_pre[b][c] = (sum_hw dy * x) * s(1-s)
+extern "C" int tf_se_scale_bwd_gate_f32(const float* dy, const float* x, const float* gate, float* dgate, int B, int HW, int C, float* ws, void* stream) {
+    TF_REQUIRE(dy && x && gate && dgate && ws && B > 0 && HW > 0 && C > 0, "tf_se_scale_bwd_gate_f32: bad arguments");
+    RedPlan p = plan_reduce(HW, C, B, 1);
+    MulF<4> f4{dy, x, C};
+    MulF<1> f1{dy, x, C};
+    launch_reduce<1>(p, f4, f1, HW, C, B, ws, stream);
+    TF_LAUNCH(se_bwd_finalize_kernel, dim3(cdiv((long)B * C, 256)), dim3(256), stream, (const float*)ws, gate, dgate, C, p.nchunks, B);
+    return launch_status("tf_se_scale_bwd_gate_f32");
+}
+// dx (+)= dy * sigmoid(gate) + dmean / HW   (dy/gate pair optional, dmean optional): the input
+// gradient of the SE block, and of a global average pool (dy = NULL).
+extern "C" int tf_se_scale_bwd_x_f32(const float* dy, const float* gate, const float* dmean, float* dx, int B, int HW, int C, int accumulate,
+                                     void* stream) {
+    TF_REQUIRE(dx && (dy || dmean) && (!dy || gate) && B > 0 && HW > 0 && C > 0, "tf_se_scale_bwd_x_f32: bad arguments");
+    const long n = (long)B * HW * C;
+    const bool v4 = C % 4 == 0 && aligned16(dx) && (!dy || (aligned16(dy) && aligned16(gate))) && (!dmean || aligned16(dmean));
+    if (v4) TF_LAUNCH(se_bwd_apply_kernel<4>, dim3(ew_blocks(n / 4)), dim3(256), stream, dy, gate, dmean, dx, n / 4, C, (long)HW * C / 4, 1.f / HW, accumulate);
+    else TF_LAUNCH(se_bwd_apply_kernel<1>, dim3(ew_blocks(n)), dim3(256), stream, dy, gate, dmean, dx, n, C, (long)HW * C, 1.f / HW, accumulate);
+    return launch_status("tf_se_scale_bwd_x_f32");
+}

@@ -1,0 +1,218 @@
+// Spatial resampling kernels (HBM-bound):
+//  - AdaptiveAvgPool2d -> token pack (+pos_emb [+vel_emb]) in one pass (transfuser.py:150-151,346-357)
+//  - its backward
+//  - bilinear interpolation fwd/bwd with arbitrary element strides, so the SAME kernel reads the
+//    GPT's raw-viewed (B,C,h,w) token memory (quirk Q1, transfuser.py:363-364) and writes / adds
+//    into NHWC feature maps (transfuser.py:154-157), nn.Upsample x2 (transfuser.py:103,114-116),
+//    decoder x8/x4 (transfuser.py:241,243) and align_corners=True pred_bev (model.py:760).
+#include "tf_common.h"
+#include "../../include/transfuser_hip.h"
+
+using namespace tf;
+
+namespace {
+
+// PyTorch adaptive pooling window: [floor(i*In/Out), ceil((i+1)*In/Out))
+__device__ __forceinline__ int ap_start(int i, int in, int out) { return (int)(((long)i * in) / out); }
+__device__ __forceinline__ int ap_end(int i, int in, int out) { return (int)(((long)(i + 1) * in + out - 1) / out); }
+
+template <int V>
+__global__ void __launch_bounds__(256) pool_tokens_fwd_kernel(const float* __restrict__ x, int B, int H, int W, int C, int oh, int ow,
+                                                              const float* __restrict__ pos, const float* __restrict__ bvec,
+                                                              float* __restrict__ tok, int T_total, int tok_off) {
+    const int cv = C / V;
+    const long total = (long)B * oh * ow * cv;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c = (int)(idx % cv) * V;
+        long t = idx / cv;
+        const int j = (int)(t % ow); t /= ow;
+        const int i = (int)(t % oh);
+        const int b = (int)(t / oh);
+        const int h0 = ap_start(i, H, oh), h1 = ap_end(i, H, oh), w0 = ap_start(j, W, ow), w1 = ap_end(j, W, ow);
+        float acc[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) acc[k] = 0.f;
+        for (int h = h0; h < h1; ++h)
+            for (int w = w0; w < w1; ++w) {
+                const float* p = x + (((long)b * H + h) * W + w) * C + c;
+                if (V == 4) { float4 v = *reinterpret_cast<const float4*>(p); acc[0] += v.x; acc[1 % V] += v.y; acc[2 % V] += v.z; acc[3 % V] += v.w; }
+                else acc[0] += *p;
+            }
+        const float inv = 1.0f / (float)((h1 - h0) * (w1 - w0));
+        const int trow = tok_off + i * ow + j;
+        float* o = tok + ((long)b * T_total + trow) * C + c;
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            float v = acc[k] * inv;
+            if (pos) v += pos[(long)trow * C + c + k];
+            if (bvec) v += bvec[(long)b * C + c + k];
+            o[k] = v;
+        }
+    }
+}
+
+template <int V>
+__global__ void __launch_bounds__(256) pool_tokens_bwd_kernel(const float* __restrict__ dtok, int B, int H, int W, int C, int oh, int ow,
+                                                              int T_total, int tok_off, float* __restrict__ dx, int accumulate) {
+    const int cv = C / V;
+    const long total = (long)B * H * W * cv;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c = (int)(idx % cv) * V;
+        long t = idx / cv;
+        const int w = (int)(t % W); t /= W;
+        const int h = (int)(t % H);
+        const int b = (int)(t / H);
+        float acc[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) acc[k] = 0.f;
+        const int ic = (int)(((long)h * oh) / H), jc = (int)(((long)w * ow) / W);
+        for (int i = (ic > 0 ? ic - 1 : 0); i <= ic + 1 && i < oh; ++i) {
+            const int h0 = ap_start(i, H, oh), h1 = ap_end(i, H, oh);
+            if (h < h0 || h >= h1) continue;
+            for (int j = (jc > 0 ? jc - 1 : 0); j <= jc + 1 && j < ow; ++j) {
+                const int w0 = ap_start(j, W, ow), w1 = ap_end(j, W, ow);
+                if (w < w0 || w >= w1) continue;
+                const float inv = 1.0f / (float)((h1 - h0) * (w1 - w0));
+                const float* g = dtok + ((long)b * T_total + tok_off + i * ow + j) * C + c;
+#pragma unroll
+                for (int k = 0; k < V; ++k) acc[k] += g[k] * inv;
+            }
+        }
+        float* o = dx + idx * V;
+#pragma unroll
+        for (int k = 0; k < V; ++k) o[k] = accumulate ? o[k] + acc[k] : acc[k];
+    }
+}
+
+// PyTorch upsample_bilinear2d source index (area_pixel_compute_source_index, cubic = false)
+__device__ __forceinline__ void bl_src(int o, float scale, int align, int in, int& i0, int& i1, float& l0, float& l1) {
+    float s = align ? scale * (float)o : scale * ((float)o + 0.5f) - 0.5f;
+    if (!align && s < 0.f) s = 0.f;
+    i0 = (int)s;
+    if (i0 > in - 1) i0 = in - 1;
+    i1 = i0 + ((i0 < in - 1) ? 1 : 0);
+    l1 = s - (float)i0;
+    l0 = 1.f - l1;
+}
+
+// one thread per output element; output index order is (b, h, w, c) with c fastest so NHWC
+// destinations are written coalesced
+__global__ void __launch_bounds__(256) bilinear_fwd_kernel(tf_bilinear_desc d, const float* __restrict__ x, float* __restrict__ y,
+                                                           const float* __restrict__ add, float sh, float sw) {
+    const long total = (long)d.B * d.Ho * d.Wo * d.C;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c = (int)(idx % d.C);
+        long t = idx / d.C;
+        const int wo = (int)(t % d.Wo); t /= d.Wo;
+        const int ho = (int)(t % d.Ho);
+        const int b = (int)(t / d.Ho);
+        int h0, h1, w0, w1; float lh0, lh1, lw0, lw1;
+        bl_src(ho, sh, d.align_corners, d.Hi, h0, h1, lh0, lh1);
+        bl_src(wo, sw, d.align_corners, d.Wi, w0, w1, lw0, lw1);
+        const float* p = x + b * d.sb_i + c * d.sc_i;
+        const float v = lh0 * (lw0 * p[h0 * d.sh_i + w0 * d.sw_i] + lw1 * p[h0 * d.sh_i + w1 * d.sw_i]) +
+                        lh1 * (lw0 * p[h1 * d.sh_i + w0 * d.sw_i] + lw1 * p[h1 * d.sh_i + w1 * d.sw_i]);
+        const long oo = b * d.sb_o + c * d.sc_o + ho * d.sh_o + wo * d.sw_o;
+        y[oo] = add ? add[oo] + v : v;
+    }
+}
+
+// gather form of the backward: one thread per INPUT element, loops over the output pixels that
+// reference it (no atomics, deterministic).  Index order follows the input's fastest stride.
+__global__ void __launch_bounds__(256) bilinear_bwd_kernel(tf_bilinear_desc d, const float* __restrict__ dy, float* __restrict__ dx, float sh,
+                                                           float sw, int accumulate, int c_fastest) {
+    const long total = (long)d.B * d.Hi * d.Wi * d.C;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        int b, c, hi, wi;
+        if (c_fastest) { c = (int)(idx % d.C); long t = idx / d.C; wi = (int)(t % d.Wi); t /= d.Wi; hi = (int)(t % d.Hi); b = (int)(t / d.Hi); }
+        else { wi = (int)(idx % d.Wi); long t = idx / d.Wi; hi = (int)(t % d.Hi); t /= d.Hi; c = (int)(t % d.C); b = (int)(t / d.C); }
+        // candidate output range: |src(o) - i| < 1  (+-1 guard band)
+        int ho_lo, ho_hi, wo_lo, wo_hi;
+        {
+            const float inv = 1.0f / sh;
+            float lo = d.align_corners ? ((float)hi - 1.f) * inv : ((float)hi - 1.f + 0.5f) * inv - 0.5f;
+            float hi_ = d.align_corners ? ((float)hi + 1.f) * inv : ((float)hi + 1.f + 0.5f) * inv - 0.5f;
+            ho_lo = (int)floorf(lo) - 1; ho_hi = (int)ceilf(hi_) + 1;
+            if (ho_lo < 0) ho_lo = 0;
+            if (ho_hi > d.Ho - 1) ho_hi = d.Ho - 1;
+        }
+        {
+            const float inv = 1.0f / sw;
+            float lo = d.align_corners ? ((float)wi - 1.f) * inv : ((float)wi - 1.f + 0.5f) * inv - 0.5f;
+            float hi_ = d.align_corners ? ((float)wi + 1.f) * inv : ((float)wi + 1.f + 0.5f) * inv - 0.5f;
+            wo_lo = (int)floorf(lo) - 1; wo_hi = (int)ceilf(hi_) + 1;
+            if (wo_lo < 0) wo_lo = 0;
+            if (wo_hi > d.Wo - 1) wo_hi = d.Wo - 1;
+        }
+        const float* g = dy + b * d.sb_o + c * d.sc_o;
+        float acc = 0.f;
+        for (int ho = ho_lo; ho <= ho_hi; ++ho) {
+            int h0, h1; float l0, l1;
+            bl_src(ho, sh, d.align_corners, d.Hi, h0, h1, l0, l1);
+            float wh = 0.f;
+            if (h0 == hi) wh += l0;
+            if (h1 == hi) wh += l1;
+            if (wh == 0.f) continue;
+            float rowacc = 0.f;
+            for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+                int w0, w1; float m0, m1;
+                bl_src(wo, sw, d.align_corners, d.Wi, w0, w1, m0, m1);
+                float ww = 0.f;
+                if (w0 == wi) ww += m0;
+                if (w1 == wi) ww += m1;
+                if (ww != 0.f) rowacc += ww * g[ho * d.sh_o + wo * d.sw_o];
+            }
+            acc += wh * rowacc;
+        }
+        const long io = b * d.sb_i + c * d.sc_i + hi * d.sh_i + wi * d.sw_i;
+        dx[io] = accumulate ? dx[io] + acc : acc;
+    }
+}
+
+inline int ew_blocks(long n) {
+    long b = (n + 255) / 256;
+    if (b > 8192) b = 8192;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+inline float bl_scale(int in, int out, int align) {
+    if (align) return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+    return (float)in / (float)out;
+}
+
+}  // namespace
+
+extern "C" int tf_pool_tokens_fwd_f32(const float* x, int B, int H, int W, int C, int oh, int ow, const float* pos, const float* bvec, float* tok,
+                                      int T_total, int tok_off, void* stream) {
+    TF_REQUIRE(x && tok && B > 0 && H > 0 && W > 0 && C > 0 && oh > 0 && ow > 0 && tok_off + oh * ow <= T_total, "tf_pool_tokens_fwd_f32: bad arguments");
+    const bool v4 = C % 4 == 0 && aligned16(x);
+    const long n = (long)B * oh * ow * (C / (v4 ? 4 : 1));
+    if (v4) TF_LAUNCH(pool_tokens_fwd_kernel<4>, dim3(ew_blocks(n)), dim3(256), stream, x, B, H, W, C, oh, ow, pos, bvec, tok, T_total, tok_off);
+    else TF_LAUNCH(pool_tokens_fwd_kernel<1>, dim3(ew_blocks(n)), dim3(256), stream, x, B, H, W, C, oh, ow, pos, bvec, tok, T_total, tok_off);
+    return launch_status("tf_pool_tokens_fwd_f32");
+}
+
+extern "C" int tf_pool_tokens_bwd_f32(const float* dtok, int B, int H, int W, int C, int oh, int ow, int T_total, int tok_off, float* dx,
+                                      int accumulate, void* stream) {
+    TF_REQUIRE(dtok && dx && B > 0 && H > 0 && W > 0 && C > 0 && oh > 0 && ow > 0 && tok_off + oh * ow <= T_total, "tf_pool_tokens_bwd_f32: bad arguments");
+    const long n = (long)B * H * W * C;
+    TF_LAUNCH(pool_tokens_bwd_kernel<1>, dim3(ew_blocks(n)), dim3(256), stream, dtok, B, H, W, C, oh, ow, T_total, tok_off, dx, accumulate);
+    return launch_status("tf_pool_tokens_bwd_f32");
+}
+
+extern "C" int tf_bilinear_fwd_f32(const tf_bilinear_desc* d, const float* x, float* y, const float* add, void* stream) {
+    TF_REQUIRE(d && x && y && d->B > 0 && d->C > 0 && d->Hi > 0 && d->Wi > 0 && d->Ho > 0 && d->Wo > 0, "tf_bilinear_fwd_f32: bad arguments");
+    const long n = (long)d->B * d->Ho * d->Wo * d->C;
+    TF_LAUNCH(bilinear_fwd_kernel, dim3(ew_blocks(n)), dim3(256), stream, *d, x, y, add, bl_scale(d->Hi, d->Ho, d->align_corners),
+              bl_scale(d->Wi, d->Wo, d->align_corners));
+    return launch_status("tf_bilinear_fwd_f32");
+}
+
+extern "C" int tf_bilinear_bwd_f32(const tf_bilinear_desc* d, const float* dy, float* dx, int accumulate, void* stream) {
+    TF_REQUIRE(d && dy && dx && d->B > 0 && d->C > 0 && d->Hi > 0 && d->Wi > 0 && d->Ho > 0 && d->Wo > 0, "tf_bilinear_bwd_f32: bad arguments");
+    TF_REQUIRE(d->Ho >= d->Hi && d->Wo >= d->Wi, "tf_bilinear_bwd_f32: only up-sampling is supported");
+    const long n = (long)d->B * d->Hi * d->Wi * d->C;
+    TF_LAUNCH(bilinear_bwd_kernel, dim3(ew_blocks(n)), dim3(256), stream, *d, dy, dx, bl_scale(d->Hi, d->Ho, d->align_corners),
+              bl_scale(d->Wi, d->Wo, d->align_corners), accumulate, d->sc_i == 1 ? 1 : 0);
+    return launch_status("tf_bilinear_bwd_f32");
+}

@@ -144,6 +144,38 @@ struct Im2colTOp {
     }
 };
 
+// im2col view of NCHW inputs for the two stem convolutions (transfuser.py:136,140): channels
+// [0,C0) come from s0 (B,C0,H,W), [C0,C0+C1) from s1 (lidar histogram + target-point image, the
+// torch.cat of model.py:741-742 never materialises).  normalize != 0 folds normalize_imagenet
+// (transfuser.py:419-428) into the load: ((x / 255) - mean) / std, padding stays 0.
+struct Im2colNchwOp {
+    const float* s0; const float* s1; int C0, C1, Hi, Wi, Ho, Wo, ks, stride, pad, Cg, rows, cols, vec, normalize;
+    float mean[4], stdv[4];
+    typedef ConvRow Row;
+    __device__ __forceinline__ void set_batch(int) {}
+    __device__ __forceinline__ Row row(int r) const {
+        Row w; w.ok = r < rows; w.base = 0; w.h0 = 0; w.w0 = 0;
+        if (w.ok) {
+            int ow = r % Wo; int t = r / Wo; int oh = t % Ho; int b = t / Ho;
+            w.base = b; w.h0 = oh * stride - pad; w.w0 = ow * stride - pad;
+        }
+        return w;
+    }
+    __device__ __forceinline__ float at(const Row& w, int c) const {
+        if (c >= cols) return 0.f;
+        int tap = c / Cg; int ci = c - tap * Cg; int kh = tap / ks; int kw = tap - kh * ks;
+        int ih = w.h0 + kh, iw = w.w0 + kw;
+        if ((unsigned)ih >= (unsigned)Hi || (unsigned)iw >= (unsigned)Wi) return 0.f;
+        float v = (ci < C0) ? s0[((w.base * C0 + ci) * Hi + ih) * Wi + iw] : s1[((w.base * C1 + (ci - C0)) * Hi + ih) * Wi + iw];
+        if (normalize) v = ((v / 255.0f) - mean[ci]) / stdv[ci];
+        return v;
+    }
+    __device__ __forceinline__ float4 load(const Row& w, int c) const {
+        if (!w.ok || c >= cols) return f4zero();
+        return make_float4(at(w, c), at(w, c + 1), at(w, c + 2), at(w, c + 3));
+    }
+};
+
 // ---------------------------------------------------------------- epilogue
 struct GemmEpi {
     float* C; long ldc; long sc_outer, sc_inner; int inner;

@@ -1,0 +1,374 @@
+"""Functional wrappers over the C ABI (include/transfuser_hip.h).
+
+No autograd here: every function launches HIP kernels on torch's current stream and returns
+tensors; ``transfuser_amd/functions.py`` composes them into a handful of block-level
+``torch.autograd.Function``s.  Layout conventions: feature maps are explicit NHWC tensors
+``(B, H, W, C)``, conv weights are ``(Cout, Cin/g, kh, kw)`` parameters in channels_last memory
+format (physically ``(Cout, kh, kw, Cin/g)``), linear weights are ``(out, in)``.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ConvGeom, GemmDesc, c_p, check, ptr, stream_of
+
+byref = ctypes.byref
+
+_ws_cache = {}
+
+
+def L():
+    return _lib.load()
+
+
+def workspace(device):
+    """Reduction scratch, one per device (kernels on one stream serialise, so it is shared)."""
+    key = str(device)
+    ws = _ws_cache.get(key)
+    if ws is None:
+        L().tf_workspace_bytes.restype = ctypes.c_long
+        ws = torch.empty(L().tf_workspace_bytes() // 4, dtype=torch.float32, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+def _c(t):
+    assert t.is_contiguous(), "expected a contiguous tensor, got strides %s for shape %s" % (t.stride(), tuple(t.shape))
+    return t
+
+
+def wptr(w):
+    """Pointer to a conv weight stored channels_last (or any 2-D / 1x1 weight)."""
+    if w.dim() == 4:
+        assert w.permute(0, 2, 3, 1).is_contiguous(), "conv weights must be channels_last"
+    else:
+        assert w.is_contiguous()
+    return ptr(w)
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+def gemm(a, b, c, m, n, k, lda, ldb, ldc, a_trans=False, b_trans=False, bias=None, res=None, ldres=0, alpha=1.0, relu=False,
+         accumulate=False, batch=1, inner=1, sa=(0, 0), sb=(0, 0), sc=(0, 0)):
+    d = GemmDesc(a=ptr(a), b=ptr(b), c=ptr(c), bias=ptr(bias), res=ptr(res), m=m, n=n, k=k, a_trans=int(a_trans), b_trans=int(b_trans),
+                 lda=lda, ldb=ldb, ldc=ldc, ldres=ldres, batch=batch, inner=inner, sa_outer=sa[0], sa_inner=sa[1], sb_outer=sb[0],
+                 sb_inner=sb[1], sc_outer=sc[0], sc_inner=sc[1], alpha=alpha, relu=int(relu), accumulate=int(accumulate))
+    check(L().tf_gemm_f32(byref(d), stream_of(c)), "tf_gemm_f32")
+    return c
+
+
+def linear_fwd(x, w, bias=None, relu=False, res=None, out=None):
+    """y = x @ w.T + bias (+res) (relu); x (M, K) row-major (row stride may exceed K), w (N, K)."""
+    M, K = x.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    return gemm(x, w, out, M, N, K, x.stride(0), w.stride(0), out.stride(0), bias=bias, res=res,
+                ldres=res.stride(0) if res is not None else 0, relu=relu)
+
+
+def linear_dgrad(dy, w, out=None, accumulate=False, res=None):
+    """dx = dy @ w (+res); dy (M, N), w (N, K)."""
+    M, N = dy.shape
+    K = w.shape[1]
+    if out is None:
+        out = torch.empty(M, K, dtype=torch.float32, device=dy.device)
+    return gemm(dy, w, out, M, K, N, dy.stride(0), w.stride(0), out.stride(0), b_trans=True, accumulate=accumulate, res=res,
+                ldres=res.stride(0) if res is not None else 0)
+
+
+def linear_wgrad(dy, x, dw, accumulate=True):
+    """dw (+)= dy.T @ x; dy (M, N), x (M, K), dw (N, K)."""
+    M, N = dy.shape
+    K = x.shape[1]
+    return gemm(dy, x, dw, N, K, M, dy.stride(0), x.stride(0), dw.stride(0), a_trans=True, b_trans=True, accumulate=accumulate)
+
+
+# ------------------------------------------------------------------------------------------ conv
+def conv_geom(x_shape, cout, ksize, stride, pad, groups):
+    B, Hi, Wi, Cin = x_shape
+    Ho = (Hi + 2 * pad - ksize) // stride + 1
+    Wo = (Wi + 2 * pad - ksize) // stride + 1
+    return ConvGeom(B, Hi, Wi, Cin, Ho, Wo, cout, ksize, stride, pad, groups)
+
+
+def conv_fwd(x, w, bias=None, stride=1, pad=None, groups=1, relu=False):
+    ks = w.shape[2]
+    pad = ks // 2 if pad is None else pad
+    g = conv_geom(x.shape, w.shape[0], ks, stride, pad, groups)
+    y = torch.empty(g.B, g.Ho, g.Wo, g.Cout, dtype=torch.float32, device=x.device)
+    check(L().tf_conv2d_fwd_f32(byref(g), ptr(_c(x)), wptr(w), ptr(bias), ptr(y), int(relu), stream_of(x)), "tf_conv2d_fwd_f32")
+    return y
+
+
+def conv_dgrad(dy, w, x_shape, stride=1, pad=None, groups=1, out=None, accumulate=False):
+    ks = w.shape[2]
+    pad = ks // 2 if pad is None else pad
+    g = conv_geom(x_shape, w.shape[0], ks, stride, pad, groups)
+    if out is None:
+        out = torch.empty(tuple(x_shape), dtype=torch.float32, device=dy.device)
+    check(L().tf_conv2d_dgrad_f32(byref(g), ptr(_c(dy)), wptr(w), ptr(_c(out)), int(accumulate), stream_of(dy)), "tf_conv2d_dgrad_f32")
+    return out
+
+
+def conv_wgrad(dy, x, dw, stride=1, pad=None, groups=1, accumulate=True):
+    ks = dw.shape[2]
+    pad = ks // 2 if pad is None else pad
+    g = conv_geom(x.shape, dw.shape[0], ks, stride, pad, groups)
+    check(L().tf_conv2d_wgrad_f32(byref(g), ptr(_c(dy)), ptr(_c(x)), wptr(dw), int(accumulate), stream_of(dy)), "tf_conv2d_wgrad_f32")
+    return dw
+
+
+def stem_conv_fwd(s0, s1, w, normalize):
+    """3x3 stride-2 conv on NCHW inputs (s1 optional extra channels) -> NHWC."""
+    B, C0, H, W = s0.shape
+    C1 = s1.shape[1] if s1 is not None else 0
+    g = conv_geom((B, H, W, C0 + C1), w.shape[0], 3, 2, 1, 1)
+    y = torch.empty(B, g.Ho, g.Wo, g.Cout, dtype=torch.float32, device=s0.device)
+    check(L().tf_stem_conv_fwd_f32(byref(g), ptr(_c(s0)), C0, ptr(_c(s1)) if s1 is not None else c_p(0), C1, int(normalize), wptr(w), ptr(y),
+                                   stream_of(s0)), "tf_stem_conv_fwd_f32")
+    return y
+
+
+def stem_conv_wgrad(dy, s0, s1, dw, normalize, accumulate=True):
+    B, C0, H, W = s0.shape
+    C1 = s1.shape[1] if s1 is not None else 0
+    g = conv_geom((B, H, W, C0 + C1), dw.shape[0], 3, 2, 1, 1)
+    check(L().tf_stem_conv_wgrad_f32(byref(g), ptr(_c(dy)), ptr(_c(s0)), C0, ptr(_c(s1)) if s1 is not None else c_p(0), C1, int(normalize),
+                                     wptr(dw), int(accumulate), stream_of(dy)), "tf_stem_conv_wgrad_f32")
+    return dw
+
+
+# ------------------------------------------------------------------------------------------ norms
+def layernorm_fwd(x, gamma, beta, eps=1e-5):
+    rows, C = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    check(L().tf_layernorm_fwd_f32(ptr(_c(x)), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), rows, C, ctypes.c_float(eps), stream_of(x)),
+          "tf_layernorm_fwd_f32")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma=None, dbeta=None, dx=None, accumulate=False):
+    rows, C = x.shape
+    if dx is None:
+        dx = torch.empty_like(x)
+    check(L().tf_layernorm_bwd_f32(ptr(_c(dy)), ptr(_c(x)), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), int(accumulate), ptr(dgamma), ptr(dbeta),
+                                   rows, C, stream_of(x)), "tf_layernorm_bwd_f32")
+    return dx
+
+
+def softmax_fwd_(s, rows, n, ld):
+    check(L().tf_softmax_fwd_f32(ptr(s), rows, n, ld, stream_of(s)), "tf_softmax_fwd_f32")
+    return s
+
+
+def softmax_bwd_(p, dp, rows, n, ld):
+    check(L().tf_softmax_bwd_f32(ptr(p), ptr(dp), rows, n, ld, stream_of(p)), "tf_softmax_bwd_f32")
+    return dp
+
+
+def bn_fwd(x, gamma, beta, rmean, rvar, res=None, relu=False, training=True, momentum=0.1, eps=1e-5):
+    """x: (..., C) NHWC; returns (y, save_mean, save_invstd)."""
+    C = x.shape[-1]
+    rows = x.numel() // C
+    y = torch.empty_like(x)
+    sm = torch.empty(C, dtype=torch.float32, device=x.device)
+    si = torch.empty_like(sm)
+    check(L().tf_bn_fwd_f32(ptr(_c(x)), rows, C, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), ctypes.c_float(momentum), ctypes.c_float(eps),
+                            ptr(res), int(relu), ptr(y), ptr(sm), ptr(si), ptr(workspace(x.device)), int(training), stream_of(x)), "tf_bn_fwd_f32")
+    return y, sm, si
+
+
+def bn_bwd(dz, z, x, gamma, sm, si, dgamma, dbeta, want_dres=False):
+    C = x.shape[-1]
+    rows = x.numel() // C
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if want_dres else None
+    check(L().tf_bn_bwd_f32(ptr(_c(dz)), ptr(z), ptr(_c(x)), rows, C, ptr(gamma), ptr(sm), ptr(si), ptr(dx), ptr(dres), ptr(dgamma), ptr(dbeta),
+                            ptr(workspace(x.device)), stream_of(x)), "tf_bn_bwd_f32")
+    return dx, dres
+
+
+def colsum(x, nseg, rows_per_seg, C, scale=1.0, mask=None, out=None, accumulate=False):
+    if out is None:
+        out = torch.empty(nseg, C, dtype=torch.float32, device=x.device)
+    check(L().tf_colsum_f32(ptr(_c(x)), ptr(mask), nseg, rows_per_seg, C, ctypes.c_float(scale), ptr(out), int(accumulate),
+                            ptr(workspace(x.device)), stream_of(x)), "tf_colsum_f32")
+    return out
+
+
+def se_scale_fwd(x, gate):
+    B, H, W, C = x.shape
+    y = torch.empty_like(x)
+    check(L().tf_se_scale_fwd_f32(ptr(_c(x)), ptr(_c(gate)), ptr(y), B, H * W, C, stream_of(x)), "tf_se_scale_fwd_f32")
+    return y
+
+
+def se_scale_bwd_gate(dy, x, gate):
+    B, H, W, C = x.shape
+    dgate = torch.empty(B, C, dtype=torch.float32, device=x.device)
+    check(L().tf_se_scale_bwd_gate_f32(ptr(_c(dy)), ptr(_c(x)), ptr(_c(gate)), ptr(dgate), B, H * W, C, ptr(workspace(x.device)), stream_of(x)),
+          "tf_se_scale_bwd_gate_f32")
+    return dgate
+
+
+def se_scale_bwd_x(dy, gate, dmean, shape, out=None, accumulate=False):
+    """dx (+)= dy * sigmoid(gate) + dmean / HW; either part optional (dy=None: global-avg-pool backward)."""
+    B, H, W, C = shape
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float32, device=(dy if dy is not None else dmean).device)
+    check(L().tf_se_scale_bwd_x_f32(ptr(dy), ptr(gate), ptr(dmean), ptr(out), B, H * W, C, int(accumulate), stream_of(out)), "tf_se_scale_bwd_x_f32")
+    return out
+
+
+# ------------------------------------------------------------------------------------------ resampling
+def pool_tokens_fwd(x, oh, ow, pos, tok, tok_off, bvec=None):
+    B, H, W, C = x.shape
+    check(L().tf_pool_tokens_fwd_f32(ptr(_c(x)), B, H, W, C, oh, ow, ptr(pos), ptr(bvec), ptr(tok), tok.shape[1], tok_off, stream_of(x)),
+          "tf_pool_tokens_fwd_f32")
+    return tok
+
+
+def pool_tokens_bwd(dtok, shape, oh, ow, tok_off, out=None, accumulate=False):
+    B, H, W, C = shape
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float32, device=dtok.device)
+    check(L().tf_pool_tokens_bwd_f32(ptr(_c(dtok)), B, H, W, C, oh, ow, dtok.shape[1], tok_off, ptr(out), int(accumulate), stream_of(dtok)),
+          "tf_pool_tokens_bwd_f32")
+    return out
+
+
+class BilinearDesc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int) for n in ("B", "C", "Hi", "Wi", "Ho", "Wo")] + \
+               [(n, ctypes.c_int64) for n in ("sb_i", "sc_i", "sh_i", "sw_i", "sb_o", "sc_o", "sh_o", "sw_o")] + [("align_corners", ctypes.c_int)]
+
+
+def _bl_desc(B, C, Hi, Wi, Ho, Wo, in_nhwc, out_nhwc, align):
+    si = (Hi * Wi * C, 1, Wi * C, C) if in_nhwc else (C * Hi * Wi, Hi * Wi, Wi, 1)
+    so = (Ho * Wo * C, 1, Wo * C, C) if out_nhwc else (C * Ho * Wo, Ho * Wo, Wo, 1)
+    return BilinearDesc(B, C, Hi, Wi, Ho, Wo, *si, *so, int(align))
+
+
+def bilinear_fwd(x, B, C, Hi, Wi, Ho, Wo, in_nhwc=True, out_nhwc=True, align_corners=False, add=None, out=None):
+    """x holds B*C*Hi*Wi floats in NHWC or NCHW order; returns (B,Ho,Wo,C) [NHWC] or (B,C,Ho,Wo)."""
+    d = _bl_desc(B, C, Hi, Wi, Ho, Wo, in_nhwc, out_nhwc, align_corners)
+    if out is None:
+        out = torch.empty((B, Ho, Wo, C) if out_nhwc else (B, C, Ho, Wo), dtype=torch.float32, device=x.device)
+    check(L().tf_bilinear_fwd_f32(byref(d), ptr(_c(x)), ptr(out), ptr(add), stream_of(x)), "tf_bilinear_fwd_f32")
+    return out
+
+
+def bilinear_bwd(dy, B, C, Hi, Wi, Ho, Wo, in_nhwc=True, out_nhwc=True, align_corners=False, out=None, accumulate=False):
+    d = _bl_desc(B, C, Hi, Wi, Ho, Wo, in_nhwc, out_nhwc, align_corners)
+    if out is None:
+        out = torch.empty((B, Hi, Wi, C) if in_nhwc else (B, C, Hi, Wi), dtype=torch.float32, device=dy.device)
+    check(L().tf_bilinear_bwd_f32(byref(d), ptr(_c(dy)), ptr(out), int(accumulate), stream_of(dy)), "tf_bilinear_bwd_f32")
+    return out
+
+
+# ------------------------------------------------------------------------------------------ losses
+def ce_fwd(logits, target, class_w=None):
+    """logits (..., C) NHWC, target (...) int64 -> (loss 0-dim, dlogits unscaled, inv_wsum 1-elem)."""
+    C = logits.shape[-1]
+    rows = logits.numel() // C
+    dl = torch.empty_like(logits)
+    out = torch.empty(2, dtype=torch.float32, device=logits.device)
+    check(L().tf_ce_fwd_f32(ptr(_c(logits)), ptr(_c(target)), ptr(class_w), ctypes.c_int64(rows), C, ptr(dl), ptr(out), ptr(out[1:]),
+                            ptr(workspace(logits.device)), stream_of(logits)), "tf_ce_fwd_f32")
+    return out[0], dl, out[1:]
+
+
+def l1_fwd(pred, target, use_sigmoid=False):
+    n = pred.numel()
+    dp = torch.empty_like(pred)
+    out = torch.empty(1, dtype=torch.float32, device=pred.device)
+    check(L().tf_l1_fwd_f32(ptr(_c(pred)), ptr(_c(target)), ctypes.c_int64(n), int(use_sigmoid), ptr(dp), ptr(out), ptr(workspace(pred.device)),
+                            stream_of(pred)), "tf_l1_fwd_f32")
+    return out[0], dp
+
+
+def scale_dev_(x, a=None, b=None, mult=1.0):
+    check(L().tf_scale_dev_f32(ptr(x), ctypes.c_int64(x.numel()), ptr(a), ptr(b), ctypes.c_float(mult), stream_of(x)), "tf_scale_dev_f32")
+    return x
+
+
+def centernet_targets(label, fh, fw, ratio_w, ratio_h, nbins):
+    B, nbox, _ = label.shape
+    tgtf = torch.empty(B, fh, fw, 8, dtype=torch.float32, device=label.device)
+    tgti = torch.empty(B, fh, fw, 2, dtype=torch.int32, device=label.device)
+    cnt = torch.empty(B, dtype=torch.int32, device=label.device)
+    check(L().tf_centernet_targets_f32(ptr(_c(label)), B, nbox, fh, fw, ctypes.c_float(ratio_w), ctypes.c_float(ratio_h), nbins, ptr(tgtf), ptr(tgti),
+                                       ptr(cnt), stream_of(label)), "tf_centernet_targets_f32")
+    return tgtf, tgti, cnt
+
+
+def centernet_loss_fwd(pred, tgtf, tgti, cnt, nbins):
+    B, fh, fw, _ = pred.shape
+    losses = torch.empty(7, dtype=torch.float32, device=pred.device)
+    check(L().tf_centernet_loss_fwd_f32(ptr(_c(pred)), ptr(tgtf), ptr(tgti), ptr(cnt), B, fh, fw, nbins, ptr(losses), ptr(workspace(pred.device)),
+                                        stream_of(pred)), "tf_centernet_loss_fwd_f32")
+    return losses
+
+
+def centernet_loss_bwd(pred, tgtf, tgti, cnt, gup, nbins):
+    B, fh, fw, _ = pred.shape
+    dpred = torch.empty_like(pred)
+    check(L().tf_centernet_loss_bwd_f32(ptr(_c(pred)), ptr(tgtf), ptr(tgti), ptr(cnt), ptr(gup), B, fh, fw, nbins, ptr(dpred), stream_of(pred)),
+          "tf_centernet_loss_bwd_f32")
+    return dpred
+
+
+# ------------------------------------------------------------------------------------------ misc
+def relu_mask(dy, y, out=None):
+    if out is None:
+        out = torch.empty_like(dy)
+    check(L().tf_relu_mask_f32(ptr(_c(dy)), ptr(_c(y)), ptr(out), ctypes.c_int64(dy.numel()), stream_of(dy)), "tf_relu_mask_f32")
+    return out
+
+
+def axpby(a, b=None, alpha=1.0, beta=1.0, out=None):
+    if out is None:
+        out = torch.empty_like(a)
+    check(L().tf_axpby_f32(ptr(_c(a)), ptr(b), ptr(out), ctypes.c_float(alpha), ctypes.c_float(beta), ctypes.c_int64(a.numel()), stream_of(a)),
+          "tf_axpby_f32")
+    return out
+
+
+def dropout(x, seed, site, p, out=None):
+    if out is None:
+        out = torch.empty_like(x)
+    check(L().tf_dropout_f32(ptr(_c(x)), ptr(out), ctypes.c_int64(x.numel()), ptr(seed), ctypes.c_uint32(site), ctypes.c_float(p), stream_of(x)),
+          "tf_dropout_f32")
+    return out
+
+
+def gru_gates_fwd(gi, gh, h):
+    B, H = h.shape
+    hn = torch.empty_like(h)
+    rzn = torch.empty(B, 3 * H, dtype=torch.float32, device=h.device)
+    check(L().tf_gru_gates_fwd_f32(ptr(_c(gi)), ptr(_c(gh)), ptr(_c(h)), ptr(hn), ptr(rzn), B, H, stream_of(h)), "tf_gru_gates_fwd_f32")
+    return hn, rzn
+
+
+def gru_gates_bwd(dhn, rzn, gh, h):
+    B, H = h.shape
+    dgi = torch.empty_like(rzn)
+    dgh = torch.empty_like(rzn)
+    dh = torch.empty_like(h)
+    check(L().tf_gru_gates_bwd_f32(ptr(_c(dhn)), ptr(rzn), ptr(gh), ptr(h), ptr(dgi), ptr(dgh), ptr(dh), B, H, stream_of(h)), "tf_gru_gates_bwd_f32")
+    return dgi, dgh, dh
+
+
+def adamw_(p, g, m, v, state, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.01):
+    check(L().tf_adamw_f32(ptr(p), ptr(g), ptr(m), ptr(v), ctypes.c_int64(p.numel()), ptr(state), ctypes.c_float(beta1), ctypes.c_float(beta2),
+                           ctypes.c_float(eps), ctypes.c_float(weight_decay), stream_of(p)), "tf_adamw_f32")
+
+
+def lidar_hist(points, num_points=None):
+    """points (B, N, >=3) float32 -> (B, 2, 256, 256) float32 BEV histogram (data.py:446-470)."""
+    B, N, S = points.shape
+    out = torch.empty(B, 2, 256, 256, dtype=torch.float32, device=points.device)
+    check(L().tf_lidar_hist_f32(ptr(_c(points)), ptr(num_points), B, N, S, ptr(out), stream_of(points)), "tf_lidar_hist_f32")
+    return out
