@@ -97,7 +97,8 @@ int tf_se_scale_bwd_x_f32(const float* dy, const float* gate, const float* dmean
  * (B, T_total, C) token matrix, + pos_emb (+ per-sample vector): transfuser.py:150-151,346-357. */
 int tf_pool_tokens_fwd_f32(const float* x, int B, int H, int W, int C, int oh, int ow, const float* pos, const float* bvec, float* tok, int T_total,
                            int tok_off, void* stream);
-int tf_pool_tokens_bwd_f32(const float* dtok, int B, int H, int W, int C, int oh, int ow, int T_total, int tok_off, float* dx, int accumulate, void* stream);
+/* dx = (add ? add : 0) + pool^T(dtok): `add` carries the identity branch of x + up(gpt(x)) */
+int tf_pool_tokens_bwd_f32(const float* dtok, int B, int H, int W, int C, int oh, int ow, int T_total, int tok_off, float* dx, const float* add, void* stream);
 
 /* F.interpolate(mode='bilinear') with explicit element strides for input and output (any layout):
  * y = up(x) (+ add);  bwd is a gather (no atomics).  transfuser.py:103,154-157,241,243; model.py:760. */
@@ -138,9 +139,16 @@ int tf_axpby_f32(const float* a, const float* b, float* out, float alpha, float 
 /* nn.Dropout with a counter-based RNG keyed by (*seed_dev, site, index); calling it on dy with the
  * same key is the backward (transfuser.py:311,504-505,542). */
 int tf_dropout_f32(const float* x, float* y, int64_t n, const uint32_t* seed_dev, uint32_t site, float p, void* stream);
-/* nn.GRUCell gate math (model.py:601,631); the four matmuls go through tf_gemm_f32. */
-int tf_gru_gates_fwd_f32(const float* gi, const float* gh, const float* h, float* hnew, float* rzn, int B, int H, void* stream);
-int tf_gru_gates_bwd_f32(const float* dhnew, const float* rzn, const float* gh, const float* h, float* dgi, float* dgh, float* dh, int B, int H, void* stream);
+/* Waypoint decoder (model.py:611-646): pred_len x { GRUCell(4|2 -> 64), Linear(64,3), running sum } fused
+ * into one launch per direction.  cache: tf_gru_waypoints_cache_floats(B, pred_len) floats kept for the
+ * backward, which ACCUMULATES the parameter gradients and writes dz0 (grad of the join-MLP output). */
+long tf_gru_waypoints_cache_floats(int B, int pred_len);
+int tf_gru_waypoints_fwd_f32(const float* z0, const float* target_point, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                             const float* w_out, const float* b_out, int B, int hidden, int pred_len, int nin, float shift_x, float* wp, float* cache,
+                             void* stream);
+int tf_gru_waypoints_bwd_f32(const float* dwp, const float* cache, const float* w_ih, const float* w_hh, const float* w_out, int B, int hidden,
+                             int pred_len, int nin, float* dz0, float* dw_ih, float* dw_hh, float* db_ih, float* db_hh, float* dw_out, float* db_out,
+                             void* stream);
 /* torch.optim.AdamW (train.py:142) over a flat arena in one launch; state_dev = {step, lr} floats
  * on the device (step is advanced by the call, so a captured hipGraph replays correctly). */
 int tf_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, float* state_dev, float beta1, float beta2, float eps, float weight_decay,

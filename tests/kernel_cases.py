@@ -237,8 +237,9 @@ def check_pool_tokens(dev, B, H, W, C, oh, ow):
     close(tok[:, 3:3 + oh * ow], ref, what="pool tokens fwd")
     dtok = R(B, T, C, seed=2, dev=dev)
     (gx,) = torch.autograd.grad(ref, [x], dtok[:, 3:3 + oh * ow])
-    dx = ops.pool_tokens_bwd(dtok, (B, H, W, C), oh, ow, 3)
-    close(dx.permute(0, 3, 1, 2), gx, what="pool tokens bwd")
+    add = R(B, H, W, C, seed=9, dev=dev)
+    dx = ops.pool_tokens_bwd(dtok, (B, H, W, C), oh, ow, 3, add=add)
+    close(dx.permute(0, 3, 1, 2), gx + add.permute(0, 3, 1, 2), what="pool tokens bwd")
 
 
 BILINEAR_CASES = [(2, 12, 5, 22, 40, 176, False, False), (2, 8, 8, 8, 64, 64, False, False), (1, 6, 5, 22, 64, 176, False, False),
@@ -284,22 +285,31 @@ def check_l1(dev, n, sig):
 
 
 def check_gru(dev, B, H):
-    cell = torch.nn.GRUCell(4, H).to(dev)
-    x, h = R(B, 4, dev=dev), R(B, H, seed=1, dev=dev).requires_grad_(True)
-    hn = cell(x, h)
-    dhn = R(B, H, seed=2, dev=dev)
-    gi = (x @ cell.weight_ih.t() + cell.bias_ih).detach().requires_grad_(True)
-    gh = (h @ cell.weight_hh.t() + cell.bias_hh).detach().requires_grad_(True)
-    h2 = h.detach().clone().requires_grad_(True)
-    r = torch.sigmoid(gi[:, :H] + gh[:, :H]); z = torch.sigmoid(gi[:, H:2 * H] + gh[:, H:2 * H])
-    n = torch.tanh(gi[:, 2 * H:] + r * gh[:, 2 * H:])
-    ref = (1 - z) * n + z * h2
-    close(ref, hn, what="gru formula")
-    ggi, ggh, gh2 = torch.autograd.grad(ref, [gi, gh, h2], dhn)
-    hh, rzn = ops.gru_gates_fwd(gi.detach(), gh.detach(), h.detach())
-    close(hh, hn, what="gru fwd")
-    dgi, dgh, dh = ops.gru_gates_bwd(dhn, rzn, gh.detach(), h.detach())
-    close(dgi, ggi, what="gru dgi"); close(dgh, ggh, what="gru dgh"); close(dh, gh2, what="gru dh")
+    """Fused waypoint decoder vs the oracle's forward_gru (model.py:611-646) incl. parameter gradients."""
+    torch.manual_seed(0)
+    gru, outl = torch.nn.GRUCell(4, H).to(dev), torch.nn.Linear(H, 3).to(dev)
+    z, tp = R(B, H, dev=dev).requires_grad_(True), R(B, 2, seed=1, dev=dev) * 10
+    x = torch.zeros(B, 2, device=dev)
+    tpf = tp.clone(); tpf[:, 1] *= -1
+    h, wps = z, []
+    for _ in range(4):
+        h = gru(torch.cat([x, tpf], 1), h)
+        x = outl(h)[:, :2] + x
+        wps.append(x)
+    ref = torch.stack(wps, 1)
+    shift = torch.zeros_like(ref); shift[:, :, 0] = 1.3
+    ref = ref - shift
+    dwp = R(B, 4, 2, seed=2, dev=dev)
+    ps = list(gru.parameters()) + list(outl.parameters())
+    grads = torch.autograd.grad(ref, [z] + ps, dwp)
+    wp, cache = ops.gru_waypoints_fwd(z.detach(), tp, gru, outl, 4, 1.3)
+    close(wp, ref, what="gru wp fwd")
+    bufs = (torch.zeros_like(gru.weight_ih), torch.zeros_like(gru.weight_hh), torch.zeros_like(gru.bias_ih), torch.zeros_like(gru.bias_hh),
+            torch.zeros_like(outl.weight), torch.zeros_like(outl.bias))
+    dz = ops.gru_waypoints_bwd(dwp, cache, gru, outl, bufs, B, H, 4)
+    close(dz, grads[0], what="gru dz")
+    for name, mine, ref_g in zip(("w_ih", "w_hh", "b_ih", "b_hh", "w_out", "b_out"), bufs, grads[1:]):
+        close(mine, ref_g, what="gru d" + name)
 
 
 def check_misc(dev):

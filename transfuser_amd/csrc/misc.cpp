@@ -1,4 +1,4 @@
-// Small elementwise kernels, GRU gates, multi-tensor AdamW, LiDAR histogram.
+// Small elementwise kernels, multi-tensor AdamW, LiDAR histogram.
 #include "tf_common.h"
 #include "../../include/transfuser_hip.h"
 
@@ -28,43 +28,6 @@ __global__ void __launch_bounds__(256) dropout_kernel(const float* __restrict__ 
     const uint32_t sd = *seed;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
         y[i] = dropout_keep(sd, site, (uint32_t)i, thresh) ? x[i] * keep_scale : 0.f;
-}
-
-// nn.GRUCell gates (model.py:601,631; torch gate order r, z, n):
-//   r = s(gi_r + gh_r), z = s(gi_z + gh_z), n = tanh(gi_n + r * gh_n), h' = (1 - z) * n + z * h
-__global__ void __launch_bounds__(256) gru_gates_fwd_kernel(const float* __restrict__ gi, const float* __restrict__ gh, const float* __restrict__ h,
-                                                            float* __restrict__ hnew, float* __restrict__ rzn, int B, int H) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= B * H) return;
-    const int b = i / H, j = i - b * H;
-    const float* a = gi + (long)b * 3 * H;
-    const float* c = gh + (long)b * 3 * H;
-    const float r = 1.f / (1.f + expf(-(a[j] + c[j])));
-    const float z = 1.f / (1.f + expf(-(a[H + j] + c[H + j])));
-    const float n = tanhf(a[2 * H + j] + r * c[2 * H + j]);
-    hnew[i] = (1.f - z) * n + z * h[i];
-    float* s = rzn + (long)b * 3 * H;
-    s[j] = r; s[H + j] = z; s[2 * H + j] = n;
-}
-// dgi, dgh (B,3H), dh_direct (B,H) = dh' * z
-__global__ void __launch_bounds__(256) gru_gates_bwd_kernel(const float* __restrict__ dhn, const float* __restrict__ rzn, const float* __restrict__ gh,
-                                                            const float* __restrict__ h, float* __restrict__ dgi, float* __restrict__ dgh,
-                                                            float* __restrict__ dh, int B, int H) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= B * H) return;
-    const int b = i / H, j = i - b * H;
-    const float* s = rzn + (long)b * 3 * H;
-    const float r = s[j], z = s[H + j], n = s[2 * H + j];
-    const float g = dhn[i];
-    const float dn_pre = g * (1.f - z) * (1.f - n * n);
-    const float dz_pre = g * (h[i] - n) * z * (1.f - z);
-    const float ghn = gh[(long)b * 3 * H + 2 * H + j];
-    const float dr_pre = dn_pre * ghn * r * (1.f - r);
-    float* a = dgi + (long)b * 3 * H;
-    float* c = dgh + (long)b * 3 * H;
-    a[j] = dr_pre; a[H + j] = dz_pre; a[2 * H + j] = dn_pre;
-    c[j] = dr_pre; c[H + j] = dz_pre; c[2 * H + j] = dn_pre * r;
-    dh[i] = g * z;
 }
 
 // torch.optim.AdamW (train.py:142: lr 1e-4, betas (.9,.999), eps 1e-8, weight_decay 0.01, decoupled),
@@ -155,17 +118,6 @@ extern "C" int tf_dropout_f32(const float* x, float* y, int64_t n, const uint32_
     const uint32_t thresh = (uint32_t)((double)p * 4294967296.0);
     TF_LAUNCH(dropout_kernel, dim3(ew_blocks(n)), dim3(256), stream, x, y, (long)n, seed_dev, site, thresh, 1.f / (1.f - p));
     return launch_status("tf_dropout_f32");
-}
-extern "C" int tf_gru_gates_fwd_f32(const float* gi, const float* gh, const float* h, float* hnew, float* rzn, int B, int H, void* stream) {
-    TF_REQUIRE(gi && gh && h && hnew && rzn && B > 0 && H > 0, "tf_gru_gates_fwd_f32: bad arguments");
-    TF_LAUNCH(gru_gates_fwd_kernel, dim3(cdiv((long)B * H, 256)), dim3(256), stream, gi, gh, h, hnew, rzn, B, H);
-    return launch_status("tf_gru_gates_fwd_f32");
-}
-extern "C" int tf_gru_gates_bwd_f32(const float* dhnew, const float* rzn, const float* gh, const float* h, float* dgi, float* dgh, float* dh, int B, int H,
-                                    void* stream) {
-    TF_REQUIRE(dhnew && rzn && gh && h && dgi && dgh && dh && B > 0 && H > 0, "tf_gru_gates_bwd_f32: bad arguments");
-    TF_LAUNCH(gru_gates_bwd_kernel, dim3(cdiv((long)B * H, 256)), dim3(256), stream, dhnew, rzn, gh, h, dgi, dgh, dh, B, H);
-    return launch_status("tf_gru_gates_bwd_f32");
 }
 extern "C" int tf_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, float* state_dev, float beta1, float beta2, float eps,
                             float weight_decay, void* stream) {

@@ -53,7 +53,7 @@ __global__ void __launch_bounds__(256) pool_tokens_fwd_kernel(const float* __res
 
 template <int V>
 __global__ void __launch_bounds__(256) pool_tokens_bwd_kernel(const float* __restrict__ dtok, int B, int H, int W, int C, int oh, int ow,
-                                                              int T_total, int tok_off, float* __restrict__ dx, int accumulate) {
+                                                              int T_total, int tok_off, float* __restrict__ dx, const float* __restrict__ add) {
     const int cv = C / V;
     const long total = (long)B * H * W * cv;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(256) pool_tokens_bwd_kernel(const float* __res
         }
         float* o = dx + idx * V;
 #pragma unroll
-        for (int k = 0; k < V; ++k) o[k] = accumulate ? o[k] + acc[k] : acc[k];
+        for (int k = 0; k < V; ++k) o[k] = add ? add[idx * V + k] + acc[k] : acc[k];
     }
 }
 
@@ -193,10 +193,10 @@ extern "C" int tf_pool_tokens_fwd_f32(const float* x, int B, int H, int W, int C
 }
 
 extern "C" int tf_pool_tokens_bwd_f32(const float* dtok, int B, int H, int W, int C, int oh, int ow, int T_total, int tok_off, float* dx,
-                                      int accumulate, void* stream) {
+                                      const float* add, void* stream) {
     TF_REQUIRE(dtok && dx && B > 0 && H > 0 && W > 0 && C > 0 && oh > 0 && ow > 0 && tok_off + oh * ow <= T_total, "tf_pool_tokens_bwd_f32: bad arguments");
     const long n = (long)B * H * W * C;
-    TF_LAUNCH(pool_tokens_bwd_kernel<1>, dim3(ew_blocks(n)), dim3(256), stream, dtok, B, H, W, C, oh, ow, T_total, tok_off, dx, accumulate);
+    TF_LAUNCH(pool_tokens_bwd_kernel<1>, dim3(ew_blocks(n)), dim3(256), stream, dtok, B, H, W, C, oh, ow, T_total, tok_off, dx, add);
     return launch_status("tf_pool_tokens_bwd_f32");
 }
 

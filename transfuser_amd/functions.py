@@ -1,0 +1,459 @@
+"""Block-level ``torch.autograd.Function``s of the TransFuser training path.
+
+Each Function runs a whole reference sub-module (RegNetY bottleneck, a GPT fusion stage, a conv
+layer, a loss...) as a hand-ordered sequence of HIP launches and implements its backward the
+same way.  PyTorch only links the blocks (a few dozen autograd nodes per step), owns the memory
+and provides the stream; no ATen compute kernel is used inside a block.
+
+Parameter gradients are ACCUMULATED by the kernels straight into ``param.grad`` (views of the
+flat gradient arena when the model is driven by ``transfuser_amd.train.Engine``), so the
+Functions return ``None`` for parameter inputs: there is no per-parameter AccumulateGrad pass
+and the arena can be all-reduced / fed to the fused AdamW kernel as one buffer.
+"""
+import math
+
+import torch
+
+from . import ops
+
+
+def gbuf(p):
+    """Gradient accumulation buffer of a parameter (allocated zero-filled on first use)."""
+    if p.grad is None:
+        p.grad = torch.zeros_like(p)
+    return p.grad
+
+
+def w2d(w):
+    """(Cout, Cin, 1, 1) -> (Cout, Cin) view of a 1x1 conv weight (or its grad)."""
+    return w.view(w.shape[0], w.shape[1])
+
+
+def bias_grad(dy2d, b, mask2d=None):
+    ops.colsum(dy2d, 1, dy2d.shape[0], dy2d.shape[1], 1.0, mask=mask2d, out=gbuf(b).view(1, -1), accumulate=True)
+
+
+def _bn(x, bn, res=None, relu=False):
+    y, sm, si = ops.bn_fwd(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, res, relu, bn.training, bn.momentum, bn.eps)
+    return y, (sm, si)
+
+
+def _bn_bwd(dz, z, x, bn, st, want_dres=False):
+    return ops.bn_bwd(dz, z, x, bn.weight, st[0], st[1], gbuf(bn.weight), gbuf(bn.bias), want_dres)
+
+
+# ============================================================================================ stem
+class StemFn(torch.autograd.Function):
+    """conv3x3/s2 (no bias) + BatchNormAct2d on the NCHW model input (transfuser.py:136-143)."""
+
+    @staticmethod
+    def forward(ctx, s0, s1, stem, w, gamma, beta):
+        y = ops.stem_conv_fwd(s0, s1, w, stem.normalize)
+        z, st = _bn(y, stem.bn, relu=True)
+        ctx.saved = (s0, s1, stem, w, y, z, st)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        s0, s1, stem, w, y, z, st = ctx.saved
+        dy, _ = _bn_bwd(dz.contiguous(), z, y, stem.bn, st)
+        ops.stem_conv_wgrad(dy, s0, s1, gbuf(w), stem.normalize)
+        return (None,) * 6
+
+
+# ============================================================================================ RegNetY block
+class YBlockFn(torch.autograd.Function):
+    """timm Bottleneck: 1x1 -> BN/ReLU -> grouped 3x3 (stride) -> BN/ReLU -> SE ->
+    1x1 -> BN (+ shortcut / 1x1-s2 downsample BN) -> ReLU."""
+
+    @staticmethod
+    def forward(ctx, x, blk, *params):
+        B, H, W, Cin = x.shape
+        C = blk.out_chs
+        x2 = x.view(-1, Cin)
+        y1 = ops.linear_fwd(x2, w2d(blk.conv1.conv.weight)).view(B, H, W, C)
+        z1, st1 = _bn(y1, blk.conv1.bn, relu=True)
+        y2 = ops.conv_fwd(z1, blk.conv2.conv.weight, None, blk.stride, 1, blk.groups)
+        z2, st2 = _bn(y2, blk.conv2.bn, relu=True)
+        _, Ho, Wo, _ = y2.shape
+        s = ops.colsum(z2, B, Ho * Wo, C, 1.0 / (Ho * Wo))
+        g1 = ops.linear_fwd(s, w2d(blk.se.fc1.weight), blk.se.fc1.bias, relu=True)
+        gate = ops.linear_fwd(g1, w2d(blk.se.fc2.weight), blk.se.fc2.bias)
+        z2s = ops.se_scale_fwd(z2, gate)
+        y3 = ops.linear_fwd(z2s.view(-1, C), w2d(blk.conv3.conv.weight)).view(B, Ho, Wo, C)
+        yd = std = None
+        if blk.downsample is not None:
+            if blk.stride == 1:
+                yd = ops.linear_fwd(x2, w2d(blk.downsample.conv.weight)).view(B, H, W, C)
+            else:
+                yd = ops.conv_fwd(x, blk.downsample.conv.weight, None, blk.stride, 0, 1)
+            sc, std = _bn(yd, blk.downsample.bn, relu=False)
+        else:
+            sc = x
+        out, st3 = _bn(y3, blk.conv3.bn, res=sc, relu=True)
+        ctx.saved = (x, blk, y1, z1, st1, y2, z2, st2, s, g1, gate, z2s, y3, st3, yd, std, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, blk, y1, z1, st1, y2, z2, st2, s, g1, gate, z2s, y3, st3, yd, std, out = ctx.saved
+        B, H, W, Cin = x.shape
+        _, Ho, Wo, C = out.shape
+        x2 = x.view(-1, Cin)
+        dy3, dsc = _bn_bwd(dout.contiguous(), out, y3, blk.conv3.bn, st3, want_dres=True)
+        dy3_2 = dy3.view(-1, C)
+        w3 = blk.conv3.conv.weight
+        ops.linear_wgrad(dy3_2, z2s.view(-1, C), w2d(gbuf(w3)))
+        dz2s = ops.linear_dgrad(dy3_2, w2d(w3)).view(B, Ho, Wo, C)
+        # squeeze-excite
+        se = blk.se
+        dgate = ops.se_scale_bwd_gate(dz2s, z2, gate)
+        ops.linear_wgrad(dgate, g1, w2d(gbuf(se.fc2.weight)))
+        bias_grad(dgate, se.fc2.bias)
+        dg1 = ops.linear_dgrad(dgate, w2d(se.fc2.weight))
+        dg1 = ops.relu_mask(dg1, g1, out=dg1)
+        ops.linear_wgrad(dg1, s, w2d(gbuf(se.fc1.weight)))
+        bias_grad(dg1, se.fc1.bias)
+        ds = ops.linear_dgrad(dg1, w2d(se.fc1.weight))
+        dz2 = ops.se_scale_bwd_x(dz2s, gate, ds, z2.shape)
+        # grouped 3x3
+        dy2, _ = _bn_bwd(dz2, z2, y2, blk.conv2.bn, st2)
+        w2 = blk.conv2.conv.weight
+        ops.conv_wgrad(dy2, z1, gbuf(w2), blk.stride, 1, blk.groups)
+        dz1 = ops.conv_dgrad(dy2, w2, z1.shape, blk.stride, 1, blk.groups)
+        dy1, _ = _bn_bwd(dz1, z1, y1, blk.conv1.bn, st1)
+        dy1_2 = dy1.view(-1, C)
+        w1 = blk.conv1.conv.weight
+        ops.linear_wgrad(dy1_2, x2, w2d(gbuf(w1)))
+        if blk.downsample is None:
+            dx = ops.linear_dgrad(dy1_2, w2d(w1), res=dsc.view(-1, Cin))
+        else:
+            dx = ops.linear_dgrad(dy1_2, w2d(w1))
+            dyd, _ = _bn_bwd(dsc, None, yd, blk.downsample.bn, std)
+            wd = blk.downsample.conv.weight
+            if blk.stride == 1:
+                ops.linear_wgrad(dyd.view(-1, C), x2, w2d(gbuf(wd)))
+                ops.linear_dgrad(dyd.view(-1, C), w2d(wd), out=dx, accumulate=True)
+            else:
+                ops.conv_wgrad(dyd, x, gbuf(wd), blk.stride, 0, 1)
+                ops.conv_dgrad(dyd, wd, x.shape, blk.stride, 0, 1, out=dx.view(B, H, W, Cin), accumulate=True)
+        ctx.saved = None
+        return (dx.view(B, H, W, Cin), None) + (None,) * (len(ctx.needs_input_grad) - 2)
+
+
+# ============================================================================================ GPT fusion stage
+def _attn_fwd(qkv, B, T, C, nh):
+    """qkv (B*T, 3C) = [key | query | value] (transfuser.py:500-502 order). Returns probs (B*nh, T, Tp), y (B*T, C)."""
+    hs = C // nh
+    Tp = (T + 3) // 4 * 4
+    att = torch.empty(B * nh, T, Tp, dtype=torch.float32, device=qkv.device)
+    k, q, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+    sq, sp = (T * 3 * C, hs), (nh * T * Tp, T * Tp)
+    ops.gemm(q, k, att, T, T, hs, 3 * C, 3 * C, Tp, alpha=1.0 / math.sqrt(hs), batch=B * nh, inner=nh, sa=sq, sb=sq, sc=sp)
+    ops.softmax_fwd_(att, B * nh * T, T, Tp)
+    return att, Tp
+
+
+def _attn_ctx(att, qkv, B, T, C, nh, Tp):
+    hs = C // nh
+    y = torch.empty(B * T, C, dtype=torch.float32, device=qkv.device)
+    ops.gemm(att, qkv[:, 2 * C:], y, T, hs, T, Tp, 3 * C, C, b_trans=True, batch=B * nh, inner=nh, sa=(nh * T * Tp, T * Tp),
+             sb=(T * 3 * C, hs), sc=(T * C, hs))
+    return y
+
+
+class GPTStageFn(torch.autograd.Function):
+    """One fusion stage (transfuser.py:150-157 + GPT.forward :333-366): adaptive pools -> tokens + pos_emb
+    -> n_layer Blocks -> ln_f -> raw view (quirk Q1) -> bilinear up-sample -> residual add, for both branches."""
+
+    @staticmethod
+    def forward(ctx, x_img, x_lid, gpt, velocity, *params):
+        cfg = gpt.geom
+        B, Hi, Wi, C = x_img.shape
+        _, Hl, Wl, _ = x_lid.shape
+        n_img, n_lid = cfg.ih * cfg.iw, cfg.lh * cfg.lw
+        T = n_img + n_lid
+        nh = gpt.n_head
+        dev = x_img.device
+        tok = torch.empty(B, T, C, dtype=torch.float32, device=dev)
+        bvec = None
+        if gpt.use_velocity:
+            bvec = ops.linear_fwd(velocity, gpt.vel_emb.weight, gpt.vel_emb.bias)
+        ops.pool_tokens_fwd(x_img, cfg.ih, cfg.iw, gpt.pos_emb, tok, 0, bvec)
+        ops.pool_tokens_fwd(x_lid, cfg.lh, cfg.lw, gpt.pos_emb, tok, n_img, bvec)
+        drop = gpt.training and gpt.pdrop_any
+        x = tok.view(B * T, C)
+        if drop and gpt.embd_pdrop > 0:
+            x = ops.dropout(x, gpt.seed, gpt.site(0), gpt.embd_pdrop)
+        saved = []
+        for li, blk in enumerate(gpt.blocks):
+            h1, m1, r1 = ops.layernorm_fwd(x, blk.ln1.weight, blk.ln1.bias, blk.ln1.eps)
+            qkv = torch.empty(B * T, 3 * C, dtype=torch.float32, device=dev)
+            fw = blk.attn.fused()
+            if fw is not None:
+                ops.linear_fwd(h1, fw[0], fw[1], out=qkv)
+            else:
+                for j, lin in enumerate((blk.attn.key, blk.attn.query, blk.attn.value)):
+                    ops.linear_fwd(h1, lin.weight, lin.bias, out=qkv[:, j * C:(j + 1) * C])
+            att, Tp = _attn_fwd(qkv, B, T, C, nh)
+            att_d = att
+            if drop and gpt.attn_pdrop > 0:
+                att_d = ops.dropout(att, gpt.seed, gpt.site(4 * li + 1), gpt.attn_pdrop)
+            y_att = _attn_ctx(att_d, qkv, B, T, C, nh, Tp)
+            if drop and gpt.resid_pdrop > 0:
+                pr = ops.linear_fwd(y_att, blk.attn.proj.weight, blk.attn.proj.bias)
+                x_mid = ops.axpby(ops.dropout(pr, gpt.seed, gpt.site(4 * li + 2), gpt.resid_pdrop, out=pr), x)
+            else:
+                x_mid = ops.linear_fwd(y_att, blk.attn.proj.weight, blk.attn.proj.bias, res=x)
+            h2, m2, r2 = ops.layernorm_fwd(x_mid, blk.ln2.weight, blk.ln2.bias, blk.ln2.eps)
+            a1 = ops.linear_fwd(h2, blk.mlp[0].weight, blk.mlp[0].bias, relu=True)
+            if drop and gpt.resid_pdrop > 0:
+                f2 = ops.linear_fwd(a1, blk.mlp[2].weight, blk.mlp[2].bias)
+                x_out = ops.axpby(ops.dropout(f2, gpt.seed, gpt.site(4 * li + 3), gpt.resid_pdrop, out=f2), x_mid)
+            else:
+                x_out = ops.linear_fwd(a1, blk.mlp[2].weight, blk.mlp[2].bias, res=x_mid)
+            saved.append((x, h1, m1, r1, qkv, att, att_d, Tp, y_att, x_mid, h2, m2, r2, a1))
+            x = x_out
+        xf, mf, rf = ops.layernorm_fwd(x, gpt.ln_f.weight, gpt.ln_f.bias, gpt.ln_f.eps)
+        # Q1: token memory (hw, C) of each sample is re-read as (C, h, w); strides relative to the slice start
+        out_img = ops.bilinear_fwd(xf, B, C, cfg.ih, cfg.iw, Hi, Wi, add=x_img, in_strides=(T * C, cfg.ih * cfg.iw, cfg.iw, 1))
+        out_lid = ops.bilinear_fwd(xf[n_img:], B, C, cfg.lh, cfg.lw, Hl, Wl, add=x_lid, in_strides=(T * C, cfg.lh * cfg.lw, cfg.lw, 1))
+        ctx.saved = (gpt, x_img.shape, x_lid.shape, saved, x, mf, rf, drop, velocity)
+        return out_img, out_lid
+
+    @staticmethod
+    def backward(ctx, d_img, d_lid):
+        gpt, s_img, s_lid, saved, x_last, mf, rf, drop, velocity = ctx.saved
+        cfg = gpt.geom
+        B, Hi, Wi, C = s_img
+        _, Hl, Wl, _ = s_lid
+        n_img, n_lid = cfg.ih * cfg.iw, cfg.lh * cfg.lw
+        T = n_img + n_lid
+        nh, hs = gpt.n_head, C // gpt.n_head
+        d_img, d_lid = d_img.contiguous(), d_lid.contiguous()
+        dev = d_img.device
+        dxf = torch.empty(B * T, C, dtype=torch.float32, device=dev)
+        ops.bilinear_bwd(d_img, B, C, cfg.ih, cfg.iw, Hi, Wi, out=dxf, in_strides=(T * C, cfg.ih * cfg.iw, cfg.iw, 1), in_nhwc=False)
+        ops.bilinear_bwd(d_lid, B, C, cfg.lh, cfg.lw, Hl, Wl, out=dxf[n_img:], in_strides=(T * C, cfg.lh * cfg.lw, cfg.lw, 1), in_nhwc=False)
+        dx = ops.layernorm_bwd(dxf, x_last, gpt.ln_f.weight, mf, rf, gbuf(gpt.ln_f.weight), gbuf(gpt.ln_f.bias))
+        alpha = 1.0 / math.sqrt(hs)
+        for li in range(len(gpt.blocks) - 1, -1, -1):
+            blk = gpt.blocks[li]
+            x, h1, m1, r1, qkv, att, att_d, Tp, y_att, x_mid, h2, m2, r2, a1 = saved[li]
+            fc1, fc2, proj = blk.mlp[0], blk.mlp[2], blk.attn.proj
+            # ---- MLP: x_out = x_mid + drop(fc2(relu(fc1(ln2(x_mid)))))
+            dres = dx
+            if drop and gpt.resid_pdrop > 0:
+                dres = ops.dropout(dx, gpt.seed, gpt.site(4 * li + 3), gpt.resid_pdrop)
+            ops.linear_wgrad(dres, a1, gbuf(fc2.weight))
+            bias_grad(dres, fc2.bias)
+            da1 = ops.linear_dgrad(dres, fc2.weight)
+            ops.relu_mask(da1, a1, out=da1)
+            ops.linear_wgrad(da1, h2, gbuf(fc1.weight))
+            bias_grad(da1, fc1.bias)
+            dh2 = ops.linear_dgrad(da1, fc1.weight)
+            # dx_mid = dx + ln2_bwd(dh2): accumulate in place into dx
+            ops.layernorm_bwd(dh2, x_mid, blk.ln2.weight, m2, r2, gbuf(blk.ln2.weight), gbuf(blk.ln2.bias), dx=dx, accumulate=True)
+            # ---- attention: x_mid = x + drop(proj(att @ v))
+            dres = dx
+            if drop and gpt.resid_pdrop > 0:
+                dres = ops.dropout(dx, gpt.seed, gpt.site(4 * li + 2), gpt.resid_pdrop)
+            ops.linear_wgrad(dres, y_att, gbuf(proj.weight))
+            bias_grad(dres, proj.bias)
+            dy = ops.linear_dgrad(dres, proj.weight)
+            dqkv = torch.empty_like(qkv)
+            datt = torch.empty_like(att)
+            k, q, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+            sq, sp, sy = (T * 3 * C, hs), (nh * T * Tp, T * Tp), (T * C, hs)
+            ops.gemm(dy, v, datt, T, T, hs, C, 3 * C, Tp, batch=B * nh, inner=nh, sa=sy, sb=sq, sc=sp)                       # dP = dY V^T
+            ops.gemm(att_d, dy, dqkv[:, 2 * C:], T, hs, T, Tp, C, 3 * C, a_trans=True, b_trans=True, batch=B * nh, inner=nh,
+                     sa=sp, sb=sy, sc=sq)                                                                                     # dV = P^T dY
+            if drop and gpt.attn_pdrop > 0:
+                ops.dropout(datt, gpt.seed, gpt.site(4 * li + 1), gpt.attn_pdrop, out=datt)
+            ops.softmax_bwd_(att, datt, B * nh * T, T, Tp)
+            ops.gemm(datt, k, dqkv[:, C:2 * C], T, hs, T, Tp, 3 * C, 3 * C, b_trans=True, alpha=alpha, batch=B * nh, inner=nh,
+                     sa=sp, sb=sq, sc=sq)                                                                                     # dQ = dS K
+            ops.gemm(datt, q, dqkv[:, :C], T, hs, T, Tp, 3 * C, 3 * C, a_trans=True, b_trans=True, alpha=alpha, batch=B * nh, inner=nh,
+                     sa=sp, sb=sq, sc=sq)                                                                                     # dK = dS^T Q
+            fw = blk.attn.fused()
+            if fw is not None:
+                ops.linear_wgrad(dqkv, h1, fw[2])
+                ops.colsum(dqkv, 1, B * T, 3 * C, 1.0, out=fw[3].view(1, -1), accumulate=True)
+                dh1 = ops.linear_dgrad(dqkv, fw[0])
+            else:
+                dh1 = None
+                for j, lin in enumerate((blk.attn.key, blk.attn.query, blk.attn.value)):
+                    dj = dqkv[:, j * C:(j + 1) * C]
+                    ops.linear_wgrad(dj, h1, gbuf(lin.weight))
+                    dh1 = ops.linear_dgrad(dj, lin.weight, out=dh1, accumulate=dh1 is not None)
+                b3 = ops.colsum(dqkv, 1, B * T, 3 * C, 1.0)
+                for j, lin in enumerate((blk.attn.key, blk.attn.query, blk.attn.value)):
+                    ops.axpby(gbuf(lin.bias), b3[0, j * C:(j + 1) * C], 1.0, 1.0, out=gbuf(lin.bias))
+            ops.layernorm_bwd(dh1, x, blk.ln1.weight, m1, r1, gbuf(blk.ln1.weight), gbuf(blk.ln1.bias), dx=dx, accumulate=True)
+        if drop and gpt.embd_pdrop > 0:
+            ops.dropout(dx, gpt.seed, gpt.site(0), gpt.embd_pdrop, out=dx)
+        dtok = dx.view(B, T, C)
+        ops.colsum(dtok, 1, B, T * C, 1.0, out=gbuf(gpt.pos_emb).view(1, -1), accumulate=True)
+        if gpt.use_velocity:
+            db = ops.colsum(dtok, B, T, C, 1.0)
+            ops.linear_wgrad(db, velocity, gbuf(gpt.vel_emb.weight))
+            bias_grad(db, gpt.vel_emb.bias)
+        dx_img = ops.pool_tokens_bwd(dtok, s_img, cfg.ih, cfg.iw, 0, add=d_img)
+        dx_lid = ops.pool_tokens_bwd(dtok, s_lid, cfg.lh, cfg.lw, n_img, add=d_lid)
+        ctx.saved = None
+        return (dx_img, dx_lid, None, None) + (None,) * (len(ctx.needs_input_grad) - 4)
+
+
+# ============================================================================================ generic conv / resample
+class ConvFn(torch.autograd.Function):
+    """conv (1x1 or 3x3, stride 1, bias) (+ReLU) on NHWC: decoders, heads, FPN, channel reducers."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, relu):
+        B, H, W, Cin = x.shape
+        if w.shape[2] == 1:
+            y = ops.linear_fwd(x.view(-1, Cin), w2d(w), b, relu=relu).view(B, H, W, w.shape[0])
+        else:
+            y = ops.conv_fwd(x, w, b, 1, 1, 1, relu)
+        ctx.saved = (x, w, b, relu, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, b, relu, y = ctx.saved
+        B, H, W, Cin = x.shape
+        Cout = w.shape[0]
+        dy = dy.contiguous()
+        g = ops.relu_mask(dy, y) if relu else dy
+        if b is not None:
+            bias_grad(g.view(-1, Cout), b)
+        dx = None
+        if w.shape[2] == 1:
+            ops.linear_wgrad(g.view(-1, Cout), x.view(-1, Cin), w2d(gbuf(w)))
+            if ctx.needs_input_grad[0]:
+                dx = ops.linear_dgrad(g.view(-1, Cout), w2d(w)).view(B, H, W, Cin)
+        else:
+            ops.conv_wgrad(g, x, gbuf(w), 1, 1, 1)
+            if ctx.needs_input_grad[0]:
+                dx = ops.conv_dgrad(g, w, x.shape, 1, 1, 1)
+        ctx.saved = None
+        return dx, None, None, None
+
+
+class UpsampleFn(torch.autograd.Function):
+    """bilinear NHWC -> NHWC (nn.Upsample x2 / F.interpolate scale_factor / size, either align mode)."""
+
+    @staticmethod
+    def forward(ctx, x, Ho, Wo, align_corners):
+        B, H, W, C = x.shape
+        ctx.meta = (B, C, H, W, Ho, Wo, align_corners)
+        return ops.bilinear_fwd(x, B, C, H, W, Ho, Wo, align_corners=align_corners)
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, C, H, W, Ho, Wo, align = ctx.meta
+        return ops.bilinear_bwd(dy.contiguous(), B, C, H, W, Ho, Wo, align_corners=align), None, None, None
+
+
+class GlobalPoolAddFn(torch.autograd.Function):
+    """fused_features = flatten(gap(img)) + flatten(gap(lidar)) (transfuser.py:203-208)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.shapes = (a.shape, b.shape)
+        pa = ops.colsum(a, a.shape[0], a.shape[1] * a.shape[2], a.shape[3], 1.0 / (a.shape[1] * a.shape[2]))
+        return ops.colsum(b, b.shape[0], b.shape[1] * b.shape[2], b.shape[3], 1.0 / (b.shape[1] * b.shape[2]), out=pa, accumulate=True)
+
+    @staticmethod
+    def backward(ctx, d):
+        sa, sb = ctx.shapes
+        d = d.contiguous()
+        return ops.se_scale_bwd_x(None, None, d, sa), ops.se_scale_bwd_x(None, None, d, sb)
+
+
+# ============================================================================================ losses
+class CrossEntropyFn(torch.autograd.Function):
+    """F.cross_entropy over NHWC logits (model.py:763,783)."""
+
+    @staticmethod
+    def forward(ctx, logits, target, class_w):
+        loss, dl, inv = ops.ce_fwd(logits, target, class_w)
+        ctx.saved = (dl, inv)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        dl, inv = ctx.saved
+        ctx.saved = None
+        return ops.scale_dev_(dl, g.contiguous(), inv, 1.0), None, None
+
+
+class L1Fn(torch.autograd.Function):
+    """mean |f(pred) - target| (model.py:765; :784 with the DepthDecoder sigmoid folded in)."""
+
+    @staticmethod
+    def forward(ctx, pred, target, use_sigmoid):
+        loss, dp = ops.l1_fwd(pred, target, use_sigmoid)
+        ctx.saved = dp
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        dp = ctx.saved
+        ctx.saved = None
+        return ops.scale_dev_(dp, g.contiguous(), None, 1.0), None, None
+
+
+class CenterNetLossFn(torch.autograd.Function):
+    """get_targets + the 7 CenterNet losses (model.py:150-248,285-374) -> (7,) tensor."""
+
+    @staticmethod
+    def forward(ctx, pred, label, nbins, ratio_w, ratio_h):
+        B, fh, fw, _ = pred.shape
+        tgtf, tgti, cnt = ops.centernet_targets(label, fh, fw, ratio_w, ratio_h, nbins)
+        ctx.saved = (pred, tgtf, tgti, cnt, nbins)
+        return ops.centernet_loss_fwd(pred, tgtf, tgti, cnt, nbins)
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, tgtf, tgti, cnt, nbins = ctx.saved
+        ctx.saved = None
+        return ops.centernet_loss_bwd(pred, tgtf, tgti, cnt, g.contiguous(), nbins), None, None, None, None
+
+
+# ============================================================================================ waypoint head
+class WaypointFn(torch.autograd.Function):
+    """join MLP 512->256->128->64 (+ReLU) on the MFMA engine, then the fused auto-regressive GRU decoder
+    (model.py:592-605,611-646) -> pred_wp (B, pred_len, 2)."""
+
+    @staticmethod
+    def forward(ctx, fused, target_point, head, *params):
+        j0, j1, j2 = head.join[0], head.join[2], head.join[4]
+        a0 = ops.linear_fwd(fused, j0.weight, j0.bias, relu=True)
+        a1 = ops.linear_fwd(a0, j1.weight, j1.bias, relu=True)
+        z = ops.linear_fwd(a1, j2.weight, j2.bias, relu=True)
+        wp, cache = ops.gru_waypoints_fwd(z, target_point.contiguous(), head.decoder, head.output, head.pred_len, float(head.config.lidar_pos[0]))
+        ctx.saved = (fused, head, a0, a1, z, cache)
+        return wp
+
+    @staticmethod
+    def backward(ctx, dwp):
+        fused, head, a0, a1, z, cache = ctx.saved
+        gru, outl = head.decoder, head.output
+        j0, j1, j2 = head.join[0], head.join[2], head.join[4]
+        grads = (gbuf(gru.weight_ih), gbuf(gru.weight_hh), gbuf(gru.bias_ih), gbuf(gru.bias_hh), gbuf(outl.weight), gbuf(outl.bias))
+        dz = ops.gru_waypoints_bwd(dwp.contiguous(), cache, gru, outl, grads, z.shape[0], z.shape[1], head.pred_len)
+        ops.relu_mask(dz, z, out=dz)
+        ops.linear_wgrad(dz, a1, gbuf(j2.weight))
+        bias_grad(dz, j2.bias)
+        da1 = ops.linear_dgrad(dz, j2.weight)
+        ops.relu_mask(da1, a1, out=da1)
+        ops.linear_wgrad(da1, a0, gbuf(j1.weight))
+        bias_grad(da1, j1.bias)
+        da0 = ops.linear_dgrad(da1, j1.weight)
+        ops.relu_mask(da0, a0, out=da0)
+        ops.linear_wgrad(da0, fused, gbuf(j0.weight))
+        bias_grad(da0, j0.bias)
+        dfused = ops.linear_dgrad(da0, j0.weight)
+        ctx.saved = None
+        return (dfused, None, None) + (None,) * (len(ctx.needs_input_grad) - 3)

@@ -231,11 +231,11 @@ def pool_tokens_fwd(x, oh, ow, pos, tok, tok_off, bvec=None):
     return tok
 
 
-def pool_tokens_bwd(dtok, shape, oh, ow, tok_off, out=None, accumulate=False):
+def pool_tokens_bwd(dtok, shape, oh, ow, tok_off, add=None):
+    """dx = add + pool^T(dtok)."""
     B, H, W, C = shape
-    if out is None:
-        out = torch.empty(shape, dtype=torch.float32, device=dtok.device)
-    check(L().tf_pool_tokens_bwd_f32(ptr(_c(dtok)), B, H, W, C, oh, ow, dtok.shape[1], tok_off, ptr(out), int(accumulate), stream_of(dtok)),
+    out = torch.empty(shape, dtype=torch.float32, device=dtok.device)
+    check(L().tf_pool_tokens_bwd_f32(ptr(_c(dtok)), B, H, W, C, oh, ow, dtok.shape[1], tok_off, ptr(out), ptr(add), stream_of(dtok)),
           "tf_pool_tokens_bwd_f32")
     return out
 
@@ -245,23 +245,24 @@ class BilinearDesc(ctypes.Structure):
                [(n, ctypes.c_int64) for n in ("sb_i", "sc_i", "sh_i", "sw_i", "sb_o", "sc_o", "sh_o", "sw_o")] + [("align_corners", ctypes.c_int)]
 
 
-def _bl_desc(B, C, Hi, Wi, Ho, Wo, in_nhwc, out_nhwc, align):
-    si = (Hi * Wi * C, 1, Wi * C, C) if in_nhwc else (C * Hi * Wi, Hi * Wi, Wi, 1)
+def _bl_desc(B, C, Hi, Wi, Ho, Wo, in_nhwc, out_nhwc, align, in_strides=None):
+    si = in_strides or ((Hi * Wi * C, 1, Wi * C, C) if in_nhwc else (C * Hi * Wi, Hi * Wi, Wi, 1))
     so = (Ho * Wo * C, 1, Wo * C, C) if out_nhwc else (C * Ho * Wo, Ho * Wo, Wo, 1)
     return BilinearDesc(B, C, Hi, Wi, Ho, Wo, *si, *so, int(align))
 
 
-def bilinear_fwd(x, B, C, Hi, Wi, Ho, Wo, in_nhwc=True, out_nhwc=True, align_corners=False, add=None, out=None):
-    """x holds B*C*Hi*Wi floats in NHWC or NCHW order; returns (B,Ho,Wo,C) [NHWC] or (B,C,Ho,Wo)."""
-    d = _bl_desc(B, C, Hi, Wi, Ho, Wo, in_nhwc, out_nhwc, align_corners)
+def bilinear_fwd(x, B, C, Hi, Wi, Ho, Wo, in_nhwc=True, out_nhwc=True, align_corners=False, add=None, out=None, in_strides=None):
+    """Up-sample x to (Ho, Wo).  x is NHWC / NCHW, or any layout described by ``in_strides`` =
+    element strides (batch, channel, row, col) relative to x.data_ptr().  Returns NHWC or NCHW."""
+    d = _bl_desc(B, C, Hi, Wi, Ho, Wo, in_nhwc, out_nhwc, align_corners, in_strides)
     if out is None:
         out = torch.empty((B, Ho, Wo, C) if out_nhwc else (B, C, Ho, Wo), dtype=torch.float32, device=x.device)
-    check(L().tf_bilinear_fwd_f32(byref(d), ptr(_c(x)), ptr(out), ptr(add), stream_of(x)), "tf_bilinear_fwd_f32")
+    check(L().tf_bilinear_fwd_f32(byref(d), ptr(x), ptr(out), ptr(add), stream_of(x)), "tf_bilinear_fwd_f32")
     return out
 
 
-def bilinear_bwd(dy, B, C, Hi, Wi, Ho, Wo, in_nhwc=True, out_nhwc=True, align_corners=False, out=None, accumulate=False):
-    d = _bl_desc(B, C, Hi, Wi, Ho, Wo, in_nhwc, out_nhwc, align_corners)
+def bilinear_bwd(dy, B, C, Hi, Wi, Ho, Wo, in_nhwc=True, out_nhwc=True, align_corners=False, out=None, accumulate=False, in_strides=None):
+    d = _bl_desc(B, C, Hi, Wi, Ho, Wo, in_nhwc, out_nhwc, align_corners, in_strides)
     if out is None:
         out = torch.empty((B, Hi, Wi, C) if in_nhwc else (B, C, Hi, Wi), dtype=torch.float32, device=dy.device)
     check(L().tf_bilinear_bwd_f32(byref(d), ptr(_c(dy)), ptr(out), int(accumulate), stream_of(dy)), "tf_bilinear_bwd_f32")
@@ -344,21 +345,24 @@ def dropout(x, seed, site, p, out=None):
     return out
 
 
-def gru_gates_fwd(gi, gh, h):
-    B, H = h.shape
-    hn = torch.empty_like(h)
-    rzn = torch.empty(B, 3 * H, dtype=torch.float32, device=h.device)
-    check(L().tf_gru_gates_fwd_f32(ptr(_c(gi)), ptr(_c(gh)), ptr(_c(h)), ptr(hn), ptr(rzn), B, H, stream_of(h)), "tf_gru_gates_fwd_f32")
-    return hn, rzn
+def gru_waypoints_fwd(z0, target_point, gru, outl, pred_len, shift_x):
+    B, H = z0.shape
+    nin = gru.weight_ih.shape[1]
+    L().tf_gru_waypoints_cache_floats.restype = ctypes.c_long
+    cache = torch.empty(L().tf_gru_waypoints_cache_floats(B, pred_len), dtype=torch.float32, device=z0.device)
+    wp = torch.empty(B, pred_len, 2, dtype=torch.float32, device=z0.device)
+    check(L().tf_gru_waypoints_fwd_f32(ptr(_c(z0)), ptr(target_point), ptr(gru.weight_ih), ptr(gru.weight_hh), ptr(gru.bias_ih), ptr(gru.bias_hh),
+                                       ptr(outl.weight), ptr(outl.bias), B, H, pred_len, nin, ctypes.c_float(shift_x), ptr(wp), ptr(cache),
+                                       stream_of(z0)), "tf_gru_waypoints_fwd_f32")
+    return wp, cache
 
 
-def gru_gates_bwd(dhn, rzn, gh, h):
-    B, H = h.shape
-    dgi = torch.empty_like(rzn)
-    dgh = torch.empty_like(rzn)
-    dh = torch.empty_like(h)
-    check(L().tf_gru_gates_bwd_f32(ptr(_c(dhn)), ptr(rzn), ptr(gh), ptr(h), ptr(dgi), ptr(dgh), ptr(dh), B, H, stream_of(h)), "tf_gru_gates_bwd_f32")
-    return dgi, dgh, dh
+def gru_waypoints_bwd(dwp, cache, gru, outl, grads, B, H, pred_len):
+    """grads = (dw_ih, dw_hh, db_ih, db_hh, dw_out, db_out) accumulation buffers; returns dz0."""
+    dz0 = torch.empty(B, H, dtype=torch.float32, device=dwp.device)
+    check(L().tf_gru_waypoints_bwd_f32(ptr(_c(dwp)), ptr(cache), ptr(gru.weight_ih), ptr(gru.weight_hh), ptr(outl.weight), B, H, pred_len,
+                                       gru.weight_ih.shape[1], ptr(dz0), *[ptr(g) for g in grads], stream_of(dwp)), "tf_gru_waypoints_bwd_f32")
+    return dz0
 
 
 def adamw_(p, g, m, v, state, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.01):
