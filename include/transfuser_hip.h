@@ -135,6 +135,7 @@ int tf_centernet_loss_bwd_f32(const float* pred, const float* tgtf, const int32_
 
 /* ---- elementwise / recurrent / optimiser / data ----------------------------------------------- */
 int tf_relu_mask_f32(const float* dy, const float* y, float* out, int64_t n, void* stream);
+int tf_sigmoid_f32(const float* x, float* y, int64_t n, void* stream);
 int tf_axpby_f32(const float* a, const float* b, float* out, float alpha, float beta, int64_t n, void* stream);
 /* nn.Dropout with a counter-based RNG keyed by (*seed_dev, site, index); calling it on dy with the
  * same key is the backward (transfuser.py:311,504-505,542). */

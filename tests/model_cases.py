@@ -1,0 +1,123 @@
+"""Whole-model parity helpers: product LidarCenterNet (HIP kernels) vs oracle.model_cpu on the same
+seeded batch and the same weights.  Used by tests/test_model_emu.py (tiny trunk, emulator) and
+tests/test_model_gpu.py (tiny + real regnety_032 on the MI355X)."""
+import copy
+import math
+
+import numpy as np
+import torch
+
+from oracle import model_cpu, hist, regnet as oracle_regnet
+from transfuser_amd import regnet as prod_regnet
+from transfuser_amd.config import GlobalConfig
+from transfuser_amd.model import LidarCenterNet
+
+TINY = dict(widths=[24, 48, 72, 96], depths=[1, 2, 1, 1], group_w=24, se_ratio=0.25)
+prod_regnet.register_arch("regnety_tiny", **TINY)
+
+
+def tiny_config(n_layer=2, lidar_res=64, dropout=0.0, use_velocity=False):
+    cfg = GlobalConfig()
+    cfg.n_layer = n_layer
+    cfg.use_target_point_image = True
+    cfg.lidar_resolution_width = cfg.lidar_resolution_height = lidar_res
+    cfg.bev_resolution_width = cfg.bev_resolution_height = 40
+    cfg.embd_pdrop = cfg.attn_pdrop = cfg.resid_pdrop = dropout
+    return cfg
+
+
+def full_config(dropout=0.0):
+    cfg = GlobalConfig()
+    cfg.n_layer = 4
+    cfg.use_target_point_image = True
+    cfg.embd_pdrop = cfg.attn_pdrop = cfg.resid_pdrop = dropout
+    return cfg
+
+
+def small_batch(B, H, W, lidar_res, bev_res, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    rng = np.random.default_rng(seed)
+    label = torch.zeros(B, 20, 7)
+    for b in range(B):
+        k = int(rng.integers(1, 6))
+        label[b, :k, 0:2] = torch.from_numpy(rng.uniform(2, lidar_res - 2, (k, 2))).float()
+        label[b, :k, 2:4] = torch.from_numpy(rng.uniform(lidar_res / 32, lidar_res / 6, (k, 2))).float()
+        label[b, :k, 4] = torch.from_numpy(rng.uniform(-math.pi, math.pi, k)).float()
+        label[b, :k, 5] = torch.from_numpy(rng.uniform(0, 8, k)).float()
+        label[b, :k, 6] = torch.from_numpy(rng.integers(0, 2, k)).float()
+    lidar = (torch.randint(0, 6, (B, 2, lidar_res, lidar_res), generator=g).float() / 5) * (torch.rand(B, 2, lidar_res, lidar_res, generator=g) < 0.2)
+    return dict(rgb=torch.randint(0, 256, (B, 3, H, W), generator=g).float(), lidar=lidar,
+                target_point_image=(torch.rand(B, 1, lidar_res, lidar_res, generator=g) < 0.02).float(),
+                ego_vel=torch.rand(B, 1, generator=g) * 8, target_point=torch.rand(B, 2, generator=g) * 40 - 10,
+                ego_waypoint=torch.rand(B, 4, 2, generator=g) * 14 - 2, bev=torch.randint(0, 3, (B, bev_res, bev_res), generator=g),
+                label=label, depth=torch.rand(B, H, W, generator=g), semantic=torch.randint(0, 7, (B, H, W), generator=g))
+
+
+def randomize(model, seed=1):
+    """Make every path carry signal: non-zero last-BN gammas, random pos_emb / biases, non-trivial running stats."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("bn.weight") or n.endswith("bn1.weight"):
+                p.copy_(torch.rand(p.shape, generator=g) * 0.5 + 0.75)
+            elif "pos_emb" in n:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.05)
+            elif n.endswith(".bias") and p.dim() == 1:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.05)
+
+
+def build_pair(cfg, arch, dev, use_velocity=False, seed=0):
+    """Product model on ``dev`` + oracle on CPU with IDENTICAL weights (strict state_dict load = key parity)."""
+    torch.manual_seed(seed)
+    prod = LidarCenterNet(cfg, dev, 'transFuser', arch, arch, use_velocity=use_velocity)
+    randomize(prod)
+    if arch == "regnety_tiny":
+        make_net = lambda: oracle_regnet.RegNet(TINY["widths"], TINY["depths"], TINY["group_w"], TINY["se_ratio"])
+    else:
+        make_net = oracle_regnet.regnety_032
+    ref = model_cpu.LidarCenterNet(cfg, 'cpu', 'transFuser', use_velocity=use_velocity, make_net=make_net)
+    sd = {k: v.detach().cpu().contiguous() for k, v in prod.state_dict().items()}
+    missing = ref.load_state_dict(sd, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return prod, ref
+
+
+def run_pair(prod, ref, cfg, batch, dev):
+    prod.train(); ref.train()
+    call = lambda m, b: m(b['rgb'], b['lidar'], ego_waypoint=b['ego_waypoint'], target_point=b['target_point'],
+                          target_point_image=b['target_point_image'], ego_vel=b['ego_vel'].reshape(-1, 1), bev=b['bev'], label=b['label'],
+                          depth=b['depth'], semantic=b['semantic'])
+    bd = {k: v.to(dev) for k, v in batch.items()}
+    lp = call(prod, bd)
+    lr = call(ref, batch)
+    w = dict(zip(cfg.detailed_losses, [1.0, 1.0, 1.0, 1.0, 0.2, 0.2, 0.2, 0.2, 0.2, 0.3, 0.4]))  # non-zero so every head is exercised
+    tot_p = sum(w[k] * v for k, v in lp.items())
+    tot_r = sum(w[k] * v for k, v in lr.items())
+    for p in prod.parameters():
+        p.grad = None
+    tot_p.backward()
+    tot_r.backward()
+    return lp, lr
+
+
+def compare(prod, ref, lp, lr, loss_tol=1e-3, grad_tol=2e-3, verbose=False):
+    worst = []
+    for k in lr:
+        a, b = float(lp[k]), float(lr[k])
+        assert abs(a - b) <= loss_tol * max(1.0, abs(b)), "loss %s: %g vs %g" % (k, a, b)
+    ref_params = dict(ref.named_parameters())
+    for n, p in prod.named_parameters():
+        gr = ref_params[n].grad
+        assert p.grad is not None, "no grad for " + n
+        gp = p.grad.detach().cpu()
+        if gr is None:
+            gr = torch.zeros_like(gp)
+        err = (gp - gr).abs().max().item()
+        scale = max(gr.abs().max().item(), 1e-3)
+        worst.append((err / scale, n, err, scale))
+    worst.sort(reverse=True)
+    if verbose:
+        for r in worst[:8]:
+            print("  grad rel %.2e  %s (abs %.2e, scale %.2e)" % r)
+    assert worst[0][0] <= grad_tol, "gradient mismatch: %s rel %.3e" % (worst[0][1], worst[0][0])
+    return worst

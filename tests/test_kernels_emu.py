@@ -54,7 +54,7 @@ def test_colsum_and_se():
     kc.check_se("cpu", 3, 5, 6, 72)
 
 
-@pytest.mark.parametrize("case", [(2, 40, 44, 24, 5, 22), (2, 16, 16, 8, 8, 8), (1, 13, 9, 4, 5, 4), (2, 5, 22, 12, 5, 22)], ids=str)
+@pytest.mark.parametrize("case", [(2, 40, 44, 24, 5, 22), (2, 16, 16, 8, 8, 8), (1, 13, 9, 4, 5, 4), (2, 5, 22, 12, 5, 22), (2, 3, 7, 8, 5, 22), (1, 1, 2, 4, 5, 22)], ids=str)
 def test_pool_tokens(case):
     kc.check_pool_tokens("cpu", *case)
 

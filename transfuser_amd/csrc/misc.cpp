@@ -22,6 +22,9 @@ __global__ void __launch_bounds__(256) axpby_kernel(const float* __restrict__ a,
                                                     float beta, long n) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = alpha * a[i] + (b ? beta * b[i] : 0.f);
 }
+__global__ void __launch_bounds__(256) sigmoid_kernel(const float* __restrict__ x, float* __restrict__ y, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] = 1.f / (1.f + expf(-x[i]));
+}
 // dropout with our counter-based RNG: y = keep ? x / (1-p) : 0 ; same call regenerates the mask in backward
 __global__ void __launch_bounds__(256) dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long n, const uint32_t* __restrict__ seed,
                                                       uint32_t site, uint32_t thresh, float keep_scale) {
@@ -111,6 +114,12 @@ extern "C" int tf_axpby_f32(const float* a, const float* b, float* out, float al
     if (n == 0) return 0;
     TF_LAUNCH(axpby_kernel, dim3(ew_blocks(n)), dim3(256), stream, a, b, out, alpha, beta, (long)n);
     return launch_status("tf_axpby_f32");
+}
+extern "C" int tf_sigmoid_f32(const float* x, float* y, int64_t n, void* stream) {
+    TF_REQUIRE(x && y && n >= 0, "tf_sigmoid_f32: bad arguments");
+    if (n == 0) return 0;
+    TF_LAUNCH(sigmoid_kernel, dim3(ew_blocks(n)), dim3(256), stream, x, y, (long)n);
+    return launch_status("tf_sigmoid_f32");
 }
 extern "C" int tf_dropout_f32(const float* x, float* y, int64_t n, const uint32_t* seed_dev, uint32_t site, float p, void* stream) {
     TF_REQUIRE(x && y && seed_dev && n >= 0 && p >= 0.f && p < 1.f, "tf_dropout_f32: bad arguments");

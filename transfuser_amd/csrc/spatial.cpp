@@ -65,11 +65,13 @@ __global__ void __launch_bounds__(256) pool_tokens_bwd_kernel(const float* __res
         float acc[V];
 #pragma unroll
         for (int k = 0; k < V; ++k) acc[k] = 0.f;
-        const int ic = (int)(((long)h * oh) / H), jc = (int)(((long)w * ow) / W);
-        for (int i = (ic > 0 ? ic - 1 : 0); i <= ic + 1 && i < oh; ++i) {
+        // output windows containing (h, w): i in [floor(h*oh/H), ceil((h+1)*oh/H) - 1] (several when oh > H)
+        const int i_lo = (int)(((long)h * oh) / H), i_hi = (int)((((long)(h + 1) * oh + H - 1) / H) - 1);
+        const int j_lo = (int)(((long)w * ow) / W), j_hi = (int)((((long)(w + 1) * ow + W - 1) / W) - 1);
+        for (int i = (i_lo > 0 ? i_lo - 1 : 0); i <= i_hi + 1 && i < oh; ++i) {
             const int h0 = ap_start(i, H, oh), h1 = ap_end(i, H, oh);
             if (h < h0 || h >= h1) continue;
-            for (int j = (jc > 0 ? jc - 1 : 0); j <= jc + 1 && j < ow; ++j) {
+            for (int j = (j_lo > 0 ? j_lo - 1 : 0); j <= j_hi + 1 && j < ow; ++j) {
                 const int w0 = ap_start(j, W, ow), w1 = ap_end(j, W, ow);
                 if (w < w0 || w >= w1) continue;
                 const float inv = 1.0f / (float)((h1 - h0) * (w1 - w0));
@@ -210,7 +212,6 @@ extern "C" int tf_bilinear_fwd_f32(const tf_bilinear_desc* d, const float* x, fl
 
 extern "C" int tf_bilinear_bwd_f32(const tf_bilinear_desc* d, const float* dy, float* dx, int accumulate, void* stream) {
     TF_REQUIRE(d && dy && dx && d->B > 0 && d->C > 0 && d->Hi > 0 && d->Wi > 0 && d->Ho > 0 && d->Wo > 0, "tf_bilinear_bwd_f32: bad arguments");
-    TF_REQUIRE(d->Ho >= d->Hi && d->Wo >= d->Wi, "tf_bilinear_bwd_f32: only up-sampling is supported");
     const long n = (long)d->B * d->Hi * d->Wi * d->C;
     TF_LAUNCH(bilinear_bwd_kernel, dim3(ew_blocks(n)), dim3(256), stream, *d, dy, dx, bl_scale(d->Hi, d->Ho, d->align_corners),
               bl_scale(d->Wi, d->Wo, d->align_corners), accumulate, d->sc_i == 1 ? 1 : 0);

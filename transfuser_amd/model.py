@@ -1,0 +1,178 @@
+"""``LidarCenterNet`` - the full trainable TransFuser model - as a drop-in for
+team_code_transfuser/model.py:538-805 (constructor :545, ``forward`` :733-805 returning the dict of
+11 losses, ``forward_gru`` :611) and ``LidarCenterNetHead`` (:34-514: heads :93-99,127-147,
+targets :285-374, losses :150-248 with mmdet 2.25 semantics).
+
+Same parameter names/shapes (reference checkpoints load with strict=True), same call signature,
+same return value; everything between the input tensors and the loss scalars runs in the HIP
+kernels of libtransfuser_hip.so.  Out of scope here: ``forward_ego`` / box decoding /
+PID control / visualisation (CARLA inference), ``late_fusion`` / ``geometric_fusion`` / ``latentTF``
+backbones, PointPillars (``use_point_pillars``) - requesting them raises.
+"""
+import torch
+from torch import nn
+
+from . import functions as F_
+from . import ops
+from .transfuser import DepthDecoder, SegDecoder, TransfuserBackbone, nchw
+
+HEAD_ORDER = ("heatmap_head", "wh_head", "offset_head", "yaw_class_head", "yaw_res_head", "velocity_head", "brake_head")
+LOSS_KEYS = ("loss_center_heatmap", "loss_wh", "loss_offset", "loss_yaw_class", "loss_yaw_res", "loss_velocity", "loss_brake")
+
+
+class LidarCenterNetHead(nn.Module):
+    """Parameter holder + loss front-end of the CenterNet head (model.py:34-248)."""
+
+    def __init__(self, in_channel, feat_channel, num_classes, train_cfg=None, **unused):
+        super().__init__()
+        assert num_classes == 1, "the TransFuser head predicts a single class (model.py:589)"
+        self.num_classes = num_classes
+        self.num_dir_bins = train_cfg.num_dir_bins
+        self.train_cfg = train_cfg
+        mk = lambda oc: nn.Sequential(nn.Conv2d(in_channel, feat_channel, kernel_size=3, padding=1), nn.ReLU(inplace=True),
+                                      nn.Conv2d(feat_channel, oc, kernel_size=1))
+        self.heatmap_head = mk(num_classes)
+        self.wh_head = mk(2)
+        self.offset_head = mk(2)
+        self.yaw_class_head = mk(self.num_dir_bins)
+        self.yaw_res_head = mk(1)
+        self.velocity_head = mk(1)
+        self.brake_head = mk(2)
+
+    @property
+    def pred_channels(self):
+        return 9 + self.num_dir_bins
+
+    def heads(self):
+        return [getattr(self, n) for n in HEAD_ORDER]
+
+
+class HeadsFn(torch.autograd.Function):
+    """The 7 CenterNet heads + pred_bev on p2 in one autograd node (model.py:127-147,581-585,759):
+    8 x [conv3x3 64->64 + ReLU + conv1x1]; head outputs are packed as (B,h,w,9+bins) logits
+    [hm, wh(2), off(2), yaw_cls(bins), yaw_res, vel, brake(2)] for the fused loss kernel."""
+
+    @staticmethod
+    def forward(ctx, p2, model, *params):
+        B, H, W, C = p2.shape
+        seqs = model.head.heads() + [model.pred_bev]
+        P = model.head.pred_channels
+        pred = torch.empty(B, H, W, P, dtype=torch.float32, device=p2.device)
+        bev = torch.empty(B, H, W, seqs[-1][2].weight.shape[0], dtype=torch.float32, device=p2.device)
+        hids, off = [], 0
+        for i, sq in enumerate(seqs):
+            hid = ops.conv_fwd(p2, sq[0].weight, sq[0].bias, 1, 1, 1, relu=True)
+            k = sq[2].weight.shape[0]
+            dst = bev.view(-1, k) if i == len(seqs) - 1 else pred.view(-1, P)[:, off:off + k]
+            ops.linear_fwd(hid.view(-1, hid.shape[-1]), F_.w2d(sq[2].weight), sq[2].bias, out=dst)
+            if i < len(seqs) - 1:
+                off += k
+            hids.append(hid)
+        ctx.saved = (p2, model, hids)
+        return pred, bev
+
+    @staticmethod
+    def backward(ctx, dpred, dbev):
+        p2, model, hids = ctx.saved
+        seqs = model.head.heads() + [model.pred_bev]
+        B, H, W, C = p2.shape
+        P = model.head.pred_channels
+        dpred, dbev = dpred.contiguous(), dbev.contiguous()
+        db_pred = ops.colsum(dpred.view(-1, P), 1, B * H * W, P)
+        dp2 = torch.empty_like(p2)
+        off = 0
+        for i, sq in enumerate(seqs):
+            k = sq[2].weight.shape[0]
+            last = i == len(seqs) - 1
+            g2 = dbev.view(-1, k) if last else dpred.view(-1, P)[:, off:off + k]
+            hid = hids[i]
+            Ch = hid.shape[-1]
+            ops.linear_wgrad(g2, hid.view(-1, Ch), F_.w2d(F_.gbuf(sq[2].weight)))
+            if last:
+                F_.bias_grad(g2, sq[2].bias)
+            else:
+                ops.axpby(F_.gbuf(sq[2].bias), db_pred[0, off:off + k], 1.0, 1.0, out=F_.gbuf(sq[2].bias))
+                off += k
+            dh = ops.linear_dgrad(g2, F_.w2d(sq[2].weight)).view(B, H, W, Ch)
+            ops.relu_mask(dh, hid, out=dh)
+            F_.bias_grad(dh.view(-1, Ch), sq[0].bias)
+            ops.conv_wgrad(dh, p2, F_.gbuf(sq[0].weight), 1, 1, 1)
+            ops.conv_dgrad(dh, sq[0].weight, p2.shape, 1, 1, 1, out=dp2, accumulate=i > 0)
+        ctx.saved = None
+        return (dp2, None) + (None,) * (len(ctx.needs_input_grad) - 2)
+
+
+class LidarCenterNet(nn.Module):
+    def __init__(self, config, device, backbone, image_architecture='resnet34', lidar_architecture='resnet18', use_velocity=True):
+        super().__init__()
+        self.device = device
+        self.config = config
+        self.pred_len = config.pred_len
+        self.use_target_point_image = config.use_target_point_image
+        self.gru_concat_target_point = config.gru_concat_target_point
+        self.use_point_pillars = config.use_point_pillars
+        if self.use_point_pillars:
+            raise NotImplementedError("use_point_pillars=1 (point_pillar.py) is a 'next' row of SURVEY.md section 8f, not built yet")
+        self.backbone = backbone
+        if backbone == 'transFuser':
+            self._model = TransfuserBackbone(config, image_architecture, lidar_architecture, use_velocity=use_velocity)
+        else:
+            raise NotImplementedError("backbone %r: only 'transFuser' is on the MI355X hot path (SURVEY.md section 8)" % (backbone,))
+        if config.multitask:
+            self.seg_decoder = SegDecoder(config, config.perception_output_features)
+            self.depth_decoder = DepthDecoder(config, config.perception_output_features)
+        channel = config.channel
+        self.pred_bev = nn.Sequential(nn.Conv2d(channel, channel, kernel_size=(3, 3), stride=1, padding=(1, 1), bias=True),
+                                      nn.ReLU(inplace=True),
+                                      nn.Conv2d(channel, 3, kernel_size=(1, 1), stride=1, padding=0, bias=True))
+        self.head = LidarCenterNetHead(channel, channel, 1, train_cfg=config)
+        self.i = 0
+        self.join = nn.Sequential(nn.Linear(512, 256), nn.ReLU(inplace=True), nn.Linear(256, 128), nn.ReLU(inplace=True),
+                                  nn.Linear(128, 64), nn.ReLU(inplace=True))
+        self.decoder = nn.GRUCell(input_size=4 if self.gru_concat_target_point else 2, hidden_size=config.gru_hidden_size)
+        self.output = nn.Linear(config.gru_hidden_size, 3)
+        self.register_buffer("bev_class_weight", torch.tensor([1., 1., 3.]), persistent=False)  # model.py:762
+        for m in self.modules():  # 3x3 conv weights live channels_last (= the kernels' (Cout,kh,kw,Cin) layout)
+            if isinstance(m, nn.Conv2d) and m.kernel_size != (1, 1):
+                m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
+        self.to(device)
+
+    # ------------------------------------------------------------------ waypoints
+    def forward_gru(self, z, target_point):
+        pred_wp = F_.WaypointFn.apply(z, target_point, self, *self.join.parameters(), *self.decoder.parameters(), *self.output.parameters())
+        return pred_wp, None, None, None, None
+
+    # ------------------------------------------------------------------ training forward
+    def forward(self, rgb, lidar_bev, ego_waypoint, target_point, target_point_image, ego_vel, bev, label, depth, semantic,
+                num_points=None, save_path=None, bev_points=None, cam_points=None):
+        cfg = self.config
+        extra = target_point_image if self.use_target_point_image else None
+        features, grid, fused = self._model.forward_nhwc(rgb, lidar_bev, ego_vel, lidar_extra=extra)
+        pred_wp, _, _, _, _ = self.forward_gru(fused, target_point)
+        p2 = features[0]
+        pred, bev_logits = HeadsFn.apply(p2, self, *self.head.parameters(), *self.pred_bev.parameters())
+        bev_up = F_.UpsampleFn.apply(bev_logits, cfg.bev_resolution_height, cfg.bev_resolution_width, True)
+        loss = {
+            "loss_wp": F_.L1Fn.apply(pred_wp, ego_waypoint.contiguous(), False),
+            "loss_bev": F_.CrossEntropyFn.apply(bev_up, bev.contiguous(), self.bev_class_weight),
+        }
+        det = F_.CenterNetLossFn.apply(pred, label.contiguous(), self.head.num_dir_bins, p2.shape[2] / float(cfg.lidar_resolution_width),
+                                       p2.shape[1] / float(cfg.lidar_resolution_height))
+        for i, k in enumerate(LOSS_KEYS):
+            loss[k] = det[i]
+        if cfg.multitask:
+            seg_logits = self.seg_decoder.forward_nhwc(grid)
+            depth_logits = self.depth_decoder.forward_nhwc(grid)
+            l_sem = F_.CrossEntropyFn.apply(seg_logits, semantic.contiguous(), None)
+            l_dep = F_.L1Fn.apply(depth_logits.squeeze(-1), depth.contiguous(), True)
+            loss["loss_depth"] = l_dep * cfg.ls_depth if cfg.ls_depth != 1.0 else l_dep
+            loss["loss_semantic"] = l_sem * cfg.ls_seg if cfg.ls_seg != 1.0 else l_sem
+        else:
+            loss["loss_depth"] = torch.zeros_like(loss["loss_wp"])
+            loss["loss_semantic"] = torch.zeros_like(loss["loss_wp"])
+        self.i += 1
+        self._last = dict(pred_wp=pred_wp, pred=pred, bev_up=bev_up, features=features, grid=grid, fused=fused)
+        return loss
+
+    def forward_ego(self, *a, **k):
+        raise NotImplementedError("forward_ego (CARLA closed-loop inference, model.py:685-731) is outside the training hot path (SURVEY.md section 8f-1)")

@@ -329,6 +329,12 @@ def relu_mask(dy, y, out=None):
     return out
 
 
+def sigmoid(x):
+    y = torch.empty_like(x)
+    check(L().tf_sigmoid_f32(ptr(_c(x)), ptr(y), ctypes.c_int64(x.numel()), stream_of(x)), "tf_sigmoid_f32")
+    return y
+
+
 def axpby(a, b=None, alpha=1.0, beta=1.0, out=None):
     if out is None:
         out = torch.empty_like(a)

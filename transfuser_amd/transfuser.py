@@ -1,0 +1,282 @@
+"""TransFuser backbone + auxiliary decoders, MI355X-native drop-in for
+team_code_transfuser/transfuser.py (``TransfuserBackbone`` :7-211, ``SegDecoder`` :214, ``DepthDecoder``
+:249, ``GPT`` :284, ``ImageCNN`` :369, ``LidarEncoder`` :431, ``SelfAttention`` :491, ``Block`` :530).
+
+Same constructor signatures, parameter names / shapes and return values; the arithmetic runs in the
+hand-written HIP kernels of ``libtransfuser_hip.so`` (there is no PyTorch fallback).  Internally
+feature maps are NHWC; tensors returned through the public API are NCHW-shaped views of them.
+"""
+import types
+
+import torch
+from torch import nn
+
+from . import functions as F_
+from . import regnet
+
+
+def nchw(x):
+    """NHWC tensor -> NCHW-shaped view (channels_last memory format), zero copy."""
+    return x.permute(0, 3, 1, 2)
+
+
+def nhwc(x):
+    """NCHW-shaped tensor -> contiguous NHWC (free when the tensor is already channels_last)."""
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+class SelfAttention(nn.Module):
+    def __init__(self, n_embd, n_head, attn_pdrop, resid_pdrop):
+        super().__init__()
+        assert n_embd % n_head == 0
+        self.key = nn.Linear(n_embd, n_embd)
+        self.query = nn.Linear(n_embd, n_embd)
+        self.value = nn.Linear(n_embd, n_embd)
+        self.attn_drop = nn.Dropout(attn_pdrop)
+        self.resid_drop = nn.Dropout(resid_pdrop)
+        self.proj = nn.Linear(n_embd, n_embd)
+        self.n_head = n_head
+        self._fused = None
+
+    def fused(self):
+        """(Wkqv (3C,C), bkqv (3C), grad views) when key/query/value are adjacent in the parameter arena
+        (transfuser_amd.train.ParamArena lays them out that way): one N=3C GEMM instead of three."""
+        f = self._fused
+        kw = self.key.weight
+        if f is not None and f[4] == (kw.data_ptr(), kw.grad.data_ptr() if kw.grad is not None else 0):
+            return f[:4]
+        ws = [self.key.weight, self.query.weight, self.value.weight]
+        bs = [self.key.bias, self.query.bias, self.value.bias]
+        C = kw.shape[0]
+
+        def adjacent(ts):
+            return all(t.is_contiguous() and ts[i + 1].data_ptr() == t.data_ptr() + t.numel() * 4 for i, t in enumerate(ts[:-1])) and \
+                ts[0].untyped_storage().data_ptr() == ts[-1].untyped_storage().data_ptr()
+
+        if any(p.grad is None for p in ws + bs):
+            return None
+        if not (adjacent(ws) and adjacent(bs) and adjacent([p.grad for p in ws]) and adjacent([p.grad for p in bs])):
+            return None
+        view = lambda t, shape: torch.as_strided(t, shape, (shape[1], 1) if len(shape) == 2 else (1,), t.storage_offset())
+        f = (view(ws[0].data, (3 * C, C)), view(bs[0].data, (3 * C,)), view(ws[0].grad, (3 * C, C)), view(bs[0].grad, (3 * C,)),
+             (kw.data_ptr(), kw.grad.data_ptr()))
+        self._fused = f
+        return f[:4]
+
+
+class Block(nn.Module):
+    def __init__(self, n_embd, n_head, block_exp, attn_pdrop, resid_pdrop):
+        super().__init__()
+        self.ln1 = nn.LayerNorm(n_embd)
+        self.ln2 = nn.LayerNorm(n_embd)
+        self.attn = SelfAttention(n_embd, n_head, attn_pdrop, resid_pdrop)
+        self.mlp = nn.Sequential(nn.Linear(n_embd, block_exp * n_embd), nn.ReLU(True), nn.Linear(block_exp * n_embd, n_embd),
+                                 nn.Dropout(resid_pdrop))
+
+
+class GPT(nn.Module):
+    """transfuser.py:284-366.  ``forward`` takes/returns NHWC maps of the two branches and performs the
+    whole fusion stage (pool -> tokens -> blocks -> ln_f -> raw view -> up-sample -> residual add)."""
+
+    _site_base = 0
+
+    def __init__(self, n_embd, n_head, block_exp, n_layer, img_vert_anchors, img_horz_anchors, lidar_vert_anchors, lidar_horz_anchors,
+                 seq_len, embd_pdrop, attn_pdrop, resid_pdrop, config, use_velocity=True):
+        super().__init__()
+        self.n_embd = n_embd
+        self.n_head = n_head
+        self.seq_len = 1
+        self.geom = types.SimpleNamespace(ih=img_vert_anchors, iw=img_horz_anchors, lh=lidar_vert_anchors, lw=lidar_horz_anchors)
+        self.config = config
+        self.pos_emb = nn.Parameter(torch.zeros(1, img_vert_anchors * img_horz_anchors + lidar_vert_anchors * lidar_horz_anchors, n_embd))
+        self.use_velocity = use_velocity
+        if use_velocity:
+            self.vel_emb = nn.Linear(self.seq_len, n_embd)
+        self.drop = nn.Dropout(embd_pdrop)
+        self.embd_pdrop, self.attn_pdrop, self.resid_pdrop = float(embd_pdrop), float(attn_pdrop), float(resid_pdrop)
+        self.pdrop_any = max(self.embd_pdrop, self.attn_pdrop, self.resid_pdrop) > 0
+        self.blocks = nn.Sequential(*[Block(n_embd, n_head, block_exp, attn_pdrop, resid_pdrop) for _ in range(n_layer)])
+        self.ln_f = nn.LayerNorm(n_embd)
+        self.block_size = self.seq_len
+        self.site_base = GPT._site_base
+        GPT._site_base += 4 * n_layer + 1
+        self.seed = None  # int32 device tensor shared by the backbone (dropout RNG key)
+        self.apply(self._init_weights)
+
+    def _init_weights(self, module):  # transfuser.py:324-331
+        if isinstance(module, nn.Linear):
+            module.weight.data.normal_(mean=self.config.gpt_linear_layer_init_mean, std=self.config.gpt_linear_layer_init_std)
+            if module.bias is not None:
+                module.bias.data.zero_()
+        elif isinstance(module, nn.LayerNorm):
+            module.bias.data.zero_()
+            module.weight.data.fill_(self.config.gpt_layer_norm_init_weight)
+
+    def site(self, i):
+        return self.site_base + i
+
+    def forward(self, image_nhwc, lidar_nhwc, velocity):
+        assert image_nhwc.shape[-1] == self.n_embd and lidar_nhwc.shape[-1] == self.n_embd
+        return F_.GPTStageFn.apply(image_nhwc, lidar_nhwc, self, velocity, *self.parameters())
+
+
+class _Stem:
+    """First conv + BN of a trunk as StemFn sees them (the modules stay registered under the reference's names)."""
+
+    def __init__(self, conv, bn, normalize):
+        self.conv, self.bn, self.normalize = conv, bn, normalize
+
+    def __call__(self, s0, s1=None):
+        return F_.StemFn.apply(s0, s1, self, self.conv.weight, self.bn.weight, self.bn.bias)
+
+
+def _relabel(net):
+    """The reference's re-labelling of a timm RegNet (transfuser.py:383-393, 445-455)."""
+    net.fc = None
+    net.conv1 = net.stem.conv
+    net.bn1 = net.stem.bn
+    net.act1 = nn.Sequential()
+    net.maxpool = nn.Sequential()
+    net.layer1, net.layer2, net.layer3, net.layer4 = net.s1, net.s2, net.s3, net.s4
+    net.global_pool = nn.AdaptiveAvgPool2d(output_size=1)
+    net.head = nn.Sequential()
+
+
+class ImageCNN(nn.Module):
+    def __init__(self, architecture, normalize=True, out_features=512):
+        super().__init__()
+        self.normalize = normalize
+        self.features = regnet.create_model(architecture, pretrained=True)
+        _relabel(self.features)
+
+
+class LidarEncoder(nn.Module):
+    def __init__(self, architecture, in_channels=2, out_features=512):
+        super().__init__()
+        self._model = regnet.create_model(architecture, pretrained=False)
+        _relabel(self._model)
+        old = self._model.conv1
+        self._model.conv1 = nn.Conv2d(in_channels, old.out_channels, kernel_size=old.kernel_size, stride=old.stride, padding=old.padding, bias=False)
+        del self._model.stem.conv  # transfuser.py:482-483
+
+
+class TransfuserBackbone(nn.Module):
+    """Multi-scale fusion transformer for image + LiDAR features (transfuser.py:7-211)."""
+
+    def __init__(self, config, image_architecture='resnet34', lidar_architecture='resnet18', use_velocity=True):
+        super().__init__()
+        self.config = config
+        self.image_encoder = ImageCNN(architecture=image_architecture, normalize=True, out_features=config.perception_output_features)
+        in_channels = config.num_features[-1] if config.use_point_pillars else 2 * config.lidar_seq_len
+        if config.use_target_point_image:
+            in_channels += 1
+        self.lidar_encoder = LidarEncoder(architecture=lidar_architecture, in_channels=in_channels, out_features=config.perception_output_features)
+        chs = [f['num_chs'] for f in self.image_encoder.features.feature_info]
+        for i in range(1, 5):
+            setattr(self, "transformer%d" % i, GPT(n_embd=chs[i], n_head=config.n_head, block_exp=config.block_exp, n_layer=config.n_layer,
+                                                   img_vert_anchors=config.img_vert_anchors, img_horz_anchors=config.img_horz_anchors,
+                                                   lidar_vert_anchors=config.lidar_vert_anchors, lidar_horz_anchors=config.lidar_horz_anchors,
+                                                   seq_len=config.seq_len, embd_pdrop=config.embd_pdrop, attn_pdrop=config.attn_pdrop,
+                                                   resid_pdrop=config.resid_pdrop, config=config, use_velocity=use_velocity))
+        pf = config.perception_output_features
+        if chs[4] != pf:
+            self.change_channel_conv_image = nn.Conv2d(chs[4], pf, (1, 1))
+            self.change_channel_conv_lidar = nn.Conv2d(chs[4], pf, (1, 1))
+        else:
+            self.change_channel_conv_image = nn.Sequential()
+            self.change_channel_conv_lidar = nn.Sequential()
+        channel = config.bev_features_chanels
+        self.relu = nn.ReLU(inplace=True)
+        self.upsample = nn.Upsample(scale_factor=config.bev_upsample_factor, mode='bilinear', align_corners=False)
+        self.up_conv5 = nn.Conv2d(channel, channel, (1, 1))
+        self.up_conv4 = nn.Conv2d(channel, channel, (1, 1))
+        self.up_conv3 = nn.Conv2d(channel, channel, (1, 1))
+        self.c5_conv = nn.Conv2d(pf, channel, (1, 1))
+        self.register_buffer("dropout_seed", torch.zeros(1, dtype=torch.int32), persistent=False)
+        self._img_stem = _Stem(self.image_encoder.features.conv1, self.image_encoder.features.bn1, True)
+        self._lid_stem = _Stem(self.lidar_encoder._model.conv1, self.lidar_encoder._model.bn1, False)
+
+    def _conv(self, conv, x, relu=False):
+        if isinstance(conv, nn.Sequential):
+            return x
+        return F_.ConvFn.apply(x, conv.weight, conv.bias, relu)
+
+    def _up(self, x):
+        B, H, W, C = x.shape
+        f = int(self.config.bev_upsample_factor)
+        return F_.UpsampleFn.apply(x, H * f, W * f, False)
+
+    def top_down_nhwc(self, x):
+        p5 = self._conv(self.c5_conv, x, True)
+        p4 = self._conv(self.up_conv5, self._up(p5), True)
+        p3 = self._conv(self.up_conv4, self._up(p4), True)
+        p2 = self._conv(self.up_conv3, self._up(p3), True)
+        return p2, p3, p4, p5
+
+    def top_down(self, x):
+        return tuple(nchw(p) for p in self.top_down_nhwc(nhwc(x)))
+
+    def forward_nhwc(self, image, lidar, velocity, lidar_extra=None):
+        """image (B,3,H,W) 0..255, lidar (B,2|3,256,256) [+ lidar_extra (B,1,256,256) instead of torch.cat];
+        returns NHWC tensors: (p2,p3,p4,p5), image_features_grid, fused_features."""
+        im, li = self.image_encoder.features, self.lidar_encoder._model
+        x = self._img_stem(image.contiguous())
+        y = self._lid_stem(lidar.contiguous(), lidar_extra.contiguous() if lidar_extra is not None else None)
+        for i in range(1, 5):
+            x = getattr(im, "layer%d" % i)(x)
+            y = getattr(li, "layer%d" % i)(y)
+            gpt = getattr(self, "transformer%d" % i)
+            gpt.seed = self.dropout_seed
+            x, y = gpt(x, y, velocity)
+        x = self._conv(self.change_channel_conv_image, x)
+        y = self._conv(self.change_channel_conv_lidar, y)
+        fused = F_.GlobalPoolAddFn.apply(x, y)
+        return self.top_down_nhwc(y), x, fused
+
+    def forward(self, image, lidar, velocity):
+        feats, grid, fused = self.forward_nhwc(image, lidar, velocity)
+        return tuple(nchw(p) for p in feats), nchw(grid), fused
+
+
+class _Decoder(nn.Module):
+    def __init__(self, config, latent_dim, out_ch):
+        super().__init__()
+        self.config = config
+        self.latent_dim = latent_dim
+        c1, c2, c3 = config.deconv_channel_num_1, config.deconv_channel_num_2, config.deconv_channel_num_3
+        self.deconv1 = nn.Sequential(nn.Conv2d(latent_dim, c1, 3, 1, 1), nn.ReLU(True), nn.Conv2d(c1, c2, 3, 1, 1), nn.ReLU(True))
+        self.deconv2 = nn.Sequential(nn.Conv2d(c2, c3, 3, 1, 1), nn.ReLU(True), nn.Conv2d(c3, c3, 3, 1, 1), nn.ReLU(True))
+        self.deconv3 = nn.Sequential(nn.Conv2d(c3, c3, 3, 1, 1), nn.ReLU(True), nn.Conv2d(c3, out_ch, 3, 1, 1))
+
+    def forward_nhwc(self, x):
+        cfg = self.config
+        cv = lambda c, t, r: F_.ConvFn.apply(t, c.weight, c.bias, r)
+        x = cv(self.deconv1[2], cv(self.deconv1[0], x, True), True)
+        x = F_.UpsampleFn.apply(x, x.shape[1] * int(cfg.deconv_scale_factor_1), x.shape[2] * int(cfg.deconv_scale_factor_1), False)
+        x = cv(self.deconv2[2], cv(self.deconv2[0], x, True), True)
+        x = F_.UpsampleFn.apply(x, x.shape[1] * int(cfg.deconv_scale_factor_2), x.shape[2] * int(cfg.deconv_scale_factor_2), False)
+        return cv(self.deconv3[2], cv(self.deconv3[0], x, True), False)
+
+
+class SegDecoder(_Decoder):
+    """transfuser.py:214-246; returns (B, num_class, H, W) logits."""
+
+    def __init__(self, config, latent_dim=512):
+        super().__init__(config, latent_dim, config.num_class)
+        self.num_class = config.num_class
+
+    def forward(self, x):
+        return nchw(self.forward_nhwc(nhwc(x)))
+
+
+class DepthDecoder(_Decoder):
+    """transfuser.py:249-281; ``forward`` returns sigmoid depth (B, H, W); the training loss consumes the
+    pre-sigmoid logits (``forward_nhwc``) so sigmoid + L1 run in one kernel."""
+
+    def __init__(self, config, latent_dim=512):
+        super().__init__(config, latent_dim, 1)
+
+    def forward(self, x):
+        from . import ops
+        logits = self.forward_nhwc(nhwc(x))
+        return ops.sigmoid(logits).squeeze(-1)
