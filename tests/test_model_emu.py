@@ -25,3 +25,29 @@ def test_tiny_model_with_velocity_and_odd_image():
     batch = mc.small_batch(1, 64, 96, 64, 40, seed=3)
     lp, lr = mc.run_pair(prod, ref, cfg, batch, "cpu")
     mc.compare(prod, ref, lp, lr)
+
+
+def test_engine_two_steps_match_oracle_adamw():
+    """Engine (flat arena, fused QKV GEMMs, one-launch AdamW) vs the oracle's Engine.train mirror
+    (torch.optim.AdamW) over two iterations: losses of step 2 and all parameters after step 2."""
+    from oracle import model_cpu
+    from transfuser_amd.train import Engine
+    cfg = mc.tiny_config(n_layer=1)
+    prod, ref = mc.build_pair(cfg, "regnety_tiny", "cpu")
+    eng = Engine(prod, cfg, lr=1e-3)
+    assert prod._model.transformer1.blocks[0].attn.fused() is not None, "arena must make k/q/v adjacent"
+    opt = torch.optim.AdamW(ref.parameters(), lr=1e-3)
+    batch = mc.small_batch(2, 32, 64, 64, 40)
+    prod.train(); ref.train()
+    for it in range(2):
+        tot_p, lp = eng.train_step(batch)
+        tot_r, lr_ = model_cpu.train_step(ref, opt, batch, cfg)
+        assert abs(float(tot_p) - float(tot_r)) <= 1e-3 * max(1.0, abs(float(tot_r))), (it, float(tot_p), float(tot_r))
+    rp = dict(ref.named_parameters())
+    worst = max(((p.detach() - rp[n].detach()).abs().max().item(), n) for n, p in prod.named_parameters())
+    assert worst[0] < 2e-3, worst   # lr 1e-3 => each AdamW step moves a weight by <= ~1e-3
+    # running BN statistics follow too
+    rb = dict(ref.named_buffers())
+    for n, b in prod.named_buffers():
+        if "running" in n:
+            assert (b - rb[n]).abs().max().item() < 1e-3 * max(1.0, rb[n].abs().max().item()), n
