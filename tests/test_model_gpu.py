@@ -18,11 +18,12 @@ def _gpu():
 
 
 def test_tiny_model_losses_and_grads():
-    cfg = mc.tiny_config(n_layer=2)
+    # larger maps than the emulated CPU test: stage-4 is 5x11 / 4x4, so tokens are not replicas of one pixel
+    cfg = mc.tiny_config(n_layer=2, lidar_res=128)
     prod, ref = mc.build_pair(cfg, "regnety_tiny", "cuda")
-    batch = mc.small_batch(2, 32, 64, 64, 40)
+    batch = mc.small_batch(2, 160, 352, 128, 40)
     lp, lr = mc.run_pair(prod, ref, cfg, batch, "cuda")
-    mc.compare(prod, ref, lp, lr, verbose=True)
+    mc.compare(prod, ref, lp, lr, grad_tol=5e-3, verbose=True)
 
 
 @pytest.mark.parametrize("H,B", [(160, 2), (256, 1)], ids=["H160_reference_resolution", "H256_bench_resolution"])
