@@ -15,6 +15,8 @@ import os
 import sys
 import time
 
+import faulthandler
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -73,6 +75,9 @@ def cpu_baseline(cfg_factory, H, W):
                 sample="oracle.model_cpu.train_step (PyTorch-CPU fp32, %d threads), B=2, %dx%d, 1 warm-up + 2 timed steps" % (os.cpu_count(), H, W))
 
 
+T0 = time.perf_counter()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -83,7 +88,13 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dropout", type=float, default=0.1)
+    ap.add_argument("--watchdog", type=int, default=600, help="dump all Python stacks to stderr if still running after this many seconds")
     args = ap.parse_args()
+    faulthandler.dump_traceback_later(args.watchdog, repeat=True, file=sys.stderr)
+    torch.set_num_threads(min(16, os.cpu_count()))   # host-side glue only; the CPU baseline sets its own count
+
+    def log(msg):
+        print("[bench %.1fs] %s" % (time.perf_counter() - T0, msg), file=sys.stderr, flush=True)
 
     from transfuser_amd import _lib, ops
     from transfuser_amd.config import GlobalConfig
@@ -111,16 +122,22 @@ def main():
     model.train()
     hist_fn = lambda pts: ops.lidar_hist(torch.from_numpy(pts).to(dev)[None])[0].cpu().numpy()
     batch = {k: v.to(dev) for k, v in synthetic_batch(B, H, W, seed=rank, hist_fn=hist_fn).items()}
+    log("model + batch on device")
     eng = Engine(model, cfg, lr=cfg.lr, use_graph=not args.no_graph)
+    log("engine ready (arena %.1f M floats)" % (eng.arena.numel / 1e6))
 
     def sync():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
         eng.train_step(batch)
+        if i == 0:
+            torch.cuda.synchronize()
+            log("first step done (incl. graph capture)" if not args.no_graph else "first eager step done")
     sync()
+    log("warm-up done")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         tot, det = eng.train_step(batch)
@@ -131,6 +148,7 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t)
     loss = float(tot)
+    log("timed region done: %.2f ms/step" % (dt / args.steps * 1e3))
     assert loss == loss, "NaN loss"
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -146,6 +164,7 @@ def main():
                        "global_batch": B * world, "parallelism": "dp%d" % world, "final_loss": round(loss, 4)},
         }
         roof = dominant_kernel_roofline(dev)
+        log("roofline microbench done")
         if gf:
             step_tf = value / world * gf / 1e3
             roof["step_achieved_tflops"] = round(step_tf, 2)
