@@ -48,12 +48,46 @@ def wptr(w):
 
 
 # ------------------------------------------------------------------------------------------ GEMM
+_CHECK = bool(int(__import__("os").environ.get("TF_CHECK", "0")))  # debug aid: verify every GEMM against fp64 ATen (slow)
+
+
+def _gemm_reference(a, b, c_old, m, n, k, lda, ldb, ldc, a_trans, b_trans, bias, res, ldres, alpha, relu, accumulate, batch, inner, sa, sb, sc):
+    outer = batch // inner
+    A = torch.as_strided(a, (outer, inner, m, k), (sa[0], sa[1], 1 if a_trans else lda, lda if a_trans else 1)).double()
+    B = torch.as_strided(b, (outer, inner, k, n), (sb[0], sb[1], ldb if b_trans else 1, 1 if b_trans else ldb)).double()
+    R = alpha * (A @ B)
+    if bias is not None:
+        R = R + bias.double().view(1, 1, 1, n)
+    if res is not None:
+        R = R + torch.as_strided(res, (outer, inner, m, n), (sc[0], sc[1], ldres, 1)).double()
+    if relu:
+        R = R.clamp_min(0)
+    if accumulate:
+        R = R + c_old
+    return R
+
+
 def gemm(a, b, c, m, n, k, lda, ldb, ldc, a_trans=False, b_trans=False, bias=None, res=None, ldres=0, alpha=1.0, relu=False,
          accumulate=False, batch=1, inner=1, sa=(0, 0), sb=(0, 0), sc=(0, 0)):
+    if _CHECK and c.is_cuda:
+        cview = lambda: torch.as_strided(c, (batch // inner, inner, m, n), (sc[0], sc[1], ldc, 1))
+        old = cview().double().clone() if accumulate else None
+        ref = _gemm_reference(a, b, old, m, n, k, lda, ldb, ldc, a_trans, b_trans, bias, res, ldres, alpha, relu, accumulate, batch, inner, sa, sb, sc)
     d = GemmDesc(a=ptr(a), b=ptr(b), c=ptr(c), bias=ptr(bias), res=ptr(res), m=m, n=n, k=k, a_trans=int(a_trans), b_trans=int(b_trans),
                  lda=lda, ldb=ldb, ldc=ldc, ldres=ldres, batch=batch, inner=inner, sa_outer=sa[0], sa_inner=sa[1], sb_outer=sb[0],
                  sb_inner=sb[1], sc_outer=sc[0], sc_inner=sc[1], alpha=alpha, relu=int(relu), accumulate=int(accumulate))
     check(L().tf_gemm_f32(byref(d), stream_of(c)), "tf_gemm_f32")
+    if _CHECK and c.is_cuda:
+        got = cview().double()
+        err = (got - ref).abs().max().item()
+        rms = ref.pow(2).mean().sqrt().item() + 1e-30
+        if not err <= 1e-4 * rms:
+            bad = ((got - ref).abs() > 1e-4 * rms)
+            idx = bad.nonzero()
+            raise RuntimeError("TF_CHECK gemm mismatch: m=%d n=%d k=%d at=%d bt=%d lda=%d ldb=%d ldc=%d batch=%d inner=%d alpha=%g relu=%d acc=%d bias=%s res=%s "
+                               "maxerr=%.3e rms=%.3e nbad=%d first_bad=%s rows=%s cols=%s" %
+                               (m, n, k, a_trans, b_trans, lda, ldb, ldc, batch, inner, alpha, relu, accumulate, bias is not None, res is not None, err, rms,
+                                int(bad.sum()), idx[:6].tolist(), sorted(set(idx[:, 2].tolist()))[:24], sorted(set(idx[:, 3].tolist()))[:24]))
     return c
 
 
