@@ -100,7 +100,13 @@ def run_pair(prod, ref, cfg, batch, dev):
     return lp, lr
 
 
-def compare(prod, ref, lp, lr, loss_tol=1e-3, grad_tol=2e-3, verbose=False):
+def compare(prod, ref, lp, lr, loss_tol=1e-3, grad_tol=2e-3, verbose=False, metric="max"):
+    """Losses within loss_tol (relative, fp32 tolerance of north_star).  Gradients per parameter tensor:
+    metric "max": max|g - g_ref| / max|g_ref|  (tight; used where CPU and device arithmetic agree closely);
+    metric "l2":  ||g - g_ref||_2 / ||g_ref||_2.  At full width a handful of the ~10^8 ReLU pre-activations lie
+    within fp32 round-off of zero, so their masks differ between ANY two fp32 implementations (MKL vs MFMA
+    summation order); one flipped unit moves one row of a weight gradient by ~1/sqrt(#rows) but the tensor's
+    L2 error by only ~1e-3, whereas a wrong kernel gives O(1)."""
     worst = []
     for k in lr:
         a, b = float(lp[k]), float(lr[k])
@@ -112,12 +118,16 @@ def compare(prod, ref, lp, lr, loss_tol=1e-3, grad_tol=2e-3, verbose=False):
         gp = p.grad.detach().cpu()
         if gr is None:
             gr = torch.zeros_like(gp)
-        err = (gp - gr).abs().max().item()
-        scale = max(gr.abs().max().item(), 1e-3)
+        if metric == "max":
+            err = (gp - gr).abs().max().item()
+            scale = max(gr.abs().max().item(), 1e-3)
+        else:
+            err = (gp - gr).double().norm().item()
+            scale = max(gr.double().norm().item(), 1e-3 * math.sqrt(gr.numel()) * 1e-2)
         worst.append((err / scale, n, err, scale))
     worst.sort(reverse=True)
     if verbose:
         for r in worst[:8]:
-            print("  grad rel %.2e  %s (abs %.2e, scale %.2e)" % r)
-    assert worst[0][0] <= grad_tol, "gradient mismatch: %s rel %.3e" % (worst[0][1], worst[0][0])
+            print("  grad rel(%s) %.2e  %s (abs %.2e, scale %.2e)" % ((metric,) + r))
+    assert worst[0][0] <= grad_tol, "gradient mismatch (%s): %s rel %.3e" % (metric, worst[0][1], worst[0][0])
     return worst
