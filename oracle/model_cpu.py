@@ -39,7 +39,7 @@ class LidarCenterNet(nn.Module):
 
     def forward_gru(self, z, target_point):  # model.py:611-646
         z = self.join(z)
-        x = torch.zeros(z.shape[0], 2, dtype=z.dtype)
+        x = torch.zeros(z.shape[0], 2, dtype=z.dtype, device=z.device)
         tp = target_point.clone()
         tp[:, 1] *= -1
         wps = []

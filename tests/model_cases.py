@@ -131,3 +131,54 @@ def compare(prod, ref, lp, lr, loss_tol=1e-3, grad_tol=2e-3, verbose=False, metr
             print("  grad rel(%s) %.2e  %s (abs %.2e, scale %.2e)" % ((metric,) + r))
     assert worst[0][0] <= grad_tol, "gradient mismatch (%s): %s rel %.3e" % (metric, worst[0][1], worst[0][0])
     return worst
+
+
+def compare_vs_fp64(prod, ref32, lp, lr32, batch, cfg, out_tol=1e-3, verbose=True):
+    """Accuracy relative to the TRUE (fp64) result.  The full-width model's fp32 gradients are only accurate to
+    ~1e-2 relative-L2 per tensor on ANY fp32 implementation (measured: oracle-fp32 vs oracle-fp64 median 1.2e-2), so
+    instead of fp32-vs-fp32 we check that the HIP path is as close to fp64 as the reference CPU fp32 path is:
+      * the 11 losses and the forward outputs within out_tol of fp64 (north_star: 1e-3 fp32),
+      * per parameter tensor  e_hip = |g_hip - g64|_2 / |g64|_2  <=  4 * e_cpu32 + 2e-3, and median(e_hip) <= 2 * median(e_cpu32)."""
+    last = ref32.__dict__.pop('_last', None)   # non-leaf tensors cannot be deep-copied
+    ref64 = copy.deepcopy(ref32).double()
+    ref32._last = last
+    for p in ref64.parameters():
+        p.grad = None
+    b64 = {k: (v.double() if v.dtype == torch.float32 else v) for k, v in batch.items()}
+    ref64.train()
+    l64 = ref64(b64['rgb'], b64['lidar'], ego_waypoint=b64['ego_waypoint'], target_point=b64['target_point'], target_point_image=b64['target_point_image'],
+                ego_vel=b64['ego_vel'].reshape(-1, 1), bev=b64['bev'], label=b64['label'], depth=b64['depth'], semantic=b64['semantic'])
+    w = dict(zip(cfg.detailed_losses, [1.0, 1.0, 1.0, 1.0, 0.2, 0.2, 0.2, 0.2, 0.2, 0.3, 0.4]))
+    sum(w[k] * v for k, v in l64.items()).backward()
+    for k in l64:
+        a, b = float(lp[k]), float(l64[k])
+        assert abs(a - b) <= out_tol * max(1.0, abs(b)), "loss %s: hip %g vs fp64 %g" % (k, a, b)
+    o, o64 = prod._last, ref64._last
+    outs = [("pred_wp", o["pred_wp"], o64["pred_wp"]), ("fused_features", o["fused"], o64["fused"]),
+            ("image_features_grid", o["grid"].permute(0, 3, 1, 2), o64["grid"]), ("p2", o["features"][0].permute(0, 3, 1, 2), o64["features"][0]),
+            ("pred_bev", o["bev_up"].permute(0, 3, 1, 2), o64["pred_bev"])]
+    for name, a, b in outs:
+        a, b = a.detach().cpu().double(), b.detach()
+        err = (a - b).abs().max().item()
+        assert err <= out_tol * max(1.0, b.abs().max().item()), "output %s: max err %.3e (scale %.3e)" % (name, err, b.abs().max().item())
+        if verbose:
+            print("  output %-20s max err %.2e (scale %.2e)" % (name, err, b.abs().max().item()))
+    p32, p64 = dict(ref32.named_parameters()), dict(ref64.named_parameters())
+    rows = []
+    for n, p in prod.named_parameters():
+        g64 = p64[n].grad
+        nrm = g64.norm().item()
+        e_cpu = (p32[n].grad.double() - g64).norm().item() / max(nrm, 1e-30)
+        e_hip = (p.grad.detach().cpu().double() - g64).norm().item() / max(nrm, 1e-30)
+        rows.append((e_hip, e_cpu, n, nrm))
+    live = [r for r in rows if r[1] < 0.5]   # drop tensors whose true gradient is zero up to round-off (e.g. attn.key.bias: softmax shift invariance)
+    med_hip = sorted(r[0] for r in live)[len(live) // 2]
+    med_cpu = sorted(r[1] for r in live)[len(live) // 2]
+    if verbose:
+        print("  gradient rel-L2 error vs fp64: median hip %.2e, median cpu-fp32 %.2e over %d tensors (%d noise-only skipped)" % (med_hip, med_cpu, len(live), len(rows) - len(live)))
+        for r in sorted(live, key=lambda r: -(r[0] / (4 * r[1] + 2e-3)))[:6]:
+            print("    hip %.2e  cpu32 %.2e  %s (|g64| %.2e)" % r)
+    assert med_hip <= 2.0 * med_cpu + 1e-4, (med_hip, med_cpu)
+    bad = [r for r in live if r[0] > 4 * r[1] + 2e-3]
+    assert not bad, "gradients further from fp64 than the CPU fp32 reference: %s" % (bad[:5],)
+    return med_hip, med_cpu

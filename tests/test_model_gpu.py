@@ -37,7 +37,7 @@ def test_regnety032_model_losses_and_grads(H, B):
     assert sum(p.numel() for p in prod.parameters()) == 168018327
     batch = synthetic_batch(B, H, 704, seed=0, hist_fn=hist.lidar_to_histogram_features, n_points=8192)
     lp, lr = mc.run_pair(prod, ref, cfg, batch, "cuda")
-    mc.compare(prod, ref, lp, lr, loss_tol=1e-3, grad_tol=1e-2, verbose=True, metric="l2")
+    mc.compare_vs_fp64(prod, ref, lp, lr, batch, cfg)
 
 
 def test_engine_graph_replay_matches_eager():

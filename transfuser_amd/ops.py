@@ -48,6 +48,24 @@ def wptr(w):
 
 
 # ------------------------------------------------------------------------------------------ GEMM
+census = None   # set to a list to record (kind, shape, flops, start_event, end_event) of every MFMA-engine call (tools/census.py)
+
+
+def _census_begin():
+    if census is None:
+        return None
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
+
+
+def _census_end(e0, kind, shape, flops):
+    if e0 is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        census.append((kind, shape, flops, e0, e1))
+
+
 _CHECK = bool(int(__import__("os").environ.get("TF_CHECK", "0")))  # debug aid: verify every GEMM against fp64 ATen (slow)
 
 
@@ -76,7 +94,9 @@ def gemm(a, b, c, m, n, k, lda, ldb, ldc, a_trans=False, b_trans=False, bias=Non
     d = GemmDesc(a=ptr(a), b=ptr(b), c=ptr(c), bias=ptr(bias), res=ptr(res), m=m, n=n, k=k, a_trans=int(a_trans), b_trans=int(b_trans),
                  lda=lda, ldb=ldb, ldc=ldc, ldres=ldres, batch=batch, inner=inner, sa_outer=sa[0], sa_inner=sa[1], sb_outer=sb[0],
                  sb_inner=sb[1], sc_outer=sc[0], sc_inner=sc[1], alpha=alpha, relu=int(relu), accumulate=int(accumulate))
+    _e = _census_begin()
     check(L().tf_gemm_f32(byref(d), stream_of(c)), "tf_gemm_f32")
+    _census_end(_e, "gemm a%db%d" % (a_trans, b_trans), (m, n, k, batch), 2.0 * m * n * k * batch)
     if _CHECK and c.is_cuda:
         got = cview().double()
         err = (got - ref).abs().max().item()
@@ -126,12 +146,22 @@ def conv_geom(x_shape, cout, ksize, stride, pad, groups):
     return ConvGeom(B, Hi, Wi, Cin, Ho, Wo, cout, ksize, stride, pad, groups)
 
 
+def _gshape(g):
+    return (g.B, g.Hi, g.Wi, g.Cin, g.Cout, g.ksize, g.stride, g.groups)
+
+
+def _gflops(g):
+    return 2.0 * g.B * g.Ho * g.Wo * g.Cout * (g.Cin // g.groups) * g.ksize * g.ksize
+
+
 def conv_fwd(x, w, bias=None, stride=1, pad=None, groups=1, relu=False):
     ks = w.shape[2]
     pad = ks // 2 if pad is None else pad
     g = conv_geom(x.shape, w.shape[0], ks, stride, pad, groups)
     y = torch.empty(g.B, g.Ho, g.Wo, g.Cout, dtype=torch.float32, device=x.device)
+    _e = _census_begin()
     check(L().tf_conv2d_fwd_f32(byref(g), ptr(_c(x)), wptr(w), ptr(bias), ptr(y), int(relu), stream_of(x)), "tf_conv2d_fwd_f32")
+    _census_end(_e, "conv fwd", _gshape(g), _gflops(g))
     return y
 
 
@@ -141,7 +171,9 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=None, groups=1, out=None, accumulat
     g = conv_geom(x_shape, w.shape[0], ks, stride, pad, groups)
     if out is None:
         out = torch.empty(tuple(x_shape), dtype=torch.float32, device=dy.device)
+    _e = _census_begin()
     check(L().tf_conv2d_dgrad_f32(byref(g), ptr(_c(dy)), wptr(w), ptr(_c(out)), int(accumulate), stream_of(dy)), "tf_conv2d_dgrad_f32")
+    _census_end(_e, "conv dgrad", _gshape(g), _gflops(g))
     return out
 
 
@@ -149,7 +181,9 @@ def conv_wgrad(dy, x, dw, stride=1, pad=None, groups=1, accumulate=True):
     ks = dw.shape[2]
     pad = ks // 2 if pad is None else pad
     g = conv_geom(x.shape, dw.shape[0], ks, stride, pad, groups)
+    _e = _census_begin()
     check(L().tf_conv2d_wgrad_f32(byref(g), ptr(_c(dy)), ptr(_c(x)), wptr(dw), int(accumulate), stream_of(dy)), "tf_conv2d_wgrad_f32")
+    _census_end(_e, "conv wgrad", _gshape(g), _gflops(g))
     return dw
 
 
