@@ -1,0 +1,94 @@
+#!/usr/bin/env python
+"""Generates tests/golden/*.npz from the REFERENCE ITSELF: team_code_transfuser/transfuser.py imported unmodified
+from /root/reference on top of oracle/timm_shim (authoring container only; /root/reference does not exist on the
+GPU box, which is why the vectors are committed).  Re-run: python tests/golden/make_golden.py
+
+Weights are not stored: both sides fill every state_dict entry from one seeded generator in sorted-key order
+(`seeded_fill`), so the fixture only holds inputs' seeds and the reference's outputs."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
+sys.path.insert(0, ROOT)
+TINY = dict(widths=[24, 48, 72, 96], depths=[1, 2, 1, 1], group_w=24, se_ratio=0.25)
+
+
+def seeded_fill(module, seed=1234):
+    g = torch.Generator().manual_seed(seed)
+    sd = module.state_dict()
+    with torch.no_grad():
+        for k in sorted(sd):
+            v = sd[k]
+            if not v.dtype.is_floating_point:
+                continue
+            if k.endswith("running_var"):
+                v.copy_(torch.rand(v.shape, generator=g) + 0.5)
+            elif "bn" in k and k.endswith("weight"):
+                v.copy_(torch.rand(v.shape, generator=g) * 0.5 + 0.75)
+            else:
+                v.copy_(torch.randn(v.shape, generator=g) * (0.3 / max(1.0, float(np.sqrt(v[0].numel()))) if v.dim() > 1 else 0.1))
+
+
+def golden_config():
+    from transfuser_amd.config import GlobalConfig
+    cfg = GlobalConfig()
+    cfg.n_layer = 2
+    cfg.use_target_point_image = True
+    cfg.embd_pdrop = cfg.attn_pdrop = cfg.resid_pdrop = 0.0
+    return cfg
+
+
+def golden_inputs(seed=7):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randint(0, 256, (2, 3, 64, 128), generator=g).float(), torch.rand(2, 3, 64, 64, generator=g), torch.rand(2, 1, generator=g) * 8)
+
+
+def main():
+    sys.path.insert(0, os.path.join(ROOT, "oracle", "timm_shim"))
+    sys.path.insert(0, "/root/reference/team_code_transfuser")
+    import timm
+    from oracle import regnet as oreg, hist
+    timm.register("regnety_tiny", lambda: oreg.RegNet(TINY["widths"], TINY["depths"], TINY["group_w"], TINY["se_ratio"]))
+    import transfuser as ref   # the reference module, unmodified
+    cfg = golden_config()
+    out = {}
+    for use_vel in (False, True):
+        torch.manual_seed(0)
+        m = ref.TransfuserBackbone(cfg, "regnety_tiny", "regnety_tiny", use_velocity=use_vel)
+        seeded_fill(m)
+        for mode in ("train", "eval"):
+            getattr(m, mode)()
+            img, lid, vel = golden_inputs()
+            with torch.no_grad():
+                feats, grid, fused = m(img, lid, vel)
+            tag = "vel%d_%s" % (use_vel, mode)
+            for i, f in enumerate(feats):
+                out["%s_p%d" % (tag, i + 2)] = f.numpy()
+            out[tag + "_grid"] = grid.numpy()
+            out[tag + "_fused"] = fused.numpy()
+            seeded_fill(m)   # train-mode forward updated the running stats: reset for the next case
+    seg, dep = ref.SegDecoder(cfg, 512), ref.DepthDecoder(cfg, 512)
+    seeded_fill(seg, 5); seeded_fill(dep, 6)
+    x = torch.randn(2, 512, 2, 4, generator=torch.Generator().manual_seed(9))
+    with torch.no_grad():
+        out["seg"] = seg(x).numpy()
+        out["depth"] = dep(x).numpy()
+        out["normalize_imagenet"] = ref.normalize_imagenet(golden_inputs()[0]).numpy()[:, :, :4, :8]
+    np.savez_compressed(os.path.join(HERE, "transfuser_backbone_tiny.npz"), **out)
+    # H1: numpy.histogramdd (the reference's algorithm, data.py:446-470) on a seeded cloud with edge cases -> sparse golden
+    rng = np.random.default_rng(3)
+    pts = np.stack([rng.uniform(-20, 20, 20000), rng.uniform(-36, 4, 20000), rng.uniform(-4, 1, 20000)], 1).astype(np.float32)
+    pts[:40, 0] = 16.0; pts[40:80, 1] = 0.0; pts[80:120, 0] = -16.0; pts[120:160, 1] = -32.0; pts[160:200, 2] = -2.3
+    pts[200:700, :2] = np.round(pts[200:700, :2] * 8) / 8
+    h = hist.lidar_to_histogram_features(pts)
+    idx = np.nonzero(h)
+    np.savez_compressed(os.path.join(HERE, "lidar_hist.npz"), points=pts, idx=np.stack(idx).astype(np.int16), val=(h[idx] * 5).round().astype(np.uint8))
+    print("wrote", sorted(os.listdir(HERE)))
+
+
+if __name__ == "__main__":
+    main()

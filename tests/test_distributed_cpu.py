@@ -1,0 +1,64 @@
+"""Data-parallel path on CPU: world_size 2, gloo.  Checks the arena layout (k/q/v adjacency), the bucketed gradient
+mean (== DDP semantics of train.py:134) and the initial parameter broadcast of transfuser_amd.train.GradReducer."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+class _Attn(torch.nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.key, self.query, self.value, self.proj = [torch.nn.Linear(c, c) for _ in range(4)]
+
+
+class _Net(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.stem = torch.nn.Conv2d(3, 8, 3)
+        self.attn = _Attn(12)
+        self.head = torch.nn.Linear(12, 5)
+
+
+def _worker(rank, world, port):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import ctypes
+    import build_emu
+    from transfuser_amd import _lib
+    _lib._install_test_backend(ctypes.CDLL(build_emu.build()))   # scale kernel runs host-emulated in this CPU test
+    from transfuser_amd.train import GradReducer, ParamArena
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)   # different init per rank: broadcast must equalise
+    net = _Net()
+    arena = ParamArena(net)
+    a = net.attn
+    assert a.query.weight.data_ptr() == a.key.weight.data_ptr() + a.key.weight.numel() * 4
+    assert a.value.weight.data_ptr() == a.query.weight.data_ptr() + a.query.weight.numel() * 4
+    assert a.value.bias.data_ptr() == a.key.bias.data_ptr() + 2 * a.key.bias.numel() * 4
+    assert a.query.weight.grad.data_ptr() == a.key.weight.grad.data_ptr() + a.key.weight.numel() * 4
+    red = GradReducer(arena, bucket_mb=0.0005)   # forces many buckets
+    assert len(red.buckets) > 3
+    red.broadcast_params()
+    ref = [torch.zeros_like(arena.params) for _ in range(world)]
+    dist.all_gather(ref, arena.params)
+    assert torch.equal(ref[0], ref[1])
+    g = torch.Generator().manual_seed(7 + rank)
+    for p in net.parameters():
+        p.grad.copy_(torch.randn(p.shape, generator=g))
+    mine = arena.grads.clone()
+    both = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(both, mine)
+    red.reduce()
+    assert torch.allclose(arena.grads, (both[0] + both[1]) / world, atol=1e-6)
+    assert torch.allclose(net.head.weight.grad, ((both[0] + both[1]) / world)[net.head.weight.grad.storage_offset():][:60].view(5, 12), atol=1e-6)
+    dist.destroy_process_group()
+
+
+def test_grad_reducer_world2_gloo():
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port), nprocs=2, join=True)

@@ -22,11 +22,14 @@ from . import ops
 _ALIGN = 64  # floats (256 B): keeps every parameter 16-byte aligned for float4 / buffer loads
 
 
+_KQV = __import__("re").compile(r"(^|\.)attn\.(key|query|value)\.")
+
+
 def _group_key(name):
     """Parameters that must be adjacent: attention key/query/value weights (and biases) per layer."""
-    for part, rank in ((".attn.key.", 0), (".attn.query.", 1), (".attn.value.", 2)):
-        if part in name:
-            return name.replace(part, ".attn.KQV."), rank
+    m = _KQV.search(name)
+    if m:
+        return name[:m.start(2)] + "KQV" + name[m.end(2):], ("key", "query", "value").index(m.group(2))
     return name, 0
 
 
