@@ -26,7 +26,7 @@ extern "C" int tf_conv2d_fwd_f32(const tf_conv_geom* g, const float* x, const fl
     Bw.p = w; Bw.ld = K; Bw.rows = Cog; Bw.cols = K; Bw.s_outer = 0; Bw.s_inner = (long)Cog * K; Bw.inner = g->groups;
     Bw.vec = (aligned16(w) && K % 4 == 0) ? 1 : 0;
     GemmEpi ep;
-    ep.C = y; ep.ldc = g->Cout; ep.sc_outer = 0; ep.sc_inner = Cog; ep.inner = g->groups; ep.bias = bias; ep.sbias = Cog;
+    ep.C = y; ep.ldc = g->Cout; ep.ldcj = 1; ep.sc_outer = 0; ep.sc_inner = Cog; ep.inner = g->groups; ep.bias = bias; ep.sbias = Cog;
     ep.res = nullptr; ep.ldres = 0; ep.alpha = 1.f; ep.relu = relu; ep.mode = 0;
     return launch_gemm<Im2colOp, true, PlainOp, true>(A, Bw, ep, M, Cog, K, g->groups, false, stream, "tf_conv2d_fwd_f32");
 }
@@ -43,7 +43,7 @@ extern "C" int tf_conv2d_dgrad_f32(const tf_conv_geom* g, const float* dy, const
     Bw.w = w; Bw.taps = taps; Bw.Cog = Cog; Bw.Cig = Cig; Bw.rows = K; Bw.cols = Cig; Bw.gstride = (long)Cog * taps * Cig;
     Bw.vec = (aligned16(w) && Cig % 4 == 0) ? 1 : 0;
     GemmEpi ep;
-    ep.C = dx; ep.ldc = g->Cin; ep.sc_outer = 0; ep.sc_inner = Cig; ep.inner = g->groups; ep.bias = nullptr; ep.sbias = 0;
+    ep.C = dx; ep.ldc = g->Cin; ep.ldcj = 1; ep.sc_outer = 0; ep.sc_inner = Cig; ep.inner = g->groups; ep.bias = nullptr; ep.sbias = 0;
     ep.res = nullptr; ep.ldres = 0; ep.alpha = 1.f; ep.relu = 0; ep.mode = accumulate ? 1 : 0;
     return launch_gemm<Im2colTOp, true, WDgradOp, false>(A, Bw, ep, M, Cig, K, g->groups, false, stream, "tf_conv2d_dgrad_f32");
 }
@@ -61,8 +61,14 @@ extern "C" int tf_conv2d_wgrad_f32(const tf_conv_geom* g, const float* dy, const
     Bx.pad = g->pad; Bx.Cg = Cig; Bx.rows = Mred; Bx.cols = Ncols; Bx.coff = 0;
     Bx.vec = (aligned16(x) && Cig % 4 == 0 && g->Cin % 4 == 0) ? 1 : 0;
     GemmEpi ep;
-    ep.C = dw; ep.ldc = Ncols; ep.sc_outer = 0; ep.sc_inner = (long)Cog * Ncols; ep.inner = g->groups; ep.bias = nullptr; ep.sbias = 0;
+    ep.C = dw; ep.ldc = Ncols; ep.ldcj = 1; ep.sc_outer = 0; ep.sc_inner = (long)Cog * Ncols; ep.inner = g->groups; ep.bias = nullptr; ep.sbias = 0;
     ep.res = nullptr; ep.ldres = 0; ep.alpha = 1.f; ep.relu = 0; ep.mode = accumulate ? 1 : 0;
+    if (Cog <= 32) {
+        // few output channels per group (RegNet group width 24, decoder / head tails with 32, 7, 1): compute dW^T -
+        // rows = (tap, ci), cols = co - so Cog sits in a 32-wide column tile instead of a 128-row tile.
+        ep.ldc = 1; ep.ldcj = Ncols;
+        return launch_gemm<Im2colOp, false, PlainOp, false>(Bx, A, ep, Ncols, Cog, Mred, g->groups, true, stream, "tf_conv2d_wgrad_f32[swapped]");
+    }
     return launch_gemm<PlainOp, false, Im2colOp, false>(A, Bx, ep, Cog, Ncols, Mred, g->groups, true, stream, "tf_conv2d_wgrad_f32");
 }
 
@@ -85,7 +91,7 @@ extern "C" int tf_stem_conv_fwd_f32(const tf_conv_geom* g, const float* s0, int 
     PlainOp Bw;
     Bw.p = w; Bw.ld = K; Bw.rows = g->Cout; Bw.cols = K; Bw.s_outer = 0; Bw.s_inner = 0; Bw.inner = 1; Bw.vec = 0;
     GemmEpi ep;
-    ep.C = y; ep.ldc = g->Cout; ep.sc_outer = 0; ep.sc_inner = 0; ep.inner = 1; ep.bias = nullptr; ep.sbias = 0; ep.res = nullptr; ep.ldres = 0;
+    ep.C = y; ep.ldc = g->Cout; ep.ldcj = 1; ep.sc_outer = 0; ep.sc_inner = 0; ep.inner = 1; ep.bias = nullptr; ep.sbias = 0; ep.res = nullptr; ep.ldres = 0;
     ep.alpha = 1.f; ep.relu = 0; ep.mode = 0;
     return launch_gemm<Im2colNchwOp, true, PlainOp, true>(A, Bw, ep, M, g->Cout, K, 1, false, stream, "tf_stem_conv_fwd_f32");
 }
@@ -100,7 +106,7 @@ extern "C" int tf_stem_conv_wgrad_f32(const tf_conv_geom* g, const float* dy, co
     A.vec = (aligned16(dy) && g->Cout % 4 == 0) ? 1 : 0;
     Im2colNchwOp Bx = make_stem(g, s0, C0, s1, C1, normalize);
     GemmEpi ep;
-    ep.C = dw; ep.ldc = K; ep.sc_outer = 0; ep.sc_inner = 0; ep.inner = 1; ep.bias = nullptr; ep.sbias = 0; ep.res = nullptr; ep.ldres = 0;
+    ep.C = dw; ep.ldc = K; ep.ldcj = 1; ep.sc_outer = 0; ep.sc_inner = 0; ep.inner = 1; ep.bias = nullptr; ep.sbias = 0; ep.res = nullptr; ep.ldres = 0;
     ep.alpha = 1.f; ep.relu = 0; ep.mode = accumulate ? 1 : 0;
     return launch_gemm<PlainOp, false, Im2colNchwOp, false>(A, Bx, ep, g->Cout, K, M, 1, true, stream, "tf_stem_conv_wgrad_f32");
 }

@@ -4,6 +4,14 @@
 
 using namespace tf;
 
+namespace tf {
+int smallm_fwd(const float* x, long ldx, const float* w, long ldw, const float* bias, const float* res, long ldres, float* y, long ldy, int M, int N,
+               int K, int relu, void* stream);
+int smallm_dgrad(const float* dy, long lddy, const float* w, long ldw, const float* res, long ldres, float* dx, long lddx, int M, int N, int K,
+                 int accumulate, void* stream);
+int smallm_wgrad(const float* dy, long lddy, const float* x, long ldx, float* dw, long lddw, int M, int N, int K, int accumulate, void* stream);
+}
+
 static PlainOp make_plain(const float* p, long ld, int rows, int cols, long so, long si, int inner, int batch) {
     PlainOp o;
     o.p = p; o.ld = ld; o.rows = rows; o.cols = cols; o.s_outer = so; o.s_inner = si; o.inner = inner > 0 ? inner : 1;
@@ -18,8 +26,17 @@ extern "C" int tf_gemm_f32(const tf_gemm_desc* d, void* stream) {
     TF_REQUIRE(d->m >= 0 && d->n >= 0 && d->k >= 0 && d->batch >= 1, "tf_gemm_f32: bad sizes m=%d n=%d k=%d batch=%d", d->m, d->n,
                d->k, d->batch);
     const int inner = d->inner > 0 ? d->inner : 1;
+    // per-sample matmuls (SE excitation, join MLP): rows = batch <= 16 -> streaming kernels instead of a 128-row MFMA tile
+    if (d->batch == 1 && d->alpha == 1.0f && d->m > 0 && d->n > 0 && d->k > 0) {
+        if (!d->a_trans && !d->b_trans && d->m <= 16 && !d->accumulate)
+            return smallm_fwd(d->a, d->lda, d->b, d->ldb, d->bias, d->res, d->ldres, d->c, d->ldc, d->m, d->n, d->k, d->relu, stream);
+        if (!d->a_trans && d->b_trans && d->m <= 16 && !d->bias && !d->relu)
+            return smallm_dgrad(d->a, d->lda, d->b, d->ldb, d->res, d->ldres, d->c, d->ldc, d->m, d->k, d->n, d->accumulate, stream);
+        if (d->a_trans && d->b_trans && d->k <= 16 && !d->bias && !d->res && !d->relu)
+            return smallm_wgrad(d->a, d->lda, d->b, d->ldb, d->c, d->ldc, d->k, d->m, d->n, d->accumulate, stream);
+    }
     GemmEpi ep;
-    ep.C = d->c; ep.ldc = d->ldc; ep.sc_outer = d->sc_outer; ep.sc_inner = d->sc_inner; ep.inner = inner;
+    ep.C = d->c; ep.ldc = d->ldc; ep.ldcj = 1; ep.sc_outer = d->sc_outer; ep.sc_inner = d->sc_inner; ep.inner = inner;
     ep.bias = d->bias; ep.sbias = 0; ep.res = d->res; ep.ldres = d->ldres; ep.alpha = d->alpha; ep.relu = d->relu;
     ep.mode = d->accumulate ? 1 : 0;
     // A: KC when stored [m][k] (rows = i), IC when stored [k][m] (rows = k)
@@ -31,6 +48,14 @@ extern "C" int tf_gemm_f32(const tf_gemm_desc* d, void* stream) {
     const bool sk = d->accumulate != 0;
     if (!d->a_trans && !d->b_trans) return launch_gemm<PlainOp, true, PlainOp, true>(A, B, ep, d->m, d->n, d->k, d->batch, sk, stream, "tf_gemm_f32[nt]");
     if (!d->a_trans && d->b_trans) return launch_gemm<PlainOp, true, PlainOp, false>(A, B, ep, d->m, d->n, d->k, d->batch, sk, stream, "tf_gemm_f32[nn]");
-    if (d->a_trans && d->b_trans) return launch_gemm<PlainOp, false, PlainOp, false>(A, B, ep, d->m, d->n, d->k, d->batch, sk, stream, "tf_gemm_f32[tn]");
+    if (d->a_trans && d->b_trans) {
+        // weight gradient with few output rows (m = out features <= 32 << n): compute C^T so the short side becomes the
+        // 32-wide column tile instead of a 128-row tile (4x less MFMA padding); stores go through the column stride.
+        if (d->m <= 32 && d->n >= 2 * d->m && !d->bias && !d->res && !d->relu) {
+            ep.ldc = 1; ep.ldcj = d->ldc;
+            return launch_gemm<PlainOp, false, PlainOp, false>(B, A, ep, d->n, d->m, d->k, d->batch, sk, stream, "tf_gemm_f32[tn,swapped]");
+        }
+        return launch_gemm<PlainOp, false, PlainOp, false>(A, B, ep, d->m, d->n, d->k, d->batch, sk, stream, "tf_gemm_f32[tn]");
+    }
     return launch_gemm<PlainOp, false, PlainOp, true>(A, B, ep, d->m, d->n, d->k, d->batch, sk, stream, "tf_gemm_f32[tt]");
 }

@@ -149,28 +149,36 @@ inline void launch_reduce(const RedPlan& p, const F4& f4, const F1& f1, int rows
     else TF_LAUNCH((colreduce_kernel<1, NACC, F1>), grid, dim3(256), stream, f1, rows_per_seg, C, p.CTV, p.rows_per_chunk, ws);
 }
 
-// ---- finalize kernels --------------------------------------------------------------------------
-// out[seg][c] (+)= scale * sum_chunks ws[seg][chunk][0][c]
-__global__ void colsum_finalize_kernel(const float* __restrict__ ws, float* __restrict__ out, int C, int nch, int nseg, float scale, int accumulate) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= nseg * C) return;
-    const int seg = i / C, c = i - seg * C;
+// ---- finalize kernels: one wave per channel, lanes sum the chunk partials (was: one thread per channel
+// walking up to 64 dependent loads = ~19 us per BatchNorm; now a shuffle tree) -------------------------------------------
+__device__ __forceinline__ float chunk_sum(const float* __restrict__ p, long stride, int nch, int lane, bool live) {
     float s = 0.f;
-    for (int j = 0; j < nch; ++j) s += ws[((long)seg * nch + j) * C + c];
-    s *= scale;
-    if (accumulate) out[i] += s; else out[i] = s;
+    if (live)
+        for (int j = lane; j < nch; j += 64) s += p[(long)j * stride];
+    return wave_sum(s);
+}
+
+// out[seg][c] (+)= scale * sum_chunks ws[seg][chunk][0][c]
+__global__ void __launch_bounds__(256) colsum_finalize_kernel(const float* __restrict__ ws, float* __restrict__ out, int C, int nch, int nseg, float scale,
+                                                              int accumulate) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const bool live = i < nseg * C;
+    const int seg = live ? i / C : 0, c = live ? i - seg * C : 0;
+    float s = chunk_sum(ws + (long)seg * nch * C + c, C, nch, lane, live) * scale;
+    if (live && lane == 0) { if (accumulate) out[i] += s; else out[i] = s; }
 }
 
 // BN training statistics (torch BatchNorm2d train mode: biased var for normalisation, unbiased for
 // running_var, momentum 0.1, eps 1e-5 - timm BatchNormAct2d).  coef = [scale | shift] (2*C).
-__global__ void bn_fwd_finalize_kernel(const float* __restrict__ ws, const float* __restrict__ K, const float* __restrict__ gamma,
-                                       const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
-                                       float* __restrict__ save_mean, float* __restrict__ save_invstd, float* __restrict__ coef, int C, int nch,
-                                       float n, float momentum, float eps) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    float s1 = 0.f, s2 = 0.f;
-    for (int j = 0; j < nch; ++j) { s1 += ws[((long)j * 2 + 0) * C + c]; s2 += ws[((long)j * 2 + 1) * C + c]; }
+__global__ void __launch_bounds__(256) bn_fwd_finalize_kernel(const float* __restrict__ ws, const float* __restrict__ K, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
+                                                              float* __restrict__ save_mean, float* __restrict__ save_invstd, float* __restrict__ coef,
+                                                              int C, int nch, float n, float momentum, float eps) {
+    const int c0 = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const bool live = c0 < C;
+    const int c = live ? c0 : 0;
+    const float s1 = chunk_sum(ws + c, 2L * C, nch, lane, live), s2 = chunk_sum(ws + C + c, 2L * C, nch, lane, live);
+    if (!live || lane != 0) return;
     const float dm = s1 / n;
     const float mean = K[c] + dm;
     float var = s2 / n - dm * dm;
@@ -196,13 +204,14 @@ __global__ void bn_eval_coef_kernel(const float* __restrict__ gamma, const float
     coef[C + c] = beta[c] - rmean[c] * sc;
 }
 // dgamma += sum g*xhat, dbeta += sum g; dx = A*g + Bc*x + Cc  (coef = [A | Bc | Cc])
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ ws, const float* __restrict__ gamma, const float* __restrict__ mean,
-                                       const float* __restrict__ invstd, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                       float* __restrict__ coef, int C, int nch, float n) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    float sg = 0.f, sgx = 0.f;
-    for (int j = 0; j < nch; ++j) { sg += ws[((long)j * 2 + 0) * C + c]; sgx += ws[((long)j * 2 + 1) * C + c]; }
+__global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const float* __restrict__ ws, const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                              const float* __restrict__ invstd, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                              float* __restrict__ coef, int C, int nch, float n) {
+    const int c0 = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const bool live = c0 < C;
+    const int c = live ? c0 : 0;
+    const float sg = chunk_sum(ws + c, 2L * C, nch, lane, live), sgx = chunk_sum(ws + C + c, 2L * C, nch, lane, live);
+    if (!live || lane != 0) return;
     if (dgamma) dgamma[c] += sgx;
     if (dbeta) dbeta[c] += sg;
     const float A = gamma[c] * invstd[c];
@@ -212,14 +221,16 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ ws, const float
     coef[2 * C + c] = -A * (sg / n) - Bc * mean[c];
 }
 // dgate_pre[b][c] = (sum_hw dy*x) * s * (1 - s), s = sigmoid(gate)
-__global__ void se_bwd_finalize_kernel(const float* __restrict__ ws, const float* __restrict__ gate, float* __restrict__ dgate, int C, int nch, int nseg) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= nseg * C) return;
-    const int seg = i / C, c = i - seg * C;
-    float s = 0.f;
-    for (int j = 0; j < nch; ++j) s += ws[((long)seg * nch + j) * C + c];
-    const float sg = 1.f / (1.f + expf(-gate[i]));
-    dgate[i] = s * sg * (1.f - sg);
+__global__ void __launch_bounds__(256) se_bwd_finalize_kernel(const float* __restrict__ ws, const float* __restrict__ gate, float* __restrict__ dgate, int C,
+                                                              int nch, int nseg) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const bool live = i < nseg * C;
+    const int seg = live ? i / C : 0, c = live ? i - seg * C : 0;
+    const float s = chunk_sum(ws + (long)seg * nch * C + c, C, nch, lane, live);
+    if (live && lane == 0) {
+        const float sg = 1.f / (1.f + expf(-gate[i]));
+        dgate[i] = s * sg * (1.f - sg);
+    }
 }
 
 // ---- per-channel elementwise passes (grid-stride over vectors) ------------------------------------
@@ -325,7 +336,7 @@ extern "C" int tf_bn_fwd_f32(const float* x, int rows, int C, const float* gamma
         BnStatF<4> f4{x, x, C};  // shift K = first row of x
         BnStatF<1> f1{x, x, C};
         launch_reduce<2>(p, f4, f1, rows, C, 1, ws, stream);
-        TF_LAUNCH(bn_fwd_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), stream, (const float*)ws, x, gamma, beta, running_mean, running_var,
+        TF_LAUNCH(bn_fwd_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), stream, (const float*)ws, x, gamma, beta, running_mean, running_var,
                   save_mean, save_invstd, coef, C, p.nchunks, (float)rows, momentum, eps);
     } else {
         TF_REQUIRE(running_mean && running_var, "tf_bn_fwd_f32: eval needs running statistics");
@@ -349,7 +360,7 @@ extern "C" int tf_bn_bwd_f32(const float* dz, const float* z, const float* x, in
     BnBwdF<4> f4{dz, z, x, save_mean, save_invstd, C};
     BnBwdF<1> f1{dz, z, x, save_mean, save_invstd, C};
     launch_reduce<2>(p, f4, f1, rows, C, 1, ws, stream);
-    TF_LAUNCH(bn_bwd_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), stream, (const float*)ws, gamma, save_mean, save_invstd, dgamma, dbeta, coef,
+    TF_LAUNCH(bn_bwd_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), stream, (const float*)ws, gamma, save_mean, save_invstd, dgamma, dbeta, coef,
               C, p.nchunks, (float)rows);
     const bool v4 = (C % 4 == 0) && aligned16(dz) && aligned16(x) && aligned16(dx) && (!z || aligned16(z)) && (!dres || aligned16(dres));
     const long n = (long)rows * C;
@@ -367,7 +378,7 @@ extern "C" int tf_colsum_f32(const float* x, const float* mask, int nseg, int ro
     MaskSumF<4> f4{x, mask, C};
     MaskSumF<1> f1{x, mask, C};
     launch_reduce<1>(p, f4, f1, rows_per_seg, C, nseg, ws, stream);
-    TF_LAUNCH(colsum_finalize_kernel, dim3(cdiv((long)nseg * C, 256)), dim3(256), stream, (const float*)ws, out, C, p.nchunks, nseg, scale, accumulate);
+    TF_LAUNCH(colsum_finalize_kernel, dim3(cdiv((long)nseg * C, 4)), dim3(256), stream, (const float*)ws, out, C, p.nchunks, nseg, scale, accumulate);
     return launch_status("tf_colsum_f32");
 }
 
@@ -388,7 +399,7 @@ extern "C" int tf_se_scale_bwd_gate_f32(const float* dy, const float* x, const f
     MulF<4> f4{dy, x, C};
     MulF<1> f1{dy, x, C};
     launch_reduce<1>(p, f4, f1, HW, C, B, ws, stream);
-    TF_LAUNCH(se_bwd_finalize_kernel, dim3(cdiv((long)B * C, 256)), dim3(256), stream, (const float*)ws, gate, dgate, C, p.nchunks, B);
+    TF_LAUNCH(se_bwd_finalize_kernel, dim3(cdiv((long)B * C, 4)), dim3(256), stream, (const float*)ws, gate, dgate, C, p.nchunks, B);
     return launch_status("tf_se_scale_bwd_gate_f32");
 }
 // dx (+)= dy * sigmoid(gate) + dmean / HW   (dy/gate pair optional, dmean optional): the input

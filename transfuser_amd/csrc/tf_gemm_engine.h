@@ -178,7 +178,7 @@ struct Im2colNchwOp {
 
 // ---------------------------------------------------------------- epilogue
 struct GemmEpi {
-    float* C; long ldc; long sc_outer, sc_inner; int inner;
+    float* C; long ldc; long ldcj; long sc_outer, sc_inner; int inner;   // element (i, j) at C[i*ldc + j*ldcj]
     const float* bias; long sbias;   // per-column bias; batch z adds z*sbias
     const float* res; long ldres;    // residual with C's batch strides
     float alpha; int relu; int mode; // mode 0: store, 1: +=, 2: atomicAdd
@@ -343,7 +343,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(LA la, LB lb, GemmEpi ep, int
                 float v = ep.alpha * acc[t][u][r] + bj;
                 if (res) v += res[(long)i * ep.ldres + j];
                 if (ep.relu) v = fmaxf(v, 0.f);
-                float* dst = C + (long)i * ep.ldc + j;
+                float* dst = C + (long)i * ep.ldc + (long)j * ep.ldcj;
                 if (ep.mode == 0) *dst = v;
                 else if (ep.mode == 1) *dst += v;
                 else atomicAdd(dst, v);
