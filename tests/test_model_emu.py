@@ -44,8 +44,13 @@ def test_engine_two_steps_match_oracle_adamw():
         tot_r, lr_ = model_cpu.train_step(ref, opt, batch, cfg)
         assert abs(float(tot_p) - float(tot_r)) <= 1e-3 * max(1.0, abs(float(tot_r))), (it, float(tot_p), float(tot_r))
     rp = dict(ref.named_parameters())
-    worst = max(((p.detach() - rp[n].detach()).abs().max().item(), n) for n, p in prod.named_parameters())
-    assert worst[0] < 2e-3, worst   # lr 1e-3 => each AdamW step moves a weight by <= ~1e-3
+    # AdamW moves a weight by ~lr * sign(g) when |g| is at round-off level, so two fp32 implementations may differ by
+    # up to 2*lr per step on isolated elements; everything else must agree closely.
+    diffs = [((p.detach() - rp[n].detach()).abs(), n) for n, p in prod.named_parameters()]
+    worst = max((d.max().item(), n) for d, n in diffs)
+    assert worst[0] < 4.4e-3, worst
+    mean = sum(d.sum().item() for d, _ in diffs) / sum(d.numel() for d, _ in diffs)
+    assert mean < 2e-5, mean
     # running BN statistics follow too
     rb = dict(ref.named_buffers())
     for n, b in prod.named_buffers():
