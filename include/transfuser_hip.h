@@ -22,6 +22,17 @@ extern "C" {
 int tf_version(void);
 const char* tf_last_error(void);
 
+/* GEMM tiling plans.  The reference turns on cudnn.benchmark (train.py:115); the equivalent here: while tf_autotune(1)
+ * is on (eager warm-up, NOT during graph capture - it synchronises), the first call of every distinct
+ * (entry point, M, N, K, batch) times the candidate tilings with HIP events and caches the winner.  Plans can be
+ * saved to / loaded from a text file (tf_plans_load returns the number of plans read). */
+int tf_autotune(int enable);
+int tf_force_plan(int bm, int bn, int bk, int splitk); /* tests: pin one tiling (bm = 0 clears) */
+int tf_plans_count(void);
+int tf_plans_clear(void);
+int tf_plans_save(const char* path);
+int tf_plans_load(const char* path);
+
 /* ---- dense contractions (fp32 MFMA, LDS-tiled) --------------------------------------------- */
 
 /* C[z] (op)= alpha * A[z] . B[z] (+bias[col]) (+res) (relu).  Replaces nn.Linear fwd/dgrad/wgrad

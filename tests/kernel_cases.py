@@ -410,3 +410,21 @@ def check_centernet(dev, B, crowded=False):
     (gp,) = torch.autograd.grad(total, [pred])
     dpred = ops.centernet_loss_bwd(pred.detach().to(dev), tgtf, tgti, cnt, gup.to(dev), nb)
     close(dpred, gp, tol=1e-4, what="centernet dpred")
+
+
+# ---------------------------------------------------------------- every engine tiling (BM x BN x BK, split-K)
+ENGINE_PLANS = [(128, 128, 16, 1), (128, 128, 32, 1), (128, 96, 16, 1), (128, 96, 32, 1), (128, 64, 32, 1), (128, 32, 32, 1), (64, 128, 32, 1),
+                (64, 64, 32, 1), (64, 64, 16, 3), (128, 32, 16, 2), (128, 96, 32, 2)]
+
+
+def check_engine_plan(dev, bm, bn, bk, splitk):
+    ops.force_plan(bm, bn, bk, splitk)
+    try:
+        check_gemm(dev, 130, 216, 40)
+        check_gemm(dev, 200, 90, 150)
+        check_attention(dev, 1, 2, 50, 54)
+        check_conv(dev, 2, 11, 13, 48, 48, 3, 2, 2)
+        check_conv(dev, 1, 9, 9, 72, 72, 3, 1, 1)
+        check_stem(dev, 1, 12, 20)
+    finally:
+        ops.force_plan(0)

@@ -87,3 +87,8 @@ def test_lidar_hist():
 @pytest.mark.parametrize("case", [(3, False), (2, True)], ids=str)
 def test_centernet_targets_and_losses(case):
     kc.check_centernet("cpu", *case)
+
+
+@pytest.mark.parametrize("plan", kc.ENGINE_PLANS, ids=str)
+def test_engine_tilings(plan):
+    kc.check_engine_plan("cpu", *plan)

@@ -2,6 +2,11 @@
 #include "tf_common.h"
 #include "../../include/transfuser_hip.h"
 #include <stdarg.h>
+#include <map>
+#include <mutex>
+#include <string>
+#include <tuple>
+#include "tf_gemm_engine.h"
 
 namespace tf {
 static thread_local char g_err[512] = "";
@@ -15,3 +20,68 @@ void set_error(const char* fmt, ...) {
 
 extern "C" int tf_version(void) { return 100; }
 extern "C" const char* tf_last_error(void) { return tf::g_err; }
+
+// ---- GEMM plan cache / autotuner switches -----------------------------------------------------------------------
+namespace tf {
+typedef std::tuple<std::string, int, int, int, int, int> PlanKey;
+static std::map<PlanKey, GemmPlan> g_plans;
+static std::mutex g_plan_mu;
+static bool g_autotune = false;
+
+bool plan_lookup(const char* what, int M, int N, int K, int batch, int acc, GemmPlan* out) {
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    auto it = g_plans.find(PlanKey(what, M, N, K, batch, acc));
+    if (it == g_plans.end()) return false;
+    *out = it->second;
+    return true;
+}
+void plan_store(const char* what, int M, int N, int K, int batch, int acc, const GemmPlan& p) {
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    g_plans[PlanKey(what, M, N, K, batch, acc)] = p;
+}
+bool autotune_enabled() { return g_autotune; }
+static GemmPlan g_forced{0, 0, 0, 0};
+bool forced_plan(GemmPlan* out) { if (g_forced.bm == 0) return false; *out = g_forced; return true; }
+}  // namespace tf
+
+extern "C" int tf_force_plan(int bm, int bn, int bk, int splitk) {
+    const bool ok = bm == 0 || (((bm == 128 && (bn == 32 || bn == 64 || bn == 96 || bn == 128)) || (bm == 64 && (bn == 64 || bn == 128))) && (bk == 16 || bk == 32) && splitk >= 1);
+    if (!ok) { tf::set_error("tf_force_plan: unsupported tiling %dx%dx%d", bm, bn, bk); return -1; }
+    tf::g_forced = tf::GemmPlan{bm, bn, bk, splitk};
+    return 0;
+}
+extern "C" int tf_autotune(int enable) { tf::g_autotune = enable != 0; return 0; }
+extern "C" int tf_plans_count(void) { std::lock_guard<std::mutex> lk(tf::g_plan_mu); return (int)tf::g_plans.size(); }
+extern "C" int tf_plans_clear(void) { std::lock_guard<std::mutex> lk(tf::g_plan_mu); tf::g_plans.clear(); return 0; }
+extern "C" int tf_plans_save(const char* path) {
+    std::lock_guard<std::mutex> lk(tf::g_plan_mu);
+    FILE* f = fopen(path, "w");
+    if (!f) { tf::set_error("tf_plans_save: cannot open %s", path); return -1; }
+    fprintf(f, "# transfuser_hip GEMM plans: site;M;N;K;batch;acc;bm;bn;bk;splitk\n");
+    for (auto& kv : tf::g_plans)
+        fprintf(f, "%s;%d;%d;%d;%d;%d;%d;%d;%d;%d\n", std::get<0>(kv.first).c_str(), std::get<1>(kv.first), std::get<2>(kv.first), std::get<3>(kv.first),
+                std::get<4>(kv.first), std::get<5>(kv.first), kv.second.bm, kv.second.bn, kv.second.bk, kv.second.splitk);
+    fclose(f);
+    return 0;
+}
+extern "C" int tf_plans_load(const char* path) {
+    FILE* f = fopen(path, "r");
+    if (!f) { tf::set_error("tf_plans_load: cannot open %s", path); return -1; }
+    char line[512];
+    int n = 0;
+    while (fgets(line, sizeof(line), f)) {
+        if (line[0] == '#') continue;
+        char site[256];
+        int M, N, K, b, acc, bm, bn, bk, sk;
+        char* semi = strchr(line, ';');
+        if (!semi || (size_t)(semi - line) >= sizeof(site)) continue;
+        memcpy(site, line, semi - line); site[semi - line] = 0;
+        if (sscanf(semi + 1, "%d;%d;%d;%d;%d;%d;%d;%d;%d", &M, &N, &K, &b, &acc, &bm, &bn, &bk, &sk) != 9) continue;
+        const bool ok = ((bm == 128 && (bn == 32 || bn == 64 || bn == 96 || bn == 128)) || (bm == 64 && (bn == 64 || bn == 128))) && (bk == 16 || bk == 32) && sk >= 1;
+        if (!ok) continue;
+        tf::plan_store(site, M, N, K, b, acc, tf::GemmPlan{bm, bn, bk, sk});
+        ++n;
+    }
+    fclose(f);
+    return n;
+}

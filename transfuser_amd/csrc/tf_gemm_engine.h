@@ -19,7 +19,6 @@
 
 namespace tf {
 
-constexpr int GEMM_BK = 16;
 constexpr int GEMM_PAD = 4;
 
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -185,21 +184,15 @@ struct GemmEpi {
 };
 
 // ---------------------------------------------------------------- kernel
-template <int R, bool KC>
-struct TileMap {  // float4 slots of an operand tile (R outer x BK reduction), spread over 256 threads
-    static constexpr int kSlots = R * GEMM_BK / 4;
-    static constexpr int kPerThread = (kSlots + 255) / 256;
-};
-
-template <int BM, int BN, int WAVES_M, class LA, bool A_KC, class LB, bool B_KC>
+template <int BM, int BN, int WAVES_M, int BK, class LA, bool A_KC, class LB, bool B_KC>
 __global__ void __launch_bounds__(256) gemm_kernel(LA la, LB lb, GemmEpi ep, int M, int N, int K, int tiles_m, int tiles_n,
                                                    int kchunk) {
-    constexpr int BK = GEMM_BK;
     constexpr int WAVES_N = 4 / WAVES_M;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int TM = WM / 32, TN = WN / 32;
     static_assert(WM % 32 == 0 && WN % 32 == 0 && TM >= 1 && TN >= 1, "wave tile must be 32x32 multiples");
-    constexpr int NLA = TileMap<BM, A_KC>::kPerThread, NLB = TileMap<BN, B_KC>::kPerThread;
+    constexpr int KQ = BK / 4;                                   // float4 per row of a KC operand tile
+    constexpr int NLA = (BM * KQ + 255) / 256, NLB = (BN * KQ + 255) / 256;   // float4 slots per thread
 
     __shared__ __attribute__((aligned(16))) float As[2][BK][BM + GEMM_PAD];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN + GEMM_PAD];
@@ -227,11 +220,11 @@ __global__ void __launch_bounds__(256) gemm_kernel(LA la, LB lb, GemmEpi ep, int
     typename LB::Row brow[NLB];
     if (A_KC) {
 #pragma unroll
-        for (int p = 0; p < NLA; ++p) arow[p] = la.row(i0 + ((tid + p * 256) >> 2));
+        for (int p = 0; p < NLA; ++p) arow[p] = la.row(i0 + (tid + p * 256) / KQ);
     }
     if (B_KC) {
 #pragma unroll
-        for (int p = 0; p < NLB; ++p) brow[p] = lb.row(j0 + ((tid + p * 256) >> 2));
+        for (int p = 0; p < NLB; ++p) brow[p] = lb.row(j0 + (tid + p * 256) / KQ);
     }
 
     float4 ra[NLA], rb[NLB];
@@ -240,7 +233,8 @@ __global__ void __launch_bounds__(256) gemm_kernel(LA la, LB lb, GemmEpi ep, int
         for (int p = 0; p < NLA; ++p) {
             const int f = tid + p * 256;
             if (A_KC) {
-                ra[p] = (f < BM * 4) ? la.load(arow[p], k0 + (f & 3) * 4 < kend ? k0 + (f & 3) * 4 : 0x3fffffff) : f4zero();
+                const int k = k0 + (f % KQ) * 4;
+                ra[p] = (f < BM * KQ) ? la.load(arow[p], k < kend ? k : 0x3fffffff) : f4zero();
             } else {
                 const int kr = f / (BM / 4), cq = f - kr * (BM / 4);
                 ra[p] = (kr < BK && k0 + kr < kend) ? la.load(la.row(k0 + kr), i0 + cq * 4) : f4zero();
@@ -250,7 +244,8 @@ __global__ void __launch_bounds__(256) gemm_kernel(LA la, LB lb, GemmEpi ep, int
         for (int p = 0; p < NLB; ++p) {
             const int f = tid + p * 256;
             if (B_KC) {
-                rb[p] = (f < BN * 4) ? lb.load(brow[p], k0 + (f & 3) * 4 < kend ? k0 + (f & 3) * 4 : 0x3fffffff) : f4zero();
+                const int k = k0 + (f % KQ) * 4;
+                rb[p] = (f < BN * KQ) ? lb.load(brow[p], k < kend ? k : 0x3fffffff) : f4zero();
             } else {
                 const int kr = f / (BN / 4), cq = f - kr * (BN / 4);
                 rb[p] = (kr < BK && k0 + kr < kend) ? lb.load(lb.row(k0 + kr), j0 + cq * 4) : f4zero();
@@ -262,8 +257,8 @@ __global__ void __launch_bounds__(256) gemm_kernel(LA la, LB lb, GemmEpi ep, int
         for (int p = 0; p < NLA; ++p) {
             const int f = tid + p * 256;
             if (A_KC) {
-                if (f < BM * 4) {
-                    const int r = f >> 2, kq = (f & 3) * 4;
+                if (f < BM * KQ) {
+                    const int r = f / KQ, kq = (f % KQ) * 4;
                     As[buf][kq + 0][r] = ra[p].x; As[buf][kq + 1][r] = ra[p].y;
                     As[buf][kq + 2][r] = ra[p].z; As[buf][kq + 3][r] = ra[p].w;
                 }
@@ -276,8 +271,8 @@ __global__ void __launch_bounds__(256) gemm_kernel(LA la, LB lb, GemmEpi ep, int
         for (int p = 0; p < NLB; ++p) {
             const int f = tid + p * 256;
             if (B_KC) {
-                if (f < BN * 4) {
-                    const int r = f >> 2, kq = (f & 3) * 4;
+                if (f < BN * KQ) {
+                    const int r = f / KQ, kq = (f % KQ) * 4;
                     Bs[buf][kq + 0][r] = rb[p].x; Bs[buf][kq + 1][r] = rb[p].y;
                     Bs[buf][kq + 2][r] = rb[p].z; Bs[buf][kq + 3][r] = rb[p].w;
                 }
@@ -352,59 +347,61 @@ __global__ void __launch_bounds__(256) gemm_kernel(LA la, LB lb, GemmEpi ep, int
 }
 
 // ---------------------------------------------------------------- host dispatch
-struct GemmPlan { int bm, bn, splitk; };
+struct GemmPlan { int bm, bn, bk, splitk; };
 
-// Heuristic tile choice: smallest BN that covers N with the least padding, BM=64 when the grid
-// would not fill the 256 CUs, split-K (atomic epilogue) for skinny outputs with deep reductions.
+// plan cache + autotuner state (api.cpp)
+bool plan_lookup(const char* what, int M, int N, int K, int batch, int acc, GemmPlan* out);
+void plan_store(const char* what, int M, int N, int K, int batch, int acc, const GemmPlan& p);
+bool autotune_enabled();
+bool forced_plan(GemmPlan* out);   // tests: pin one tiling for every call
+
+inline int heuristic_splitk(int M, int N, int K, int batch, int bm, int bn, int bk) {
+    const long tiles = (long)cdiv(M, bm) * cdiv(N, bn) * batch;
+    const int ktiles = cdiv(K, bk);
+    if (tiles >= 512 || ktiles * bk < 256) return 1;
+    long want = (1024 + tiles - 1) / tiles;
+    long maxs = (long)ktiles * bk / 128;
+    if (want > maxs) want = maxs;
+    return want < 1 ? 1 : (int)want;
+}
+
+// Heuristic tile choice (used when no tuned plan exists): smallest BN that covers N with the least padding,
+// BM=64 when the grid would not fill the 256 CUs, split-K (atomic epilogue) for skinny outputs with deep reductions.
 inline GemmPlan plan_gemm(int M, int N, int K, int batch, bool allow_splitk) {
     GemmPlan p;
     if (N <= 32) p.bn = 32;
     else if (N <= 64) p.bn = 64;
     else if (N <= 96) p.bn = 96;
     else {
-        // padding waste of 128-wide vs 96-wide column tiles
         const long w128 = (long)cdiv(N, 128) * 128, w96 = (long)cdiv(N, 96) * 96;
         p.bn = (w96 < w128) ? 96 : 128;
     }
     p.bm = 128;
+    p.bk = 16;
     const long t128 = (long)cdiv(M, 128) * cdiv(N, p.bn) * batch;
-    if (p.bn == 128 || p.bn == 64) {
-        if (t128 < 384 && M > 64) p.bm = 64;  // more, smaller tiles when the chip would be under-filled
-    }
-    p.splitk = 1;
-    if (allow_splitk) {
-        const long tiles = (long)cdiv(M, p.bm) * cdiv(N, p.bn) * batch;
-        const int ktiles = cdiv(K, GEMM_BK);
-        if (tiles < 512 && ktiles >= 16) {
-            long want = (1024 + tiles - 1) / tiles;
-            long maxs = ktiles / 8;
-            if (want > maxs) want = maxs;
-            if (want < 1) want = 1;
-            p.splitk = (int)want;
-        }
-    }
+    if ((p.bn == 128 || p.bn == 64) && t128 < 384 && M > 64) p.bm = 64;
+    p.splitk = allow_splitk ? heuristic_splitk(M, N, K, batch, p.bm, p.bn, p.bk) : 1;
     return p;
 }
 
-template <int BM, int BN, int WAVES_M, class LA, bool A_KC, class LB, bool B_KC>
+template <int BM, int BN, int WAVES_M, int BK, class LA, bool A_KC, class LB, bool B_KC>
 inline void launch_cfg(const LA& la, const LB& lb, const GemmEpi& ep, int M, int N, int K, int batch, int splitk, void* stream) {
     const int tiles_m = cdiv(M, BM), tiles_n = cdiv(N, BN);
-    int kchunk = cdiv(cdiv(K, splitk), GEMM_BK) * GEMM_BK;
-    if (kchunk < GEMM_BK) kchunk = GEMM_BK;
+    int kchunk = cdiv(cdiv(K, splitk), BK) * BK;
+    if (kchunk < BK) kchunk = BK;
     const int nsplit = cdiv(K, kchunk);
     dim3 grid(tiles_m * tiles_n, nsplit > 0 ? nsplit : 1, batch);
-    TF_LAUNCH((gemm_kernel<BM, BN, WAVES_M, LA, A_KC, LB, B_KC>), grid, dim3(256), stream, la, lb, ep, M, N, K, tiles_m, tiles_n,
+    TF_LAUNCH((gemm_kernel<BM, BN, WAVES_M, BK, LA, A_KC, LB, B_KC>), grid, dim3(256), stream, la, lb, ep, M, N, K, tiles_m, tiles_n,
               kchunk);
 }
 
 template <class LA, bool A_KC, class LB, bool B_KC>
-inline int launch_gemm(const LA& la, const LB& lb, GemmEpi ep, int M, int N, int K, int batch, bool allow_splitk, void* stream,
-                       const char* what) {
-    if (M <= 0 || N <= 0 || batch <= 0) return 0;
-    // split-K only for pure accumulations (weight gradients into the grad arena): atomic epilogue
-    GemmPlan p = plan_gemm(M, N, K, batch, allow_splitk && ep.mode == 1 && !ep.bias && !ep.res && !ep.relu);
-    if (p.splitk > 1) ep.mode = 2;
-#define TF_CFG(BM_, BN_, WM_) launch_cfg<BM_, BN_, WM_, LA, A_KC, LB, B_KC>(la, lb, ep, M, N, K, batch, p.splitk, stream)
+inline void launch_plan(const GemmPlan& p, const LA& la, const LB& lb, const GemmEpi& ep, int M, int N, int K, int batch, void* stream) {
+#define TF_CFG(BM_, BN_, WM_)                                                                                      \
+    do {                                                                                                           \
+        if (p.bk == 32) launch_cfg<BM_, BN_, WM_, 32, LA, A_KC, LB, B_KC>(la, lb, ep, M, N, K, batch, p.splitk, stream); \
+        else launch_cfg<BM_, BN_, WM_, 16, LA, A_KC, LB, B_KC>(la, lb, ep, M, N, K, batch, p.splitk, stream);       \
+    } while (0)
     if (p.bm == 128) {
         if (p.bn == 32) TF_CFG(128, 32, 4);
         else if (p.bn == 64) TF_CFG(128, 64, 2);
@@ -415,6 +412,74 @@ inline int launch_gemm(const LA& la, const LB& lb, GemmEpi ep, int M, int N, int
         else TF_CFG(64, 128, 1);
     }
 #undef TF_CFG
+}
+
+#ifndef TF_EMU
+// cudnn.benchmark-style tuning (the reference enables it, train.py:115): time every candidate tiling of this exact
+// problem ONCE with HIP events during eager warm-up; the winner goes into the plan cache.  Trial launches of
+// accumulating epilogues run with alpha = 0 so the destination is left unchanged.
+template <class LA, bool A_KC, class LB, bool B_KC>
+inline GemmPlan autotune_gemm(const LA& la, const LB& lb, const GemmEpi& ep, int M, int N, int K, int batch, bool allow_splitk, void* stream) {
+    static const int tiles[6][2] = {{128, 128}, {128, 96}, {128, 64}, {128, 32}, {64, 128}, {64, 64}};
+    GemmEpi trial = ep;
+    if (ep.mode != 0) trial.alpha = 0.f;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    GemmPlan best = plan_gemm(M, N, K, batch, allow_splitk);
+    float best_ms = 1e30f;
+    const int npad = cdiv(N, 32) * 32;
+    for (int t = 0; t < 6; ++t) {
+        const int bm = tiles[t][0], bn = tiles[t][1];
+        if (bn > 32 && bn >= npad + 32) continue;          // a whole extra 32-column strip of padding
+        if (bm == 64 && M <= 64 && t != 4 && t != 5) continue;
+        for (int bk = 16; bk <= 32; bk += 16) {
+            int sks[3] = {1, 0, 0}, nsk = 1;
+            if (allow_splitk) {
+                const int h = heuristic_splitk(M, N, K, batch, bm, bn, bk);
+                if (h > 1) { sks[nsk++] = h; if (h >= 4) sks[nsk++] = h / 2; }
+            }
+            for (int s = 0; s < nsk; ++s) {
+                GemmPlan p{bm, bn, bk, sks[s]};
+                GemmEpi e = trial;
+                if (p.splitk > 1) { if (ep.mode == 0) continue; e.mode = 2; }
+                launch_plan<LA, A_KC, LB, B_KC>(p, la, lb, e, M, N, K, batch, stream);   // warm
+                hipEventRecord(e0, (hipStream_t)stream);
+                for (int r = 0; r < 3; ++r) launch_plan<LA, A_KC, LB, B_KC>(p, la, lb, e, M, N, K, batch, stream);
+                hipEventRecord(e1, (hipStream_t)stream);
+                hipEventSynchronize(e1);
+                float ms = 0.f;
+                hipEventElapsedTime(&ms, e0, e1);
+                if (ms < best_ms) { best_ms = ms; best = p; }
+            }
+        }
+    }
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return best;
+}
+#endif
+
+template <class LA, bool A_KC, class LB, bool B_KC>
+inline int launch_gemm(const LA& la, const LB& lb, GemmEpi ep, int M, int N, int K, int batch, bool allow_splitk, void* stream,
+                       const char* what) {
+    if (M <= 0 || N <= 0 || batch <= 0) return 0;
+    // split-K only for pure accumulations (weight gradients into the grad arena): atomic epilogue
+    const bool sk_ok = allow_splitk && ep.mode == 1 && !ep.bias && !ep.res && !ep.relu;
+    const int acc = ep.mode != 0 ? (sk_ok ? 2 : 1) : 0;
+    GemmPlan p;
+    if (forced_plan(&p)) {
+        if (!sk_ok) p.splitk = 1;
+    } else if (!plan_lookup(what, M, N, K, batch, acc, &p)) {
+#ifndef TF_EMU
+        if (autotune_enabled()) {
+            p = autotune_gemm<LA, A_KC, LB, B_KC>(la, lb, ep, M, N, K, batch, sk_ok, stream);
+            plan_store(what, M, N, K, batch, acc, p);
+        } else
+#endif
+            p = plan_gemm(M, N, K, batch, sk_ok);
+    }
+    if (!sk_ok) p.splitk = 1;
+    if (p.splitk > 1) ep.mode = 2;
+    launch_plan<LA, A_KC, LB, B_KC>(p, la, lb, ep, M, N, K, batch, stream);
     return launch_status(what);
 }
 

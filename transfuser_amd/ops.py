@@ -33,6 +33,27 @@ def workspace(device):
     return ws
 
 
+def autotune(enable):
+    """cudnn.benchmark-style tiling search for the MFMA engine (eager warm-up only: it synchronises)."""
+    check(L().tf_autotune(int(bool(enable))), "tf_autotune")
+
+
+def force_plan(bm=0, bn=0, bk=0, splitk=1):
+    """Tests: pin one engine tiling for every call (bm=0 restores planning)."""
+    check(L().tf_force_plan(bm, bn, bk, splitk), "tf_force_plan")
+
+
+def plans_save(path):
+    check(L().tf_plans_save(path.encode()), "tf_plans_save")
+
+
+def plans_load(path):
+    n = L().tf_plans_load(path.encode())
+    if n < 0:
+        check(n, "tf_plans_load")
+    return n
+
+
 def _c(t):
     assert t.is_contiguous(), "expected a contiguous tensor, got strides %s for shape %s" % (t.stride(), tuple(t.shape))
     return t

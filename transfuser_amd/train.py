@@ -156,9 +156,12 @@ class Engine:
 
     BATCH_KEYS = ("rgb", "lidar", "ego_waypoint", "target_point", "target_point_image", "ego_vel", "bev", "label", "depth", "semantic")
 
-    def __init__(self, model, config, lr=1e-4, use_graph=False, group=None, bucket_mb=64.0, wp_only=False):
+    def __init__(self, model, config, lr=1e-4, use_graph=False, group=None, bucket_mb=64.0, wp_only=False, autotune=True, plan_file=None):
         self.model = model
         self.config = config
+        self._autotune_pending = bool(autotune) and next(model.parameters()).is_cuda
+        if plan_file is not None and os.path.exists(plan_file):
+            ops.plans_load(plan_file)
         self.arena = ParamArena(model)
         self.optimizer = FlatAdamW(self.arena, lr=lr)
         self.reducer = GradReducer(self.arena, group, bucket_mb)
@@ -177,6 +180,14 @@ class Engine:
                           label=data["label"], depth=data["depth"], semantic=data["semantic"])
 
     def _fwd_bwd(self, data):
+        if self._autotune_pending and not torch.cuda.is_current_stream_capturing():
+            # first eager iteration: let the engine time its candidate tilings for every distinct problem of the step
+            self._autotune_pending = False
+            ops.autotune(True)
+            try:
+                return self._fwd_bwd(data)
+            finally:
+                ops.autotune(False)
         self.optimizer.zero_grad()
         losses = self.load_data_compute_loss(data)
         loss = None
