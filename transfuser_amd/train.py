@@ -160,7 +160,9 @@ class Engine:
         self.model = model
         self.config = config
         self._autotune_pending = bool(autotune) and next(model.parameters()).is_cuda
-        if plan_file is not None and os.path.exists(plan_file):
+        if plan_file is None:   # tilings tuned offline on an MI355X for the bench / reference shapes (tools/tune.py); unknown shapes are tuned on first use
+            plan_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "plans", "mi355x.txt")
+        if next(model.parameters()).is_cuda and os.path.exists(plan_file):
             ops.plans_load(plan_file)
         self.arena = ParamArena(model)
         self.optimizer = FlatAdamW(self.arena, lr=lr)
