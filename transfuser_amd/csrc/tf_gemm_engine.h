@@ -16,6 +16,7 @@
 // t and written to the other LDS buffer after them: one barrier per K tile.
 #pragma once
 #include "tf_common.h"
+#include <type_traits>
 
 namespace tf {
 
@@ -24,23 +25,27 @@ constexpr int GEMM_PAD = 4;
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
 // ---------------------------------------------------------------- loaders
-struct PlainRow { const float* p; };
+// All loaders are BRANCH-FREE: an out-of-range element loads from a clamped (always valid) address and is
+// replaced by 0 with a select.  With branches around the loads hipcc has to wait for them at the merge point,
+// i.e. before the MFMAs of the current tile; unconditional loads stay in flight across the whole compute phase and
+// are only waited for where the next tile is written to LDS.
+// loaders return the RAW (possibly clamped-address) data plus a 4-bit validity mask; gemm_tile applies the mask when it
+// writes the tile to LDS, so nothing depends on the loaded registers until after the MFMAs of the current tile.
+
+struct PlainRow { const float* p; int ok; };
 
 // X(r, c) = p[r*ld + c], r < rows, c < cols.  Batch z -> p + (z / inner) * s_outer + (z % inner) * s_inner.
 struct PlainOp {
     const float* p; long ld; int rows, cols, vec; long s_outer, s_inner; int inner;
     typedef PlainRow Row;
     __device__ __forceinline__ void set_batch(int z) { p += (long)(z / inner) * s_outer + (long)(z % inner) * s_inner; }
-    __device__ __forceinline__ Row row(int r) const { Row w; w.p = (r < rows) ? p + (long)r * ld : nullptr; return w; }
-    __device__ __forceinline__ float4 load(const Row& w, int c) const {
-        if (!w.p || c >= cols) return f4zero();
-        if (vec) return *reinterpret_cast<const float4*>(w.p + c);
-        float4 v = f4zero();
-        v.x = w.p[c];
-        if (c + 1 < cols) v.y = w.p[c + 1];
-        if (c + 2 < cols) v.z = w.p[c + 2];
-        if (c + 3 < cols) v.w = w.p[c + 3];
-        return v;
+    __device__ __forceinline__ Row row(int r) const { Row w; w.ok = r < rows; w.p = p + (w.ok ? (long)r * ld : 0L); return w; }
+    template <bool V> __device__ __forceinline__ float4 load(const Row& w, int c, bool en, unsigned& m) const {
+        const bool ok = en && w.ok && c < cols;
+        if (V || vec) { m = ok ? 15u : 0u; return *reinterpret_cast<const float4*>(w.p + (ok ? c : 0)); }
+        const bool o1 = ok && c + 1 < cols, o2 = ok && c + 2 < cols, o3 = ok && c + 3 < cols;
+        m = (ok ? 1u : 0u) | (o1 ? 2u : 0u) | (o2 ? 4u : 0u) | (o3 ? 8u : 0u);
+        return make_float4(w.p[ok ? c : 0], w.p[o1 ? c + 1 : 0], w.p[o2 ? c + 2 : 0], w.p[o3 ? c + 3 : 0]);
     }
 };
 
@@ -51,19 +56,18 @@ struct WDgradOp {
     typedef PlainRow Row;
     __device__ __forceinline__ void set_batch(int z) { w += (long)z * gstride; }
     __device__ __forceinline__ Row row(int k) const {
-        Row r; r.p = nullptr;
-        if (k < rows) { int tap = k / Cog; int co = k - tap * Cog; r.p = w + ((long)co * taps + tap) * Cig; }
+        Row r; r.ok = k < rows;
+        const int kk = r.ok ? k : 0;
+        const int tap = kk / Cog, co = kk - tap * Cog;
+        r.p = w + ((long)co * taps + tap) * Cig;
         return r;
     }
-    __device__ __forceinline__ float4 load(const Row& r, int c) const {
-        if (!r.p || c >= cols) return f4zero();
-        if (vec) return *reinterpret_cast<const float4*>(r.p + c);
-        float4 v = f4zero();
-        v.x = r.p[c];
-        if (c + 1 < cols) v.y = r.p[c + 1];
-        if (c + 2 < cols) v.z = r.p[c + 2];
-        if (c + 3 < cols) v.w = r.p[c + 3];
-        return v;
+    template <bool V> __device__ __forceinline__ float4 load(const Row& r, int c, bool en, unsigned& m) const {
+        const bool ok = en && r.ok && c < cols;
+        if (V || vec) { m = ok ? 15u : 0u; return *reinterpret_cast<const float4*>(r.p + (ok ? c : 0)); }
+        const bool o1 = ok && c + 1 < cols, o2 = ok && c + 2 < cols, o3 = ok && c + 3 < cols;
+        m = (ok ? 1u : 0u) | (o1 ? 2u : 0u) | (o2 ? 4u : 0u) | (o3 ? 8u : 0u);
+        return make_float4(r.p[ok ? c : 0], r.p[o1 ? c + 1 : 0], r.p[o2 ? c + 2 : 0], r.p[o3 ? c + 3 : 0]);
     }
 };
 
@@ -76,29 +80,32 @@ struct Im2colOp {
     typedef ConvRow Row;
     __device__ __forceinline__ void set_batch(int z) { coff += z * Cg; }
     __device__ __forceinline__ Row row(int r) const {
-        Row w; w.ok = r < rows; w.base = 0; w.h0 = 0; w.w0 = 0;
-        if (w.ok) {
-            int ow = r % Wo; int t = r / Wo; int oh = t % Ho; int b = t / Ho;
-            w.base = (long)b * Hi * Wi; w.h0 = oh * stride - pad; w.w0 = ow * stride - pad;
-        }
+        Row w; w.ok = r < rows;
+        const int rr = w.ok ? r : 0;
+        const int ow = rr % Wo, t = rr / Wo, oh = t % Ho, b = t / Ho;
+        w.base = (long)b * Hi * Wi; w.h0 = oh * stride - pad; w.w0 = ow * stride - pad;
         return w;
     }
-    __device__ __forceinline__ float at(const Row& w, int c) const {
-        if (c >= cols) return 0.f;
-        int tap = c / Cg; int ci = c - tap * Cg; int kh = tap / ks; int kw = tap - kh * ks;
-        int ih = w.h0 + kh, iw = w.w0 + kw;
-        if ((unsigned)ih >= (unsigned)Hi || (unsigned)iw >= (unsigned)Wi) return 0.f;
-        return x[(w.base + (long)ih * Wi + iw) * Ct + coff + ci];
+    // element offset of (row, col) and its validity, no branches
+    __device__ __forceinline__ long off(const Row& w, int c, bool& ok) const {
+        ok = ok && w.ok && c < cols;
+        const int cc = ok ? c : 0;
+        const int tap = cc / Cg, ci = cc - tap * Cg, kh = tap / ks, kw = tap - kh * ks;
+        const int ih = w.h0 + kh, iw = w.w0 + kw;
+        ok = ok && (unsigned)ih < (unsigned)Hi && (unsigned)iw < (unsigned)Wi;
+        return ok ? (w.base + (long)ih * Wi + iw) * Ct + coff + ci : 0L;
     }
-    __device__ __forceinline__ float4 load(const Row& w, int c) const {
-        if (!w.ok || c >= cols) return f4zero();
-        if (vec) {
-            int tap = c / Cg; int ci = c - tap * Cg; int kh = tap / ks; int kw = tap - kh * ks;
-            int ih = w.h0 + kh, iw = w.w0 + kw;
-            if ((unsigned)ih >= (unsigned)Hi || (unsigned)iw >= (unsigned)Wi) return f4zero();
-            return *reinterpret_cast<const float4*>(x + (w.base + (long)ih * Wi + iw) * Ct + coff + ci);
+    template <bool V> __device__ __forceinline__ float4 load(const Row& w, int c, bool en, unsigned& m) const {
+        if (V || vec) {
+            bool ok = en;
+            const long o = off(w, c, ok);
+            m = ok ? 15u : 0u;
+            return *reinterpret_cast<const float4*>(x + o);
         }
-        return make_float4(at(w, c), at(w, c + 1), at(w, c + 2), at(w, c + 3));
+        bool k0 = en, k1 = en, k2 = en, k3 = en;
+        const long o0 = off(w, c, k0), o1 = off(w, c + 1, k1), o2 = off(w, c + 2, k2), o3 = off(w, c + 3, k3);
+        m = (k0 ? 1u : 0u) | (k1 ? 2u : 0u) | (k2 ? 4u : 0u) | (k3 ? 8u : 0u);
+        return make_float4(x[o0], x[o1], x[o2], x[o3]);
     }
 };
 
@@ -109,37 +116,33 @@ struct Im2colTOp {
     typedef ConvRow Row;
     __device__ __forceinline__ void set_batch(int z) { coff += z * Cg; }
     __device__ __forceinline__ Row row(int r) const {
-        Row w; w.ok = r < rows; w.base = 0; w.h0 = 0; w.w0 = 0;
-        if (w.ok) {
-            int iw = r % Wi; int t = r / Wi; int ih = t % Hi; int b = t / Hi;
-            w.base = (long)b * Ho * Wo; w.h0 = ih + pad; w.w0 = iw + pad;
-        }
+        Row w; w.ok = r < rows;
+        const int rr = w.ok ? r : 0;
+        const int iw = rr % Wi, t = rr / Wi, ih = t % Hi, b = t / Hi;
+        w.base = (long)b * Ho * Wo; w.h0 = ih + pad; w.w0 = iw + pad;
         return w;
     }
-    __device__ __forceinline__ const float* addr(const Row& w, int c) const {
-        int tap = c / Cg; int co = c - tap * Cg; int kh = tap / ks; int kw = tap - kh * ks;
-        int th = w.h0 - kh, tw = w.w0 - kw;
-        if (th < 0 || tw < 0) return nullptr;
+    __device__ __forceinline__ long off(const Row& w, int c, bool& ok) const {
+        ok = ok && w.ok && c < cols;
+        const int cc = ok ? c : 0;
+        const int tap = cc / Cg, co = cc - tap * Cg, kh = tap / ks, kw = tap - kh * ks;
+        const int th = w.h0 - kh, tw = w.w0 - kw;
         int oh = th, ow = tw;
-        if (stride != 1) {
-            oh = th / stride; ow = tw / stride;
-            if (oh * stride != th || ow * stride != tw) return nullptr;
-        }
-        if (oh >= Ho || ow >= Wo) return nullptr;
-        return dy + (w.base + (long)oh * Wo + ow) * Ct + coff + co;
+        if (stride != 1) { oh = th / stride; ow = tw / stride; }   // uniform branch
+        ok = ok && th >= 0 && tw >= 0 && oh * stride == th && ow * stride == tw && oh < Ho && ow < Wo;
+        return ok ? (w.base + (long)oh * Wo + ow) * Ct + coff + co : 0L;
     }
-    __device__ __forceinline__ float at(const Row& w, int c) const {
-        if (c >= cols) return 0.f;
-        const float* p = addr(w, c);
-        return p ? *p : 0.f;
-    }
-    __device__ __forceinline__ float4 load(const Row& w, int c) const {
-        if (!w.ok || c >= cols) return f4zero();
-        if (vec) {
-            const float* p = addr(w, c);
-            return p ? *reinterpret_cast<const float4*>(p) : f4zero();
+    template <bool V> __device__ __forceinline__ float4 load(const Row& w, int c, bool en, unsigned& m) const {
+        if (V || vec) {
+            bool ok = en;
+            const long o = off(w, c, ok);
+            m = ok ? 15u : 0u;
+            return *reinterpret_cast<const float4*>(dy + o);
         }
-        return make_float4(at(w, c), at(w, c + 1), at(w, c + 2), at(w, c + 3));
+        bool k0 = en, k1 = en, k2 = en, k3 = en;
+        const long o0 = off(w, c, k0), o1 = off(w, c + 1, k1), o2 = off(w, c + 2, k2), o3 = off(w, c + 3, k3);
+        m = (k0 ? 1u : 0u) | (k1 ? 2u : 0u) | (k2 ? 4u : 0u) | (k3 ? 8u : 0u);
+        return make_float4(dy[o0], dy[o1], dy[o2], dy[o3]);
     }
 };
 
@@ -153,25 +156,31 @@ struct Im2colNchwOp {
     typedef ConvRow Row;
     __device__ __forceinline__ void set_batch(int) {}
     __device__ __forceinline__ Row row(int r) const {
-        Row w; w.ok = r < rows; w.base = 0; w.h0 = 0; w.w0 = 0;
-        if (w.ok) {
-            int ow = r % Wo; int t = r / Wo; int oh = t % Ho; int b = t / Ho;
-            w.base = b; w.h0 = oh * stride - pad; w.w0 = ow * stride - pad;
-        }
+        Row w; w.ok = r < rows;
+        const int rr = w.ok ? r : 0;
+        const int ow = rr % Wo, t = rr / Wo, oh = t % Ho, b = t / Ho;
+        w.base = b; w.h0 = oh * stride - pad; w.w0 = ow * stride - pad;
         return w;
     }
-    __device__ __forceinline__ float at(const Row& w, int c) const {
-        if (c >= cols) return 0.f;
-        int tap = c / Cg; int ci = c - tap * Cg; int kh = tap / ks; int kw = tap - kh * ks;
-        int ih = w.h0 + kh, iw = w.w0 + kw;
-        if ((unsigned)ih >= (unsigned)Hi || (unsigned)iw >= (unsigned)Wi) return 0.f;
-        float v = (ci < C0) ? s0[((w.base * C0 + ci) * Hi + ih) * Wi + iw] : s1[((w.base * C1 + (ci - C0)) * Hi + ih) * Wi + iw];
-        if (normalize) v = ((v / 255.0f) - mean[ci]) / stdv[ci];
+    __device__ __forceinline__ float at(const Row& w, int c, bool en, bool& ok) const {
+        ok = en && w.ok && c < cols;
+        const int cc = ok ? c : 0;
+        const int tap = cc / Cg, ci = cc - tap * Cg, kh = tap / ks, kw = tap - kh * ks;
+        const int ih = w.h0 + kh, iw = w.w0 + kw;
+        ok = ok && (unsigned)ih < (unsigned)Hi && (unsigned)iw < (unsigned)Wi;
+        const bool first = ci < C0;
+        const float* src = (first || !s1) ? s0 : s1;
+        const int cs = first ? ci : ci - C0, Cn = first ? C0 : C1;
+        const long o = ok ? ((w.base * Cn + cs) * Hi + ih) * Wi + iw : 0L;
+        float v = src[o];
+        if (normalize) v = ((v / 255.0f) - mean[ci & 3]) / stdv[ci & 3];
         return v;
     }
-    __device__ __forceinline__ float4 load(const Row& w, int c) const {
-        if (!w.ok || c >= cols) return f4zero();
-        return make_float4(at(w, c), at(w, c + 1), at(w, c + 2), at(w, c + 3));
+    template <bool V> __device__ __forceinline__ float4 load(const Row& w, int c, bool en, unsigned& m) const {
+        bool k0, k1, k2, k3;
+        const float v0 = at(w, c, en, k0), v1 = at(w, c + 1, en, k1), v2 = at(w, c + 2, en, k2), v3 = at(w, c + 3, en, k3);
+        m = (k0 ? 1u : 0u) | (k1 ? 2u : 0u) | (k2 ? 4u : 0u) | (k3 ? 8u : 0u);
+        return make_float4(v0, v1, v2, v3);
     }
 };
 
@@ -184,18 +193,15 @@ struct GemmEpi {
 };
 
 // ---------------------------------------------------------------- kernel
-template <int BM, int BN, int WAVES_M, int BK, class LA, bool A_KC, class LB, bool B_KC>
-__global__ void __launch_bounds__(256) gemm_kernel(LA la, LB lb, GemmEpi ep, int M, int N, int K, int tiles_m, int tiles_n,
-                                                   int kchunk) {
+template <int BM, int BN, int WAVES_M, int BK, class LA, bool A_KC, class LB, bool B_KC, bool ALLVEC>
+__device__ __forceinline__ void gemm_tile(LA& la, LB& lb, const GemmEpi& ep, int M, int N, int K, int tiles_m, int tiles_n, int kchunk,
+                                          float (*As)[BK][BM + GEMM_PAD], float (*Bs)[BK][BN + GEMM_PAD]) {
     constexpr int WAVES_N = 4 / WAVES_M;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int TM = WM / 32, TN = WN / 32;
     static_assert(WM % 32 == 0 && WN % 32 == 0 && TM >= 1 && TN >= 1, "wave tile must be 32x32 multiples");
     constexpr int KQ = BK / 4;                                   // float4 per row of a KC operand tile
     constexpr int NLA = (BM * KQ + 255) / 256, NLB = (BN * KQ + 255) / 256;   // float4 slots per thread
-
-    __shared__ __attribute__((aligned(16))) float As[2][BK][BM + GEMM_PAD];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN + GEMM_PAD];
 
     const int tid = threadIdx.x;
     const int z = blockIdx.z;
@@ -228,16 +234,18 @@ __global__ void __launch_bounds__(256) gemm_kernel(LA la, LB lb, GemmEpi ep, int
     }
 
     float4 ra[NLA], rb[NLB];
+    unsigned ma[NLA], mb[NLB];   // validity bits of the prefetched slots
     auto fetch = [&](int k0) {
 #pragma unroll
         for (int p = 0; p < NLA; ++p) {
             const int f = tid + p * 256;
             if (A_KC) {
                 const int k = k0 + (f % KQ) * 4;
-                ra[p] = (f < BM * KQ) ? la.load(arow[p], k < kend ? k : 0x3fffffff) : f4zero();
+                ra[p] = la.template load<ALLVEC>(arow[p], k, f < BM * KQ && k < kend, ma[p]);
             } else {
                 const int kr = f / (BM / 4), cq = f - kr * (BM / 4);
-                ra[p] = (kr < BK && k0 + kr < kend) ? la.load(la.row(k0 + kr), i0 + cq * 4) : f4zero();
+                const bool en = kr < BK && k0 + kr < kend;
+                ra[p] = la.template load<ALLVEC>(la.row(en ? k0 + kr : 0), i0 + cq * 4, en, ma[p]);
             }
         }
 #pragma unroll
@@ -245,10 +253,11 @@ __global__ void __launch_bounds__(256) gemm_kernel(LA la, LB lb, GemmEpi ep, int
             const int f = tid + p * 256;
             if (B_KC) {
                 const int k = k0 + (f % KQ) * 4;
-                rb[p] = (f < BN * KQ) ? lb.load(brow[p], k < kend ? k : 0x3fffffff) : f4zero();
+                rb[p] = lb.template load<ALLVEC>(brow[p], k, f < BN * KQ && k < kend, mb[p]);
             } else {
                 const int kr = f / (BN / 4), cq = f - kr * (BN / 4);
-                rb[p] = (kr < BK && k0 + kr < kend) ? lb.load(lb.row(k0 + kr), j0 + cq * 4) : f4zero();
+                const bool en = kr < BK && k0 + kr < kend;
+                rb[p] = lb.template load<ALLVEC>(lb.row(en ? k0 + kr : 0), j0 + cq * 4, en, mb[p]);
             }
         }
     };
@@ -259,12 +268,12 @@ __global__ void __launch_bounds__(256) gemm_kernel(LA la, LB lb, GemmEpi ep, int
             if (A_KC) {
                 if (f < BM * KQ) {
                     const int r = f / KQ, kq = (f % KQ) * 4;
-                    As[buf][kq + 0][r] = ra[p].x; As[buf][kq + 1][r] = ra[p].y;
-                    As[buf][kq + 2][r] = ra[p].z; As[buf][kq + 3][r] = ra[p].w;
+                    As[buf][kq + 0][r] = (ma[p] & 1u) ? ra[p].x : 0.f; As[buf][kq + 1][r] = (ma[p] & 2u) ? ra[p].y : 0.f;
+                    As[buf][kq + 2][r] = (ma[p] & 4u) ? ra[p].z : 0.f; As[buf][kq + 3][r] = (ma[p] & 8u) ? ra[p].w : 0.f;
                 }
             } else {
                 const int kr = f / (BM / 4), cq = f - kr * (BM / 4);
-                if (kr < BK) *reinterpret_cast<float4*>(&As[buf][kr][cq * 4]) = ra[p];
+                if (kr < BK) *reinterpret_cast<float4*>(&As[buf][kr][cq * 4]) = make_float4((ma[p] & 1u) ? ra[p].x : 0.f, (ma[p] & 2u) ? ra[p].y : 0.f, (ma[p] & 4u) ? ra[p].z : 0.f, (ma[p] & 8u) ? ra[p].w : 0.f);
             }
         }
 #pragma unroll
@@ -273,12 +282,12 @@ __global__ void __launch_bounds__(256) gemm_kernel(LA la, LB lb, GemmEpi ep, int
             if (B_KC) {
                 if (f < BN * KQ) {
                     const int r = f / KQ, kq = (f % KQ) * 4;
-                    Bs[buf][kq + 0][r] = rb[p].x; Bs[buf][kq + 1][r] = rb[p].y;
-                    Bs[buf][kq + 2][r] = rb[p].z; Bs[buf][kq + 3][r] = rb[p].w;
+                    Bs[buf][kq + 0][r] = (mb[p] & 1u) ? rb[p].x : 0.f; Bs[buf][kq + 1][r] = (mb[p] & 2u) ? rb[p].y : 0.f;
+                    Bs[buf][kq + 2][r] = (mb[p] & 4u) ? rb[p].z : 0.f; Bs[buf][kq + 3][r] = (mb[p] & 8u) ? rb[p].w : 0.f;
                 }
             } else {
                 const int kr = f / (BN / 4), cq = f - kr * (BN / 4);
-                if (kr < BK) *reinterpret_cast<float4*>(&Bs[buf][kr][cq * 4]) = rb[p];
+                if (kr < BK) *reinterpret_cast<float4*>(&Bs[buf][kr][cq * 4]) = make_float4((mb[p] & 1u) ? rb[p].x : 0.f, (mb[p] & 2u) ? rb[p].y : 0.f, (mb[p] & 4u) ? rb[p].z : 0.f, (mb[p] & 8u) ? rb[p].w : 0.f);
             }
         }
     };
@@ -319,31 +328,56 @@ __global__ void __launch_bounds__(256) gemm_kernel(LA la, LB lb, GemmEpi ep, int
         __syncthreads();
     }
 
-    // epilogue: lane holds column j of 16 rows per 32x32 tile
+    // epilogue: lane holds column j of 16 rows per 32x32 tile.  Mode / residual / bounds are resolved ONCE per tile
+    // (wave-uniform) so the 16 x TM x TN stores of a lane are straight-line code, not a branch + wait per element.
     const long cz = (long)(z / ep.inner) * ep.sc_outer + (long)(z % ep.inner) * ep.sc_inner;
     float* C = ep.C + cz;
     const float* res = ep.res ? ep.res + cz : nullptr;
     const float* bias = ep.bias ? ep.bias + (long)z * ep.sbias : nullptr;
+    const bool full = (i0 + BM <= M) && (j0 + BN <= N);
+    auto emit = [&](auto mode_c, auto res_c, auto full_c) {
+        constexpr int MODE = decltype(mode_c)::value;
+        constexpr bool RES = decltype(res_c)::value, FULL = decltype(full_c)::value;
 #pragma unroll
-    for (int t = 0; t < TM; ++t)
+        for (int t = 0; t < TM; ++t)
 #pragma unroll
-        for (int u = 0; u < TN; ++u) {
-            const int j = j0 + wn0 + u * 32 + l31;
-            if (j >= N) continue;
-            const float bj = bias ? bias[j] : 0.f;
+            for (int u = 0; u < TN; ++u) {
+                const int j = j0 + wn0 + u * 32 + l31;
+                const bool jok = FULL || j < N;
+                const float bj = (bias && jok) ? bias[j] : 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int i = i0 + wm0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                if (i >= M) continue;
-                float v = ep.alpha * acc[t][u][r] + bj;
-                if (res) v += res[(long)i * ep.ldres + j];
-                if (ep.relu) v = fmaxf(v, 0.f);
-                float* dst = C + (long)i * ep.ldc + (long)j * ep.ldcj;
-                if (ep.mode == 0) *dst = v;
-                else if (ep.mode == 1) *dst += v;
-                else atomicAdd(dst, v);
+                for (int r = 0; r < 16; ++r) {
+                    const int i = i0 + wm0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (FULL || (jok && i < M)) {
+                        float v = ep.alpha * acc[t][u][r] + bj;
+                        if (RES) v += res[(long)i * ep.ldres + j];
+                        v = ep.relu ? fmaxf(v, 0.f) : v;
+                        float* dst = C + (long)i * ep.ldc + (long)j * ep.ldcj;
+                        if (MODE == 0) *dst = v;
+                        else if (MODE == 1) *dst += v;
+                        else atomicAdd(dst, v);
+                    }
+                }
             }
-        }
+    };
+    auto by_full = [&](auto mode_c, auto res_c) {
+        if (full) emit(mode_c, res_c, std::true_type()); else emit(mode_c, res_c, std::false_type());
+    };
+    auto by_res = [&](auto mode_c) {
+        if (res) by_full(mode_c, std::true_type()); else by_full(mode_c, std::false_type());
+    };
+    if (ep.mode == 0) by_res(std::integral_constant<int, 0>());
+    else if (ep.mode == 1) by_res(std::integral_constant<int, 1>());
+    else by_res(std::integral_constant<int, 2>());
+}
+
+// ALLVEC = both operands may be read with 16-byte loads (decided on the host): separate instantiation so the common
+// vector kernel does not inherit the register pressure of the element-wise (attention head / stem) path.
+template <int BM, int BN, int WAVES_M, int BK, class LA, bool A_KC, class LB, bool B_KC, bool ALLVEC>
+__global__ void __launch_bounds__(256) gemm_kernel(LA la, LB lb, GemmEpi ep, int M, int N, int K, int tiles_m, int tiles_n, int kchunk) {
+    __shared__ __attribute__((aligned(16))) float As[2][BK][BM + GEMM_PAD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN + GEMM_PAD];
+    gemm_tile<BM, BN, WAVES_M, BK, LA, A_KC, LB, B_KC, ALLVEC>(la, lb, ep, M, N, K, tiles_m, tiles_n, kchunk, As, Bs);
 }
 
 // ---------------------------------------------------------------- host dispatch
@@ -391,8 +425,10 @@ inline void launch_cfg(const LA& la, const LB& lb, const GemmEpi& ep, int M, int
     if (kchunk < BK) kchunk = BK;
     const int nsplit = cdiv(K, kchunk);
     dim3 grid(tiles_m * tiles_n, nsplit > 0 ? nsplit : 1, batch);
-    TF_LAUNCH((gemm_kernel<BM, BN, WAVES_M, BK, LA, A_KC, LB, B_KC>), grid, dim3(256), stream, la, lb, ep, M, N, K, tiles_m, tiles_n,
-              kchunk);
+    if (la.vec && lb.vec)
+        TF_LAUNCH((gemm_kernel<BM, BN, WAVES_M, BK, LA, A_KC, LB, B_KC, true>), grid, dim3(256), stream, la, lb, ep, M, N, K, tiles_m, tiles_n, kchunk);
+    else
+        TF_LAUNCH((gemm_kernel<BM, BN, WAVES_M, BK, LA, A_KC, LB, B_KC, false>), grid, dim3(256), stream, la, lb, ep, M, N, K, tiles_m, tiles_n, kchunk);
 }
 
 template <class LA, bool A_KC, class LB, bool B_KC>
