@@ -30,7 +30,7 @@ extern "C" int tf_gemm_f32(const tf_gemm_desc* d, void* stream) {
     if (d->batch == 1 && d->alpha == 1.0f && d->m > 0 && d->n > 0 && d->k > 0) {
         if (!d->a_trans && !d->b_trans && d->m <= 16 && !d->accumulate)
             return smallm_fwd(d->a, d->lda, d->b, d->ldb, d->bias, d->res, d->ldres, d->c, d->ldc, d->m, d->n, d->k, d->relu, stream);
-        if (!d->a_trans && d->b_trans && d->m <= 16 && !d->bias && !d->relu)
+        if (!d->a_trans && d->b_trans && d->m <= 16 && !d->bias && !d->relu && !(d->accumulate && d->res))
             return smallm_dgrad(d->a, d->lda, d->b, d->ldb, d->res, d->ldres, d->c, d->ldc, d->m, d->k, d->n, d->accumulate, stream);
         if (d->a_trans && d->b_trans && d->k <= 16 && !d->bias && !d->res && !d->relu)
             return smallm_wgrad(d->a, d->lda, d->b, d->ldb, d->c, d->ldc, d->k, d->m, d->n, d->accumulate, stream);

@@ -25,7 +25,7 @@ template <int V> __device__ __forceinline__ void stv(float* p, const vecf<V>& a)
     else *p = a.v[0];
 }
 
-constexpr int kMaxChunks = 64;
+constexpr int kMaxChunks = 512;   // finalize is wave-parallel over chunks, so many small partials are cheap
 constexpr long kWsFloats = 4L << 20;  // 16 MiB workspace (floats), see tf_workspace_bytes()
 
 struct RedPlan { int V, CTV, coltiles, rpp, nchunks, rows_per_chunk; };
@@ -40,7 +40,7 @@ inline RedPlan plan_reduce(int rows, int C, int nseg, int nacc, bool allow_vec =
     p.CTV = ctv;
     p.coltiles = cv / ctv;
     p.rpp = 256 / ctv;
-    int want = 1024 / (p.coltiles * nseg);
+    int want = 2048 / (p.coltiles * nseg);   // ~8 blocks per CU: a streaming reduction needs many loads in flight
     if (want < 1) want = 1;
     if (want > kMaxChunks) want = kMaxChunks;
     int maxc = cdiv(rows, p.rpp * 4);

@@ -41,18 +41,21 @@ __global__ void __launch_bounds__(256) smallm_fwd_kernel(const float* __restrict
     }
 }
 
-// dx[m][k] (+)= sum_n dy[m][n] * w[n][k] (+ res): block = 32 k-columns x 8 n-slices, LDS combine
+// dx[m][k] (+)= sum_n dy[m][n] * w[n][k] (+ res): block = 32 k-columns x 8 n-slices of ONE n-chunk (grid.y chunks);
+// partial sums are combined through LDS and, across chunks, with fp32 atomics into a destination that the first chunk
+// initialises (res / old value / 0) - so the grid has K/32 x N/256 blocks instead of K/32.
 __global__ void __launch_bounds__(256) smallm_dgrad_kernel(const float* __restrict__ dy, long lddy, const float* __restrict__ w, long ldw,
-                                                           const float* __restrict__ res, long ldres, float* __restrict__ dx, long lddx, int M,
-                                                           int N, int K, int accumulate) {
+                                                           float* __restrict__ dx, long lddx, int M, int N, int K, int nchunk) {
     __shared__ float red[8][SM_MAXM][32];
     const int kx = threadIdx.x & 31, sl = threadIdx.x >> 5;
     const int k = blockIdx.x * 32 + kx;
+    const int n0 = blockIdx.y * nchunk;
+    const int n1 = (n0 + nchunk < N) ? n0 + nchunk : N;
     float acc[SM_MAXM];
 #pragma unroll
     for (int m = 0; m < SM_MAXM; ++m) acc[m] = 0.f;
     if (k < K)
-        for (int n = sl; n < N; n += 8) {
+        for (int n = n0 + sl; n < n1; n += 8) {
             const float wv = w[(long)n * ldw + k];
 #pragma unroll
             for (int m = 0; m < SM_MAXM; ++m)
@@ -61,17 +64,21 @@ __global__ void __launch_bounds__(256) smallm_dgrad_kernel(const float* __restri
 #pragma unroll
     for (int m = 0; m < SM_MAXM; ++m) red[sl][m][kx] = acc[m];
     __syncthreads();
-    // thread (sl, kx) finalises rows m = sl, sl + 8
     for (int m = sl; m < M; m += 8) {
         if (k < K) {
             float v = 0.f;
 #pragma unroll
             for (int s = 0; s < 8; ++s) v += red[s][m][kx];
-            if (res) v += res[m * ldres + k];
-            float* d = dx + m * lddx + k;
-            *d = accumulate ? *d + v : v;
+            atomicAdd(dx + m * lddx + k, v);
         }
     }
+}
+// dx = res (or 0, or unchanged when accumulating) before the atomics of smallm_dgrad_kernel
+__global__ void __launch_bounds__(256) smallm_init_kernel(float* __restrict__ dx, long lddx, const float* __restrict__ res, long ldres, int M, int K) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= M * K) return;
+    const int m = i / K, k = i - m * K;
+    dx[m * lddx + k] = res ? res[m * ldres + k] : 0.f;
 }
 
 // dw[n][k] (+)= sum_m dy[m][n] * x[m][k]; one thread per (n, k), k fastest
@@ -94,7 +101,9 @@ int smallm_fwd(const float* x, long ldx, const float* w, long ldw, const float* 
 }
 int smallm_dgrad(const float* dy, long lddy, const float* w, long ldw, const float* res, long ldres, float* dx, long lddx, int M, int N, int K,
                  int accumulate, void* stream) {
-    TF_LAUNCH(smallm_dgrad_kernel, dim3(cdiv(K, 32)), dim3(256), stream, dy, lddy, w, ldw, res, ldres, dx, lddx, M, N, K, accumulate);
+    if (!accumulate) TF_LAUNCH(smallm_init_kernel, dim3(cdiv((long)M * K, 256)), dim3(256), stream, dx, lddx, res, ldres, M, K);
+    const int nchunk = 256;
+    TF_LAUNCH(smallm_dgrad_kernel, dim3(cdiv(K, 32), cdiv(N, nchunk)), dim3(256), stream, dy, lddy, w, ldw, dx, lddx, M, N, K, nchunk);
     return launch_status("tf_gemm_f32[small-m dgrad]");
 }
 int smallm_wgrad(const float* dy, long lddy, const float* x, long ldx, float* dw, long lddw, int M, int N, int K, int accumulate, void* stream) {
