@@ -373,8 +373,11 @@ __device__ __forceinline__ void gemm_tile(LA& la, LB& lb, const GemmEpi& ep, int
 
 // ALLVEC = both operands may be read with 16-byte loads (decided on the host): separate instantiation so the common
 // vector kernel does not inherit the register pressure of the element-wise (attention head / stem) path.
+// __launch_bounds__ 2nd argument = waves per SIMD the register allocator must leave room for (= resident 256-thread
+// blocks per CU): PMC showed the big tiles lose more to the tail round (tiles / resident slots) than to anything in the
+// K loop, so they are held to 3 blocks per CU (<= 168 registers incl. 64 accumulators) and the small ones to 4+.
 template <int BM, int BN, int WAVES_M, int BK, class LA, bool A_KC, class LB, bool B_KC, bool ALLVEC>
-__global__ void __launch_bounds__(256) gemm_kernel(LA la, LB lb, GemmEpi ep, int M, int N, int K, int tiles_m, int tiles_n, int kchunk) {
+__global__ void __launch_bounds__(256, (BM * BN >= 128 * 96) ? 3 : 4) gemm_kernel(LA la, LB lb, GemmEpi ep, int M, int N, int K, int tiles_m, int tiles_n, int kchunk) {
     __shared__ __attribute__((aligned(16))) float As[2][BK][BM + GEMM_PAD];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN + GEMM_PAD];
     gemm_tile<BM, BN, WAVES_M, BK, LA, A_KC, LB, B_KC, ALLVEC>(la, lb, ep, M, N, K, tiles_m, tiles_n, kchunk, As, Bs);

@@ -23,8 +23,8 @@ def L():
 
 
 def workspace(device):
-    """Reduction scratch, one per device (kernels on one stream serialise, so it is shared)."""
-    key = str(device)
+    """Reduction scratch: one per (device, stream) - kernels on one stream serialise, so each stream shares one buffer."""
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream if getattr(device, "type", str(device)[:4]) == "cuda" else 0)
     ws = _ws_cache.get(key)
     if ws is None:
         L().tf_workspace_bytes.restype = ctypes.c_long

@@ -196,6 +196,13 @@ class TransfuserBackbone(nn.Module):
         self._img_stem = _Stem(self.image_encoder.features.conv1, self.image_encoder.features.bn1, True)
         self._lid_stem = _Stem(self.lidar_encoder._model.conv1, self.lidar_encoder._model.bn1, False)
 
+    def _side_stream(self, device):
+        st = getattr(self, "_side", None)
+        if st is None or st.device != device:
+            st = torch.cuda.Stream(device)
+            self._side = st
+        return st
+
     def _conv(self, conv, x, relu=False):
         if isinstance(conv, nn.Sequential):
             return x
@@ -220,14 +227,34 @@ class TransfuserBackbone(nn.Module):
         """image (B,3,H,W) 0..255, lidar (B,2|3,256,256) [+ lidar_extra (B,1,256,256) instead of torch.cat];
         returns NHWC tensors: (p2,p3,p4,p5), image_features_grid, fused_features."""
         im, li = self.image_encoder.features, self.lidar_encoder._model
+        # The two trunks are independent between fusion stages: the LiDAR branch runs on a side HIP stream so its blocks
+        # fill the tail rounds of the image branch's kernels (and vice versa); under hipGraph capture the fork/join
+        # below become graph edges.  Autograd replays each node's backward on its forward stream, so the backward of
+        # the two branches overlaps the same way.
+        side = self._side_stream(image.device) if image.is_cuda else None
+        main = torch.cuda.current_stream(image.device) if image.is_cuda else None
+
+        def lidar_branch(fn):
+            if side is None:
+                return fn()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                out = fn()
+            return out
+
         x = self._img_stem(image.contiguous())
-        y = self._lid_stem(lidar.contiguous(), lidar_extra.contiguous() if lidar_extra is not None else None)
+        y = lidar_branch(lambda: self._lid_stem(lidar.contiguous(), lidar_extra.contiguous() if lidar_extra is not None else None))
         for i in range(1, 5):
             x = getattr(im, "layer%d" % i)(x)
-            y = getattr(li, "layer%d" % i)(y)
+            y = lidar_branch(lambda y=y, i=i: getattr(li, "layer%d" % i)(y))
+            if side is not None:
+                main.wait_stream(side)          # join: the fusion stage consumes both branches on the main stream
+                y.record_stream(main)
             gpt = getattr(self, "transformer%d" % i)
             gpt.seed = self.dropout_seed
             x, y = gpt(x, y, velocity)
+            if side is not None:
+                y.record_stream(side)
         x = self._conv(self.change_channel_conv_image, x)
         y = self._conv(self.change_channel_conv_lidar, y)
         fused = F_.GlobalPoolAddFn.apply(x, y)
