@@ -47,7 +47,7 @@ def dominant_kernel_roofline(dev, iters=20):
     sec = e0.elapsed_time(e1) / 1e3 / iters
     flops = 2.0 * M * N * K
     ach = flops / sec / 1e12
-    return dict(bound="mfma", kernel="tf::gemm_kernel<128,128,2,PlainOp,KC,PlainOp,KC> (GPT4 mlp.0: 1740x1512x6048, bias+ReLU epilogue)",
+    return dict(bound="mfma", kernel="tf::gemm_kernel<BM,BN,WM,BK,PlainOp,KC,PlainOp,KC,vec> (autotuned tiling) on GPT4 mlp.0: [1740x1512].[1512x6048], bias+ReLU epilogue",
                 achieved=round(ach, 2), peak=PEAK_F32_MFMA_TF, unit="TFLOP/s", frac=round(ach / PEAK_F32_MFMA_TF, 4),
                 flops_per_launch=flops, avg_launch_us=round(sec * 1e6, 2), traffic=None)
 
