@@ -102,31 +102,6 @@ class HeadsFn(torch.autograd.Function):
         return (dp2, None) + (None,) * (len(ctx.needs_input_grad) - 2)
 
 
-class _Forker:
-    """Runs independent sub-graphs on side HIP streams forked from / joined to the current stream (no-op on CPU)."""
-
-    def __init__(self, device, owner):
-        self.device = device
-        self.used = []
-        if device is not None:
-            pool = owner.__dict__.setdefault("_branch_streams", {})
-            self.pool = pool.setdefault(str(device), [torch.cuda.Stream(device) for _ in range(4)])
-            self.main = torch.cuda.current_stream(device)
-
-    def run(self, idx, fn):
-        if self.device is None:
-            return fn()
-        st = self.pool[idx]
-        st.wait_stream(self.main)
-        with torch.cuda.stream(st):
-            fn()
-        self.used.append(st)
-
-    def join(self):
-        for st in self.used:
-            self.main.wait_stream(st)
-
-
 class LidarCenterNet(nn.Module):
     def __init__(self, config, device, backbone, image_architecture='resnet34', lidar_architecture='resnet18', use_velocity=True):
         super().__init__()
@@ -173,43 +148,23 @@ class LidarCenterNet(nn.Module):
         cfg = self.config
         extra = target_point_image if self.use_target_point_image else None
         features, grid, fused = self._model.forward_nhwc(rgb, lidar_bev, ego_vel, lidar_extra=extra)
+        pred_wp, _, _, _, _ = self.forward_gru(fused, target_point)
         p2 = features[0]
-        # The four consumers of the backbone (waypoint GRU, CenterNet heads + BEV, seg decoder, depth decoder) are
-        # independent: each runs on its own HIP stream (graph edges under capture; backward overlaps the same way).
-        fork = _Forker(p2.device if p2.is_cuda else None, self)
-        out = {}
-
-        def wp_branch():
-            pred_wp, _, _, _, _ = self.forward_gru(fused, target_point)
-            out["pred_wp"] = pred_wp
-            out["loss_wp"] = F_.L1Fn.apply(pred_wp, ego_waypoint.contiguous(), False)
-
-        def det_branch():
-            pred, bev_logits = HeadsFn.apply(p2, self, *self.head.parameters(), *self.pred_bev.parameters())
-            bev_up = F_.UpsampleFn.apply(bev_logits, cfg.bev_resolution_height, cfg.bev_resolution_width, True)
-            out["pred"], out["bev_up"] = pred, bev_up
-            out["loss_bev"] = F_.CrossEntropyFn.apply(bev_up, bev.contiguous(), self.bev_class_weight)
-            out["det"] = F_.CenterNetLossFn.apply(pred, label.contiguous(), self.head.num_dir_bins, p2.shape[2] / float(cfg.lidar_resolution_width),
-                                                  p2.shape[1] / float(cfg.lidar_resolution_height))
-
-        def seg_branch():
-            out["l_sem"] = F_.CrossEntropyFn.apply(self.seg_decoder.forward_nhwc(grid), semantic.contiguous(), None)
-
-        def depth_branch():
-            out["l_dep"] = F_.L1Fn.apply(self.depth_decoder.forward_nhwc(grid).squeeze(-1), depth.contiguous(), True)
-
-        fork.run(0, det_branch)
-        if cfg.multitask:
-            fork.run(1, seg_branch)
-            fork.run(2, depth_branch)
-        fork.run(3, wp_branch)
-        fork.join()
-        pred_wp, pred, bev_up = out["pred_wp"], out["pred"], out["bev_up"]
-        loss = {"loss_wp": out["loss_wp"], "loss_bev": out["loss_bev"]}
+        pred, bev_logits = HeadsFn.apply(p2, self, *self.head.parameters(), *self.pred_bev.parameters())
+        bev_up = F_.UpsampleFn.apply(bev_logits, cfg.bev_resolution_height, cfg.bev_resolution_width, True)
+        loss = {
+            "loss_wp": F_.L1Fn.apply(pred_wp, ego_waypoint.contiguous(), False),
+            "loss_bev": F_.CrossEntropyFn.apply(bev_up, bev.contiguous(), self.bev_class_weight),
+        }
+        det = F_.CenterNetLossFn.apply(pred, label.contiguous(), self.head.num_dir_bins, p2.shape[2] / float(cfg.lidar_resolution_width),
+                                       p2.shape[1] / float(cfg.lidar_resolution_height))
         for i, k in enumerate(LOSS_KEYS):
-            loss[k] = out["det"][i]
+            loss[k] = det[i]
         if cfg.multitask:
-            l_sem, l_dep = out["l_sem"], out["l_dep"]
+            seg_logits = self.seg_decoder.forward_nhwc(grid)
+            depth_logits = self.depth_decoder.forward_nhwc(grid)
+            l_sem = F_.CrossEntropyFn.apply(seg_logits, semantic.contiguous(), None)
+            l_dep = F_.L1Fn.apply(depth_logits.squeeze(-1), depth.contiguous(), True)
             loss["loss_depth"] = l_dep * cfg.ls_depth if cfg.ls_depth != 1.0 else l_dep
             loss["loss_semantic"] = l_sem * cfg.ls_seg if cfg.ls_seg != 1.0 else l_sem
         else:
