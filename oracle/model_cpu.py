@@ -23,9 +23,10 @@ class LidarCenterNet(nn.Module):
         self.gru_concat_target_point = config.gru_concat_target_point
         assert not config.use_point_pillars, "pillars: see oracle/pillars.py"
         tf = backbone_module or transfuser_cpu
-        assert backbone == 'transFuser'
+        assert backbone in ('transFuser', 'latentTF')
         kw = {} if backbone_module is not None else dict(make_net=make_net)
-        self._model = tf.TransfuserBackbone(config, image_architecture, lidar_architecture, use_velocity=use_velocity, **kw)
+        cls = tf.TransfuserBackbone if backbone == 'transFuser' else tf.latentTFBackbone
+        self._model = cls(config, image_architecture, lidar_architecture, use_velocity=use_velocity, **kw)
         if config.multitask:
             self.seg_decoder = tf.SegDecoder(config, config.perception_output_features)
             self.depth_decoder = tf.DepthDecoder(config, config.perception_output_features)

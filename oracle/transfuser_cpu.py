@@ -190,6 +190,23 @@ class TransfuserBackbone(nn.Module):
         return self.top_down(y), x, fused
 
 
+class latentTFBackbone(TransfuserBackbone):
+    """team_code_transfuser/latentTF.py:8-217: LiDAR channels 0/1 overwritten IN PLACE by a (-1..1) meshgrid (:132-137,
+    quirk Q5); LidarEncoder deletes the whole stem (:416)."""
+
+    def __init__(self, config, image_architecture='regnety_032', lidar_architecture='regnety_032', use_velocity=True, make_net=None):
+        super().__init__(config, image_architecture, lidar_architecture, use_velocity, make_net)
+        del self.lidar_encoder._model.stem
+
+    def forward(self, image, lidar, velocity):
+        x = torch.linspace(-1, 1, self.config.lidar_resolution_width)
+        y = torch.linspace(-1, 1, self.config.lidar_resolution_height)
+        y_grid, x_grid = torch.meshgrid(x, y, indexing='ij')
+        lidar[:, 0] = y_grid.unsqueeze(0).to(lidar.dtype)
+        lidar[:, 1] = x_grid.unsqueeze(0).to(lidar.dtype)
+        return super().forward(image, lidar, velocity)
+
+
 def _decoder(config, latent, out_ch):
     c1, c2, c3 = config.deconv_channel_num_1, config.deconv_channel_num_2, config.deconv_channel_num_3
     conv = lambda a, b: nn.Conv2d(a, b, 3, 1, 1)

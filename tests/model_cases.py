@@ -66,16 +66,16 @@ def randomize(model, seed=1):
                 p.copy_(torch.randn(p.shape, generator=g) * 0.05)
 
 
-def build_pair(cfg, arch, dev, use_velocity=False, seed=0):
+def build_pair(cfg, arch, dev, use_velocity=False, seed=0, backbone='transFuser'):
     """Product model on ``dev`` + oracle on CPU with IDENTICAL weights (strict state_dict load = key parity)."""
     torch.manual_seed(seed)
-    prod = LidarCenterNet(cfg, dev, 'transFuser', arch, arch, use_velocity=use_velocity)
+    prod = LidarCenterNet(cfg, dev, backbone, arch, arch, use_velocity=use_velocity)
     randomize(prod)
     if arch == "regnety_tiny":
         make_net = lambda: oracle_regnet.RegNet(TINY["widths"], TINY["depths"], TINY["group_w"], TINY["se_ratio"])
     else:
         make_net = oracle_regnet.regnety_032
-    ref = model_cpu.LidarCenterNet(cfg, 'cpu', 'transFuser', use_velocity=use_velocity, make_net=make_net)
+    ref = model_cpu.LidarCenterNet(cfg, 'cpu', backbone, use_velocity=use_velocity, make_net=make_net)
     sd = {k: v.detach().cpu().contiguous() for k, v in prod.state_dict().items()}
     missing = ref.load_state_dict(sd, strict=True)
     assert not missing.missing_keys and not missing.unexpected_keys

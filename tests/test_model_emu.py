@@ -56,3 +56,15 @@ def test_engine_two_steps_match_oracle_adamw():
     for n, b in prod.named_buffers():
         if "running" in n:
             assert (b - rb[n]).abs().max().item() < 1e-3 * max(1.0, rb[n].abs().max().item()), n
+
+
+def test_latentTF_backbone_matches_oracle():
+    """BASELINE config 5 backbone (latentTF.py): positional grid instead of the LiDAR histogram; state_dict keys as the
+    reference (no _model.stem.*).  LiDAR 128x128 so that stage-4 BatchNorm sees 32 (not 8) values per channel: with the
+    SAME grid in both samples a 2x2 map makes BN-backward a round-off amplifier (degenerate, checked by hand)."""
+    cfg = mc.tiny_config(n_layer=1, lidar_res=128)
+    prod, ref = mc.build_pair(cfg, "regnety_tiny", "cpu", backbone="latentTF")
+    assert not any(k.startswith("_model.lidar_encoder._model.stem") for k in prod.state_dict())
+    batch = mc.small_batch(2, 32, 64, 128, 40)
+    lp, lr = mc.run_pair(prod, ref, cfg, batch, "cpu")
+    mc.compare_vs_fp64(prod, ref, lp, lr, batch, cfg)

@@ -6,7 +6,7 @@ targets :285-374, losses :150-248 with mmdet 2.25 semantics).
 Same parameter names/shapes (reference checkpoints load with strict=True), same call signature,
 same return value; everything between the input tensors and the loss scalars runs in the HIP
 kernels of libtransfuser_hip.so.  Out of scope here: ``forward_ego`` / box decoding /
-PID control / visualisation (CARLA inference), ``late_fusion`` / ``geometric_fusion`` / ``latentTF``
+PID control / visualisation (CARLA inference), ``late_fusion`` / ``geometric_fusion``
 backbones, PointPillars (``use_point_pillars``) - requesting them raises.
 """
 import torch
@@ -14,7 +14,7 @@ from torch import nn
 
 from . import functions as F_
 from . import ops
-from .transfuser import DepthDecoder, SegDecoder, TransfuserBackbone, nchw
+from .transfuser import DepthDecoder, SegDecoder, TransfuserBackbone, latentTFBackbone, nchw
 
 HEAD_ORDER = ("heatmap_head", "wh_head", "offset_head", "yaw_class_head", "yaw_res_head", "velocity_head", "brake_head")
 LOSS_KEYS = ("loss_center_heatmap", "loss_wh", "loss_offset", "loss_yaw_class", "loss_yaw_res", "loss_velocity", "loss_brake")
@@ -116,8 +116,10 @@ class LidarCenterNet(nn.Module):
         self.backbone = backbone
         if backbone == 'transFuser':
             self._model = TransfuserBackbone(config, image_architecture, lidar_architecture, use_velocity=use_velocity)
+        elif backbone == 'latentTF':
+            self._model = latentTFBackbone(config, image_architecture, lidar_architecture, use_velocity=use_velocity)
         else:
-            raise NotImplementedError("backbone %r: only 'transFuser' is on the MI355X hot path (SURVEY.md section 8)" % (backbone,))
+            raise NotImplementedError("backbone %r: 'transFuser' and 'latentTF' are built; geometric_fusion / late_fusion are SURVEY.md section 8 next rows" % (backbone,))
         if config.multitask:
             self.seg_decoder = SegDecoder(config, config.perception_output_features)
             self.depth_decoder = DepthDecoder(config, config.perception_output_features)

@@ -265,6 +265,35 @@ class TransfuserBackbone(nn.Module):
         return tuple(nchw(p) for p in feats), nchw(grid), fused
 
 
+class latentTFBackbone(TransfuserBackbone):
+    """team_code_transfuser/latentTF.py:8-217 (BASELINE config 5): identical modules, but the two LiDAR histogram channels
+    are replaced by a fixed (-1..1) positional grid (:132-137); a third input channel (target point) is kept.  The
+    reference's LidarEncoder deletes the whole ``stem`` here (latentTF.py:416), so ``_model.stem.bn.*`` keys are absent
+    (``_model.bn1.*`` remain) - reproduced for checkpoint compatibility (quirk Q5)."""
+
+    def __init__(self, config, image_architecture='resnet34', lidar_architecture='resnet18', use_velocity=True):
+        super().__init__(config, image_architecture, lidar_architecture, use_velocity)
+        del self.lidar_encoder._model.stem
+        self._grid = None
+
+    def _pos_grid(self, B, device):
+        g = self._grid
+        H, W = self.config.lidar_resolution_height, self.config.lidar_resolution_width
+        if g is None or g.shape[0] != B or g.device != device:
+            x = torch.linspace(-1, 1, self.config.lidar_resolution_width)
+            y = torch.linspace(-1, 1, self.config.lidar_resolution_height)
+            y_grid, x_grid = torch.meshgrid(x, y, indexing='ij')   # latentTF.py:132-134 (sic: x along rows)
+            g = torch.stack((y_grid, x_grid), 0).unsqueeze(0).expand(B, 2, H, W).contiguous().to(device)
+            self._grid = g
+        return g
+
+    def forward_nhwc(self, image, lidar, velocity, lidar_extra=None):
+        grid = self._pos_grid(lidar.shape[0], lidar.device)
+        if lidar_extra is None and lidar.shape[1] > 2:
+            lidar_extra = lidar[:, 2:].contiguous()
+        return super().forward_nhwc(image, grid, velocity, lidar_extra=lidar_extra)
+
+
 class _Decoder(nn.Module):
     def __init__(self, config, latent_dim, out_ch):
         super().__init__()
