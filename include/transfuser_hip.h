@@ -122,6 +122,14 @@ typedef struct {
 int tf_bilinear_fwd_f32(const tf_bilinear_desc* d, const float* x, float* y, const float* add, void* stream);
 int tf_bilinear_bwd_f32(const tf_bilinear_desc* d, const float* dy, float* dx, int accumulate, void* stream);
 
+/* G1 - geometric-fusion correspondence gather (geometric_fusion.py:134-137,147-150; and :173-176 ... :262-266 for the other
+ * stages): out[b, i, :] = sum_k src[b, idx[b,i,k,1] * Ws + idx[b,i,k,0], :].  The reference indexes B x B and keeps the diagonal;
+ * only the diagonal is computed here.  src (B, Hs*Ws, E) fp32, idx (B, n, K, 2) int64 (x, y) pairs, out (B, n, E).
+ * bwd is the transposed gather in a fixed summation order (deterministic); accumulate != 0 adds into dsrc. */
+int tf_gather_sum_fwd_f32(const float* src, const long long* idx, int B, int Hs, int Ws, int E, int n, int K, float* out, void* stream);
+int tf_gather_sum_bwd_f32(const float* dout, const long long* idx, int B, int Hs, int Ws, int E, int n, int K, float* dsrc, int accumulate,
+                          void* stream);
+
 /* ---- losses ---------------------------------------------------------------------------------- */
 
 /* F.cross_entropy(logits, target, weight=class_w) (model.py:763,783) over NHWC logits (rows, C <= 16):

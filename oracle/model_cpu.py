@@ -23,9 +23,11 @@ class LidarCenterNet(nn.Module):
         self.gru_concat_target_point = config.gru_concat_target_point
         assert not config.use_point_pillars, "pillars: see oracle/pillars.py"
         tf = backbone_module or transfuser_cpu
-        assert backbone in ('transFuser', 'latentTF')
+        assert backbone in ('transFuser', 'latentTF', 'geometric_fusion')
+        self.backbone = backbone
         kw = {} if backbone_module is not None else dict(make_net=make_net)
-        cls = tf.TransfuserBackbone if backbone == 'transFuser' else tf.latentTFBackbone
+        cls = dict(transFuser='TransfuserBackbone', latentTF='latentTFBackbone', geometric_fusion='GeometricFusionBackbone')[backbone]
+        cls = getattr(tf, cls)
         self._model = cls(config, image_architecture, lidar_architecture, use_velocity=use_velocity, **kw)
         if config.multitask:
             self.seg_decoder = tf.SegDecoder(config, config.perception_output_features)
@@ -58,7 +60,10 @@ class LidarCenterNet(nn.Module):
                 num_points=None, save_path=None, bev_points=None, cam_points=None):  # model.py:733-805
         if self.use_target_point_image:
             lidar_bev = torch.cat((lidar_bev, target_point_image), dim=1)
-        features, grid, fused = self._model(rgb, lidar_bev, ego_vel)
+        if self.backbone == 'geometric_fusion':   # model.py:749-750
+            features, grid, fused = self._model(rgb, lidar_bev, ego_vel, bev_points, cam_points)
+        else:
+            features, grid, fused = self._model(rgb, lidar_bev, ego_vel)
         pred_wp = self.forward_gru(fused, target_point)
         cfg = self.config
         pred_bev = F.interpolate(self.pred_bev(features[0]), (cfg.bev_resolution_height, cfg.bev_resolution_width),
@@ -91,7 +96,8 @@ def train_step(model, optimizer, batch, config):
     optimizer.zero_grad(set_to_none=True)
     losses = model(batch['rgb'], batch['lidar'], ego_waypoint=batch['ego_waypoint'], target_point=batch['target_point'],
                    target_point_image=batch['target_point_image'], ego_vel=batch['ego_vel'].reshape(-1, 1), bev=batch['bev'],
-                   label=batch['label'], depth=batch['depth'], semantic=batch['semantic'])
+                   label=batch['label'], depth=batch['depth'], semantic=batch['semantic'],
+                   **{k: batch[k] for k in ('bev_points', 'cam_points') if k in batch})
     loss = total_loss(losses, config)
     loss.backward()
     optimizer.step()

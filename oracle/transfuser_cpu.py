@@ -207,6 +207,76 @@ class latentTFBackbone(TransfuserBackbone):
         return super().forward(image, lidar, velocity)
 
 
+class GeometricFusionBackbone(TransfuserBackbone):
+    """team_code_transfuser/geometric_fusion.py:6-288 (BASELINE config 4), in the reference's operation order: 1x1 conv C->n_embd
+    on the full map, adaptive pool, gather (the reference's B x B advanced index + ``torch.diagonal`` :134-135 is restated as the
+    equivalent per-sample gather), sum over the 5 correspondences, 3 x [Linear+ReLU], ``F.interpolate(scale_factor=8/4/2)``
+    (none at stage 4), 1x1 conv n_embd->C, residual add, optional velocity embedding.  Quirk Q4 (:264): stage 4's image side
+    reads ``lidar_embd_layer3``.  LidarEncoder deletes the whole stem (:417)."""
+
+    SCALES = (8, 4, 2, None)
+
+    def __init__(self, config, image_architecture='regnety_032', lidar_architecture='regnety_032', use_velocity=0, make_net=None):
+        super().__init__(config, image_architecture, lidar_architecture, use_velocity, make_net)
+        for i in range(1, 5):
+            delattr(self, "transformer%d" % i)
+        del self.lidar_encoder._model.stem
+        self.use_velocity = use_velocity
+        chs = [f['num_chs'] for f in self.image_encoder.features.feature_info]
+        E = config.n_embd
+        mlp = lambda: nn.Sequential(nn.Linear(E, E), nn.ReLU(True), nn.Linear(E, E), nn.ReLU(True), nn.Linear(E, E), nn.ReLU(True))
+        for i in range(1, 5):
+            setattr(self, "image_conv%d" % i, nn.Conv2d(chs[i], E, 1))
+            setattr(self, "image_deconv%d" % i, nn.Conv2d(E, chs[i], 1))
+            setattr(self, "lidar_conv%d" % i, nn.Conv2d(chs[i], E, 1))
+            setattr(self, "lidar_deconv%d" % i, nn.Conv2d(E, chs[i], 1))
+            setattr(self, "image_projection%d" % i, mlp())
+            setattr(self, "lidar_projection%d" % i, mlp())
+            if use_velocity:
+                setattr(self, "vel_emb%d" % i, nn.Linear(1, chs[i]))
+
+    @staticmethod
+    def _gather_sum(emb, pts, h, w):
+        """emb (B,E,hs,ws); pts flat (B*h*w*5, 2) = (x, y): out[b,:,i,j] = sum_k emb[b, :, y, x]   (:133-136)."""
+        B, E = emb.shape[:2]
+        pts = pts.reshape(B, h * w * 5, 2)
+        b = torch.arange(B).view(B, 1).expand(B, h * w * 5)
+        g = emb.permute(0, 2, 3, 1)[b, pts[..., 1], pts[..., 0]]            # (B, h*w*5, E)
+        return g.view(B, h, w, 5, E).sum(3)                                 # (B, h, w, E)   (sum over the 5 points, :136)
+
+    def forward(self, image, lidar, velocity, bev_points, img_points):
+        im, li = self.image_encoder.features, self.lidar_encoder._model
+        x = im.bn1(im.conv1(normalize_imagenet(image)))
+        y = li.bn1(li.conv1(lidar))
+        lid_embd = {}
+        for i in range(1, 5):
+            x = getattr(im, "layer%d" % i)(x)
+            y = getattr(li, "layer%d" % i)(y)
+            if self.config.n_scale < 5 - i:
+                continue
+            img_e = self.avgpool_img(getattr(self, "image_conv%d" % i)(x))
+            lid_e = self.avgpool_lidar(getattr(self, "lidar_conv%d" % i)(y))
+            lid_embd[i] = lid_e
+            hi, wi = img_e.shape[-2:]
+            hl, wl = lid_e.shape[-2:]
+            sf = self.SCALES[i - 1]
+            up = (lambda t: F.interpolate(t, scale_factor=sf, mode='bilinear', align_corners=False)) if sf else (lambda t: t)
+            bev = getattr(self, "image_projection%d" % i)(self._gather_sum(img_e, bev_points, hl, wl)).permute(0, 3, 1, 2).contiguous()
+            y = y + getattr(self, "lidar_deconv%d" % i)(up(bev))
+            if self.use_velocity:
+                vel = getattr(self, "vel_emb%d" % i)(velocity).unsqueeze(-1).unsqueeze(-1)
+                y = y + vel
+            src = lid_embd[3] if i == 4 else lid_e                           # quirk Q4 (:264)
+            img = getattr(self, "lidar_projection%d" % i)(self._gather_sum(src, img_points, hi, wi)).permute(0, 3, 1, 2).contiguous()
+            x = x + getattr(self, "image_deconv%d" % i)(up(img))
+            if self.use_velocity:
+                x = x + vel
+        x = self.change_channel_conv_image(x)
+        y = self.change_channel_conv_lidar(y)
+        fused = torch.flatten(im.global_pool(x), 1) + torch.flatten(li.global_pool(y), 1)
+        return self.top_down(y), x, fused
+
+
 def _decoder(config, latent, out_ch):
     c1, c2, c3 = config.deconv_channel_num_1, config.deconv_channel_num_2, config.deconv_channel_num_3
     conv = lambda a, b: nn.Conv2d(a, b, 3, 1, 1)

@@ -47,6 +47,51 @@ def golden_inputs(seed=7):
     return (torch.randint(0, 256, (2, 3, 64, 128), generator=g).float(), torch.rand(2, 3, 64, 64, generator=g), torch.rand(2, 1, generator=g) * 8)
 
 
+def geo_config():
+    """Geometric fusion (BASELINE config 4) at toy size: anchors 2x3 / 3x3 so the FIXED x8/x4/x2/x1 factors of
+    geometric_fusion.py:139,177,216 fit a 64x96 image and a 96x96 BEV."""
+    cfg = golden_config()
+    cfg.img_vert_anchors, cfg.img_horz_anchors, cfg.lidar_vert_anchors, cfg.lidar_horz_anchors = 2, 3, 3, 3
+    cfg.n_embd = 32
+    return cfg
+
+
+def geo_inputs(seed=11):
+    g = torch.Generator().manual_seed(seed)
+    bev = torch.stack((torch.randint(0, 3, (2, 3, 3, 5), generator=g), torch.randint(0, 2, (2, 3, 3, 5), generator=g)), -1)
+    cam = torch.stack((torch.randint(0, 3, (2, 3, 2, 5), generator=g), torch.randint(0, 3, (2, 3, 2, 5), generator=g)), -1)
+    bev[0, 0, :2] = 0
+    cam[1, 1] = 0
+    return (torch.randint(0, 256, (2, 3, 64, 96), generator=g).float(), torch.rand(2, 3, 96, 96, generator=g), torch.rand(2, 1, generator=g) * 8, bev, cam)
+
+
+def geo_golden(ref_mod):
+    """Outputs AND a few parameter gradients of the reference's GeometricFusionBackbone (train mode)."""
+    cfg = geo_config()
+    out = {}
+    for use_vel in (0, 1):
+        torch.manual_seed(0)
+        m = ref_mod.GeometricFusionBackbone(cfg, "regnety_tiny", "regnety_tiny", use_velocity=use_vel)
+        seeded_fill(m)
+        m.train()
+        img, lid, vel, bev, cam = geo_inputs()
+        feats, grid, fused = m(img, lid, vel, bev, cam)
+        (feats[0].square().mean() + grid.square().mean() + fused.square().mean()).backward()
+        tag = "geo_vel%d" % use_vel
+        for i, f in enumerate(feats):
+            out["%s_p%d" % (tag, i + 2)] = f.detach().numpy()
+        out[tag + "_grid"] = grid.detach().numpy()
+        out[tag + "_fused"] = fused.detach().numpy()
+        for n in GEO_GRAD_KEYS + (("vel_emb2.weight",) if use_vel else ()):
+            out["%s_grad_%s" % (tag, n)] = dict(m.named_parameters())[n].grad.numpy()
+        assert m.lidar_conv4.weight.grad is None   # quirk Q4
+    return out
+
+
+GEO_GRAD_KEYS = ("image_conv1.weight", "lidar_conv3.weight", "image_projection2.2.weight", "lidar_projection4.4.bias", "lidar_deconv1.weight",
+                 "image_deconv4.bias", "image_encoder.features.s1.b1.conv1.conv.weight", "lidar_encoder._model.conv1.weight")
+
+
 def main():
     sys.path.insert(0, os.path.join(ROOT, "oracle", "timm_shim"))
     sys.path.insert(0, "/root/reference/team_code_transfuser")
@@ -79,6 +124,8 @@ def main():
         out["depth"] = dep(x).numpy()
         out["normalize_imagenet"] = ref.normalize_imagenet(golden_inputs()[0]).numpy()[:, :, :4, :8]
     np.savez_compressed(os.path.join(HERE, "transfuser_backbone_tiny.npz"), **out)
+    import geometric_fusion as ref_geo   # the reference module, unmodified
+    np.savez_compressed(os.path.join(HERE, "geometric_fusion_tiny.npz"), **geo_golden(ref_geo))
     # H1: numpy.histogramdd (the reference's algorithm, data.py:446-470) on a seeded cloud with edge cases -> sparse golden
     rng = np.random.default_rng(3)
     pts = np.stack([rng.uniform(-20, 20, 20000), rng.uniform(-36, 4, 20000), rng.uniform(-4, 1, 20000)], 1).astype(np.float32)

@@ -260,6 +260,31 @@ def check_bilinear(dev, B, C, Hi, Wi, Ho, Wo, in_nhwc, align):
     close(dx.permute(0, 3, 1, 2) if in_nhwc else dx, gx, what="bilinear bwd")
 
 
+GATHER_CASES = [(2, 5, 22, 8, 64, 5), (3, 8, 8, 512, 110, 5), (1, 2, 3, 4, 9, 5), (2, 4, 4, 36, 7, 3)]
+
+
+def check_gather_sum(dev, B, Hs, Ws, E, n, K):
+    """G1 vs the reference's own formulation: B x B advanced indexing + torch.diagonal (geometric_fusion.py:133-136)."""
+    g = torch.Generator().manual_seed(3)
+    emb = R(B, E, Hs, Ws, dev="cpu").requires_grad_(True)
+    pts = torch.stack((torch.randint(0, Ws, (B, n, K), generator=g), torch.randint(0, Hs, (B, n, K), generator=g)), -1)
+    pts[0, 0] = 0                                  # the dataset pads missing correspondences with (0, 0): duplicates
+    flat = pts.view(B * n * K, 2)
+    enc = emb.permute(0, 2, 3, 1).contiguous()[:, flat[:, 1], flat[:, 0]].view(B, B, n, 1, K, -1)
+    ref = torch.sum(torch.diagonal(enc, 0).permute(4, 3, 0, 1, 2).contiguous(), -1)[:, :, :, 0]     # (B, E, n)
+    src = emb.detach().permute(0, 2, 3, 1).reshape(B, Hs * Ws, E).contiguous().to(dev)
+    out = ops.gather_sum_fwd(src, pts.to(dev), Hs, Ws)
+    close(out.cpu(), ref.permute(0, 2, 1), what="gather_sum fwd", tol=1e-6)
+    dout = R(B, n, E, seed=5, dev="cpu")
+    (gemb,) = torch.autograd.grad(ref, [emb], dout.permute(0, 2, 1))
+    want = gemb.permute(0, 2, 3, 1).reshape(B, Hs * Ws, E)
+    dsrc = ops.gather_sum_bwd(dout.to(dev), pts.to(dev), Hs, Ws)
+    close(dsrc.cpu(), want, what="gather_sum bwd", tol=1e-5)
+    acc = R(B, Hs * Ws, E, seed=6, dev=dev)
+    dsrc2 = ops.gather_sum_bwd(dout.to(dev), pts.to(dev), Hs, Ws, out=acc.clone(), accumulate=True)
+    close(dsrc2.cpu(), want + acc.cpu(), what="gather_sum bwd accumulate", tol=1e-5)
+
+
 # ---------------------------------------------------------------- losses
 def check_ce(dev, rows, C, weighted):
     lg = R(rows, C, dev=dev).requires_grad_(True)

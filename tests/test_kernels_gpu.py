@@ -99,3 +99,8 @@ def test_centernet_targets_and_losses(case):
 @pytest.mark.parametrize("plan", kc.ENGINE_PLANS, ids=str)
 def test_engine_tilings(plan):
     kc.check_engine_plan("cuda", *plan)
+
+
+@pytest.mark.parametrize("case", kc.GATHER_CASES, ids=str)
+def test_gather_sum(case):
+    kc.check_gather_sum("cuda", *case)

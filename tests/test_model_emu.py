@@ -68,3 +68,44 @@ def test_latentTF_backbone_matches_oracle():
     batch = mc.small_batch(2, 32, 64, 128, 40)
     lp, lr = mc.run_pair(prod, ref, cfg, batch, "cpu")
     mc.compare_vs_fp64(prod, ref, lp, lr, batch, cfg)
+
+
+def test_geometric_fusion_backbone_matches_oracle():
+    """BASELINE config 4 backbone (geometric_fusion.py): gather kernel G1 + per-stage MLPs, velocity embeddings on,
+    quirk Q4 (lidar_conv4 unreachable).  Anchors 2x3 / 3x3 so the fixed x8/x4/x2/x1 factors give a 64x96 image and a 96x96 BEV."""
+    cfg = mc.tiny_config(n_layer=1, lidar_res=96)
+    cfg.img_vert_anchors, cfg.img_horz_anchors, cfg.lidar_vert_anchors, cfg.lidar_horz_anchors = 2, 3, 3, 3
+    cfg.n_embd = 32
+    prod, ref = mc.build_pair(cfg, "regnety_tiny", "cpu", backbone="geometric_fusion", use_velocity=True)
+    batch = mc.small_batch(2, 64, 96, 96, 40)
+    batch.update(mc.geo_points(2, cfg))
+    lp, lr = mc.run_pair(prod, ref, cfg, batch, "cpu")
+    assert prod._model.lidar_conv4.weight.grad is None and ref._model.lidar_conv4.weight.grad is None
+    mc.compare_vs_fp64(prod, ref, lp, lr, batch, cfg)
+
+
+def test_geometric_fusion_engine_skips_unreachable_parameters():
+    """Engine + geometric fusion: two AdamW steps track the oracle's torch.optim.AdamW, and lidar_conv4 (grad None in the
+    reference, quirk Q4) is bit-identical afterwards - no weight decay applied, exactly like torch.optim.AdamW."""
+    from oracle import model_cpu
+    from transfuser_amd.train import Engine
+    cfg = mc.tiny_config(n_layer=1, lidar_res=96)
+    cfg.img_vert_anchors, cfg.img_horz_anchors, cfg.lidar_vert_anchors, cfg.lidar_horz_anchors = 2, 3, 3, 3
+    cfg.n_embd = 32
+    prod, ref = mc.build_pair(cfg, "regnety_tiny", "cpu", backbone="geometric_fusion", use_velocity=True)
+    w4 = prod._model.lidar_conv4.weight.detach().clone()
+    eng = Engine(prod, cfg, lr=1e-3)
+    assert eng.arena.active_numel < eng.arena.numel
+    opt = torch.optim.AdamW(ref.parameters(), lr=1e-3)
+    batch = mc.small_batch(2, 64, 96, 96, 40)
+    batch.update(mc.geo_points(2, cfg))
+    prod.train(); ref.train()
+    for it in range(2):
+        tot_p, _ = eng.train_step(batch)
+        tot_r, _ = model_cpu.train_step(ref, opt, batch, cfg)
+        assert abs(float(tot_p) - float(tot_r)) <= 1e-3 * max(1.0, abs(float(tot_r))), (it, float(tot_p), float(tot_r))
+    assert torch.equal(prod._model.lidar_conv4.weight, w4) and torch.equal(ref._model.lidar_conv4.weight, w4)
+    rp = dict(ref.named_parameters())
+    diffs = [((p.detach() - rp[n].detach()).abs(), n) for n, p in prod.named_parameters()]
+    assert max(d.max().item() for d, _ in diffs) < 4.4e-3
+    assert sum(d.sum().item() for d, _ in diffs) / sum(d.numel() for d, _ in diffs) < 2e-5

@@ -26,6 +26,15 @@ def test_tiny_model_losses_and_grads():
     mc.compare(prod, ref, lp, lr, grad_tol=5e-3, verbose=True, metric="l2")
 
 
+def test_tiny_latentTF_losses_and_grads():
+    """BASELINE config 5 backbone (latentTF.py:118-217): positional grid replaces the LiDAR histogram."""
+    cfg = mc.tiny_config(n_layer=2, lidar_res=128)
+    prod, ref = mc.build_pair(cfg, "regnety_tiny", "cuda", backbone="latentTF")
+    batch = mc.small_batch(2, 160, 352, 128, 40)
+    lp, lr = mc.run_pair(prod, ref, cfg, batch, "cuda")
+    mc.compare_vs_fp64(prod, ref, lp, lr, batch, cfg)
+
+
 @pytest.mark.parametrize("H,B", [(160, 2), (256, 1)], ids=["H160_reference_resolution", "H256_bench_resolution"])
 def test_regnety032_model_losses_and_grads(H, B):
     """The real architecture (RegNetY-3.2GF x2, 4 GPT stages x 4 layers, 168.0 M parameters) at the
@@ -38,6 +47,41 @@ def test_regnety032_model_losses_and_grads(H, B):
     batch = synthetic_batch(B, H, 704, seed=0, hist_fn=hist.lidar_to_histogram_features, n_points=8192)
     lp, lr = mc.run_pair(prod, ref, cfg, batch, "cuda")
     mc.compare_vs_fp64(prod, ref, lp, lr, batch, cfg)
+
+
+def test_tiny_geometric_fusion_losses_and_grads():
+    """BASELINE config 4 backbone (geometric_fusion.py): gather kernel G1, velocity embeddings, quirk Q4."""
+    cfg = mc.tiny_config(n_layer=1, lidar_res=96)
+    cfg.img_vert_anchors, cfg.img_horz_anchors, cfg.lidar_vert_anchors, cfg.lidar_horz_anchors = 2, 3, 3, 3
+    cfg.n_embd = 32
+    prod, ref = mc.build_pair(cfg, "regnety_tiny", "cuda", backbone="geometric_fusion", use_velocity=True)
+    batch = mc.small_batch(2, 64, 96, 96, 40)
+    batch.update(mc.geo_points(2, cfg))
+    lp, lr = mc.run_pair(prod, ref, cfg, batch, "cuda")
+    assert prod._model.lidar_conv4.weight.grad is None
+    mc.compare_vs_fp64(prod, ref, lp, lr, batch, cfg)
+
+
+def test_regnety032_geometric_fusion_reference_resolution():
+    """Config 4 at its only valid resolution (160x704 + 256x256, default anchors, n_embd 512), real RegNetY-3.2GF trunks:
+    48.6 M-parameter backbone; the Engine (flat arena, AdamW skipping the unreachable lidar_conv4) takes steps."""
+    from oracle import hist
+    from transfuser_amd.data import synthetic_batch
+    from transfuser_amd.train import Engine
+    cfg = mc.full_config()
+    prod, ref = mc.build_pair(cfg, "regnety_032", "cuda", backbone="geometric_fusion")
+    assert sum(p.numel() for p in prod._model.parameters()) == 48619940
+    batch = synthetic_batch(2, 160, 704, seed=0, hist_fn=hist.lidar_to_histogram_features, n_points=8192)
+    batch = {k: batch[k] for k in Engine.BATCH_KEYS + Engine.GEO_KEYS}
+    lp, lr = mc.run_pair(prod, ref, cfg, batch, "cuda")
+    mc.compare_vs_fp64(prod, ref, lp, lr, batch, cfg)
+    w4 = prod._model.lidar_conv4.weight.detach().clone()
+    eng = Engine(prod, cfg, lr=1e-3)
+    bd = {k: v.cuda() for k, v in batch.items()}
+    l0 = float(eng.train_step(bd)[0])
+    for _ in range(3):
+        l1 = float(eng.train_step(bd)[0])
+    assert l1 < l0 and torch.equal(prod._model.lidar_conv4.weight, w4)   # untouched: no weight decay on grad-None parameters
 
 
 def test_engine_graph_replay_matches_eager():

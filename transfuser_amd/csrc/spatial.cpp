@@ -182,6 +182,63 @@ inline float bl_scale(int in, int out, int align) {
     return (float)in / (float)out;
 }
 
+// ---- G1: geometric-fusion correspondence gather (geometric_fusion.py:134-137,147-150).  The reference gathers B x B and keeps the
+// diagonal; here each sample gathers only its own K correspondences.  idx holds (x, y) int64 pairs, src is (B, Hs*Ws, E).
+constexpr int kGatherMaxCorr = 2048;   // n*K correspondences per sample (reference: 8*8*5 = 320 and 5*22*5 = 550)
+
+__global__ void __launch_bounds__(256) gather_sum_fwd_kernel(const float* __restrict__ src, const long long* __restrict__ idx, int B, int S, int Ws,
+                                                             int E, int n, int K, float* __restrict__ out) {
+    const int ev = E >> 2;
+    const long total = (long)B * n * ev;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+        const int e = (int)(t % ev) * 4;
+        const long cell = t / ev;                  // b * n + i
+        const int b = (int)(cell / n);
+        const long long* q = idx + cell * K * 2;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < K; ++k) {
+            long long j = q[2 * k + 1] * Ws + q[2 * k];
+            j = j < 0 ? 0 : (j >= S ? S - 1 : j);   // indices are validated on the host; clamp keeps a bad value from faulting
+            const float4 v = *reinterpret_cast<const float4*>(src + ((long)b * S + j) * E + e);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        *reinterpret_cast<float4*>(out + cell * E + e) = acc;
+    }
+}
+
+// backward = the transposed gather, evaluated per SOURCE cell in a fixed order (deterministic, no atomics): every block owns one
+// (sample, source cell), scans the n*K correspondences of that sample staged in LDS and adds the matching rows of dout.
+__global__ void __launch_bounds__(128) gather_sum_bwd_kernel(const float* __restrict__ dout, const long long* __restrict__ idx, int B, int S, int Ws,
+                                                             int E, int n, int K, float* __restrict__ dsrc, int accumulate) {
+    __shared__ int hits[kGatherMaxCorr];            // destination cells i that read this source cell (with multiplicity)
+    __shared__ int nhit;
+    const int b = blockIdx.x / S, j = blockIdx.x % S;
+    if (threadIdx.x == 0) nhit = 0;
+    __syncthreads();
+    const long long* q = idx + (long)b * n * K * 2;
+    if (threadIdx.x == 0) {                         // n*K <= a few hundred: a serial ordered scan keeps the summation order fixed
+        int c = 0;
+        for (int t = 0; t < n * K; ++t) {
+            long long jj = q[2 * t + 1] * Ws + q[2 * t];
+            jj = jj < 0 ? 0 : (jj >= S ? S - 1 : jj);
+            if ((int)jj == j) hits[c++] = t / K;
+        }
+        nhit = c;
+    }
+    __syncthreads();
+    const int c = nhit;
+    for (int e = threadIdx.x * 4; e < E; e += 128 * 4) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int h = 0; h < c; ++h) {
+            const float4 v = *reinterpret_cast<const float4*>(dout + ((long)b * n + hits[h]) * E + e);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        float4* o = reinterpret_cast<float4*>(dsrc + ((long)b * S + j) * E + e);
+        if (accumulate) { const float4 p = *o; acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w; }
+        *o = acc;
+    }
+}
+
 }  // namespace
 
 extern "C" int tf_pool_tokens_fwd_f32(const float* x, int B, int H, int W, int C, int oh, int ow, const float* pos, const float* bvec, float* tok,
@@ -216,4 +273,20 @@ extern "C" int tf_bilinear_bwd_f32(const tf_bilinear_desc* d, const float* dy, f
     TF_LAUNCH(bilinear_bwd_kernel, dim3(ew_blocks(n)), dim3(256), stream, *d, dy, dx, bl_scale(d->Hi, d->Ho, d->align_corners),
               bl_scale(d->Wi, d->Wo, d->align_corners), accumulate, d->sc_i == 1 ? 1 : 0);
     return launch_status("tf_bilinear_bwd_f32");
+}
+
+extern "C" int tf_gather_sum_fwd_f32(const float* src, const long long* idx, int B, int Hs, int Ws, int E, int n, int K, float* out, void* stream) {
+    TF_REQUIRE(src && idx && out && B > 0 && Hs > 0 && Ws > 0 && E > 0 && E % 4 == 0 && n > 0 && K > 0 && aligned16(src) && aligned16(out),
+               "tf_gather_sum_fwd_f32: bad arguments (E must be a multiple of 4, pointers 16-byte aligned)");
+    const long total = (long)B * n * (E / 4);
+    TF_LAUNCH(gather_sum_fwd_kernel, dim3(ew_blocks(total)), dim3(256), stream, src, idx, B, Hs * Ws, Ws, E, n, K, out);
+    return launch_status("tf_gather_sum_fwd_f32");
+}
+
+extern "C" int tf_gather_sum_bwd_f32(const float* dout, const long long* idx, int B, int Hs, int Ws, int E, int n, int K, float* dsrc, int accumulate,
+                                     void* stream) {
+    TF_REQUIRE(dout && idx && dsrc && B > 0 && Hs > 0 && Ws > 0 && E > 0 && E % 4 == 0 && n > 0 && K > 0 && aligned16(dout) && aligned16(dsrc) &&
+               (long)n * K <= kGatherMaxCorr, "tf_gather_sum_bwd_f32: bad arguments (E % 4 == 0, n*K <= 2048)");
+    TF_LAUNCH(gather_sum_bwd_kernel, dim3(B * Hs * Ws), dim3(128), stream, dout, idx, B, Hs * Ws, Ws, E, n, K, dsrc, accumulate);
+    return launch_status("tf_gather_sum_bwd_f32");
 }

@@ -41,7 +41,11 @@ def synthetic_batch(B, H=256, W=704, seed=0, hist_fn=None, n_points=32768):
             label[b, :k, 4] = torch.from_numpy(rng.uniform(-math.pi, math.pi, k)).float()
             label[b, :k, 5] = torch.from_numpy(rng.uniform(0, 8, k)).float()
             label[b, :k, 6] = torch.from_numpy(rng.integers(0, 2, k)).float()
+    g2 = torch.Generator().manual_seed(seed + 2)   # C4 correspondences (data.py:632-675): bev_points (x<22, y<5), cam_points (<8)
+    bev_points = torch.stack((torch.randint(0, 22, (B, 8, 8, 5), generator=g2), torch.randint(0, 5, (B, 8, 8, 5), generator=g2)), -1)
+    cam_points = torch.randint(0, 8, (B, 22, 5, 5, 2), generator=g2)
     return dict(
+        bev_points=bev_points, cam_points=cam_points,
         rgb=torch.randint(0, 256, (B, 3, H, W), generator=g).float(),
         lidar=torch.from_numpy(lidar).float(),
         lidar_raw=torch.from_numpy(np.pad(cloud, ((0, 0), (0, 40000 - n_points), (0, 0)))),

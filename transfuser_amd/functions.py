@@ -307,6 +307,117 @@ class GPTStageFn(torch.autograd.Function):
         return (dx_img, dx_lid, None, None) + (None,) * (len(ctx.needs_input_grad) - 4)
 
 
+# ============================================================================================ geometric-fusion stage (C4)
+def _mlp_fwd(h, seq):
+    """3 x [Linear + ReLU] (geometric_fusion.py:56-64): returns the activation list [h0, h1, h2, h3]."""
+    acts = [h]
+    for lin in (seq[0], seq[2], seq[4]):
+        acts.append(ops.linear_fwd(acts[-1], lin.weight, lin.bias, relu=True))
+    return acts
+
+
+def _mlp_bwd(dh, acts, seq):
+    for i, lin in reversed(list(enumerate((seq[0], seq[2], seq[4])))):
+        g = ops.relu_mask(dh, acts[i + 1])
+        ops.linear_wgrad(g, acts[i], gbuf(lin.weight))
+        bias_grad(g, lin.bias)
+        dh = ops.linear_dgrad(g, lin.weight)
+    return dh
+
+
+class GeoStageFn(torch.autograd.Function):
+    """One geometric-fusion stage for both branches (geometric_fusion.py:125-166 and the three copies below it):
+    1x1 conv C->E + adaptive pool, gather the 5 correspondences of every cell from the OTHER branch (kernel G1), sum, 3-layer
+    MLP, bilinear up-sample by the stage's fixed factor, 1x1 conv E->C, residual add (+ velocity embedding).
+
+    Both 1x1 convs are evaluated at the pooled resolution: average pooling and bilinear interpolation are affine maps whose
+    weights sum to one, so conv(pool(x)) == pool(conv(x)) and conv(up(z)) == up(conv(z)) in exact arithmetic (differences are
+    fp32 round-off); this removes ~95 % of the stage's FLOPs.  Quirk Q4: stage 4's image side gathers from stage 3's pooled
+    LiDAR embedding (``prev_lid_e``); ``lidar_conv4`` therefore never receives a gradient."""
+
+    @staticmethod
+    def forward(ctx, x_img, x_lid, prev_lid_e, st, velocity, bev_idx, img_idx, *params):
+        ctx.set_materialize_grads(False)
+        g = st.geom
+        B, Hi, Wi, C = x_img.shape
+        _, Hl, Wl, _ = x_lid.shape
+        assert (Hi, Wi, Hl, Wl) == (g.ih * st.scale, g.iw * st.scale, g.lh * st.scale, g.lw * st.scale), \
+            "geometric fusion: feature maps %s / %s do not match the fixed scale factor %d (reference shape error at geometric_fusion.py:154)" % (
+                (Hi, Wi), (Hl, Wl), st.scale)
+        E = st.image_conv.weight.shape[0]
+        n_img, n_lid = g.ih * g.iw, g.lh * g.lw
+        dev = x_img.device
+        pi = ops.pool_tokens_fwd(x_img, g.ih, g.iw, None, torch.empty(B, n_img, C, dtype=torch.float32, device=dev), 0)
+        img_e = ops.linear_fwd(pi.view(-1, C), w2d(st.image_conv.weight), st.image_conv.bias)
+        pl = lid_e = None
+        if not st.use_prev:
+            pl = ops.pool_tokens_fwd(x_lid, g.lh, g.lw, None, torch.empty(B, n_lid, C, dtype=torch.float32, device=dev), 0)
+            lid_e = ops.linear_fwd(pl.view(-1, C), w2d(st.lidar_conv.weight), st.lidar_conv.bias)
+        src = prev_lid_e if st.use_prev else lid_e
+        vel_l = vel_i = vrep_l = vrep_i = None
+        if st.vel_emb is not None:   # vel_emb(velocity)[:, :, None, None] added to both maps == added to the low-res increment
+            vrep_l = velocity.reshape(B, 1).repeat_interleave(n_lid, 0).contiguous()
+            vrep_i = velocity.reshape(B, 1).repeat_interleave(n_img, 0).contiguous()
+            vel_l = ops.linear_fwd(vrep_l, st.vel_emb.weight, st.vel_emb.bias)
+            vel_i = ops.linear_fwd(vrep_i, st.vel_emb.weight, st.vel_emb.bias)
+        # image -> BEV
+        gb = ops.gather_sum_fwd(img_e.view(B, n_img, E), bev_idx, g.ih, g.iw)
+        hb = _mlp_fwd(gb.view(-1, E), st.image_projection)
+        inc_l = ops.linear_fwd(hb[-1], w2d(st.lidar_deconv.weight), st.lidar_deconv.bias, res=vel_l)
+        out_lid = ops.bilinear_fwd(inc_l, B, C, g.lh, g.lw, Hl, Wl, add=x_lid)
+        # BEV -> image
+        gi = ops.gather_sum_fwd(src.reshape(B, n_lid, E), img_idx, g.lh, g.lw)
+        hi = _mlp_fwd(gi.view(-1, E), st.lidar_projection)
+        inc_i = ops.linear_fwd(hi[-1], w2d(st.image_deconv.weight), st.image_deconv.bias, res=vel_i)
+        out_img = ops.bilinear_fwd(inc_i, B, C, g.ih, g.iw, Hi, Wi, add=x_img)
+        ctx.saved = (st, x_img.shape, x_lid.shape, pi, pl, hb, hi, bev_idx, img_idx, vrep_l, vrep_i)
+        if lid_e is not None:
+            lid_e = lid_e.view(B, n_lid, E)
+        return out_img, out_lid, lid_e
+
+    @staticmethod
+    def backward(ctx, d_img, d_lid, d_lid_e_out):
+        st, s_img, s_lid, pi, pl, hb, hi, bev_idx, img_idx, vrep_l, vrep_i = ctx.saved
+        g = st.geom
+        B, Hi, Wi, C = s_img
+        _, Hl, Wl, _ = s_lid
+        E = st.image_conv.weight.shape[0]
+        n_img, n_lid = g.ih * g.iw, g.lh * g.lw
+        d_img, d_lid = d_img.contiguous(), d_lid.contiguous()
+
+        def side(d_map, oh, ow, Ho, Wo, deconv, acts, proj, vrep):
+            dinc = ops.bilinear_bwd(d_map, B, C, oh, ow, Ho, Wo).view(-1, C)
+            ops.linear_wgrad(dinc, acts[-1], w2d(gbuf(deconv.weight)))
+            bias_grad(dinc, deconv.bias)
+            if vrep is not None:
+                ops.linear_wgrad(dinc, vrep, gbuf(st.vel_emb.weight))
+                bias_grad(dinc, st.vel_emb.bias)
+            return _mlp_bwd(ops.linear_dgrad(dinc, w2d(deconv.weight)), acts, proj)
+
+        dgb = side(d_lid, g.lh, g.lw, Hl, Wl, st.lidar_deconv, hb, st.image_projection, vrep_l)
+        d_img_e = ops.gather_sum_bwd(dgb.view(B, n_lid, E), bev_idx, g.ih, g.iw).view(-1, E)
+        dgi = side(d_img, g.ih, g.iw, Hi, Wi, st.image_deconv, hi, st.lidar_projection, vrep_i)
+        d_src = ops.gather_sum_bwd(dgi.view(B, n_img, E), img_idx, g.lh, g.lw)
+        d_prev = None
+        if st.use_prev:
+            d_prev, d_lid_e = d_src, d_lid_e_out
+        else:
+            d_lid_e = d_src if d_lid_e_out is None else ops.axpby(d_src, d_lid_e_out.contiguous().view_as(d_src), 1.0, 1.0, out=d_src)
+        ops.linear_wgrad(d_img_e, pi.view(-1, C), w2d(gbuf(st.image_conv.weight)))
+        bias_grad(d_img_e, st.image_conv.bias)
+        dpi = ops.linear_dgrad(d_img_e, w2d(st.image_conv.weight))
+        dx_img = ops.pool_tokens_bwd(dpi.view(B, n_img, C), s_img, g.ih, g.iw, 0, add=d_img)
+        dx_lid = d_lid
+        if d_lid_e is not None and pl is not None:
+            d2 = d_lid_e.contiguous().view(-1, E)
+            ops.linear_wgrad(d2, pl.view(-1, C), w2d(gbuf(st.lidar_conv.weight)))
+            bias_grad(d2, st.lidar_conv.bias)
+            dpl = ops.linear_dgrad(d2, w2d(st.lidar_conv.weight))
+            dx_lid = ops.pool_tokens_bwd(dpl.view(B, n_lid, C), s_lid, g.lh, g.lw, 0, add=d_lid)
+        ctx.saved = None
+        return (dx_img, dx_lid, d_prev, None, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 7)
+
+
 # ============================================================================================ generic conv / resample
 class ConvFn(torch.autograd.Function):
     """conv (1x1 or 3x3, stride 1, bias) (+ReLU) on NHWC: decoders, heads, FPN, channel reducers."""

@@ -6,14 +6,15 @@ targets :285-374, losses :150-248 with mmdet 2.25 semantics).
 Same parameter names/shapes (reference checkpoints load with strict=True), same call signature,
 same return value; everything between the input tensors and the loss scalars runs in the HIP
 kernels of libtransfuser_hip.so.  Out of scope here: ``forward_ego`` / box decoding /
-PID control / visualisation (CARLA inference), ``late_fusion`` / ``geometric_fusion``
-backbones, PointPillars (``use_point_pillars``) - requesting them raises.
+PID control / visualisation (CARLA inference), the ``late_fusion``
+backbone, PointPillars (``use_point_pillars``) - requesting them raises.
 """
 import torch
 from torch import nn
 
 from . import functions as F_
 from . import ops
+from .geometric_fusion import GeometricFusionBackbone
 from .transfuser import DepthDecoder, SegDecoder, TransfuserBackbone, latentTFBackbone, nchw
 
 HEAD_ORDER = ("heatmap_head", "wh_head", "offset_head", "yaw_class_head", "yaw_res_head", "velocity_head", "brake_head")
@@ -118,8 +119,10 @@ class LidarCenterNet(nn.Module):
             self._model = TransfuserBackbone(config, image_architecture, lidar_architecture, use_velocity=use_velocity)
         elif backbone == 'latentTF':
             self._model = latentTFBackbone(config, image_architecture, lidar_architecture, use_velocity=use_velocity)
+        elif backbone == 'geometric_fusion':
+            self._model = GeometricFusionBackbone(config, image_architecture, lidar_architecture, use_velocity=use_velocity)
         else:
-            raise NotImplementedError("backbone %r: 'transFuser' and 'latentTF' are built; geometric_fusion / late_fusion are SURVEY.md section 8 next rows" % (backbone,))
+            raise NotImplementedError("backbone %r: 'transFuser', 'latentTF' and 'geometric_fusion' are built; late_fusion is outside SURVEY.md section 8" % (backbone,))
         if config.multitask:
             self.seg_decoder = SegDecoder(config, config.perception_output_features)
             self.depth_decoder = DepthDecoder(config, config.perception_output_features)
@@ -149,7 +152,10 @@ class LidarCenterNet(nn.Module):
                 num_points=None, save_path=None, bev_points=None, cam_points=None):
         cfg = self.config
         extra = target_point_image if self.use_target_point_image else None
-        features, grid, fused = self._model.forward_nhwc(rgb, lidar_bev, ego_vel, lidar_extra=extra)
+        if self.backbone == 'geometric_fusion':   # model.py:749-750
+            features, grid, fused = self._model.forward_nhwc(rgb, lidar_bev, ego_vel, bev_points, cam_points, lidar_extra=extra)
+        else:
+            features, grid, fused = self._model.forward_nhwc(rgb, lidar_bev, ego_vel, lidar_extra=extra)
         pred_wp, _, _, _, _ = self.forward_gru(fused, target_point)
         p2 = features[0]
         pred, bev_logits = HeadsFn.apply(p2, self, *self.head.parameters(), *self.pred_bev.parameters())

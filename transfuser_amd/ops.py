@@ -358,6 +358,27 @@ def bilinear_bwd(dy, B, C, Hi, Wi, Ho, Wo, in_nhwc=True, out_nhwc=True, align_co
     return out
 
 
+def gather_sum_fwd(src, idx, Hs, Ws):
+    """G1: out[b,i,:] = sum_k src[b, idx[b,i,k,1]*Ws + idx[b,i,k,0], :]; src (B, Hs*Ws, E), idx (B, n, K, 2) int64 (x, y)."""
+    B, S, E = src.shape
+    assert S == Hs * Ws and idx.dtype == torch.int64 and idx.dim() == 4 and idx.shape[0] == B and idx.shape[3] == 2
+    n, K = idx.shape[1], idx.shape[2]
+    out = torch.empty(B, n, E, dtype=torch.float32, device=src.device)
+    check(L().tf_gather_sum_fwd_f32(ptr(_c(src)), ptr(_c(idx)), B, Hs, Ws, E, n, K, ptr(out), stream_of(src)), "tf_gather_sum_fwd_f32")
+    return out
+
+
+def gather_sum_bwd(dout, idx, Hs, Ws, out=None, accumulate=False):
+    """Transposed gather of gather_sum_fwd (fixed summation order): dsrc (B, Hs*Ws, E)."""
+    B, n, E = dout.shape
+    K = idx.shape[2]
+    if out is None:
+        assert not accumulate
+        out = torch.empty(B, Hs * Ws, E, dtype=torch.float32, device=dout.device)
+    check(L().tf_gather_sum_bwd_f32(ptr(_c(dout)), ptr(_c(idx)), B, Hs, Ws, E, n, K, ptr(_c(out)), int(accumulate), stream_of(dout)), "tf_gather_sum_bwd_f32")
+    return out
+
+
 # ------------------------------------------------------------------------------------------ losses
 def ce_fwd(logits, target, class_w=None):
     """logits (..., C) NHWC, target (...) int64 -> (loss 0-dim, dlogits unscaled, inv_wsum 1-elem)."""

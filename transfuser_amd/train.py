@@ -40,6 +40,10 @@ class ParamArena:
             if id(p) not in seen:
                 seen.add(id(p))
                 named.append((n, p))
+        # parameters the reference's autograd graph never reaches keep grad None there and torch.optim.AdamW skips them
+        # (no weight decay either): they go to the END of the arena, outside the range the optimizer updates.
+        unused = {id(p) for m in model.modules() if hasattr(m, "unused_parameters") for p in m.unused_parameters()}
+        named = [t for t in named if id(t[1]) not in unused] + [t for t in named if id(t[1]) in unused]
         groups, order = {}, []
         for n, p in named:
             k, rank = _group_key(n)
@@ -53,9 +57,9 @@ class ParamArena:
             for _, n, p in sorted(groups[k], key=lambda t: t[0]):
                 layout.append((n, p, off))
                 off += p.numel()   # no padding inside a group: members are exactly contiguous
-                if len(groups[k]) == 1:
-                    pass
         self.numel = (off + _ALIGN - 1) // _ALIGN * _ALIGN
+        first_unused = [o for n, p, o in layout if id(p) in unused]
+        self.active_numel = first_unused[0] // _ALIGN * _ALIGN if first_unused else self.numel
         dev = named[0][1].device
         self.params = torch.zeros(self.numel, dtype=torch.float32, device=dev)
         self.grads = torch.zeros(self.numel, dtype=torch.float32, device=dev)
@@ -90,8 +94,8 @@ class FlatAdamW:
         self.arena.zero_grad()
 
     def step(self):
-        a = self.arena
-        ops.adamw_(a.params, a.grads, self.exp_avg, self.exp_avg_sq, self.state, self.betas[0], self.betas[1], self.eps, self.weight_decay)
+        a, n = self.arena, self.arena.active_numel
+        ops.adamw_(a.params[:n], a.grads[:n], self.exp_avg[:n], self.exp_avg_sq[:n], self.state, self.betas[0], self.betas[1], self.eps, self.weight_decay)
 
     def state_dict(self):
         return dict(exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, state=self.state)
@@ -155,6 +159,7 @@ class Engine:
     """One training iteration of train.py:304-316 on a resident batch."""
 
     BATCH_KEYS = ("rgb", "lidar", "ego_waypoint", "target_point", "target_point_image", "ego_vel", "bev", "label", "depth", "semantic")
+    GEO_KEYS = ("bev_points", "cam_points")   # train.py:280-288 (geometric_fusion only)
 
     def __init__(self, model, config, lr=1e-4, use_graph=False, group=None, bucket_mb=64.0, wp_only=False, autotune=True, plan_file=None):
         self.model = model
@@ -177,9 +182,10 @@ class Engine:
 
     def load_data_compute_loss(self, data):
         """train.py:246-293 (transFuser branch); ``data`` tensors must already be on the device."""
+        extra = {k: data[k] for k in self.GEO_KEYS} if getattr(self.model, "backbone", "") == "geometric_fusion" else {}
         return self.model(data["rgb"], data["lidar"], ego_waypoint=data["ego_waypoint"], target_point=data["target_point"],
                           target_point_image=data["target_point_image"], ego_vel=data["ego_vel"].reshape(-1, 1), bev=data["bev"],
-                          label=data["label"], depth=data["depth"], semantic=data["semantic"])
+                          label=data["label"], depth=data["depth"], semantic=data["semantic"], **extra)
 
     def _fwd_bwd(self, data):
         if self._autotune_pending and not torch.cuda.is_current_stream_capturing():
@@ -215,7 +221,7 @@ class Engine:
         if self._graph is None:
             self._capture(data)
         else:
-            for k in self.BATCH_KEYS:
+            for k in self._static:
                 if self._static[k].data_ptr() != data[k].data_ptr():
                     self._static[k].copy_(data[k], non_blocking=True)
         self._graph.replay()
@@ -227,7 +233,7 @@ class Engine:
     def _capture(self, data):
         """Capture forward+backward(+AdamW when single-GPU) into a hipGraph.  With >1 rank the gradient
         all-reduce stays outside the graph (eager RCCL calls) followed by a second, tiny AdamW graph."""
-        self._static = {k: data[k].clone() for k in self.BATCH_KEYS}
+        self._static = {k: data[k].clone() for k in self.BATCH_KEYS + self.GEO_KEYS if k in data}
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):   # warm-up on a side stream (allocator + lazy inits) before capture

@@ -160,24 +160,21 @@ class LidarEncoder(nn.Module):
         del self._model.stem.conv  # transfuser.py:482-483
 
 
-class TransfuserBackbone(nn.Module):
-    """Multi-scale fusion transformer for image + LiDAR features (transfuser.py:7-211)."""
+class _FusionBackbone(nn.Module):
+    """What the reference's backbones share: the two RegNet trunks, the 1512->512 channel reducers, the FPN top-down path
+    (transfuser.py:91-118) and the two-stream execution of the trunks."""
 
-    def __init__(self, config, image_architecture='resnet34', lidar_architecture='resnet18', use_velocity=True):
-        super().__init__()
+    def _build_common(self, config, image_architecture, lidar_architecture):
         self.config = config
         self.image_encoder = ImageCNN(architecture=image_architecture, normalize=True, out_features=config.perception_output_features)
         in_channels = config.num_features[-1] if config.use_point_pillars else 2 * config.lidar_seq_len
         if config.use_target_point_image:
             in_channels += 1
         self.lidar_encoder = LidarEncoder(architecture=lidar_architecture, in_channels=in_channels, out_features=config.perception_output_features)
-        chs = [f['num_chs'] for f in self.image_encoder.features.feature_info]
-        for i in range(1, 5):
-            setattr(self, "transformer%d" % i, GPT(n_embd=chs[i], n_head=config.n_head, block_exp=config.block_exp, n_layer=config.n_layer,
-                                                   img_vert_anchors=config.img_vert_anchors, img_horz_anchors=config.img_horz_anchors,
-                                                   lidar_vert_anchors=config.lidar_vert_anchors, lidar_horz_anchors=config.lidar_horz_anchors,
-                                                   seq_len=config.seq_len, embd_pdrop=config.embd_pdrop, attn_pdrop=config.attn_pdrop,
-                                                   resid_pdrop=config.resid_pdrop, config=config, use_velocity=use_velocity))
+        return [f['num_chs'] for f in self.image_encoder.features.feature_info]
+
+    def _build_neck(self, chs):
+        config = self.config
         pf = config.perception_output_features
         if chs[4] != pf:
             self.change_channel_conv_image = nn.Conv2d(chs[4], pf, (1, 1))
@@ -192,7 +189,6 @@ class TransfuserBackbone(nn.Module):
         self.up_conv4 = nn.Conv2d(channel, channel, (1, 1))
         self.up_conv3 = nn.Conv2d(channel, channel, (1, 1))
         self.c5_conv = nn.Conv2d(pf, channel, (1, 1))
-        self.register_buffer("dropout_seed", torch.zeros(1, dtype=torch.int32), persistent=False)
         self._img_stem = _Stem(self.image_encoder.features.conv1, self.image_encoder.features.bn1, True)
         self._lid_stem = _Stem(self.lidar_encoder._model.conv1, self.lidar_encoder._model.bn1, False)
 
@@ -223,14 +219,12 @@ class TransfuserBackbone(nn.Module):
     def top_down(self, x):
         return tuple(nchw(p) for p in self.top_down_nhwc(nhwc(x)))
 
-    def forward_nhwc(self, image, lidar, velocity, lidar_extra=None):
-        """image (B,3,H,W) 0..255, lidar (B,2|3,256,256) [+ lidar_extra (B,1,256,256) instead of torch.cat];
-        returns NHWC tensors: (p2,p3,p4,p5), image_features_grid, fused_features."""
+    def _run(self, image, lidar, lidar_extra, fuse):
+        """Stem + 4 stages of both trunks with ``fuse(i, x, y) -> (x, y)`` after stage i, then the neck.
+        The two trunks are independent between fusion stages: the LiDAR branch runs on a side HIP stream so its blocks fill
+        the tail rounds of the image branch's kernels (and vice versa); under hipGraph capture the fork/join below become
+        graph edges.  Autograd replays each node's backward on its forward stream, so the backward overlaps the same way."""
         im, li = self.image_encoder.features, self.lidar_encoder._model
-        # The two trunks are independent between fusion stages: the LiDAR branch runs on a side HIP stream so its blocks
-        # fill the tail rounds of the image branch's kernels (and vice versa); under hipGraph capture the fork/join
-        # below become graph edges.  Autograd replays each node's backward on its forward stream, so the backward of
-        # the two branches overlaps the same way.
         side = self._side_stream(image.device) if image.is_cuda else None
         main = torch.cuda.current_stream(image.device) if image.is_cuda else None
 
@@ -250,15 +244,38 @@ class TransfuserBackbone(nn.Module):
             if side is not None:
                 main.wait_stream(side)          # join: the fusion stage consumes both branches on the main stream
                 y.record_stream(main)
-            gpt = getattr(self, "transformer%d" % i)
-            gpt.seed = self.dropout_seed
-            x, y = gpt(x, y, velocity)
+            x, y = fuse(i, x, y)
             if side is not None:
                 y.record_stream(side)
         x = self._conv(self.change_channel_conv_image, x)
         y = self._conv(self.change_channel_conv_lidar, y)
         fused = F_.GlobalPoolAddFn.apply(x, y)
         return self.top_down_nhwc(y), x, fused
+
+
+class TransfuserBackbone(_FusionBackbone):
+    """Multi-scale fusion transformer for image + LiDAR features (transfuser.py:7-211)."""
+
+    def __init__(self, config, image_architecture='resnet34', lidar_architecture='resnet18', use_velocity=True):
+        super().__init__()
+        chs = self._build_common(config, image_architecture, lidar_architecture)
+        for i in range(1, 5):
+            setattr(self, "transformer%d" % i, GPT(n_embd=chs[i], n_head=config.n_head, block_exp=config.block_exp, n_layer=config.n_layer,
+                                                   img_vert_anchors=config.img_vert_anchors, img_horz_anchors=config.img_horz_anchors,
+                                                   lidar_vert_anchors=config.lidar_vert_anchors, lidar_horz_anchors=config.lidar_horz_anchors,
+                                                   seq_len=config.seq_len, embd_pdrop=config.embd_pdrop, attn_pdrop=config.attn_pdrop,
+                                                   resid_pdrop=config.resid_pdrop, config=config, use_velocity=use_velocity))
+        self._build_neck(chs)
+        self.register_buffer("dropout_seed", torch.zeros(1, dtype=torch.int32), persistent=False)
+
+    def forward_nhwc(self, image, lidar, velocity, lidar_extra=None):
+        """image (B,3,H,W) 0..255, lidar (B,2|3,256,256) [+ lidar_extra (B,1,256,256) instead of torch.cat];
+        returns NHWC tensors: (p2,p3,p4,p5), image_features_grid, fused_features."""
+        def fuse(i, x, y):
+            gpt = getattr(self, "transformer%d" % i)
+            gpt.seed = self.dropout_seed
+            return gpt(x, y, velocity)
+        return self._run(image, lidar, lidar_extra, fuse)
 
     def forward(self, image, lidar, velocity):
         feats, grid, fused = self.forward_nhwc(image, lidar, velocity)
