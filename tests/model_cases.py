@@ -152,7 +152,9 @@ def compare_vs_fp64(prod, ref32, lp, lr32, batch, cfg, out_tol=1e-3, verbose=Tru
     ~1e-2 relative-L2 per tensor on ANY fp32 implementation (measured: oracle-fp32 vs oracle-fp64 median 1.2e-2), so
     instead of fp32-vs-fp32 we check that the HIP path is as close to fp64 as the reference CPU fp32 path is:
       * the 11 losses and the forward outputs within out_tol of fp64 (north_star: 1e-3 fp32),
-      * per parameter tensor  e_hip = |g_hip - g64|_2 / |g64|_2  <=  4 * e_cpu32 + 2e-3, and median(e_hip) <= 2 * median(e_cpu32)."""
+      * per parameter tensor  e_hip = |g_hip - g64|_2 / |g64|_2  <=  4 * max(e_cpu32, median e_cpu32) + 2e-3 (which tensors a ReLU-mask
+        flip lands in is random, so a tensor may be as noisy as the model's typical fp32 noise level; a wrong kernel gives O(1)),
+        and median(e_hip) <= 2 * median(e_cpu32)."""
     last = ref32.__dict__.pop('_last', None)   # non-leaf tensors cannot be deep-copied
     ref64 = copy.deepcopy(ref32).double()
     ref32._last = last
@@ -194,9 +196,9 @@ def compare_vs_fp64(prod, ref32, lp, lr32, batch, cfg, out_tol=1e-3, verbose=Tru
     med_cpu = sorted(r[1] for r in live)[len(live) // 2]
     if verbose:
         print("  gradient rel-L2 error vs fp64: median hip %.2e, median cpu-fp32 %.2e over %d tensors (%d noise-only skipped)" % (med_hip, med_cpu, len(live), len(rows) - len(live)))
-        for r in sorted(live, key=lambda r: -(r[0] / (4 * r[1] + 2e-3)))[:6]:
+        for r in sorted(live, key=lambda r: -(r[0] / (4 * max(r[1], med_cpu) + 2e-3)))[:6]:
             print("    hip %.2e  cpu32 %.2e  %s (|g64| %.2e)" % r)
     assert med_hip <= 2.0 * med_cpu + 1e-4, (med_hip, med_cpu)
-    bad = [r for r in live if r[0] > 4 * r[1] + 2e-3]
+    bad = [r for r in live if r[0] > 4 * max(r[1], med_cpu) + 2e-3]
     assert not bad, "gradients further from fp64 than the CPU fp32 reference: %s" % (bad[:5],)
     return med_hip, med_cpu
