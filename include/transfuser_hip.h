@@ -177,6 +177,32 @@ int tf_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, float*
  * integer-exact; num_points may be NULL. */
 int tf_lidar_hist_f32(const float* points, const int32_t* num_points, int B, int max_points, int point_stride, float* out, void* stream);
 
+/* ---- H2: PointPillars front-end (point_pillar.py:37-122, model.py:736-738) - integer-exact pillar ids without a sort ---------
+ * The reference's torch.unique(dim=0, return_inverse=True) over (batch, x_idx, y_idx) rows == rank of the occupied cell in an
+ * occupancy grid scanned in (b, x_idx, y_idx) order.  GX = nx + 1, GY = ny + 1 (an index may reach nx / ny when (x - min) rounds
+ * up; the reference clamps it in scatter_points).  Call order (host reads the two scan totals N, P in between):
+ *   tf_pillar_keys_f32  -> keys (B*Nmax; -1 = dropped), keep flags, occupancy grid (B*GX*GY)         [:70-83, first num_points]
+ *   tf_exclusive_scan_i32 x2 -> pos = scan(keep) (+N), rank = scan(occ) (+P)                          [torch.unique, :88]
+ *   tf_pillar_gather_f32 -> stable compaction pts4 (N,4), inv (N), per-pillar xyz sums + count (P,4), cellkey (P)
+ *   tf_pillar_decorate_f32 -> 9 features per point (:54-67, quirk Q15 kept)
+ *   [DynamicPointNet: Linear+BN1d+ReLU x2 through tf_gemm_f32 / tf_bn_*]
+ *   tf_pillar_scatter_max_f32 -> pillar_feat (P,C) = scatter_max (:32), arg (P,C) = lowest row attaining it
+ *   tf_pillar_canvas_f32 -> NHWC (B,H,W,C+Ce): scatter_points (:94-95, clamps, last duplicate wins) + rot90(-1) (model.py:738)
+ *                           + the Ce extra NCHW channels (target-point image, model.py:741-742) appended un-rotated
+ *   tf_pillar_canvas_bwd_f32 -> dz (N,C): the canvas gradient routed to each pillar's arg-max point. */
+int tf_pillar_keys_f32(const float* points, const int32_t* num_points, int B, int max_points, int point_stride, float min_x, float max_x,
+                       float min_y, float max_y, float pixels_per_meter, int GX, int GY, int32_t* keys, int32_t* keep, int32_t* occ, void* stream);
+int tf_exclusive_scan_i32(const int32_t* in, int64_t n, int32_t* out, int32_t* total, int32_t* ws /* n/1024+1 ints */, void* stream);
+int tf_pillar_gather_f32(const float* points, int point_stride, const int32_t* keys, const int32_t* pos, const int32_t* occ, const int32_t* rank,
+                         int64_t n_all, int64_t ncells, int P, float* pts4, int32_t* inv, float* sums, int32_t* cellkey, void* stream);
+int tf_pillar_decorate_f32(const float* pts4, const int32_t* inv, const float* sums, const int32_t* cellkey, int64_t N, int GX, int GY,
+                           float pixels_per_meter, float min_x, float min_y, float* feat, void* stream);
+int tf_pillar_scatter_max_f32(const float* z, const int32_t* inv, int64_t N, int C, int P, float* pillar_feat, int32_t* arg, void* stream);
+int tf_pillar_canvas_f32(const float* pillar_feat, const int32_t* cellkey, int P, int C, int B, int H, int W, int GX, int GY,
+                         const float* extra_nchw, int Ce, int32_t* owner, float* out_nhwc, void* stream);
+int tf_pillar_canvas_bwd_f32(const float* dout_nhwc, const int32_t* owner, const int32_t* cellkey, const int32_t* inv, const int32_t* arg,
+                             int64_t N, int C, int Cs, int GX, int GY, int H, int W, float* dz, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

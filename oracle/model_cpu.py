@@ -21,7 +21,11 @@ class LidarCenterNet(nn.Module):
         self.pred_len = config.pred_len
         self.use_target_point_image = config.use_target_point_image
         self.gru_concat_target_point = config.gru_concat_target_point
-        assert not config.use_point_pillars, "pillars: see oracle/pillars.py"
+        self.use_point_pillars = config.use_point_pillars
+        if self.use_point_pillars:   # model.py:554-559
+            from .pillars import PointPillarNet
+            self.point_pillar_net = PointPillarNet(config.num_input, config.num_features, min_x=config.min_x, max_x=config.max_x,
+                                                   min_y=config.min_y, max_y=config.max_y, pixels_per_meter=int(config.pixels_per_meter))
         tf = backbone_module or transfuser_cpu
         assert backbone in ('transFuser', 'latentTF', 'geometric_fusion')
         self.backbone = backbone
@@ -58,6 +62,8 @@ class LidarCenterNet(nn.Module):
 
     def forward(self, rgb, lidar_bev, ego_waypoint, target_point, target_point_image, ego_vel, bev, label, depth, semantic,
                 num_points=None, save_path=None, bev_points=None, cam_points=None):  # model.py:733-805
+        if self.use_point_pillars:   # model.py:736-738
+            lidar_bev = torch.rot90(self.point_pillar_net(lidar_bev, num_points), -1, dims=(2, 3))
         if self.use_target_point_image:
             lidar_bev = torch.cat((lidar_bev, target_point_image), dim=1)
         if self.backbone == 'geometric_fusion':   # model.py:749-750
@@ -97,7 +103,7 @@ def train_step(model, optimizer, batch, config):
     losses = model(batch['rgb'], batch['lidar'], ego_waypoint=batch['ego_waypoint'], target_point=batch['target_point'],
                    target_point_image=batch['target_point_image'], ego_vel=batch['ego_vel'].reshape(-1, 1), bev=batch['bev'],
                    label=batch['label'], depth=batch['depth'], semantic=batch['semantic'],
-                   **{k: batch[k] for k in ('bev_points', 'cam_points') if k in batch})
+                   **{k: batch[k] for k in ('bev_points', 'cam_points', 'num_points') if k in batch})
     loss = total_loss(losses, config)
     loss.backward()
     optimizer.step()

@@ -92,7 +92,38 @@ GEO_GRAD_KEYS = ("image_conv1.weight", "lidar_conv3.weight", "image_projection2.
                  "image_deconv4.bias", "image_encoder.features.s1.b1.conv1.conv.weight", "lidar_encoder._model.conv1.weight")
 
 
+PILLAR_KW = dict(min_x=-16, max_x=16, min_y=-32, max_y=0, pixels_per_meter=8)
+
+
+def pillar_inputs(seed=21):
+    g = torch.Generator().manual_seed(seed)
+    pts = torch.stack([torch.rand(2, 2000, generator=g) * 40 - 20, torch.rand(2, 2000, generator=g) * 40 - 36, torch.rand(2, 2000, generator=g) * 5 - 4,
+                       torch.rand(2, 2000, generator=g)], -1)
+    pts[0, :20, 0] = torch.nextafter(torch.tensor(16.0), torch.tensor(0.0)); pts[0, :20, 1] = -1.0     # x_idx = 256 edge (clamped)
+    pts[1, :40, :2] = torch.round(pts[1, :40, :2] * 8) / 8                                              # exactly on cell edges
+    return pts, torch.tensor([2000, 1500], dtype=torch.int32)
+
+
+def pillar_golden(ref_mod):
+    """Reference PointPillarNet (point_pillar.py imported unmodified on top of oracle/scatter_shim): sparse canvas, pillar rows, grads."""
+    torch.manual_seed(0)
+    m = ref_mod.PointPillarNet(9, [32, 32], **PILLAR_KW)
+    seeded_fill(m, 77)
+    m.train()
+    pts, num = pillar_inputs()
+    canvas = m(pts, num)
+    (canvas * torch.linspace(0.5, 1.5, 256).view(1, 1, 1, 256)).sum().backward()
+    nz = torch.nonzero(canvas[:, 0:1].abs() + canvas.abs().sum(1, keepdim=True) > 0)[:, [0, 2, 3]]
+    nz = torch.unique(nz, dim=0)
+    out = dict(pillar_cells=nz.numpy().astype(np.int16), pillar_feat=canvas.detach()[nz[:, 0], :, nz[:, 1], nz[:, 2]].numpy(),
+               pillar_nnz=np.array([(canvas != 0).sum().item()]))
+    for n, p in m.named_parameters():
+        out["pillar_grad_" + n] = p.grad.numpy()
+    return out
+
+
 def main():
+    sys.path.insert(0, os.path.join(ROOT, "oracle", "scatter_shim"))
     sys.path.insert(0, os.path.join(ROOT, "oracle", "timm_shim"))
     sys.path.insert(0, "/root/reference/team_code_transfuser")
     import timm
@@ -126,6 +157,8 @@ def main():
     np.savez_compressed(os.path.join(HERE, "transfuser_backbone_tiny.npz"), **out)
     import geometric_fusion as ref_geo   # the reference module, unmodified
     np.savez_compressed(os.path.join(HERE, "geometric_fusion_tiny.npz"), **geo_golden(ref_geo))
+    import point_pillar as ref_pp        # the reference module, unmodified (torch_scatter = oracle/scatter_shim)
+    np.savez_compressed(os.path.join(HERE, "point_pillar.npz"), **pillar_golden(ref_pp))
     # H1: numpy.histogramdd (the reference's algorithm, data.py:446-470) on a seeded cloud with edge cases -> sparse golden
     rng = np.random.default_rng(3)
     pts = np.stack([rng.uniform(-20, 20, 20000), rng.uniform(-36, 4, 20000), rng.uniform(-4, 1, 20000)], 1).astype(np.float32)

@@ -285,6 +285,68 @@ def check_gather_sum(dev, B, Hs, Ws, E, n, K):
     close(dsrc2.cpu(), want + acc.cpu(), what="gather_sum bwd accumulate", tol=1e-5)
 
 
+PILLAR_CASES = [(3, 5000, (5000, 4000, 100)), (2, 3000, (0, 3000)), (1, 64, (64,))]
+
+
+def pillar_cloud(B, N, seed=1):
+    g = torch.Generator().manual_seed(seed)
+    pts = torch.stack([torch.rand(B, N, generator=g) * 40 - 20, torch.rand(B, N, generator=g) * 40 - 36, torch.rand(B, N, generator=g) * 5 - 4,
+                       torch.rand(B, N, generator=g)], -1)
+    k = min(50, N // 4)
+    pts[0, :k, 0] = torch.nextafter(torch.tensor(16.0), torch.tensor(0.0))      # (x + 16) rounds up to 32.0 -> x_idx = 256 (clamped later)
+    pts[0, :k, 1] = -1.0
+    pts[0, k:2 * k, :2] = torch.round(pts[0, k:2 * k, :2] * 8) / 8                # points exactly on cell edges
+    pts[0, 2 * k:3 * k] = pts[0, 2 * k:2 * k + 1]                                   # exact duplicates (ties in scatter_max)
+    return pts
+
+
+def check_pillars(dev, B, N, npts):
+    """H2 vs the oracle restatement of point_pillar.py: pillar ids / inverse indices / unique rows EXACT (integers), decorated
+    features and canvas within fp32 tolerance, gradients of the point-net parameters."""
+    from oracle import pillars as op
+    from transfuser_amd import point_pillar as pp
+    kw = dict(min_x=-16, max_x=16, min_y=-32, max_y=0, pixels_per_meter=8)
+    pts = pillar_cloud(B, N)
+    num = torch.tensor(npts, dtype=torch.int32)
+    torch.manual_seed(0)
+    o = op.PointPillarNet(9, [32, 32], **kw)
+    with torch.no_grad():
+        for n_, p_ in o.named_parameters():
+            if n_.endswith("1.weight") or n_.endswith("4.weight"):
+                p_.copy_(torch.rand(p_.shape) * 0.5 + 0.75)
+            if n_.endswith("bias"):
+                p_.copy_(torch.randn(p_.shape) * 0.1)
+    m = pp.PointPillarNet(9, [32, 32], **kw).to(dev)
+    m.load_state_dict(o.state_dict(), strict=True)
+    o.train(); m.train()
+    kept, uniq, inverse = o.index(pts, num)
+    ix = ops.pillar_index(pts.to(dev), num.to(dev), -16, 16, -32, 0, 8)
+    assert ix["N"] == kept.shape[0] and ix["P"] == uniq.shape[0]
+    assert torch.equal(ix["inv"].cpu().long(), inverse), "inverse indices differ from torch.unique"
+    key = (uniq[:, 0] * ix["GX"] + uniq[:, 1]) * ix["GY"] + uniq[:, 2]
+    assert torch.equal(ix["cellkey"].cpu().long(), key), "unique pillar rows differ from torch.unique (sorted)"
+    assert torch.equal(ix["points"].cpu(), kept), "kept points (stable order)"
+    close(ix["feat"], o.decorate(kept, uniq, inverse), what="decorated features", tol=1e-5)
+    if ix["N"] == 0:
+        return
+    extra = (torch.rand(B, 1, 256, 256, generator=torch.Generator().manual_seed(4)) < 0.05).float()
+    want = torch.cat((torch.rot90(o(pts, num), -1, dims=(2, 3)), extra), 1)       # model.py:738-742
+    got = m.forward_nhwc(pts.to(dev), num.to(dev), extra.to(dev))
+    close(got.permute(0, 3, 1, 2), want, what="pillar canvas (rot90 + concat)", tol=2e-4)
+    assert torch.equal(got.permute(0, 3, 1, 2).cpu() != 0, want != 0), "canvas occupancy pattern"
+    close(m.forward(pts.to(dev), num.to(dev)), o(pts, num), what="reference-API canvas", tol=2e-4)
+    wgt = R(B, 33, 256, 256, seed=8)
+    (want * wgt).sum().backward()
+    (got * wgt.permute(0, 2, 3, 1).to(dev)).sum().backward()
+    gmax = max(q.grad.abs().max().item() for q in o.parameters())
+    for (n_, p), (_, q) in zip(m.named_parameters(), o.named_parameters()):
+        err = (p.grad.cpu() - q.grad).abs().max().item()   # (the Linear biases feed a BatchNorm: their true gradient is 0, both sides hold round-off)
+        assert err <= 2e-3 * q.grad.abs().max().item() + 1e-6 * gmax, "grad %s: err %.3e scale %.3e" % (n_, err, q.grad.abs().max().item())
+    for (n_, p), (_, q) in zip(m.named_buffers(), o.named_buffers()):
+        if "running" in n_:
+            close(p, q, what=n_, tol=1e-4)
+
+
 # ---------------------------------------------------------------- losses
 def check_ce(dev, rows, C, weighted):
     lg = R(rows, C, dev=dev).requires_grad_(True)

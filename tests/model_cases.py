@@ -98,7 +98,7 @@ def run_pair(prod, ref, cfg, batch, dev):
     prod.train(); ref.train()
     call = lambda m, b: m(b['rgb'], b['lidar'], ego_waypoint=b['ego_waypoint'], target_point=b['target_point'],
                           target_point_image=b['target_point_image'], ego_vel=b['ego_vel'].reshape(-1, 1), bev=b['bev'], label=b['label'],
-                          depth=b['depth'], semantic=b['semantic'], **{k: b[k] for k in ('bev_points', 'cam_points') if k in b})
+                          depth=b['depth'], semantic=b['semantic'], **{k: b[k] for k in ('bev_points', 'cam_points', 'num_points') if k in b})
     bd = {k: v.to(dev) for k, v in batch.items()}
     lp = call(prod, bd)
     lr = call(ref, batch)
@@ -164,7 +164,7 @@ def compare_vs_fp64(prod, ref32, lp, lr32, batch, cfg, out_tol=1e-3, verbose=Tru
     ref64.train()
     l64 = ref64(b64['rgb'], b64['lidar'], ego_waypoint=b64['ego_waypoint'], target_point=b64['target_point'], target_point_image=b64['target_point_image'],
                 ego_vel=b64['ego_vel'].reshape(-1, 1), bev=b64['bev'], label=b64['label'], depth=b64['depth'], semantic=b64['semantic'],
-                **{k: b64[k] for k in ('bev_points', 'cam_points') if k in b64})
+                **{k: b64[k] for k in ('bev_points', 'cam_points', 'num_points') if k in b64})
     w = dict(zip(cfg.detailed_losses, [1.0, 1.0, 1.0, 1.0, 0.2, 0.2, 0.2, 0.2, 0.2, 0.3, 0.4]))
     sum(w[k] * v for k, v in l64.items()).backward()
     for k in l64:

@@ -97,3 +97,8 @@ def test_engine_tilings(plan):
 @pytest.mark.parametrize("case", kc.GATHER_CASES, ids=str)
 def test_gather_sum(case):
     kc.check_gather_sum("cpu", *case)
+
+
+@pytest.mark.parametrize("case", kc.PILLAR_CASES, ids=str)
+def test_point_pillars(case):
+    kc.check_pillars("cpu", *case)

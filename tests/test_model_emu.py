@@ -109,3 +109,21 @@ def test_geometric_fusion_engine_skips_unreachable_parameters():
     diffs = [((p.detach() - rp[n].detach()).abs(), n) for n, p in prod.named_parameters()]
     assert max(d.max().item() for d, _ in diffs) < 4.4e-3
     assert sum(d.sum().item() for d, _ in diffs) / sum(d.numel() for d, _ in diffs) < 2e-5
+
+
+def test_point_pillars_model_matches_oracle():
+    """--use_point_pillars 1 (row H2): raw cloud -> pillar ids (scan, no sort) -> point net -> canvas -> differentiable LiDAR stem;
+    the point-net parameters receive their gradients through the whole TransFuser model."""
+    cfg = mc.tiny_config(n_layer=1, lidar_res=64)
+    cfg.use_point_pillars = True
+    cfg.min_x, cfg.max_x, cfg.min_y, cfg.max_y = -4, 4, -8, 0          # 8 px/m -> a 64 x 64 canvas
+    prod, ref = mc.build_pair(cfg, "regnety_tiny", "cpu")
+    assert prod._model.lidar_encoder._model.conv1.weight.shape[1] == 33
+    batch = mc.small_batch(2, 32, 64, 64, 40)
+    g = torch.Generator().manual_seed(5)
+    batch["lidar"] = torch.stack([torch.rand(2, 3000, generator=g) * 10 - 5, torch.rand(2, 3000, generator=g) * 10 - 9,
+                                  torch.rand(2, 3000, generator=g) * 5 - 4, torch.rand(2, 3000, generator=g)], -1)
+    batch["num_points"] = torch.tensor([3000, 2500], dtype=torch.int32)
+    lp, lr = mc.run_pair(prod, ref, cfg, batch, "cpu")
+    assert prod.point_pillar_net.point_net.net[0].weight.grad.abs().max() > 0
+    mc.compare_vs_fp64(prod, ref, lp, lr, batch, cfg)

@@ -1,0 +1,300 @@
+// H2 - PointPillars front-end (team_code_transfuser/point_pillar.py:37-122): index-exact pillar ids without a sort.
+//
+// The reference builds (batch, x_idx, y_idx) rows, calls torch.unique(dim=0, return_inverse=True) (a lexicographic SORT) and
+// uses torch_scatter for the per-pillar mean / max.  On the GPU the sorted-unique rank of a pillar is simply the number of
+// occupied grid cells with a smaller (b, x_idx, y_idx) key, so: mark an occupancy grid, exclusive-scan it, and every point reads
+// its pillar id from the scanned grid - integer-exact by construction, HBM-bound (12 B/point + 4 B/cell), no sort.
+// Everything is fp32 / int32; kept points are compacted in their original order (stable), like points[keep].
+#include "tf_common.h"
+#include "../../include/transfuser_hip.h"
+
+using namespace tf;
+
+namespace {
+
+inline int pl_blocks(long n, int cap = 8192) {
+    long b = (n + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+// point_pillar.py:70-83: keep iff min <= x < max (both axes); coords = ((xy - min) * ppm).long()  [fp32 sub, fp32 mul, trunc]
+__global__ void __launch_bounds__(256) pillar_keys_kernel(const float* __restrict__ pts, const int32_t* __restrict__ npts, int B, int Nmax, int F,
+                                                          float min_x, float max_x, float min_y, float max_y, float ppm, int GX, int GY,
+                                                          int32_t* __restrict__ keys, int32_t* __restrict__ keep, int32_t* __restrict__ occ) {
+    const long total = (long)B * Nmax;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int b = (int)(i / Nmax), j = (int)(i % Nmax);
+        const int n = npts ? (npts[b] < Nmax ? npts[b] : Nmax) : Nmax;
+        int key = -1;
+        if (j < n) {
+            const float x = pts[i * F], y = pts[i * F + 1];
+            if (x >= min_x && x < max_x && y >= min_y && y < max_y) {
+                const float fx = (x - min_x) * ppm, fy = (y - min_y) * ppm;
+                int cx = (int)fx, cy = (int)fy;                 // >= 0; may reach nx / ny when (x - min) rounds up to the range
+                cx = cx < GX ? cx : GX - 1;
+                cy = cy < GY ? cy : GY - 1;
+                key = (b * GX + cx) * GY + cy;
+            }
+        }
+        keys[i] = key;
+        keep[i] = key >= 0;
+        if (key >= 0) occ[key] = 1;
+    }
+}
+
+// ---- exclusive scan of int32 flags / counts: 1024 elements per block, three small kernels
+__global__ void __launch_bounds__(256) scan_block_sums_kernel(const int32_t* __restrict__ in, long n, int32_t* __restrict__ bsum) {
+    __shared__ int sm[256];
+    const long base = (long)blockIdx.x * 1024 + threadIdx.x * 4;
+    int s = 0;
+    for (int k = 0; k < 4; ++k)
+        if (base + k < n) s += in[base + k];
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) sm[threadIdx.x] += sm[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) bsum[blockIdx.x] = sm[0];
+}
+
+__global__ void __launch_bounds__(256) scan_carry_kernel(int32_t* __restrict__ bsum, int nb, int32_t* __restrict__ total) {
+    __shared__ int sm[256];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nb; base += 256) {
+        const int i = base + threadIdx.x;
+        const int v = i < nb ? bsum[i] : 0;
+        sm[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {       // inclusive Hillis-Steele
+            const int t = (int)threadIdx.x >= off ? sm[threadIdx.x - off] : 0;
+            __syncthreads();
+            sm[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < nb) bsum[i] = carry + sm[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 0) carry += sm[255];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+
+__global__ void __launch_bounds__(256) scan_final_kernel(const int32_t* __restrict__ in, long n, const int32_t* __restrict__ boff, int32_t* __restrict__ out) {
+    __shared__ int sm[256];
+    const long base = (long)blockIdx.x * 1024 + threadIdx.x * 4;
+    int v[4], s = 0;
+    for (int k = 0; k < 4; ++k) {
+        v[k] = base + k < n ? in[base + k] : 0;
+        s += v[k];
+    }
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const int t = (int)threadIdx.x >= off ? sm[threadIdx.x - off] : 0;
+        __syncthreads();
+        sm[threadIdx.x] += t;
+        __syncthreads();
+    }
+    int run = boff[blockIdx.x] + sm[threadIdx.x] - s;
+    for (int k = 0; k < 4; ++k) {
+        if (base + k < n) out[base + k] = run;
+        run += v[k];
+    }
+}
+
+// rank -> cell key of every occupied cell (= torch.unique's sorted unique_coords, point_pillar.py:88)
+__global__ void __launch_bounds__(256) pillar_cells_kernel(const int32_t* __restrict__ occ, const int32_t* __restrict__ rank, long ncells,
+                                                           int32_t* __restrict__ cellkey) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < ncells; i += (long)gridDim.x * 256)
+        if (occ[i]) cellkey[rank[i]] = (int32_t)i;
+}
+
+// stable compaction of the kept points + inverse indices + per-pillar xyz sums / counts (scatter_mean numerator, :61)
+__global__ void __launch_bounds__(256) pillar_gather_kernel(const float* __restrict__ pts, int F, const int32_t* __restrict__ keys,
+                                                            const int32_t* __restrict__ pos, const int32_t* __restrict__ rank, long n_all,
+                                                            float* __restrict__ pts4, int32_t* __restrict__ inv, float* __restrict__ sums) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n_all; i += (long)gridDim.x * 256) {
+        const int key = keys[i];
+        if (key < 0) continue;
+        const int row = pos[i], r = rank[key];
+        const float x = pts[i * F], y = pts[i * F + 1], z = pts[i * F + 2], w = pts[i * F + 3];
+        *reinterpret_cast<float4*>(pts4 + (long)row * 4) = make_float4(x, y, z, w);
+        inv[row] = r;
+        atomicAdd(sums + (long)r * 4, x);
+        atomicAdd(sums + (long)r * 4 + 1, y);
+        atomicAdd(sums + (long)r * 4 + 2, z);
+        atomicAdd(sums + (long)r * 4 + 3, 1.0f);
+    }
+}
+
+// decorate (:54-67): [x, y, z, i, xyz - pillar mean, x - x_center, y - y_center]; quirk Q15: x_center comes from the y index
+// (column 2 of the (b, x_idx, y_idx) rows) + min_x and y_center from the x index + min_y - reproduced literally.
+__global__ void __launch_bounds__(256) pillar_decorate_kernel(const float* __restrict__ pts4, const int32_t* __restrict__ inv,
+                                                              const float* __restrict__ sums, const int32_t* __restrict__ cellkey, long N, int GX,
+                                                              int GY, float ppm, float min_x, float min_y, float* __restrict__ feat) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < N; i += (long)gridDim.x * 256) {
+        const float4 p = *reinterpret_cast<const float4*>(pts4 + i * 4);
+        const int r = inv[i];
+        const float4 s = *reinterpret_cast<const float4*>(sums + (long)r * 4);
+        const float cnt = s.w < 1.f ? 1.f : s.w;
+        const int key = cellkey[r];
+        const int cy = key % GY, cx = (key / GY) % GX;
+        const float xc = (float)cy / ppm + min_x, yc = (float)cx / ppm + min_y;
+        float* f = feat + i * 9;
+        f[0] = p.x; f[1] = p.y; f[2] = p.z; f[3] = p.w;
+        f[4] = p.x - s.x / cnt; f[5] = p.y - s.y / cnt; f[6] = p.z - s.z / cnt;
+        f[7] = p.x - xc; f[8] = p.y - yc;
+    }
+}
+
+__global__ void __launch_bounds__(256) fill_i32_kernel(int32_t* __restrict__ p, long n, int32_t v) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) p[i] = v;
+}
+
+// scatter_max (:32) of post-ReLU features (>= 0, so the uint bit pattern orders like the float and 0 is the identity)
+__global__ void __launch_bounds__(256) pillar_max_kernel(const float* __restrict__ z, const int32_t* __restrict__ inv, long N, int C,
+                                                         float* __restrict__ pf) {
+    const long total = N * C;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const float v = z[i];
+        if (v > 0.f) atomicMax(reinterpret_cast<unsigned*>(pf) + (long)inv[i / C] * C + (i % C), __float_as_uint(v));
+    }
+}
+
+// arg of the max: the LOWEST point row attaining it (torch_scatter's CPU kernel updates on strict '>' in row order)
+__global__ void __launch_bounds__(256) pillar_arg_kernel(const float* __restrict__ z, const int32_t* __restrict__ inv, const float* __restrict__ pf,
+                                                         long N, int C, int32_t* __restrict__ arg) {
+    const long total = N * C;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const float v = z[i];
+        const long o = (long)inv[i / C] * C + (i % C);
+        if (v > 0.f && v == pf[o]) atomicMin(arg + o, (int32_t)(i / C));
+    }
+}
+
+// canvas cell of a pillar after scatter_points (:94-95) AND rot90(-1) (model.py:738): row = clamp(y_idx), col = clamp(x_idx)
+__device__ __forceinline__ long pillar_cell(int key, int GX, int GY, int H, int W) {
+    const int cy = key % GY, cx = (key / GY) % GX, b = key / (GY * GX);
+    const int row = cy < H ? cy : H - 1, col = cx < W ? cx : W - 1;
+    return ((long)b * H + row) * W + col;
+}
+
+__global__ void __launch_bounds__(256) pillar_owner_kernel(const int32_t* __restrict__ cellkey, int P, int GX, int GY, int H, int W,
+                                                           int32_t* __restrict__ owner) {
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < P; r += gridDim.x * 256)
+        atomicMax(owner + pillar_cell(cellkey[r], GX, GY, H, W), r);      // index_put: the last (highest-rank) duplicate wins
+}
+
+__global__ void __launch_bounds__(256) pillar_canvas_kernel(const float* __restrict__ pf, const int32_t* __restrict__ owner, long ncell, int C,
+                                                            const float* __restrict__ extra, int Ce, long HW, float* __restrict__ out) {
+    const int Cs = C + Ce;
+    const long total = ncell * Cs;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long cell = i / Cs;
+        const int c = (int)(i % Cs);
+        float v;
+        if (c < C) {
+            const int r = owner[cell];
+            v = r >= 0 ? pf[(long)r * C + c] : 0.f;
+        } else {
+            const long b = cell / HW, px = cell % HW;
+            v = extra[(b * Ce + (c - C)) * HW + px];
+        }
+        out[i] = v;
+    }
+}
+
+__global__ void __launch_bounds__(256) pillar_canvas_bwd_kernel(const float* __restrict__ dout, const int32_t* __restrict__ owner,
+                                                                const int32_t* __restrict__ cellkey, const int32_t* __restrict__ inv,
+                                                                const int32_t* __restrict__ arg, long N, int C, int Cs, int GX, int GY, int H, int W,
+                                                                float* __restrict__ dz) {
+    const long total = N * C;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int row = (int)(i / C), c = (int)(i % C);
+        const int r = inv[row];
+        float g = 0.f;
+        if (arg[(long)r * C + c] == row) {
+            const long cell = pillar_cell(cellkey[r], GX, GY, H, W);
+            if (owner[cell] == r) g = dout[cell * Cs + c];
+        }
+        dz[i] = g;
+    }
+}
+
+}  // namespace
+
+extern "C" int tf_pillar_keys_f32(const float* points, const int32_t* num_points, int B, int max_points, int point_stride, float min_x, float max_x,
+                                  float min_y, float max_y, float pixels_per_meter, int GX, int GY, int32_t* keys, int32_t* keep, int32_t* occ,
+                                  void* stream) {
+    TF_REQUIRE(points && keys && keep && occ && B > 0 && max_points > 0 && point_stride >= 4 && GX > 0 && GY > 0 &&
+                   (long)B * GX * GY < 2147483647L, "tf_pillar_keys_f32: bad arguments");
+    TF_LAUNCH(fill_i32_kernel, dim3(pl_blocks((long)B * GX * GY)), dim3(256), stream, occ, (long)B * GX * GY, 0);
+    TF_LAUNCH(pillar_keys_kernel, dim3(pl_blocks((long)B * max_points)), dim3(256), stream, points, num_points, B, max_points, point_stride, min_x,
+              max_x, min_y, max_y, pixels_per_meter, GX, GY, keys, keep, occ);
+    return launch_status("tf_pillar_keys_f32");
+}
+
+extern "C" int tf_exclusive_scan_i32(const int32_t* in, int64_t n, int32_t* out, int32_t* total, int32_t* ws, void* stream) {
+    TF_REQUIRE(in && out && total && ws && n > 0, "tf_exclusive_scan_i32: bad arguments (ws needs n/1024 + 1 ints)");
+    const int nb = cdiv(n, 1024);
+    TF_LAUNCH(scan_block_sums_kernel, dim3(nb), dim3(256), stream, in, (long)n, ws);
+    TF_LAUNCH(scan_carry_kernel, dim3(1), dim3(256), stream, ws, nb, total);
+    TF_LAUNCH(scan_final_kernel, dim3(nb), dim3(256), stream, in, (long)n, (const int32_t*)ws, out);
+    return launch_status("tf_exclusive_scan_i32");
+}
+
+extern "C" int tf_pillar_gather_f32(const float* points, int point_stride, const int32_t* keys, const int32_t* pos, const int32_t* occ,
+                                    const int32_t* rank, int64_t n_all, int64_t ncells, int P, float* pts4, int32_t* inv, float* sums,
+                                    int32_t* cellkey, void* stream) {
+    TF_REQUIRE(points && keys && pos && occ && rank && pts4 && inv && sums && cellkey && n_all > 0 && ncells > 0 && P >= 0,
+               "tf_pillar_gather_f32: bad arguments");
+    if (P == 0) return 0;
+    TF_LAUNCH(fill_i32_kernel, dim3(pl_blocks((long)P * 4)), dim3(256), stream, reinterpret_cast<int32_t*>(sums), (long)P * 4, 0);
+    TF_LAUNCH(pillar_cells_kernel, dim3(pl_blocks(ncells)), dim3(256), stream, occ, rank, (long)ncells, cellkey);
+    TF_LAUNCH(pillar_gather_kernel, dim3(pl_blocks(n_all)), dim3(256), stream, points, point_stride, keys, pos, rank, (long)n_all, pts4, inv, sums);
+    return launch_status("tf_pillar_gather_f32");
+}
+
+extern "C" int tf_pillar_decorate_f32(const float* pts4, const int32_t* inv, const float* sums, const int32_t* cellkey, int64_t N, int GX, int GY,
+                                      float pixels_per_meter, float min_x, float min_y, float* feat, void* stream) {
+    TF_REQUIRE(pts4 && inv && sums && cellkey && feat && N >= 0, "tf_pillar_decorate_f32: bad arguments");
+    if (N == 0) return 0;
+    TF_LAUNCH(pillar_decorate_kernel, dim3(pl_blocks(N)), dim3(256), stream, pts4, inv, sums, cellkey, (long)N, GX, GY, pixels_per_meter, min_x, min_y,
+              feat);
+    return launch_status("tf_pillar_decorate_f32");
+}
+
+extern "C" int tf_pillar_scatter_max_f32(const float* z, const int32_t* inv, int64_t N, int C, int P, float* pillar_feat, int32_t* arg, void* stream) {
+    TF_REQUIRE(z && inv && pillar_feat && arg && N >= 0 && C > 0 && P >= 0, "tf_pillar_scatter_max_f32: bad arguments");
+    if (P == 0) return 0;
+    TF_LAUNCH(fill_i32_kernel, dim3(pl_blocks((long)P * C)), dim3(256), stream, reinterpret_cast<int32_t*>(pillar_feat), (long)P * C, 0);
+    TF_LAUNCH(fill_i32_kernel, dim3(pl_blocks((long)P * C)), dim3(256), stream, arg, (long)P * C, 2147483647);
+    if (N > 0) {
+        TF_LAUNCH(pillar_max_kernel, dim3(pl_blocks(N * C)), dim3(256), stream, z, inv, (long)N, C, pillar_feat);
+        TF_LAUNCH(pillar_arg_kernel, dim3(pl_blocks(N * C)), dim3(256), stream, z, inv, (const float*)pillar_feat, (long)N, C, arg);
+    }
+    return launch_status("tf_pillar_scatter_max_f32");
+}
+
+extern "C" int tf_pillar_canvas_f32(const float* pillar_feat, const int32_t* cellkey, int P, int C, int B, int H, int W, int GX, int GY,
+                                    const float* extra_nchw, int Ce, int32_t* owner, float* out_nhwc, void* stream) {
+    TF_REQUIRE(owner && out_nhwc && B > 0 && H > 0 && W > 0 && C > 0 && Ce >= 0 && (Ce == 0 || extra_nchw) && (P == 0 || (pillar_feat && cellkey)),
+               "tf_pillar_canvas_f32: bad arguments");
+    const long ncell = (long)B * H * W;
+    TF_LAUNCH(fill_i32_kernel, dim3(pl_blocks(ncell)), dim3(256), stream, owner, ncell, -1);
+    if (P > 0) TF_LAUNCH(pillar_owner_kernel, dim3(pl_blocks(P)), dim3(256), stream, cellkey, P, GX, GY, H, W, owner);
+    TF_LAUNCH(pillar_canvas_kernel, dim3(pl_blocks(ncell * (C + Ce))), dim3(256), stream, pillar_feat, (const int32_t*)owner, ncell, C, extra_nchw, Ce,
+              (long)H * W, out_nhwc);
+    return launch_status("tf_pillar_canvas_f32");
+}
+
+extern "C" int tf_pillar_canvas_bwd_f32(const float* dout_nhwc, const int32_t* owner, const int32_t* cellkey, const int32_t* inv, const int32_t* arg,
+                                        int64_t N, int C, int Cs, int GX, int GY, int H, int W, float* dz, void* stream) {
+    TF_REQUIRE(dout_nhwc && owner && cellkey && inv && arg && dz && N >= 0 && C > 0 && Cs >= C, "tf_pillar_canvas_bwd_f32: bad arguments");
+    if (N == 0) return 0;
+    TF_LAUNCH(pillar_canvas_bwd_kernel, dim3(pl_blocks(N * C)), dim3(256), stream, dout_nhwc, owner, cellkey, inv, arg, (long)N, C, Cs, GX, GY, H, W, dz);
+    return launch_status("tf_pillar_canvas_bwd_f32");
+}

@@ -571,3 +571,4 @@ class WaypointFn(torch.autograd.Function):
         dfused = ops.linear_dgrad(da0, j0.weight)
         ctx.saved = None
         return (dfused, None, None) + (None,) * (len(ctx.needs_input_grad) - 3)
+

@@ -70,7 +70,7 @@ class GeometricFusionBackbone(_FusionBackbone):
             "geometric fusion needs int64 bev_points / cam_points with B*%d*5*2 elements" % n
         return pts.contiguous().view(B, n, 5, 2)
 
-    def forward_nhwc(self, image, lidar, velocity, bev_points, img_points, lidar_extra=None):
+    def forward_nhwc(self, image, lidar, velocity, bev_points, img_points, lidar_extra=None, lidar_nhwc=None):
         cfg = self.config
         B = image.shape[0]
         g = self._stages[0].geom
@@ -90,7 +90,7 @@ class GeometricFusionBackbone(_FusionBackbone):
             if lid_e is not None:
                 carry["lid_e"] = lid_e
             return x, y
-        return self._run(image, lidar, lidar_extra, fuse)
+        return self._run(image, lidar, lidar_extra, fuse, lidar_nhwc)
 
     def forward(self, image, lidar, velocity, bev_points, img_points):
         feats, grid, fused = self.forward_nhwc(image, lidar, velocity, bev_points, img_points)

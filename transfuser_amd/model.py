@@ -6,8 +6,8 @@ targets :285-374, losses :150-248 with mmdet 2.25 semantics).
 Same parameter names/shapes (reference checkpoints load with strict=True), same call signature,
 same return value; everything between the input tensors and the loss scalars runs in the HIP
 kernels of libtransfuser_hip.so.  Out of scope here: ``forward_ego`` / box decoding /
-PID control / visualisation (CARLA inference), the ``late_fusion``
-backbone, PointPillars (``use_point_pillars``) - requesting them raises.
+PID control / visualisation (CARLA inference) and the ``late_fusion``
+backbone - requesting them raises.
 """
 import torch
 from torch import nn
@@ -15,6 +15,7 @@ from torch import nn
 from . import functions as F_
 from . import ops
 from .geometric_fusion import GeometricFusionBackbone
+from .point_pillar import PointPillarNet
 from .transfuser import DepthDecoder, SegDecoder, TransfuserBackbone, latentTFBackbone, nchw
 
 HEAD_ORDER = ("heatmap_head", "wh_head", "offset_head", "yaw_class_head", "yaw_res_head", "velocity_head", "brake_head")
@@ -112,8 +113,10 @@ class LidarCenterNet(nn.Module):
         self.use_target_point_image = config.use_target_point_image
         self.gru_concat_target_point = config.gru_concat_target_point
         self.use_point_pillars = config.use_point_pillars
-        if self.use_point_pillars:
-            raise NotImplementedError("use_point_pillars=1 (point_pillar.py) is a 'next' row of SURVEY.md section 8f, not built yet")
+        if self.use_point_pillars:   # model.py:554-559
+            self.point_pillar_net = PointPillarNet(config.num_input, config.num_features, min_x=config.min_x, max_x=config.max_x,
+                                                   min_y=config.min_y, max_y=config.max_y, pixels_per_meter=int(config.pixels_per_meter))
+            assert backbone != 'latentTF', "latentTF overwrites the LiDAR input with a positional grid (latentTF.py:132-137)"
         self.backbone = backbone
         if backbone == 'transFuser':
             self._model = TransfuserBackbone(config, image_architecture, lidar_architecture, use_velocity=use_velocity)
@@ -152,10 +155,13 @@ class LidarCenterNet(nn.Module):
                 num_points=None, save_path=None, bev_points=None, cam_points=None):
         cfg = self.config
         extra = target_point_image if self.use_target_point_image else None
+        kw = dict(lidar_extra=extra)
+        if self.use_point_pillars:   # model.py:736-742: lidar_bev is the raw cloud (B, N, 4); pillars -> rot90 -> cat target point
+            kw = dict(lidar_nhwc=self.point_pillar_net.forward_nhwc(lidar_bev, num_points, extra))
         if self.backbone == 'geometric_fusion':   # model.py:749-750
-            features, grid, fused = self._model.forward_nhwc(rgb, lidar_bev, ego_vel, bev_points, cam_points, lidar_extra=extra)
+            features, grid, fused = self._model.forward_nhwc(rgb, lidar_bev, ego_vel, bev_points, cam_points, **kw)
         else:
-            features, grid, fused = self._model.forward_nhwc(rgb, lidar_bev, ego_vel, lidar_extra=extra)
+            features, grid, fused = self._model.forward_nhwc(rgb, lidar_bev, ego_vel, **kw)
         pred_wp, _, _, _, _ = self.forward_gru(fused, target_point)
         p2 = features[0]
         pred, bev_logits = HeadsFn.apply(p2, self, *self.head.parameters(), *self.pred_bev.parameters())

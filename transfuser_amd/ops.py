@@ -492,3 +492,69 @@ def lidar_hist(points, num_points=None):
     out = torch.empty(B, 2, 256, 256, dtype=torch.float32, device=points.device)
     check(L().tf_lidar_hist_f32(ptr(_c(points)), ptr(num_points), B, N, S, ptr(out), stream_of(points)), "tf_lidar_hist_f32")
     return out
+
+
+# ------------------------------------------------------------------------------------------ H2 PointPillars front-end
+def _scan(flags):
+    n = flags.numel()
+    out = torch.empty_like(flags)
+    total = torch.empty(1, dtype=torch.int32, device=flags.device)
+    ws = torch.empty(n // 1024 + 2, dtype=torch.int32, device=flags.device)
+    check(L().tf_exclusive_scan_i32(ptr(flags), ctypes.c_int64(n), ptr(out), ptr(total), ptr(ws), stream_of(flags)), "tf_exclusive_scan_i32")
+    return out, total
+
+
+def pillar_index(points, num_points, min_x, max_x, min_y, max_y, ppm):
+    """point_pillar.py:98-117 without the sort: returns a dict with the compacted points (N,4), 9 decorated features (N,9),
+    inverse indices (N) int32, cellkey (P) int32 [= ((b*GX + x_idx)*GY + y_idx), sorted like torch.unique] and the grid dims.
+    One host read (N, P) - the reference's unique() synchronises at the same place."""
+    B, Nmax, Fp = points.shape
+    nx, ny = int((max_x - min_x) * ppm), int((max_y - min_y) * ppm)
+    GX, GY = nx + 1, ny + 1
+    dev = points.device
+    i32 = lambda *s: torch.empty(*s, dtype=torch.int32, device=dev)
+    keys, keep, occ = i32(B * Nmax), i32(B * Nmax), i32(B * GX * GY)
+    f = ctypes.c_float
+    check(L().tf_pillar_keys_f32(ptr(_c(points)), ptr(num_points), B, Nmax, Fp, f(min_x), f(max_x), f(min_y), f(max_y), f(ppm), GX, GY,
+                                 ptr(keys), ptr(keep), ptr(occ), stream_of(points)), "tf_pillar_keys_f32")
+    pos, n_tot = _scan(keep)
+    rank, p_tot = _scan(occ)
+    N, P = int(n_tot.item()), int(p_tot.item())
+    pts4 = torch.empty(N, 4, dtype=torch.float32, device=dev)
+    feat = torch.empty(N, 9, dtype=torch.float32, device=dev)
+    inv, cellkey = i32(N), i32(P)
+    sums = torch.empty(P, 4, dtype=torch.float32, device=dev)
+    if N:
+        check(L().tf_pillar_gather_f32(ptr(points), Fp, ptr(keys), ptr(pos), ptr(occ), ptr(rank), ctypes.c_int64(B * Nmax), ctypes.c_int64(B * GX * GY), P,
+                                       ptr(pts4), ptr(inv), ptr(sums), ptr(cellkey), stream_of(points)), "tf_pillar_gather_f32")
+        check(L().tf_pillar_decorate_f32(ptr(pts4), ptr(inv), ptr(sums), ptr(cellkey), ctypes.c_int64(N), GX, GY, f(ppm), f(min_x), f(min_y), ptr(feat),
+                                         stream_of(points)), "tf_pillar_decorate_f32")
+    return dict(points=pts4, feat=feat, inv=inv, cellkey=cellkey, N=N, P=P, GX=GX, GY=GY, nx=nx, ny=ny)
+
+
+def pillar_scatter_max(z, inv, P):
+    N, C = z.shape
+    pf = torch.empty(P, C, dtype=torch.float32, device=z.device)
+    arg = torch.empty(P, C, dtype=torch.int32, device=z.device)
+    check(L().tf_pillar_scatter_max_f32(ptr(_c(z)), ptr(inv), ctypes.c_int64(N), C, P, ptr(pf), ptr(arg), stream_of(z)), "tf_pillar_scatter_max_f32")
+    return pf, arg
+
+
+def pillar_canvas(pf, cellkey, B, H, W, GX, GY, extra=None):
+    """(B, H, W, C + Ce) NHWC = rot90(scatter_points(...), -1) with the extra NCHW channels appended (model.py:738-742)."""
+    P, C = pf.shape
+    Ce = 0 if extra is None else extra.shape[1]
+    out = torch.empty(B, H, W, C + Ce, dtype=torch.float32, device=pf.device)
+    owner = torch.empty(B * H * W, dtype=torch.int32, device=pf.device)
+    check(L().tf_pillar_canvas_f32(ptr(pf), ptr(cellkey), P, C, B, H, W, GX, GY, ptr(_c(extra) if extra is not None else None), Ce, ptr(owner), ptr(out),
+                                   stream_of(out)), "tf_pillar_canvas_f32")
+    return out, owner
+
+
+def pillar_canvas_bwd(dout, owner, cellkey, inv, arg, C, GX, GY):
+    B, H, W, Cs = dout.shape
+    N = inv.numel()
+    dz = torch.empty(N, C, dtype=torch.float32, device=dout.device)
+    check(L().tf_pillar_canvas_bwd_f32(ptr(_c(dout)), ptr(owner), ptr(cellkey), ptr(inv), ptr(arg), ctypes.c_int64(N), C, Cs, GX, GY, H, W, ptr(dz),
+                                       stream_of(dout)), "tf_pillar_canvas_bwd_f32")
+    return dz

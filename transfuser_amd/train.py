@@ -183,6 +183,8 @@ class Engine:
     def load_data_compute_loss(self, data):
         """train.py:246-293 (transFuser branch); ``data`` tensors must already be on the device."""
         extra = {k: data[k] for k in self.GEO_KEYS} if getattr(self.model, "backbone", "") == "geometric_fusion" else {}
+        if getattr(self.model, "use_point_pillars", False):   # train.py:258-260: data["lidar"] is then the raw cloud (B, N, 4)
+            extra["num_points"] = data["num_points"]
         return self.model(data["rgb"], data["lidar"], ego_waypoint=data["ego_waypoint"], target_point=data["target_point"],
                           target_point_image=data["target_point_image"], ego_vel=data["ego_vel"].reshape(-1, 1), bev=data["bev"],
                           label=data["label"], depth=data["depth"], semantic=data["semantic"], **extra)
@@ -212,7 +214,7 @@ class Engine:
 
     def train_step(self, data):
         """Returns (total loss, dict of the 11 detailed losses) as device tensors (no host sync)."""
-        if not self.use_graph:
+        if not self.use_graph or getattr(self.model, "use_point_pillars", False):   # pillar counts are read on the host: eager only
             out = self._fwd_bwd(data)
             self.reducer.reduce()
             self.optimizer.step()
@@ -233,7 +235,7 @@ class Engine:
     def _capture(self, data):
         """Capture forward+backward(+AdamW when single-GPU) into a hipGraph.  With >1 rank the gradient
         all-reduce stays outside the graph (eager RCCL calls) followed by a second, tiny AdamW graph."""
-        self._static = {k: data[k].clone() for k in self.BATCH_KEYS + self.GEO_KEYS if k in data}
+        self._static = {k: data[k].clone() for k in self.BATCH_KEYS + self.GEO_KEYS + ("num_points",) if k in data}
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):   # warm-up on a side stream (allocator + lazy inits) before capture

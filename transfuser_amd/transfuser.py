@@ -219,7 +219,7 @@ class _FusionBackbone(nn.Module):
     def top_down(self, x):
         return tuple(nchw(p) for p in self.top_down_nhwc(nhwc(x)))
 
-    def _run(self, image, lidar, lidar_extra, fuse):
+    def _run(self, image, lidar, lidar_extra, fuse, lidar_nhwc=None):
         """Stem + 4 stages of both trunks with ``fuse(i, x, y) -> (x, y)`` after stage i, then the neck.
         The two trunks are independent between fusion stages: the LiDAR branch runs on a side HIP stream so its blocks fill
         the tail rounds of the image branch's kernels (and vice versa); under hipGraph capture the fork/join below become
@@ -237,7 +237,12 @@ class _FusionBackbone(nn.Module):
             return out
 
         x = self._img_stem(image.contiguous())
-        y = lidar_branch(lambda: self._lid_stem(lidar.contiguous(), lidar_extra.contiguous() if lidar_extra is not None else None))
+        if lidar_nhwc is not None:    # PointPillars canvas (already NHWC, rotated, target-point channel appended): differentiable stem
+            from .point_pillar import PillarStemFn
+            st = self._lid_stem
+            y = lidar_branch(lambda: PillarStemFn.apply(lidar_nhwc, st, st.conv.weight, st.bn.weight, st.bn.bias))
+        else:
+            y = lidar_branch(lambda: self._lid_stem(lidar.contiguous(), lidar_extra.contiguous() if lidar_extra is not None else None))
         for i in range(1, 5):
             x = getattr(im, "layer%d" % i)(x)
             y = lidar_branch(lambda y=y, i=i: getattr(li, "layer%d" % i)(y))
@@ -268,14 +273,14 @@ class TransfuserBackbone(_FusionBackbone):
         self._build_neck(chs)
         self.register_buffer("dropout_seed", torch.zeros(1, dtype=torch.int32), persistent=False)
 
-    def forward_nhwc(self, image, lidar, velocity, lidar_extra=None):
-        """image (B,3,H,W) 0..255, lidar (B,2|3,256,256) [+ lidar_extra (B,1,256,256) instead of torch.cat];
-        returns NHWC tensors: (p2,p3,p4,p5), image_features_grid, fused_features."""
+    def forward_nhwc(self, image, lidar, velocity, lidar_extra=None, lidar_nhwc=None):
+        """image (B,3,H,W) 0..255, lidar (B,2|3,256,256) [+ lidar_extra (B,1,256,256) instead of torch.cat], or
+        ``lidar_nhwc`` = the PointPillars canvas; returns NHWC tensors: (p2,p3,p4,p5), image_features_grid, fused_features."""
         def fuse(i, x, y):
             gpt = getattr(self, "transformer%d" % i)
             gpt.seed = self.dropout_seed
             return gpt(x, y, velocity)
-        return self._run(image, lidar, lidar_extra, fuse)
+        return self._run(image, lidar, lidar_extra, fuse, lidar_nhwc)
 
     def forward(self, image, lidar, velocity):
         feats, grid, fused = self.forward_nhwc(image, lidar, velocity)
