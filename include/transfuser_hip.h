@@ -102,6 +102,15 @@ int tf_se_scale_fwd_f32(const float* x, const float* gate, float* y, int B, int 
 int tf_se_scale_bwd_gate_f32(const float* dy, const float* x, const float* gate, float* dgate, int B, int HW, int C, float* ws, void* stream);
 int tf_se_scale_bwd_x_f32(const float* dy, const float* gate, const float* dmean, float* dx, int B, int HW, int C, int accumulate, void* stream);
 
+/* SE excitation MLP fused (timm SEModule.fc1 -> ReLU -> fc2 on the pooled (B, C) vector; B <= 16):
+ *   fwd: g1 (B, Cr) = relu(s W1^T + b1), gate (B, C) = g1 W2^T + b2 (pre-sigmoid; tf_se_scale_fwd_f32 applies the sigmoid).
+ *   bwd: given dgate (B, C): dW2 += dgate^T g1, db2 += sum_b dgate, dg1 = (dgate W2) * (g1 > 0), dW1 += dg1^T s, db1 += sum_b dg1,
+ *        ds (B, C) = dg1 W1.  All parameter gradients are ACCUMULATED; scratch = B*Cr floats. */
+int tf_se_excite_fwd_f32(const float* s, const float* W1, const float* b1, const float* W2, const float* b2, int B, int C, int Cr, float* g1,
+                         float* gate, void* stream);
+int tf_se_excite_bwd_f32(const float* dgate, const float* s, const float* g1, const float* W1, const float* W2, int B, int C, int Cr, float* dW1,
+                         float* db1, float* dW2, float* db2, float* ds, float* scratch, void* stream);
+
 /* ---- resampling ------------------------------------------------------------------------------ */
 
 /* AdaptiveAvgPool2d((oh,ow)) of an NHWC map written straight into rows [tok_off, tok_off+oh*ow) of the

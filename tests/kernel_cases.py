@@ -347,6 +347,28 @@ def check_pillars(dev, B, N, npts):
             close(p, q, what=n_, tol=1e-4)
 
 
+SE_EXCITE_CASES = [(10, 576, 144), (2, 72, 8), (16, 1512, 378), (3, 218, 54), (1, 24, 6)]
+
+
+def check_se_excite(dev, B, C, Cr):
+    s = R(B, C, dev=dev).requires_grad_(True)
+    w1 = R(Cr, C, 1, 1, seed=1, dev=dev, scale=0.1).requires_grad_(True); b1 = R(Cr, seed=2, dev=dev, scale=0.1).requires_grad_(True)
+    w2 = R(C, Cr, 1, 1, seed=3, dev=dev, scale=0.1).requires_grad_(True); b2 = R(C, seed=4, dev=dev, scale=0.1).requires_grad_(True)
+    h = F.relu(F.linear(s, w1.view(Cr, C), b1))
+    ref = F.linear(h, w2.view(C, Cr), b2)
+    g1, gate = ops.se_excite_fwd(s.detach(), w1.detach(), b1.detach(), w2.detach(), b2.detach())
+    close(g1, h, what="se excite g1")
+    close(gate, ref, what="se excite gate")
+    dgate = R(B, C, seed=5, dev=dev)
+    gs, gw1, gb1, gw2, gb2 = torch.autograd.grad(ref, [s, w1, b1, w2, b2], dgate)
+    acc = [R(*t.shape, seed=6 + i, dev=dev) for i, t in enumerate((w1, b1, w2, b2))]
+    out = [a.clone() for a in acc]
+    ds = ops.se_excite_bwd(dgate, s.detach(), g1, w1.detach(), w2.detach(), *out)
+    close(ds, gs, what="se excite ds")
+    for o, a, g, n in zip(out, acc, (gw1, gb1, gw2, gb2), ("dW1", "db1", "dW2", "db2")):
+        close(o, a + g, what="se excite " + n)
+
+
 # ---------------------------------------------------------------- losses
 def check_ce(dev, rows, C, weighted):
     lg = R(rows, C, dev=dev).requires_grad_(True)

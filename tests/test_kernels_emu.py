@@ -102,3 +102,8 @@ def test_gather_sum(case):
 @pytest.mark.parametrize("case", kc.PILLAR_CASES, ids=str)
 def test_point_pillars(case):
     kc.check_pillars("cpu", *case)
+
+
+@pytest.mark.parametrize("case", kc.SE_EXCITE_CASES, ids=str)
+def test_se_excite_fused(case):
+    kc.check_se_excite("cpu", *case)

@@ -109,3 +109,8 @@ def test_gather_sum(case):
 @pytest.mark.parametrize("case", kc.PILLAR_CASES, ids=str)
 def test_point_pillars(case):
     kc.check_pillars("cuda", *case)
+
+
+@pytest.mark.parametrize("case", kc.SE_EXCITE_CASES, ids=str)
+def test_se_excite_fused(case):
+    kc.check_se_excite("cuda", *case)

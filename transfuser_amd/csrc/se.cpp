@@ -1,0 +1,180 @@
+// Squeeze-excite excitation MLP (timm SEModule fc1 -> ReLU -> fc2; 42 blocks x 2 trunks per step), fused.
+//
+// M = batch rows (<= 16): as separate "small-M" linears the excitation costs ~17 launches per block in forward+backward
+// (2 FCs, ReLU mask, 2 bias sums, 2 dgrads with init, 2 wgrads ...), each a few microseconds of mostly latency.
+// Here: ONE forward kernel and a 3-launch backward (zero scratch, fc2 pass, fc1 pass).  The weights (<= 2.3 MB) are streamed with
+// 16-byte loads; all batch rows live in LDS / registers.
+#include "tf_common.h"
+#include "../../include/transfuser_hip.h"
+
+using namespace tf;
+
+namespace {
+
+constexpr int SE_MAXB = 16;
+constexpr int SE_SPLIT = 4;        // forward: blocks per sample (each recomputes fc1 - cheap - and owns 1/4 of the fc2 outputs)
+constexpr int SE_MAXC = 4096, SE_MAXR = 1024;
+
+__device__ __forceinline__ float dot4(const float4 a, const float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+
+// g1[b][j] = relu(b1[j] + sum_k W1[j][k] s[b][k]);   gate[b][n] = b2[n] + sum_j W2[n][j] g1[b][j]
+template <bool V4>
+__global__ void __launch_bounds__(1024) se_excite_fwd_kernel(const float* __restrict__ s, const float* __restrict__ W1, const float* __restrict__ b1,
+                                                             const float* __restrict__ W2, const float* __restrict__ b2, int C, int Cr,
+                                                             float* __restrict__ g1, float* __restrict__ gate) {
+    __shared__ __attribute__((aligned(16))) float ss[SE_MAXC];
+    __shared__ __attribute__((aligned(16))) float hh[SE_MAXR];
+    const int b = blockIdx.x, part = blockIdx.y;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
+    for (int k = tid; k < C; k += blockDim.x) ss[k] = s[(long)b * C + k];
+    __syncthreads();
+    for (int j = wave; j < Cr; j += nw) {
+        const float* w = W1 + (long)j * C;
+        float acc = 0.f;
+        if (V4) {
+            for (int k4 = lane; k4 < (C >> 2); k4 += 64) acc += dot4(*reinterpret_cast<const float4*>(w + 4 * k4), *reinterpret_cast<const float4*>(ss + 4 * k4));
+        } else {
+            for (int k = lane; k < C; k += 64) acc += w[k] * ss[k];
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) {
+            const float v = fmaxf(acc + (b1 ? b1[j] : 0.f), 0.f);
+            hh[j] = v;
+            if (part == 0) g1[(long)b * Cr + j] = v;
+        }
+    }
+    __syncthreads();
+    const int per = (C + SE_SPLIT - 1) / SE_SPLIT;
+    const int n0 = part * per, n1 = (n0 + per < C) ? n0 + per : C;
+    for (int n = n0 + wave; n < n1; n += nw) {
+        const float* w = W2 + (long)n * Cr;
+        float acc = 0.f;
+        if (V4) {
+            for (int j4 = lane; j4 < (Cr >> 2); j4 += 64) acc += dot4(*reinterpret_cast<const float4*>(w + 4 * j4), *reinterpret_cast<const float4*>(hh + 4 * j4));
+        } else {
+            for (int j = lane; j < Cr; j += 64) acc += w[j] * hh[j];
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) gate[(long)b * C + n] = acc + (b2 ? b2[n] : 0.f);
+    }
+}
+
+__global__ void __launch_bounds__(256) se_zero_kernel(float* __restrict__ p, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = 0.f;
+}
+
+// fc2 pass, one block per SE_ROWS rows n of W2:  dW2[n][:] += dgate[:,n]^T g1,  db2[n] += sum_b dgate[b][n],
+// and this slice's contribution to dg1[b][j] = sum_n dgate[b][n] W2[n][j] (atomics into the zeroed scratch).
+constexpr int SE_ROWS = 16;
+__global__ void __launch_bounds__(256) se_excite_bwd2_kernel(const float* __restrict__ dgate, const float* __restrict__ g1, const float* __restrict__ W2,
+                                                             int B, int C, int Cr, float* __restrict__ dW2, float* __restrict__ db2,
+                                                             float* __restrict__ dg1) {
+    __shared__ float dgs[SE_MAXB][SE_ROWS];
+    __shared__ float g1s[SE_MAXB * SE_MAXR / 2];     // B * Cr <= 8192 floats (32 KB): checked on the host
+    const int n0 = blockIdx.x * SE_ROWS, tid = threadIdx.x;
+    const int rows = (C - n0 < SE_ROWS) ? C - n0 : SE_ROWS;
+    for (int i = tid; i < B * SE_ROWS; i += 256) {
+        const int b = i / SE_ROWS, r = i % SE_ROWS;
+        dgs[b][r] = r < rows ? dgate[(long)b * C + n0 + r] : 0.f;
+    }
+    for (int i = tid; i < B * Cr; i += 256) g1s[i] = g1[i];
+    __syncthreads();
+    for (int i = tid; i < rows * Cr; i += 256) {
+        const int r = i / Cr, j = i - r * Cr;
+        float v = 0.f;
+        for (int b = 0; b < B; ++b) v += dgs[b][r] * g1s[b * Cr + j];
+        dW2[(long)(n0 + r) * Cr + j] += v;
+    }
+    if (tid < rows && db2) {
+        float v = 0.f;
+        for (int b = 0; b < B; ++b) v += dgs[b][tid];
+        db2[n0 + tid] += v;
+    }
+    for (int j = tid; j < Cr; j += 256) {
+        float acc[SE_MAXB];
+#pragma unroll
+        for (int b = 0; b < SE_MAXB; ++b) acc[b] = 0.f;
+        for (int r = 0; r < rows; ++r) {
+            const float w = W2[(long)(n0 + r) * Cr + j];
+#pragma unroll
+            for (int b = 0; b < SE_MAXB; ++b)
+                if (b < B) acc[b] += dgs[b][r] * w;
+        }
+#pragma unroll
+        for (int b = 0; b < SE_MAXB; ++b)
+            if (b < B) atomicAdd(dg1 + b * Cr + j, acc[b]);
+    }
+}
+
+// fc1 pass, one block per 32 columns k of W1:  dg = dg1 * (g1 > 0);  dW1[j][k] += sum_b dg[b][j] s[b][k];  db1[j] += sum_b dg[b][j]
+// (block 0);  ds[b][k] = sum_j dg[b][j] W1[j][k].
+__global__ void __launch_bounds__(256) se_excite_bwd1_kernel(const float* __restrict__ dg1, const float* __restrict__ g1, const float* __restrict__ s,
+                                                             const float* __restrict__ W1, int B, int C, int Cr, float* __restrict__ dW1,
+                                                             float* __restrict__ db1, float* __restrict__ ds) {
+    __shared__ float dgm[SE_MAXB * SE_MAXR / 2];
+    __shared__ float ssl[SE_MAXB][32];
+    __shared__ float red[8][SE_MAXB][32];
+    const int tid = threadIdx.x, kx = tid & 31, jg = tid >> 5;
+    const int k = blockIdx.x * 32 + kx;
+    for (int i = tid; i < B * Cr; i += 256) dgm[i] = g1[i] > 0.f ? dg1[i] : 0.f;
+    for (int i = tid; i < B * 32; i += 256) {
+        const int b = i >> 5, c = blockIdx.x * 32 + (i & 31);
+        ssl[b][i & 31] = c < C ? s[(long)b * C + c] : 0.f;
+    }
+    __syncthreads();
+    float acc[SE_MAXB];
+#pragma unroll
+    for (int b = 0; b < SE_MAXB; ++b) acc[b] = 0.f;
+    if (k < C)
+        for (int j = jg; j < Cr; j += 8) {
+            const float w = W1[(long)j * C + k];
+            float dw = 0.f;
+#pragma unroll
+            for (int b = 0; b < SE_MAXB; ++b)
+                if (b < B) {
+                    const float d = dgm[b * Cr + j];
+                    acc[b] += d * w;
+                    dw += d * ssl[b][kx];
+                }
+            dW1[(long)j * C + k] += dw;
+        }
+#pragma unroll
+    for (int b = 0; b < SE_MAXB; ++b) red[jg][b][kx] = acc[b];
+    __syncthreads();
+    for (int b = jg; b < B; b += 8)
+        if (k < C) {
+            float v = 0.f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) v += red[g][b][kx];
+            ds[(long)b * C + k] = v;
+        }
+    if (blockIdx.x == 0 && db1)
+        for (int j = tid; j < Cr; j += 256) {
+            float v = 0.f;
+            for (int b = 0; b < B; ++b) v += dgm[b * Cr + j];
+            db1[j] += v;
+        }
+}
+
+}  // namespace
+
+extern "C" int tf_se_excite_fwd_f32(const float* s, const float* W1, const float* b1, const float* W2, const float* b2, int B, int C, int Cr, float* g1,
+                                    float* gate, void* stream) {
+    TF_REQUIRE(s && W1 && W2 && g1 && gate && B > 0 && C > 0 && Cr > 0 && C <= SE_MAXC && Cr <= SE_MAXR,
+               "tf_se_excite_fwd_f32: bad arguments (C <= 4096, Cr <= 1024)");
+    const bool v4 = C % 4 == 0 && Cr % 4 == 0 && aligned16(W1) && aligned16(W2);
+    if (v4) TF_LAUNCH(se_excite_fwd_kernel<true>, dim3(B, SE_SPLIT), dim3(1024), stream, s, W1, b1, W2, b2, C, Cr, g1, gate);
+    else TF_LAUNCH(se_excite_fwd_kernel<false>, dim3(B, SE_SPLIT), dim3(1024), stream, s, W1, b1, W2, b2, C, Cr, g1, gate);
+    return launch_status("tf_se_excite_fwd_f32");
+}
+
+extern "C" int tf_se_excite_bwd_f32(const float* dgate, const float* s, const float* g1, const float* W1, const float* W2, int B, int C, int Cr,
+                                    float* dW1, float* db1, float* dW2, float* db2, float* ds, float* scratch, void* stream) {
+    TF_REQUIRE(dgate && s && g1 && W1 && W2 && dW1 && dW2 && ds && scratch && B > 0 && B <= SE_MAXB && C > 0 && Cr > 0 &&
+                   (long)B * Cr <= SE_MAXB * SE_MAXR / 2, "tf_se_excite_bwd_f32: bad arguments (B <= 16, B*Cr <= 8192)");
+    TF_LAUNCH(se_zero_kernel, dim3(cdiv((long)B * Cr, 256)), dim3(256), stream, scratch, B * Cr);
+    TF_LAUNCH(se_excite_bwd2_kernel, dim3(cdiv(C, SE_ROWS)), dim3(256), stream, dgate, g1, W2, B, C, Cr, dW2, db2, scratch);
+    TF_LAUNCH(se_excite_bwd1_kernel, dim3(cdiv(C, 32)), dim3(256), stream, (const float*)scratch, g1, s, W1, B, C, Cr, dW1, db1, ds);
+    return launch_status("tf_se_excite_bwd_f32");
+}

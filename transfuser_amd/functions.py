@@ -77,8 +77,11 @@ class YBlockFn(torch.autograd.Function):
         z2, st2 = _bn(y2, blk.conv2.bn, relu=True)
         _, Ho, Wo, _ = y2.shape
         s = ops.colsum(z2, B, Ho * Wo, C, 1.0 / (Ho * Wo))
-        g1 = ops.linear_fwd(s, w2d(blk.se.fc1.weight), blk.se.fc1.bias, relu=True)
-        gate = ops.linear_fwd(g1, w2d(blk.se.fc2.weight), blk.se.fc2.bias)
+        if B <= 16:
+            g1, gate = ops.se_excite_fwd(s, blk.se.fc1.weight, blk.se.fc1.bias, blk.se.fc2.weight, blk.se.fc2.bias)
+        else:
+            g1 = ops.linear_fwd(s, w2d(blk.se.fc1.weight), blk.se.fc1.bias, relu=True)
+            gate = ops.linear_fwd(g1, w2d(blk.se.fc2.weight), blk.se.fc2.bias)
         z2s = ops.se_scale_fwd(z2, gate)
         y3 = ops.linear_fwd(z2s.view(-1, C), w2d(blk.conv3.conv.weight)).view(B, Ho, Wo, C)
         yd = std = None
@@ -108,13 +111,17 @@ class YBlockFn(torch.autograd.Function):
         # squeeze-excite
         se = blk.se
         dgate = ops.se_scale_bwd_gate(dz2s, z2, gate)
-        ops.linear_wgrad(dgate, g1, w2d(gbuf(se.fc2.weight)))
-        bias_grad(dgate, se.fc2.bias)
-        dg1 = ops.linear_dgrad(dgate, w2d(se.fc2.weight))
-        dg1 = ops.relu_mask(dg1, g1, out=dg1)
-        ops.linear_wgrad(dg1, s, w2d(gbuf(se.fc1.weight)))
-        bias_grad(dg1, se.fc1.bias)
-        ds = ops.linear_dgrad(dg1, w2d(se.fc1.weight))
+        if B <= 16 and B * g1.shape[1] <= 8192:
+            ds = ops.se_excite_bwd(dgate, s, g1, se.fc1.weight, se.fc2.weight, gbuf(se.fc1.weight), gbuf(se.fc1.bias), gbuf(se.fc2.weight),
+                                   gbuf(se.fc2.bias))
+        else:
+            ops.linear_wgrad(dgate, g1, w2d(gbuf(se.fc2.weight)))
+            bias_grad(dgate, se.fc2.bias)
+            dg1 = ops.linear_dgrad(dgate, w2d(se.fc2.weight))
+            dg1 = ops.relu_mask(dg1, g1, out=dg1)
+            ops.linear_wgrad(dg1, s, w2d(gbuf(se.fc1.weight)))
+            bias_grad(dg1, se.fc1.bias)
+            ds = ops.linear_dgrad(dg1, w2d(se.fc1.weight))
         dz2 = ops.se_scale_bwd_x(dz2s, gate, ds, z2.shape)
         # grouped 3x3
         dy2, _ = _bn_bwd(dz2, z2, y2, blk.conv2.bn, st2)

@@ -312,6 +312,27 @@ def se_scale_bwd_x(dy, gate, dmean, shape, out=None, accumulate=False):
     return out
 
 
+def se_excite_fwd(s, w1, b1, w2, b2):
+    """Fused SE excitation: returns (g1 (B, Cr) post-ReLU, gate (B, C) pre-sigmoid)."""
+    B, C = s.shape
+    Cr = w1.shape[0]
+    g1 = torch.empty(B, Cr, dtype=torch.float32, device=s.device)
+    gate = torch.empty(B, C, dtype=torch.float32, device=s.device)
+    check(L().tf_se_excite_fwd_f32(ptr(_c(s)), wptr(w1), ptr(b1), wptr(w2), ptr(b2), B, C, Cr, ptr(g1), ptr(gate), stream_of(s)), "tf_se_excite_fwd_f32")
+    return g1, gate
+
+
+def se_excite_bwd(dgate, s, g1, w1, w2, dw1, db1, dw2, db2):
+    """Accumulates the four parameter gradients, returns ds (B, C)."""
+    B, C = s.shape
+    Cr = w1.shape[0]
+    ds = torch.empty(B, C, dtype=torch.float32, device=s.device)
+    scratch = torch.empty(B, Cr, dtype=torch.float32, device=s.device)
+    check(L().tf_se_excite_bwd_f32(ptr(_c(dgate)), ptr(_c(s)), ptr(_c(g1)), wptr(w1), wptr(w2), B, C, Cr, wptr(dw1), ptr(db1), wptr(dw2), ptr(db2),
+                                   ptr(ds), ptr(scratch), stream_of(s)), "tf_se_excite_bwd_f32")
+    return ds
+
+
 # ------------------------------------------------------------------------------------------ resampling
 def pool_tokens_fwd(x, oh, ow, pos, tok, tok_off, bvec=None):
     B, H, W, C = x.shape
