@@ -24,6 +24,8 @@ torch.manual_seed(0)
 model = LidarCenterNet(cfg, dev, 'transFuser', 'regnety_032', 'regnety_032', use_velocity=False).train()
 hist_fn = lambda pts: ops.lidar_hist(torch.from_numpy(pts).to(dev)[None])[0].cpu().numpy()
 eng = Engine(model, cfg, autotune=False)
+if os.environ.get("TF_RETUNE", "1") == "1":
+    ops.L().tf_plans_clear()   # re-tune every shape from scratch (kernels changed)
 for H in hs:
     batch = {k: v.to(dev) for k, v in synthetic_batch(B, H, 704, seed=0, hist_fn=hist_fn).items()}
     eng.train_step(batch); torch.cuda.synchronize()

@@ -12,7 +12,8 @@ using namespace tf;
 namespace {
 
 constexpr int SE_MAXB = 16;
-constexpr int SE_SPLIT = 4;        // forward: blocks per sample (each recomputes fc1 - cheap - and owns 1/4 of the fc2 outputs)
+constexpr int SE_SPLIT = 8;        // forward: blocks per sample (each recomputes fc1 - cheap - and owns 1/8 of the fc2 outputs)
+constexpr int SE_U = 4;            // independent dot products in flight per wave
 constexpr int SE_MAXC = 4096, SE_MAXR = 1024;
 
 __device__ __forceinline__ float dot4(const float4 a, const float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
@@ -28,34 +29,67 @@ __global__ void __launch_bounds__(1024) se_excite_fwd_kernel(const float* __rest
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
     for (int k = tid; k < C; k += blockDim.x) ss[k] = s[(long)b * C + k];
     __syncthreads();
-    for (int j = wave; j < Cr; j += nw) {
-        const float* w = W1 + (long)j * C;
-        float acc = 0.f;
-        if (V4) {
-            for (int k4 = lane; k4 < (C >> 2); k4 += 64) acc += dot4(*reinterpret_cast<const float4*>(w + 4 * k4), *reinterpret_cast<const float4*>(ss + 4 * k4));
-        } else {
-            for (int k = lane; k < C; k += 64) acc += w[k] * ss[k];
+    // SE_U independent dot products per wave iteration: SE_U x more loads in flight (the weights come from HBM, ~1 us away)
+    for (int j0 = wave * SE_U; j0 < Cr; j0 += nw * SE_U) {
+        float acc[SE_U];
+        const float* w[SE_U];
+#pragma unroll
+        for (int u = 0; u < SE_U; ++u) {
+            acc[u] = 0.f;
+            w[u] = W1 + (long)((j0 + u < Cr) ? j0 + u : Cr - 1) * C;
         }
-        acc = wave_sum(acc);
-        if (lane == 0) {
-            const float v = fmaxf(acc + (b1 ? b1[j] : 0.f), 0.f);
-            hh[j] = v;
-            if (part == 0) g1[(long)b * Cr + j] = v;
+        if (V4) {
+            for (int k4 = lane; k4 < (C >> 2); k4 += 64) {
+                const float4 sv = *reinterpret_cast<const float4*>(ss + 4 * k4);
+#pragma unroll
+                for (int u = 0; u < SE_U; ++u) acc[u] += dot4(*reinterpret_cast<const float4*>(w[u] + 4 * k4), sv);
+            }
+        } else {
+            for (int k = lane; k < C; k += 64) {
+#pragma unroll
+                for (int u = 0; u < SE_U; ++u) acc[u] += w[u][k] * ss[k];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < SE_U; ++u) {
+            const float a = wave_sum(acc[u]);
+            const int j = j0 + u;
+            if (lane == 0 && j < Cr) {
+                const float v = fmaxf(a + (b1 ? b1[j] : 0.f), 0.f);
+                hh[j] = v;
+                if (part == 0) g1[(long)b * Cr + j] = v;
+            }
         }
     }
     __syncthreads();
     const int per = (C + SE_SPLIT - 1) / SE_SPLIT;
     const int n0 = part * per, n1 = (n0 + per < C) ? n0 + per : C;
-    for (int n = n0 + wave; n < n1; n += nw) {
-        const float* w = W2 + (long)n * Cr;
-        float acc = 0.f;
-        if (V4) {
-            for (int j4 = lane; j4 < (Cr >> 2); j4 += 64) acc += dot4(*reinterpret_cast<const float4*>(w + 4 * j4), *reinterpret_cast<const float4*>(hh + 4 * j4));
-        } else {
-            for (int j = lane; j < Cr; j += 64) acc += w[j] * hh[j];
+    for (int nb = n0 + wave * SE_U; nb < n1; nb += nw * SE_U) {
+        float acc[SE_U];
+        const float* w[SE_U];
+#pragma unroll
+        for (int u = 0; u < SE_U; ++u) {
+            acc[u] = 0.f;
+            w[u] = W2 + (long)((nb + u < n1) ? nb + u : n1 - 1) * Cr;
         }
-        acc = wave_sum(acc);
-        if (lane == 0) gate[(long)b * C + n] = acc + (b2 ? b2[n] : 0.f);
+        if (V4) {
+            for (int j4 = lane; j4 < (Cr >> 2); j4 += 64) {
+                const float4 hv = *reinterpret_cast<const float4*>(hh + 4 * j4);
+#pragma unroll
+                for (int u = 0; u < SE_U; ++u) acc[u] += dot4(*reinterpret_cast<const float4*>(w[u] + 4 * j4), hv);
+            }
+        } else {
+            for (int j = lane; j < Cr; j += 64) {
+#pragma unroll
+                for (int u = 0; u < SE_U; ++u) acc[u] += w[u][j] * hh[j];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < SE_U; ++u) {
+            const float a = wave_sum(acc[u]);
+            const int n = nb + u;
+            if (lane == 0 && n < n1) gate[(long)b * C + n] = a + (b2 ? b2[n] : 0.f);
+        }
     }
 }
 
@@ -66,7 +100,7 @@ __global__ void __launch_bounds__(256) se_zero_kernel(float* __restrict__ p, int
 
 // fc2 pass, one block per SE_ROWS rows n of W2:  dW2[n][:] += dgate[:,n]^T g1,  db2[n] += sum_b dgate[b][n],
 // and this slice's contribution to dg1[b][j] = sum_n dgate[b][n] W2[n][j] (atomics into the zeroed scratch).
-constexpr int SE_ROWS = 16;
+constexpr int SE_ROWS = 8;
 __global__ void __launch_bounds__(256) se_excite_bwd2_kernel(const float* __restrict__ dgate, const float* __restrict__ g1, const float* __restrict__ W2,
                                                              int B, int C, int Cr, float* __restrict__ dW2, float* __restrict__ db2,
                                                              float* __restrict__ dg1) {

@@ -18,6 +18,13 @@ constexpr int kWave = 64;  // CDNA wavefront
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// instruction-scheduling fence for hipcc (nothing may be moved across it); no-op in the host emulation
+#ifdef TF_EMU
+#define TF_SCHED_FENCE() ((void)0)
+#else
+#define TF_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+
 #ifdef TF_EMU
 __forceinline__ int lane_id() { return emu::cur_lane(); }
 
