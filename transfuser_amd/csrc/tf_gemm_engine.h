@@ -384,19 +384,9 @@ __device__ __forceinline__ void gemm_tile(LA& la, LB& lb, const GemmEpi& ep, int
     const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wm0 = (wave % WAVES_M) * WM, wn0 = (wave / WAVES_M) * WN;
 
-    if (nkt > 0) {
-        if (CANFAST && nfast > 0) { fetch_fast(0); stash_fast(0); }
-        else { fetch(kbeg); stash(0); }
-    }
-    __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int cur = kt & 1;
-        const bool more = kt + 1 < nkt;
-        const bool fastn = CANFAST && kt + 1 < nfast;
-        if (fastn) fetch_fast(kt + 1);
-        else if (more) fetch(kbeg + (kt + 1) * BK);
-        // software-pipelined operand fetch: the LDS reads of step kk+1 are issued BEFORE the MFMAs of step kk (hipcc otherwise emits
-        // read -> s_waitcnt lgkmcnt(0) -> MFMAs per step, exposing the LDS latency whenever a SIMD holds fewer than ~3 waves)
+    // software-pipelined operand fetch: the LDS reads of step kk+1 are issued BEFORE the MFMAs of step kk (hipcc otherwise emits
+    // read -> s_waitcnt lgkmcnt(0) -> MFMAs per step, exposing the LDS latency whenever a SIMD holds fewer than ~3 waves)
+    auto compute = [&](int cur) {
         float a[2][TM], b[2][TN];
 #pragma unroll
         for (int t = 0; t < TM; ++t) a[0][t] = As[cur][hi][wm0 + t * 32 + l31];
@@ -418,9 +408,42 @@ __device__ __forceinline__ void gemm_tile(LA& la, LB& lb, const GemmEpi& ep, int
                 for (int u = 0; u < TN; ++u) mfma_32x32x2(a[s][t], b[s][u], acc[t][u]);
             TF_SCHED_FENCE();
         }
-        if (fastn) stash_fast(cur ^ 1);
-        else if (more) stash(cur ^ 1);
+    };
+
+    if constexpr (CANFAST) {
+        // hot loop: complete k tiles only, nothing but pointer bumps, 16-byte loads, MFMAs and one barrier per tile; a ragged last
+        // tile is peeled off below (keeping the masked code out of the loop also keeps its registers out of the loop's allocation)
+        if (nfast > 0) {
+            fetch_fast(0);
+            stash_fast(0);
+        }
         __syncthreads();
+        for (int kt = 0; kt < nfast; ++kt) {     // branch-free body: the last iteration re-fetches its own tile into the idle buffer
+            const int cur = kt & 1;
+            fetch_fast(kt + 1 < nfast ? kt + 1 : kt);
+            compute(cur);
+            stash_fast(cur ^ 1);
+            __syncthreads();
+        }
+        if (nkt > nfast) {
+            fetch(kbeg + nfast * BK);
+            stash(nfast & 1);
+            __syncthreads();
+            compute(nfast & 1);
+        }
+    } else {
+        if (nkt > 0) {
+            fetch(kbeg);
+            stash(0);
+        }
+        __syncthreads();
+        for (int kt = 0; kt < nkt; ++kt) {       // branch-free body: past the last tile every validity bit is 0 (zeros into the idle buffer)
+            const int cur = kt & 1;
+            fetch(kbeg + (kt + 1) * BK);
+            compute(cur);
+            stash(cur ^ 1);
+            __syncthreads();
+        }
     }
 
     // epilogue: lane holds column j of 16 rows per 32x32 tile.  Mode / residual / bounds are resolved ONCE per tile
