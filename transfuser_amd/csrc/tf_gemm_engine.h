@@ -32,16 +32,26 @@ __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0
 // loaders return the RAW (possibly clamped-address) data plus a 4-bit validity mask; gemm_tile applies the mask when it
 // writes the tile to LDS, so nothing depends on the loaded registers until after the MFMAs of the current tile.
 
-struct PlainRow { const float* p; int ok; };
+// CURSORS.  A thread's LDS slot keeps either its ROW fixed over the K loop and walks along the columns (KC operand) or keeps its
+// COLUMN fixed and walks down the rows (IC operand).  The expensive index decompositions ((tap, ci) of a column, (b, oh, ow) of a
+// pixel row: integer divisions by run-time values) are therefore done ONCE per slot (row() / col()), and stepping by BK is a few
+// adds and compares (row_advance / col_advance).  Recomputing them per k-step cost ~390 VALU instructions per 16 MFMAs in the
+// 3x3-conv kernels (2x the MFMA time).
+
+struct PlainRow { const float* p; int r, ok; };
 
 // X(r, c) = p[r*ld + c], r < rows, c < cols.  Batch z -> p + (z / inner) * s_outer + (z % inner) * s_inner.
 struct PlainOp {
     const float* p; long ld; int rows, cols, vec; long s_outer, s_inner; int inner;
     typedef PlainRow Row;
+    typedef int Col;
     static constexpr bool kFast = true;    // plain strided matrix: interior / clamped tiles can skip all masking (gemm_tile fast path)
     __device__ __forceinline__ void set_batch(int z) { p += (long)(z / inner) * s_outer + (long)(z % inner) * s_inner; }
-    __device__ __forceinline__ Row row(int r) const { Row w; w.ok = r < rows; w.p = p + (w.ok ? (long)r * ld : 0L); return w; }
-    template <bool V> __device__ __forceinline__ float4 load(const Row& w, int c, bool en, unsigned& m) const {
+    __device__ __forceinline__ Row row(int r) const { Row w; w.r = r; w.ok = r < rows; w.p = p + (w.ok ? (long)r * ld : 0L); return w; }
+    __device__ __forceinline__ void row_advance(Row& w, int d) const { w.r += d; w.ok = w.r < rows; w.p = p + (w.ok ? (long)w.r * ld : 0L); }
+    __device__ __forceinline__ Col col(int c) const { return c; }
+    __device__ __forceinline__ void col_advance(Col& c, int d) const { c += d; }
+    template <bool V> __device__ __forceinline__ float4 load(const Row& w, const Col& c, bool en, unsigned& m) const {
         const bool ok = en && w.ok && c < cols;
         if (V || vec) { m = ok ? 15u : 0u; return *reinterpret_cast<const float4*>(w.p + (ok ? c : 0)); }
         const bool o1 = ok && c + 1 < cols, o2 = ok && c + 2 < cols, o3 = ok && c + 3 < cols;
@@ -50,21 +60,32 @@ struct PlainOp {
     }
 };
 
+struct WDgradRow { const float* p; int r, tap, co, ok; };   // row r = (tap, co)
+
 // Conv weight in channels-last physical order W[co][tap][ci] seen as rows = (tap, co), cols = ci
 // (the B operand of dgrad).  Batch z = group.
 struct WDgradOp {
     static constexpr bool kFast = false;
     const float* w; int taps, Cog, Cig, rows, cols, vec; long gstride;
-    typedef PlainRow Row;
+    typedef WDgradRow Row;
+    typedef int Col;
     __device__ __forceinline__ void set_batch(int z) { w += (long)z * gstride; }
+    __device__ __forceinline__ void fix(Row& r) const { r.ok = r.r < rows; r.p = w + (r.ok ? ((long)r.co * taps + r.tap) * Cig : 0L); }
     __device__ __forceinline__ Row row(int k) const {
-        Row r; r.ok = k < rows;
-        const int kk = r.ok ? k : 0;
-        const int tap = kk / Cog, co = kk - tap * Cog;
-        r.p = w + ((long)co * taps + tap) * Cig;
+        Row r; r.r = k;
+        const int kk = k < rows ? k : 0;
+        r.tap = kk / Cog; r.co = kk - r.tap * Cog;
+        fix(r);
         return r;
     }
-    template <bool V> __device__ __forceinline__ float4 load(const Row& r, int c, bool en, unsigned& m) const {
+    __device__ __forceinline__ void row_advance(Row& r, int d) const {
+        r.r += d; r.co += d;
+        while (r.co >= Cog) { r.co -= Cog; ++r.tap; }
+        fix(r);
+    }
+    __device__ __forceinline__ Col col(int c) const { return c; }
+    __device__ __forceinline__ void col_advance(Col& c, int d) const { c += d; }
+    template <bool V> __device__ __forceinline__ float4 load(const Row& r, const Col& c, bool en, unsigned& m) const {
         const bool ok = en && r.ok && c < cols;
         if (V || vec) { m = ok ? 15u : 0u; return *reinterpret_cast<const float4*>(r.p + (ok ? c : 0)); }
         const bool o1 = ok && c + 1 < cols, o2 = ok && c + 2 < cols, o3 = ok && c + 3 < cols;
@@ -73,7 +94,34 @@ struct WDgradOp {
     }
 };
 
-struct ConvRow { long base; int h0, w0, ok; };
+struct ConvRow { long base; int r, b, y, x, h0, w0, ok; };   // pixel row r = (b, y, x); (h0, w0) = window origin / padded position
+struct ConvCol { int c, ci, kh, kw; };                       // column c = ((kh, kw), ci)
+
+__device__ __forceinline__ int cidx(int c) { return c; }
+__device__ __forceinline__ int cidx(const ConvCol& k) { return k.c; }
+
+// shared cursor arithmetic of the three im2col views: rows walk over (b, y, x) of an (Hy, Wx) map, columns over (tap, channel)
+__device__ __forceinline__ void conv_row_split(ConvRow& w, int r, int rows, int Hy, int Wx) {
+    w.r = r; w.ok = r < rows;
+    const int rr = w.ok ? r : 0;
+    w.x = rr % Wx;
+    const int t = rr / Wx;
+    w.y = t % Hy; w.b = t / Hy;
+}
+__device__ __forceinline__ void conv_row_step(ConvRow& w, int d, int rows, int Hy, int Wx) {
+    w.r += d; w.ok = w.r < rows; w.x += d;
+    while (w.x >= Wx) { w.x -= Wx; if (++w.y >= Hy) { w.y = 0; ++w.b; } }
+}
+__device__ __forceinline__ ConvCol conv_col_split(int c, int Cg, int ks) {
+    ConvCol k; k.c = c;
+    const int tap = c / Cg;
+    k.ci = c - tap * Cg; k.kh = tap / ks; k.kw = tap - k.kh * ks;
+    return k;
+}
+__device__ __forceinline__ void conv_col_step(ConvCol& k, int d, int Cg, int ks) {
+    k.c += d; k.ci += d;
+    while (k.ci >= Cg) { k.ci -= Cg; if (++k.kw >= ks) { k.kw = 0; ++k.kh; } }
+}
 
 // im2col view of an NHWC tensor X (B, Hi, Wi, Ct): rows = output pixels (b, oh, ow), cols = (tap, ci)
 // with ci fastest in [0, Cg).  Batch z = group (channel offset z*Cg).
@@ -81,33 +129,31 @@ struct Im2colOp {
     static constexpr bool kFast = false;
     const float* x; int Hi, Wi, Ct, Ho, Wo, ks, stride, pad, Cg, rows, cols, vec, coff;
     typedef ConvRow Row;
+    typedef ConvCol Col;
     __device__ __forceinline__ void set_batch(int z) { coff += z * Cg; }
-    __device__ __forceinline__ Row row(int r) const {
-        Row w; w.ok = r < rows;
-        const int rr = w.ok ? r : 0;
-        const int ow = rr % Wo, t = rr / Wo, oh = t % Ho, b = t / Ho;
-        w.base = (long)b * Hi * Wi; w.h0 = oh * stride - pad; w.w0 = ow * stride - pad;
-        return w;
-    }
+    __device__ __forceinline__ void fix(Row& w) const { w.base = (long)w.b * Hi * Wi; w.h0 = w.y * stride - pad; w.w0 = w.x * stride - pad; }
+    __device__ __forceinline__ Row row(int r) const { Row w; conv_row_split(w, r, rows, Ho, Wo); fix(w); return w; }
+    __device__ __forceinline__ void row_advance(Row& w, int d) const { conv_row_step(w, d, rows, Ho, Wo); fix(w); }
+    __device__ __forceinline__ Col col(int c) const { return conv_col_split(c, Cg, ks); }
+    __device__ __forceinline__ void col_advance(Col& k, int d) const { conv_col_step(k, d, Cg, ks); }
     // element offset of (row, col) and its validity, no branches
-    __device__ __forceinline__ long off(const Row& w, int c, bool& ok) const {
-        ok = ok && w.ok && c < cols;
-        const int cc = ok ? c : 0;
-        const int tap = cc / Cg, ci = cc - tap * Cg, kh = tap / ks, kw = tap - kh * ks;
-        const int ih = w.h0 + kh, iw = w.w0 + kw;
-        ok = ok && (unsigned)ih < (unsigned)Hi && (unsigned)iw < (unsigned)Wi;
-        return ok ? (w.base + (long)ih * Wi + iw) * Ct + coff + ci : 0L;
+    __device__ __forceinline__ long off(const Row& w, const Col& k, bool& ok) const {
+        const int ih = w.h0 + k.kh, iw = w.w0 + k.kw;
+        ok = ok && w.ok && k.c < cols && (unsigned)ih < (unsigned)Hi && (unsigned)iw < (unsigned)Wi;
+        return ok ? (w.base + (long)ih * Wi + iw) * Ct + coff + k.ci : 0L;
     }
-    template <bool V> __device__ __forceinline__ float4 load(const Row& w, int c, bool en, unsigned& m) const {
+    template <bool V> __device__ __forceinline__ float4 load(const Row& w, const Col& k, bool en, unsigned& m) const {
         if (V || vec) {
             bool ok = en;
-            const long o = off(w, c, ok);
+            const long o = off(w, k, ok);
             m = ok ? 15u : 0u;
             return *reinterpret_cast<const float4*>(x + o);
         }
-        bool k0 = en, k1 = en, k2 = en, k3 = en;
-        const long o0 = off(w, c, k0), o1 = off(w, c + 1, k1), o2 = off(w, c + 2, k2), o3 = off(w, c + 3, k3);
-        m = (k0 ? 1u : 0u) | (k1 ? 2u : 0u) | (k2 ? 4u : 0u) | (k3 ? 8u : 0u);
+        Col k1 = k, k2, k3;
+        conv_col_step(k1, 1, Cg, ks); k2 = k1; conv_col_step(k2, 1, Cg, ks); k3 = k2; conv_col_step(k3, 1, Cg, ks);
+        bool b0 = en, b1 = en, b2 = en, b3 = en;
+        const long o0 = off(w, k, b0), o1 = off(w, k1, b1), o2 = off(w, k2, b2), o3 = off(w, k3, b3);
+        m = (b0 ? 1u : 0u) | (b1 ? 2u : 0u) | (b2 ? 4u : 0u) | (b3 ? 8u : 0u);
         return make_float4(x[o0], x[o1], x[o2], x[o3]);
     }
 };
@@ -118,34 +164,34 @@ struct Im2colTOp {
     static constexpr bool kFast = false;
     const float* dy; int Hi, Wi, Ct, Ho, Wo, ks, stride, pad, Cg, rows, cols, vec, coff;
     typedef ConvRow Row;
+    typedef ConvCol Col;
     __device__ __forceinline__ void set_batch(int z) { coff += z * Cg; }
-    __device__ __forceinline__ Row row(int r) const {
-        Row w; w.ok = r < rows;
-        const int rr = w.ok ? r : 0;
-        const int iw = rr % Wi, t = rr / Wi, ih = t % Hi, b = t / Hi;
-        w.base = (long)b * Ho * Wo; w.h0 = ih + pad; w.w0 = iw + pad;
-        return w;
-    }
-    __device__ __forceinline__ long off(const Row& w, int c, bool& ok) const {
-        ok = ok && w.ok && c < cols;
-        const int cc = ok ? c : 0;
-        const int tap = cc / Cg, co = cc - tap * Cg, kh = tap / ks, kw = tap - kh * ks;
-        const int th = w.h0 - kh, tw = w.w0 - kw;
+    __device__ __forceinline__ void fix(Row& w) const { w.base = (long)w.b * Ho * Wo; w.h0 = w.y + pad; w.w0 = w.x + pad; }
+    __device__ __forceinline__ Row row(int r) const { Row w; conv_row_split(w, r, rows, Hi, Wi); fix(w); return w; }
+    __device__ __forceinline__ void row_advance(Row& w, int d) const { conv_row_step(w, d, rows, Hi, Wi); fix(w); }
+    __device__ __forceinline__ Col col(int c) const { return conv_col_split(c, Cg, ks); }
+    __device__ __forceinline__ void col_advance(Col& k, int d) const { conv_col_step(k, d, Cg, ks); }
+    __device__ __forceinline__ long off(const Row& w, const Col& k, bool& ok) const {
+        const int th = w.h0 - k.kh, tw = w.w0 - k.kw;
         int oh = th, ow = tw;
-        if (stride != 1) { oh = th / stride; ow = tw / stride; }   // uniform branch
-        ok = ok && th >= 0 && tw >= 0 && oh * stride == th && ow * stride == tw && oh < Ho && ow < Wo;
-        return ok ? (w.base + (long)oh * Wo + ow) * Ct + coff + co : 0L;
+        bool div = true;
+        if (stride == 2) { oh = th >> 1; ow = tw >> 1; div = ((th | tw) & 1) == 0; }                       // uniform branches
+        else if (stride != 1) { oh = th / stride; ow = tw / stride; div = oh * stride == th && ow * stride == tw; }
+        ok = ok && w.ok && k.c < cols && th >= 0 && tw >= 0 && div && oh < Ho && ow < Wo;
+        return ok ? (w.base + (long)oh * Wo + ow) * Ct + coff + k.ci : 0L;
     }
-    template <bool V> __device__ __forceinline__ float4 load(const Row& w, int c, bool en, unsigned& m) const {
+    template <bool V> __device__ __forceinline__ float4 load(const Row& w, const Col& k, bool en, unsigned& m) const {
         if (V || vec) {
             bool ok = en;
-            const long o = off(w, c, ok);
+            const long o = off(w, k, ok);
             m = ok ? 15u : 0u;
             return *reinterpret_cast<const float4*>(dy + o);
         }
-        bool k0 = en, k1 = en, k2 = en, k3 = en;
-        const long o0 = off(w, c, k0), o1 = off(w, c + 1, k1), o2 = off(w, c + 2, k2), o3 = off(w, c + 3, k3);
-        m = (k0 ? 1u : 0u) | (k1 ? 2u : 0u) | (k2 ? 4u : 0u) | (k3 ? 8u : 0u);
+        Col k1 = k, k2, k3;
+        conv_col_step(k1, 1, Cg, ks); k2 = k1; conv_col_step(k2, 1, Cg, ks); k3 = k2; conv_col_step(k3, 1, Cg, ks);
+        bool b0 = en, b1 = en, b2 = en, b3 = en;
+        const long o0 = off(w, k, b0), o1 = off(w, k1, b1), o2 = off(w, k2, b2), o3 = off(w, k3, b3);
+        m = (b0 ? 1u : 0u) | (b1 ? 2u : 0u) | (b2 ? 4u : 0u) | (b3 ? 8u : 0u);
         return make_float4(dy[o0], dy[o1], dy[o2], dy[o3]);
     }
 };
@@ -159,20 +205,17 @@ struct Im2colNchwOp {
     const float* s0; const float* s1; int C0, C1, Hi, Wi, Ho, Wo, ks, stride, pad, Cg, rows, cols, vec, normalize;
     float mean[4], stdv[4];
     typedef ConvRow Row;
+    typedef ConvCol Col;
     __device__ __forceinline__ void set_batch(int) {}
-    __device__ __forceinline__ Row row(int r) const {
-        Row w; w.ok = r < rows;
-        const int rr = w.ok ? r : 0;
-        const int ow = rr % Wo, t = rr / Wo, oh = t % Ho, b = t / Ho;
-        w.base = b; w.h0 = oh * stride - pad; w.w0 = ow * stride - pad;
-        return w;
-    }
-    __device__ __forceinline__ float at(const Row& w, int c, bool en, bool& ok) const {
-        ok = en && w.ok && c < cols;
-        const int cc = ok ? c : 0;
-        const int tap = cc / Cg, ci = cc - tap * Cg, kh = tap / ks, kw = tap - kh * ks;
-        const int ih = w.h0 + kh, iw = w.w0 + kw;
-        ok = ok && (unsigned)ih < (unsigned)Hi && (unsigned)iw < (unsigned)Wi;
+    __device__ __forceinline__ void fix(Row& w) const { w.base = w.b; w.h0 = w.y * stride - pad; w.w0 = w.x * stride - pad; }
+    __device__ __forceinline__ Row row(int r) const { Row w; conv_row_split(w, r, rows, Ho, Wo); fix(w); return w; }
+    __device__ __forceinline__ void row_advance(Row& w, int d) const { conv_row_step(w, d, rows, Ho, Wo); fix(w); }
+    __device__ __forceinline__ Col col(int c) const { return conv_col_split(c, Cg, ks); }
+    __device__ __forceinline__ void col_advance(Col& k, int d) const { conv_col_step(k, d, Cg, ks); }
+    __device__ __forceinline__ float at(const Row& w, const Col& k, bool en, bool& ok) const {
+        const int ih = w.h0 + k.kh, iw = w.w0 + k.kw;
+        ok = en && w.ok && k.c < cols && (unsigned)ih < (unsigned)Hi && (unsigned)iw < (unsigned)Wi;
+        const int ci = ok ? k.ci : 0;
         const bool first = ci < C0;
         const float* src = (first || !s1) ? s0 : s1;
         const int cs = first ? ci : ci - C0, Cn = first ? C0 : C1;
@@ -181,10 +224,12 @@ struct Im2colNchwOp {
         if (normalize) v = ((v / 255.0f) - mean[ci & 3]) / stdv[ci & 3];
         return v;
     }
-    template <bool V> __device__ __forceinline__ float4 load(const Row& w, int c, bool en, unsigned& m) const {
-        bool k0, k1, k2, k3;
-        const float v0 = at(w, c, en, k0), v1 = at(w, c + 1, en, k1), v2 = at(w, c + 2, en, k2), v3 = at(w, c + 3, en, k3);
-        m = (k0 ? 1u : 0u) | (k1 ? 2u : 0u) | (k2 ? 4u : 0u) | (k3 ? 8u : 0u);
+    template <bool V> __device__ __forceinline__ float4 load(const Row& w, const Col& k, bool en, unsigned& m) const {
+        Col k1 = k, k2, k3;
+        conv_col_step(k1, 1, Cg, ks); k2 = k1; conv_col_step(k2, 1, Cg, ks); k3 = k2; conv_col_step(k3, 1, Cg, ks);
+        bool b0, b1, b2, b3;
+        const float v0 = at(w, k, en, b0), v1 = at(w, k1, en, b1), v2 = at(w, k2, en, b2), v3 = at(w, k3, en, b3);
+        m = (b0 ? 1u : 0u) | (b1 ? 2u : 0u) | (b2 ? 4u : 0u) | (b3 ? 8u : 0u);
         return make_float4(v0, v1, v2, v3);
     }
 };
@@ -226,43 +271,52 @@ __device__ __forceinline__ void gemm_tile(LA& la, LB& lb, const GemmEpi& ep, int
     const int kend = (kbeg + kchunk < K) ? kbeg + kchunk : K;
     const int nkt = (kend - kbeg + BK - 1) / BK;
 
-    // KC operands: a thread's rows are fixed over the K loop -> resolve them once
+    // masked (general) path: per-slot cursors, see CURSORS above.  KC slot: row fixed, column cursor walks k; IC slot: column fixed,
+    // row cursor walks k.  fetch() loads the tile at the cursors and steps them by BK, i.e. tiles are fetched in order from gen_seek().
     typename LA::Row arow[NLA];
     typename LB::Row brow[NLB];
-    if (A_KC) {
+    typename LA::Col acol[NLA];
+    typename LB::Col bcol[NLB];
+    auto gen_seek = [&](int k0) {
 #pragma unroll
-        for (int p = 0; p < NLA; ++p) arow[p] = la.row(i0 + (tid + p * 256) / KQ);
-    }
-    if (B_KC) {
+        for (int p = 0; p < NLA; ++p) {
+            const int f = tid + p * 256;
+            if (A_KC) { arow[p] = la.row(i0 + f / KQ); acol[p] = la.col(k0 + (f % KQ) * 4); }
+            else { const int kr = f / (BM / 4), cq = f - kr * (BM / 4); arow[p] = la.row(k0 + kr); acol[p] = la.col(i0 + cq * 4); }
+        }
 #pragma unroll
-        for (int p = 0; p < NLB; ++p) brow[p] = lb.row(j0 + (tid + p * 256) / KQ);
-    }
+        for (int p = 0; p < NLB; ++p) {
+            const int f = tid + p * 256;
+            if (B_KC) { brow[p] = lb.row(j0 + f / KQ); bcol[p] = lb.col(k0 + (f % KQ) * 4); }
+            else { const int kr = f / (BN / 4), cq = f - kr * (BN / 4); brow[p] = lb.row(k0 + kr); bcol[p] = lb.col(j0 + cq * 4); }
+        }
+    };
 
     float4 ra[NLA], rb[NLB];
     unsigned ma[NLA], mb[NLB];   // validity bits of the prefetched slots
-    auto fetch = [&](int k0) {
+    auto fetch = [&]() {
 #pragma unroll
         for (int p = 0; p < NLA; ++p) {
             const int f = tid + p * 256;
             if (A_KC) {
-                const int k = k0 + (f % KQ) * 4;
-                ra[p] = la.template load<ALLVEC>(arow[p], k, f < BM * KQ && k < kend, ma[p]);
+                ra[p] = la.template load<ALLVEC>(arow[p], acol[p], ((BM * KQ) % 256 == 0 || f < BM * KQ) && cidx(acol[p]) < kend, ma[p]);
+                la.col_advance(acol[p], BK);
             } else {
-                const int kr = f / (BM / 4), cq = f - kr * (BM / 4);
-                const bool en = kr < BK && k0 + kr < kend;
-                ra[p] = la.template load<ALLVEC>(la.row(en ? k0 + kr : 0), i0 + cq * 4, en, ma[p]);
+                const int kr = f / (BM / 4);
+                ra[p] = la.template load<ALLVEC>(arow[p], acol[p], (((BM / 4) * BK) % 256 == 0 || kr < BK) && arow[p].r < kend, ma[p]);
+                la.row_advance(arow[p], BK);
             }
         }
 #pragma unroll
         for (int p = 0; p < NLB; ++p) {
             const int f = tid + p * 256;
             if (B_KC) {
-                const int k = k0 + (f % KQ) * 4;
-                rb[p] = lb.template load<ALLVEC>(brow[p], k, f < BN * KQ && k < kend, mb[p]);
+                rb[p] = lb.template load<ALLVEC>(brow[p], bcol[p], ((BN * KQ) % 256 == 0 || f < BN * KQ) && cidx(bcol[p]) < kend, mb[p]);
+                lb.col_advance(bcol[p], BK);
             } else {
-                const int kr = f / (BN / 4), cq = f - kr * (BN / 4);
-                const bool en = kr < BK && k0 + kr < kend;
-                rb[p] = lb.template load<ALLVEC>(lb.row(en ? k0 + kr : 0), j0 + cq * 4, en, mb[p]);
+                const int kr = f / (BN / 4);
+                rb[p] = lb.template load<ALLVEC>(brow[p], bcol[p], (((BN / 4) * BK) % 256 == 0 || kr < BK) && brow[p].r < kend, mb[p]);
+                lb.row_advance(brow[p], BK);
             }
         }
     };
@@ -426,20 +480,22 @@ __device__ __forceinline__ void gemm_tile(LA& la, LB& lb, const GemmEpi& ep, int
             __syncthreads();
         }
         if (nkt > nfast) {
-            fetch(kbeg + nfast * BK);
+            gen_seek(kbeg + nfast * BK);
+            fetch();
             stash(nfast & 1);
             __syncthreads();
             compute(nfast & 1);
         }
     } else {
+        gen_seek(kbeg);
         if (nkt > 0) {
-            fetch(kbeg);
+            fetch();
             stash(0);
         }
         __syncthreads();
         for (int kt = 0; kt < nkt; ++kt) {       // branch-free body: past the last tile every validity bit is 0 (zeros into the idle buffer)
             const int cur = kt & 1;
-            fetch(kbeg + (kt + 1) * BK);
+            fetch();
             compute(cur);
             stash(cur ^ 1);
             __syncthreads();
