@@ -96,7 +96,8 @@ template <int V> struct MaskSumF {  // dy * [y > 0] (bias gradient behind a fuse
 };
 
 template <int V, int NACC, class F>
-__global__ void __launch_bounds__(256) colreduce_kernel(F f, int rows_per_seg, int C, int CTV, int rows_per_chunk, float* __restrict__ ws) {
+__global__ void __launch_bounds__(256) colreduce_kernel(F f, int rows_per_seg, int C, int CTV, int rows_per_chunk, float* __restrict__ ws, int atomic,
+                                                        float scale) {
     __shared__ __attribute__((aligned(16))) float red[NACC][256][V];
     const int tid = threadIdx.x;
     const int rpp = 256 / CTV;
@@ -137,16 +138,26 @@ __global__ void __launch_bounds__(256) colreduce_kernel(F f, int rows_per_seg, i
             for (int j = 0; j < rpp; ++j)
 #pragma unroll
                 for (int i = 0; i < V; ++i) t.v[i] += red[a][j * CTV + cq][i];
-            stv<V>(ws + (((long)seg * nch + chunk) * NACC + a) * C + c, t);
+            if (atomic == 2) {   // fp64 accumulators (BatchNorm statistics: the variance is a difference of two large sums)
+                double* wd = reinterpret_cast<double*>(ws);
+#pragma unroll
+                for (int i = 0; i < V; ++i) atomicAdd(wd + ((long)seg * NACC + a) * C + c + i, (double)t.v[i]);
+            } else if (atomic) {   // ws = accumulators [seg][NACC][C] (zeroed, or a gradient being accumulated): no partials, no finalize pass
+#pragma unroll
+                for (int i = 0; i < V; ++i) atomicAdd(ws + ((long)seg * NACC + a) * C + c + i, t.v[i] * scale);
+            } else {
+                stv<V>(ws + (((long)seg * nch + chunk) * NACC + a) * C + c, t);
+            }
         }
     }
 }
 
 template <int NACC, class F4, class F1>
-inline void launch_reduce(const RedPlan& p, const F4& f4, const F1& f1, int rows_per_seg, int C, int nseg, float* ws, void* stream) {
+inline void launch_reduce(const RedPlan& p, const F4& f4, const F1& f1, int rows_per_seg, int C, int nseg, float* ws, void* stream, int atomic = 0,
+                          float scale = 1.f) {
     dim3 grid(p.coltiles, p.nchunks, nseg);
-    if (p.V == 4) TF_LAUNCH((colreduce_kernel<4, NACC, F4>), grid, dim3(256), stream, f4, rows_per_seg, C, p.CTV, p.rows_per_chunk, ws);
-    else TF_LAUNCH((colreduce_kernel<1, NACC, F1>), grid, dim3(256), stream, f1, rows_per_seg, C, p.CTV, p.rows_per_chunk, ws);
+    if (p.V == 4) TF_LAUNCH((colreduce_kernel<4, NACC, F4>), grid, dim3(256), stream, f4, rows_per_seg, C, p.CTV, p.rows_per_chunk, ws, atomic, scale);
+    else TF_LAUNCH((colreduce_kernel<1, NACC, F1>), grid, dim3(256), stream, f1, rows_per_seg, C, p.CTV, p.rows_per_chunk, ws, atomic, scale);
 }
 
 // ---- finalize kernels: one wave per channel, lanes sum the chunk partials (was: one thread per channel
@@ -270,6 +281,93 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restri
         stv<V>(dx + i * V, a);
     }
 }
+// ---- single-pass-after-reduce BatchNorm: the statistics were ACCUMULATED with atomics into acc = [S1 | S2] (2*C floats), so there is
+// no finalize kernel: threads own a fixed channel group (the colreduce thread layout), derive its scale / shift from the sums once,
+// then stream their rows.  The chunk-0 block of every column tile also writes save_mean / save_invstd and the running statistics.
+template <int V>
+__global__ void __launch_bounds__(256) bn_apply_cols_kernel(const float* __restrict__ x, const double* __restrict__ acc, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
+                                                            float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                                            const float* __restrict__ res, float* __restrict__ y, int rows, int C, int CTV,
+                                                            int rows_per_chunk, float n, float momentum, float eps, int relu) {
+    const int tid = threadIdx.x, rpp = 256 / CTV, cq = tid % CTV, rl = tid / CTV;
+    if (rl >= rpp) return;
+    const int c = (blockIdx.x * CTV + cq) * V;
+    vecf<V> sc, sh;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        const double dmd = acc[c + i] / (double)n;
+        const float dm = (float)dmd;
+        const float mean = x[c + i] + dm;               // shift K = first row of x (same as BnStatF)
+        float var = (float)(acc[C + c + i] / (double)n - dmd * dmd);
+        if (var < 0.f) var = 0.f;
+        const float invstd = 1.0f / sqrtf(var + eps);
+        sc.v[i] = gamma[c + i] * invstd;
+        sh.v[i] = beta[c + i] - mean * sc.v[i];
+        if (blockIdx.y == 0 && rl == 0) {
+            save_mean[c + i] = mean;
+            save_invstd[c + i] = invstd;
+            if (rmean) {
+                rmean[c + i] = (1.f - momentum) * rmean[c + i] + momentum * mean;
+                const float unb = (n > 1.f) ? var * (n / (n - 1.f)) : var;
+                rvar[c + i] = (1.f - momentum) * rvar[c + i] + momentum * unb;
+            }
+        }
+    }
+    const int r0 = blockIdx.y * rows_per_chunk;
+    int r1 = r0 + rows_per_chunk;
+    if (r1 > rows) r1 = rows;
+    for (int r = r0 + rl; r < r1; r += rpp) {
+        const long o = (long)r * C + c;
+        vecf<V> a = ldv<V>(x + o), rr;
+        if (res) rr = ldv<V>(res + o);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            float v = a.v[k] * sc.v[k] + sh.v[k];
+            if (res) v += rr.v[k];
+            if (relu) v = fmaxf(v, 0.f);
+            a.v[k] = v;
+        }
+        stv<V>(y + o, a);
+    }
+}
+// acc = [sum g | sum g*xhat]; dx = A*g + Bc*x + Cc; dgamma += sum g*xhat, dbeta += sum g (chunk-0 blocks)
+template <int V>
+__global__ void __launch_bounds__(256) bn_bwd_apply_cols_kernel(const float* __restrict__ dz, const float* __restrict__ z, const float* __restrict__ x,
+                                                                const double* __restrict__ acc, const float* __restrict__ gamma,
+                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dx,
+                                                                float* __restrict__ dres, int rows, int C, int CTV, int rows_per_chunk, float n) {
+    const int tid = threadIdx.x, rpp = 256 / CTV, cq = tid % CTV, rl = tid / CTV;
+    if (rl >= rpp) return;
+    const int c = (blockIdx.x * CTV + cq) * V;
+    vecf<V> A, Bc, Cc;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        const float sg = (float)acc[c + i], sgx = (float)acc[C + c + i];
+        A.v[i] = gamma[c + i] * invstd[c + i];
+        Bc.v[i] = -A.v[i] * invstd[c + i] * (sgx / n);
+        Cc.v[i] = -A.v[i] * (sg / n) - Bc.v[i] * mean[c + i];
+        if (blockIdx.y == 0 && rl == 0) {
+            if (dgamma) dgamma[c + i] += sgx;
+            if (dbeta) dbeta[c + i] += sg;
+        }
+    }
+    const int r0 = blockIdx.y * rows_per_chunk;
+    int r1 = r0 + rows_per_chunk;
+    if (r1 > rows) r1 = rows;
+    for (int r = r0 + rl; r < r1; r += rpp) {
+        const long o = (long)r * C + c;
+        vecf<V> g = ldv<V>(dz + o), a = ldv<V>(x + o);
+        if (z) { vecf<V> zz = ldv<V>(z + o);
+#pragma unroll
+            for (int k = 0; k < V; ++k) if (!(zz.v[k] > 0.f)) g.v[k] = 0.f; }
+        if (dres) stv<V>(dres + o, g);
+#pragma unroll
+        for (int k = 0; k < V; ++k) a.v[k] = A.v[k] * g.v[k] + Bc.v[k] * a.v[k] + Cc.v[k];
+        stv<V>(dx + o, a);
+    }
+}
 // y = x * sigmoid(gate[b][c])
 template <int V>
 __global__ void __launch_bounds__(256) se_scale_kernel(const float* __restrict__ x, const float* __restrict__ gate, float* __restrict__ y, long nvec,
@@ -327,9 +425,23 @@ extern "C" long tf_workspace_bytes(void) { return kWsFloats * 4; }
 // eval: running statistics.  y = bn(x) (+res) (relu).  ws: tf_workspace_bytes() scratch.
 extern "C" int tf_bn_fwd_f32(const float* x, int rows, int C, const float* gamma, const float* beta, float* running_mean, float* running_var,
                              float momentum, float eps, const float* res, int relu, float* y, float* save_mean, float* save_invstd, float* ws,
-                             int training, void* stream) {
+                             int training, double* zacc, void* stream) {
     TF_REQUIRE(x && gamma && beta && y && ws && rows > 0 && C > 0, "tf_bn_fwd_f32: bad arguments");
     float* coef = ws + kWsFloats / 2;
+    if (training && zacc) {   // 2 launches: atomically accumulated statistics, then a column-owned normalise pass (no finalize kernel)
+        TF_REQUIRE(save_mean && save_invstd, "tf_bn_fwd_f32: training needs save_mean/save_invstd");
+        const bool v4ok = aligned16(x) && aligned16(y) && (!res || aligned16(res));
+        RedPlan p = plan_reduce(rows, C, 1, 2, v4ok);
+        BnStatF<4> f4{x, x, C};
+        BnStatF<1> f1{x, x, C};
+        launch_reduce<2>(p, f4, f1, rows, C, 1, reinterpret_cast<float*>(zacc), stream, 2, 1.f);
+        dim3 grid(p.coltiles, p.nchunks);
+        if (p.V == 4) TF_LAUNCH(bn_apply_cols_kernel<4>, grid, dim3(256), stream, x, (const double*)zacc, gamma, beta, running_mean, running_var, save_mean,
+                                save_invstd, res, y, rows, C, p.CTV, p.rows_per_chunk, (float)rows, momentum, eps, relu);
+        else TF_LAUNCH(bn_apply_cols_kernel<1>, grid, dim3(256), stream, x, (const double*)zacc, gamma, beta, running_mean, running_var, save_mean,
+                       save_invstd, res, y, rows, C, p.CTV, p.rows_per_chunk, (float)rows, momentum, eps, relu);
+        return launch_status("tf_bn_fwd_f32");
+    }
     if (training) {
         TF_REQUIRE(save_mean && save_invstd, "tf_bn_fwd_f32: training needs save_mean/save_invstd");
         RedPlan p = plan_reduce(rows, C, 1, 2);
@@ -353,12 +465,22 @@ extern "C" int tf_bn_fwd_f32(const float* x, int rows, int C, const float* gamma
 // BatchNorm2d backward (training statistics).  dz: grad of the (post-residual, post-ReLU) output;
 // z: that output when a ReLU followed (mask) else NULL.  dgamma/dbeta are ACCUMULATED.
 extern "C" int tf_bn_bwd_f32(const float* dz, const float* z, const float* x, int rows, int C, const float* gamma, const float* save_mean,
-                             const float* save_invstd, float* dx, float* dres, float* dgamma, float* dbeta, float* ws, void* stream) {
+                             const float* save_invstd, float* dx, float* dres, float* dgamma, float* dbeta, float* ws, double* zacc, void* stream) {
     TF_REQUIRE(dz && x && gamma && save_mean && save_invstd && dx && ws && rows > 0 && C > 0, "tf_bn_bwd_f32: bad arguments");
     float* coef = ws + kWsFloats / 2;
-    RedPlan p = plan_reduce(rows, C, 1, 2);
+    const bool v4ok = aligned16(dz) && aligned16(x) && aligned16(dx) && (!z || aligned16(z)) && (!dres || aligned16(dres));
+    RedPlan p = plan_reduce(rows, C, 1, 2, zacc ? v4ok : true);
     BnBwdF<4> f4{dz, z, x, save_mean, save_invstd, C};
     BnBwdF<1> f1{dz, z, x, save_mean, save_invstd, C};
+    if (zacc) {
+        launch_reduce<2>(p, f4, f1, rows, C, 1, reinterpret_cast<float*>(zacc), stream, 2, 1.f);
+        dim3 grid(p.coltiles, p.nchunks);
+        if (p.V == 4) TF_LAUNCH(bn_bwd_apply_cols_kernel<4>, grid, dim3(256), stream, dz, z, x, (const double*)zacc, gamma, save_mean, save_invstd, dgamma,
+                                dbeta, dx, dres, rows, C, p.CTV, p.rows_per_chunk, (float)rows);
+        else TF_LAUNCH(bn_bwd_apply_cols_kernel<1>, grid, dim3(256), stream, dz, z, x, (const double*)zacc, gamma, save_mean, save_invstd, dgamma, dbeta, dx,
+                       dres, rows, C, p.CTV, p.rows_per_chunk, (float)rows);
+        return launch_status("tf_bn_bwd_f32");
+    }
     launch_reduce<2>(p, f4, f1, rows, C, 1, ws, stream);
     TF_LAUNCH(bn_bwd_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), stream, (const float*)ws, gamma, save_mean, save_invstd, dgamma, dbeta, coef,
               C, p.nchunks, (float)rows);
@@ -377,6 +499,10 @@ extern "C" int tf_colsum_f32(const float* x, const float* mask, int nseg, int ro
     RedPlan p = plan_reduce(rows_per_seg, C, nseg, 1, aligned16(x) && (!mask || aligned16(mask)));
     MaskSumF<4> f4{x, mask, C};
     MaskSumF<1> f1{x, mask, C};
+    if (accumulate) {   // += : the blocks add straight into the destination with fp32 atomics - one launch, no partials, no finalize
+        launch_reduce<1>(p, f4, f1, rows_per_seg, C, nseg, out, stream, 1, scale);
+        return launch_status("tf_colsum_f32");
+    }
     launch_reduce<1>(p, f4, f1, rows_per_seg, C, nseg, ws, stream);
     TF_LAUNCH(colsum_finalize_kernel, dim3(cdiv((long)nseg * C, 4)), dim3(256), stream, (const float*)ws, out, C, p.nchunks, nseg, scale, accumulate);
     return launch_status("tf_colsum_f32");

@@ -258,6 +258,35 @@ def softmax_bwd_(p, dp, rows, n, ld):
     return dp
 
 
+# ---- zero arena: a device buffer cleared ONCE per training step (zero_scratch_reset, called by LidarCenterNet.forward) from which
+# kernels that accumulate with atomics (BatchNorm statistics, SE squeeze) take pre-zeroed slices - instead of one memset / finalize
+# launch each.  Slices stay valid until the next reset (the next forward); when the pool runs dry a fresh torch.zeros is returned.
+_zpool = {}
+_DBG_LEGACY_BN = bool(int(__import__('os').environ.get('TF_LEGACY_BN', '0')))
+_DBG_LEGACY_BNB = bool(int(__import__('os').environ.get('TF_LEGACY_BNB', '0')))
+_ZPOOL_FLOATS = 4 << 20
+
+
+def zero_scratch_reset(device):
+    key = str(device)
+    st = _zpool.get(key)
+    if st is None:
+        st = _zpool[key] = [torch.zeros(_ZPOOL_FLOATS, dtype=torch.float32, device=device), 0]
+    else:
+        st[0].zero_()
+        st[1] = 0
+
+
+def zero_scratch(n, device):
+    st = _zpool.get(str(device))
+    n4 = (n + 3) // 4 * 4
+    if st is None or st[1] + n4 > _ZPOOL_FLOATS:
+        return torch.zeros(n, dtype=torch.float32, device=device)
+    out = st[0][st[1]:st[1] + n]
+    st[1] += n4
+    return out
+
+
 def bn_fwd(x, gamma, beta, rmean, rvar, res=None, relu=False, training=True, momentum=0.1, eps=1e-5):
     """x: (..., C) NHWC; returns (y, save_mean, save_invstd)."""
     C = x.shape[-1]
@@ -265,8 +294,10 @@ def bn_fwd(x, gamma, beta, rmean, rvar, res=None, relu=False, training=True, mom
     y = torch.empty_like(x)
     sm = torch.empty(C, dtype=torch.float32, device=x.device)
     si = torch.empty_like(sm)
+    zacc = zero_scratch(4 * C, x.device) if training and not _DBG_LEGACY_BN else None   # 2*C doubles
     check(L().tf_bn_fwd_f32(ptr(_c(x)), rows, C, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), ctypes.c_float(momentum), ctypes.c_float(eps),
-                            ptr(res), int(relu), ptr(y), ptr(sm), ptr(si), ptr(workspace(x.device)), int(training), stream_of(x)), "tf_bn_fwd_f32")
+                            ptr(res), int(relu), ptr(y), ptr(sm), ptr(si), ptr(workspace(x.device)), int(training), ptr(zacc), stream_of(x)),
+          "tf_bn_fwd_f32")
     return y, sm, si
 
 
@@ -275,14 +306,20 @@ def bn_bwd(dz, z, x, gamma, sm, si, dgamma, dbeta, want_dres=False):
     rows = x.numel() // C
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if want_dres else None
+    zacc = zero_scratch(4 * C, x.device) if not _DBG_LEGACY_BNB else None
     check(L().tf_bn_bwd_f32(ptr(_c(dz)), ptr(z), ptr(_c(x)), rows, C, ptr(gamma), ptr(sm), ptr(si), ptr(dx), ptr(dres), ptr(dgamma), ptr(dbeta),
-                            ptr(workspace(x.device)), stream_of(x)), "tf_bn_bwd_f32")
+                            ptr(workspace(x.device)), ptr(zacc), stream_of(x)), "tf_bn_bwd_f32")
     return dx, dres
 
 
-def colsum(x, nseg, rows_per_seg, C, scale=1.0, mask=None, out=None, accumulate=False):
+def colsum(x, nseg, rows_per_seg, C, scale=1.0, mask=None, out=None, accumulate=False, pooled=False):
+    """pooled=True (internal temporaries only): the result lives in a zero-arena slice and is produced by ONE atomically accumulating
+    launch; it is valid until the next LidarCenterNet.forward."""
     if out is None:
-        out = torch.empty(nseg, C, dtype=torch.float32, device=x.device)
+        if pooled:
+            out, accumulate = zero_scratch(nseg * C, x.device).view(nseg, C), True
+        else:
+            out = torch.empty(nseg, C, dtype=torch.float32, device=x.device)
     check(L().tf_colsum_f32(ptr(_c(x)), ptr(mask), nseg, rows_per_seg, C, ctypes.c_float(scale), ptr(out), int(accumulate),
                             ptr(workspace(x.device)), stream_of(x)), "tf_colsum_f32")
     return out
