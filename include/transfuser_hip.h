@@ -90,14 +90,15 @@ int tf_softmax_bwd_f32(const float* p, float* dp, int rows, int n, int ld, void*
 long tf_workspace_bytes(void);
 /* timm BatchNormAct2d on NHWC (rows = B*H*W): y = bn(x) (+res) (relu); training uses batch statistics
  * and updates the running buffers (momentum, unbiased var).  bwd accumulates dgamma/dbeta.
- * zacc: optional 2*C DOUBLES that the CALLER has zeroed (e.g. a slice of a scratch arena cleared once per step): the statistics are then
- * accumulated there with fp64 atomics and folded into the normalise pass - 2 launches instead of 3.  NULL: partials in ws + a
+ * zacc: optional tf_bn_zacc_floats(C) floats that the CALLER has zeroed (e.g. a slice of a scratch arena cleared once per step): the statistics are then
+ * accumulated there with fp32 atomics (16 copies, added up in fp64) and folded into the normalise pass - 2 launches instead of 3.  NULL: partials in ws + a
  * finalize kernel (bit-reproducible summation order). */
 int tf_bn_fwd_f32(const float* x, int rows, int C, const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
-                  float eps, const float* res, int relu, float* y, float* save_mean, float* save_invstd, float* ws, int training, double* zacc,
+                  float eps, const float* res, int relu, float* y, float* save_mean, float* save_invstd, float* ws, int training, float* zacc,
                   void* stream);
+int tf_bn_zacc_floats(int C);
 int tf_bn_bwd_f32(const float* dz, const float* z, const float* x, int rows, int C, const float* gamma, const float* save_mean, const float* save_invstd,
-                  float* dx, float* dres, float* dgamma, float* dbeta, float* ws, double* zacc, void* stream);
+                  float* dx, float* dres, float* dgamma, float* dbeta, float* ws, float* zacc, void* stream);
 /* out[seg][c] (+)= scale * sum_rows x (* [mask > 0]): SE squeeze / global average pool
  * (transfuser.py:203-205), bias gradients, pos_emb gradient. */
 int tf_colsum_f32(const float* x, const float* mask, int nseg, int rows_per_seg, int C, float scale, float* out, int accumulate, float* ws, void* stream);

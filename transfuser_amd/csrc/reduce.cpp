@@ -6,6 +6,7 @@
 // wave reads whole contiguous row segments (coalesced float4), accumulates in registers,
 // combines its row lanes through LDS and writes ONE partial per (chunk, column) to a workspace;
 // a tiny finalize kernel sums the chunk partials in a fixed order (deterministic, no atomics).
+#include <cstdlib>
 #include "tf_common.h"
 #include "../../include/transfuser_hip.h"
 
@@ -25,6 +26,7 @@ template <int V> __device__ __forceinline__ void stv(float* p, const vecf<V>& a)
     else *p = a.v[0];
 }
 
+constexpr int kBnSlots = 16;    // accumulator copies of the atomically accumulated BatchNorm statistics
 constexpr int kMaxChunks = 512;   // finalize is wave-parallel over chunks, so many small partials are cheap
 constexpr long kWsFloats = 4L << 20;  // 16 MiB workspace (floats), see tf_workspace_bytes()
 
@@ -138,10 +140,12 @@ __global__ void __launch_bounds__(256) colreduce_kernel(F f, int rows_per_seg, i
             for (int j = 0; j < rpp; ++j)
 #pragma unroll
                 for (int i = 0; i < V; ++i) t.v[i] += red[a][j * CTV + cq][i];
-            if (atomic == 2) {   // fp64 accumulators (BatchNorm statistics: the variance is a difference of two large sums)
-                double* wd = reinterpret_cast<double*>(ws);
+            if (atomic == 2) {   // BatchNorm statistics: kBnSlots accumulator copies [slot][NACC][C] (the consumer adds them up in fp64) -
+                                 // same-address atomics serialise in the memory-side atomic unit, and <= nchunks/kBnSlots fp32 adds per
+                                 // copy keep the rounding at the level of a summation tree
+                float* wsl = ws + (long)(chunk % kBnSlots) * NACC * C;
 #pragma unroll
-                for (int i = 0; i < V; ++i) atomicAdd(wd + ((long)seg * NACC + a) * C + c + i, (double)t.v[i]);
+                for (int i = 0; i < V; ++i) atomicAdd(wsl + (long)a * C + c + i, t.v[i]);
             } else if (atomic) {   // ws = accumulators [seg][NACC][C] (zeroed, or a gradient being accumulated): no partials, no finalize pass
 #pragma unroll
                 for (int i = 0; i < V; ++i) atomicAdd(ws + ((long)seg * NACC + a) * C + c + i, t.v[i] * scale);
@@ -285,7 +289,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restri
 // no finalize kernel: threads own a fixed channel group (the colreduce thread layout), derive its scale / shift from the sums once,
 // then stream their rows.  The chunk-0 block of every column tile also writes save_mean / save_invstd and the running statistics.
 template <int V>
-__global__ void __launch_bounds__(256) bn_apply_cols_kernel(const float* __restrict__ x, const double* __restrict__ acc, const float* __restrict__ gamma,
+__global__ void __launch_bounds__(256) bn_apply_cols_kernel(const float* __restrict__ x, const float* __restrict__ acc, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
                                                             float* __restrict__ save_mean, float* __restrict__ save_invstd,
                                                             const float* __restrict__ res, float* __restrict__ y, int rows, int C, int CTV,
@@ -296,10 +300,13 @@ __global__ void __launch_bounds__(256) bn_apply_cols_kernel(const float* __restr
     vecf<V> sc, sh;
 #pragma unroll
     for (int i = 0; i < V; ++i) {
-        const double dmd = acc[c + i] / (double)n;
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int sl = 0; sl < kBnSlots; ++sl) { s1 += (double)acc[(long)sl * 2 * C + c + i]; s2 += (double)acc[(long)sl * 2 * C + C + c + i]; }
+        const double dmd = s1 / (double)n;
         const float dm = (float)dmd;
         const float mean = x[c + i] + dm;               // shift K = first row of x (same as BnStatF)
-        float var = (float)(acc[C + c + i] / (double)n - dmd * dmd);
+        float var = (float)(s2 / (double)n - dmd * dmd);
         if (var < 0.f) var = 0.f;
         const float invstd = 1.0f / sqrtf(var + eps);
         sc.v[i] = gamma[c + i] * invstd;
@@ -334,7 +341,7 @@ __global__ void __launch_bounds__(256) bn_apply_cols_kernel(const float* __restr
 // acc = [sum g | sum g*xhat]; dx = A*g + Bc*x + Cc; dgamma += sum g*xhat, dbeta += sum g (chunk-0 blocks)
 template <int V>
 __global__ void __launch_bounds__(256) bn_bwd_apply_cols_kernel(const float* __restrict__ dz, const float* __restrict__ z, const float* __restrict__ x,
-                                                                const double* __restrict__ acc, const float* __restrict__ gamma,
+                                                                const float* __restrict__ acc, const float* __restrict__ gamma,
                                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dx,
                                                                 float* __restrict__ dres, int rows, int C, int CTV, int rows_per_chunk, float n) {
@@ -344,7 +351,10 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_cols_kernel(const float* __r
     vecf<V> A, Bc, Cc;
 #pragma unroll
     for (int i = 0; i < V; ++i) {
-        const float sg = (float)acc[c + i], sgx = (float)acc[C + c + i];
+        double d1 = 0.0, d2 = 0.0;
+#pragma unroll
+        for (int sl = 0; sl < kBnSlots; ++sl) { d1 += (double)acc[(long)sl * 2 * C + c + i]; d2 += (double)acc[(long)sl * 2 * C + C + c + i]; }
+        const float sg = (float)d1, sgx = (float)d2;
         A.v[i] = gamma[c + i] * invstd[c + i];
         Bc.v[i] = -A.v[i] * invstd[c + i] * (sgx / n);
         Cc.v[i] = -A.v[i] * (sg / n) - Bc.v[i] * mean[c + i];
@@ -420,12 +430,13 @@ inline int ew_blocks(long nvec) {
 }  // namespace
 
 extern "C" long tf_workspace_bytes(void) { return kWsFloats * 4; }
+extern "C" int tf_bn_zacc_floats(int C) { return kBnSlots * 2 * C; }
 
 // BatchNorm2d forward on NHWC (rows = B*H*W).  training: batch statistics (+ running update);
 // eval: running statistics.  y = bn(x) (+res) (relu).  ws: tf_workspace_bytes() scratch.
 extern "C" int tf_bn_fwd_f32(const float* x, int rows, int C, const float* gamma, const float* beta, float* running_mean, float* running_var,
                              float momentum, float eps, const float* res, int relu, float* y, float* save_mean, float* save_invstd, float* ws,
-                             int training, double* zacc, void* stream) {
+                             int training, float* zacc, void* stream) {
     TF_REQUIRE(x && gamma && beta && y && ws && rows > 0 && C > 0, "tf_bn_fwd_f32: bad arguments");
     float* coef = ws + kWsFloats / 2;
     if (training && zacc) {   // 2 launches: atomically accumulated statistics, then a column-owned normalise pass (no finalize kernel)
@@ -434,11 +445,11 @@ extern "C" int tf_bn_fwd_f32(const float* x, int rows, int C, const float* gamma
         RedPlan p = plan_reduce(rows, C, 1, 2, v4ok);
         BnStatF<4> f4{x, x, C};
         BnStatF<1> f1{x, x, C};
-        launch_reduce<2>(p, f4, f1, rows, C, 1, reinterpret_cast<float*>(zacc), stream, 2, 1.f);
+        launch_reduce<2>(p, f4, f1, rows, C, 1, zacc, stream, 2, 1.f);
         dim3 grid(p.coltiles, p.nchunks);
-        if (p.V == 4) TF_LAUNCH(bn_apply_cols_kernel<4>, grid, dim3(256), stream, x, (const double*)zacc, gamma, beta, running_mean, running_var, save_mean,
+        if (p.V == 4) TF_LAUNCH(bn_apply_cols_kernel<4>, grid, dim3(256), stream, x, (const float*)zacc, gamma, beta, running_mean, running_var, save_mean,
                                 save_invstd, res, y, rows, C, p.CTV, p.rows_per_chunk, (float)rows, momentum, eps, relu);
-        else TF_LAUNCH(bn_apply_cols_kernel<1>, grid, dim3(256), stream, x, (const double*)zacc, gamma, beta, running_mean, running_var, save_mean,
+        else TF_LAUNCH(bn_apply_cols_kernel<1>, grid, dim3(256), stream, x, (const float*)zacc, gamma, beta, running_mean, running_var, save_mean,
                        save_invstd, res, y, rows, C, p.CTV, p.rows_per_chunk, (float)rows, momentum, eps, relu);
         return launch_status("tf_bn_fwd_f32");
     }
@@ -465,7 +476,7 @@ extern "C" int tf_bn_fwd_f32(const float* x, int rows, int C, const float* gamma
 // BatchNorm2d backward (training statistics).  dz: grad of the (post-residual, post-ReLU) output;
 // z: that output when a ReLU followed (mask) else NULL.  dgamma/dbeta are ACCUMULATED.
 extern "C" int tf_bn_bwd_f32(const float* dz, const float* z, const float* x, int rows, int C, const float* gamma, const float* save_mean,
-                             const float* save_invstd, float* dx, float* dres, float* dgamma, float* dbeta, float* ws, double* zacc, void* stream) {
+                             const float* save_invstd, float* dx, float* dres, float* dgamma, float* dbeta, float* ws, float* zacc, void* stream) {
     TF_REQUIRE(dz && x && gamma && save_mean && save_invstd && dx && ws && rows > 0 && C > 0, "tf_bn_bwd_f32: bad arguments");
     float* coef = ws + kWsFloats / 2;
     const bool v4ok = aligned16(dz) && aligned16(x) && aligned16(dx) && (!z || aligned16(z)) && (!dres || aligned16(dres));
@@ -473,11 +484,11 @@ extern "C" int tf_bn_bwd_f32(const float* dz, const float* z, const float* x, in
     BnBwdF<4> f4{dz, z, x, save_mean, save_invstd, C};
     BnBwdF<1> f1{dz, z, x, save_mean, save_invstd, C};
     if (zacc) {
-        launch_reduce<2>(p, f4, f1, rows, C, 1, reinterpret_cast<float*>(zacc), stream, 2, 1.f);
+        launch_reduce<2>(p, f4, f1, rows, C, 1, zacc, stream, 2, 1.f);
         dim3 grid(p.coltiles, p.nchunks);
-        if (p.V == 4) TF_LAUNCH(bn_bwd_apply_cols_kernel<4>, grid, dim3(256), stream, dz, z, x, (const double*)zacc, gamma, save_mean, save_invstd, dgamma,
+        if (p.V == 4) TF_LAUNCH(bn_bwd_apply_cols_kernel<4>, grid, dim3(256), stream, dz, z, x, (const float*)zacc, gamma, save_mean, save_invstd, dgamma,
                                 dbeta, dx, dres, rows, C, p.CTV, p.rows_per_chunk, (float)rows);
-        else TF_LAUNCH(bn_bwd_apply_cols_kernel<1>, grid, dim3(256), stream, dz, z, x, (const double*)zacc, gamma, save_mean, save_invstd, dgamma, dbeta, dx,
+        else TF_LAUNCH(bn_bwd_apply_cols_kernel<1>, grid, dim3(256), stream, dz, z, x, (const float*)zacc, gamma, save_mean, save_invstd, dgamma, dbeta, dx,
                        dres, rows, C, p.CTV, p.rows_per_chunk, (float)rows);
         return launch_status("tf_bn_bwd_f32");
     }
@@ -499,7 +510,8 @@ extern "C" int tf_colsum_f32(const float* x, const float* mask, int nseg, int ro
     RedPlan p = plan_reduce(rows_per_seg, C, nseg, 1, aligned16(x) && (!mask || aligned16(mask)));
     MaskSumF<4> f4{x, mask, C};
     MaskSumF<1> f1{x, mask, C};
-    if (accumulate) {   // += : the blocks add straight into the destination with fp32 atomics - one launch, no partials, no finalize
+    static const bool atomic_colsum = [] { const char* e = getenv("TF_ATOMIC_COLSUM"); return e ? e[0] != '0' : false; }();   // measured slower on the MI355X (165.4 vs 167.1 samples/s): opt-in
+    if (accumulate && atomic_colsum) {   // += : the blocks add straight into the destination with fp32 atomics - one launch, no partials, no finalize
         launch_reduce<1>(p, f4, f1, rows_per_seg, C, nseg, out, stream, 1, scale);
         return launch_status("tf_colsum_f32");
     }

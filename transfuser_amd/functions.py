@@ -76,7 +76,7 @@ class YBlockFn(torch.autograd.Function):
         y2 = ops.conv_fwd(z1, blk.conv2.conv.weight, None, blk.stride, 1, blk.groups)
         z2, st2 = _bn(y2, blk.conv2.bn, relu=True)
         _, Ho, Wo, _ = y2.shape
-        s = ops.colsum(z2, B, Ho * Wo, C, 1.0 / (Ho * Wo), pooled=True)
+        s = ops.colsum(z2, B, Ho * Wo, C, 1.0 / (Ho * Wo))
         if B <= 16:
             g1, gate = ops.se_excite_fwd(s, blk.se.fc1.weight, blk.se.fc1.bias, blk.se.fc2.weight, blk.se.fc2.bias)
         else:

@@ -154,7 +154,8 @@ class LidarCenterNet(nn.Module):
     def forward(self, rgb, lidar_bev, ego_waypoint, target_point, target_point_image, ego_vel, bev, label, depth, semantic,
                 num_points=None, save_path=None, bev_points=None, cam_points=None):
         cfg = self.config
-        ops.zero_scratch_reset(rgb.device)   # one memset per step for every atomically accumulated statistic (ops.zero_scratch)
+        if ops.uses_zero_arena():
+            ops.zero_scratch_reset(rgb.device)   # one memset per step for every atomically accumulated statistic (opt-in experiment)
         extra = target_point_image if self.use_target_point_image else None
         kw = dict(lidar_extra=extra)
         if self.use_point_pillars:   # model.py:736-742: lidar_bev is the raw cloud (B, N, 4); pillars -> rot90 -> cat target point

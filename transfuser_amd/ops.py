@@ -262,9 +262,15 @@ def softmax_bwd_(p, dp, rows, n, ld):
 # kernels that accumulate with atomics (BatchNorm statistics, SE squeeze) take pre-zeroed slices - instead of one memset / finalize
 # launch each.  Slices stay valid until the next reset (the next forward); when the pool runs dry a fresh torch.zeros is returned.
 _zpool = {}
-_DBG_LEGACY_BN = bool(int(__import__('os').environ.get('TF_LEGACY_BN', '0')))
-_DBG_LEGACY_BNB = bool(int(__import__('os').environ.get('TF_LEGACY_BNB', '0')))
-_ZPOOL_FLOATS = 4 << 20
+# Measured on the MI355X: accumulating the BatchNorm statistics with atomics (tf_bn_*_f32 zacc != NULL; 2 launches per BN instead of 3)
+# is SLOWER than partials + a finalize kernel (64.6 vs 60.0 ms/step): same-address atomics serialise.  Kept selectable for experiments.
+_DBG_LEGACY_BN = not bool(int(__import__('os').environ.get('TF_ATOMIC_BN', '0')))
+_DBG_LEGACY_BNB = _DBG_LEGACY_BN
+_ZPOOL_FLOATS = 8 << 20
+
+
+def uses_zero_arena():
+    return not _DBG_LEGACY_BN
 
 
 def zero_scratch_reset(device):
@@ -294,7 +300,7 @@ def bn_fwd(x, gamma, beta, rmean, rvar, res=None, relu=False, training=True, mom
     y = torch.empty_like(x)
     sm = torch.empty(C, dtype=torch.float32, device=x.device)
     si = torch.empty_like(sm)
-    zacc = zero_scratch(4 * C, x.device) if training and not _DBG_LEGACY_BN else None   # 2*C doubles
+    zacc = zero_scratch(32 * C, x.device) if training and not _DBG_LEGACY_BN else None   # tf_bn_zacc_floats(C)
     check(L().tf_bn_fwd_f32(ptr(_c(x)), rows, C, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), ctypes.c_float(momentum), ctypes.c_float(eps),
                             ptr(res), int(relu), ptr(y), ptr(sm), ptr(si), ptr(workspace(x.device)), int(training), ptr(zacc), stream_of(x)),
           "tf_bn_fwd_f32")
@@ -306,7 +312,7 @@ def bn_bwd(dz, z, x, gamma, sm, si, dgamma, dbeta, want_dres=False):
     rows = x.numel() // C
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if want_dres else None
-    zacc = zero_scratch(4 * C, x.device) if not _DBG_LEGACY_BNB else None
+    zacc = zero_scratch(32 * C, x.device) if not _DBG_LEGACY_BNB else None
     check(L().tf_bn_bwd_f32(ptr(_c(dz)), ptr(z), ptr(_c(x)), rows, C, ptr(gamma), ptr(sm), ptr(si), ptr(dx), ptr(dres), ptr(dgamma), ptr(dbeta),
                             ptr(workspace(x.device)), ptr(zacc), stream_of(x)), "tf_bn_bwd_f32")
     return dx, dres
