@@ -244,7 +244,9 @@ def check_pool_tokens(dev, B, H, W, C, oh, ow):
 
 BILINEAR_CASES = [(2, 12, 5, 22, 40, 176, False, False), (2, 8, 8, 8, 64, 64, False, False), (1, 6, 5, 22, 64, 176, False, False),
                   (2, 4, 8, 8, 16, 16, True, False), (1, 3, 16, 16, 40, 40, True, True), (2, 8, 5, 22, 5, 22, False, False),
-                  (1, 5, 8, 22, 16, 44, False, False), (2, 6, 5, 22, 1, 2, False, False), (1, 4, 9, 7, 4, 5, True, True)]
+                  (1, 5, 8, 22, 16, 44, False, False), (2, 6, 5, 22, 1, 2, False, False), (1, 4, 9, 7, 4, 5, True, True),
+                  (2, 8, 8, 22, 64, 176, True, False), (1, 32, 16, 44, 64, 176, True, False), (2, 8, 5, 22, 40, 176, True, False),
+                  (1, 12, 16, 16, 40, 40, True, True), (2, 4, 3, 5, 30, 50, True, False)]
 
 
 def check_bilinear(dev, B, C, Hi, Wi, Ho, Wo, in_nhwc, align):
