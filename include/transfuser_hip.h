@@ -66,6 +66,15 @@ int tf_conv2d_fwd_f32(const tf_conv_geom* g, const float* x, const float* w, con
 int tf_conv2d_dgrad_f32(const tf_conv_geom* g, const float* dy, const float* w, float* dx, int accumulate, void* stream);
 int tf_conv2d_wgrad_f32(const tf_conv_geom* g, const float* dy, const float* x, float* dw, int accumulate, void* stream);
 
+/* Direct LDS-tiled 3x3 / stride 1 / pad 1 convolutions for Cin, Cout <= 32 at large resolution (the last decoder layers,
+ * transfuser.py:232-237,267-272, and their gradients): one read of the input instead of 9 im2col reads through L2.  NHWC activations,
+ * weights (Cout, 3, 3, Cin) channels-last as everywhere.  dgrad/wgrad take the FORWARD conv's Cin / Cout.  wgrad needs
+ * tf_conv3x3_small_wgrad_ws_floats() floats of scratch. */
+int tf_conv3x3_small_fwd_f32(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Cin, int Cout, int relu, void* stream);
+int tf_conv3x3_small_dgrad_f32(const float* dy, const float* w, float* dx, int B, int H, int W, int Cin, int Cout, int accumulate, void* stream);
+long tf_conv3x3_small_wgrad_ws_floats(void);
+int tf_conv3x3_small_wgrad_f32(const float* dy, const float* x, float* dw, int B, int H, int W, int Cin, int Cout, int accumulate, float* ws, void* stream);
+
 /* Stem convolutions reading the NCHW model inputs directly (Cin <= 4, no bias, NHWC output):
  * channels [0,C0) from s0, [C0,C0+C1) from s1 - the torch.cat of model.py:741-742 is never
  * materialised; normalize != 0 folds normalize_imagenet (transfuser.py:419-428, K17) into the load.

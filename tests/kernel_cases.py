@@ -115,6 +115,31 @@ def check_conv(dev, B, Hi, Wi, Cin, Cout, ks, stride, groups):
     close(db[0], (dy * (y > 0)).sum((0, 2, 3)), what="bias grad")
 
 
+DIRECT_CONV_CASES = [(2, 10, 70, 32, 32), (1, 9, 33, 32, 7), (2, 5, 40, 32, 1), (1, 12, 64, 8, 32), (1, 4, 32, 12, 20), (3, 3, 5, 32, 32)]
+
+
+def check_conv_direct(dev, B, H, W, Cin, Cout):
+    """The LDS-tiled direct 3x3 kernels (decoder tail layers): same checks as check_conv with the size threshold lifted, plus the
+    accumulate modes of dgrad / wgrad."""
+    old = ops._DIRECT_MIN_PIXELS
+    ops._DIRECT_MIN_PIXELS = 0
+    try:
+        assert ops._direct_ok((B, H, W, Cin), Cout, Cin, 3, 1, 1, 1)
+        check_conv(dev, B, H, W, Cin, Cout, 3, 1, 1)
+        x = R(B, H, W, Cin, seed=3, dev=dev)
+        dy = R(B, H, W, Cout, seed=4, dev=dev)
+        w = cl(R(Cout, Cin, 3, 3, seed=5, dev=dev) * 0.1)
+        base_dx, base_dw = R(B, H, W, Cin, seed=6, dev=dev), cl(R(Cout, Cin, 3, 3, seed=7, dev=dev))
+        dx0 = ops.conv_dgrad(dy, w, x.shape, 1, None, 1)
+        dx1 = ops.conv_dgrad(dy, w, x.shape, 1, None, 1, out=base_dx.clone(), accumulate=True)
+        close(dx1, base_dx + dx0, what="direct dgrad accumulate")
+        dw0 = ops.conv_wgrad(dy, x, torch.zeros_like(w), 1, None, 1, accumulate=False)
+        dw1 = ops.conv_wgrad(dy, x, base_dw.clone(), 1, None, 1, accumulate=True)
+        close(dw1, base_dw + dw0, what="direct wgrad accumulate", tol=2e-5 * max(1.0, B * H * W / 500.0))
+    finally:
+        ops._DIRECT_MIN_PIXELS = old
+
+
 def check_stem(dev, B, H, W):
     rgb = torch.randint(0, 256, (B, 3, H, W), generator=torch.Generator().manual_seed(0)).float().to(dev)
     w = (R(32, 3, 3, 3, dev=dev) * 0.2).requires_grad_(True)

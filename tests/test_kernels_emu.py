@@ -107,3 +107,8 @@ def test_point_pillars(case):
 @pytest.mark.parametrize("case", kc.SE_EXCITE_CASES, ids=str)
 def test_se_excite_fused(case):
     kc.check_se_excite("cpu", *case)
+
+
+@pytest.mark.parametrize("case", kc.DIRECT_CONV_CASES, ids=str)
+def test_conv_direct_small_channels(case):
+    kc.check_conv_direct("cpu", *case)

@@ -114,3 +114,17 @@ def test_point_pillars(case):
 @pytest.mark.parametrize("case", kc.SE_EXCITE_CASES, ids=str)
 def test_se_excite_fused(case):
     kc.check_se_excite("cuda", *case)
+
+
+@pytest.mark.parametrize("case", kc.DIRECT_CONV_CASES, ids=str)
+def test_conv_direct_small_channels(case):
+    kc.check_conv_direct("cuda", *case)
+
+
+@pytest.mark.parametrize("case", [(2, 128, 352, 32, 32), (1, 256, 704, 32, 7), (3, 130, 197, 32, 1)], ids=str)
+def test_conv_direct_full_resolution(case):
+    """Decoder-tail shapes at (near) full resolution: these take the direct kernels through the normal size threshold."""
+    B, H, W, Cin, Cout = case
+    from transfuser_amd import ops
+    assert ops._direct_ok((B, H, W, Cin), Cout, Cin, 3, 1, 1, 1)
+    kc.check_conv("cuda", B, H, W, Cin, Cout, 3, 1, 1)

@@ -1,0 +1,212 @@
+// Direct (LDS-tiled) 3x3 / stride 1 / pad 1 convolutions for SMALL channel counts at LARGE resolution: the last layers of the
+// segmentation / depth decoders (transfuser.py:232-237,267-272: 32 -> 32, 32 -> 7, 32 -> 1 at 256 x 704, B = 10) and their gradients.
+//
+// Through the implicit-GEMM engine every input pixel is re-read 9x through L2 (one im2col row per tap): those launches are L2-bandwidth
+// bound (~5 TB/s, 0.4-0.8 ms each, 12 per step).  Here a block stages a (4+2) x (32+2) pixel patch (<= 32 channels) in LDS ONCE and
+// every tap reads it from there: HBM/L2 traffic drops to one read of x and one write of y.  The contraction still runs on the fp32
+// MFMA (v_mfma_f32_32x32x2_f32): per wave one row of 32 output pixels x 32 output channels (channel counts are zero-padded to 32).
+// Blocks are persistent over tiles so the 9 x 32 x 32 weight panel is staged once per block.
+#include "tf_common.h"
+#include "../../include/transfuser_hip.h"
+
+using namespace tf;
+
+namespace {
+
+constexpr int TH = 4, TW = 32;                 // output tile: 4 rows x 32 columns = 4 waves x 32 pixels
+constexpr int PH = TH + 2, PW = TW + 2;        // input patch with halo
+constexpr int PP = 33;                         // floats per patch pixel (32 channels + 1: conflict-free stride for the MFMA A fetch)
+constexpr int WP = 36;                         // pitch of a weight row (32 output channels + 4)
+constexpr int NV = (PH * PW * 8 + 255) / 256;  // float4 patch slots per thread
+
+struct DcGeom { int B, H, W, Ci, Co, tiles_h, tiles_w, ntiles; };
+
+// stage W into LDS as wl[(tap, k)][n]: fwd  wl[tap][ci][co] = Wt[co][tap][ci];  dgrad  wl[tap][co][ci] = Wt[co][8 - tap][ci]
+__device__ __forceinline__ void load_weights(float (*wl)[WP], const float* __restrict__ w, int CoW, int CiW, int dgrad) {
+    for (int i = threadIdx.x; i < 9 * 32 * 32; i += 256) {
+        const int n = i & 31, k = (i >> 5) & 31, tap = i >> 10;
+        float v = 0.f;
+        if (!dgrad) { if (n < CoW && k < CiW) v = w[((long)n * 9 + tap) * CiW + k]; }
+        else { if (k < CoW && n < CiW) v = w[((long)k * 9 + (8 - tap)) * CiW + n]; }
+        wl[tap * 32 + k][n] = v;
+    }
+}
+
+// patch slot s of this thread -> (pixel, channel quad); loads 4 channels of one patch pixel (zero outside the image / beyond Ci)
+template <bool VEC>
+__device__ __forceinline__ float4 load_patch_slot(const float* __restrict__ x, const DcGeom& g, int b, int h0, int w0, int s) {
+    const int pix = s >> 3, c = (s & 7) * 4;
+    const int ph = pix / PW, pw = pix - ph * PW;
+    const int h = h0 - 1 + ph, w = w0 - 1 + pw;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (pix < PH * PW && (unsigned)h < (unsigned)g.H && (unsigned)w < (unsigned)g.W && c < g.Ci) {
+        const float* p = x + (((long)b * g.H + h) * g.W + w) * g.Ci + c;
+        if (VEC) v = *reinterpret_cast<const float4*>(p);
+        else { v.x = p[0]; if (c + 1 < g.Ci) v.y = p[1]; if (c + 2 < g.Ci) v.z = p[2]; if (c + 3 < g.Ci) v.w = p[3]; }
+    }
+    return v;
+}
+__device__ __forceinline__ void store_patch_slot(float* patch, int s, const float4 v) {
+    const int pix = s >> 3, c = (s & 7) * 4;
+    if (pix < PH * PW) { float* q = patch + pix * PP + c; q[0] = v.x; q[1] = v.y; q[2] = v.z; q[3] = v.w; }
+}
+
+// y = conv3x3(x, W) (+bias) (relu) (+= when accumulate).  dgrad != 0: x is dY (Ci = W's Cout), y is dX (Co = W's Cin).
+template <bool VEC>
+__global__ void __launch_bounds__(256, 2) conv3x3_small_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                               float* __restrict__ y, DcGeom g, int CoW, int CiW, int dgrad, int relu, int accumulate) {
+    __shared__ float patch[PH * PW * PP];
+    __shared__ float wl[9 * 32][WP];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    load_weights(wl, w, CoW, CiW, dgrad);
+    const int kpairs = (g.Ci + 1) >> 1;          // MFMA k-steps per tap (channels padded to even with the zero-filled LDS columns)
+    int tile = blockIdx.x;
+    float4 pre[NV];
+    auto fetch = [&](int t) {
+        const int b = t / (g.tiles_h * g.tiles_w), r = t - b * (g.tiles_h * g.tiles_w);
+        const int h0 = (r / g.tiles_w) * TH, w0 = (r % g.tiles_w) * TW;
+#pragma unroll
+        for (int p = 0; p < NV; ++p) pre[p] = load_patch_slot<VEC>(x, g, b, h0, w0, tid + p * 256);
+    };
+    if (tile < g.ntiles) fetch(tile);
+    for (; tile < g.ntiles; tile += gridDim.x) {
+        __syncthreads();                           // previous tile's MFMAs are done with the patch (and the weights are staged)
+#pragma unroll
+        for (int p = 0; p < NV; ++p) store_patch_slot(patch, tid + p * 256, pre[p]);
+        __syncthreads();
+        const int nxt = tile + gridDim.x;
+        if (nxt < g.ntiles) fetch(nxt);            // next patch travels while this one is multiplied
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int tap = 0; tap < 9; ++tap) {        // (explicit operand prefetch + scheduling fences measured slower here: 463 vs 366 us)
+            const int kh = tap / 3, kw = tap - kh * 3;
+            const float* pa = patch + ((wave + kh) * PW + l31 + kw) * PP + hi;
+            const float* pb = &wl[tap * 32 + hi][l31];
+            for (int kk = 0; kk < kpairs; ++kk) mfma_32x32x2(pa[2 * kk], pb[2 * kk * WP], acc);
+        }
+        const int b = tile / (g.tiles_h * g.tiles_w), r = tile - b * (g.tiles_h * g.tiles_w);
+        const int h = (r / g.tiles_w) * TH + wave, w0 = (r % g.tiles_w) * TW;
+        if (h < g.H && l31 < g.Co) {
+            const float bj = bias ? bias[l31] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int wv = w0 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+                if (wv < g.W) {
+                    float* dst = y + (((long)b * g.H + h) * g.W + wv) * g.Co + l31;
+                    float v = acc[e] + bj;
+                    if (relu) v = fmaxf(v, 0.f);
+                    *dst = accumulate ? *dst + v : v;
+                }
+            }
+        }
+    }
+}
+
+// dW[co][tap][ci] (+)= sum_pixels dY[p][co] * X[p + tap][ci]: per wave a row of 32 pixels as the K dimension, 9 accumulators (one per
+// tap, 32 co x 32 ci); blocks are persistent, their partial panels are summed by conv3x3_small_wgrad_reduce_kernel.
+template <bool VEC>
+__global__ void __launch_bounds__(256, 1) conv3x3_small_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part,
+                                                                     DcGeom g) {
+    __shared__ float patch[PH * PW * PP];
+    __shared__ float dyt[TH * TW * PP];            // [pixel][co], co padded to 32 (+1)
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    for (int tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
+        const int b = tile / (g.tiles_h * g.tiles_w), r = tile - b * (g.tiles_h * g.tiles_w);
+        const int h0 = (r / g.tiles_w) * TH, w0 = (r % g.tiles_w) * TW;
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < NV; ++p) store_patch_slot(patch, tid + p * 256, load_patch_slot<VEC>(x, g, b, h0, w0, tid + p * 256));
+        for (int i = tid; i < TH * TW * 32; i += 256) {
+            const int co = i & 31, pix = i >> 5, ph = pix / TW, pw = pix - ph * TW;
+            const int h = h0 + ph, w = w0 + pw;
+            dyt[pix * PP + co] = (co < g.Co && h < g.H && w < g.W) ? dy[(((long)b * g.H + h) * g.W + w) * g.Co + co] : 0.f;
+        }
+        __syncthreads();
+        // K = the 32 pixels of this wave's row: A[i = co][k = pixel] = dyt, B[k = pixel][j = ci] = patch shifted by the tap
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int kh = tap / 3, kw = tap - kh * 3;
+            const float* pa = dyt + (wave * TW + hi) * PP + l31;
+            const float* pb = patch + ((wave + kh) * PW + hi + kw) * PP + l31;
+#pragma unroll 4
+            for (int kk = 0; kk < TW / 2; ++kk) mfma_32x32x2(pa[2 * kk * PP], pb[2 * kk * PP], acc[tap]);
+        }
+    }
+    // reduce the 4 waves through LDS (patch + dyt are free now), then one partial panel per block: part[block][tap][co][ci]
+    __syncthreads();
+    float* red = patch;                            // 6732 floats >= 32*32 per pass
+    for (int tap = 0; tap < 9; ++tap) {
+        for (int wv = 0; wv < 4; ++wv) {
+            if (wave == wv) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int i = (e & 3) + 8 * (e >> 2) + 4 * hi;
+                    float* q = red + i * 32 + l31;
+                    *q = (wv == 0) ? acc[tap][e] : *q + acc[tap][e];
+                }
+            }
+            __syncthreads();
+        }
+        for (int i = tid; i < 1024; i += 256) part[((long)blockIdx.x * 9 + tap) * 1024 + i] = red[i];
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(256) conv3x3_small_wgrad_reduce_kernel(const float* __restrict__ part, int nblocks, float* __restrict__ dw, int Co, int Ci,
+                                                                         int accumulate) {
+    const int i = blockIdx.x * 256 + threadIdx.x;   // (tap, co, ci) over 9 x 32 x 32
+    if (i >= 9 * 1024) return;
+    const int ci = i & 31, co = (i >> 5) & 31, tap = i >> 10;
+    if (co >= Co || ci >= Ci) return;
+    float s = 0.f;
+    for (int b = 0; b < nblocks; ++b) s += part[(long)b * 9216 + i];
+    float* d = dw + ((long)co * 9 + tap) * Ci + ci;
+    *d = accumulate ? *d + s : s;
+}
+
+inline DcGeom make_geom(int B, int H, int W, int Ci, int Co) {
+    DcGeom g; g.B = B; g.H = H; g.W = W; g.Ci = Ci; g.Co = Co;
+    g.tiles_h = cdiv(H, TH); g.tiles_w = cdiv(W, TW); g.ntiles = B * g.tiles_h * g.tiles_w;
+    return g;
+}
+
+}  // namespace
+
+extern "C" int tf_conv3x3_small_fwd_f32(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Cin, int Cout, int relu,
+                                        void* stream) {
+    TF_REQUIRE(x && w && y && B > 0 && H > 0 && W > 0 && Cin > 0 && Cin <= 32 && Cout > 0 && Cout <= 32, "tf_conv3x3_small_fwd_f32: needs Cin, Cout <= 32");
+    DcGeom g = make_geom(B, H, W, Cin, Cout);
+    const int grid = g.ntiles < 512 ? g.ntiles : 512;
+    if (Cin % 4 == 0 && aligned16(x)) TF_LAUNCH(conv3x3_small_kernel<true>, dim3(grid), dim3(256), stream, x, w, bias, y, g, Cout, Cin, 0, relu, 0);
+    else TF_LAUNCH(conv3x3_small_kernel<false>, dim3(grid), dim3(256), stream, x, w, bias, y, g, Cout, Cin, 0, relu, 0);
+    return launch_status("tf_conv3x3_small_fwd_f32");
+}
+
+extern "C" int tf_conv3x3_small_dgrad_f32(const float* dy, const float* w, float* dx, int B, int H, int W, int Cin, int Cout, int accumulate, void* stream) {
+    TF_REQUIRE(dy && w && dx && B > 0 && H > 0 && W > 0 && Cin > 0 && Cin <= 32 && Cout > 0 && Cout <= 32, "tf_conv3x3_small_dgrad_f32: needs Cin, Cout <= 32");
+    DcGeom g = make_geom(B, H, W, Cout, Cin);      // the "input" of this pass is dY (Cout channels), the output dX (Cin channels)
+    const int grid = g.ntiles < 512 ? g.ntiles : 512;
+    if (Cout % 4 == 0 && aligned16(dy)) TF_LAUNCH(conv3x3_small_kernel<true>, dim3(grid), dim3(256), stream, dy, w, (const float*)nullptr, dx, g, Cout, Cin, 1, 0, accumulate);
+    else TF_LAUNCH(conv3x3_small_kernel<false>, dim3(grid), dim3(256), stream, dy, w, (const float*)nullptr, dx, g, Cout, Cin, 1, 0, accumulate);
+    return launch_status("tf_conv3x3_small_dgrad_f32");
+}
+
+extern "C" long tf_conv3x3_small_wgrad_ws_floats(void) { return 256L * 9216; }
+
+extern "C" int tf_conv3x3_small_wgrad_f32(const float* dy, const float* x, float* dw, int B, int H, int W, int Cin, int Cout, int accumulate, float* ws,
+                                          void* stream) {
+    TF_REQUIRE(dy && x && dw && ws && B > 0 && H > 0 && W > 0 && Cin > 0 && Cin <= 32 && Cout > 0 && Cout <= 32,
+               "tf_conv3x3_small_wgrad_f32: needs Cin, Cout <= 32 and ws of tf_conv3x3_small_wgrad_ws_floats() floats");
+    DcGeom g = make_geom(B, H, W, Cin, Cout);
+    const int grid = g.ntiles < 256 ? g.ntiles : 256;
+    if (Cin % 4 == 0 && aligned16(x)) TF_LAUNCH(conv3x3_small_wgrad_kernel<true>, dim3(grid), dim3(256), stream, x, dy, ws, g);
+    else TF_LAUNCH(conv3x3_small_wgrad_kernel<false>, dim3(grid), dim3(256), stream, x, dy, ws, g);
+    TF_LAUNCH(conv3x3_small_wgrad_reduce_kernel, dim3(36), dim3(256), stream, (const float*)ws, grid, dw, Cout, Cin, accumulate);
+    return launch_status("tf_conv3x3_small_wgrad_f32");
+}

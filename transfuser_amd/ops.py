@@ -175,12 +175,30 @@ def _gflops(g):
     return 2.0 * g.B * g.Ho * g.Wo * g.Cout * (g.Cin // g.groups) * g.ksize * g.ksize
 
 
+_DIRECT_MIN_PIXELS = 1 << 16   # below this the engine's im2col path is not L2-bound and wins
+
+
+def _direct_ok(shape, cout, cin, ks, stride, pad, groups):
+    """Large-resolution 3x3/s1/p1 conv with <= 32 channels on both sides -> the LDS-tiled direct kernels (csrc/conv_direct.cpp)."""
+    B, H, W, _ = shape
+    return _DIRECT and ks == 3 and stride == 1 and pad == 1 and groups == 1 and cin <= 32 and cout <= 32 and B * H * W >= _DIRECT_MIN_PIXELS
+
+
+_DIRECT = bool(int(__import__("os").environ.get("TF_DIRECT_CONV", "1")))
+_DIRECT_WGRAD_MAX_COUT = 4   # measured (tools/conv_bench.py): the direct wgrad only beats the engine's split-K path for 1-4 output channels
+
+
 def conv_fwd(x, w, bias=None, stride=1, pad=None, groups=1, relu=False):
     ks = w.shape[2]
     pad = ks // 2 if pad is None else pad
     g = conv_geom(x.shape, w.shape[0], ks, stride, pad, groups)
     y = torch.empty(g.B, g.Ho, g.Wo, g.Cout, dtype=torch.float32, device=x.device)
     _e = _census_begin()
+    if _direct_ok(x.shape, g.Cout, g.Cin, ks, stride, pad, groups):
+        check(L().tf_conv3x3_small_fwd_f32(ptr(_c(x)), wptr(w), ptr(bias), ptr(y), g.B, g.Hi, g.Wi, g.Cin, g.Cout, int(relu), stream_of(x)),
+              "tf_conv3x3_small_fwd_f32")
+        _census_end(_e, "conv fwd*", _gshape(g), _gflops(g))
+        return y
     check(L().tf_conv2d_fwd_f32(byref(g), ptr(_c(x)), wptr(w), ptr(bias), ptr(y), int(relu), stream_of(x)), "tf_conv2d_fwd_f32")
     _census_end(_e, "conv fwd", _gshape(g), _gflops(g))
     return y
@@ -193,6 +211,11 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=None, groups=1, out=None, accumulat
     if out is None:
         out = torch.empty(tuple(x_shape), dtype=torch.float32, device=dy.device)
     _e = _census_begin()
+    if _direct_ok(x_shape, g.Cout, g.Cin, ks, stride, pad, groups):
+        check(L().tf_conv3x3_small_dgrad_f32(ptr(_c(dy)), wptr(w), ptr(_c(out)), g.B, g.Hi, g.Wi, g.Cin, g.Cout, int(accumulate), stream_of(dy)),
+              "tf_conv3x3_small_dgrad_f32")
+        _census_end(_e, "conv dgrad*", _gshape(g), _gflops(g))
+        return out
     check(L().tf_conv2d_dgrad_f32(byref(g), ptr(_c(dy)), wptr(w), ptr(_c(out)), int(accumulate), stream_of(dy)), "tf_conv2d_dgrad_f32")
     _census_end(_e, "conv dgrad", _gshape(g), _gflops(g))
     return out
@@ -203,6 +226,11 @@ def conv_wgrad(dy, x, dw, stride=1, pad=None, groups=1, accumulate=True):
     pad = ks // 2 if pad is None else pad
     g = conv_geom(x.shape, dw.shape[0], ks, stride, pad, groups)
     _e = _census_begin()
+    if _direct_ok(x.shape, g.Cout, g.Cin, ks, stride, pad, groups) and (g.Cout <= _DIRECT_WGRAD_MAX_COUT or _DIRECT_MIN_PIXELS == 0):
+        check(L().tf_conv3x3_small_wgrad_f32(ptr(_c(dy)), ptr(_c(x)), wptr(dw), g.B, g.Hi, g.Wi, g.Cin, g.Cout, int(accumulate), ptr(workspace(x.device)),
+                                             stream_of(dy)), "tf_conv3x3_small_wgrad_f32")
+        _census_end(_e, "conv wgrad*", _gshape(g), _gflops(g))
+        return dw
     check(L().tf_conv2d_wgrad_f32(byref(g), ptr(_c(dy)), ptr(_c(x)), wptr(dw), int(accumulate), stream_of(dy)), "tf_conv2d_wgrad_f32")
     _census_end(_e, "conv wgrad", _gshape(g), _gflops(g))
     return dw
