@@ -17,6 +17,7 @@
 #pragma once
 #include "tf_common.h"
 #include <type_traits>
+#include <cstdlib>
 
 namespace tf {
 
@@ -240,6 +241,7 @@ struct GemmEpi {
     const float* bias; long sbias;   // per-column bias; batch z adds z*sbias
     const float* res; long ldres;    // residual with C's batch strides
     float alpha; int relu; int mode; // mode 0: store, 1: +=, 2: atomicAdd
+    int group_m;                     // tile rasterisation: rows of tiles walked together (set by launch_cfg)
 };
 
 // ---------------------------------------------------------------- kernel
@@ -266,7 +268,17 @@ __device__ __forceinline__ void gemm_tile(LA& la, LB& lb, const GemmEpi& ep, int
         const int q = nt >> 3, r = nt & 7, xcd = bid & 7, loc = bid >> 3;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
-    const int i0 = (tile / tiles_n) * BM, j0 = (tile % tiles_n) * BN;
+    // grouped rasterisation: inside an XCD's range the tiles of group_m consecutive tile-rows are walked column by column, so the
+    // ~128 tiles resident on the XCD reuse every B panel group_m times while their group_m A panels stay in the 4 MB L2 (row-major
+    // order re-streams the whole B operand once per tile-row: 1.1 GB of fabric reads for the 47 MB GPT-4 mlp.0 operands, PMC FETCH_SIZE)
+    int tm, tn;
+    if (ep.group_m > 1) {
+        const int per = ep.group_m * tiles_n, sr = tile / per, rem = tile - sr * per;
+        int gsz = tiles_m - sr * ep.group_m;
+        gsz = gsz < ep.group_m ? gsz : ep.group_m;
+        tn = rem / gsz; tm = sr * ep.group_m + (rem - tn * gsz);
+    } else { tm = tile / tiles_n; tn = tile - tm * tiles_n; }
+    const int i0 = tm * BM, j0 = tn * BN;
     const int kbeg = blockIdx.y * kchunk;
     const int kend = (kbeg + kchunk < K) ? kbeg + kchunk : K;
     const int nkt = (kend - kbeg + BK - 1) / BK;
@@ -602,10 +614,20 @@ inline void launch_cfg(const LA& la, const LB& lb, const GemmEpi& ep, int M, int
     if (kchunk < BK) kchunk = BK;
     const int nsplit = cdiv(K, kchunk);
     dim3 grid(tiles_m * tiles_n, nsplit > 0 ? nsplit : 1, batch);
+    GemmEpi epg = ep;
+    {
+        static const int forced = [] { const char* e = getenv("TF_GROUP_M"); return e ? atoi(e) : 0; }();
+        long panel = (long)BM * (kchunk < K ? kchunk : K) * 4;          // bytes of one A panel of this launch
+        int g = (int)((2L << 20) / (panel > 0 ? panel : 1));            // as many tile-rows as keep their A panels in ~half the L2
+        if (g > 8) g = 8;
+        if (forced > 0) g = forced;
+        if (g > tiles_m) g = tiles_m;
+        epg.group_m = (g >= 2 && tiles_n >= 4) ? g : 1;
+    }
     if (la.vec && lb.vec)
-        TF_LAUNCH((gemm_kernel<BM, BN, WAVES_M, BK, LA, A_KC, LB, B_KC, true>), grid, dim3(256), stream, la, lb, ep, M, N, K, tiles_m, tiles_n, kchunk);
+        TF_LAUNCH((gemm_kernel<BM, BN, WAVES_M, BK, LA, A_KC, LB, B_KC, true>), grid, dim3(256), stream, la, lb, epg, M, N, K, tiles_m, tiles_n, kchunk);
     else
-        TF_LAUNCH((gemm_kernel<BM, BN, WAVES_M, BK, LA, A_KC, LB, B_KC, false>), grid, dim3(256), stream, la, lb, ep, M, N, K, tiles_m, tiles_n, kchunk);
+        TF_LAUNCH((gemm_kernel<BM, BN, WAVES_M, BK, LA, A_KC, LB, B_KC, false>), grid, dim3(256), stream, la, lb, epg, M, N, K, tiles_m, tiles_n, kchunk);
 }
 
 template <class LA, bool A_KC, class LB, bool B_KC>
