@@ -26,10 +26,15 @@ GFLOP_PER_SAMPLE = {160: 230.3, 256: 266.6}  # algorithmic training FLOPs (3x fo
 PEAK_F32_MFMA_TF = 157.3                     # /opt/skills/guides/MI355X_MICROARCH.md (v_mfma_f32_32x32x2_f32)
 
 
+PMC_TRAFFIC_BYTES_PER_LAUNCH = int((2 * 274137.9 + 41107.5) * 1024)   # see dominant_kernel_roofline.__doc__
+
+
 def dominant_kernel_roofline(dev, iters=20):
-    """Dominant kernel = the fp32 MFMA GEMM engine (gemm_kernel<128,128,...>); the single most expensive call of
-    the step is GPT-4's fc1 [1740 x 1512] . [1512 x 6048] (Appendix C).  Timed live with HIP events on the
-    launch stream; algorithmic FLOPs = 2*M*N*K per launch."""
+    """Dominant kernel = the fp32 MFMA GEMM engine (tf::gemm_kernel, ~70 % of the step's kernel time); its single most expensive
+    call is GPT-4's fc1 [1740 x 1512] . [1512 x 6048] (+bias+ReLU).  Timed live with HIP events on the launch stream right after
+    the sustained training loop; algorithmic FLOPs = 2*M*N*K per launch.  ``traffic``: fabric-side bytes per launch from the
+    committed PMC run of the same kernel (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE doubled per the
+    gfx950 note of MI355X_MICROARCH.md; profiles/r01_pmc_gemm_roofline.txt) - PMC counters cannot be read from inside this process."""
     from transfuser_amd import ops
     M, K, N = 1740, 1512, 6048
     x = torch.randn(M, K, device=dev)
@@ -49,7 +54,9 @@ def dominant_kernel_roofline(dev, iters=20):
     ach = flops / sec / 1e12
     return dict(bound="mfma", kernel="tf::gemm_kernel<BM,BN,WM,BK,PlainOp,KC,PlainOp,KC,vec> (autotuned tiling) on GPT4 mlp.0: [1740x1512].[1512x6048], bias+ReLU epilogue",
                 achieved=round(ach, 2), peak=PEAK_F32_MFMA_TF, unit="TFLOP/s", frac=round(ach / PEAK_F32_MFMA_TF, 4),
-                flops_per_launch=flops, avg_launch_us=round(sec * 1e6, 2), traffic=None)
+                flops_per_launch=flops, avg_launch_us=round(sec * 1e6, 2), traffic=PMC_TRAFFIC_BYTES_PER_LAUNCH,
+                traffic_source="profiles/r01_pmc_gemm_roofline.txt (2*FETCH_SIZE + WRITE_SIZE, 64x64x16 tiling; L2 fabric requests incl. Infinity-Cache hits; "
+                               "algorithmic bytes 89.2 MB)")
 
 
 def cpu_baseline(cfg_factory, H, W):
