@@ -175,6 +175,11 @@ int tf_centernet_loss_fwd_f32(const float* pred, const float* tgtf, const int32_
 int tf_centernet_loss_bwd_f32(const float* pred, const float* tgtf, const int32_t* tgti, const int32_t* cnt, const float* gup, int B, int fh, int fw,
                               int num_dir_bins, float* dpred, void* stream);
 
+/* Inference decode of the CenterNet head (model.py:436-497 decode_heatmap with mmdet's get_local_maximum /
+ * get_topk_from_heatmap / transpose_and_gather_feat): pred (B, fh, fw, 9 + bins) packed logits as in tf_centernet_loss_*,
+ * out (B, k, 8) = [x, y, w, h (already x ratio), yaw, velocity, brake (0/1), score], sorted by decreasing score. */
+int tf_centernet_decode_f32(const float* pred, int B, int fh, int fw, int num_dir_bins, int k, int kernel, float ratio, float* out, void* stream);
+
 /* ---- elementwise / recurrent / optimiser / data ----------------------------------------------- */
 int tf_relu_mask_f32(const float* dy, const float* y, float* out, int64_t n, void* stream);
 int tf_sigmoid_f32(const float* x, float* y, int64_t n, void* stream);

@@ -140,3 +140,57 @@ class LidarCenterNetHead(nn.Module):
             loss_velocity=lw['velocity'] * weight_reduce_loss((vel_p - t['velocity_target']).abs(), w1, af),
             loss_brake=lw['brake'] * weight_reduce_loss(ce(br_p, t['brake_target']), w1.float(), af),  # Q3 broadcast
         )
+
+
+# ---------------------------------------------------------------- inference decode
+def get_local_maximum(heat, kernel=3):
+    """mmdet 2.25 core/utils/gaussian_target.py: keep the cells that equal their kernel x kernel max-pool, zero the rest."""
+    pad = (kernel - 1) // 2
+    hmax = F.max_pool2d(heat, kernel, stride=1, padding=pad)
+    return heat * (hmax == heat).float()
+
+
+def get_topk_from_heatmap(scores, k=20):
+    """mmdet 2.25: top-k over (class, y, x) of every image."""
+    batch, _, height, width = scores.size()
+    topk_scores, topk_inds = torch.topk(scores.view(batch, -1), k)
+    topk_clses = topk_inds // (height * width)
+    topk_inds = topk_inds % (height * width)
+    topk_ys = topk_inds // width
+    topk_xs = (topk_inds % width).int().float()
+    return topk_scores, topk_inds, topk_clses, topk_ys, topk_xs
+
+
+def transpose_and_gather_feat(feat, ind):
+    """mmdet 2.25: (B, C, H, W) -> rows of the (B, H*W, C) view selected by ind (B, k)."""
+    feat = feat.permute(0, 2, 3, 1).contiguous()
+    feat = feat.view(feat.size(0), -1, feat.size(3))
+    return feat.gather(1, ind.unsqueeze(2).repeat(1, 1, feat.size(2)))
+
+
+def class2angle(angle_cls, angle_res, num_dir_bins):
+    """model.py:270-284."""
+    angle_per_class = 2 * np.pi / float(num_dir_bins)
+    angle = angle_cls.float() * angle_per_class + angle_res
+    angle[angle > np.pi] -= 2 * np.pi
+    return angle
+
+
+def decode_heatmap(preds, num_dir_bins, k=100, kernel=3):
+    """model.py:436-497: preds = the 7 maps of forward_single -> (B, k, 8) boxes [x, y, w, h, yaw, velocity, brake, score]."""
+    hm, wh_pred, offset_pred, yaw_class_pred, yaw_res_pred, velocity_pred, brake_pred = preds
+    hm = get_local_maximum(hm, kernel=kernel)
+    scores, index, labels, ys, xs = get_topk_from_heatmap(hm, k=k)
+    wh = transpose_and_gather_feat(wh_pred, index)
+    offset = transpose_and_gather_feat(offset_pred, index)
+    yaw_class = torch.argmax(transpose_and_gather_feat(yaw_class_pred, index), -1)
+    yaw_res = transpose_and_gather_feat(yaw_res_pred, index)
+    velocity = transpose_and_gather_feat(velocity_pred, index)[..., 0]
+    brake = torch.argmax(transpose_and_gather_feat(brake_pred, index), -1)
+    yaw = class2angle(yaw_class, yaw_res.squeeze(2), num_dir_bins)
+    xs = xs + offset[..., 0]
+    ys = ys + offset[..., 1]
+    boxes = torch.stack([xs, ys, wh[..., 0], wh[..., 1], yaw, velocity, brake], dim=2)
+    boxes = torch.cat((boxes, scores[..., None]), dim=-1)
+    boxes[:, :, :4] *= 4.
+    return boxes, labels

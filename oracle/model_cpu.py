@@ -88,6 +88,44 @@ class LidarCenterNet(nn.Module):
         return loss
 
 
+def get_lidar_to_bevimage_transform():
+    """utils.py:29-37."""
+    T = np.array([[0, -1, 16], [-1, 0, 32], [0, 0, 1]], dtype=np.float32)
+    T[:2, :] *= 8
+    return T
+
+
+def get_bbox_local_metric(bbox, config):
+    """model.py:810-843: pixels -> metres, x front / y right, 4 corners + centre + velocity arrow."""
+    x, y, w, h, yaw, speed, brake, confidence = bbox
+    w = w / config.bounding_box_divisor / config.pixels_per_meter
+    h = h / config.bounding_box_divisor / config.pixels_per_meter
+    T_inv = np.linalg.inv(get_lidar_to_bevimage_transform())
+    center = T_inv @ np.array([x, y, 1.0]) + np.array(config.lidar_pos)
+    center[1] = -center[1]
+    box = np.array([[-h, -w, 1], [-h, w, 1], [h, w, 1], [h, -w, 1], [0, 0, 1], [0, h * speed * 0.5, 1]])
+    R = np.array([[np.cos(yaw), -np.sin(yaw), 0], [np.sin(yaw), np.cos(yaw), 0], [0, 0, 1]])
+    for i in range(box.shape[0]):
+        box[i] = R @ box[i]
+        box[i] = box[i] + np.array([center[0], center[1], 0])
+    return box, brake, confidence
+
+
+def forward_ego(model, rgb, lidar_bev, target_point, target_point_image, ego_vel):
+    """LidarCenterNet.forward_ego (model.py:685-731) without the visualisation branch: (pred_wp, [(bbox (6,3), brake, confidence)])."""
+    from .centernet import decode_heatmap
+    cfg = model.config
+    if model.use_target_point_image:
+        lidar_bev = torch.cat((lidar_bev, target_point_image), dim=1)
+    features, grid, fused = model._model(rgb, lidar_bev, ego_vel)
+    pred_wp = model.forward_gru(fused, target_point)
+    preds = model.head.forward_single(features[0])
+    boxes, _ = decode_heatmap(preds, model.head.num_dir_bins, k=cfg.top_k_center_keypoints, kernel=cfg.center_net_max_pooling_kernel)
+    boxes = boxes[0]
+    boxes = boxes[boxes[:, -1] > cfg.bb_confidence_threshold]
+    return pred_wp, [get_bbox_local_metric(b, cfg) for b in boxes.detach().cpu().numpy()], boxes
+
+
 def total_loss(losses, config):
     """train.py:307-311."""
     w = dict(zip(config.detailed_losses, config.detailed_losses_weights))

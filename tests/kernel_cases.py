@@ -564,3 +564,37 @@ def check_engine_plan(dev, bm, bn, bk, splitk):
         check_stem(dev, 1, 12, 20)
     finally:
         ops.force_plan(0)
+
+
+# ---------------------------------------------------------------- inference decode
+DECODE_CASES = [(2, 64, 64, 12, 100), (1, 16, 20, 12, 30), (3, 8, 8, 4, 64)]
+
+
+def check_centernet_decode(dev, B, fh, fw, nbins, k):
+    """decode_heatmap kernel vs the oracle restatement (mmdet get_local_maximum / get_topk_from_heatmap / gather): all k rows in
+    order wherever the scores are distinct and positive; suppressed cells (score 0) can appear in any order at the tail."""
+    from oracle import centernet as oc
+    P = 9 + nbins
+    pred = R(B, fh, fw, P, dev="cpu", scale=2.0)
+    g = torch.Generator().manual_seed(11)
+    pred[..., 0] = torch.randn(B, fh, fw, generator=g) * 2.0
+    pred[0, :2, :2, 0] = 3.0                          # a plateau of equal maxima: all four survive the NMS (hmax == heat)
+    nchw = pred.permute(0, 3, 1, 2)
+    preds = (torch.sigmoid(nchw[:, 0:1]), nchw[:, 1:3], nchw[:, 3:5], nchw[:, 5:5 + nbins], nchw[:, 5 + nbins:6 + nbins],
+             nchw[:, 6 + nbins:7 + nbins], nchw[:, 7 + nbins:9 + nbins])
+    want, _ = oc.decode_heatmap(preds, nbins, k=min(k, fh * fw), kernel=3)
+    got = ops.centernet_decode(pred.to(dev), nbins, min(k, fh * fw), 3, 4.0).cpu()
+    assert got.shape == want.shape
+    for b in range(B):
+        close(got[b, :, 7], want[b, :, 7], what="decode scores", tol=1e-6)          # the sorted score lists agree
+        sw = want[b, :, 7]
+        distinct = torch.ones_like(sw, dtype=torch.bool)
+        distinct[1:] &= sw[1:] != sw[:-1]
+        distinct[:-1] &= sw[:-1] != sw[1:]
+        sel = distinct & (sw > 0)
+        assert int(sel.sum()) >= 1
+        close(got[b][sel], want[b][sel], what="decoded boxes", tol=1e-5)
+        tie = (~distinct) & (sw > 0)              # tied maxima: same set of boxes, any order
+        if tie.any():
+            a = got[b][tie]; w = want[b][tie]
+            assert all(((a - r).abs().sum(1) < 1e-4).any() for r in w), "tied boxes differ as a set"

@@ -112,3 +112,8 @@ def test_se_excite_fused(case):
 @pytest.mark.parametrize("case", kc.DIRECT_CONV_CASES, ids=str)
 def test_conv_direct_small_channels(case):
     kc.check_conv_direct("cpu", *case)
+
+
+@pytest.mark.parametrize("case", kc.DECODE_CASES, ids=str)
+def test_centernet_decode(case):
+    kc.check_centernet_decode("cpu", *case)

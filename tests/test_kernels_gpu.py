@@ -128,3 +128,8 @@ def test_conv_direct_full_resolution(case):
     from transfuser_amd import ops
     assert ops._direct_ok((B, H, W, Cin), Cout, Cin, 3, 1, 1, 1)
     kc.check_conv("cuda", B, H, W, Cin, Cout, 3, 1, 1)
+
+
+@pytest.mark.parametrize("case", kc.DECODE_CASES, ids=str)
+def test_centernet_decode(case):
+    kc.check_centernet_decode("cuda", *case)

@@ -127,3 +127,23 @@ def test_point_pillars_model_matches_oracle():
     lp, lr = mc.run_pair(prod, ref, cfg, batch, "cpu")
     assert prod.point_pillar_net.point_net.net[0].weight.grad.abs().max() > 0
     mc.compare_vs_fp64(prod, ref, lp, lr, batch, cfg)
+
+
+def test_forward_ego_and_reference_checkpoint():
+    """(a) a reference-style checkpoint (DDP 'module.' prefix, NCHW-contiguous conv weights) loads with strict key
+    matching; (b) forward_ego / control_pid reproduce the oracle's inference outputs."""
+    cfg = mc.tiny_config(n_layer=1, lidar_res=128)
+    prod, ref = mc.build_pair(cfg, "regnety_tiny", "cpu")
+    sd = {"module." + k: v.detach().clone().contiguous() for k, v in ref.state_dict().items()}
+    with torch.no_grad():
+        for v in sd.values():
+            if v.dtype.is_floating_point:
+                v.add_(0.01)
+    ref.load_state_dict({k[7:]: v for k, v in sd.items()}, strict=True)
+    missing, unexpected = prod.load_reference_checkpoint(sd)
+    assert not missing and not unexpected
+    for k, v in prod.state_dict().items():
+        assert torch.equal(v.cpu(), sd["module." + k]), k
+    assert prod.pred_bev[0].weight.permute(0, 2, 3, 1).is_contiguous()      # still channels-last storage
+    batch = mc.small_batch(2, 64, 128, 128, 40)
+    mc.check_forward_ego(prod, ref, cfg, batch, "cpu")

@@ -136,6 +136,14 @@ def test_full_size_point_pillars_step():
     assert float(tot) < first
 
 
+def test_forward_ego_inference_path():
+    """SURVEY.md 8f-1 on the MI355X: eval-mode forward_ego (backbone, heads, fused decode_heatmap kernel) vs the oracle."""
+    cfg = mc.tiny_config(n_layer=2, lidar_res=128)
+    prod, ref = mc.build_pair(cfg, "regnety_tiny", "cuda")
+    batch = mc.small_batch(2, 160, 352, 128, 40)
+    mc.check_forward_ego(prod, ref, cfg, batch, "cuda")
+
+
 def test_engine_graph_replay_matches_eager():
     """hipGraph-captured training step == eager step (same kernels, same order) on the tiny model."""
     from transfuser_amd.train import Engine

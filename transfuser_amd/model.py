@@ -5,10 +5,12 @@ targets :285-374, losses :150-248 with mmdet 2.25 semantics).
 
 Same parameter names/shapes (reference checkpoints load with strict=True), same call signature,
 same return value; everything between the input tensors and the loss scalars runs in the HIP
-kernels of libtransfuser_hip.so.  Out of scope here: ``forward_ego`` / box decoding /
-PID control / visualisation (CARLA inference) and the ``late_fusion``
-backbone - requesting them raises.
+kernels of libtransfuser_hip.so.  ``forward_ego`` / ``control_pid`` are built on the same kernels plus
+the fused decode_heatmap kernel; not built: visualisation and the ``late_fusion`` backbone (raises).
 """
+from collections import deque
+
+import numpy as np
 import torch
 from torch import nn
 
@@ -20,6 +22,29 @@ from .transfuser import DepthDecoder, SegDecoder, TransfuserBackbone, latentTFBa
 
 HEAD_ORDER = ("heatmap_head", "wh_head", "offset_head", "yaw_class_head", "yaw_res_head", "velocity_head", "brake_head")
 LOSS_KEYS = ("loss_center_heatmap", "loss_wh", "loss_offset", "loss_yaw_class", "loss_yaw_res", "loss_velocity", "loss_brake")
+
+
+class PIDController(object):
+    """model.py:517-535: P + I (mean of the last n errors) + D (last difference)."""
+
+    def __init__(self, K_P=1.0, K_I=0.0, K_D=0.0, n=20):
+        self._K_P, self._K_I, self._K_D = K_P, K_I, K_D
+        self._window = deque([0 for _ in range(n)], maxlen=n)
+
+    def step(self, error):
+        self._window.append(error)
+        if len(self._window) >= 2:
+            integral, derivative = np.mean(self._window), self._window[-1] - self._window[-2]
+        else:
+            integral = derivative = 0.0
+        return self._K_P * error + self._K_I * integral + self._K_D * derivative
+
+
+def get_lidar_to_bevimage_transform():
+    """utils.py:29-37: LiDAR metres -> BEV pixels (rotate, shift by (16, 32) m, 8 px/m)."""
+    T = np.array([[0, -1, 16], [-1, 0, 32], [0, 0, 1]], dtype=np.float32)
+    T[:2, :] *= 8
+    return T
 
 
 class LidarCenterNetHead(nn.Module):
@@ -190,5 +215,82 @@ class LidarCenterNet(nn.Module):
         self._last = dict(pred_wp=pred_wp, pred=pred, bev_up=bev_up, features=features, grid=grid, fused=fused)
         return loss
 
-    def forward_ego(self, *a, **k):
-        raise NotImplementedError("forward_ego (CARLA closed-loop inference, model.py:685-731) is outside the training hot path (SURVEY.md section 8f-1)")
+    # ------------------------------------------------------------------ inference
+    def get_bbox_local_metric(self, bbox):
+        """model.py:810-843: box in BEV pixels -> 4 corners + centre + velocity arrow in metres (x front, y right, ego at the origin)."""
+        x, y, w, h, yaw, speed, brake, confidence = bbox
+        cfg = self.config
+        w = w / cfg.bounding_box_divisor / cfg.pixels_per_meter
+        h = h / cfg.bounding_box_divisor / cfg.pixels_per_meter
+        center = np.linalg.inv(get_lidar_to_bevimage_transform()) @ np.array([x, y, 1.0]) + np.array(cfg.lidar_pos)
+        center[1] = -center[1]
+        box = np.array([[-h, -w, 1], [-h, w, 1], [h, w, 1], [h, -w, 1], [0, 0, 1], [0, h * speed * 0.5, 1]])
+        R = np.array([[np.cos(yaw), -np.sin(yaw), 0], [np.sin(yaw), np.cos(yaw), 0], [0, 0, 1]])
+        shift = np.array([center[0], center[1], 0])
+        for i in range(box.shape[0]):
+            box[i] = R @ box[i] + shift
+        return box, brake, confidence
+
+    def control_pid(self, waypoints, velocity, is_stuck):
+        """model.py:648-683: waypoints (1, 4, 2) + speed -> (steer, throttle, brake)."""
+        assert waypoints.size(0) == 1
+        cfg = self.config
+        if not hasattr(self, "turn_controller"):    # model.py:607-608
+            self.turn_controller = PIDController(K_P=cfg.turn_KP, K_I=cfg.turn_KI, K_D=cfg.turn_KD, n=cfg.turn_n)
+            self.speed_controller = PIDController(K_P=cfg.speed_KP, K_I=cfg.speed_KI, K_D=cfg.speed_KD, n=cfg.speed_n)
+        wp = waypoints[0].data.cpu().numpy()
+        wp[:, 0] += cfg.lidar_pos[0]
+        speed = velocity[0].data.cpu().numpy()
+        desired_speed = np.linalg.norm(wp[0] - wp[1]) * 2.0
+        if is_stuck:
+            desired_speed = np.array(cfg.default_speed)
+        brake = (desired_speed < cfg.brake_speed) or ((speed / desired_speed) > cfg.brake_ratio)
+        delta = np.clip(desired_speed - speed, 0.0, cfg.clip_delta)
+        throttle = np.clip(self.speed_controller.step(delta), 0.0, cfg.clip_throttle)
+        throttle = throttle if not brake else 0.0
+        aim = (wp[1] + wp[0]) / 2.0
+        angle = np.degrees(np.arctan2(aim[1], aim[0])) / 90.0
+        if speed < 0.01 or brake:
+            angle = 0.0
+        steer = np.clip(self.turn_controller.step(angle), -1.0, 1.0)
+        return steer, throttle, brake
+
+    @torch.no_grad()
+    def forward_ego(self, rgb, lidar_bev, target_point, target_point_image, ego_vel, bev_points=None, cam_points=None, save_path=None,
+                    expert_waypoints=None, stuck_detector=0, forced_move=False, num_points=None, rgb_back=None, debug=False):
+        """model.py:685-731 (the visualisation branch is not built): (pred_wp (B, 4, 2), [(bbox (6, 3) ndarray, brake, confidence), ...]
+        of sample 0).  Backbone, heads and the whole decode_heatmap (NMS + top-k + gather) run in HIP kernels; only the final
+        per-box coordinate change is host numpy, as in the reference."""
+        cfg = self.config
+        extra = target_point_image if self.use_target_point_image else None
+        kw = dict(lidar_extra=extra)
+        if self.use_point_pillars:
+            kw = dict(lidar_nhwc=self.point_pillar_net.forward_nhwc(lidar_bev, num_points, extra))
+        if self.backbone == 'geometric_fusion':
+            features, grid, fused = self._model.forward_nhwc(rgb, lidar_bev, ego_vel, bev_points, cam_points, **kw)
+        else:
+            features, grid, fused = self._model.forward_nhwc(rgb, lidar_bev, ego_vel, **kw)
+        pred_wp, _, _, _, _ = self.forward_gru(fused, target_point)
+        pred, _ = HeadsFn.apply(features[0], self, *self.head.parameters(), *self.pred_bev.parameters())
+        boxes = ops.centernet_decode(pred, self.head.num_dir_bins, cfg.top_k_center_keypoints, cfg.center_net_max_pooling_kernel, 4.0)[0]
+        boxes = boxes[boxes[:, -1] > cfg.bb_confidence_threshold]
+        self.i += 1
+        self._last_boxes = boxes
+        return pred_wp, [self.get_bbox_local_metric(b) for b in boxes.cpu().numpy()]
+
+    def load_reference_checkpoint(self, path_or_state_dict, strict=True):
+        """Load a checkpoint written by the reference's train.py (possibly from a DistributedDataParallel model: keys prefixed with
+        'module.', stripped exactly like submission_agent.py:94-96).  Parameter names / shapes are the reference's, conv weights are
+        converted to this package's channels-last storage in place."""
+        sd = torch.load(path_or_state_dict, map_location="cpu") if isinstance(path_or_state_dict, str) else path_or_state_dict
+        sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in sd.items()}
+        own = self.state_dict()
+        with torch.no_grad():
+            missing = [k for k in own if k not in sd]
+            unexpected = [k for k in sd if k not in own]
+            if strict and (missing or unexpected):
+                raise RuntimeError("load_reference_checkpoint: missing %s, unexpected %s" % (missing[:5], unexpected[:5]))
+            for k, v in sd.items():
+                if k in own:
+                    own[k].copy_(v)      # copy_ keeps our memory format (channels_last conv weights) and the arena views
+        return missing, unexpected

@@ -524,6 +524,15 @@ def centernet_loss_bwd(pred, tgtf, tgti, cnt, gup, nbins):
 
 
 # ------------------------------------------------------------------------------------------ misc
+def centernet_decode(pred, nbins, k=100, kernel=3, ratio=4.0):
+    """decode_heatmap (model.py:436-497): pred (B, fh, fw, 9+bins) -> (B, k, 8) boxes [x, y, w, h, yaw, vel, brake, score]."""
+    B, fh, fw, P = pred.shape
+    assert P == 9 + nbins
+    out = torch.empty(B, k, 8, dtype=torch.float32, device=pred.device)
+    check(L().tf_centernet_decode_f32(ptr(_c(pred)), B, fh, fw, nbins, k, kernel, ctypes.c_float(ratio), ptr(out), stream_of(pred)), "tf_centernet_decode_f32")
+    return out
+
+
 def relu_mask(dy, y, out=None):
     if out is None:
         out = torch.empty_like(dy)
