@@ -245,15 +245,15 @@ struct GemmEpi {
 };
 
 // ---------------------------------------------------------------- kernel
-template <int BM, int BN, int WAVES_M, int BK, class LA, bool A_KC, class LB, bool B_KC, bool ALLVEC>
+template <int BM, int BN, int WAVES_M, int BK, class LA, bool A_KC, class LB, bool B_KC, bool ALLVEC, int NT = 256, int PF = 1>
 __device__ __forceinline__ void gemm_tile(LA& la, LB& lb, const GemmEpi& ep, int M, int N, int K, int tiles_m, int tiles_n, int kchunk,
                                           float (*As)[BK][BM + GEMM_PAD], float (*Bs)[BK][BN + GEMM_PAD]) {
-    constexpr int WAVES_N = 4 / WAVES_M;
+    constexpr int WAVES_N = (NT / 64) / WAVES_M;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int TM = WM / 32, TN = WN / 32;
     static_assert(WM % 32 == 0 && WN % 32 == 0 && TM >= 1 && TN >= 1, "wave tile must be 32x32 multiples");
     constexpr int KQ = BK / 4;                                   // float4 per row of a KC operand tile
-    constexpr int NLA = (BM * KQ + 255) / 256, NLB = (BN * KQ + 255) / 256;   // float4 slots per thread
+    constexpr int NLA = (BM * KQ + NT - 1) / NT, NLB = (BN * KQ + NT - 1) / NT;   // float4 slots per thread
 
     const int tid = threadIdx.x;
     const int z = blockIdx.z;
@@ -292,13 +292,13 @@ __device__ __forceinline__ void gemm_tile(LA& la, LB& lb, const GemmEpi& ep, int
     auto gen_seek = [&](int k0) {
 #pragma unroll
         for (int p = 0; p < NLA; ++p) {
-            const int f = tid + p * 256;
+            const int f = tid + p * NT;
             if (A_KC) { arow[p] = la.row(i0 + f / KQ); acol[p] = la.col(k0 + (f % KQ) * 4); }
             else { const int kr = f / (BM / 4), cq = f - kr * (BM / 4); arow[p] = la.row(k0 + kr); acol[p] = la.col(i0 + cq * 4); }
         }
 #pragma unroll
         for (int p = 0; p < NLB; ++p) {
-            const int f = tid + p * 256;
+            const int f = tid + p * NT;
             if (B_KC) { brow[p] = lb.row(j0 + f / KQ); bcol[p] = lb.col(k0 + (f % KQ) * 4); }
             else { const int kr = f / (BN / 4), cq = f - kr * (BN / 4); brow[p] = lb.row(k0 + kr); bcol[p] = lb.col(j0 + cq * 4); }
         }
@@ -309,25 +309,25 @@ __device__ __forceinline__ void gemm_tile(LA& la, LB& lb, const GemmEpi& ep, int
     auto fetch = [&]() {
 #pragma unroll
         for (int p = 0; p < NLA; ++p) {
-            const int f = tid + p * 256;
+            const int f = tid + p * NT;
             if (A_KC) {
-                ra[p] = la.template load<ALLVEC>(arow[p], acol[p], ((BM * KQ) % 256 == 0 || f < BM * KQ) && cidx(acol[p]) < kend, ma[p]);
+                ra[p] = la.template load<ALLVEC>(arow[p], acol[p], ((BM * KQ) % NT == 0 || f < BM * KQ) && cidx(acol[p]) < kend, ma[p]);
                 la.col_advance(acol[p], BK);
             } else {
                 const int kr = f / (BM / 4);
-                ra[p] = la.template load<ALLVEC>(arow[p], acol[p], (((BM / 4) * BK) % 256 == 0 || kr < BK) && arow[p].r < kend, ma[p]);
+                ra[p] = la.template load<ALLVEC>(arow[p], acol[p], (((BM / 4) * BK) % NT == 0 || kr < BK) && arow[p].r < kend, ma[p]);
                 la.row_advance(arow[p], BK);
             }
         }
 #pragma unroll
         for (int p = 0; p < NLB; ++p) {
-            const int f = tid + p * 256;
+            const int f = tid + p * NT;
             if (B_KC) {
-                rb[p] = lb.template load<ALLVEC>(brow[p], bcol[p], ((BN * KQ) % 256 == 0 || f < BN * KQ) && cidx(bcol[p]) < kend, mb[p]);
+                rb[p] = lb.template load<ALLVEC>(brow[p], bcol[p], ((BN * KQ) % NT == 0 || f < BN * KQ) && cidx(bcol[p]) < kend, mb[p]);
                 lb.col_advance(bcol[p], BK);
             } else {
                 const int kr = f / (BN / 4);
-                rb[p] = lb.template load<ALLVEC>(brow[p], bcol[p], (((BN / 4) * BK) % 256 == 0 || kr < BK) && brow[p].r < kend, mb[p]);
+                rb[p] = lb.template load<ALLVEC>(brow[p], bcol[p], (((BN / 4) * BK) % NT == 0 || kr < BK) && brow[p].r < kend, mb[p]);
                 lb.row_advance(brow[p], BK);
             }
         }
@@ -335,7 +335,7 @@ __device__ __forceinline__ void gemm_tile(LA& la, LB& lb, const GemmEpi& ep, int
     auto stash = [&](int buf) {
 #pragma unroll
         for (int p = 0; p < NLA; ++p) {
-            const int f = tid + p * 256;
+            const int f = tid + p * NT;
             if (A_KC) {
                 if (f < BM * KQ) {
                     const int r = f / KQ, kq = (f % KQ) * 4;
@@ -349,7 +349,7 @@ __device__ __forceinline__ void gemm_tile(LA& la, LB& lb, const GemmEpi& ep, int
         }
 #pragma unroll
         for (int p = 0; p < NLB; ++p) {
-            const int f = tid + p * 256;
+            const int f = tid + p * NT;
             if (B_KC) {
                 if (f < BN * KQ) {
                     const int r = f / KQ, kq = (f % KQ) * 4;
@@ -374,7 +374,7 @@ __device__ __forceinline__ void gemm_tile(LA& la, LB& lb, const GemmEpi& ep, int
     if constexpr (CANFAST) {
 #pragma unroll
         for (int p = 0; p < NLA; ++p) {
-            const int f = tid + p * 256;
+            const int f = tid + p * NT;
             if (A_KC) {
                 const int fr = (f < BM * KQ) ? f : 0;
                 int r = i0 + fr / KQ; r = r < la.rows ? r : la.rows - 1;
@@ -388,7 +388,7 @@ __device__ __forceinline__ void gemm_tile(LA& la, LB& lb, const GemmEpi& ep, int
         }
 #pragma unroll
         for (int p = 0; p < NLB; ++p) {
-            const int f = tid + p * 256;
+            const int f = tid + p * NT;
             if (B_KC) {
                 const int fr = (f < BN * KQ) ? f : 0;
                 int r = j0 + fr / KQ; r = r < lb.rows ? r : lb.rows - 1;
@@ -403,40 +403,42 @@ __device__ __forceinline__ void gemm_tile(LA& la, LB& lb, const GemmEpi& ep, int
         fa_step = A_KC ? BK : (long)BK * la.ld;
         fb_step = B_KC ? BK : (long)BK * lb.ld;
     }
-    auto fetch_fast = [&](int kt) {
+    auto fetch_set = [&](float4* qa, float4* qb, int kt) {
 #pragma unroll
-        for (int p = 0; p < NLA; ++p) ra[p] = *reinterpret_cast<const float4*>(fa[p] + (long)kt * fa_step);
+        for (int p = 0; p < NLA; ++p) qa[p] = *reinterpret_cast<const float4*>(fa[p] + (long)kt * fa_step);
 #pragma unroll
-        for (int p = 0; p < NLB; ++p) rb[p] = *reinterpret_cast<const float4*>(fb[p] + (long)kt * fb_step);
+        for (int p = 0; p < NLB; ++p) qb[p] = *reinterpret_cast<const float4*>(fb[p] + (long)kt * fb_step);
     };
-    auto stash_fast = [&](int buf) {
+    auto stash_set = [&](const float4* qa, const float4* qb, int buf) {
 #pragma unroll
         for (int p = 0; p < NLA; ++p) {
-            const int f = tid + p * 256;
+            const int f = tid + p * NT;
             if (A_KC) {
-                if ((BM * KQ) % 256 == 0 || f < BM * KQ) {
+                if ((BM * KQ) % NT == 0 || f < BM * KQ) {
                     const int r = f / KQ, kq = (f % KQ) * 4;
-                    As[buf][kq + 0][r] = ra[p].x; As[buf][kq + 1][r] = ra[p].y; As[buf][kq + 2][r] = ra[p].z; As[buf][kq + 3][r] = ra[p].w;
+                    As[buf][kq + 0][r] = qa[p].x; As[buf][kq + 1][r] = qa[p].y; As[buf][kq + 2][r] = qa[p].z; As[buf][kq + 3][r] = qa[p].w;
                 }
             } else {
                 const int kr = f / (BM / 4), cq = f - kr * (BM / 4);
-                if (((BM / 4) * BK) % 256 == 0 || kr < BK) *reinterpret_cast<float4*>(&As[buf][kr][cq * 4]) = ra[p];
+                if (((BM / 4) * BK) % NT == 0 || kr < BK) *reinterpret_cast<float4*>(&As[buf][kr][cq * 4]) = qa[p];
             }
         }
 #pragma unroll
         for (int p = 0; p < NLB; ++p) {
-            const int f = tid + p * 256;
+            const int f = tid + p * NT;
             if (B_KC) {
-                if ((BN * KQ) % 256 == 0 || f < BN * KQ) {
+                if ((BN * KQ) % NT == 0 || f < BN * KQ) {
                     const int r = f / KQ, kq = (f % KQ) * 4;
-                    Bs[buf][kq + 0][r] = rb[p].x; Bs[buf][kq + 1][r] = rb[p].y; Bs[buf][kq + 2][r] = rb[p].z; Bs[buf][kq + 3][r] = rb[p].w;
+                    Bs[buf][kq + 0][r] = qb[p].x; Bs[buf][kq + 1][r] = qb[p].y; Bs[buf][kq + 2][r] = qb[p].z; Bs[buf][kq + 3][r] = qb[p].w;
                 }
             } else {
                 const int kr = f / (BN / 4), cq = f - kr * (BN / 4);
-                if (((BN / 4) * BK) % 256 == 0 || kr < BK) *reinterpret_cast<float4*>(&Bs[buf][kr][cq * 4]) = rb[p];
+                if (((BN / 4) * BK) % NT == 0 || kr < BK) *reinterpret_cast<float4*>(&Bs[buf][kr][cq * 4]) = qb[p];
             }
         }
     };
+    auto fetch_fast = [&](int kt) { fetch_set(ra, rb, kt); };
+    auto stash_fast = [&](int buf) { stash_set(ra, rb, buf); };
     const int nfast = CANFAST ? (kend - kbeg) / BK : 0;    // leading k tiles that are complete (block-uniform)
 
     f32x16 acc[TM][TN];
@@ -479,6 +481,30 @@ __device__ __forceinline__ void gemm_tile(LA& la, LB& lb, const GemmEpi& ep, int
     if constexpr (CANFAST) {
         // hot loop: complete k tiles only, nothing but pointer bumps, 16-byte loads, MFMAs and one barrier per tile; a ragged last
         // tile is peeled off below (keeping the masked code out of the loop also keeps its registers out of the loop's allocation)
+        if constexpr (PF == 2) {
+            // prefetch distance 2: tile kt+2 is requested while tile kt is multiplied (two register sets A = ra/rb, B = ra2/rb2; the
+            // loop is unrolled by 2 so the set roles are static); measured +5-10 % on 128x128 tiles with 8 waves (tools/probe/gemm_lab.cpp)
+            float4 ra2[NLA], rb2[NLB];
+            const int last = nfast - 1;
+            if (nfast > 0) {
+                fetch_set(ra, rb, 0);
+                stash_set(ra, rb, 0);
+                fetch_set(ra, rb, 1 < nfast ? 1 : last);                   // A <- tile 1
+            }
+            __syncthreads();
+            for (int kt = 0; kt < nfast; kt += 2) {                        // LDS 0 holds tile kt, set A holds tile kt+1
+                fetch_set(ra2, rb2, kt + 2 < nfast ? kt + 2 : last);       // B <- tile kt+2
+                compute(0);
+                stash_set(ra, rb, 1);                                      // A (tile kt+1) -> LDS 1
+                __syncthreads();
+                if (kt + 1 < nfast) {
+                    fetch_set(ra, rb, kt + 3 < nfast ? kt + 3 : last);     // A <- tile kt+3
+                    compute(1);
+                    stash_set(ra2, rb2, 0);                                // B (tile kt+2) -> LDS 0
+                    __syncthreads();
+                }
+            }
+        } else {
         if (nfast > 0) {
             fetch_fast(0);
             stash_fast(0);
@@ -490,6 +516,7 @@ __device__ __forceinline__ void gemm_tile(LA& la, LB& lb, const GemmEpi& ep, int
             compute(cur);
             stash_fast(cur ^ 1);
             __syncthreads();
+        }
         }
         if (nkt > nfast) {
             gen_seek(kbeg + nfast * BK);
@@ -562,11 +589,11 @@ __device__ __forceinline__ void gemm_tile(LA& la, LB& lb, const GemmEpi& ep, int
 // __launch_bounds__ 2nd argument = waves per SIMD the register allocator must leave room for (= resident 256-thread
 // blocks per CU): PMC showed the big tiles lose more to the tail round (tiles / resident slots) than to anything in the
 // K loop, so they are held to 3 blocks per CU (<= 168 registers incl. 64 accumulators) and the small ones to 4+.
-template <int BM, int BN, int WAVES_M, int BK, class LA, bool A_KC, class LB, bool B_KC, bool ALLVEC>
-__global__ void __launch_bounds__(256, (BM * BN >= 128 * 96) ? 3 : 4) gemm_kernel(LA la, LB lb, GemmEpi ep, int M, int N, int K, int tiles_m, int tiles_n, int kchunk) {
+template <int BM, int BN, int WAVES_M, int BK, class LA, bool A_KC, class LB, bool B_KC, bool ALLVEC, int NT = 256, int PF = 1>
+__global__ void __launch_bounds__(NT, NT == 512 ? 2 : ((BM * BN >= 128 * 96) ? 3 : 4)) gemm_kernel(LA la, LB lb, GemmEpi ep, int M, int N, int K, int tiles_m, int tiles_n, int kchunk) {
     __shared__ __attribute__((aligned(16))) float As[2][BK][BM + GEMM_PAD];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN + GEMM_PAD];
-    gemm_tile<BM, BN, WAVES_M, BK, LA, A_KC, LB, B_KC, ALLVEC>(la, lb, ep, M, N, K, tiles_m, tiles_n, kchunk, As, Bs);
+    gemm_tile<BM, BN, WAVES_M, BK, LA, A_KC, LB, B_KC, ALLVEC, NT, PF>(la, lb, ep, M, N, K, tiles_m, tiles_n, kchunk, As, Bs);
 }
 
 // ---------------------------------------------------------------- host dispatch
@@ -607,7 +634,7 @@ inline GemmPlan plan_gemm(int M, int N, int K, int batch, bool allow_splitk) {
     return p;
 }
 
-template <int BM, int BN, int WAVES_M, int BK, class LA, bool A_KC, class LB, bool B_KC>
+template <int BM, int BN, int WAVES_M, int BK, class LA, bool A_KC, class LB, bool B_KC, int NT = 256, int PF = 1>
 inline void launch_cfg(const LA& la, const LB& lb, const GemmEpi& ep, int M, int N, int K, int batch, int splitk, void* stream) {
     const int tiles_m = cdiv(M, BM), tiles_n = cdiv(N, BN);
     int kchunk = cdiv(cdiv(K, splitk), BK) * BK;
@@ -625,9 +652,9 @@ inline void launch_cfg(const LA& la, const LB& lb, const GemmEpi& ep, int M, int
         epg.group_m = (g >= 2 && tiles_n >= 4) ? g : 1;
     }
     if (la.vec && lb.vec)
-        TF_LAUNCH((gemm_kernel<BM, BN, WAVES_M, BK, LA, A_KC, LB, B_KC, true>), grid, dim3(256), stream, la, lb, epg, M, N, K, tiles_m, tiles_n, kchunk);
+        TF_LAUNCH((gemm_kernel<BM, BN, WAVES_M, BK, LA, A_KC, LB, B_KC, true, NT, PF>), grid, dim3(NT), stream, la, lb, epg, M, N, K, tiles_m, tiles_n, kchunk);
     else
-        TF_LAUNCH((gemm_kernel<BM, BN, WAVES_M, BK, LA, A_KC, LB, B_KC, false>), grid, dim3(256), stream, la, lb, epg, M, N, K, tiles_m, tiles_n, kchunk);
+        TF_LAUNCH((gemm_kernel<BM, BN, WAVES_M, BK, LA, A_KC, LB, B_KC, false, NT, PF>), grid, dim3(NT), stream, la, lb, epg, M, N, K, tiles_m, tiles_n, kchunk);
 }
 
 template <class LA, bool A_KC, class LB, bool B_KC>
@@ -641,7 +668,8 @@ inline void launch_plan(const GemmPlan& p, const LA& la, const LB& lb, const Gem
         if (p.bn == 32) TF_CFG(128, 32, 4);
         else if (p.bn == 64) TF_CFG(128, 64, 2);
         else if (p.bn == 96) TF_CFG(128, 96, 4);
-        else TF_CFG(128, 128, 2);
+        else TF_CFG(128, 128, 2);   // (an 8-wave / prefetch-distance-2 variant - gemm_tile<..., NT = 512, PF = 2> - reached 102-111 TF/s in
+                                    //  tools/probe/gemm_lab.cpp but only 88-93 TF/s inside the engine: not dispatched)
     } else {
         if (p.bn == 64) TF_CFG(64, 64, 2);
         else TF_CFG(64, 128, 1);
