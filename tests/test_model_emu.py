@@ -147,3 +147,37 @@ def test_forward_ego_and_reference_checkpoint():
     assert prod.pred_bev[0].weight.permute(0, 2, 3, 1).is_contiguous()      # still channels-last storage
     batch = mc.small_batch(2, 64, 128, 128, 40)
     mc.check_forward_ego(prod, ref, cfg, batch, "cpu")
+
+
+def test_edge_cases_empty_labels_single_sample_empty_cloud_partial_fusion():
+    """Ragged / empty inputs of the domain: (1) B = 1 with NO boxes at all (avg_factor falls back to 1, mmdet eps paths), (2) PointPillars
+    with a sample whose cloud is empty (num_points = 0), (3) geometric fusion with n_scale = 2 (only stages 3 and 4 fuse)."""
+    cfg = mc.tiny_config(n_layer=1)
+    prod, ref = mc.build_pair(cfg, "regnety_tiny", "cpu")
+    batch = mc.small_batch(1, 32, 64, 64, 40)
+    batch["label"].zero_()
+    lp, lr = mc.run_pair(prod, ref, cfg, batch, "cpu")
+    assert float(lp["loss_wh"]) == 0.0
+    mc.compare_vs_fp64(prod, ref, lp, lr, batch, cfg, verbose=False)
+
+    cfg = mc.tiny_config(n_layer=1, lidar_res=64)
+    cfg.use_point_pillars = True
+    cfg.min_x, cfg.max_x, cfg.min_y, cfg.max_y = -4, 4, -8, 0
+    prod, ref = mc.build_pair(cfg, "regnety_tiny", "cpu")
+    batch = mc.small_batch(2, 32, 64, 64, 40)
+    g = torch.Generator().manual_seed(5)
+    batch["lidar"] = torch.stack([torch.rand(2, 500, generator=g) * 10 - 5, torch.rand(2, 500, generator=g) * 10 - 9,
+                                  torch.rand(2, 500, generator=g) * 5 - 4, torch.rand(2, 500, generator=g)], -1)
+    batch["num_points"] = torch.tensor([0, 400], dtype=torch.int32)
+    lp, lr = mc.run_pair(prod, ref, cfg, batch, "cpu")
+    mc.compare_vs_fp64(prod, ref, lp, lr, batch, cfg, verbose=False)
+
+    cfg = mc.tiny_config(n_layer=1, lidar_res=96)
+    cfg.img_vert_anchors, cfg.img_horz_anchors, cfg.lidar_vert_anchors, cfg.lidar_horz_anchors = 2, 3, 3, 3
+    cfg.n_embd, cfg.n_scale = 32, 2
+    prod, ref = mc.build_pair(cfg, "regnety_tiny", "cpu", backbone="geometric_fusion")
+    batch = mc.small_batch(2, 64, 96, 96, 40)
+    batch.update(mc.geo_points(2, cfg))
+    lp, lr = mc.run_pair(prod, ref, cfg, batch, "cpu")
+    mc.compare_vs_fp64(prod, ref, lp, lr, batch, cfg, verbose=False)
+    assert prod._model.image_conv1.weight.grad is None and ref._model.image_conv1.weight.grad is None    # stages 1-2 do not fuse

@@ -61,7 +61,13 @@ class GeometricFusionBackbone(_FusionBackbone):
 
     def unused_parameters(self):
         """Parameters the reference's graph never reaches (grad stays None there): quirk Q4."""
-        return [] if self.config.n_scale < 1 else [self.lidar_conv4.weight, self.lidar_conv4.bias]
+        out = [] if self.config.n_scale < 1 else [self.lidar_conv4.weight, self.lidar_conv4.bias]
+        for i, st in enumerate(self._stages, 1):          # stages that do not fuse (n_scale < 5 - i) keep all their modules untouched
+            if self.config.n_scale < 5 - i:
+                mods = [st.image_conv, st.image_deconv, st.lidar_deconv, st.image_projection, st.lidar_projection] + ([st.vel_emb] if st.vel_emb is not None else [])
+                mods += [st.lidar_conv] if i != 4 else []
+                out += [p for m in mods for p in m.parameters()]
+        return out
 
     @staticmethod
     def _flat_idx(pts, B, n):
