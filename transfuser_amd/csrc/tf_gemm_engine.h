@@ -11,9 +11,9 @@
 // copied straight).  LDS tiles are K-major ([BK][BM+4]) so an MFMA operand fetch is a
 // conflict-free ds_read_b32 (lanes 0-31 consecutive, lanes 32-63 the next k row).
 //
-// Tile: BM x BN x 16, 256 threads = 4 waves, each wave owns (BM/WAVES_M) x (BN/WAVES_N) as
-// 32x32 MFMA tiles.  Global->register prefetch of tile t+1 is issued before the MFMAs of tile
-// t and written to the other LDS buffer after them: one barrier per K tile.
+// Tile: BM x BN x BK (16 | 32), NT = 256 threads = 4 waves (the engine's dispatch; 512 is supported by the template), each wave owns
+// (BM/WAVES_M) x (BN/WAVES_N) as 32x32 MFMA tiles.  Global->register prefetch of tile t+1 is issued before the MFMAs of tile t and
+// written to the other LDS buffer after them: one barrier per K tile.  Plain operands take a mask-free fast loop (gemm_tile).
 #pragma once
 #include "tf_common.h"
 #include <type_traits>

@@ -144,9 +144,6 @@ class YBlockFn(torch.autograd.Function):
             else:
                 ops.conv_wgrad(dyd, x, gbuf(wd), blk.stride, 0, 1)
                 ops.conv_dgrad(dyd, wd, x.shape, blk.stride, 0, 1, out=dx.view(B, H, W, Cin), accumulate=True)
-        dbg = getattr(blk, "_dbg", None)
-        if dbg is not None:
-            dbg.update(y2=y2, z2=z2, st2=st2, dout=dout, dy3=dy3, dsc=dsc, dz2s=dz2s, dgate=dgate, ds=ds, dz2=dz2, dy2=dy2, dz1=dz1, dy1=dy1, dx=dx.view(B, H, W, Cin))
         ctx.saved = None
         return (dx.view(B, H, W, Cin), None) + (None,) * (len(ctx.needs_input_grad) - 2)
 
