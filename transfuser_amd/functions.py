@@ -106,7 +106,7 @@ class YBlockFn(torch.autograd.Function):
         dy3, dsc = _bn_bwd(dout.contiguous(), out, y3, blk.conv3.bn, st3, want_dres=True)
         dy3_2 = dy3.view(-1, C)
         w3 = blk.conv3.conv.weight
-        ops.linear_wgrad(dy3_2, z2s.view(-1, C), w2d(gbuf(w3)))
+        ops.wgrad_fork((dy3, z2s), lambda: ops.linear_wgrad(dy3_2, z2s.view(-1, C), w2d(gbuf(w3))))
         dz2s = ops.linear_dgrad(dy3_2, w2d(w3)).view(B, Ho, Wo, C)
         # squeeze-excite
         se = blk.se
@@ -126,12 +126,12 @@ class YBlockFn(torch.autograd.Function):
         # grouped 3x3
         dy2, _ = _bn_bwd(dz2, z2, y2, blk.conv2.bn, st2)
         w2 = blk.conv2.conv.weight
-        ops.conv_wgrad(dy2, z1, gbuf(w2), blk.stride, 1, blk.groups)
+        ops.wgrad_fork((dy2, z1), lambda: ops.conv_wgrad(dy2, z1, gbuf(w2), blk.stride, 1, blk.groups))
         dz1 = ops.conv_dgrad(dy2, w2, z1.shape, blk.stride, 1, blk.groups)
         dy1, _ = _bn_bwd(dz1, z1, y1, blk.conv1.bn, st1)
         dy1_2 = dy1.view(-1, C)
         w1 = blk.conv1.conv.weight
-        ops.linear_wgrad(dy1_2, x2, w2d(gbuf(w1)))
+        ops.wgrad_fork((dy1, x), lambda: ops.linear_wgrad(dy1_2, x2, w2d(gbuf(w1))))
         if blk.downsample is None:
             dx = ops.linear_dgrad(dy1_2, w2d(w1), res=dsc.view(-1, Cin))
         else:
@@ -139,10 +139,10 @@ class YBlockFn(torch.autograd.Function):
             dyd, _ = _bn_bwd(dsc, None, yd, blk.downsample.bn, std)
             wd = blk.downsample.conv.weight
             if blk.stride == 1:
-                ops.linear_wgrad(dyd.view(-1, C), x2, w2d(gbuf(wd)))
+                ops.wgrad_fork((dyd, x), lambda: ops.linear_wgrad(dyd.view(-1, C), x2, w2d(gbuf(wd))))
                 ops.linear_dgrad(dyd.view(-1, C), w2d(wd), out=dx, accumulate=True)
             else:
-                ops.conv_wgrad(dyd, x, gbuf(wd), blk.stride, 0, 1)
+                ops.wgrad_fork((dyd, x), lambda: ops.conv_wgrad(dyd, x, gbuf(wd), blk.stride, 0, 1))
                 ops.conv_dgrad(dyd, wd, x.shape, blk.stride, 0, 1, out=dx.view(B, H, W, Cin), accumulate=True)
         ctx.saved = None
         return (dx.view(B, H, W, Cin), None) + (None,) * (len(ctx.needs_input_grad) - 2)

@@ -68,6 +68,43 @@ def wptr(w):
     return ptr(w)
 
 
+# ------------------------------------------------------------------------------------------ weight-gradient stream
+# A layer's weight gradient (dW = f(dy, x)) is off the critical path of the backward pass (only dx feeds the next layer), and many of
+# these launches under-fill the GPU (grouped-conv / small-Cout weight gradients: a few dozen tiles).  wgrad_fork runs them on a second
+# HIP stream - one more parallel branch of the captured hipGraph - so they could overlap the dgrad / BatchNorm chain (experiment).  Inputs are kept alive
+# with record_stream; the join is queued as an autograd-engine callback (end of backward()).
+_WGRAD_FORK = bool(int(__import__("os").environ.get("TF_WGRAD_STREAM", "0")))   # measured SLOWER on the MI355X (155-158 vs 170 samples/s): opt-in
+_wg = {"stream": {}, "pending": False}
+
+
+def _wgrad_join():
+    _wg["pending"] = False
+    for dev, ws in _wg["stream"].items():
+        torch.cuda.current_stream(dev).wait_stream(ws)
+
+
+def wgrad_fork(tensors, fn):
+    t0 = tensors[0]
+    if not (_WGRAD_FORK and t0.is_cuda):
+        return fn()
+    dev = t0.device
+    ws = _wg["stream"].get(dev)
+    if ws is None:
+        ws = _wg["stream"][dev] = torch.cuda.Stream(dev)
+    cur = torch.cuda.current_stream(dev)
+    ws.wait_stream(cur)
+    with torch.cuda.stream(ws):
+        fn()
+    for t in tensors:
+        t.record_stream(ws)
+    if not _wg["pending"]:
+        _wg["pending"] = True
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_wgrad_join)
+        except RuntimeError:      # not inside backward(): join right away
+            _wgrad_join()
+
+
 # ------------------------------------------------------------------------------------------ GEMM
 census = None   # set to a list to record (kind, shape, flops, start_event, end_event) of every MFMA-engine call (tools/census.py)
 
