@@ -21,6 +21,7 @@ for (B, H, W, Ci, Co) in [(10, 256, 704, 32, 32), (10, 256, 704, 32, 7), (10, 25
     res = {}
     for direct in (0, 1):
         ops._DIRECT = bool(direct)
+        ops._DIRECT_WGRAD_MAX_COUT = 32 if direct else 4      # time the direct weight gradient for every Cout
         res[direct] = (t(lambda: ops.conv_fwd(x, w, b, 1, None, 1, relu=True)), t(lambda: ops.conv_dgrad(dy, w, x.shape, 1, None, 1, out=dx)),
                        t(lambda: ops.conv_wgrad(dy, x, dw, 1, None, 1)))
     print("%s  engine fwd/dgrad/wgrad %.0f %.0f %.0f us   direct %.0f %.0f %.0f us" % ((B, H, W, Ci, Co), *res[0], *res[1]), flush=True)

@@ -116,26 +116,45 @@ __global__ void __launch_bounds__(256, 1) conv3x3_small_wgrad_kernel(const float
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    for (int tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
-        const int b = tile / (g.tiles_h * g.tiles_w), r = tile - b * (g.tiles_h * g.tiles_w);
+    // register prefetch of the next tile (patch + dY rows) while the current one is multiplied
+    constexpr int ND = TH * TW * 32 / 256;         // dY elements per thread (co fastest: thread -> fixed co, ND pixels)
+    float4 pre[NV];
+    float dpre[ND];
+    auto fetch = [&](int t) {
+        const int b = t / (g.tiles_h * g.tiles_w), r = t - b * (g.tiles_h * g.tiles_w);
         const int h0 = (r / g.tiles_w) * TH, w0 = (r % g.tiles_w) * TW;
-        __syncthreads();
 #pragma unroll
-        for (int p = 0; p < NV; ++p) store_patch_slot(patch, tid + p * 256, load_patch_slot<VEC>(x, g, b, h0, w0, tid + p * 256));
-        for (int i = tid; i < TH * TW * 32; i += 256) {
-            const int co = i & 31, pix = i >> 5, ph = pix / TW, pw = pix - ph * TW;
+        for (int p = 0; p < NV; ++p) pre[p] = load_patch_slot<VEC>(x, g, b, h0, w0, tid + p * 256);
+#pragma unroll
+        for (int p = 0; p < ND; ++p) {
+            const int i = tid + p * 256, co = i & 31, pix = i >> 5, ph = pix / TW, pw = pix - ph * TW;
             const int h = h0 + ph, w = w0 + pw;
-            dyt[pix * PP + co] = (co < g.Co && h < g.H && w < g.W) ? dy[(((long)b * g.H + h) * g.W + w) * g.Co + co] : 0.f;
+            const bool ok = co < g.Co && h < g.H && w < g.W;
+            dpre[p] = ok ? dy[(((long)b * g.H + h) * g.W + w) * g.Co + co] : 0.f;
         }
-        __syncthreads();
-        // K = the 32 pixels of this wave's row: A[i = co][k = pixel] = dyt, B[k = pixel][j = ci] = patch shifted by the tap
+    };
+    int tile = blockIdx.x;
+    if (tile < g.ntiles) fetch(tile);
+    for (; tile < g.ntiles; tile += gridDim.x) {
+        __syncthreads();                           // the previous tile's MFMAs are done with both LDS tiles
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int kh = tap / 3, kw = tap - kh * 3;
-            const float* pa = dyt + (wave * TW + hi) * PP + l31;
-            const float* pb = patch + ((wave + kh) * PW + hi + kw) * PP + l31;
-#pragma unroll 4
-            for (int kk = 0; kk < TW / 2; ++kk) mfma_32x32x2(pa[2 * kk * PP], pb[2 * kk * PP], acc[tap]);
+        for (int p = 0; p < NV; ++p) store_patch_slot(patch, tid + p * 256, pre[p]);
+#pragma unroll
+        for (int p = 0; p < ND; ++p) { const int i = tid + p * 256; dyt[(i >> 5) * PP + (i & 31)] = dpre[p]; }
+        __syncthreads();
+        if (tile + (int)gridDim.x < g.ntiles) fetch(tile + gridDim.x);
+        // K = the 32 pixels of this wave's row: A[i = co][k = pixel] = dyt (shared by the 9 taps), B[k = pixel][j = ci] = patch shifted by
+        // the tap -> 9 independent accumulator chains per k step
+        const float* pa = dyt + (wave * TW + hi) * PP + l31;
+        const float* pb = patch + (wave * PW + hi) * PP + l31;
+#pragma unroll 2
+        for (int kk = 0; kk < TW / 2; ++kk) {
+            const float a = pa[2 * kk * PP];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int kh = tap / 3, kw = tap - kh * 3;
+                mfma_32x32x2(a, pb[((kh * PW + kw) + 2 * kk) * PP], acc[tap]);
+            }
         }
     }
     // reduce the 4 waves through LDS (patch + dyt are free now), then one partial panel per block: part[block][tap][co][ci]

@@ -222,7 +222,7 @@ def _direct_ok(shape, cout, cin, ks, stride, pad, groups):
 
 
 _DIRECT = bool(int(__import__("os").environ.get("TF_DIRECT_CONV", "1")))
-_DIRECT_WGRAD_MAX_COUT = 4   # measured (tools/conv_bench.py): the direct wgrad only beats the engine's split-K path for 1-4 output channels
+_DIRECT_WGRAD_MAX_COUT = 32  # measured (tools/conv_bench.py): 421-425 us for every Cout at 256x704 vs 674-752 us through the engine's split-K path
 
 
 def conv_fwd(x, w, bias=None, stride=1, pad=None, groups=1, relu=False):
