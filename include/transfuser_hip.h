@@ -52,6 +52,8 @@ typedef struct {
     int batch, inner;
     int64_t sa_outer, sa_inner, sb_outer, sb_inner, sc_outer, sc_inner;
     float alpha; int relu; int accumulate;
+    const float* mask; int64_t ldmask;   /* optional (batch == 1, store mode): c(i,j) is zeroed unless mask[i*ldmask + j] > 0 - the ReLU
+                                          * mask of a backward GEMM (dX = (dY W) * [act > 0]) fused into the epilogue */
 } tf_gemm_desc;
 int tf_gemm_f32(const tf_gemm_desc* d, void* stream);
 

@@ -603,3 +603,11 @@ def check_centernet_decode(dev, B, fh, fw, nbins, k):
         if tie.any():
             a = got[b][tie]; w = want[b][tie]
             assert all(((a - r).abs().sum(1) < 1e-4).any() for r in w), "tied boxes differ as a set"
+
+
+def check_gemm_mask(dev, M, N, K):
+    """dX = (dY W) * [act > 0]: the ReLU mask fused into the dgrad epilogue (tf_gemm_desc.mask)."""
+    dy, w, act = R(M, N, dev=dev), R(N, K, seed=1, dev=dev) * 0.1, R(M, K, seed=2, dev=dev)
+    want = (dy @ w) * (act > 0)
+    got = ops.linear_dgrad(dy, w, mask=act)
+    close(got, want, what="masked dgrad")

@@ -133,3 +133,8 @@ def test_conv_direct_full_resolution(case):
 @pytest.mark.parametrize("case", kc.DECODE_CASES, ids=str)
 def test_centernet_decode(case):
     kc.check_centernet_decode("cuda", *case)
+
+
+@pytest.mark.parametrize("case", [(130, 72, 96), (10, 64, 32), (200, 50, 150)], ids=str)
+def test_gemm_relu_mask_epilogue(case):
+    kc.check_gemm_mask("cuda", *case)

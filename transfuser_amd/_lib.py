@@ -27,7 +27,7 @@ class GemmDesc(ctypes.Structure):
                 ("lda", c_l), ("ldb", c_l), ("ldc", c_l), ("ldres", c_l),
                 ("batch", c_i), ("inner", c_i),
                 ("sa_outer", c_l), ("sa_inner", c_l), ("sb_outer", c_l), ("sb_inner", c_l), ("sc_outer", c_l), ("sc_inner", c_l),
-                ("alpha", c_f), ("relu", c_i), ("accumulate", c_i)]
+                ("alpha", c_f), ("relu", c_i), ("accumulate", c_i), ("mask", c_p), ("ldmask", c_l)]
 
 
 class ConvGeom(ctypes.Structure):

@@ -27,7 +27,7 @@ extern "C" int tf_gemm_f32(const tf_gemm_desc* d, void* stream) {
                d->k, d->batch);
     const int inner = d->inner > 0 ? d->inner : 1;
     // per-sample matmuls (SE excitation, join MLP): rows = batch <= 16 -> streaming kernels instead of a 128-row MFMA tile
-    if (d->batch == 1 && d->alpha == 1.0f && d->m > 0 && d->n > 0 && d->k > 0) {
+    if (d->batch == 1 && d->alpha == 1.0f && d->m > 0 && d->n > 0 && d->k > 0 && !d->mask) {
         if (!d->a_trans && !d->b_trans && d->m <= 16 && !d->accumulate)
             return smallm_fwd(d->a, d->lda, d->b, d->ldb, d->bias, d->res, d->ldres, d->c, d->ldc, d->m, d->n, d->k, d->relu, stream);
         if (!d->a_trans && d->b_trans && d->m <= 16 && !d->bias && !d->relu && !(d->accumulate && d->res))
@@ -39,6 +39,8 @@ extern "C" int tf_gemm_f32(const tf_gemm_desc* d, void* stream) {
     ep.C = d->c; ep.ldc = d->ldc; ep.ldcj = 1; ep.sc_outer = d->sc_outer; ep.sc_inner = d->sc_inner; ep.inner = inner;
     ep.bias = d->bias; ep.sbias = 0; ep.res = d->res; ep.ldres = d->ldres; ep.alpha = d->alpha; ep.relu = d->relu;
     ep.mode = d->accumulate ? 1 : 0;
+    ep.mask = d->mask; ep.ldmask = d->ldmask;
+    TF_REQUIRE(!d->mask || (d->batch == 1 && !d->accumulate), "tf_gemm_f32: mask needs batch == 1 and a plain store");
     // A: KC when stored [m][k] (rows = i), IC when stored [k][m] (rows = k)
     PlainOp A = d->a_trans ? make_plain(d->a, d->lda, d->k, d->m, d->sa_outer, d->sa_inner, inner, d->batch)
                            : make_plain(d->a, d->lda, d->m, d->k, d->sa_outer, d->sa_inner, inner, d->batch);

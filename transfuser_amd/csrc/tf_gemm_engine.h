@@ -241,7 +241,8 @@ struct GemmEpi {
     const float* bias; long sbias;   // per-column bias; batch z adds z*sbias
     const float* res; long ldres;    // residual with C's batch strides
     float alpha; int relu; int mode; // mode 0: store, 1: +=, 2: atomicAdd
-    int group_m;                     // tile rasterisation: rows of tiles walked together (set by launch_cfg)
+    int group_m = 1;                 // tile rasterisation: rows of tiles walked together (set by launch_cfg)
+    const float* mask = nullptr; long ldmask = 0;   // optional ReLU mask of a backward GEMM: element (i, j) is zeroed unless mask(i, j) > 0
 };
 
 // ---------------------------------------------------------------- kernel
@@ -565,6 +566,7 @@ __device__ __forceinline__ void gemm_tile(LA& la, LB& lb, const GemmEpi& ep, int
                         float v = ep.alpha * acc[t][u][r] + bj;
                         if (RES) v += res[(long)i * ep.ldres + j];
                         v = ep.relu ? fmaxf(v, 0.f) : v;
+                        if (ep.mask) v = (ep.mask[(long)i * ep.ldmask + j] > 0.f) ? v : 0.f;
                         float* dst = C + (long)i * ep.ldc + (long)j * ep.ldcj;
                         if (MODE == 0) *dst = v;
                         else if (MODE == 1) *dst += v;

@@ -254,8 +254,7 @@ class GPTStageFn(torch.autograd.Function):
                 dres = ops.dropout(dx, gpt.seed, gpt.site(4 * li + 3), gpt.resid_pdrop)
             ops.linear_wgrad(dres, a1, gbuf(fc2.weight))
             bias_grad(dres, fc2.bias)
-            da1 = ops.linear_dgrad(dres, fc2.weight)
-            ops.relu_mask(da1, a1, out=da1)
+            da1 = ops.linear_dgrad(dres, fc2.weight, mask=a1)     # ReLU backward fused into the dgrad epilogue
             ops.linear_wgrad(da1, h2, gbuf(fc1.weight))
             bias_grad(da1, fc1.bias)
             dh2 = ops.linear_dgrad(da1, fc1.weight)

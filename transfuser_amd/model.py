@@ -108,9 +108,14 @@ class HeadsFn(torch.autograd.Function):
         db_pred = ops.colsum(dpred.view(-1, P), 1, B * H * W, P)
         dp2 = torch.empty_like(p2)
         off = 0
+        dead = getattr(model, "_dead_heads", ())   # heads whose loss weight is 0 (config.detailed_losses_weights: velocity, brake - quirk Q6):
+        first = True                               # their incoming gradient is exactly 0, so is everything their backward would add
         for i, sq in enumerate(seqs):
             k = sq[2].weight.shape[0]
             last = i == len(seqs) - 1
+            if not last and HEAD_ORDER[i] in dead:
+                off += k
+                continue
             g2 = dbev.view(-1, k) if last else dpred.view(-1, P)[:, off:off + k]
             hid = hids[i]
             Ch = hid.shape[-1]
@@ -120,11 +125,11 @@ class HeadsFn(torch.autograd.Function):
             else:
                 ops.axpby(F_.gbuf(sq[2].bias), db_pred[0, off:off + k], 1.0, 1.0, out=F_.gbuf(sq[2].bias))
                 off += k
-            dh = ops.linear_dgrad(g2, F_.w2d(sq[2].weight)).view(B, H, W, Ch)
-            ops.relu_mask(dh, hid, out=dh)
+            dh = ops.linear_dgrad(g2, F_.w2d(sq[2].weight), mask=hid.view(-1, Ch)).view(B, H, W, Ch)     # ReLU backward in the epilogue
             F_.bias_grad(dh.view(-1, Ch), sq[0].bias)
             ops.conv_wgrad(dh, p2, F_.gbuf(sq[0].weight), 1, 1, 1)
-            ops.conv_dgrad(dh, sq[0].weight, p2.shape, 1, 1, 1, out=dp2, accumulate=i > 0)
+            ops.conv_dgrad(dh, sq[0].weight, p2.shape, 1, 1, 1, out=dp2, accumulate=not first)
+            first = False
         ctx.saved = None
         return (dp2, None) + (None,) * (len(ctx.needs_input_grad) - 2)
 

@@ -144,14 +144,15 @@ def _gemm_reference(a, b, c_old, m, n, k, lda, ldb, ldc, a_trans, b_trans, bias,
 
 
 def gemm(a, b, c, m, n, k, lda, ldb, ldc, a_trans=False, b_trans=False, bias=None, res=None, ldres=0, alpha=1.0, relu=False,
-         accumulate=False, batch=1, inner=1, sa=(0, 0), sb=(0, 0), sc=(0, 0)):
+         accumulate=False, batch=1, inner=1, sa=(0, 0), sb=(0, 0), sc=(0, 0), mask=None):
     if _CHECK and c.is_cuda:
         cview = lambda: torch.as_strided(c, (batch // inner, inner, m, n), (sc[0], sc[1], ldc, 1))
         old = cview().double().clone() if accumulate else None
         ref = _gemm_reference(a, b, old, m, n, k, lda, ldb, ldc, a_trans, b_trans, bias, res, ldres, alpha, relu, accumulate, batch, inner, sa, sb, sc)
     d = GemmDesc(a=ptr(a), b=ptr(b), c=ptr(c), bias=ptr(bias), res=ptr(res), m=m, n=n, k=k, a_trans=int(a_trans), b_trans=int(b_trans),
                  lda=lda, ldb=ldb, ldc=ldc, ldres=ldres, batch=batch, inner=inner, sa_outer=sa[0], sa_inner=sa[1], sb_outer=sb[0],
-                 sb_inner=sb[1], sc_outer=sc[0], sc_inner=sc[1], alpha=alpha, relu=int(relu), accumulate=int(accumulate))
+                 sb_inner=sb[1], sc_outer=sc[0], sc_inner=sc[1], alpha=alpha, relu=int(relu), accumulate=int(accumulate), mask=ptr(mask),
+                 ldmask=mask.stride(0) if mask is not None else 0)
     _e = _census_begin()
     check(L().tf_gemm_f32(byref(d), stream_of(c)), "tf_gemm_f32")
     _census_end(_e, "gemm a%db%d" % (a_trans, b_trans), (m, n, k, batch), 2.0 * m * n * k * batch)
@@ -179,14 +180,14 @@ def linear_fwd(x, w, bias=None, relu=False, res=None, out=None):
                 ldres=res.stride(0) if res is not None else 0, relu=relu)
 
 
-def linear_dgrad(dy, w, out=None, accumulate=False, res=None):
-    """dx = dy @ w (+res); dy (M, N), w (N, K)."""
+def linear_dgrad(dy, w, out=None, accumulate=False, res=None, mask=None):
+    """dx = dy @ w (+res); dy (M, N), w (N, K).  mask (M, K): dx is zeroed where mask <= 0 (fused ReLU backward)."""
     M, N = dy.shape
     K = w.shape[1]
     if out is None:
         out = torch.empty(M, K, dtype=torch.float32, device=dy.device)
     return gemm(dy, w, out, M, K, N, dy.stride(0), w.stride(0), out.stride(0), b_trans=True, accumulate=accumulate, res=res,
-                ldres=res.stride(0) if res is not None else 0)
+                ldres=res.stride(0) if res is not None else 0, mask=mask)
 
 
 def linear_wgrad(dy, x, dw, accumulate=True):

@@ -175,6 +175,11 @@ class Engine:
         self.reducer.broadcast_params()
         w = [1.0] + [0.0] * 10 if wp_only else list(config.detailed_losses_weights)
         self.detailed_weights = dict(zip(config.detailed_losses, w))
+        # a head whose loss has weight 0 receives an exactly-zero gradient: its backward kernels are skipped (the gradients stay 0,
+        # AdamW still applies weight decay to it, exactly as in the reference)
+        loss_to_head = dict(zip(("loss_center_heatmap", "loss_wh", "loss_offset", "loss_yaw_class", "loss_yaw_res", "loss_velocity", "loss_brake"),
+                                ("heatmap_head", "wh_head", "offset_head", "yaw_class_head", "yaw_res_head", "velocity_head", "brake_head")))
+        model._dead_heads = frozenset(h for k, h in loss_to_head.items() if self.detailed_weights.get(k, 1.0) == 0.0)
         self.use_graph = use_graph
         self._graph = None
         self._static = None
