@@ -242,7 +242,9 @@ class GeometricFusionBackbone(TransfuserBackbone):
         pts = pts.reshape(B, h * w * 5, 2)
         b = torch.arange(B).view(B, 1).expand(B, h * w * 5)
         g = emb.permute(0, 2, 3, 1)[b, pts[..., 1], pts[..., 0]]            # (B, h*w*5, E)
-        return g.view(B, h, w, 5, E).sum(3)                                 # (B, h, w, E)   (sum over the 5 points, :136)
+        # same memory layout as the reference before its sum (:135-136: (B, E, h, w, 5) contiguous, reduced over the last axis), so the
+        # 5-term additions associate identically -> bit-exact against the reference import
+        return g.view(B, h, w, 5, E).permute(0, 4, 1, 2, 3).contiguous().sum(-1).permute(0, 2, 3, 1)
 
     def forward(self, image, lidar, velocity, bev_points, img_points):
         im, li = self.image_encoder.features, self.lidar_encoder._model
