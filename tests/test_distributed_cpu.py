@@ -1,5 +1,6 @@
 """Data-parallel path on CPU: world_size 2, gloo.  Checks the arena layout (k/q/v adjacency), the bucketed gradient
-mean (== DDP semantics of train.py:134) and the initial parameter broadcast of transfuser_amd.train.GradReducer."""
+mean (== DDP semantics of train.py:134), the initial parameter broadcast of transfuser_amd.train.GradReducer and the ZeRO-1
+sharded optimizer (train.py:138-140)."""
 import os
 import sys
 
@@ -56,6 +57,20 @@ def _worker(rank, world, port):
     red.reduce()
     assert torch.allclose(arena.grads, (both[0] + both[1]) / world, atol=1e-6)
     assert torch.allclose(net.head.weight.grad, ((both[0] + both[1]) / world)[net.head.weight.grad.storage_offset():][:60].view(5, 12), atol=1e-6)
+    # ZeRO-1 (--zero_redundancy_optimizer 1, train.py:138-140): sharded AdamW + slice broadcast == full AdamW on every rank
+    from transfuser_amd.train import FlatAdamW
+    p0 = arena.params.clone()
+    full_opt = FlatAdamW(arena, lr=1e-2)
+    for _ in range(2):
+        full_opt.step()
+    full = arena.params.clone()
+    arena.params.copy_(p0)
+    z = FlatAdamW(arena, lr=1e-2, shard=(rank, world))
+    assert z.exp_avg.numel() <= (arena.active_numel + world - 1) // world + 64 and z.exp_avg.numel() < full_opt.exp_avg.numel()
+    for _ in range(2):
+        z.step()
+        red.all_gather_params(z)
+    assert torch.equal(arena.params, full)
     dist.destroy_process_group()
 
 

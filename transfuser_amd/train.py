@@ -78,13 +78,26 @@ class ParamArena:
 
 
 class FlatAdamW:
-    """torch.optim.AdamW(lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01) over a ParamArena."""
+    """torch.optim.AdamW(lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01) over a ParamArena.
 
-    def __init__(self, arena, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01):
+    ``shard=(rank, world)`` = the reference's ``--zero_redundancy_optimizer 1`` (train.py:143-146, ZeRO stage 1): every rank keeps the
+    AdamW moments of - and updates - only its contiguous 1/world slice of the arena; ``GradReducer.all_gather_params`` then circulates
+    the updated slices (what ZeroRedundancyOptimizer's parameter broadcast does).  Same parameter trajectory, 1/world of the state."""
+
+    def __init__(self, arena, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, shard=None):
         self.arena = arena
         self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
-        self.exp_avg = torch.zeros_like(arena.params)
-        self.exp_avg_sq = torch.zeros_like(arena.params)
+        n = arena.active_numel
+        self.lo, self.hi = 0, n
+        if shard is not None and shard[1] > 1:
+            rank, world = shard
+            per = (n + world - 1) // world
+            per = (per + _ALIGN - 1) // _ALIGN * _ALIGN       # slices stay 256-byte aligned
+            self.lo, self.hi = min(n, rank * per), min(n, (rank + 1) * per)
+            self.shard_size = per
+        m = self.hi - self.lo
+        self.exp_avg = torch.zeros(m, dtype=torch.float32, device=arena.params.device)
+        self.exp_avg_sq = torch.zeros_like(self.exp_avg)
         self.state = torch.tensor([0.0, lr], dtype=torch.float32, device=arena.params.device)  # {step, lr} on the device
 
     def set_lr(self, lr):
@@ -94,8 +107,9 @@ class FlatAdamW:
         self.arena.zero_grad()
 
     def step(self):
-        a, n = self.arena, self.arena.active_numel
-        ops.adamw_(a.params[:n], a.grads[:n], self.exp_avg[:n], self.exp_avg_sq[:n], self.state, self.betas[0], self.betas[1], self.eps, self.weight_decay)
+        a = self.arena
+        ops.adamw_(a.params[self.lo:self.hi], a.grads[self.lo:self.hi], self.exp_avg, self.exp_avg_sq, self.state, self.betas[0], self.betas[1],
+                   self.eps, self.weight_decay)
 
     def state_dict(self):
         return dict(exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, state=self.state)
@@ -124,6 +138,16 @@ class GradReducer:
         """DDP's initial parameter broadcast (rank 0 -> all)."""
         if self.world > 1:
             dist.broadcast(self.arena.params, src, group=self.group)
+
+    def all_gather_params(self, optimizer):
+        """ZeRO-1: after the sharded AdamW step every rank broadcasts its updated slice (rank r owns [r*per, (r+1)*per))."""
+        if self.world == 1 or not hasattr(optimizer, "shard_size"):
+            return
+        p, per, n = self.arena.params, optimizer.shard_size, self.arena.active_numel
+        for r in range(self.world):
+            lo, hi = min(n, r * per), min(n, (r + 1) * per)
+            if hi > lo:
+                dist.broadcast(p[lo:hi], r, group=self.group)
 
     def reduce(self):
         if self.world == 1:
@@ -161,7 +185,8 @@ class Engine:
     BATCH_KEYS = ("rgb", "lidar", "ego_waypoint", "target_point", "target_point_image", "ego_vel", "bev", "label", "depth", "semantic")
     GEO_KEYS = ("bev_points", "cam_points")   # train.py:280-288 (geometric_fusion only)
 
-    def __init__(self, model, config, lr=1e-4, use_graph=False, group=None, bucket_mb=64.0, wp_only=False, autotune=True, plan_file=None):
+    def __init__(self, model, config, lr=1e-4, use_graph=False, group=None, bucket_mb=64.0, wp_only=False, autotune=True, plan_file=None,
+                 zero_redundancy_optimizer=False):
         self.model = model
         self.config = config
         self._autotune_pending = bool(autotune) and next(model.parameters()).is_cuda
@@ -170,8 +195,10 @@ class Engine:
         if next(model.parameters()).is_cuda and os.path.exists(plan_file):
             ops.plans_load(plan_file)
         self.arena = ParamArena(model)
-        self.optimizer = FlatAdamW(self.arena, lr=lr)
         self.reducer = GradReducer(self.arena, group, bucket_mb)
+        self.zero = bool(zero_redundancy_optimizer) and self.reducer.world > 1      # train.py:143-146
+        rank = dist.get_rank(group) if self.zero else 0
+        self.optimizer = FlatAdamW(self.arena, lr=lr, shard=(rank, self.reducer.world) if self.zero else None)
         self.reducer.broadcast_params()
         w = [1.0] + [0.0] * 10 if wp_only else list(config.detailed_losses_weights)
         self.detailed_weights = dict(zip(config.detailed_losses, w))
@@ -223,6 +250,8 @@ class Engine:
             out = self._fwd_bwd(data)
             self.reducer.reduce()
             self.optimizer.step()
+            if self.zero:
+                self.reducer.all_gather_params(self.optimizer)
             self._bump_seed()
             return out
         if self._graph is None:
@@ -235,6 +264,8 @@ class Engine:
         if self.reducer.world > 1:
             self.reducer.reduce()
             self._opt_graph.replay()
+            if self.zero:
+                self.reducer.all_gather_params(self.optimizer)
         return self._out
 
     def _capture(self, data):
@@ -248,6 +279,8 @@ class Engine:
                 self._fwd_bwd(self._static)
                 self.reducer.reduce()
                 self.optimizer.step()
+                if self.zero:
+                    self.reducer.all_gather_params(self.optimizer)
                 self._bump_seed()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
