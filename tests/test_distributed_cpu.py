@@ -1,6 +1,6 @@
 """Data-parallel path on CPU: world_size 2, gloo.  Checks the arena layout (k/q/v adjacency), the bucketed gradient
 mean (== DDP semantics of train.py:134), the initial parameter broadcast of transfuser_amd.train.GradReducer and the ZeRO-1
-sharded optimizer (train.py:138-140)."""
+sharded optimizer (train.py:138-140) and SyncBatchNorm (train.py:132-133)."""
 import os
 import sys
 
@@ -71,6 +71,34 @@ def _worker(rank, world, port):
         z.step()
         red.all_gather_params(z)
     assert torch.equal(arena.params, full)
+    # SyncBatchNorm (--sync_batch_norm 1, train.py:132-133): statistics over both ranks == BatchNorm over the concatenated batch
+    import torch.nn.functional as Fn
+    from transfuser_amd import functions as F_
+    C = 12
+    gen = torch.Generator().manual_seed(3)
+    xs = [torch.randn(rows, C, generator=gen) * 2 + 1 for rows in (24, 40)]         # unequal per-rank batch sizes
+    dzs = [torch.randn(x.shape, generator=gen) for x in xs]
+    gamma, beta = torch.rand(C, generator=gen) + 0.5, torch.randn(C, generator=gen)
+    bn = torch.nn.BatchNorm2d(C)
+    with torch.no_grad():
+        bn.weight.copy_(gamma); bn.bias.copy_(beta)
+    bn.train()
+    F_.convert_sync_batchnorm(bn)
+    x, dz = xs[rank].contiguous(), dzs[rank].contiguous()
+    y, st = F_._bn(x, bn, relu=True)
+    dx, _ = F_._bn_bwd(dz, y, x, bn, st)
+    xa = torch.cat(xs).requires_grad_(True)
+    ga, ba = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm, rv = torch.zeros(C), torch.ones(C)
+    ya = torch.relu(Fn.batch_norm(xa, rm, rv, ga, ba, True, 0.1, 1e-5))
+    gxa, gga, gba = torch.autograd.grad(ya, [xa, ga, ba], torch.cat(dzs))
+    lo = 0 if rank == 0 else xs[0].shape[0]
+    assert torch.allclose(y, ya[lo:lo + x.shape[0]], atol=1e-5), (y - ya[lo:lo + x.shape[0]]).abs().max()
+    assert torch.allclose(dx, gxa[lo:lo + x.shape[0]], atol=1e-5), (dx - gxa[lo:lo + x.shape[0]]).abs().max()
+    assert torch.allclose(bn.running_mean, rm, atol=1e-6) and torch.allclose(bn.running_var, rv, atol=1e-5)
+    pg = torch.stack([bn.weight.grad, bn.bias.grad])
+    dist.all_reduce(pg)                                                              # local parameter gradients add up to the full-batch ones
+    assert torch.allclose(pg[0], gga, atol=1e-4) and torch.allclose(pg[1], gba, atol=1e-4)
     dist.destroy_process_group()
 
 

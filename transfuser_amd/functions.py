@@ -34,12 +34,77 @@ def bias_grad(dy2d, b, mask2d=None):
 
 
 def _bn(x, bn, res=None, relu=False):
+    grp = getattr(bn, "_sync_group", None)
+    if grp is not None and bn.training:
+        return _bn_sync_fwd(x, bn, res, relu, grp)
     y, sm, si = ops.bn_fwd(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, res, relu, bn.training, bn.momentum, bn.eps)
     return y, (sm, si)
 
 
 def _bn_bwd(dz, z, x, bn, st, want_dres=False):
+    if len(st) == 4:
+        return _bn_sync_bwd(dz, z, x, bn, st, want_dres)
     return ops.bn_bwd(dz, z, x, bn.weight, st[0], st[1], gbuf(bn.weight), gbuf(bn.bias), want_dres)
+
+
+# ---- SyncBatchNorm (--sync_batch_norm 1, train.py:132-133 = torch.nn.SyncBatchNorm.convert_sync_batchnorm): batch statistics over ALL
+# ranks.  Composed from the existing kernels plus two tiny collectives per layer; the per-channel algebra between them runs on (C,)
+# tensors.  Not hipGraph-capturable (collectives between kernels): the Engine runs eagerly with this flag.
+def convert_sync_batchnorm(model, group=None):
+    import torch.distributed as dist
+    grp = group if group is not None else dist.group.WORLD
+    for m in model.modules():
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            m._sync_group = grp
+    return model
+
+
+def _bn_sync_fwd(x, bn, res, relu, grp):
+    import torch.distributed as dist
+    C = x.shape[-1]
+    n = x.numel() // C
+    _, m_loc, i_loc = ops.bn_fwd(x, bn.weight, bn.bias, None, None, None, False, True, bn.momentum, bn.eps)     # local mean / invstd only
+    world = dist.get_world_size(grp)
+    mine = torch.cat([m_loc.double(), (1.0 / (i_loc.double() * i_loc.double()) - bn.eps).clamp_(min=0.0), torch.full((1,), float(n), dtype=torch.float64, device=x.device)])
+    allst = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(allst, mine, group=grp)
+    cnt = torch.stack([t[2 * C] for t in allst])                       # (world,)
+    means = torch.stack([t[:C] for t in allst]); varis = torch.stack([t[C:2 * C] for t in allst])
+    N = cnt.sum()
+    mean = (means * cnt[:, None]).sum(0) / N                           # Chan's parallel combination, in fp64
+    var = ((varis + (means - mean) ** 2) * cnt[:, None]).sum(0) / N    # biased variance of the global batch
+    mean32, var32 = mean.float(), var.float()
+    y, _, _ = ops.bn_fwd(x, bn.weight, bn.bias, mean32, var32, res, relu, False, bn.momentum, bn.eps)           # normalise with the global statistics
+    if bn.running_mean is not None:
+        with torch.no_grad():
+            mom = bn.momentum
+            Nf = float(N)
+            bn.running_mean.mul_(1 - mom).add_(mean32, alpha=mom)
+            bn.running_var.mul_(1 - mom).add_(var32 * (Nf / (Nf - 1)) if Nf > 1 else var32, alpha=mom)
+    invstd = (1.0 / torch.sqrt(var + bn.eps)).float()
+    return y, (mean32, invstd, float(N), grp)
+
+
+def _bn_sync_bwd(dz, z, x, bn, st, want_dres):
+    import torch.distributed as dist
+    mean, invstd, N, grp = st
+    C = x.shape[-1]
+    n = x.numel() // C
+    loc = torch.zeros(2, C, dtype=torch.float32, device=x.device)      # [sum g * xhat, sum g] of THIS rank
+    dx_loc, dres = ops.bn_bwd(dz, z, x, bn.weight, mean, invstd, loc[0], loc[1], want_dres)
+    ops.axpby(gbuf(bn.weight), loc[0], 1.0, 1.0, out=gbuf(bn.weight))  # local parameter gradients; the gradient all-reduce averages them
+    ops.axpby(gbuf(bn.bias), loc[1], 1.0, 1.0, out=gbuf(bn.bias))
+    tot = loc.clone()
+    dist.all_reduce(tot, group=grp)
+    # dx = A (g - S/N - xhat T/N) with the GLOBAL sums; bn_bwd used the local ones (s/n, t/n): add the per-channel affine correction c1 x + c0
+    A = bn.weight.detach() * invstd
+    dT = tot[0] / N - loc[0] / n
+    dS = tot[1] / N - loc[1] / n
+    c1 = -A * invstd * dT
+    c0 = -A * dS - c1 * mean
+    ones = torch.full_like(c1, 1.0 - bn.eps)
+    dx, _, _ = ops.bn_fwd(x, c1.contiguous(), c0.contiguous(), torch.zeros_like(c1), ones, dx_loc, False, False, bn.momentum, bn.eps)
+    return dx, dres
 
 
 # ============================================================================================ stem

@@ -186,7 +186,7 @@ class Engine:
     GEO_KEYS = ("bev_points", "cam_points")   # train.py:280-288 (geometric_fusion only)
 
     def __init__(self, model, config, lr=1e-4, use_graph=False, group=None, bucket_mb=64.0, wp_only=False, autotune=True, plan_file=None,
-                 zero_redundancy_optimizer=False):
+                 zero_redundancy_optimizer=False, sync_batch_norm=False):
         self.model = model
         self.config = config
         self._autotune_pending = bool(autotune) and next(model.parameters()).is_cuda
@@ -194,6 +194,10 @@ class Engine:
             plan_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "plans", "mi355x.txt")
         if next(model.parameters()).is_cuda and os.path.exists(plan_file):
             ops.plans_load(plan_file)
+        if sync_batch_norm and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:   # train.py:132-133
+            from .functions import convert_sync_batchnorm
+            convert_sync_batchnorm(model, group)
+            use_graph = False       # collectives between the BatchNorm kernels: eager only
         self.arena = ParamArena(model)
         self.reducer = GradReducer(self.arena, group, bucket_mb)
         self.zero = bool(zero_redundancy_optimizer) and self.reducer.world > 1      # train.py:143-146
