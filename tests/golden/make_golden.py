@@ -122,9 +122,124 @@ def pillar_golden(ref_mod):
     return out
 
 
+# ---------------------------------------------------------------- model.py (LidarCenterNet / LidarCenterNetHead), rows a9-a13 + f1
+def model_config(lidar_res=64):
+    """Toy-size LidarCenterNet config shared by the golden generator and the pinning tests (tests/model_cases.tiny_config values)."""
+    cfg = golden_config()
+    cfg.lidar_resolution_width = cfg.lidar_resolution_height = lidar_res
+    cfg.bev_resolution_width = cfg.bev_resolution_height = 40
+    return cfg
+
+
+def model_batch(B=2, H=32, W=64, lidar_res=64, bev_res=40, seed=0):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import model_cases as mc
+    return mc.small_batch(B, H, W, lidar_res, bev_res, seed)
+
+
+def target_labels(res=64):
+    """(3, 20, 7) label tensor exercising get_targets (model.py:285-374): ignored all-zero rows, Gaussians clipped at every border,
+    two boxes landing on the same cell (later row overwrites), a tiny box (radius clamps to 2), yaw at the bin edges / negative, brake 0/1."""
+    lab = torch.zeros(3, 20, 7)
+    rows = [  # x, y, w, h, yaw, speed, brake   (pixels of the res x res BEV frame)
+        (0.4, 0.7, 9.0, 5.0, 0.0, 1.5, 0), (res - 0.6, res - 0.3, 12.0, 20.0, 3.1, 0.0, 1), (0.9, res - 1.2, 4.0, 4.0, -3.1, 7.9, 0),
+        (res - 1.1, 1.9, 30.0, 8.0, 1.5707963, 2.0, 1), (31.2, 17.9, 1.0, 1.0, -0.2617994, 3.0, 0), (31.9, 17.1, 16.0, 6.0, 0.2617994, 4.0, 1),
+        (12.49, 40.51, 7.5, 7.5, 2.8797933, 5.5, 0), (50.0, 50.0, 63.0, 63.0, -1.0, 6.5, 1)]
+    for i, r in enumerate(rows):
+        lab[0, i] = torch.tensor(r)
+    lab[0, 10] = torch.tensor((20.3, 9.6, 10.0, 3.0, 0.7, 1.0, 1))          # after a gap of ignored rows
+    g = torch.Generator().manual_seed(5)
+    k = 20                                                                   # sample 1: all 20 rows real
+    lab[1, :, 0:2] = torch.rand(k, 2, generator=g) * (res - 1)
+    lab[1, :, 2:4] = torch.rand(k, 2, generator=g) * (res / 4) + 1
+    lab[1, :, 4] = torch.rand(k, generator=g) * 6.2831853 - 3.1415926
+    lab[1, :, 5] = torch.rand(k, generator=g) * 8
+    lab[1, :, 6] = (torch.rand(k, generator=g) < 0.5).float()
+    return lab                                                               # sample 2: no boxes at all (avg_factor -> max(1, 0))
+
+
+def head_preds(B=3, res=16, nbins=12, seed=3):
+    g = torch.Generator().manual_seed(seed)
+    r = lambda c: torch.randn(B, c, res, res, generator=g)
+    return [r(1).sigmoid(), r(2) * 3, r(2), r(nbins), r(1), r(1) * 2, r(2)]
+
+
+MODEL_GRAD_KEYS = ("head.heatmap_head.0.weight", "head.heatmap_head.2.bias", "head.wh_head.2.weight", "head.offset_head.0.bias",
+                   "head.yaw_class_head.2.weight", "head.yaw_res_head.2.weight", "head.velocity_head.2.bias", "head.brake_head.2.weight",
+                   "pred_bev.0.weight", "pred_bev.2.bias", "join.0.weight", "join.4.bias", "decoder.weight_ih", "decoder.weight_hh",
+                   "decoder.bias_ih", "decoder.bias_hh", "output.weight", "output.bias", "seg_decoder.deconv1.2.weight", "depth_decoder.deconv3.2.weight",
+                   "_model.transformer1.pos_emb", "_model.transformer4.blocks.1.attn.proj.weight", "_model.change_channel_conv_image.weight",
+                   "_model.image_encoder.features.s1.b1.conv1.conv.weight", "_model.lidar_encoder._model.s2.b1.conv2.conv.weight", "_model.up_conv3.weight")
+LOSS_WEIGHTS = [1.0, 1.0, 1.0, 1.0, 0.2, 0.2, 0.2, 0.2, 0.2, 0.3, 0.4]      # non-zero everywhere so every head gets a gradient
+
+
+def call_model(m, b):
+    return m(b['rgb'], b['lidar'], ego_waypoint=b['ego_waypoint'], target_point=b['target_point'], target_point_image=b['target_point_image'],
+             ego_vel=b['ego_vel'].reshape(-1, 1), bev=b['bev'], label=b['label'], depth=b['depth'], semantic=b['semantic'])
+
+
+def model_golden(ref_model):
+    """The reference's OWN model.py (imported unmodified over oracle/{mm,timm,scatter}_shim): LidarCenterNet.forward losses + gradients,
+    LidarCenterNetHead.get_targets / loss / decode_heatmap, forward_gru, forward_ego + get_bbox_local_metric, control_pid."""
+    out = {}
+    cfg = model_config()
+    torch.manual_seed(0)
+    m = ref_model.LidarCenterNet(cfg, 'cpu', 'transFuser', 'regnety_tiny', 'regnety_tiny', use_velocity=False)
+    seeded_fill(m, 4321)
+    m.train()
+    b = model_batch()
+    losses = call_model(m, b)
+    assert set(losses) == set(cfg.detailed_losses) and len(losses) == 11
+    sum(w * losses[k] for w, k in zip(LOSS_WEIGHTS, cfg.detailed_losses)).backward()
+    out["model_losses"] = np.array([float(losses[k]) for k in cfg.detailed_losses], np.float64)
+    named = dict(m.named_parameters())
+    for k in MODEL_GRAD_KEYS:
+        out["model_grad_" + k] = named[k].grad.numpy()
+    names = sorted(n for n, p in named.items() if p.grad is not None)
+    out["model_grad_norms"] = np.array([named[n].grad.double().norm().item() for n in names])
+    out["model_grad_names"] = np.array(names)
+    # --- get_targets (model.py:285-374) on the crafted labels, 16x16 map of a 64x64 frame
+    lab = target_labels()
+    t, af = m.head.get_targets([lab], [torch.zeros_like(lab[:, :, 0])], [lab.sum(-1) == 0.], (3, 1, 16, 16))
+    for k, v in t.items():
+        out["tgt_" + k] = v.numpy()
+    out["tgt_avg_factor"] = np.array([int(af)])
+    # --- loss (model.py:150-248) on random predictions
+    preds = head_preds()
+    l = m.head.loss(*[[p] for p in preds], [lab], gt_labels=[torch.zeros_like(lab[:, :, 0])], gt_bboxes_ignore=[lab.sum(-1) == 0.], img_metas=None)
+    out["head_losses"] = np.array([float(l[k]) for k in ("loss_center_heatmap", "loss_wh", "loss_offset", "loss_yaw_class", "loss_yaw_res",
+                                                         "loss_velocity", "loss_brake")], np.float64)
+    # --- decode_heatmap / get_bboxes (model.py:376-497)
+    cfg.top_k_center_keypoints = 20
+    res = m.head.get_bboxes(*[[p] for p in preds])
+    out["decode_boxes"] = torch.stack([r[0] for r in res]).numpy()
+    out["decode_labels"] = torch.stack([r[1] for r in res]).numpy()
+    # --- forward_gru (model.py:611-646)
+    g = torch.Generator().manual_seed(8)
+    z, tp = torch.randn(3, 512, generator=g), torch.randn(3, 2, generator=g) * 10
+    with torch.no_grad():
+        out["gru_wp"] = m.forward_gru(z, tp)[0].numpy()
+    # --- forward_ego (model.py:685-731) incl. get_bbox_local_metric (:810-843); eval mode, batch of one
+    m.eval()
+    cfg.bb_confidence_threshold = 0.0
+    with torch.no_grad():
+        wp, boxes = m.forward_ego(b['rgb'][:1], b['lidar'][:1], b['target_point'][:1], b['target_point_image'][:1], b['ego_vel'][:1].reshape(-1, 1))
+    out["ego_wp"] = wp.numpy()
+    out["ego_boxes"] = np.stack([bb[0] for bb in boxes])
+    out["ego_brake_conf"] = np.array([[bb[1], bb[2]] for bb in boxes])
+    # --- control_pid (model.py:648-683): three successive calls (the PID controllers keep state)
+    pid = []
+    for i in range(3):
+        s, t_, br = m.control_pid(wp + 0.5 * i, torch.tensor([1.0 + i]), bool(i == 2))
+        pid.append([float(s), float(t_), float(br)])
+    out["ego_pid"] = np.array(pid)
+    return out
+
+
 def main():
     sys.path.insert(0, os.path.join(ROOT, "oracle", "scatter_shim"))
     sys.path.insert(0, os.path.join(ROOT, "oracle", "timm_shim"))
+    sys.path.insert(0, os.path.join(ROOT, "oracle", "mm_shim"))
     sys.path.insert(0, "/root/reference/team_code_transfuser")
     import timm
     from oracle import regnet as oreg, hist
@@ -159,6 +274,8 @@ def main():
     np.savez_compressed(os.path.join(HERE, "geometric_fusion_tiny.npz"), **geo_golden(ref_geo))
     import point_pillar as ref_pp        # the reference module, unmodified (torch_scatter = oracle/scatter_shim)
     np.savez_compressed(os.path.join(HERE, "point_pillar.npz"), **pillar_golden(ref_pp))
+    import model as ref_model            # the reference module, unmodified (cv2 / torchvision / mmcv / mmdet = oracle/mm_shim)
+    np.savez_compressed(os.path.join(HERE, "lidar_centernet_tiny.npz"), **model_golden(ref_model))
     # H1: numpy.histogramdd (the reference's algorithm, data.py:446-470) on a seeded cloud with edge cases -> sparse golden
     rng = np.random.default_rng(3)
     pts = np.stack([rng.uniform(-20, 20, 20000), rng.uniform(-36, 4, 20000), rng.uniform(-4, 1, 20000)], 1).astype(np.float32)
