@@ -27,7 +27,8 @@ const char* tf_last_error(void);
  * (entry point, M, N, K, batch) times the candidate tilings with HIP events and caches the winner.  Plans can be
  * saved to / loaded from a text file (tf_plans_load returns the number of plans read). */
 int tf_autotune(int enable);
-int tf_force_plan(int bm, int bn, int bk, int splitk); /* tests: pin one tiling (bm = 0 clears) */
+int tf_force_plan(int bm, int bn, int bk, int splitk); /* tests: pin one tiling of the register-staged kernel (bm = 0 clears) */
+int tf_force_dma(int kind, int splitk);                /* tests: pin LDS-DMA configuration `kind` (1..5, tf_gemm_dma.h) for every eligible call */
 int tf_plans_count(void);
 int tf_plans_clear(void);
 int tf_plans_save(const char* path);

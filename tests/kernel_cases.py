@@ -571,6 +571,43 @@ def check_engine_plan(dev, bm, bn, bk, splitk):
         ops.force_plan(0)
 
 
+# ---------------------------------------------------------------- LDS-DMA GEMM configurations (tf_gemm_dma.h), kind 1..5 (+ split-K)
+DMA_KINDS = [(1, 1), (2, 1), (3, 1), (4, 1), (5, 1), (2, 3), (1, 2)]
+DMA_SHAPES_SMALL = [(130, 216, 40), (200, 92, 152), (70, 36, 20)]
+DMA_SHAPES_GPU = [(1740, 1512, 576), (333, 700, 1028), (130, 216, 40), (64, 64, 16), (1740, 216, 864)]
+
+
+def check_gemm_dma(dev, kind, splitk, shapes):
+    """Every operand layout (nt / nn / tn / tt) of the LDS-DMA kernels with ragged M / N / K (k % 16 != 0: zero-filled tails through the
+    buffer bounds check), the full epilogue (bias + residual + ReLU, masked store, accumulate, split-K atomics) and batched strides."""
+    ops.force_dma(kind, splitk)
+    try:
+        for (m, n, k) in shapes:
+            check_gemm(dev, m, n, k)                       # nt fwd (bias+res+relu), nn dgrad (+ strided view), tn wgrad accumulate (split-K)
+            check_gemm_mask(dev, m, n, k)
+            a, b = R(m, k, dev=dev), R(k, n, seed=4, dev=dev)
+            c = torch.empty(m, n, device=dev)
+            ops.gemm(a, b, c, m, n, k, k, n, n, b_trans=True)                                  # nn
+            close(c, a @ b, what="dma nn")
+            at = a.t().contiguous()                                                            # (k, m)
+            ops.gemm(at, b.t().contiguous(), c, m, n, k, m, k, n, a_trans=True)               # tt: A^T stored [k][m], B stored [n][k]
+            close(c, a @ b, what="dma tt")
+            ops.gemm(at, b, c, m, n, k, m, n, n, a_trans=True, b_trans=True, alpha=0.5)      # tn
+            close(c, 0.5 * (a @ b), what="dma tn")
+        # batched (outer, inner) strides as the attention GEMMs use them, 16-byte aligned head slices
+        B_, nh, T, hs = 2, 2, 52, 24
+        C = nh * hs
+        qkv = R(B_, T, 3 * C, dev=dev, scale=0.5)
+        att = torch.zeros(B_ * nh, T, T, device=dev)
+        q, kk = qkv[..., :C], qkv[..., C:2 * C]
+        sa = (T * 3 * C, hs)
+        ops.gemm(q, kk, att, T, T, hs, 3 * C, 3 * C, T, alpha=0.25, batch=B_ * nh, inner=nh, sa=sa, sb=sa, sc=(nh * T * T, T * T))
+        qh, kh = [t.reshape(B_, T, nh, hs).transpose(1, 2) for t in (q, kk)]
+        close(att.view(B_, nh, T, T), 0.25 * (qh @ kh.transpose(-2, -1)), what="dma batched")
+    finally:
+        ops.force_plan(0)
+
+
 # ---------------------------------------------------------------- inference decode (SURVEY.md 8f-1)
 DECODE_CASES = [(2, 64, 64, 12, 100), (1, 16, 20, 12, 30), (3, 8, 8, 4, 64)]
 

@@ -94,6 +94,11 @@ def test_engine_tilings(plan):
     kc.check_engine_plan("cpu", *plan)
 
 
+@pytest.mark.parametrize("cfg", kc.DMA_KINDS, ids=str)
+def test_gemm_dma_configurations(cfg):
+    kc.check_gemm_dma("cpu", cfg[0], cfg[1], kc.DMA_SHAPES_SMALL)
+
+
 @pytest.mark.parametrize("case", kc.GATHER_CASES, ids=str)
 def test_gather_sum(case):
     kc.check_gather_sum("cpu", *case)

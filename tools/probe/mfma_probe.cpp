@@ -8,15 +8,16 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 template <int ACC, int MODE>
-__global__ void __launch_bounds__(256) probe(float* out, int iters) {
+__global__ void __launch_bounds__(256) probe(float* out, int iters, int rnd) {
     __shared__ float lds[2][16][132];
     const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
-    for (int i = threadIdx.x; i < 2 * 16 * 132; i += 256) (&lds[0][0][0])[i] = (float)(i & 7) * 0.001f;
+    for (int i = threadIdx.x; i < 2 * 16 * 132; i += 256) { unsigned h = (unsigned)i * 2654435761u + blockIdx.x * 40503u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        (&lds[0][0][0])[i] = rnd ? (float)(int)(h & 0xffffff) * (1.0f / 8388608.0f) - 1.0f : (float)(i & 7) * 0.001f; }
     __syncthreads();
     f32x16 acc[ACC];
     for (int a = 0; a < ACC; ++a)
         for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
-    float a0 = lane * 0.01f, b0 = lane * 0.02f;
+    float a0 = rnd ? lds[0][lane & 15][lane] : lane * 0.01f, b0 = rnd ? lds[1][lane & 15][lane + 64] : lane * 0.02f;
     for (int it = 0; it < iters; ++it) {
         const int cur = it & 1;
         if (MODE == 0) {
@@ -49,24 +50,25 @@ __global__ void __launch_bounds__(256) probe(float* out, int iters) {
 }
 
 template <int ACC, int MODE>
-void run(int wps, float* d) {
+void run(int wps, float* d, int rnd) {
     const int iters = 4000, blocks = 256 * wps;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    probe<ACC, MODE><<<blocks, 256>>>(d, 10);
+    probe<ACC, MODE><<<blocks, 256>>>(d, 10, rnd);
     hipEventRecord(e0);
-    probe<ACC, MODE><<<blocks, 256>>>(d, iters);
+    probe<ACC, MODE><<<blocks, 256>>>(d, iters, rnd);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     const double flops = (double)blocks * 4 * iters * 8 * ACC * 4096.0;
-    printf("acc=%d mode=%d waves/SIMD=%d: %.1f TFLOP/s (%.2f ms)\n", ACC, MODE, wps, flops / ms / 1e9, ms);
+    printf("acc=%d mode=%d waves/SIMD=%d %s: %.1f TFLOP/s (%.2f ms)\n", ACC, MODE, wps, rnd ? "random operands" : "constant operands", flops / ms / 1e9, ms);
 }
 
 int main() {
     float* d; hipMalloc(&d, 1024);
-    for (int wps = 1; wps <= 4; ++wps) {
-        run<1, 0>(wps, d); run<2, 0>(wps, d); run<4, 0>(wps, d);
-        run<1, 1>(wps, d); run<4, 1>(wps, d);
-        run<1, 2>(wps, d); run<4, 2>(wps, d);
-    }
+    for (int rnd = 0; rnd <= 1; ++rnd)      // DVFS: identical instruction stream, constant vs random operand bits
+        for (int wps = 1; wps <= 4; ++wps) {
+            run<1, 0>(wps, d, rnd); run<2, 0>(wps, d, rnd); run<4, 0>(wps, d, rnd);
+            run<1, 1>(wps, d, rnd); run<4, 1>(wps, d, rnd);
+            run<1, 2>(wps, d, rnd); run<4, 2>(wps, d, rnd);
+        }
     return 0;
 }

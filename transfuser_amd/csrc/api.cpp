@@ -40,14 +40,24 @@ void plan_store(const char* what, int M, int N, int K, int batch, int acc, const
     g_plans[PlanKey(what, M, N, K, batch, acc)] = p;
 }
 bool autotune_enabled() { return g_autotune; }
-static GemmPlan g_forced{0, 0, 0, 0};
+static GemmPlan g_forced{0, 0, 0, 0, 0};
 bool forced_plan(GemmPlan* out) { if (g_forced.bm == 0) return false; *out = g_forced; return true; }
 }  // namespace tf
 
+static bool plan_tile_ok(int bm, int bn, int bk, int sk, int kind) {
+    if (kind != 0) { const tf::DmaKindInfo ki = tf::dma_kind_info(kind); return kind >= 1 && kind <= tf::kDmaKinds && sk >= 1 && ki.bm == bm && ki.bn == bn && ki.bk == bk; }
+    return ((bm == 128 && (bn == 32 || bn == 64 || bn == 96 || bn == 128)) || (bm == 64 && (bn == 64 || bn == 128))) && (bk == 16 || bk == 32) && sk >= 1;
+}
+extern "C" int tf_force_dma(int kind, int splitk) {
+    if (kind < 1 || kind > tf::kDmaKinds || splitk < 1) { tf::set_error("tf_force_dma: unknown LDS-DMA configuration %d", kind); return -1; }
+    const tf::DmaKindInfo ki = tf::dma_kind_info(kind);
+    tf::g_forced = tf::GemmPlan{ki.bm, ki.bn, ki.bk, splitk, kind};
+    return 0;
+}
 extern "C" int tf_force_plan(int bm, int bn, int bk, int splitk) {
     const bool ok = bm == 0 || (((bm == 128 && (bn == 32 || bn == 64 || bn == 96 || bn == 128)) || (bm == 64 && (bn == 64 || bn == 128))) && (bk == 16 || bk == 32) && splitk >= 1);
     if (!ok) { tf::set_error("tf_force_plan: unsupported tiling %dx%dx%d", bm, bn, bk); return -1; }
-    tf::g_forced = tf::GemmPlan{bm, bn, bk, splitk};
+    tf::g_forced = tf::GemmPlan{bm, bn, bk, splitk, 0};
     return 0;
 }
 extern "C" int tf_autotune(int enable) { tf::g_autotune = enable != 0; return 0; }
@@ -57,10 +67,10 @@ extern "C" int tf_plans_save(const char* path) {
     std::lock_guard<std::mutex> lk(tf::g_plan_mu);
     FILE* f = fopen(path, "w");
     if (!f) { tf::set_error("tf_plans_save: cannot open %s", path); return -1; }
-    fprintf(f, "# transfuser_hip GEMM plans: site;M;N;K;batch;acc;bm;bn;bk;splitk\n");
+    fprintf(f, "# transfuser_hip GEMM plans: site;M;N;K;batch;acc;bm;bn;bk;splitk;kind   (kind 0 = register-staged kernel, >= 1 = LDS-DMA configuration)\n");
     for (auto& kv : tf::g_plans)
-        fprintf(f, "%s;%d;%d;%d;%d;%d;%d;%d;%d;%d\n", std::get<0>(kv.first).c_str(), std::get<1>(kv.first), std::get<2>(kv.first), std::get<3>(kv.first),
-                std::get<4>(kv.first), std::get<5>(kv.first), kv.second.bm, kv.second.bn, kv.second.bk, kv.second.splitk);
+        fprintf(f, "%s;%d;%d;%d;%d;%d;%d;%d;%d;%d;%d\n", std::get<0>(kv.first).c_str(), std::get<1>(kv.first), std::get<2>(kv.first), std::get<3>(kv.first),
+                std::get<4>(kv.first), std::get<5>(kv.first), kv.second.bm, kv.second.bn, kv.second.bk, kv.second.splitk, kv.second.kind);
     fclose(f);
     return 0;
 }
@@ -72,14 +82,13 @@ extern "C" int tf_plans_load(const char* path) {
     while (fgets(line, sizeof(line), f)) {
         if (line[0] == '#') continue;
         char site[256];
-        int M, N, K, b, acc, bm, bn, bk, sk;
+        int M, N, K, b, acc, bm, bn, bk, sk, kind = 0;
         char* semi = strchr(line, ';');
         if (!semi || (size_t)(semi - line) >= sizeof(site)) continue;
         memcpy(site, line, semi - line); site[semi - line] = 0;
-        if (sscanf(semi + 1, "%d;%d;%d;%d;%d;%d;%d;%d;%d", &M, &N, &K, &b, &acc, &bm, &bn, &bk, &sk) != 9) continue;
-        const bool ok = ((bm == 128 && (bn == 32 || bn == 64 || bn == 96 || bn == 128)) || (bm == 64 && (bn == 64 || bn == 128))) && (bk == 16 || bk == 32) && sk >= 1;
-        if (!ok) continue;
-        tf::plan_store(site, M, N, K, b, acc, tf::GemmPlan{bm, bn, bk, sk});
+        if (sscanf(semi + 1, "%d;%d;%d;%d;%d;%d;%d;%d;%d;%d", &M, &N, &K, &b, &acc, &bm, &bn, &bk, &sk, &kind) < 9) continue;   // 10th field optional (r01 files)
+        if (!plan_tile_ok(bm, bn, bk, sk, kind)) continue;
+        tf::plan_store(site, M, N, K, b, acc, tf::GemmPlan{bm, bn, bk, sk, kind});
         ++n;
     }
     fclose(f);

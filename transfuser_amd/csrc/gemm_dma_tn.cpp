@@ -1,0 +1,5 @@
+// LDS-DMA GEMM kernels, operand layout "tn" (A_KC = false, B_KC = false): see tf_gemm_dma.h.
+#include "tf_gemm_dma_launch.h"
+namespace tf {
+template void launch_dma_plan<false, false>(int, const PlainOp&, const PlainOp&, const GemmEpi&, int, int, int, int, int, void*);
+}

@@ -1,0 +1,278 @@
+// Direct-to-LDS (LDS-DMA) fp32 MFMA GEMM for gfx950: the plain-operand fast path of the engine.
+//
+//   C[z](i, j) (op)= alpha * sum_k A[z](i, k) * B[z](k, j)  (+ bias[j]) (+ res(i, j)) (relu)        (same contract / epilogue as gemm_kernel)
+//
+// What differs from tf_gemm_engine.h's gemm_kernel (global -> VGPR -> 4 x ds_write_b32 per float4 -> LDS, prefetch distance 1):
+//  * operand tiles go global -> LDS with `buffer_load_dwordx4 ... lds` (1 KiB per wave-instruction, no staging registers, no ds_write
+//    pass); out-of-range rows / ragged K tails are ZERO-FILLED by the buffer bounds check (per-lane offset forced past num_records),
+//    so every tile is handled by the same branch-free loop;
+//  * a STAGES-deep LDS ring with counted `s_waitcnt vmcnt(N)` (never 0 inside the loop) and ONE raw s_barrier per k-tile: STAGES-1
+//    tiles stay in flight across the barriers (hipcc's __syncthreads would drain them: cdna_hip_programming.md "glds vs register staging");
+//  * KC operands (k contiguous in memory: X[m][k], W[n][k]) keep their row-major order in LDS.  LDS-DMA writes lane-linearly, so the
+//    bank-conflict-free layout is obtained by permuting the SOURCE chunk each lane fetches (XOR swizzle of the 16-byte chunk index
+//    with the row) and reading fragments with ds_read_b128 through the same involution.  One b128 read feeds FOUR MFMA k-steps:
+//    the k order inside a tile is permuted (lane half `hi` takes chunk 2q+hi), identically for A and B - a sum over k does not care;
+//  * IC operands (k rows in memory: A^T, B) are copied as they are ([k][m] tiles) and read with conflict-free ds_read_b32;
+//  * workgroups of 1, 2 or 4 waves; every wave owns a (32 TM) x (32 TN) accumulator block (TM x TN MFMA tiles, 4 = the sweet spot of
+//    tools/probe/mfma_probe.cpp).  Single-wave workgroups need no barrier at all and give a fine tile menu (64x64 ... 96x96 ... 128x64):
+//    the GPT shapes (M = 1740) lose 12-17 % to tile-count quantisation with 128-row tiles.
+//
+// Requirements (checked by the host dispatcher, otherwise the call stays on gemm_kernel): both operands 16-byte aligned with ld % 4 == 0,
+// cols % 4 == 0, and every operand slab (incl. batch offset) < 2 GiB so a 32-bit byte offset addresses it.
+#pragma once
+#include "tf_gemm_engine.h"
+
+namespace tf {
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+constexpr unsigned DMA_OOB = 0x80000000u;   // per-lane byte offset beyond any num_records (< 2 GiB): the load returns / writes zeros
+
+#ifdef TF_EMU
+struct DmaSrc { const float* base; unsigned bytes; };
+__forceinline__ DmaSrc dma_make_src(const float* p, unsigned bytes) { return DmaSrc{p, bytes}; }
+// host emulation: the copy happens at issue time (the pipeline's waits / barriers are still executed, races are not modelled)
+__forceinline__ void dma_b128(float* lds_wave_dst, const DmaSrc& s, unsigned voff) {
+    float* d = lds_wave_dst + emu::cur_lane() * 4;
+    if (voff >= s.bytes || voff + 16u > s.bytes) { d[0] = d[1] = d[2] = d[3] = 0.f; }
+    else memcpy(d, reinterpret_cast<const char*>(s.base) + voff, 16);
+}
+template <int N> __forceinline__ void dma_wait() {}
+__forceinline__ void lds_wait() {}
+template <int NW> __forceinline__ void dma_barrier() { if (NW > 1) __syncthreads(); else emu::wave_barrier(); }
+__forceinline__ int wave_uniform(int v) { return v; }
+#else
+typedef i32x4 DmaSrc;
+__device__ __forceinline__ DmaSrc dma_make_src(const float* p, unsigned bytes) {
+    // raw buffer descriptor (stride 0): base[47:0], num_records = bytes, dword3 = 0x00020000 (cdna_hip_programming.md T8)
+    DmaSrc r;
+    r.x = (int)(unsigned)(size_t)p; r.y = (int)(unsigned)((size_t)p >> 32) & 0xffff; r.z = (int)bytes; r.w = 0x00020000;
+    return r;
+}
+// one LDS-DMA piece: every lane's 16 bytes at (base + voff) land at lds_wave_dst + 16 * lane.  M0 carries the LDS destination and is
+// written in the same asm statement that uses it (cdna_hip_programming.md 5.7); the load is invisible to hipcc's vmcnt bookkeeping
+// (no register destination): completion is counted by dma_wait<N>().
+__device__ __forceinline__ void dma_b128(float* lds_wave_dst, const DmaSrc& s, unsigned voff) {
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_wave_dst);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(dst), "s"(s) : "memory");
+}
+template <int N> __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
+__device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+template <int NW> __device__ __forceinline__ void dma_barrier() {
+    if (NW > 1) asm volatile("s_barrier" ::: "memory");
+}
+__device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+#endif
+
+// swizzle of the 16-byte chunk index inside a row of CH chunks (CH = BK / 4 = 4 or 8): with it the 16 lanes of every ds_read_b128 lane
+// group (MI355X_MICROARCH.md, LDS table) hit 16 distinct 16-byte slots of the 256-byte bank row.  Depends on (row mod 32) only.
+template <int CH> __device__ __forceinline__ int dma_swz(int row) { return CH == 4 ? ((row >> 2) & 3) : ((row >> 1) & 7); }
+
+template <int TM, int TN, int WAVES_M, int WAVES_N, int BK, int STAGES, bool A_KC, bool B_KC>
+struct DmaCfg {
+    static constexpr int NW = WAVES_M * WAVES_N, NT = 64 * NW;
+    static constexpr int BM = 32 * TM * WAVES_M, BN = 32 * TN * WAVES_N, CH = BK / 4;
+    static constexpr int A_FL = BM * BK, B_FL = BN * BK, STAGE_FL = A_FL + B_FL;        // floats per stage
+    static constexpr int NA = A_FL / 256, NB = B_FL / 256;                              // 1 KiB DMA pieces per stage
+    static constexpr int DA = NA / NW, DB = NB / NW, DPW = DA + DB;                     // pieces per wave per stage
+    static constexpr int LDS_BYTES = STAGES * STAGE_FL * 4;
+    static_assert(BK == 16 || BK == 32, "BK");
+    static_assert(NA % NW == 0 && NB % NW == 0, "every wave must issue the same number of DMA pieces per stage (vmcnt is counted)");
+    static_assert(STAGES >= 2 && STAGES <= 4 && (STAGES - 1) * DPW <= 60, "ring depth / vmcnt range");
+    static_assert(LDS_BYTES <= 64 * 1024, "M0 LDS base is kept within 64 KiB");
+};
+
+template <int TM, int TN, int WAVES_M, int WAVES_N, int BK, int STAGES, bool A_KC, bool B_KC>
+__device__ __forceinline__ void gemm_dma_tile(const PlainOp& la_in, const PlainOp& lb_in, const GemmEpi& ep, int M, int N, int K, int tiles_m,
+                                              int tiles_n, int kchunk, float* smem) {
+    typedef DmaCfg<TM, TN, WAVES_M, WAVES_N, BK, STAGES, A_KC, B_KC> C;
+    constexpr int NW = C::NW, BM = C::BM, BN = C::BN, CH = C::CH, DA = C::DA, DB = C::DB, DPW = C::DPW;
+    constexpr int QN = BK / 8;                       // b128 fragment reads per 32-row sub-tile per stage (KC); 4 k-steps each
+
+    PlainOp la = la_in, lb = lb_in;
+    const int tid = threadIdx.x, z = blockIdx.z;
+    la.set_batch(z);
+    lb.set_batch(z);
+    const int wave = wave_uniform(tid >> 6), lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+
+    // XCD-aware bijective block -> tile map + grouped rasterisation (identical to gemm_kernel)
+    int tile;
+    {
+        const int nt = tiles_m * tiles_n, bid = blockIdx.x;
+        const int q = nt >> 3, r = nt & 7, xcd = bid & 7, loc = bid >> 3;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    int tm, tn;
+    if (ep.group_m > 1) {
+        const int per = ep.group_m * tiles_n, sr = tile / per, rem = tile - sr * per;
+        int gsz = tiles_m - sr * ep.group_m;
+        gsz = gsz < ep.group_m ? gsz : ep.group_m;
+        tn = rem / gsz; tm = sr * ep.group_m + (rem - tn * gsz);
+    } else { tm = tile / tiles_n; tn = tile - tm * tiles_n; }
+    const int i0 = tm * BM, j0 = tn * BN;
+    const int kbeg = blockIdx.y * kchunk;
+    const int kend = (kbeg + kchunk < K) ? kbeg + kchunk : K;
+    const int nkt = (kend - kbeg + BK - 1) / BK;
+
+    // ---- DMA sources.  Piece j of an operand covers LDS floats [256 j, 256 j + 256) of the stage tile; wave w issues pieces w, w + NW, ...
+    //  KC tile [rows][CH chunks]:  slot = 64 j + lane -> row = slot / CH, physical chunk p = slot % CH holds LOGICAL chunk p ^ swz(row).
+    //  IC tile [BK][cols]:         slot -> k row = slot / (cols / 4), column chunk = slot % (cols / 4).
+    const DmaSrc sa = dma_make_src(la.p, (unsigned)(((long)(la.rows - 1) * la.ld + la.cols) * 4));
+    const DmaSrc sb = dma_make_src(lb.p, (unsigned)(((long)(lb.rows - 1) * lb.ld + lb.cols) * 4));
+    unsigned voff[DPW];      // byte offset of this lane's 16 bytes in k-tile 0
+    int klim[DPW];           // the chunk is inside the matrix while (k-tile index * BK) < klim (INT_MIN: row / column out of range)
+    unsigned astep, bstep;   // byte step per k-tile
+    {
+        auto setup = [&](const PlainOp& op, bool kc, int r0, int extent, int piece, unsigned& vo, int& kl) {
+            const int slot = piece * 64 + lane;
+            if (kc) {
+                const int row = slot / CH, c = (slot % CH) ^ dma_swz<CH>(row);
+                const bool ok = r0 + row < op.rows;
+                vo = (unsigned)(((long)(r0 + row) * op.ld + kbeg + c * 4) * 4);
+                kl = ok ? (kend - kbeg - c * 4) : (int)0x80000000;
+            } else {
+                const int cq_n = extent / 4, kr = slot / cq_n, cq = slot % cq_n;
+                const bool ok = r0 + cq * 4 < op.cols;
+                vo = (unsigned)(((long)(kbeg + kr) * op.ld + r0 + cq * 4) * 4);
+                kl = ok ? (kend - kbeg - kr) : (int)0x80000000;
+            }
+        };
+#pragma unroll
+        for (int i = 0; i < DA; ++i) setup(la, A_KC, i0, BM, wave + i * NW, voff[i], klim[i]);
+#pragma unroll
+        for (int i = 0; i < DB; ++i) setup(lb, B_KC, j0, BN, wave + i * NW, voff[DA + i], klim[DA + i]);
+        astep = (unsigned)((A_KC ? (long)BK : (long)BK * la.ld) * 4);
+        bstep = (unsigned)((B_KC ? (long)BK : (long)BK * lb.ld) * 4);
+    }
+    auto issue = [&](int kt, int slot) {     // k-tile kt -> ring slot (all-zero tile when kt >= nkt)
+        float* base = smem + slot * C::STAGE_FL + wave * 256;
+        const int kpos = kt * BK;
+#pragma unroll
+        for (int i = 0; i < DA; ++i) {
+            const unsigned o = voff[i] + (unsigned)kt * astep;
+            dma_b128(base + i * NW * 256, sa, kpos < klim[i] ? o : DMA_OOB);
+        }
+#pragma unroll
+        for (int i = 0; i < DB; ++i) {
+            const unsigned o = voff[DA + i] + (unsigned)kt * bstep;
+            dma_b128(base + C::A_FL + i * NW * 256, sb, kpos < klim[DA + i] ? o : DMA_OOB);
+        }
+    };
+
+    // ---- fragment addresses
+    const int wm0 = (wave % WAVES_M) * 32 * TM, wn0 = (wave / WAVES_M) * 32 * TN;
+    const int sw = dma_swz<CH>(l31);
+    // KC: float index of (row, logical chunk c) = row * BK + ((c ^ sw) * 4);  lane reads chunk 2q + hi
+    // IC: float index of (k, col) = k * EXTENT + col;                         lane reads k = 8q + 4hi + e, e = 0..3
+    int a_off, b_off;
+    a_off = A_KC ? (wm0 + l31) * BK : (4 * hi) * BM + wm0 + l31;
+    b_off = B_KC ? (wn0 + l31) * BK : (4 * hi) * BN + wn0 + l31;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    auto compute = [&](int slot) {
+        const float* As = smem + slot * C::STAGE_FL;
+        const float* Bs = As + C::A_FL;
+        float4 a[2][TM], b[2][TN];
+        auto load = [&](int q, int s) {
+#pragma unroll
+            for (int t = 0; t < TM; ++t) {
+                if (A_KC) a[s][t] = *reinterpret_cast<const float4*>(As + a_off + t * 32 * BK + (((2 * q + hi) ^ sw) * 4));
+                else {
+                    const float* p = As + a_off + (8 * q) * BM + t * 32;
+                    a[s][t] = make_float4(p[0], p[BM], p[2 * BM], p[3 * BM]);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < TN; ++t) {
+                if (B_KC) b[s][t] = *reinterpret_cast<const float4*>(Bs + b_off + t * 32 * BK + (((2 * q + hi) ^ sw) * 4));
+                else {
+                    const float* p = Bs + b_off + (8 * q) * BN + t * 32;
+                    b[s][t] = make_float4(p[0], p[BN], p[2 * BN], p[3 * BN]);
+                }
+            }
+        };
+        load(0, 0);
+#pragma unroll
+        for (int q = 0; q < QN; ++q) {
+            const int s = q & 1;
+            if (q + 1 < QN) load(q + 1, s ^ 1);
+            TF_SCHED_FENCE();
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int t = 0; t < TM; ++t)
+#pragma unroll
+                    for (int u = 0; u < TN; ++u) {
+                        const float av = e == 0 ? a[s][t].x : e == 1 ? a[s][t].y : e == 2 ? a[s][t].z : a[s][t].w;
+                        const float bv = e == 0 ? b[s][u].x : e == 1 ? b[s][u].y : e == 2 ? b[s][u].z : b[s][u].w;
+                        mfma_32x32x2(av, bv, acc[t][u]);
+                    }
+            TF_SCHED_FENCE();
+        }
+    };
+
+    // ---- pipeline: STAGES-1 tiles in flight; iteration t: wait for tile t (counted), barrier (also frees slot (t-1) % STAGES for
+    // everyone), request tile t + STAGES - 1 into that slot, multiply tile t.
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s) issue(s, s);
+    int cur = 0, nxt = STAGES - 1;
+    for (int kt = 0; kt < nkt; ++kt) {
+        dma_wait<(STAGES - 2) * DPW>();
+        lds_wait();
+        dma_barrier<NW>();
+        issue(kt + STAGES - 1, nxt);
+        compute(cur);
+        cur = cur + 1 == STAGES ? 0 : cur + 1;
+        nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
+    }
+    dma_wait<0>();      // drain the (all-zero) tail requests before the epilogue's own loads / the end of the block
+
+    gemm_epilogue<TM, TN>(acc, ep, M, N, i0, j0, BM, BN, wm0, wn0, z);
+}
+
+template <int TM, int TN, int WAVES_M, int WAVES_N, int BK, int STAGES, bool A_KC, bool B_KC, int OCC>
+__global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, OCC)
+gemm_dma_kernel(PlainOp la, PlainOp lb, GemmEpi ep, int M, int N, int K, int tiles_m, int tiles_n, int kchunk) {
+    typedef DmaCfg<TM, TN, WAVES_M, WAVES_N, BK, STAGES, A_KC, B_KC> C;
+    __shared__ __attribute__((aligned(1024))) float smem[STAGES * C::STAGE_FL];
+    gemm_dma_tile<TM, TN, WAVES_M, WAVES_N, BK, STAGES, A_KC, B_KC>(la, lb, ep, M, N, K, tiles_m, tiles_n, kchunk, smem);
+}
+
+// can this problem run on the DMA kernels?  (vector-aligned plain operands, 32-bit addressable)
+inline bool dma_eligible_impl(const PlainOp& a, const PlainOp& b) {
+    auto ok = [](const PlainOp& o) {
+        return o.vec && o.rows > 0 && o.cols > 0 && ((long)(o.rows - 1) * o.ld + o.cols) * 4 < 0x7ffffff0L;
+    };
+    return ok(a) && ok(b);
+}
+
+template <int TM, int TN, int WAVES_M, int WAVES_N, int BK, int STAGES, bool A_KC, bool B_KC, int OCC>
+inline void launch_dma_cfg(const PlainOp& la, const PlainOp& lb, const GemmEpi& ep, int M, int N, int K, int batch, int splitk, void* stream) {
+    typedef DmaCfg<TM, TN, WAVES_M, WAVES_N, BK, STAGES, A_KC, B_KC> C;
+    const int tiles_m = cdiv(M, C::BM), tiles_n = cdiv(N, C::BN);
+    int kchunk = cdiv(cdiv(K, splitk), BK) * BK;
+    if (kchunk < BK) kchunk = BK;
+    const int nsplit = cdiv(K, kchunk);
+    dim3 grid(tiles_m * tiles_n, nsplit > 0 ? nsplit : 1, batch);
+    GemmEpi epg = ep;
+    {
+        long panel = (long)C::BM * (kchunk < K ? kchunk : K) * 4;
+        int g = (int)((2L << 20) / (panel > 0 ? panel : 1));
+        if (g > 8) g = 8;
+        if (g > tiles_m) g = tiles_m;
+        epg.group_m = (g >= 2 && tiles_n >= 4) ? g : 1;
+    }
+    TF_LAUNCH((gemm_dma_kernel<TM, TN, WAVES_M, WAVES_N, BK, STAGES, A_KC, B_KC, OCC>), grid, dim3(C::NT), stream, la, lb, epg, M, N, K, tiles_m,
+              tiles_n, kchunk);
+}
+
+}  // namespace tf

@@ -245,6 +245,55 @@ struct GemmEpi {
     const float* mask = nullptr; long ldmask = 0;   // optional ReLU mask of a backward GEMM: element (i, j) is zeroed unless mask(i, j) > 0
 };
 
+// ---------------------------------------------------------------- epilogue (shared by gemm_kernel and gemm_dma_kernel)
+// lane holds column j of 16 rows per 32x32 tile.  Mode / residual / bounds are resolved ONCE per tile
+// (wave-uniform) so the 16 x TM x TN stores of a lane are straight-line code, not a branch + wait per element.
+template <int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[TM][TN], const GemmEpi& ep, int M, int N, int i0, int j0, int BM, int BN,
+                                              int wm0, int wn0, int z) {
+    const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
+    const long cz = (long)(z / ep.inner) * ep.sc_outer + (long)(z % ep.inner) * ep.sc_inner;
+    float* C = ep.C + cz;
+    const float* res = ep.res ? ep.res + cz : nullptr;
+    const float* bias = ep.bias ? ep.bias + (long)z * ep.sbias : nullptr;
+    const bool full = (i0 + BM <= M) && (j0 + BN <= N);
+    auto emit = [&](auto mode_c, auto res_c, auto full_c) {
+        constexpr int MODE = decltype(mode_c)::value;
+        constexpr bool RES = decltype(res_c)::value, FULL = decltype(full_c)::value;
+#pragma unroll
+        for (int t = 0; t < TM; ++t)
+#pragma unroll
+            for (int u = 0; u < TN; ++u) {
+                const int j = j0 + wn0 + u * 32 + l31;
+                const bool jok = FULL || j < N;
+                const float bj = (bias && jok) ? bias[j] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int i = i0 + wm0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (FULL || (jok && i < M)) {
+                        float v = ep.alpha * acc[t][u][r] + bj;
+                        if (RES) v += res[(long)i * ep.ldres + j];
+                        v = ep.relu ? fmaxf(v, 0.f) : v;
+                        if (ep.mask) v = (ep.mask[(long)i * ep.ldmask + j] > 0.f) ? v : 0.f;
+                        float* dst = C + (long)i * ep.ldc + (long)j * ep.ldcj;
+                        if (MODE == 0) *dst = v;
+                        else if (MODE == 1) *dst += v;
+                        else atomicAdd(dst, v);
+                    }
+                }
+            }
+    };
+    auto by_full = [&](auto mode_c, auto res_c) {
+        if (full) emit(mode_c, res_c, std::true_type()); else emit(mode_c, res_c, std::false_type());
+    };
+    auto by_res = [&](auto mode_c) {
+        if (res) by_full(mode_c, std::true_type()); else by_full(mode_c, std::false_type());
+    };
+    if (ep.mode == 0) by_res(std::integral_constant<int, 0>());
+    else if (ep.mode == 1) by_res(std::integral_constant<int, 1>());
+    else by_res(std::integral_constant<int, 2>());
+}
+
 // ---------------------------------------------------------------- kernel
 template <int BM, int BN, int WAVES_M, int BK, class LA, bool A_KC, class LB, bool B_KC, bool ALLVEC, int NT = 256, int PF = 1>
 __device__ __forceinline__ void gemm_tile(LA& la, LB& lb, const GemmEpi& ep, int M, int N, int K, int tiles_m, int tiles_n, int kchunk,
@@ -542,48 +591,7 @@ __device__ __forceinline__ void gemm_tile(LA& la, LB& lb, const GemmEpi& ep, int
         }
     }
 
-    // epilogue: lane holds column j of 16 rows per 32x32 tile.  Mode / residual / bounds are resolved ONCE per tile
-    // (wave-uniform) so the 16 x TM x TN stores of a lane are straight-line code, not a branch + wait per element.
-    const long cz = (long)(z / ep.inner) * ep.sc_outer + (long)(z % ep.inner) * ep.sc_inner;
-    float* C = ep.C + cz;
-    const float* res = ep.res ? ep.res + cz : nullptr;
-    const float* bias = ep.bias ? ep.bias + (long)z * ep.sbias : nullptr;
-    const bool full = (i0 + BM <= M) && (j0 + BN <= N);
-    auto emit = [&](auto mode_c, auto res_c, auto full_c) {
-        constexpr int MODE = decltype(mode_c)::value;
-        constexpr bool RES = decltype(res_c)::value, FULL = decltype(full_c)::value;
-#pragma unroll
-        for (int t = 0; t < TM; ++t)
-#pragma unroll
-            for (int u = 0; u < TN; ++u) {
-                const int j = j0 + wn0 + u * 32 + l31;
-                const bool jok = FULL || j < N;
-                const float bj = (bias && jok) ? bias[j] : 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int i = i0 + wm0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (FULL || (jok && i < M)) {
-                        float v = ep.alpha * acc[t][u][r] + bj;
-                        if (RES) v += res[(long)i * ep.ldres + j];
-                        v = ep.relu ? fmaxf(v, 0.f) : v;
-                        if (ep.mask) v = (ep.mask[(long)i * ep.ldmask + j] > 0.f) ? v : 0.f;
-                        float* dst = C + (long)i * ep.ldc + (long)j * ep.ldcj;
-                        if (MODE == 0) *dst = v;
-                        else if (MODE == 1) *dst += v;
-                        else atomicAdd(dst, v);
-                    }
-                }
-            }
-    };
-    auto by_full = [&](auto mode_c, auto res_c) {
-        if (full) emit(mode_c, res_c, std::true_type()); else emit(mode_c, res_c, std::false_type());
-    };
-    auto by_res = [&](auto mode_c) {
-        if (res) by_full(mode_c, std::true_type()); else by_full(mode_c, std::false_type());
-    };
-    if (ep.mode == 0) by_res(std::integral_constant<int, 0>());
-    else if (ep.mode == 1) by_res(std::integral_constant<int, 1>());
-    else by_res(std::integral_constant<int, 2>());
+    gemm_epilogue<TM, TN>(acc, ep, M, N, i0, j0, BM, BN, wm0, wn0, z);
 }
 
 // ALLVEC = both operands may be read with 16-byte loads (decided on the host): separate instantiation so the common
@@ -599,7 +607,20 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 2 : ((BM * BN >= 128 * 96) ? 3
 }
 
 // ---------------------------------------------------------------- host dispatch
-struct GemmPlan { int bm, bn, bk, splitk; };
+// kind 0: gemm_kernel (register-staged, any loader).  kind >= 1: LDS-DMA kernel configuration of tf_gemm_dma.h (plain vector operands
+// only; bm/bn/bk then mirror that configuration's tile for the plan file's readers).
+struct GemmPlan { int bm, bn, bk, splitk; int kind = 0; };
+
+// LDS-DMA configurations (tf_gemm_dma.h); the launchers live in gemm_dma_{nt,nn,tn,tt}.cpp (one translation unit per operand layout)
+constexpr int kDmaKinds = 5;
+struct DmaKindInfo { int bm, bn, bk; };
+inline DmaKindInfo dma_kind_info(int kind) {
+    static const DmaKindInfo t[kDmaKinds + 1] = {{0, 0, 0}, {128, 128, 16}, {64, 64, 16}, {128, 64, 16}, {64, 128, 16}, {128, 128, 32}};
+    return t[(kind >= 1 && kind <= kDmaKinds) ? kind : 0];
+}
+template <bool A_KC, bool B_KC>
+void launch_dma_plan(int kind, const PlainOp& la, const PlainOp& lb, const GemmEpi& ep, int M, int N, int K, int batch, int splitk, void* stream);
+bool dma_eligible(const PlainOp& a, const PlainOp& b);
 
 // plan cache + autotuner state (api.cpp)
 bool plan_lookup(const char* what, int M, int N, int K, int batch, int acc, GemmPlan* out);
@@ -661,6 +682,12 @@ inline void launch_cfg(const LA& la, const LB& lb, const GemmEpi& ep, int M, int
 
 template <class LA, bool A_KC, class LB, bool B_KC>
 inline void launch_plan(const GemmPlan& p, const LA& la, const LB& lb, const GemmEpi& ep, int M, int N, int K, int batch, void* stream) {
+    if constexpr (std::is_same<LA, PlainOp>::value && std::is_same<LB, PlainOp>::value) {
+        if (p.kind >= 1 && p.kind <= kDmaKinds && dma_eligible(la, lb)) {
+            launch_dma_plan<A_KC, B_KC>(p.kind, la, lb, ep, M, N, K, batch, p.splitk, stream);
+            return;
+        }
+    }
 #define TF_CFG(BM_, BN_, WM_)                                                                                      \
     do {                                                                                                           \
         if (p.bk == 32) launch_cfg<BM_, BN_, WM_, 32, LA, A_KC, LB, B_KC>(la, lb, ep, M, N, K, batch, p.splitk, stream); \
@@ -687,7 +714,7 @@ template <class LA, bool A_KC, class LB, bool B_KC>
 inline GemmPlan autotune_gemm(const LA& la, const LB& lb, const GemmEpi& ep, int M, int N, int K, int batch, bool allow_splitk, void* stream) {
     static const int tiles[6][2] = {{128, 128}, {128, 96}, {128, 64}, {128, 32}, {64, 128}, {64, 64}};
     GemmEpi trial = ep;
-    if (ep.mode != 0) trial.alpha = 0.f;
+    if (ep.mode != 0) { trial.alpha = 0.f; trial.bias = nullptr; trial.res = nullptr; trial.relu = 0; trial.mask = nullptr; }   // accumulating trials add exactly +0
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     GemmPlan best = plan_gemm(M, N, K, batch, allow_splitk);
@@ -704,7 +731,7 @@ inline GemmPlan autotune_gemm(const LA& la, const LB& lb, const GemmEpi& ep, int
                 if (h > 1) { sks[nsk++] = h; if (h >= 4) sks[nsk++] = h / 2; }
             }
             for (int s = 0; s < nsk; ++s) {
-                GemmPlan p{bm, bn, bk, sks[s]};
+                GemmPlan p{bm, bn, bk, sks[s], 0};
                 GemmEpi e = trial;
                 if (p.splitk > 1) { if (ep.mode == 0) continue; e.mode = 2; }
                 launch_plan<LA, A_KC, LB, B_KC>(p, la, lb, e, M, N, K, batch, stream);   // warm
@@ -719,6 +746,37 @@ inline GemmPlan autotune_gemm(const LA& la, const LB& lb, const GemmEpi& ep, int
                     if (t < ms) ms = t;
                 }
                 if (ms < best_ms) { best_ms = ms; best = p; }
+            }
+        }
+    }
+    if constexpr (std::is_same<LA, PlainOp>::value && std::is_same<LB, PlainOp>::value) {
+        if (dma_eligible(la, lb)) {
+            for (int kind = 1; kind <= kDmaKinds; ++kind) {
+                const DmaKindInfo ki = dma_kind_info(kind);
+                if (ki.bn > 32 && ki.bn >= npad + 32) continue;
+                if (ki.bm > 64 && M <= 64) continue;
+                int sks[3] = {1, 0, 0}, nsk = 1;
+                if (allow_splitk) {
+                    const int h = heuristic_splitk(M, N, K, batch, ki.bm, ki.bn, ki.bk);
+                    if (h > 1) { sks[nsk++] = h; if (h >= 4) sks[nsk++] = h / 2; }
+                }
+                for (int s = 0; s < nsk; ++s) {
+                    GemmPlan p{ki.bm, ki.bn, ki.bk, sks[s], kind};
+                    GemmEpi e = trial;
+                    if (p.splitk > 1) { if (ep.mode == 0) continue; e.mode = 2; }
+                    launch_plan<LA, A_KC, LB, B_KC>(p, la, lb, e, M, N, K, batch, stream);
+                    float ms = 1e30f;
+                    for (int pass = 0; pass < 3; ++pass) {
+                        hipEventRecord(e0, (hipStream_t)stream);
+                        for (int r = 0; r < 4; ++r) launch_plan<LA, A_KC, LB, B_KC>(p, la, lb, e, M, N, K, batch, stream);
+                        hipEventRecord(e1, (hipStream_t)stream);
+                        hipEventSynchronize(e1);
+                        float t = 0.f;
+                        hipEventElapsedTime(&t, e0, e1);
+                        if (t < ms) ms = t;
+                    }
+                    if (ms < best_ms) { best_ms = ms; best = p; }
+                }
             }
         }
     }

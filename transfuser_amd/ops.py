@@ -43,6 +43,11 @@ def force_plan(bm=0, bn=0, bk=0, splitk=1):
     check(L().tf_force_plan(bm, bn, bk, splitk), "tf_force_plan")
 
 
+def force_dma(kind, splitk=1):
+    """tests: pin LDS-DMA GEMM configuration ``kind`` (1..5); calls that are not eligible (unaligned / non-plain operands) keep the heuristic."""
+    check(L().tf_force_dma(kind, splitk), "tf_force_dma")
+
+
 def plans_save(path):
     check(L().tf_plans_save(path.encode()), "tf_plans_save")
 
