@@ -1,107 +1,181 @@
 #!/usr/bin/env python
 """Headline benchmark: TransFuser training samples/s (one RGB+LiDAR pair = one sample), bs=10/GPU.
 
-  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
 
-A "step" = one full training iteration on a resident synthetic batch: zero grads ->
-LidarCenterNet forward (RegNetY-3.2GF x2, 4 GPT stages x 4 layers, decoders, CenterNet head, GRU) ->
-11 losses -> weighted sum -> backward -> [gradient all-reduce] -> AdamW, fp32, dropout p=0.1, every
-kernel hand-written HIP.  Workload = BASELINE.json configs[1]: B=10, 3x256x704 RGB + 2x256x256 BEV
-(+1x256x256 target-point channel), captured into one hipGraph.  Prints ONE JSON line on rank 0.
+N > 1 works both ways: launched by ``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`` (one rank per GPU, the
+driver's command) or from a bare shell - without a torchrun environment bench.py spawns its N ranks itself (127.0.0.1 rendezvous),
+relays rank 0's JSON line and exits with the worst rank's status.
+
+A "step" = one full training iteration on a resident synthetic batch: zero grads -> LidarCenterNet forward
+(RegNetY-3.2GF x2, 4 GPT stages x 4 layers, decoders, CenterNet head, GRU) -> 11 losses -> weighted sum -> backward -> [gradient
+all-reduce over RCCL, overlapped with the backward of the earlier stages] -> AdamW, dropout p=0.1, every kernel hand-written HIP.
+Default workload = BASELINE.json configs[1]: B=10, 3x256x704 RGB + 2x256x256 BEV (+1x256x256 target-point channel), fp32, hipGraph
+replay.  ``--backbone geometric_fusion --batch 12 --height 160`` / ``--backbone latentTF --batch 16`` are configs[3] / [4].
+Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 import faulthandler
 
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-GFLOP_PER_SAMPLE = {160: 230.3, 256: 266.6}  # algorithmic training FLOPs (3x forward), SURVEY.md section 8(d)
-PEAK_F32_MFMA_TF = 157.3                     # /opt/skills/guides/MI355X_MICROARCH.md (v_mfma_f32_32x32x2_f32)
+GFLOP_PER_SAMPLE = {("transFuser", 160): 230.3, ("transFuser", 256): 266.6, ("latentTF", 160): 230.3, ("latentTF", 256): 266.6,
+                    ("geometric_fusion", 160): 110.2}   # algorithmic training FLOPs (3x forward), SURVEY.md section 8(d)
+PEAK_F32_MFMA_TF = 157.3                                # /opt/skills/guides/MI355X_MICROARCH.md (v_mfma_f32_32x32x2_f32)
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_gemm_roofline.json")   # written by tools/pmc_roofline.sh (rocprofv3 --pmc passes)
+DOMINANT = ("gemm a0b0", (1740, 6048, 1512, 1))         # GPT-4 mlp.0 forward: [1740 x 1512] . [1512 x 6048], bias + ReLU epilogue
 
 
-PMC_TRAFFIC_BYTES_PER_LAUNCH = int((2 * 274137.9 + 41107.5) * 1024)   # see dominant_kernel_roofline.__doc__
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: 10 transFuser, 12 geometric_fusion, 16 latentTF)")
+    ap.add_argument("--height", type=int, default=None, help="RGB height (default 256; geometric_fusion only runs at 160)")
+    ap.add_argument("--backbone", default="transFuser", choices=["transFuser", "geometric_fusion", "latentTF"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dropout", type=float, default=0.1)
+    ap.add_argument("--watchdog", type=int, default=900, help="dump all Python stacks to stderr if still running after this many seconds")
+    return ap.parse_args()
 
 
-def dominant_kernel_roofline(dev, iters=20):
-    """Dominant kernel = the fp32 MFMA GEMM engine (tf::gemm_kernel, ~70 % of the step's kernel time); its single most expensive
-    call is GPT-4's fc1 [1740 x 1512] . [1512 x 6048] (+bias+ReLU).  Timed live with HIP events on the launch stream right after
-    the sustained training loop; algorithmic FLOPs = 2*M*N*K per launch.  ``traffic``: fabric-side bytes per launch from the
-    committed PMC run of the same kernel (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE doubled per the
-    gfx950 note of MI355X_MICROARCH.md; profiles/r01_pmc_gemm_roofline.txt) - PMC counters cannot be read from inside this process."""
+def spawn_ranks(args):
+    """No torchrun environment and --gpus N > 1: be the launcher (one process per GPU, env:// rendezvous on 127.0.0.1)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    sys.exit(max(abs(rc) for rc in rcs))
+
+
+def dominant_kernel_roofline(eng, batch, dev, log):
+    """Roofline of the dominant kernel family (the fp32 MFMA GEMM engine, ~70 % of the step's kernel time) from INSIDE the step: one more
+    training iteration is run eagerly with a HIP-event pair around every engine call (ops.census; events on the launch stream), and the
+    figures are averages over that step's own launches - the same kernels, plans, operands and neighbours as in the timed region.
+      achieved = 2 M N K of GPT-4's mlp.0 forward GEMM / its average in-step duration (4 launches per step);
+      engine_* = all plain-GEMM + conv launches of the step (algorithmic FLOPs / event time);
+      traffic  = fabric-side bytes per launch of the same kernel + plan from the committed rocprofv3 PMC passes (tools/pmc_roofline.sh ->
+                 profiles/r02_pmc_gemm_roofline.json: 2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction of MI355X_MICROARCH.md); PMC
+                 counters cannot be read from inside this process, so the number is read from that file at run time (null if absent)."""
+    import torch
     from transfuser_amd import ops
-    M, K, N = 1740, 1512, 6048
-    x = torch.randn(M, K, device=dev)
-    w = torch.randn(N, K, device=dev) * 0.02
-    b = torch.zeros(N, device=dev)
-    out = torch.empty(M, N, device=dev)
-    for _ in range(3):
-        ops.linear_fwd(x, w, b, relu=True, out=out)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        ops.linear_fwd(x, w, b, relu=True, out=out)
-    e1.record()
-    e1.synchronize()
-    sec = e0.elapsed_time(e1) / 1e3 / iters
-    flops = 2.0 * M * N * K
-    ach = flops / sec / 1e12
-    return dict(bound="mfma", kernel="tf::gemm_kernel<BM,BN,WM,BK,PlainOp,KC,PlainOp,KC,vec> (autotuned tiling) on GPT4 mlp.0: [1740x1512].[1512x6048], bias+ReLU epilogue",
-                achieved=round(ach, 2), peak=PEAK_F32_MFMA_TF, unit="TFLOP/s", frac=round(ach / PEAK_F32_MFMA_TF, 4),
-                flops_per_launch=flops, avg_launch_us=round(sec * 1e6, 2), traffic=PMC_TRAFFIC_BYTES_PER_LAUNCH,
-                traffic_source="profiles/r01_pmc_gemm_roofline.txt (2*FETCH_SIZE + WRITE_SIZE, 64x64x16 tiling; L2 fabric requests incl. Infinity-Cache hits; "
-                               "algorithmic bytes 89.2 MB)")
+    torch.cuda.synchronize()
+    ops.census = []
+    eng._eager_step(batch)
+    torch.cuda.synchronize()
+    rows, ops.census = ops.census, None
+    dom = [(a.elapsed_time(b) * 1e-3, fl) for kind, shape, fl, a, b in rows if (kind, tuple(shape)) == DOMINANT]
+    tot_s = sum(a.elapsed_time(b) for _, _, _, a, b in rows) * 1e-3
+    tot_fl = sum(fl for _, _, fl, _, _ in rows)
+    roof = dict(bound="mfma", peak=PEAK_F32_MFMA_TF, unit="TFLOP/s")
+    if dom:
+        sec = sum(t for t, _ in dom) / len(dom)
+        ach = dom[0][1] / sec / 1e12
+        roof.update(kernel="tf::gemm_kernel / tf::gemm_dma_kernel (autotuned plan) on GPT4 mlp.0 forward: [1740x1512].[1512x6048], bias+ReLU epilogue; "
+                           "average of its %d launches inside one eager training step" % len(dom),
+                    achieved=round(ach, 2), frac=round(ach / PEAK_F32_MFMA_TF, 4), flops_per_launch=dom[0][1], avg_launch_us=round(sec * 1e6, 2))
+    else:   # other backbones / shapes: the engine aggregate is the roofline entry
+        ach = tot_fl / tot_s / 1e12
+        roof.update(kernel="all MFMA-engine launches of one eager training step (plain GEMMs + implicit-GEMM convolutions)",
+                    achieved=round(ach, 2), frac=round(ach / PEAK_F32_MFMA_TF, 4), flops_per_launch=None, avg_launch_us=None)
+    roof.update(engine_calls=len(rows), engine_ms_per_step=round(tot_s * 1e3, 2), engine_tflops=round(tot_fl / tot_s / 1e12, 2),
+                engine_frac=round(tot_fl / tot_s / 1e12 / PEAK_F32_MFMA_TF, 4))
+    roof["traffic"], roof["traffic_source"] = None, "no PMC summary committed"
+    if os.path.exists(PMC_FILE) and dom:
+        try:
+            pmc = json.load(open(PMC_FILE))
+            roof["traffic"] = int(pmc["traffic_bytes_per_launch"])
+            roof["traffic_source"] = "profiles/%s: %s" % (os.path.basename(PMC_FILE), pmc.get("note", ""))
+            if pmc.get("mfma_busy_frac") is not None:
+                roof["mfma_busy_frac_pmc"] = pmc["mfma_busy_frac"]
+        except Exception as e:   # a malformed summary must not kill the bench line
+            roof["traffic_source"] = "unreadable %s: %s" % (PMC_FILE, e)
+    log("in-step roofline census done (%d engine launches)" % len(rows))
+    return roof
 
 
-def cpu_baseline(cfg_factory, H, W):
-    """The oracle (CPU restatement of the reference path, backbone pinned bit-exact to the reference's own
-    transfuser.py) timed on this host: B=2 train steps of oracle.model_cpu.train_step, bounded to ~10-40 s."""
+def cpu_baseline(make_cfg, backbone, H, W, budget_s=75.0):
+    """The oracle (CPU restatement of the reference path; its backbone is pinned bit-exact to the reference's own transfuser.py and
+    its heads/losses to the reference's model.py) timed on this host with PyTorch-CPU fp32: B=2 (BASELINE configs[0], the reference's
+    CPU-runnable case) with 2 warm-up + 5 timed steps, then B=10 (the workload of the GPU line) with 1 warm-up + up to 3 timed steps
+    inside the time budget.  Thread count: the faster of 64 and all cores on a probe step (oneDNN/OpenMP stops scaling on these layers)."""
+    import torch
     from oracle import hist, model_cpu
     from transfuser_amd.data import synthetic_batch
-    threads = min(os.cpu_count(), 64)   # oneDNN/OpenMP does not scale past this on these layer sizes
-    torch.set_num_threads(threads)
-    cfg = cfg_factory()
+    ncpu = os.cpu_count()
+    cfg = make_cfg()
     torch.manual_seed(0)
-    ref = model_cpu.LidarCenterNet(cfg, 'cpu', 'transFuser', use_velocity=False)
+    ref = model_cpu.LidarCenterNet(cfg, 'cpu', backbone, use_velocity=False)
     ref.train()
     opt = model_cpu.make_optimizer(ref)
-    B = 2
-    batch = synthetic_batch(B, H, W, seed=0, hist_fn=hist.lidar_to_histogram_features, n_points=8192)
-    t0 = time.time()
-    model_cpu.train_step(ref, opt, batch, cfg)
-    warm = time.time() - t0
-    times = []
-    while len(times) < 3 and sum(times) + warm < 30.0:
+    keys = ("rgb", "lidar", "ego_waypoint", "target_point", "target_point_image", "ego_vel", "bev", "label", "depth", "semantic") + \
+        (("bev_points", "cam_points") if backbone == "geometric_fusion" else ())
+    mk = lambda B: {k: v for k, v in synthetic_batch(B, H, W, seed=0, hist_fn=hist.lidar_to_histogram_features, n_points=8192).items() if k in keys}
+    b2 = mk(2)
+
+    def step(batch):
         t0 = time.time()
         model_cpu.train_step(ref, opt, batch, cfg)
-        times.append(time.time() - t0)
-    dt = sorted(times)[len(times) // 2] if times else warm
-    return dict(value=round(B / dt, 3), unit="samples/s", cores=threads, kind="port",
-                sample="oracle.model_cpu.train_step (PyTorch-CPU fp32, %d threads of %d cores), B=2, %dx%d, 1 warm-up + %d timed step(s), median" %
-                       (threads, os.cpu_count(), H, W, len(times)))
+        return time.time() - t0
+
+    t_start = time.time()
+    probes = {}
+    for th in sorted({min(64, ncpu), ncpu}):
+        torch.set_num_threads(th)
+        probes[th] = step(b2)                      # doubles as the warm-up steps
+    threads = min(probes, key=probes.get)
+    torch.set_num_threads(threads)
+    if len(probes) == 1:
+        step(b2)
+    t2 = sorted(step(b2) for _ in range(5))
+    res = dict(unit="samples/s", cores=threads, cores_available=ncpu, kind="port",
+               b2_value=round(2 / t2[2], 3), b2_sample="B=2, %dx%d, 2 warm-up + 5 timed steps, median %.2f s/step" % (H, W, t2[2]))
+    value, sample = res["b2_value"], "B=2"
+    left = budget_s - (time.time() - t_start)
+    if left > 6 * t2[2] * 5:                        # a B=10 step costs ~5x a B=2 step: only if warm-up + >=1 timed step fit
+        b10 = mk(10)
+        step(b10)
+        t10 = []
+        while len(t10) < 3 and (time.time() - t_start) + (t10[-1] if t10 else 5 * t2[2]) < budget_s + 20:
+            t10.append(step(b10))
+        if t10:
+            t10.sort()
+            res["b10_value"] = round(10 / t10[len(t10) // 2], 3)
+            res["b10_sample"] = "B=10, %dx%d, 1 warm-up + %d timed step(s), median %.2f s/step" % (H, W, len(t10), t10[len(t10) // 2])
+            value, sample = res["b10_value"], "B=10 (the GPU line's workload)"
+    res["value"] = value
+    res["sample"] = "oracle.model_cpu.train_step (PyTorch-CPU fp32 restatement of train.py:304-316, %s backbone), %d threads of %d cores; value = %s; %s%s" % (
+        backbone, threads, ncpu, sample, res["b2_sample"], ("; " + res["b10_sample"]) if "b10_sample" in res else "")
+    return res
 
 
 T0 = time.perf_counter()
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=10)
-    ap.add_argument("--height", type=int, default=256)
-    ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dropout", type=float, default=0.1)
-    ap.add_argument("--watchdog", type=int, default=600, help="dump all Python stacks to stderr if still running after this many seconds")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        spawn_ranks(args)
+    import torch
     faulthandler.dump_traceback_later(args.watchdog, repeat=True, file=sys.stderr)
     torch.set_num_threads(min(16, os.cpu_count()))   # host-side glue only; the CPU baseline sets its own count
 
@@ -119,7 +193,10 @@ def main():
     assert world == args.gpus, "WORLD_SIZE %d != --gpus %d" % (world, args.gpus)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
-    H, W, B = args.height, 704, args.batch
+    backbone = args.backbone
+    B = args.batch or {"transFuser": 10, "geometric_fusion": 12, "latentTF": 16}[backbone]
+    H = args.height or (160 if backbone == "geometric_fusion" else 256)
+    W = 704
 
     def make_cfg():   # train.py defaults: n_layer 4, use_target_point_image 1, use_velocity 0, multitask, dropout .1
         cfg = GlobalConfig()
@@ -130,13 +207,14 @@ def main():
 
     cfg = make_cfg()
     torch.manual_seed(0)
-    model = LidarCenterNet(cfg, dev, 'transFuser', 'regnety_032', 'regnety_032', use_velocity=False)
+    model = LidarCenterNet(cfg, dev, backbone, 'regnety_032', 'regnety_032', use_velocity=False)
     model.train()
+    nparam = sum(p.numel() for p in model.parameters())
     hist_fn = lambda pts: ops.lidar_hist(torch.from_numpy(pts).to(dev)[None])[0].cpu().numpy()
     batch = {k: v.to(dev) for k, v in synthetic_batch(B, H, W, seed=rank, hist_fn=hist_fn).items()}
     log("model + batch on device")
     eng = Engine(model, cfg, lr=cfg.lr, use_graph=not args.no_graph)
-    log("engine ready (arena %.1f M floats)" % (eng.arena.numel / 1e6))
+    log("engine ready (arena %.1f M floats, %d backward piece(s))" % (eng.arena.numel / 1e6, eng.n_pieces()))
 
     def sync():
         if world > 1:
@@ -162,28 +240,29 @@ def main():
     loss = float(tot)
     log("timed region done: %.2f ms/step" % (dt / args.steps * 1e3))
     assert loss == loss, "NaN loss"
+    roof = dominant_kernel_roofline(eng, batch, dev, log)      # every rank runs the census step (it contains the collectives); rank 0 reports
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = B * world * args.steps / dt
-        gf = GFLOP_PER_SAMPLE.get(H)
+        gf = GFLOP_PER_SAMPLE.get((backbone, H))
+        names = {"transFuser": "TransFuser", "geometric_fusion": "GeometricFusion", "latentTF": "latentTF"}
         res = {
-            "metric": "training samples/sec (RGB+LiDAR pair), bs=10/GPU", "value": round(value, 2), "unit": "samples/s",
+            "metric": "training samples/sec (RGB+LiDAR pair), bs=%d/GPU" % B, "value": round(value, 2), "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "TransFuser LidarCenterNet (RegNetY-3.2GF x2, 4 GPT x 4 layers, 168.0 M params) full train step, "
-                                   "B=%d/GPU, 3x%dx%d RGB + 3x256x256 BEV, fp32, dropout %.2f, %s" %
-                                   (B, H, W, args.dropout, "hipGraph replay" if not args.no_graph else "eager"),
-                       "global_batch": B * world, "parallelism": "dp%d" % world, "final_loss": round(loss, 4)},
+            "config": {"workload": "%s LidarCenterNet (RegNetY-3.2GF x2, %.1f M params) full train step, B=%d/GPU, 3x%dx%d RGB + 3x256x256 BEV, "
+                                   "fp32, dropout %.2f, %s" % (names[backbone], nparam / 1e6, B, H, W, args.dropout,
+                                                               "hipGraph replay" if not args.no_graph else "eager"),
+                       "global_batch": B * world, "parallelism": "dp%d" % world, "final_loss": round(loss, 4),
+                       "grad_allreduce": ("RCCL, %d backward segments, bucket all-reduce overlapped on a side stream" % eng.n_pieces()) if world > 1 else "none (1 rank)"},
         }
-        roof = dominant_kernel_roofline(dev)
-        log("roofline microbench done")
         if gf:
             step_tf = value / world * gf / 1e3
             roof["step_achieved_tflops"] = round(step_tf, 2)
             roof["step_frac"] = round(step_tf / PEAK_F32_MFMA_TF, 4)
         res["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(make_cfg, H, W)
+            res["cpu_baseline"] = cpu_baseline(make_cfg, backbone, H, W)
         print(json.dumps(res), flush=True)
     if world > 1:
         torch.distributed.barrier()

@@ -648,3 +648,46 @@ def check_gemm_mask(dev, M, N, K):
     want = (dy @ w) * (act > 0)
     got = ops.linear_dgrad(dy, w, mask=act)
     close(got, want, what="masked dgrad")
+
+
+# ---------------------------------------------------------------- the benchmarked shapes under the shipped (tuned) plans, CPU fp32 reference
+BENCH_GEMMS = [(1740, 6048, 1512), (1740, 1512, 6048), (1740, 4536, 1512), (1740, 1512, 1512), (7040, 576, 576), (2560, 576, 576), (28160, 216, 216)]
+
+
+def check_bench_gemm(dev, m, n, k):
+    """GPT-4 / trunk GEMMs of the B=10, 256x704 step exactly as bench.py launches them: the tilings of
+    transfuser_amd/plans/mi355x.txt are loaded (the caller does it), and the reference is PyTorch-CPU fp32 - the reference's own
+    arithmetic path (north_star) - not rocBLAS.  fwd (bias+ReLU), dgrad (+fused ReLU mask), wgrad (accumulate, split-K where tuned)."""
+    x, w, b = R(m, k, dev="cpu"), R(n, k, dev="cpu") * (1.0 / math.sqrt(k)), R(n, dev="cpu")
+    xd, wd, bd = x.to(dev), w.to(dev), b.to(dev)
+    y = ops.linear_fwd(xd, wd, bd, relu=True)
+    close(y, torch.relu(x @ w.t() + b), tol=1e-4, what="bench fwd %dx%dx%d" % (m, n, k))
+    dy = R(m, n, seed=1, dev="cpu")
+    dyd = dy.to(dev)
+    act = R(m, k, seed=2, dev="cpu")
+    close(ops.linear_dgrad(dyd, wd, mask=act.to(dev)), (dy @ w) * (act > 0), tol=1e-4, what="bench dgrad")
+    dw0 = R(n, k, seed=3, dev="cpu") * 0.1
+    dw = ops.linear_wgrad(dyd, xd, dw0.to(dev), accumulate=True)
+    close(dw, dw0 + dy.t() @ x, tol=1e-4, what="bench wgrad")
+
+
+BENCH_CONVS = [(10, 256, 704, 32, 32), (10, 256, 704, 32, 7), (10, 256, 704, 32, 1), (10, 64, 176, 64, 32), (10, 16, 44, 576, 576)]
+
+
+def check_bench_conv(dev, B, H, W, Cin, Cout):
+    """Decoder-tail / grouped trunk 3x3 convolutions at the bench batch (B=10, 256x704 maps) vs F.conv2d on the CPU."""
+    groups = Cin // 24 if Cin == 576 else 1
+    x = R(B, Cin, H, W, dev="cpu").requires_grad_(True)
+    w = (R(Cout, Cin // groups, 3, 3, dev="cpu") * 0.1).requires_grad_(True)
+    b = R(Cout, dev="cpu")
+    y = F.conv2d(x, w, b, 1, 1, 1, groups)
+    dy = R(*y.shape, seed=1, dev="cpu")
+    gx, gw = torch.autograd.grad(y, [x, w], dy)
+    xh, wh = x.detach().permute(0, 2, 3, 1).contiguous().to(dev), cl(w.detach()).to(dev)
+    yh = ops.conv_fwd(xh, wh, b.to(dev), 1, None, groups, relu=False)
+    close(yh.permute(0, 3, 1, 2), y, tol=1e-4, what="bench conv fwd")
+    dyh = dy.permute(0, 2, 3, 1).contiguous().to(dev)
+    close(ops.conv_dgrad(dyh, wh, xh.shape, 1, None, groups).permute(0, 3, 1, 2), gx, tol=1e-4, what="bench conv dgrad")
+    dw = torch.zeros_like(wh)
+    ops.conv_wgrad(dyh, xh, dw, 1, None, groups)
+    close(dw, gw, tol=2e-4, what="bench conv wgrad")

@@ -105,3 +105,57 @@ def _worker(rank, world, port):
 def test_grad_reducer_world2_gloo():
     port = 29500 + (os.getpid() % 2000)
     mp.spawn(_worker, args=(2, port), nprocs=2, join=True)
+
+
+def _engine_worker(rank, world, port, tmp):
+    """The Engine's multi-rank paths on the tiny model (host-emulated kernels): backward cut into segments whose arena ranges are
+    all-reduced as they become ready (the overlap path) == the plain reduce-after-backward path == ZeRO-1; consolidated optimizer save."""
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import ctypes
+    import build_emu
+    from transfuser_amd import _lib
+    _lib._install_test_backend(ctypes.CDLL(build_emu.build()))
+    import model_cases as mc
+    from transfuser_amd.train import Engine, FlatAdamW
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    cfg = mc.tiny_config(n_layer=1)
+    batch = mc.small_batch(1, 32, 64, 64, 40, seed=10 + rank)          # every rank its own shard of the global batch
+    finals = {}
+    for tag, kw in (("overlap", {}), ("plain", dict(cuts=())), ("zero", dict(zero_redundancy_optimizer=True))):
+        prod, _ = mc.build_pair(cfg, "regnety_tiny", "cpu", seed=rank)  # different init per rank: the engine's broadcast equalises
+        prod.train()
+        eng = Engine(prod, cfg, lr=1e-3, **kw)
+        assert eng.cuts == (() if tag == "plain" else (3, 2, 1)) and eng.n_pieces() == len(eng.cuts) + 1
+        for _ in range(2):
+            eng.train_step(batch)
+        finals[tag] = (eng.arena, eng)
+        both = [torch.zeros_like(eng.arena.params) for _ in range(world)]
+        dist.all_gather(both, eng.arena.params)
+        assert torch.equal(both[0], both[1]), tag                       # replicas stay in lock-step
+    name_to = lambda arena: {n: p for n, p, _ in arena.layout}
+    a, b, z = (name_to(finals[t][0]) for t in ("overlap", "plain", "zero"))
+    for n in a:
+        assert torch.equal(a[n], b[n]), n                               # same sums, same scaling: bitwise
+        assert torch.allclose(a[n], z[n], atol=1e-7), n
+    # consolidated ZeRO state (train.py:206-207) == the replicated optimizer's state, on any rank count
+    ez, eo = finals["zero"][1], finals["overlap"][1]
+    assert ez.optimizer.exp_avg.numel() < eo.optimizer.exp_avg.numel()
+    ez.save(tmp, 0)
+    dist.barrier()
+    sd = torch.load(os.path.join(tmp, "optimizer_0.pth"))
+    assert sd["exp_avg"].numel() == eo.arena.active_numel
+    assert torch.allclose(sd["exp_avg"], eo.optimizer.exp_avg, atol=1e-7) and torch.allclose(sd["exp_avg_sq"], eo.optimizer.exp_avg_sq, atol=1e-9)
+    fresh = FlatAdamW(eo.arena, lr=1e-3)                                # resume unsharded ...
+    fresh.load_state_dict(sd)
+    assert torch.equal(fresh.exp_avg, sd["exp_avg"]) and float(fresh.state[0]) == 2.0
+    shard = FlatAdamW(ez.arena, lr=1e-3, shard=(rank, world))           # ... or sharded
+    shard.load_state_dict(sd)
+    assert torch.equal(shard.exp_avg, sd["exp_avg"][shard.lo:shard.hi])
+    dist.destroy_process_group()
+
+
+def test_engine_overlap_plain_zero_world2_gloo(tmp_path):
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_engine_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)

@@ -143,3 +143,24 @@ def test_centernet_decode(case):
 @pytest.mark.parametrize("case", [(130, 72, 96), (10, 64, 32), (200, 50, 150)], ids=str)
 def test_gemm_relu_mask_epilogue(case):
     kc.check_gemm_mask("cuda", *case)
+
+
+@pytest.fixture
+def tuned_plans():
+    """The plan cache bench.py runs with (transfuser_amd/plans/mi355x.txt, loaded by train.Engine)."""
+    import os
+    from transfuser_amd import ops
+    path = os.path.join(os.path.dirname(os.path.abspath(ops.__file__)), "plans", "mi355x.txt")
+    assert ops.plans_load(path) > 100
+    yield
+    ops.L().tf_plans_clear()
+
+
+@pytest.mark.parametrize("case", kc.BENCH_GEMMS, ids=str)
+def test_bench_shape_gemms_with_tuned_plans(case, tuned_plans):
+    kc.check_bench_gemm("cuda", *case)
+
+
+@pytest.mark.parametrize("case", kc.BENCH_CONVS, ids=str)
+def test_bench_shape_convs_with_tuned_plans(case, tuned_plans):
+    kc.check_bench_conv("cuda", *case)

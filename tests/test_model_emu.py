@@ -181,3 +181,49 @@ def test_edge_cases_empty_labels_single_sample_empty_cloud_partial_fusion():
     lp, lr = mc.run_pair(prod, ref, cfg, batch, "cpu")
     mc.compare_vs_fp64(prod, ref, lp, lr, batch, cfg, verbose=False)
     assert prod._model.image_conv1.weight.grad is None and ref._model.image_conv1.weight.grad is None    # stages 1-2 do not fuse
+
+
+def test_segmented_backward_equals_single_autograd_graph():
+    """train.Engine's backward cuts (the multi-GPU overlap path): with cuts after fusion stages 3, 2, 1 the step runs as 4 separately
+    enqueued backward pieces restarted from detached boundary tensors, over an arena re-laid-out in backward-ready order.  Same kernels,
+    same order => gradients, losses and the parameters after two AdamW steps are IDENTICAL to the uncut engine, and the segment ranges
+    tile the arena with every parameter inside the range of its own stage."""
+    from transfuser_amd.train import Engine, param_stage
+    cfg = mc.tiny_config(n_layer=1)
+    batch = mc.small_batch(2, 32, 64, 64, 40)
+    res = []
+    for cuts in ((), (3, 2, 1), (2,)):
+        prod, _ = mc.build_pair(cfg, "regnety_tiny", "cpu")
+        prod.train()
+        eng = Engine(prod, cfg, lr=1e-3, cuts=cuts)
+        assert eng.n_pieces() == len(cuts) + 1 and len(eng.arena.segment_ranges) == len(cuts) + 1
+        out = eng._fwd_bwd(batch)
+        grads = {n: p.grad.detach().clone() for n, p in prod.named_parameters()}
+        eng.optimizer.step()
+        tot2, _ = eng.train_step(batch)
+        res.append((float(out[0]), grads, {n: p.detach().clone() for n, p in prod.named_parameters()}, float(tot2)))
+        # layout: ranges are contiguous, ordered, cover the active arena; each parameter lies in the range of its segment
+        rr = eng.arena.segment_ranges
+        assert rr[0][0] == 0 and rr[-1][1] == eng.arena.active_numel and all(a[1] == b[0] for a, b in zip(rr, rr[1:]))
+        srt = sorted(cuts, reverse=True)
+        for n, p, o in eng.arena.layout:
+            k = sum(1 for c in srt if param_stage(n) <= c)
+            assert rr[k][0] <= o and o + p.numel() <= rr[k][1], (n, k, o, rr)
+        if cuts == (3, 2, 1):
+            sizes = [b - a for a, b in rr]
+            assert sizes[0] > sum(sizes[1:]) * 0 and all(s > 0 for s in sizes)
+    for other in res[1:]:
+        assert other[0] == res[0][0] and other[3] == res[0][3]
+        for n in res[0][1]:
+            assert torch.equal(other[1][n], res[0][1][n]), n
+            assert torch.equal(other[2][n], res[0][2][n]), n
+
+
+def test_param_stage_names():
+    from transfuser_amd.train import param_stage
+    assert param_stage("_model.image_encoder.features.s3.b2.conv1.conv.weight") == 3
+    assert param_stage("_model.lidar_encoder._model.layer4.b1.se.fc1.bias") == 4
+    assert param_stage("_model.transformer2.blocks.1.attn.key.weight") == 2
+    assert param_stage("_model.image_encoder.features.stem.conv.weight") == 0
+    assert param_stage("_model.lidar_encoder._model.conv1.weight") == 0 and param_stage("_model.lidar_encoder._model.bn1.bias") == 0
+    assert param_stage("head.heatmap_head.0.weight") == 5 and param_stage("_model.up_conv4.weight") == 5 and param_stage("join.0.weight") == 5

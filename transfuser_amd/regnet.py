@@ -104,8 +104,35 @@ def register_arch(name, **cfg):
 
 
 def create_model(architecture, pretrained=False, in_chans=3):
-    """Stand-in for ``timm.create_model`` on the training path (transfuser.py:380,442).  ImageNet weights
-    need the network; ``pretrained`` is accepted and ignored (load a checkpoint instead)."""
+    """Stand-in for ``timm.create_model`` on the training path (transfuser.py:380,442).
+
+    ``pretrained=True`` (the reference's ImageCNN default, transfuser.py:380) needs timm's ImageNet weights, which cannot be downloaded
+    here: point ``TRANSFUSER_PRETRAINED`` at a timm ``regnety_032`` state_dict (``torch.save(timm_model.state_dict(), path)``; the key
+    names are timm's, which this class reproduces) and it is loaded - 3x3 weights are converted to channels_last by ``load_state_dict`` -
+    otherwise a warning says loudly that the trunk starts from random initialisation (a recipe difference vs. the reference)."""
+    net = _create(architecture, in_chans)
+    if pretrained:
+        import os
+        import warnings
+        path = os.environ.get("TRANSFUSER_PRETRAINED", "")
+        if path and os.path.exists(path):
+            sd = torch.load(path, map_location="cpu")
+            sd = {k: v for k, v in sd.items() if not k.startswith(("head.", "fc."))}
+            own = net.state_dict()
+            if in_chans != 3:
+                sd.pop("stem.conv.weight", None)
+            sd = {k: (v.contiguous(memory_format=torch.channels_last) if v.dim() == 4 else v) for k, v in sd.items() if k in own and own[k].shape == v.shape}
+            missing = net.load_state_dict(sd, strict=False)
+            left = [k for k in missing.missing_keys if not k.startswith("fc.") and not (in_chans != 3 and k == "stem.conv.weight")]
+            if left:
+                warnings.warn("pretrained RegNet checkpoint %s lacks %d tensors (e.g. %s): they keep their random initialisation" % (path, len(left), left[0]))
+        else:
+            warnings.warn("create_model(%r, pretrained=True): no ImageNet weights available (set TRANSFUSER_PRETRAINED=<timm regnety_032 state_dict>); "
+                          "the trunk is RANDOMLY initialised - the reference starts from timm's ImageNet weights (transfuser.py:380)" % architecture)
+    return net
+
+
+def _create(architecture, in_chans=3):
     if architecture not in _ARCH:
         raise ValueError("transfuser_amd supports RegNetY trunks %s on the hot path (train.py:50-53 defaults), got %r" % (sorted(_ARCH), architecture))
     c = dict(_ARCH[architecture])

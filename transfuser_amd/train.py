@@ -7,10 +7,15 @@ AdamW optimiser (:142) and the DDP gradient all-reduce (:134), re-designed for M
 * ``FlatAdamW``    - torch.optim.AdamW semantics in one kernel launch over the arena (K18).
 * ``GradReducer``  - data-parallel gradient mean over RCCL (``torch.distributed`` backend "nccl" on
   ROCm; "gloo" in the CPU tests): the arena is cut into large buckets that are all-reduced on a side
-  HIP stream while the next bucket is being queued - no per-parameter hooks, no Python in the loop.
+  HIP stream - no per-parameter hooks, no Python in the loop.  ``reduce_async(lo, hi)`` starts the
+  all-reduce of one arena range as soon as the backward SEGMENT that produces it has been enqueued.
 * ``Engine``       - ``train_step`` = zero grads -> forward -> weighted loss sum -> backward ->
-  (all-reduce) -> AdamW, optionally captured into ONE hipGraph and replayed (the step has ~2.5k
-  kernel launches; replay removes the host launch cost and Python entirely).
+  (all-reduce) -> AdamW, optionally captured into hipGraphs and replayed (the step has ~2.5k
+  kernel launches; replay removes the host launch cost and Python entirely).  With more than one
+  rank the backward is cut at the fusion-stage boundaries into segments (one graph each) and the
+  arena is laid out in backward-ready order, so the all-reduce of the ~130 M stage-4 / head gradients
+  runs on the side stream while stages 3..1 are still being differentiated (DDP's overlap,
+  train.py:134, without hooks).
 """
 import os
 
@@ -33,8 +38,23 @@ def _group_key(name):
     return name, 0
 
 
+_STAGE_RE = __import__("re").compile(r"(?:^|\.)(?:image_encoder\.features|lidar_encoder\._model)\.(?:s|layer)([1-4])\.|(?:^|\.)transformer([1-4])\.")
+_STEM_RE = __import__("re").compile(r"(?:^|\.)(?:image_encoder\.features|lidar_encoder\._model)\.(?:stem|conv1|bn1)\.")
+
+
+def param_stage(name):
+    """Fusion stage a parameter belongs to: 1..4 = RegNet stage k of either trunk / GPT k, 0 = the two stems, 5 = everything after the
+    backbone's last stage (channel reducers, FPN, decoders, heads, join / GRU).  Backward produces gradients in DEcreasing stage order."""
+    m = _STAGE_RE.search(name)
+    if m:
+        return int(m.group(1) or m.group(2))
+    return 0 if _STEM_RE.search(name) else 5
+
+
 class ParamArena:
-    def __init__(self, model):
+    def __init__(self, model, cuts=()):
+        """``cuts`` = fusion stages after which the backward is cut (e.g. (3, 2, 1)): parameters are then grouped by backward segment,
+        first-finished segment first, and ``segment_ranges`` lists each segment's [lo, hi) float range of the arena."""
         named, seen = [], set()
         for n, p in model.named_parameters(remove_duplicate=True):
             if id(p) not in seen:
@@ -44,6 +64,11 @@ class ParamArena:
         # (no weight decay either): they go to the END of the arena, outside the range the optimizer updates.
         unused = {id(p) for m in model.modules() if hasattr(m, "unused_parameters") for p in m.unused_parameters()}
         named = [t for t in named if id(t[1]) not in unused] + [t for t in named if id(t[1]) in unused]
+        cuts = sorted(set(int(c) for c in cuts), reverse=True)
+        seg_of = lambda name: sum(1 for c in cuts if param_stage(name) <= c)      # 0 = produced first in the backward
+        if cuts:   # stable sort by segment; the never-reached parameters stay at the very end
+            live = [t for t in named if id(t[1]) not in unused]
+            named = sorted(live, key=lambda t: seg_of(t[0])) + [t for t in named if id(t[1]) in unused]
         groups, order = {}, []
         for n, p in named:
             k, rank = _group_key(n)
@@ -65,6 +90,18 @@ class ParamArena:
         self.grads = torch.zeros(self.numel, dtype=torch.float32, device=dev)
         self.layout = layout
         self.n_params = sum(p.numel() for _, p in named)
+        # [lo, hi) of every backward segment (aligned; together they cover [0, active_numel)); one range when there are no cuts
+        nseg = len(cuts) + 1
+        first = [None] * nseg
+        for n, p, o in layout:
+            if id(p) not in unused and first[seg_of(n)] is None:
+                first[seg_of(n)] = o // _ALIGN * _ALIGN
+        self.segment_ranges, hi = [], self.active_numel
+        for k in reversed(range(nseg)):
+            lo = first[k] if first[k] is not None else hi
+            self.segment_ranges.insert(0, (lo, hi))
+            hi = lo
+        assert self.segment_ranges[0][0] == 0 or not cuts
         with torch.no_grad():
             for n, p, o in layout:
                 # keep each parameter's logical shape AND memory format (channels_last conv weights)
@@ -111,11 +148,34 @@ class FlatAdamW:
         ops.adamw_(a.params[self.lo:self.hi], a.grads[self.lo:self.hi], self.exp_avg, self.exp_avg_sq, self.state, self.betas[0], self.betas[1],
                    self.eps, self.weight_decay)
 
-    def state_dict(self):
-        return dict(exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, state=self.state)
+    def state_dict(self, group=None):
+        """FULL optimizer state (moments over the whole active arena, {step, lr}).  With a sharded optimizer every rank must call this
+        (collective): the slices are gathered first - the reference's ``optimizer.consolidate_state_dict(0)`` before saving
+        (train.py:206-207) - so a checkpoint never depends on the world size it was written with."""
+        ea, es = self.exp_avg, self.exp_avg_sq
+        if hasattr(self, "shard_size") and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            world, per, n = dist.get_world_size(group), self.shard_size, self.arena.active_numel
+            full = []
+            for t in (ea, es):
+                mine = torch.zeros(per, dtype=t.dtype, device=t.device)
+                mine[:t.numel()] = t
+                parts = [torch.empty_like(mine) for _ in range(world)]
+                dist.all_gather(parts, mine, group=group)
+                full.append(torch.cat(parts)[:n].clone())
+            ea, es = full
+        return dict(exp_avg=ea, exp_avg_sq=es, state=self.state, active_numel=self.arena.active_numel)
 
     def load_state_dict(self, sd):
-        self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"]); self.state.copy_(sd["state"])
+        """Accepts the full state written by ``state_dict`` on any world size; a sharded optimizer keeps its own slice."""
+        n = self.arena.active_numel
+        for name, dst in (("exp_avg", self.exp_avg), ("exp_avg_sq", self.exp_avg_sq)):
+            src = sd[name]
+            if src.numel() == n and dst.numel() != n:
+                src = src[self.lo:self.hi]
+            if src.numel() != dst.numel():
+                raise ValueError("optimizer state %s has %d elements, expected %d (full) or %d (this rank's shard)" % (name, sd[name].numel(), n, dst.numel()))
+            dst.copy_(src)
+        self.state.copy_(sd["state"])
 
 
 class GradReducer:
@@ -148,6 +208,31 @@ class GradReducer:
             lo, hi = min(n, r * per), min(n, (r + 1) * per)
             if hi > lo:
                 dist.broadcast(p[lo:hi], r, group=self.group)
+
+    def reduce_async(self, lo, hi):
+        """All-reduce (mean) the gradient range [lo, hi) on the side stream, ordered after everything enqueued so far on the current
+        stream - call it right after the backward segment that produces the range; the current stream keeps running the next segment."""
+        if self.world == 1 or hi <= lo:
+            return
+        g = self.arena.grads
+        per = self.buckets[0][1] - self.buckets[0][0]
+        if self.stream is not None:
+            self.stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream):
+                for s in range(lo, hi, per):
+                    e = min(hi, s + per)
+                    dist.all_reduce(g[s:e], op=dist.ReduceOp.SUM, group=self.group)
+                    ops.scale_dev_(g[s:e], None, None, 1.0 / self.world)
+        else:
+            for s in range(lo, hi, per):
+                e = min(hi, s + per)
+                dist.all_reduce(g[s:e], op=dist.ReduceOp.SUM, group=self.group)
+                ops.scale_dev_(g[s:e], None, None, 1.0 / self.world)
+
+    def finish(self):
+        """The optimizer (current stream) waits for every pending bucket."""
+        if self.world > 1 and self.stream is not None:
+            torch.cuda.current_stream().wait_stream(self.stream)
 
     def reduce(self):
         if self.world == 1:
@@ -184,9 +269,13 @@ class Engine:
 
     BATCH_KEYS = ("rgb", "lidar", "ego_waypoint", "target_point", "target_point_image", "ego_vel", "bev", "label", "depth", "semantic")
     GEO_KEYS = ("bev_points", "cam_points")   # train.py:280-288 (geometric_fusion only)
+    DEFAULT_CUTS = (3, 2, 1)                  # backward segments: [heads + stage 4] [stage 3] [stage 2] [stage 1 + stems]
 
     def __init__(self, model, config, lr=1e-4, use_graph=False, group=None, bucket_mb=64.0, wp_only=False, autotune=True, plan_file=None,
-                 zero_redundancy_optimizer=False, sync_batch_norm=False):
+                 zero_redundancy_optimizer=False, sync_batch_norm=False, cuts=None):
+        """``cuts``: fusion stages after which the backward is cut into separately enqueued (and separately captured) segments whose
+        gradient ranges are all-reduced while the next segment runs.  None = DEFAULT_CUTS when there is more than one rank (and the
+        backbone is a chain: transFuser / latentTF), no cut on a single GPU; () = never cut."""
         self.model = model
         self.config = config
         self._autotune_pending = bool(autotune) and next(model.parameters()).is_cuda
@@ -194,11 +283,19 @@ class Engine:
             plan_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "plans", "mi355x.txt")
         if next(model.parameters()).is_cuda and os.path.exists(plan_file):
             ops.plans_load(plan_file)
-        if sync_batch_norm and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:   # train.py:132-133
+        world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        if sync_batch_norm and world > 1:   # train.py:132-133
             from .functions import convert_sync_batchnorm
             convert_sync_batchnorm(model, group)
             use_graph = False       # collectives between the BatchNorm kernels: eager only
-        self.arena = ParamArena(model)
+        backbone = getattr(model, "_model", None)
+        can_cut = getattr(model, "backbone", "") in ("transFuser", "latentTF") and hasattr(backbone, "_cuts")
+        if cuts is None:
+            cuts = self.DEFAULT_CUTS if world > 1 else ()
+        self.cuts = tuple(sorted(set(int(c) for c in cuts), reverse=True)) if can_cut else ()
+        if can_cut:
+            backbone._cuts = frozenset(self.cuts)
+        self.arena = ParamArena(model, self.cuts)
         self.reducer = GradReducer(self.arena, group, bucket_mb)
         self.zero = bool(zero_redundancy_optimizer) and self.reducer.world > 1      # train.py:143-146
         rank = dist.get_rank(group) if self.zero else 0
@@ -212,7 +309,7 @@ class Engine:
                                 ("heatmap_head", "wh_head", "offset_head", "yaw_class_head", "yaw_res_head", "velocity_head", "brake_head")))
         model._dead_heads = frozenset(h for k, h in loss_to_head.items() if self.detailed_weights.get(k, 1.0) == 0.0)
         self.use_graph = use_graph
-        self._graph = None
+        self._graphs = None
         self._static = None
         self._out = None
 
@@ -225,15 +322,14 @@ class Engine:
                           target_point_image=data["target_point_image"], ego_vel=data["ego_vel"].reshape(-1, 1), bev=data["bev"],
                           label=data["label"], depth=data["depth"], semantic=data["semantic"], **extra)
 
-    def _fwd_bwd(self, data):
-        if self._autotune_pending and not torch.cuda.is_current_stream_capturing():
-            # first eager iteration: let the engine time its candidate tilings for every distinct problem of the step
-            self._autotune_pending = False
-            ops.autotune(True)
-            try:
-                return self._fwd_bwd(data)
-            finally:
-                ops.autotune(False)
+    # ---- the step as a sequence of PIECES: piece 0 = zero grads + forward + weighted loss + backward down to the first cut, piece i > 0 =
+    # backward of the next segment (restarted from the detached boundary tensors the backbone recorded).  After piece i the arena range
+    # self.arena.segment_ranges[i] holds this rank's final gradients.  Eager mode runs the pieces back to back; graph mode captures one
+    # hipGraph per piece; in both the reducer is told about a range as soon as its piece is enqueued.
+    def n_pieces(self):
+        return len(self.cuts) + 1
+
+    def _piece0(self, data):
         self.optimizer.zero_grad()
         losses = self.load_data_compute_loss(data)
         loss = None
@@ -241,67 +337,113 @@ class Engine:
             term = self.detailed_weights[key] * value
             loss = term if loss is None else loss + term
         loss.backward()
+        self._pending = list(getattr(getattr(self.model, "_model", None), "_boundaries", ()) or ()) if self.cuts else []
+        assert len(self._pending) == len(self.cuts), "backbone recorded %d boundaries for %d cuts" % (len(self._pending), len(self.cuts))
         return loss.detach(), {k: v.detach() for k, v in losses.items()}
+
+    def _piece(self, i):
+        outs, leaves = self._pending[len(self._pending) - i]        # boundaries were recorded in forward order; backward walks them in reverse
+        torch.autograd.backward(list(outs), [l.grad for l in leaves])
+        if i == len(self._pending):
+            self._pending = []
+            self.model._model._boundaries = []
+
+    def _fwd_bwd(self, data, reduce=False):
+        if self._autotune_pending and not torch.cuda.is_current_stream_capturing():
+            # first eager iteration: let the engine time its candidate tilings for every distinct problem of the step
+            self._autotune_pending = False
+            ops.autotune(True)
+            try:
+                return self._fwd_bwd(data, reduce)
+            finally:
+                ops.autotune(False)
+        out = self._piece0(data)
+        if reduce:
+            self.reducer.reduce_async(*self.arena.segment_ranges[0])
+        for i in range(1, self.n_pieces()):
+            self._piece(i)
+            if reduce:
+                self.reducer.reduce_async(*self.arena.segment_ranges[i])
+        if reduce:
+            self.reducer.finish()
+        return out
 
     def _bump_seed(self):
         seed = getattr(self.model._model, "dropout_seed", None)
         if seed is not None:
             seed.add_(1)
 
+    def _eager_step(self, data):
+        out = self._fwd_bwd(data, reduce=True)
+        self.optimizer.step()
+        if self.zero:
+            self.reducer.all_gather_params(self.optimizer)
+        self._bump_seed()
+        return out
+
     def train_step(self, data):
         """Returns (total loss, dict of the 11 detailed losses) as device tensors (no host sync)."""
         if not self.use_graph or getattr(self.model, "use_point_pillars", False):   # pillar counts are read on the host: eager only
-            out = self._fwd_bwd(data)
-            self.reducer.reduce()
-            self.optimizer.step()
-            if self.zero:
-                self.reducer.all_gather_params(self.optimizer)
-            self._bump_seed()
-            return out
-        if self._graph is None:
+            return self._eager_step(data)
+        if self._graphs is None:
             self._capture(data)
         else:
             for k in self._static:
                 if self._static[k].data_ptr() != data[k].data_ptr():
                     self._static[k].copy_(data[k], non_blocking=True)
-        self._graph.replay()
-        if self.reducer.world > 1:
-            self.reducer.reduce()
+        for i, g in enumerate(self._graphs):
+            g.replay()
+            self.reducer.reduce_async(*self.arena.segment_ranges[i])      # no-op on a single rank
+        if self._opt_graph is not None:
+            self.reducer.finish()
             self._opt_graph.replay()
             if self.zero:
                 self.reducer.all_gather_params(self.optimizer)
         return self._out
 
     def _capture(self, data):
-        """Capture forward+backward(+AdamW when single-GPU) into a hipGraph.  With >1 rank the gradient
-        all-reduce stays outside the graph (eager RCCL calls) followed by a second, tiny AdamW graph."""
+        """Capture the step into hipGraphs: ONE graph (forward + backward + AdamW) on a single GPU without cuts; otherwise one graph per
+        backward piece (sharing a memory pool; the autograd graph built while capturing piece 0 is consumed by the later captures) plus a
+        tiny AdamW graph - the gradient all-reduces stay outside the graphs as eager RCCL calls on the reducer's side stream."""
         self._static = {k: data[k].clone() for k in self.BATCH_KEYS + self.GEO_KEYS + ("num_points",) if k in data}
+        # The warm-up iterations (allocator, lazy inits, autotune) must leave NO trace: the first replay is training step 1, exactly as in
+        # the eager loop / the reference's one-update-per-batch loop (train.py:304-316).  Everything a step mutates is snapshotted and put
+        # back: parameters, AdamW moments + step counter, BatchNorm running statistics / dropout seed (all module buffers).
+        opt = self.optimizer
+        snap = [(t, t.clone()) for t in [self.arena.params, opt.exp_avg, opt.exp_avg_sq, opt.state] + list(self.model.buffers())]
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):   # warm-up on a side stream (allocator + lazy inits) before capture
             for _ in range(2):
-                self._fwd_bwd(self._static)
-                self.reducer.reduce()
-                self.optimizer.step()
-                if self.zero:
-                    self.reducer.all_gather_params(self.optimizer)
-                self._bump_seed()
+                self._eager_step(self._static)
+            with torch.no_grad():
+                for t, saved in snap:
+                    t.copy_(saved)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        self._graph = torch.cuda.CUDAGraph()
-        single = self.reducer.world == 1
-        with torch.cuda.graph(self._graph):
-            self._out = self._fwd_bwd(self._static)
-            if single:
+        del snap
+        fused_opt = self.reducer.world == 1 and self.n_pieces() == 1
+        self._graphs = [torch.cuda.CUDAGraph() for _ in range(self.n_pieces())]
+        with torch.cuda.graph(self._graphs[0]):
+            self._out = self._piece0(self._static)
+            if fused_opt:
                 self.optimizer.step()
                 self._bump_seed()
-        if not single:
+        pool = self._graphs[0].pool()
+        for i in range(1, self.n_pieces()):
+            with torch.cuda.graph(self._graphs[i], pool=pool):
+                self._piece(i)
+        if fused_opt:
+            self._opt_graph = None
+        else:
             self._opt_graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._opt_graph):
+            with torch.cuda.graph(self._opt_graph, pool=pool):
                 self.optimizer.step()
                 self._bump_seed()
 
     def save(self, path_prefix, epoch):
-        """train.py:381-384 (rank 0)."""
-        torch.save(self.model.state_dict(), "%s/model_%d.pth" % (path_prefix, epoch))
-        torch.save(self.optimizer.state_dict(), "%s/optimizer_%d.pth" % (path_prefix, epoch))
+        """train.py:204-210,381-384: every rank calls it (the ZeRO state is consolidated collectively), rank 0 writes."""
+        osd = self.optimizer.state_dict(self.reducer.group)
+        if self.reducer.world == 1 or dist.get_rank(self.reducer.group) == 0:
+            torch.save(self.model.state_dict(), "%s/model_%d.pth" % (path_prefix, epoch))
+            torch.save({k: (v.cpu() if torch.is_tensor(v) else v) for k, v in osd.items()}, "%s/optimizer_%d.pth" % (path_prefix, epoch))

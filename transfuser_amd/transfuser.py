@@ -164,6 +164,8 @@ class _FusionBackbone(nn.Module):
     """What the reference's backbones share: the two RegNet trunks, the 1512->512 channel reducers, the FPN top-down path
     (transfuser.py:91-118) and the two-stream execution of the trunks."""
 
+    _cuts = frozenset()      # fusion stages after which train.Engine cuts the backward (set by the engine; () = one autograd graph)
+
     def _build_common(self, config, image_architecture, lidar_architecture):
         self.config = config
         self.image_encoder = ImageCNN(architecture=image_architecture, normalize=True, out_features=config.perception_output_features)
@@ -236,20 +238,31 @@ class _FusionBackbone(nn.Module):
                 out = fn()
             return out
 
-        x = self._img_stem(image.contiguous())
+        # fork BEFORE the image branch's kernels are enqueued (side.wait_stream(main) orders the LiDAR branch after everything already on
+        # main): the two trunks of a stage are then independent graph branches instead of image-then-LiDAR
         if lidar_nhwc is not None:    # PointPillars canvas (already NHWC, rotated, target-point channel appended): differentiable stem
             from .point_pillar import PillarStemFn
             st = self._lid_stem
             y = lidar_branch(lambda: PillarStemFn.apply(lidar_nhwc, st, st.conv.weight, st.bn.weight, st.bn.bias))
         else:
             y = lidar_branch(lambda: self._lid_stem(lidar.contiguous(), lidar_extra.contiguous() if lidar_extra is not None else None))
+        x = self._img_stem(image.contiguous())
+        self._boundaries = []
+        cuts = getattr(self, "_cuts", frozenset())
         for i in range(1, 5):
-            x = getattr(im, "layer%d" % i)(x)
             y = lidar_branch(lambda y=y, i=i: getattr(li, "layer%d" % i)(y))
+            x = getattr(im, "layer%d" % i)(x)
             if side is not None:
                 main.wait_stream(side)          # join: the fusion stage consumes both branches on the main stream
                 y.record_stream(main)
             x, y = fuse(i, x, y)
+            if i in cuts and torch.is_grad_enabled() and x.requires_grad:
+                # backward cut (train.Engine): the autograd graph is severed here; the engine restarts the backward of the earlier stages
+                # from these tensors with the gradients that arrive at the detached leaves, after it has handed the later stages'
+                # gradient range to the all-reduce.  Values are untouched - same memory, no copy.
+                xd, yd = x.detach().requires_grad_(True), y.detach().requires_grad_(True)
+                self._boundaries.append(((x, y), (xd, yd)))
+                x, y = xd, yd
             if side is not None:
                 y.record_stream(side)
         x = self._conv(self.change_channel_conv_image, x)
