@@ -148,9 +148,9 @@ def test_forward_ego_inference_path():
 def test_engine_graph_replay_matches_eager(dropout):
     """hipGraph-captured training == eager training STEP FOR STEP: same kernels in the same order on the same batch, the capture's warm-up
     iterations leave no trace (parameters / AdamW state / BatchNorm statistics / dropout seed restored), so the loss SEQUENCE, the final
-    parameters and the AdamW step counter must coincide.  One tiling without split-K is pinned so no fp32 atomics are involved and the
-    comparison is exact; dropout uses the counter-based RNG keyed by the (restored) device seed, so p > 0 is covered as well."""
-    from transfuser_amd import ops
+    parameters and the AdamW step counter must coincide (up to the fp32-atomics noise explained at the assertion).  One tiling without
+    split-K is pinned; dropout uses the counter-based RNG keyed by the (restored) device seed, so p > 0 is covered as well."""
+    from transfuser_amd import ops, transfuser as ptf
     from transfuser_amd.train import Engine
     cfg = mc.tiny_config(n_layer=1, dropout=dropout)
     batch = {k: v.cuda() for k, v in mc.small_batch(2, 32, 64, 64, 40).items()}
@@ -158,6 +158,7 @@ def test_engine_graph_replay_matches_eager(dropout):
     ops.force_plan(64, 64, 16, 1)
     try:
         for use_graph in (False, True):
+            ptf.GPT._site_base = 0          # dropout sites are numbered per constructed GPT (class counter): same numbering for both models
             prod, _ = mc.build_pair(cfg, "regnety_tiny", "cuda")
             prod.train()
             eng = Engine(prod, cfg, lr=1e-3, use_graph=use_graph, autotune=False)
@@ -173,8 +174,43 @@ def test_engine_graph_replay_matches_eager(dropout):
     finally:
         ops.force_plan(0)
     assert steps == [5.0, 5.0], steps                                   # one AdamW update per train_step call, graph or not
-    assert torch.equal(outs[0], outs[1]), (outs[0] - outs[1]).abs().max()
-    assert torch.equal(params[0], params[1]) and torch.equal(rmean[0], rmean[1])
+    # Not bitwise: the SE squeeze / pooled column sums accumulate with fp32 atomics (ops.colsum(pooled=True)), so two runs of the SAME
+    # program differ in the last bits and AdamW amplifies round-off-level gradients to +-lr on isolated weights.  A left-over warm-up
+    # update (the r01 bug: 3 updates before the first replay) shifts the whole loss sequence by two steps - several per cent.
+    rel = ((outs[0] - outs[1]).abs() / outs[0].abs().clamp_min(1e-3)).max().item()
+    print("  graph vs eager: max relative loss difference over 5 steps x 12 values: %.2e; params max abs diff %.2e, mean %.2e" %
+          (rel, (params[0] - params[1]).abs().max().item(), (params[0] - params[1]).abs().mean().item()))
+    assert rel <= 2e-4, (rel, outs[0][:, 0], outs[1][:, 0])
+    assert (params[0] - params[1]).abs().mean().item() <= 2e-6 and (rmean[0] - rmean[1]).abs().max().item() <= 1e-4
+
+
+def test_engine_segmented_graphs_match_single_graph():
+    """The multi-GPU step structure on one GPU: backward cut after fusion stages 3, 2, 1 -> four hipGraphs sharing one memory pool (the
+    autograd graph built while capturing piece 0 is consumed by the later captures) + an AdamW graph, arena re-laid-out in backward-ready
+    order.  Must reproduce the single-graph engine exactly (losses of 4 steps, final parameters by name)."""
+    from transfuser_amd import ops, transfuser as ptf
+    from transfuser_amd.train import Engine
+    cfg = mc.tiny_config(n_layer=2, lidar_res=128, dropout=0.1)
+    batch = {k: v.cuda() for k, v in mc.small_batch(2, 160, 352, 128, 40).items()}
+    res = []
+    ops.force_plan(64, 64, 16, 1)
+    try:
+        for cuts in ((), (3, 2, 1)):
+            ptf.GPT._site_base = 0
+            prod, _ = mc.build_pair(cfg, "regnety_tiny", "cuda")
+            prod.train()
+            eng = Engine(prod, cfg, lr=1e-3, use_graph=True, autotune=False, cuts=cuts)
+            losses = [float(eng.train_step(batch)[0]) for _ in range(4)]
+            torch.cuda.synchronize()
+            assert len(eng._graphs) == len(cuts) + 1
+            res.append((losses, {n: p.detach().clone() for n, p in prod.named_parameters()}))
+    finally:
+        ops.force_plan(0)
+    a, b = torch.tensor(res[0][0], dtype=torch.float64), torch.tensor(res[1][0], dtype=torch.float64)
+    assert ((a - b).abs() / a.abs()).max().item() <= 2e-4, (res[0][0], res[1][0])        # fp32 atomics: see test_engine_graph_replay_matches_eager
+    num = sum((p - res[1][1][n]).abs().sum().item() for n, p in res[0][1].items())
+    den = sum(p.numel() for p in res[0][1].values())
+    assert num / den <= 2e-6, num / den
 
 
 def test_bench_configuration_parity_B10_H256():
@@ -232,7 +268,10 @@ def test_single_block_gradients_within_1e3():
     with torch.no_grad():
         ob.conv3.bn.weight.uniform_(0.5, 1.0)
     pb = preg.Bottleneck(216, 576, 2, 24, 0.25).cuda()
-    pb.load_state_dict({k: (v.contiguous(memory_format=torch.channels_last) if v.dim() == 4 else v) for k, v in ob.state_dict().items()}, strict=True)
+    pb.load_state_dict(ob.state_dict(), strict=True)
+    for m in pb.modules():                # 3x3 weights live channels_last on the product path (LidarCenterNet.__init__ does this for the whole model)
+        if isinstance(m, torch.nn.Conv2d):
+            m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
     ob.train(); pb.train()
     x = torch.randn(4, 216, 32, 44)
     xo = x.clone().requires_grad_(True)

@@ -1,0 +1,19 @@
+#!/usr/bin/env python
+"""Launches ONE GEMM shape under the shipped tuned plan (transfuser_amd/plans/mi355x.txt) - the PMC target of tools/pmc_roofline.sh.
+python tools/gemm_tuned.py M N K [form nt|nn|tn] [iters]"""
+import os, sys, torch
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+from transfuser_amd import ops
+M, N, K = [int(v) for v in sys.argv[1:4]]
+form = sys.argv[4] if len(sys.argv) > 4 else "nt"
+iters = int(sys.argv[5]) if len(sys.argv) > 5 else 10
+ops.plans_load(os.path.join(ROOT, "transfuser_amd", "plans", "mi355x.txt"))
+dev = "cuda"
+x = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev) * 0.02; b = torch.zeros(N, device=dev); out = torch.empty(M, N, device=dev)
+dy = torch.randn(M, N, device=dev); dw = torch.zeros(N, K, device=dev); dx = torch.empty(M, K, device=dev)
+for _ in range(iters + 2):
+    if form == "nt": ops.linear_fwd(x, w, b, relu=True, out=out)
+    elif form == "nn": ops.linear_dgrad(dy, w, out=dx)
+    else: ops.linear_wgrad(dy, x, dw, accumulate=True)
+torch.cuda.synchronize()

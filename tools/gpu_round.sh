@@ -1,0 +1,20 @@
+#!/bin/bash
+# One GPU-box pass of the round-2 evidence (run from the repo root through gpurun); every step bounded by its own timeout.
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out
+mkdir -p $O
+cd $R
+for what in "$@"; do
+case $what in
+tests_new)  timeout 900 python -m pytest tests/test_model_gpu.py -q -k "graph or segmented or bench_configuration or single_block" -s 2>&1 | tail -40 > $O/r02_tests_new.log; tail -15 $O/r02_tests_new.log ;;
+tests_all)  timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -25 > $O/r02_gpu_tests.log; tail -8 $O/r02_gpu_tests.log ;;
+bench)      timeout 420 python bench.py --steps 20 --warmup 5 > $O/r02_bench_n1.json 2> $O/r02_bench_n1.err; tail -4 $O/r02_bench_n1.err; cat $O/r02_bench_n1.json ;;
+bench_fast) timeout 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/r02_bench_fast.json 2> $O/r02_bench_fast.err; tail -2 $O/r02_bench_fast.err; cat $O/r02_bench_fast.json ;;
+pmc)        timeout 600 bash tools/pmc_roofline.sh 2>&1 | tail -20 ;;
+hbm)        timeout 200 python tools/hbm_bench.py > $O/r02_hbm_kernels.txt 2>&1; cat $O/r02_hbm_kernels.txt ;;
+trace)      (cd /tmp && export TMPDIR=/tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $O/trace_r02 -o step --output-format csv -- python $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline > $O/r02_trace_bench.log 2>&1)
+            python tools/trace_csv_stats.py $O/trace_r02 > $O/r02_kernel_trace_graph.txt 2>&1; head -60 $O/r02_kernel_trace_graph.txt
+            cp $O/trace_r02/*kernel_stats.csv $O/r02_kernel_stats.csv 2>/dev/null; rm -rf $O/trace_r02 ;;
+tune)       timeout 300 python tools/tune.py $O/mi355x_r02.txt 10 256,160 2>&1 | tail -4 ;;
+esac
+done

@@ -108,7 +108,7 @@ def create_model(architecture, pretrained=False, in_chans=3):
 
     ``pretrained=True`` (the reference's ImageCNN default, transfuser.py:380) needs timm's ImageNet weights, which cannot be downloaded
     here: point ``TRANSFUSER_PRETRAINED`` at a timm ``regnety_032`` state_dict (``torch.save(timm_model.state_dict(), path)``; the key
-    names are timm's, which this class reproduces) and it is loaded - 3x3 weights are converted to channels_last by ``load_state_dict`` -
+    names are timm's, which this class reproduces) and it is loaded (LidarCenterNet.__init__ then moves the 3x3 weights to channels_last) -
     otherwise a warning says loudly that the trunk starts from random initialisation (a recipe difference vs. the reference)."""
     net = _create(architecture, in_chans)
     if pretrained:
