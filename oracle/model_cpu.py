@@ -27,10 +27,11 @@ class LidarCenterNet(nn.Module):
             self.point_pillar_net = PointPillarNet(config.num_input, config.num_features, min_x=config.min_x, max_x=config.max_x,
                                                    min_y=config.min_y, max_y=config.max_y, pixels_per_meter=int(config.pixels_per_meter))
         tf = backbone_module or transfuser_cpu
-        assert backbone in ('transFuser', 'latentTF', 'geometric_fusion')
+        assert backbone in ('transFuser', 'latentTF', 'geometric_fusion', 'late_fusion')
         self.backbone = backbone
         kw = {} if backbone_module is not None else dict(make_net=make_net)
-        cls = dict(transFuser='TransfuserBackbone', latentTF='latentTFBackbone', geometric_fusion='GeometricFusionBackbone')[backbone]
+        cls = dict(transFuser='TransfuserBackbone', latentTF='latentTFBackbone', geometric_fusion='GeometricFusionBackbone',
+                   late_fusion='LateFusionBackbone')[backbone]
         cls = getattr(tf, cls)
         self._model = cls(config, image_architecture, lidar_architecture, use_velocity=use_velocity, **kw)
         if config.multitask:

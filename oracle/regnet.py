@@ -112,6 +112,19 @@ class RegNet(nn.Module):
                 nn.init.zeros_(m.conv3.bn.weight)  # zero_init_last_bn
 
 
+def _regnet_forward(self, x):
+    """timm RegNet.forward = forward_features (stem, s1..s4) + head; late_fusion.py:126-130 replaces head / fc / global_pool by identities."""
+    x = self.s4(self.s3(self.s2(self.s1(self.stem(x)))))
+    for name in ("global_pool", "head"):
+        m = getattr(self, name, None)
+        if isinstance(m, nn.Module):
+            x = m(x)
+    return x
+
+
+RegNet.forward = _regnet_forward
+
+
 def regnety_032(in_chans=3):
     widths, depths = regnet_widths(80, 42.63, 2.66, 21, 24)
     assert widths == [72, 216, 576, 1512] and depths == [2, 5, 13, 1], (widths, depths)

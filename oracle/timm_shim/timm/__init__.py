@@ -14,8 +14,13 @@ def register(name, fn):
 
 
 def create_model(architecture, pretrained=False, **kw):
+    in_chans = kw.get("in_chans", 3)        # late_fusion.py:155 builds the LiDAR trunk with in_chans=...
     if architecture in _REGISTRY:
-        return _REGISTRY[architecture]()
+        try:
+            return _REGISTRY[architecture](in_chans=in_chans)
+        except TypeError:
+            assert in_chans == 3, "registered test net does not take in_chans"
+            return _REGISTRY[architecture]()
     if architecture == "regnety_032":
-        return _regnet.regnety_032()  # pretrained weights need network: seeded random init instead
+        return _regnet.regnety_032(in_chans)  # pretrained weights need network: seeded random init instead
     raise ValueError("timm shim only provides regnety_032 (+registered test nets), got %r" % architecture)

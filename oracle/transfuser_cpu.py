@@ -207,6 +207,56 @@ class latentTFBackbone(TransfuserBackbone):
         return super().forward(image, lidar, velocity)
 
 
+class LateFusionBackbone(nn.Module):
+    """team_code_transfuser/late_fusion.py:5-111: the two trunks run WITHOUT any exchange (timm models used as they
+    are - no re-labelling, the LiDAR trunk is created with in_chans, late_fusion.py:126-130,155-159), 1x1 reducers to 512, FPN on the
+    LiDAR map, fused = gap(image) + gap(lidar) (+ vel_emb(velocity)).  ConvNeXt / ResNet trunks are not restated (RegNetY only)."""
+
+    def __init__(self, config, image_architecture='regnety_032', lidar_architecture='regnety_032', use_velocity=0, make_net=None):
+        super().__init__()
+        self.config = config
+        make_net = make_net or regnet.regnety_032
+        in_ch = config.num_features[-1] if config.use_point_pillars else 2 * config.lidar_seq_len
+        if config.use_target_point_image:
+            in_ch += 1
+
+        def bare(net):
+            for name in ("fc", "classifier", "global_pool", "head"):
+                setattr(net, name, nn.Sequential())
+            return net
+        self.image_encoder = nn.Module()
+        self.image_encoder.normalize = True
+        self.image_encoder.features = bare(make_net())
+        self.lidar_encoder = nn.Module()
+        self.lidar_encoder._model = bare(make_net(in_chans=in_ch))
+        self.norm_after_pool_img = nn.Sequential()
+        self.norm_after_pool_lidar = nn.Sequential()
+        self.use_velocity = use_velocity
+        pf = config.perception_output_features
+        if use_velocity:
+            self.vel_emb = nn.Linear(1, pf)
+        ch = config.bev_features_chanels
+        self.relu = nn.ReLU(inplace=True)
+        nf = self.image_encoder.features.num_features
+        self.reduce_channels_conv_image = nn.Conv2d(nf, pf, (1, 1)) if nf != pf else nn.Sequential()
+        self.reduce_channels_conv_lidar = nn.Conv2d(self.lidar_encoder._model.num_features, pf, (1, 1)) if nf != pf else nn.Sequential()
+        self.upsample = nn.Upsample(scale_factor=config.bev_upsample_factor, mode='bilinear', align_corners=False)
+        self.up_conv5 = nn.Conv2d(ch, ch, (1, 1))
+        self.up_conv4 = nn.Conv2d(ch, ch, (1, 1))
+        self.up_conv3 = nn.Conv2d(ch, ch, (1, 1))
+        self.c5_conv = nn.Conv2d(pf, ch, (1, 1))
+
+    top_down = TransfuserBackbone.top_down
+
+    def forward(self, image, lidar, velocity):
+        x = self.reduce_channels_conv_image(self.image_encoder.features(normalize_imagenet(image)))
+        y = self.reduce_channels_conv_lidar(self.lidar_encoder._model(lidar))
+        fused = torch.flatten(F.adaptive_avg_pool2d(x, 1), 1) + torch.flatten(F.adaptive_avg_pool2d(y, 1), 1)
+        if self.use_velocity:
+            fused = fused + self.vel_emb(velocity)
+        return self.top_down(y), x, fused
+
+
 class GeometricFusionBackbone(TransfuserBackbone):
     """team_code_transfuser/geometric_fusion.py:6-288 (BASELINE config 4), in the reference's operation order: 1x1 conv C->n_embd
     on the full map, adaptive pool, gather (the reference's B x B advanced index + ``torch.diagonal`` :134-135 is restated as the

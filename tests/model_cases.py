@@ -84,7 +84,7 @@ def build_pair(cfg, arch, dev, use_velocity=False, seed=0, backbone='transFuser'
     prod = LidarCenterNet(cfg, dev, backbone, arch, arch, use_velocity=use_velocity)
     randomize(prod)
     if arch == "regnety_tiny":
-        make_net = lambda: oracle_regnet.RegNet(TINY["widths"], TINY["depths"], TINY["group_w"], TINY["se_ratio"])
+        make_net = lambda in_chans=3: oracle_regnet.RegNet(TINY["widths"], TINY["depths"], TINY["group_w"], TINY["se_ratio"], in_chans)
     else:
         make_net = oracle_regnet.regnety_032
     ref = model_cpu.LidarCenterNet(cfg, 'cpu', backbone, use_velocity=use_velocity, make_net=make_net)

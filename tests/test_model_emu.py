@@ -227,3 +227,20 @@ def test_param_stage_names():
     assert param_stage("_model.image_encoder.features.stem.conv.weight") == 0
     assert param_stage("_model.lidar_encoder._model.conv1.weight") == 0 and param_stage("_model.lidar_encoder._model.bn1.bias") == 0
     assert param_stage("head.heatmap_head.0.weight") == 5 and param_stage("_model.up_conv4.weight") == 5 and param_stage("join.0.weight") == 5
+
+
+def test_late_fusion_backbone_matches_oracle():
+    """SURVEY.md 8f-4 (late_fusion.py:5-111): trunks without exchange, reducers, FPN, pooled sum (+ velocity embedding); state_dict keys
+    are the reference's (features.stem.* / _model.stem.* with in_chans, reduce_channels_conv_*), losses + all gradients vs the oracle."""
+    cfg = mc.tiny_config(n_layer=1, lidar_res=128)
+    for use_vel in (False, True):
+        prod, ref = mc.build_pair(cfg, "regnety_tiny", "cpu", backbone="late_fusion", use_velocity=use_vel)
+        keys = set(prod.state_dict())
+        assert "_model.lidar_encoder._model.stem.conv.weight" in keys and "_model.reduce_channels_conv_image.weight" in keys
+        assert not any(".layer1." in k or k.endswith("conv1.weight") and "encoder" in k and ".s" not in k for k in keys)
+        assert prod._model.lidar_encoder._model.stem.conv.weight.shape[1] == 3
+        batch = mc.small_batch(2, 32, 64, 128, 40)
+        lp, lr = mc.run_pair(prod, ref, cfg, batch, "cpu")
+        # the un-fused LiDAR trunk sees only the sparse histogram: a few ReLU / SE units sit at round-off distance from 0 and flip between
+        # two fp32 summation orders (see mc.compare): relative-L2 per tensor with the tolerance of the GPU tiny-model test
+        mc.compare(prod, ref, lp, lr, grad_tol=1e-2, metric="l2")

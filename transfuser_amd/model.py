@@ -6,7 +6,7 @@ targets :285-374, losses :150-248 with mmdet 2.25 semantics).
 Same parameter names/shapes (reference checkpoints load with strict=True), same call signature,
 same return value; everything between the input tensors and the loss scalars runs in the HIP
 kernels of libtransfuser_hip.so.  ``forward_ego`` / ``control_pid`` are built on the same kernels plus
-the fused decode_heatmap kernel; not built: visualisation and the ``late_fusion`` backbone (raises).
+the fused decode_heatmap kernel; not built: the visualisation branch.
 """
 from collections import deque
 
@@ -18,7 +18,7 @@ from . import functions as F_
 from . import ops
 from .geometric_fusion import GeometricFusionBackbone
 from .point_pillar import PointPillarNet
-from .transfuser import DepthDecoder, SegDecoder, TransfuserBackbone, latentTFBackbone, nchw
+from .transfuser import DepthDecoder, LateFusionBackbone, SegDecoder, TransfuserBackbone, latentTFBackbone, nchw
 
 HEAD_ORDER = ("heatmap_head", "wh_head", "offset_head", "yaw_class_head", "yaw_res_head", "velocity_head", "brake_head")
 LOSS_KEYS = ("loss_center_heatmap", "loss_wh", "loss_offset", "loss_yaw_class", "loss_yaw_res", "loss_velocity", "loss_brake")
@@ -154,8 +154,10 @@ class LidarCenterNet(nn.Module):
             self._model = latentTFBackbone(config, image_architecture, lidar_architecture, use_velocity=use_velocity)
         elif backbone == 'geometric_fusion':
             self._model = GeometricFusionBackbone(config, image_architecture, lidar_architecture, use_velocity=use_velocity)
+        elif backbone == 'late_fusion':
+            self._model = LateFusionBackbone(config, image_architecture, lidar_architecture, use_velocity=use_velocity)
         else:
-            raise NotImplementedError("backbone %r: 'transFuser', 'latentTF' and 'geometric_fusion' are built; late_fusion is outside SURVEY.md section 8" % (backbone,))
+            raise TypeError("The chosen vision backbone does not exist. The options are: transFuser, late_fusion, geometric_fusion, latentTF")   # model.py:573
         if config.multitask:
             self.seg_decoder = SegDecoder(config, config.perception_output_features)
             self.depth_decoder = DepthDecoder(config, config.perception_output_features)

@@ -164,6 +164,7 @@ class _FusionBackbone(nn.Module):
     """What the reference's backbones share: the two RegNet trunks, the 1512->512 channel reducers, the FPN top-down path
     (transfuser.py:91-118) and the two-stream execution of the trunks."""
 
+    _reducers = ("change_channel_conv_image", "change_channel_conv_lidar")
     _cuts = frozenset()      # fusion stages after which train.Engine cuts the backward (set by the engine; () = one autograd graph)
 
     def _build_common(self, config, image_architecture, lidar_architecture):
@@ -249,9 +250,10 @@ class _FusionBackbone(nn.Module):
         x = self._img_stem(image.contiguous())
         self._boundaries = []
         cuts = getattr(self, "_cuts", frozenset())
+        stage = lambda net, i: getattr(net, "layer%d" % i, None) or getattr(net, "s%d" % i)    # re-labelled (transfuser.py) or plain timm names (late_fusion.py)
         for i in range(1, 5):
-            y = lidar_branch(lambda y=y, i=i: getattr(li, "layer%d" % i)(y))
-            x = getattr(im, "layer%d" % i)(x)
+            y = lidar_branch(lambda y=y, i=i: stage(li, i)(y))
+            x = stage(im, i)(x)
             if side is not None:
                 main.wait_stream(side)          # join: the fusion stage consumes both branches on the main stream
                 y.record_stream(main)
@@ -265,8 +267,8 @@ class _FusionBackbone(nn.Module):
                 x, y = xd, yd
             if side is not None:
                 y.record_stream(side)
-        x = self._conv(self.change_channel_conv_image, x)
-        y = self._conv(self.change_channel_conv_lidar, y)
+        x = self._conv(getattr(self, self._reducers[0]), x)
+        y = self._conv(getattr(self, self._reducers[1]), y)
         fused = F_.GlobalPoolAddFn.apply(x, y)
         return self.top_down_nhwc(y), x, fused
 
@@ -294,6 +296,57 @@ class TransfuserBackbone(_FusionBackbone):
             gpt.seed = self.dropout_seed
             return gpt(x, y, velocity)
         return self._run(image, lidar, lidar_extra, fuse, lidar_nhwc)
+
+    def forward(self, image, lidar, velocity):
+        feats, grid, fused = self.forward_nhwc(image, lidar, velocity)
+        return tuple(nchw(p) for p in feats), nchw(grid), fused
+
+
+class LateFusionBackbone(_FusionBackbone):
+    """team_code_transfuser/late_fusion.py:5-111: both RegNetY trunks run without any exchange between the stages (on two
+    HIP streams, like the fused backbones), 1x1 reducers 1512 -> 512, FPN on the LiDAR map, fused = gap(image) + gap(lidar) (+ vel_emb).
+    Module / parameter names are the reference's (timm models used as they are: ``features.stem.*`` / ``_model.stem.*`` with in_chans
+    input channels, no conv1/layerN aliases; ``reduce_channels_conv_*``), so late-fusion checkpoints load.  ResNet / ConvNeXt trunks (the
+    re-labelling branches of late_fusion.py:23-33) are not built: RegNetY only, as everywhere on this path."""
+
+    _reducers = ("reduce_channels_conv_image", "reduce_channels_conv_lidar")
+
+    def __init__(self, config, image_architecture='resnet34', lidar_architecture='resnet18', use_velocity=0):
+        super().__init__()
+        self.config = config
+        in_channels = config.num_features[-1] if config.use_point_pillars else 2 * config.lidar_seq_len
+        if config.use_target_point_image:
+            in_channels += 1
+        self.image_encoder = nn.Module()
+        self.image_encoder.normalize = True
+        self.image_encoder.features = regnet.create_model(image_architecture, pretrained=True)
+        self.lidar_encoder = nn.Module()
+        self.lidar_encoder._model = regnet.create_model(lidar_architecture, pretrained=False, in_chans=in_channels)
+        self.norm_after_pool_img = nn.Sequential()
+        self.norm_after_pool_lidar = nn.Sequential()
+        self.use_velocity = use_velocity
+        pf = config.perception_output_features
+        if use_velocity:
+            self.vel_emb = nn.Linear(1, pf)
+        channel = config.bev_features_chanels
+        self.relu = nn.ReLU(inplace=True)
+        nf = self.image_encoder.features.num_features
+        self.reduce_channels_conv_image = nn.Conv2d(nf, pf, (1, 1)) if nf != pf else nn.Sequential()
+        self.reduce_channels_conv_lidar = nn.Conv2d(self.lidar_encoder._model.num_features, pf, (1, 1)) if nf != pf else nn.Sequential()
+        self.upsample = nn.Upsample(scale_factor=config.bev_upsample_factor, mode='bilinear', align_corners=False)
+        self.up_conv5 = nn.Conv2d(channel, channel, (1, 1))
+        self.up_conv4 = nn.Conv2d(channel, channel, (1, 1))
+        self.up_conv3 = nn.Conv2d(channel, channel, (1, 1))
+        self.c5_conv = nn.Conv2d(pf, channel, (1, 1))
+        im, li = self.image_encoder.features, self.lidar_encoder._model
+        self._img_stem = _Stem(im.stem.conv, im.stem.bn, True)
+        self._lid_stem = _Stem(li.stem.conv, li.stem.bn, False)
+
+    def forward_nhwc(self, image, lidar, velocity, lidar_extra=None, lidar_nhwc=None):
+        feats, grid, fused = self._run(image, lidar, lidar_extra, lambda i, x, y: (x, y), lidar_nhwc)
+        if self.use_velocity:   # optional flag (train.py default 0): a (B,1) x (1,512) outer product - bookkeeping-size ATen op
+            fused = fused + torch.nn.functional.linear(velocity, self.vel_emb.weight, self.vel_emb.bias)
+        return feats, grid, fused
 
     def forward(self, image, lidar, velocity):
         feats, grid, fused = self.forward_nhwc(image, lidar, velocity)
