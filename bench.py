@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 GFLOP_PER_SAMPLE = {("transFuser", 160): 230.3, ("transFuser", 256): 266.6, ("latentTF", 160): 230.3, ("latentTF", 256): 266.6,
                     ("geometric_fusion", 160): 110.2}   # algorithmic training FLOPs (3x forward), SURVEY.md section 8(d)
 PEAK_F32_MFMA_TF = 157.3                                # /opt/skills/guides/MI355X_MICROARCH.md (v_mfma_f32_32x32x2_f32)
+PEAK_BF16_MFMA_TF = 2500.0                              # dense bf16 MFMA peak of the same guide (never the 2:1-sparsity figure)
 PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_gemm_roofline.json")   # written by tools/pmc_roofline.sh (rocprofv3 --pmc passes)
 DOMINANT = ("gemm a0b0", (1740, 6048, 1512, 1))         # GPT-4 mlp.0 forward: [1740 x 1512] . [1512 x 6048], bias + ReLU epilogue
 
@@ -41,6 +42,8 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: 10 transFuser, 12 geometric_fusion, 16 latentTF)")
     ap.add_argument("--height", type=int, default=None, help="RGB height (default 256; geometric_fusion only runs at 160)")
     ap.add_argument("--backbone", default="transFuser", choices=["transFuser", "geometric_fusion", "latentTF"])
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="f32 = the reference's arithmetic (headline); bf16 = bf16-MFMA contractions with fp32 accumulate/storage/master weights (BASELINE configs[2])")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dropout", type=float, default=0.1)
@@ -67,7 +70,7 @@ def spawn_ranks(args):
     sys.exit(max(abs(rc) for rc in rcs))
 
 
-def dominant_kernel_roofline(eng, batch, dev, log):
+def dominant_kernel_roofline(eng, batch, dev, log, peak=PEAK_F32_MFMA_TF):
     """Roofline of the dominant kernel family (the fp32 MFMA GEMM engine, ~70 % of the step's kernel time) from INSIDE the step: one more
     training iteration is run eagerly with a HIP-event pair around every engine call (ops.census; events on the launch stream), and the
     figures are averages over that step's own launches - the same kernels, plans, operands and neighbours as in the timed region.
@@ -86,21 +89,22 @@ def dominant_kernel_roofline(eng, batch, dev, log):
     dom = [(a.elapsed_time(b) * 1e-3, fl) for kind, shape, fl, a, b in rows if (kind, tuple(shape)) == DOMINANT]
     tot_s = sum(a.elapsed_time(b) for _, _, _, a, b in rows) * 1e-3
     tot_fl = sum(fl for _, _, fl, _, _ in rows)
-    roof = dict(bound="mfma", peak=PEAK_F32_MFMA_TF, unit="TFLOP/s")
+    PEAK = peak
+    roof = dict(bound="mfma", peak=PEAK, unit="TFLOP/s")
     if dom:
         sec = sum(t for t, _ in dom) / len(dom)
         ach = dom[0][1] / sec / 1e12
         roof.update(kernel="tf::gemm_kernel / tf::gemm_dma_kernel (autotuned plan) on GPT4 mlp.0 forward: [1740x1512].[1512x6048], bias+ReLU epilogue; "
                            "average of its %d launches inside one eager training step" % len(dom),
-                    achieved=round(ach, 2), frac=round(ach / PEAK_F32_MFMA_TF, 4), flops_per_launch=dom[0][1], avg_launch_us=round(sec * 1e6, 2))
+                    achieved=round(ach, 2), frac=round(ach / PEAK, 4), flops_per_launch=dom[0][1], avg_launch_us=round(sec * 1e6, 2))
     else:   # other backbones / shapes: the engine aggregate is the roofline entry
         ach = tot_fl / tot_s / 1e12
         roof.update(kernel="all MFMA-engine launches of one eager training step (plain GEMMs + implicit-GEMM convolutions)",
-                    achieved=round(ach, 2), frac=round(ach / PEAK_F32_MFMA_TF, 4), flops_per_launch=None, avg_launch_us=None)
+                    achieved=round(ach, 2), frac=round(ach / PEAK, 4), flops_per_launch=None, avg_launch_us=None)
     roof.update(engine_calls=len(rows), engine_ms_per_step=round(tot_s * 1e3, 2), engine_tflops=round(tot_fl / tot_s / 1e12, 2),
-                engine_frac=round(tot_fl / tot_s / 1e12 / PEAK_F32_MFMA_TF, 4))
+                engine_frac=round(tot_fl / tot_s / 1e12 / PEAK, 4))
     roof["traffic"], roof["traffic_source"] = None, "no PMC summary committed"
-    if os.path.exists(PMC_FILE) and dom:
+    if os.path.exists(PMC_FILE) and dom and peak == PEAK_F32_MFMA_TF:
         try:
             pmc = json.load(open(PMC_FILE))
             roof["traffic"] = int(pmc["traffic_bytes_per_launch"])
@@ -210,7 +214,8 @@ def main():
     hist_fn = lambda pts: ops.lidar_hist(torch.from_numpy(pts).to(dev)[None])[0].cpu().numpy()
     batch = {k: v.to(dev) for k, v in synthetic_batch(B, H, W, seed=rank, hist_fn=hist_fn).items()}
     log("model + batch on device")
-    eng = Engine(model, cfg, lr=cfg.lr, use_graph=not args.no_graph)
+    eng = Engine(model, cfg, lr=cfg.lr, use_graph=not args.no_graph, precision={"f32": "fp32", "bf16": "bf16"}[args.dtype])
+    peak = PEAK_BF16_MFMA_TF if args.dtype == "bf16" else PEAK_F32_MFMA_TF
     log("engine ready (arena %.1f M floats, %d backward piece(s))" % (eng.arena.numel / 1e6, eng.n_pieces()))
 
     def sync():
@@ -237,7 +242,7 @@ def main():
     loss = float(tot)
     log("timed region done: %.2f ms/step" % (dt / args.steps * 1e3))
     assert loss == loss, "NaN loss"
-    roof = dominant_kernel_roofline(eng, batch, dev, log)      # every rank runs the census step (it contains the collectives); rank 0 reports
+    roof = dominant_kernel_roofline(eng, batch, dev, log, peak)      # every rank runs the census step (it contains the collectives); rank 0 reports
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = B * world * args.steps / dt
@@ -246,9 +251,10 @@ def main():
         res = {
             "metric": "training samples/sec (RGB+LiDAR pair), bs=%d/GPU" % B, "value": round(value, 2), "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "%s LidarCenterNet (RegNetY-3.2GF x2, %.1f M params) full train step, B=%d/GPU, 3x%dx%d RGB + 3x256x256 BEV, "
-                                   "fp32, dropout %.2f, %s" % (names[backbone], nparam / 1e6, B, H, W, args.dropout,
+                                   "%s, dropout %.2f, %s" % (names[backbone], nparam / 1e6, B, H, W,
+                                                             "fp32" if args.dtype == "f32" else "bf16 MFMA contractions (fp32 accumulate, fp32 activations / master weights / AdamW)", args.dropout,
                                                                "hipGraph replay" if not args.no_graph else "eager"),
                        "global_batch": B * world, "parallelism": "dp%d" % world, "final_loss": round(loss, 4),
                        "grad_allreduce": ("RCCL, %d backward segments, bucket all-reduce overlapped on a side stream" % eng.n_pieces()) if world > 1 else "none (1 rank)"},
@@ -256,7 +262,7 @@ def main():
         if gf:
             step_tf = value / world * gf / 1e3
             roof["step_achieved_tflops"] = round(step_tf, 2)
-            roof["step_frac"] = round(step_tf / PEAK_F32_MFMA_TF, 4)
+            roof["step_frac"] = round(step_tf / peak, 4)
         res["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(make_cfg, backbone, H, W)

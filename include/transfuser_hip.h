@@ -26,6 +26,12 @@ const char* tf_last_error(void);
  * is on (eager warm-up, NOT during graph capture - it synchronises), the first call of every distinct
  * (entry point, M, N, K, batch) times the candidate tilings with HIP events and caches the winner.  Plans can be
  * saved to / loaded from a text file (tf_plans_load returns the number of plans read). */
+/* Compute precision of every MFMA-engine contraction (GEMMs and implicit-GEMM convolutions): 0 = exact fp32 MFMA (the reference's
+ * arithmetic, config.py:55 trains fp32; default), 1 = operands rounded to bf16 (RNE) on the LDS->register path and multiplied on the bf16
+ * MFMA (v_mfma_f32_32x32x16_bf16), fp32 accumulation, fp32 storage of activations / weights / gradients - the MI355X counterpart of
+ * torch.autocast(bfloat16) with fp32 master weights (BASELINE configs[2]).  Tuned plans are kept per precision. */
+int tf_set_precision(int mode);
+int tf_get_precision(void);
 int tf_autotune(int enable);
 int tf_force_plan(int bm, int bn, int bk, int splitk); /* tests: pin one tiling of the register-staged kernel (bm = 0 clears) */
 int tf_force_dma(int kind, int splitk);                /* tests: pin LDS-DMA configuration `kind` (1..5, tf_gemm_dma.h) for every eligible call */

@@ -691,3 +691,60 @@ def check_bench_conv(dev, B, H, W, Cin, Cout):
     dw = torch.zeros_like(wh)
     ops.conv_wgrad(dyh, xh, dw, 1, None, groups)
     close(dw, gw, tol=2e-4, what="bench conv wgrad")
+
+
+# ---------------------------------------------------------------- bf16-MFMA compute mode (tf_set_precision(1), BASELINE configs[2])
+BF16_PLANS = [("plan", (64, 64, 16, 1)), ("plan", (128, 128, 32, 1)), ("plan", (128, 32, 16, 2)), ("plan", (64, 128, 32, 1)), ("dma", (1, 1)), ("dma", (2, 2)),
+              ("dma", (4, 1)), ("dma", (5, 1))]
+
+
+def _bf(t):
+    return t.bfloat16().float()
+
+
+def check_bf16_mode(dev, kind, plan, shapes=((130, 216, 40), (200, 92, 152))):
+    """Engine contractions in bf16-MFMA mode: every operand is rounded to bf16 (round-to-nearest-even) on its way into the MFMA, products
+    are exact, accumulation and epilogue stay fp32 - so the result must equal an fp32 GEMM of the bf16-rounded operands to fp32 summation
+    accuracy (tolerance 1e-4, NOT a loose 'bf16 tolerance').  All layouts, the masked (im2col) loaders, batched non-vector operands."""
+    ops.set_precision("bf16")
+    (ops.force_dma if kind == "dma" else ops.force_plan)(*plan)
+    try:
+        for (m, n, k) in shapes:
+            x, w, b, r = R(m, k, dev=dev), R(n, k, dev=dev), R(n, dev=dev), R(m, n, dev=dev)
+            close(ops.linear_fwd(x, w, b, relu=True, res=r), torch.relu(_bf(x) @ _bf(w).t() + b + r), tol=1e-4, what="bf16 fwd")
+            dy = R(m, n, seed=1, dev=dev)
+            close(ops.linear_dgrad(dy, w), _bf(dy) @ _bf(w), tol=1e-4, what="bf16 dgrad")
+            dw0 = R(n, k, seed=2, dev=dev)
+            close(ops.linear_wgrad(dy, x, dw0.clone(), accumulate=True), dw0 + _bf(dy).t() @ _bf(x), tol=1e-4, what="bf16 wgrad")
+            a, bb = R(m, k, dev=dev), R(n, k, seed=4, dev=dev)
+            c = torch.empty(m, n, device=dev)
+            ops.gemm(a.t().contiguous(), bb, c, m, n, k, m, k, n, a_trans=True)                 # tt
+            close(c, _bf(a) @ _bf(bb).t(), tol=1e-4, what="bf16 tt")
+        # grouped / strided 3x3 convolution through the im2col loaders
+        B, Hi, Wi, Cin, Cout, groups, stride = 2, 9, 11, 48, 48, 2, 2
+        x = R(B, Cin, Hi, Wi, dev="cpu").requires_grad_(True)
+        w = (R(Cout, Cin // groups, 3, 3, dev="cpu") * 0.1).requires_grad_(True)
+        y = F.conv2d(_bf(x), _bf(w), None, stride, 1, 1, groups)
+        xh, wh = x.detach().permute(0, 2, 3, 1).contiguous().to(dev), cl(w.detach()).to(dev)
+        close(ops.conv_fwd(xh, wh, None, stride, None, groups).permute(0, 3, 1, 2), y, tol=1e-4, what="bf16 conv fwd")
+        dy = R(*y.shape, seed=1, dev="cpu")
+        gx = torch.autograd.grad(F.conv2d(x, _bf(w), None, stride, 1, 1, groups), x, _bf(dy))[0]
+        dyh = dy.permute(0, 2, 3, 1).contiguous().to(dev)
+        close(ops.conv_dgrad(dyh, wh, xh.shape, stride, None, groups).permute(0, 3, 1, 2), gx, tol=1e-4, what="bf16 conv dgrad")
+        gw = torch.autograd.grad(F.conv2d(_bf(x), w, None, stride, 1, 1, groups), w, _bf(dy))[0]
+        dw = torch.zeros_like(wh)
+        ops.conv_wgrad(dyh, xh, dw, stride, None, groups)
+        close(dw, gw, tol=1e-4, what="bf16 conv wgrad")
+        # attention-style batched GEMM with head size 18 (element-wise loaders)
+        B_, nh, T, hs = 1, 2, 50, 18
+        C = nh * hs
+        qkv = R(B_, T, 3 * C, dev=dev, scale=0.5)
+        att = torch.zeros(B_ * nh, T, 52, device=dev)
+        q, kk = qkv[..., :C], qkv[..., C:2 * C]
+        sa = (T * 3 * C, hs)
+        ops.gemm(q, kk, att, T, T, hs, 3 * C, 3 * C, 52, alpha=0.5, batch=B_ * nh, inner=nh, sa=sa, sb=sa, sc=(nh * T * 52, T * 52))
+        qh, kh = [_bf(t).reshape(B_, T, nh, hs).transpose(1, 2) for t in (q, kk)]
+        close(att[:, :, :T].reshape(B_, nh, T, T), 0.5 * (qh @ kh.transpose(-2, -1)), tol=1e-4, what="bf16 batched")
+    finally:
+        ops.force_plan(0)
+        ops.set_precision("fp32")

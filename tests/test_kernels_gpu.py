@@ -106,6 +106,11 @@ def test_gemm_dma_configurations(cfg):
     kc.check_gemm_dma("cuda", cfg[0], cfg[1], kc.DMA_SHAPES_GPU)
 
 
+@pytest.mark.parametrize("cfg", kc.BF16_PLANS, ids=str)
+def test_bf16_mfma_mode(cfg):
+    kc.check_bf16_mode("cuda", cfg[0], cfg[1])
+
+
 @pytest.mark.parametrize("case", kc.GATHER_CASES, ids=str)
 def test_gather_sum(case):
     kc.check_gather_sum("cuda", *case)

@@ -181,7 +181,9 @@ def test_engine_graph_replay_matches_eager(dropout):
     print("  graph vs eager: max relative loss difference over 5 steps x 12 values: %.2e; params max abs diff %.2e, mean %.2e" %
           (rel, (params[0] - params[1]).abs().max().item(), (params[0] - params[1]).abs().mean().item()))
     assert rel <= 2e-4, (rel, outs[0][:, 0], outs[1][:, 0])
-    assert (params[0] - params[1]).abs().mean().item() <= 2e-6 and (rmean[0] - rmean[1]).abs().max().item() <= 1e-4
+    # with dropout more weight-gradient entries sit at round-off level (sign flips move them by 2 lr each): measured mean 1.6e-5 at p = 0.1; a
+    # stray optimizer update would move EVERY weight by ~lr = 1e-3
+    assert (params[0] - params[1]).abs().mean().item() <= (2e-6 if dropout == 0 else 1e-4) and (rmean[0] - rmean[1]).abs().max().item() <= 1e-4
 
 
 def test_engine_segmented_graphs_match_single_graph():
@@ -210,7 +212,7 @@ def test_engine_segmented_graphs_match_single_graph():
     assert ((a - b).abs() / a.abs()).max().item() <= 2e-4, (res[0][0], res[1][0])        # fp32 atomics: see test_engine_graph_replay_matches_eager
     num = sum((p - res[1][1][n]).abs().sum().item() for n, p in res[0][1].items())
     den = sum(p.numel() for p in res[0][1].values())
-    assert num / den <= 2e-6, num / den
+    assert num / den <= 1e-4, num / den          # dropout 0.1: see test_engine_graph_replay_matches_eager
 
 
 def test_bench_configuration_parity_B10_H256():
@@ -324,6 +326,37 @@ def test_single_block_gradients_within_1e3():
         if "attn.key.bias" in n:
             continue                                       # exact gradient is 0 (softmax shift invariance): only round-off on both sides
         assert rel(p.grad, pgo[n].grad) <= 1e-3, (n, rel(p.grad, pgo[n].grad))
+
+
+def test_bf16_mfma_mode_model_parity():
+    """BASELINE configs[2] compute mode (tf_set_precision(1): every engine contraction rounds its operands to bf16 and runs on the bf16
+    MFMA, fp32 accumulation / storage / master weights) against the fp32 CPU oracle.  Stated tolerance: losses and forward outputs within
+    3e-2 relative (bf16 has an 8-bit mantissa: ~4e-3 per operand, accumulated over ~60 layers); gradients: global cosine >= 0.9 with the
+    fp32 gradient.  The operation-level test (test_bf16_mfma_mode) pins the exact rounding semantics; this one bounds the end-to-end drift."""
+    from transfuser_amd import ops
+    cfg = mc.tiny_config(n_layer=2, lidar_res=128)
+    prod, ref = mc.build_pair(cfg, "regnety_tiny", "cuda")
+    batch = mc.small_batch(2, 160, 352, 128, 40)
+    ops.set_precision("bf16")
+    try:
+        lp, lr = mc.run_pair(prod, ref, cfg, batch, "cuda")
+        torch.cuda.synchronize()
+    finally:
+        ops.set_precision("fp32")
+    for k in lr:
+        a, b = float(lp[k].detach()), float(lr[k].detach())
+        assert abs(a - b) <= 3e-2 * max(1.0, abs(b)), "loss %s: bf16 %g vs fp32 oracle %g" % (k, a, b)
+    rp = dict(ref.named_parameters())
+    errs = sorted((p.grad.detach().cpu().double() - rp[n].grad.double()).norm().item() / max(rp[n].grad.double().norm().item(), 1e-12)
+                  for n, p in prod.named_parameters() if rp[n].grad is not None and rp[n].grad.norm().item() > 1e-10 and "attn.key.bias" not in n)
+    gp = torch.cat([p.grad.detach().cpu().double().flatten() for n, p in prod.named_parameters() if rp[n].grad is not None])
+    gr = torch.cat([rp[n].grad.double().flatten() for n, p in prod.named_parameters() if rp[n].grad is not None])
+    cos = float(torch.dot(gp, gr) / (gp.norm() * gr.norm()))
+    print("  bf16 mode: gradient vs fp32 oracle: global cosine %.4f, per-tensor rel-L2 median %.2e, 90th pct %.2e, max %.2e" %
+          (cos, errs[len(errs) // 2], errs[int(len(errs) * 0.9)], errs[-1]))
+    # this network amplifies round-off ~1e5x into its gradients (fp32 vs fp64: 1e-2 per tensor, see compare_vs_fp64), so bf16 operand
+    # rounding (4e-3) cannot give per-tensor agreement; what low-precision training needs is the descent DIRECTION: global cosine >= 0.9
+    assert cos >= 0.9 and errs[len(errs) // 2] <= 0.6, (cos, errs[len(errs) // 2])
 
 
 def test_full_size_step_properties():

@@ -15,6 +15,8 @@ hbm)        timeout 200 python tools/hbm_bench.py > $O/r02_hbm_kernels.txt 2>&1;
 trace)      (cd /tmp && export TMPDIR=/tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $O/trace_r02 -o step --output-format csv -- python $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline > $O/r02_trace_bench.log 2>&1)
             python tools/trace_csv_stats.py $O/trace_r02 > $O/r02_kernel_trace_graph.txt 2>&1; head -60 $O/r02_kernel_trace_graph.txt
             cp $O/trace_r02/*kernel_stats.csv $O/r02_kernel_stats.csv 2>/dev/null; rm -rf $O/trace_r02 ;;
-tune)       timeout 300 python tools/tune.py $O/mi355x_r02.txt 10 256,160 2>&1 | tail -4 ;;
+tune)       timeout 400 python tools/tune.py $O/mi355x_r02.txt 10 256,160 fp32,bf16 2>&1 | tail -6; cp $O/mi355x_r02.txt transfuser_amd/plans/mi355x.txt ;;
+tests_bf16) timeout 600 python -m pytest tests/test_kernels_gpu.py tests/test_model_gpu.py -q -k "bf16" -s 2>&1 | tail -12 ;;
+bench_bf16) timeout 300 python bench.py --steps 20 --warmup 5 --dtype bf16 --no-cpu-baseline > $O/r02_bench_bf16.json 2> $O/r02_bench_bf16.err; tail -3 $O/r02_bench_bf16.err; cat $O/r02_bench_bf16.json ;;
 esac
 done

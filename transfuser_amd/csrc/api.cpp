@@ -60,6 +60,16 @@ extern "C" int tf_force_plan(int bm, int bn, int bk, int splitk) {
     tf::g_forced = tf::GemmPlan{bm, bn, bk, splitk, 0};
     return 0;
 }
+namespace tf {
+static int g_precision = 0;
+int gemm_precision() { return g_precision; }
+}
+extern "C" int tf_set_precision(int mode) {
+    if (mode != 0 && mode != 1) { tf::set_error("tf_set_precision: mode %d (0 = fp32 MFMA, 1 = bf16 MFMA with fp32 storage/accumulate)", mode); return -1; }
+    tf::g_precision = mode;
+    return 0;
+}
+extern "C" int tf_get_precision(void) { return tf::g_precision; }
 extern "C" int tf_autotune(int enable) { tf::g_autotune = enable != 0; return 0; }
 extern "C" int tf_plans_count(void) { std::lock_guard<std::mutex> lk(tf::g_plan_mu); return (int)tf::g_plans.size(); }
 extern "C" int tf_plans_clear(void) { std::lock_guard<std::mutex> lk(tf::g_plan_mu); tf::g_plans.clear(); return 0; }

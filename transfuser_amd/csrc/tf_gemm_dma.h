@@ -220,6 +220,50 @@ __device__ __forceinline__ void gemm_dma_tile(const PlainOp& la_in, const PlainO
         }
     };
 
+    // bf16-MFMA variant (ep.prec != 0): lane half hi owns k = 8 hi .. 8 hi + 7 of every 16-deep group = logical chunks 2 hi, 2 hi + 1 of a
+    // KC row (two b128 reads) or 8 k-rows of an IC tile; fp32 values are rounded to bf16 in registers, one MFMA per 32x32 tile and group.
+    auto compute_bf16 = [&](int slot) {
+        const float* As = smem + slot * C::STAGE_FL;
+        const float* Bs = As + C::A_FL;
+#pragma unroll
+        for (int g = 0; g < BK / 16; ++g) {
+            float a[TM][8], b[TN][8];
+#pragma unroll
+            for (int t = 0; t < TM; ++t) {
+                if (A_KC) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const float4 v = *reinterpret_cast<const float4*>(As + a_off + t * 32 * BK + (((4 * g + 2 * hi + h) ^ sw) * 4));
+                        a[t][4 * h] = v.x; a[t][4 * h + 1] = v.y; a[t][4 * h + 2] = v.z; a[t][4 * h + 3] = v.w;
+                    }
+                } else {
+                    const float* p = As + (wm0 + l31) + (16 * g + 8 * hi) * BM + t * 32;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) a[t][j] = p[j * BM];
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < TN; ++t) {
+                if (B_KC) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const float4 v = *reinterpret_cast<const float4*>(Bs + b_off + t * 32 * BK + (((4 * g + 2 * hi + h) ^ sw) * 4));
+                        b[t][4 * h] = v.x; b[t][4 * h + 1] = v.y; b[t][4 * h + 2] = v.z; b[t][4 * h + 3] = v.w;
+                    }
+                } else {
+                    const float* p = Bs + (wn0 + l31) + (16 * g + 8 * hi) * BN + t * 32;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) b[t][j] = p[j * BN];
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < TM; ++t)
+#pragma unroll
+                for (int u = 0; u < TN; ++u) mfma_32x32x16_bf16(a[t], b[u], acc[t][u]);
+        }
+    };
+    const bool lowp = ep.prec != 0;
+
     // ---- pipeline: STAGES-1 tiles in flight; iteration t: wait for tile t (counted), barrier (also frees slot (t-1) % STAGES for
     // everyone), request tile t + STAGES - 1 into that slot, multiply tile t.
 #pragma unroll
@@ -230,7 +274,7 @@ __device__ __forceinline__ void gemm_dma_tile(const PlainOp& la_in, const PlainO
         lds_wait();
         dma_barrier<NW>();
         issue(kt + STAGES - 1, nxt);
-        compute(cur);
+        if (lowp) compute_bf16(cur); else compute(cur);
         cur = cur + 1 == STAGES ? 0 : cur + 1;
         nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
     }
@@ -264,6 +308,7 @@ inline void launch_dma_cfg(const PlainOp& la, const PlainOp& lb, const GemmEpi& 
     const int nsplit = cdiv(K, kchunk);
     dim3 grid(tiles_m * tiles_n, nsplit > 0 ? nsplit : 1, batch);
     GemmEpi epg = ep;
+    epg.prec = gemm_precision();
     {
         long panel = (long)C::BM * (kchunk < K ? kchunk : K) * 4;
         int g = (int)((2L << 20) / (panel > 0 ? panel : 1));

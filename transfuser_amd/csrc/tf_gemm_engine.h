@@ -243,7 +243,10 @@ struct GemmEpi {
     float alpha; int relu; int mode; // mode 0: store, 1: +=, 2: atomicAdd
     int group_m = 1;                 // tile rasterisation: rows of tiles walked together (set by launch_cfg)
     const float* mask = nullptr; long ldmask = 0;   // optional ReLU mask of a backward GEMM: element (i, j) is zeroed unless mask(i, j) > 0
+    int prec = 0;                    // 0: exact fp32 MFMA; 1: operands rounded to bf16 on the LDS->register path, bf16 MFMA, fp32 accumulate (set by launch_cfg)
 };
+
+int gemm_precision();   // api.cpp: process-wide compute precision of the engine (tf_set_precision)
 
 // ---------------------------------------------------------------- epilogue (shared by gemm_kernel and gemm_dma_kernel)
 // lane holds column j of 16 rows per 32x32 tile.  Mode / residual / bounds are resolved ONCE per tile
@@ -528,6 +531,30 @@ __device__ __forceinline__ void gemm_tile(LA& la, LB& lb, const GemmEpi& ep, int
         }
     };
 
+    // bf16-MFMA variant of compute(): one v_mfma_f32_32x32x16_bf16 per 32x32 tile and 16 k (lane half hi owns k = 8 hi .. 8 hi + 7 of
+    // the group); operands are read as fp32 from the same K-major tiles and rounded in registers.  Kept in the same kernel behind a
+    // block-uniform flag: its extra live registers exist only inside this branch.
+    auto compute_bf16 = [&](int cur) {
+#pragma unroll
+        for (int g = 0; g < BK / 16; ++g) {
+            float a[TM][8], b[TN][8];
+#pragma unroll
+            for (int t = 0; t < TM; ++t)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a[t][j] = As[cur][g * 16 + 8 * hi + j][wm0 + t * 32 + l31];
+#pragma unroll
+            for (int t = 0; t < TN; ++t)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) b[t][j] = Bs[cur][g * 16 + 8 * hi + j][wn0 + t * 32 + l31];
+#pragma unroll
+            for (int t = 0; t < TM; ++t)
+#pragma unroll
+                for (int u = 0; u < TN; ++u) mfma_32x32x16_bf16(a[t], b[u], acc[t][u]);
+        }
+    };
+    const bool lowp = ep.prec != 0;
+    auto mult = [&](int cur) { if (lowp) compute_bf16(cur); else compute(cur); };
+
     if constexpr (CANFAST) {
         // hot loop: complete k tiles only, nothing but pointer bumps, 16-byte loads, MFMAs and one barrier per tile; a ragged last
         // tile is peeled off below (keeping the masked code out of the loop also keeps its registers out of the loop's allocation)
@@ -544,12 +571,12 @@ __device__ __forceinline__ void gemm_tile(LA& la, LB& lb, const GemmEpi& ep, int
             __syncthreads();
             for (int kt = 0; kt < nfast; kt += 2) {                        // LDS 0 holds tile kt, set A holds tile kt+1
                 fetch_set(ra2, rb2, kt + 2 < nfast ? kt + 2 : last);       // B <- tile kt+2
-                compute(0);
+                mult(0);
                 stash_set(ra, rb, 1);                                      // A (tile kt+1) -> LDS 1
                 __syncthreads();
                 if (kt + 1 < nfast) {
                     fetch_set(ra, rb, kt + 3 < nfast ? kt + 3 : last);     // A <- tile kt+3
-                    compute(1);
+                    mult(1);
                     stash_set(ra2, rb2, 0);                                // B (tile kt+2) -> LDS 0
                     __syncthreads();
                 }
@@ -563,7 +590,7 @@ __device__ __forceinline__ void gemm_tile(LA& la, LB& lb, const GemmEpi& ep, int
         for (int kt = 0; kt < nfast; ++kt) {     // branch-free body: the last iteration re-fetches its own tile into the idle buffer
             const int cur = kt & 1;
             fetch_fast(kt + 1 < nfast ? kt + 1 : kt);
-            compute(cur);
+            mult(cur);
             stash_fast(cur ^ 1);
             __syncthreads();
         }
@@ -573,7 +600,7 @@ __device__ __forceinline__ void gemm_tile(LA& la, LB& lb, const GemmEpi& ep, int
             fetch();
             stash(nfast & 1);
             __syncthreads();
-            compute(nfast & 1);
+            mult(nfast & 1);
         }
     } else {
         gen_seek(kbeg);
@@ -585,7 +612,7 @@ __device__ __forceinline__ void gemm_tile(LA& la, LB& lb, const GemmEpi& ep, int
         for (int kt = 0; kt < nkt; ++kt) {       // branch-free body: past the last tile every validity bit is 0 (zeros into the idle buffer)
             const int cur = kt & 1;
             fetch();
-            compute(cur);
+            mult(cur);
             stash(cur ^ 1);
             __syncthreads();
         }
@@ -665,6 +692,7 @@ inline void launch_cfg(const LA& la, const LB& lb, const GemmEpi& ep, int M, int
     const int nsplit = cdiv(K, kchunk);
     dim3 grid(tiles_m * tiles_n, nsplit > 0 ? nsplit : 1, batch);
     GemmEpi epg = ep;
+    epg.prec = gemm_precision();
     {
         static const int forced = [] { const char* e = getenv("TF_GROUP_M"); return e ? atoi(e) : 0; }();
         long panel = (long)BM * (kchunk < K ? kchunk : K) * 4;          // bytes of one A panel of this launch
@@ -791,7 +819,7 @@ inline int launch_gemm(const LA& la, const LB& lb, GemmEpi ep, int M, int N, int
     if (M <= 0 || N <= 0 || batch <= 0) return 0;
     // split-K only for pure accumulations (weight gradients into the grad arena): atomic epilogue
     const bool sk_ok = allow_splitk && ep.mode == 1 && !ep.bias && !ep.res && !ep.relu;
-    const int acc = ep.mode != 0 ? (sk_ok ? 2 : 1) : 0;
+    const int acc = (ep.mode != 0 ? (sk_ok ? 2 : 1) : 0) + 4 * gemm_precision();   // plans are tuned per compute precision
     GemmPlan p;
     if (forced_plan(&p)) {
         if (!sk_ok) p.splitk = 1;

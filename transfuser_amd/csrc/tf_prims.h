@@ -46,6 +46,32 @@ __forceinline__ void mfma_32x32x2(float a, float b, f32x16& acc) {
     }
     emu::wave_barrier();
 }
+// v_mfma_f32_32x32x16_bf16 with fp32 inputs rounded to bf16 (RNE): A lane l holds A[i=l&31][k=8*(l>>5)+j], B lane l holds B[k=8*(l>>5)+j][j'=l&31],
+// j = 0..7; D layout as mfma_32x32x2.  Emulation: exact bf16 x bf16 products accumulated in fp32 in k order (hardware order may differ).
+__forceinline__ float emu_bf16_round(float f) {
+    uint32_t u; memcpy(&u, &f, 4);
+    if ((u & 0x7f800000u) == 0x7f800000u) return f;
+    u = (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u;
+    memcpy(&f, &u, 4);
+    return f;
+}
+__forceinline__ void mfma_32x32x16_bf16(const float (&a)[8], const float (&b)[8], f32x16& acc) {
+    float* s = emu::wave_scratch();
+    const int l = lane_id(), jc = l & 31, hi = l >> 5;
+    for (int j = 0; j < 8; ++j) {        // one k pair (k = j of lane half 0, k = 8 + j of lane half 1) per round through the wave scratch
+        s[l] = emu_bf16_round(a[j]);
+        s[64 + l] = emu_bf16_round(b[j]);
+        emu::wave_barrier();
+        for (int r = 0; r < 16; ++r) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            float c = acc[r];
+            c = fmaf(s[i], s[64 + jc], c);
+            c = fmaf(s[32 + i], s[64 + 32 + jc], c);
+            acc[r] = c;
+        }
+        emu::wave_barrier();
+    }
+}
 __forceinline__ float shfl(float v, int src) {
     float* s = emu::wave_scratch();
     s[128 + lane_id()] = v;
@@ -60,6 +86,15 @@ __forceinline__ float shfl_down(float v, int d) { int s = lane_id() + d; return 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ void mfma_32x32x2(float a, float b, f32x16& acc) {
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+}
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// fp32 operands rounded to bf16 in registers (v_cvt_pk_bf16_f32, RNE) -> v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate), fp32 accumulate
+__device__ __forceinline__ void mfma_32x32x16_bf16(const float (&a)[8], const float (&b)[8], f32x16& acc) {
+    f32x8 x, y;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { x[j] = a[j]; y[j] = b[j]; }
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_convertvector(x, bf16x8), __builtin_convertvector(y, bf16x8), acc, 0, 0, 0);
 }
 __device__ __forceinline__ float shfl(float v, int src) { return __shfl(v, src, 64); }
 __device__ __forceinline__ float shfl_xor(float v, int m) { return __shfl_xor(v, m, 64); }

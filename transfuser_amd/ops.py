@@ -38,6 +38,16 @@ def autotune(enable):
     check(L().tf_autotune(int(bool(enable))), "tf_autotune")
 
 
+def set_precision(mode):
+    """"fp32" (exact fp32 MFMA, default) or "bf16" (bf16 MFMA operands, fp32 accumulate + storage) for every engine contraction."""
+    m = {"fp32": 0, "f32": 0, 0: 0, "bf16": 1, 1: 1}[mode]
+    check(L().tf_set_precision(m), "tf_set_precision")
+
+
+def get_precision():
+    return "bf16" if L().tf_get_precision() else "fp32"
+
+
 def force_plan(bm=0, bn=0, bk=0, splitk=1):
     """Tests: pin one engine tiling for every call (bm=0 restores planning)."""
     check(L().tf_force_plan(bm, bn, bk, splitk), "tf_force_plan")

@@ -272,12 +272,15 @@ class Engine:
     DEFAULT_CUTS = (3, 2, 1)                  # backward segments: [heads + stage 4] [stage 3] [stage 2] [stage 1 + stems]
 
     def __init__(self, model, config, lr=1e-4, use_graph=False, group=None, bucket_mb=64.0, wp_only=False, autotune=True, plan_file=None,
-                 zero_redundancy_optimizer=False, sync_batch_norm=False, cuts=None):
+                 zero_redundancy_optimizer=False, sync_batch_norm=False, cuts=None, precision=None):
         """``cuts``: fusion stages after which the backward is cut into separately enqueued (and separately captured) segments whose
         gradient ranges are all-reduced while the next segment runs.  None = DEFAULT_CUTS when there is more than one rank (and the
-        backbone is a chain: transFuser / latentTF), no cut on a single GPU; () = never cut."""
+        backbone is a chain: transFuser / latentTF), no cut on a single GPU; () = never cut.
+        ``precision``: compute precision of every MFMA-engine contraction (process-wide, ops.set_precision); None keeps the current one."""
         self.model = model
         self.config = config
+        if precision is not None:   # "fp32" (exact fp32 MFMA: the reference's arithmetic) | "bf16" (bf16 MFMA operands, fp32 accumulate / storage / master weights)
+            ops.set_precision(precision)
         self._autotune_pending = bool(autotune) and next(model.parameters()).is_cuda
         if plan_file is None:   # tilings tuned offline on an MI355X for the bench / reference shapes (tools/tune.py); unknown shapes are tuned on first use
             plan_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "plans", "mi355x.txt")
