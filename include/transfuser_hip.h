@@ -84,6 +84,15 @@ int tf_conv3x3_small_dgrad_f32(const float* dy, const float* w, float* dx, int B
 long tf_conv3x3_small_wgrad_ws_floats(void);
 int tf_conv3x3_small_wgrad_f32(const float* dy, const float* x, float* dw, int B, int H, int W, int Cin, int Cout, int accumulate, float* ws, void* stream);
 
+/* Grouped 3x3 / stride 1 / pad 1 convolution with group width 24 (C / 24 groups of 24 -> 24 channels): the timm regnety_032 bottleneck
+ * convolution (transfuser.py:380,442; timm 0.5.4 regnet.py Bottleneck.conv2) and its gradients as per-group direct kernels.  x, y, dy, dx:
+ * NHWC (B, H, W, C); w / dw: (C, 3, 3, 24) = the channels-last storage of a (C, 24, 3, 3) parameter.  wgrad needs
+ * tf_conv3x3_grouped_wgrad_ws_floats() floats of scratch.  Stride-2 grouped convolutions use tf_conv2d_*. */
+int tf_conv3x3_grouped_fwd_f32(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int C, int relu, void* stream);
+int tf_conv3x3_grouped_dgrad_f32(const float* dy, const float* w, float* dx, int B, int H, int W, int C, int accumulate, void* stream);
+long tf_conv3x3_grouped_wgrad_ws_floats(void);
+int tf_conv3x3_grouped_wgrad_f32(const float* dy, const float* x, float* dw, int B, int H, int W, int C, int accumulate, float* ws, void* stream);
+
 /* Stem convolutions reading the NCHW model inputs directly (Cin <= 4, no bias, NHWC output):
  * channels [0,C0) from s0, [C0,C0+C1) from s1 - the torch.cat of model.py:741-742 is never
  * materialised; normalize != 0 folds normalize_imagenet (transfuser.py:419-428, K17) into the load.

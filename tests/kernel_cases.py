@@ -748,3 +748,43 @@ def check_bf16_mode(dev, kind, plan, shapes=((130, 216, 40), (200, 92, 152))):
     finally:
         ops.force_plan(0)
         ops.set_precision("fp32")
+
+
+# ---------------------------------------------------------------- grouped 3x3 direct kernels (csrc/conv_grouped.cpp), group width 24
+GROUPED_CONV_CASES = [(2, 16, 44, 72), (1, 9, 13, 48), (2, 8, 16, 24), (1, 5, 70, 72), (3, 4, 8, 48), (1, 33, 31, 24)]
+
+
+def check_conv_grouped(dev, B, H, W, C):
+    """fwd (+bias, ReLU), dgrad (store and accumulate), wgrad (store and accumulate) of the per-group direct kernels vs F.conv2d; map sizes
+    that pick both tile shapes (8x16 / 4x32), ragged borders in both directions, 1..3 groups."""
+    groups = C // 24
+    assert ops._grouped_ok((B, H, W, C), C, C, 3, 1, 1, groups) or groups == 1
+    x = R(B, C, H, W, dev="cpu").requires_grad_(True)
+    w = (R(C, 24, 3, 3, dev="cpu") * 0.1).requires_grad_(True)
+    b = R(C, dev="cpu")
+    y = F.conv2d(x, w, b, 1, 1, 1, groups)
+    dy = R(*y.shape, seed=1, dev="cpu")
+    gx, gw = torch.autograd.grad(y, [x, w], dy)
+    xh, wh = x.detach().permute(0, 2, 3, 1).contiguous().to(dev), cl(w.detach()).to(dev)
+    dyh = dy.permute(0, 2, 3, 1).contiguous().to(dev)
+    L = ops.L()
+    from transfuser_amd.ops import ptr, wptr, stream_of, check
+    yh = torch.empty(B, H, W, C, device=dev)
+    check(L.tf_conv3x3_grouped_fwd_f32(ptr(xh), wptr(wh), ptr(b.to(dev)), ptr(yh), B, H, W, C, 1, stream_of(xh)), "grouped fwd")
+    close(yh.permute(0, 3, 1, 2), torch.relu(y), what="grouped fwd")
+    dx = torch.full((B, H, W, C), 0.5, device=dev)
+    check(L.tf_conv3x3_grouped_dgrad_f32(ptr(dyh), wptr(wh), ptr(dx), B, H, W, C, 1, stream_of(xh)), "grouped dgrad")
+    close(dx.permute(0, 3, 1, 2), gx + 0.5, what="grouped dgrad (accumulate)")
+    check(L.tf_conv3x3_grouped_dgrad_f32(ptr(dyh), wptr(wh), ptr(dx), B, H, W, C, 0, stream_of(xh)), "grouped dgrad")
+    close(dx.permute(0, 3, 1, 2), gx, what="grouped dgrad")
+    dw = torch.full_like(wh, 0.25)
+    ws = ops._grouped_ws(xh.device)
+    check(L.tf_conv3x3_grouped_wgrad_f32(ptr(dyh), ptr(xh), wptr(dw), B, H, W, C, 1, ptr(ws), stream_of(xh)), "grouped wgrad")
+    close(dw, gw + 0.25, what="grouped wgrad (accumulate)")
+    # and through the public ops (dispatch)
+    if groups > 1:
+        close(ops.conv_fwd(xh, wh, None, 1, None, groups).permute(0, 3, 1, 2), y - b.view(1, -1, 1, 1), what="ops.conv_fwd -> grouped")
+        dw2 = torch.zeros_like(wh)
+        ops.conv_wgrad(dyh, xh, dw2, 1, None, groups)
+        close(dw2, gw, what="ops.conv_wgrad -> grouped")
+        close(ops.conv_dgrad(dyh, wh, xh.shape, 1, None, groups).permute(0, 3, 1, 2), gx, what="ops.conv_dgrad -> grouped")

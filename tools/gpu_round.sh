@@ -16,6 +16,10 @@ trace)      (cd /tmp && export TMPDIR=/tmp && timeout 400 rocprofv3 --kernel-tra
             python tools/trace_csv_stats.py $O/trace_r02 > $O/r02_kernel_trace_graph.txt 2>&1; head -60 $O/r02_kernel_trace_graph.txt
             cp $O/trace_r02/*kernel_stats.csv $O/r02_kernel_stats.csv 2>/dev/null; rm -rf $O/trace_r02 ;;
 tune)       timeout 400 python tools/tune.py $O/mi355x_r02.txt 10 256,160 fp32,bf16 2>&1 | tail -6; cp $O/mi355x_r02.txt transfuser_amd/plans/mi355x.txt ;;
+tests_grouped) timeout 300 python -m pytest tests/test_kernels_gpu.py -q -k "grouped_conv or bench_shape_convs" 2>&1 | tail -5 ;;
+conv_bench) timeout 200 python tools/grouped_bench.py 2>&1 | tail -20 ;;
+ab_grouped) for v in 0 1 0 1; do TF_GROUPED_CONV=$v timeout 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('TF_GROUPED_CONV=$v', d['ms_per_step'], 'ms/step', d['value'], 'samples/s; GPT4 fc1', d['roofline']['avg_launch_us'], 'us')"; done ;;
+test_graph) timeout 300 python -m pytest tests/test_model_gpu.py -q -k "graph_replay" -s 2>&1 | grep -v "Warning\|warn" | tail -30 ;;
 tests_bf16) timeout 600 python -m pytest tests/test_kernels_gpu.py tests/test_model_gpu.py -q -k "bf16" -s 2>&1 | tail -12 ;;
 bench_bf16) timeout 300 python bench.py --steps 20 --warmup 5 --dtype bf16 --no-cpu-baseline > $O/r02_bench_bf16.json 2> $O/r02_bench_bf16.err; tail -3 $O/r02_bench_bf16.err; cat $O/r02_bench_bf16.json ;;
 esac

@@ -1,0 +1,263 @@
+// Direct (LDS-tiled) GROUPED 3x3 / stride 1 / pad 1 convolutions for the RegNetY bottlenecks (timm regnety_032: group width 24, i.e.
+// C / 24 groups of a 24 -> 24 channel 3x3 convolution; transfuser.py:380,442 via timm) and their two gradients.
+//
+// Through the implicit-GEMM engine these launches ran at 18-30 TFLOP/s (profiles/r01_engine_census_eager_step.txt): a 24-wide group is a
+// K = 216, N = 24 problem - 13.5 short k-tiles per 128 x 32 tile, every im2col element gathered with per-element index arithmetic and the
+// input re-read 9x through L2.  Here a block owns ONE group: it stages the group's 9 x 24 x 24 weight panel in LDS once, then walks its
+// share of 128-pixel tiles: the (TH+2) x (TW+2) x 24 input patch is staged once per tile and all 9 taps are read from LDS
+// (v_mfma_f32_32x32x2_f32, one 32-pixel x 32-channel accumulator per wave, 108 MFMAs per tile and wave; the 24 channels occupy 24 of the
+// 32 MFMA columns = the 75 % ceiling of any MFMA mapping of a 24-wide group).  Tiles are 8 x 16 or 4 x 32 pixels (picked per map
+// width: 44 -> 3 x 16, 88 -> 3 x 32, 16 / 32 / 64 exact).  dgrad = the same kernel on dY with the flipped, transposed panel.  wgrad keeps
+// 9 accumulators (one per tap, 24 x 24 used of 32 x 32) per wave with the tile's pixels as the K dimension, reduced over the block's
+// waves through LDS and over a group's blocks by a second tiny kernel (deterministic, no atomics).
+#include "tf_common.h"
+#include "../../include/transfuser_hip.h"
+
+using namespace tf;
+
+namespace {
+
+constexpr int CG = 24;              // channels per group (in and out)
+constexpr int PP = 25;              // floats per patch pixel: 24 channels + 1 (odd pitch: conflict-free MFMA A fetch)
+constexpr int WP = 36;              // pitch of a weight row (32 output columns + 4)
+
+struct GcGeom { int B, H, W, C, G, tiles_h, tiles_w, ntiles, nb; };   // C = total channels (pixel stride), nb = blocks per group
+
+template <int TW> struct Tile {
+    static constexpr int RW = 32 / TW;            // image rows per wave
+    static constexpr int TH = 4 * RW;             // tile rows (4 waves)
+    static constexpr int PH = TH + 2, PW = TW + 2;
+    static constexpr int NPIX = PH * PW;
+    static constexpr int NV = (NPIX * 6 + 255) / 256;   // float4 patch slots per thread (6 per pixel)
+};
+
+// group panel -> LDS as wl[tap * CG + k][n] (n < 32 zero padded):  fwd   wl[tap][ci][co] = W[g*CG + co][tap][ci]
+//                                                                   dgrad wl[tap][co][ci] = W[g*CG + co][8 - tap][ci]
+__device__ __forceinline__ void load_group_weights(float (*wl)[WP], const float* __restrict__ w, int dgrad) {
+    for (int i = threadIdx.x; i < 9 * CG * 32; i += 256) {
+        const int n = i & 31, k = (i >> 5) % CG, tap = i / (32 * CG);
+        float v = 0.f;
+        if (n < CG) v = dgrad ? w[((long)k * 9 + (8 - tap)) * CG + n] : w[((long)n * 9 + tap) * CG + k];
+        wl[tap * CG + k][n] = v;
+    }
+}
+
+template <int TW>
+__device__ __forceinline__ float4 load_patch_slot(const float* __restrict__ x, const GcGeom& g, int coff, int b, int h0, int w0, int s) {
+    typedef Tile<TW> T;
+    const int pix = s / 6, c = (s - pix * 6) * 4;
+    const int ph = pix / T::PW, pw = pix - ph * T::PW;
+    const int h = h0 - 1 + ph, w = w0 - 1 + pw;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (pix < T::NPIX && (unsigned)h < (unsigned)g.H && (unsigned)w < (unsigned)g.W)
+        v = *reinterpret_cast<const float4*>(x + (((long)b * g.H + h) * g.W + w) * g.C + coff + c);
+    return v;
+}
+template <int TW>
+__device__ __forceinline__ void store_patch_slot(float* patch, int s, const float4 v) {
+    const int pix = s / 6, c = (s - pix * 6) * 4;
+    if (pix < Tile<TW>::NPIX) { float* q = patch + pix * PP + c; q[0] = v.x; q[1] = v.y; q[2] = v.z; q[3] = v.w; }
+}
+
+// y[.., g*24 + co] = sum_{tap, ci} x[.. + tap, g*24 + ci] * W  (+ bias) (relu) (+= when accumulate); dgrad != 0: x is dY, y is dX
+template <int TW>
+__global__ void __launch_bounds__(256, 2) conv3x3_grouped_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                                 float* __restrict__ y, GcGeom g, int dgrad, int relu, int accumulate) {
+    typedef Tile<TW> T;
+    __shared__ float patch[T::NPIX * PP];
+    __shared__ float wl[9 * CG][WP];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int grp = blockIdx.x / g.nb, sub = blockIdx.x - grp * g.nb, coff = grp * CG;
+    load_group_weights(wl, w + (long)grp * CG * 9 * CG, dgrad);
+    float4 pre[T::NV];
+    auto fetch = [&](int t) {
+        const int b = t / (g.tiles_h * g.tiles_w), r = t - b * (g.tiles_h * g.tiles_w);
+        const int h0 = (r / g.tiles_w) * T::TH, w0 = (r % g.tiles_w) * TW;
+#pragma unroll
+        for (int p = 0; p < T::NV; ++p) pre[p] = load_patch_slot<TW>(x, g, coff, b, h0, w0, tid + p * 256);
+    };
+    int tile = sub;
+    if (tile < g.ntiles) fetch(tile);
+    // this lane's pixel inside the wave's 32: (row, col) of the tile
+    const int prow = wave * T::RW + l31 / TW, pcol = l31 % TW;
+    for (; tile < g.ntiles; tile += g.nb) {
+        __syncthreads();                           // previous tile's MFMAs are done with the patch (and the weights are staged)
+#pragma unroll
+        for (int p = 0; p < T::NV; ++p) store_patch_slot<TW>(patch, tid + p * 256, pre[p]);
+        __syncthreads();
+        const int nxt = tile + g.nb;
+        if (nxt < g.ntiles) fetch(nxt);            // next patch travels while this one is multiplied
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int kh = tap / 3, kw = tap - kh * 3;
+            const float* pa = patch + ((prow + kh) * T::PW + pcol + kw) * PP + hi;
+            const float* pb = &wl[tap * CG + hi][l31];
+#pragma unroll
+            for (int kk = 0; kk < CG / 2; ++kk) mfma_32x32x2(pa[2 * kk], pb[2 * kk * WP], acc);
+        }
+        const int b = tile / (g.tiles_h * g.tiles_w), r = tile - b * (g.tiles_h * g.tiles_w);
+        const int h0 = (r / g.tiles_w) * T::TH, w0 = (r % g.tiles_w) * TW;
+        if (l31 < CG) {
+            const float bj = bias ? bias[coff + l31] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int i = (e & 3) + 8 * (e >> 2) + 4 * hi;           // pixel index inside the wave's 32
+                const int hh = h0 + wave * T::RW + i / TW, ww = w0 + i % TW;
+                if (hh < g.H && ww < g.W) {
+                    float* dst = y + (((long)b * g.H + hh) * g.W + ww) * g.C + coff + l31;
+                    float v = acc[e] + bj;
+                    if (relu) v = fmaxf(v, 0.f);
+                    *dst = accumulate ? *dst + v : v;
+                }
+            }
+        }
+    }
+}
+
+// dW[g*24 + co][tap][ci] (+)= sum_pixels dY[p][g*24 + co] * X[p + tap][g*24 + ci]: per wave 32 pixels as K, 9 accumulators (one per tap);
+// part[(grp * nb + sub)][tap][32][32] partial panels, summed by conv3x3_grouped_wgrad_reduce_kernel.
+template <int TW>
+__global__ void __launch_bounds__(256, 1) conv3x3_grouped_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part, GcGeom g) {
+    typedef Tile<TW> T;
+    __shared__ float lds[T::NPIX * PP + 128 * PP];
+    float* patch = lds;
+    float* dyt = lds + T::NPIX * PP;               // [pixel][co]
+    static_assert(T::NPIX * PP + 128 * PP >= 4 * 32 * 33, "the cross-wave reduction reuses the tile memory");
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int grp = blockIdx.x / g.nb, sub = blockIdx.x - grp * g.nb, coff = grp * CG;
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    constexpr int ND = (128 * 6 + 255) / 256;      // dY float4 slots per thread (6 per pixel)
+    float4 pre[T::NV], dpre[ND];
+    auto fetch = [&](int t) {
+        const int b = t / (g.tiles_h * g.tiles_w), r = t - b * (g.tiles_h * g.tiles_w);
+        const int h0 = (r / g.tiles_w) * T::TH, w0 = (r % g.tiles_w) * TW;
+#pragma unroll
+        for (int p = 0; p < T::NV; ++p) pre[p] = load_patch_slot<TW>(x, g, coff, b, h0, w0, tid + p * 256);
+#pragma unroll
+        for (int p = 0; p < ND; ++p) {
+            const int s = tid + p * 256, pix = s / 6, c = (s - pix * 6) * 4;
+            const int h = h0 + pix / TW, w = w0 + pix % TW;
+            dpre[p] = (pix < 128 && h < g.H && w < g.W) ? *reinterpret_cast<const float4*>(dy + (((long)b * g.H + h) * g.W + w) * g.C + coff + c)
+                                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    int tile = sub;
+    if (tile < g.ntiles) fetch(tile);
+    for (; tile < g.ntiles; tile += g.nb) {
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < T::NV; ++p) store_patch_slot<TW>(patch, tid + p * 256, pre[p]);
+#pragma unroll
+        for (int p = 0; p < ND; ++p) {
+            const int s = tid + p * 256, pix = s / 6, c = (s - pix * 6) * 4;
+            if (pix < 128) { float* q = dyt + pix * PP + c; q[0] = dpre[p].x; q[1] = dpre[p].y; q[2] = dpre[p].z; q[3] = dpre[p].w; }
+        }
+        __syncthreads();
+        if (tile + g.nb < g.ntiles) fetch(tile + g.nb);
+        // k = pixel 2 kk + hi of this wave's 32: A[i = co][k] = dyt (shared by the 9 taps), B[k][j = ci] = patch shifted by the tap
+#pragma unroll 2
+        for (int kk = 0; kk < 16; ++kk) {
+            const int pi = 2 * kk + hi, prow = wave * T::RW + pi / TW, pcol = pi % TW;
+            const float a = (l31 < CG) ? dyt[(wave * 32 + pi) * PP + l31] : 0.f;
+            const float* pb = patch + (prow * T::PW + pcol) * PP + (l31 < CG ? l31 : 0);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int kh = tap / 3, kw = tap - kh * 3;
+                const float bv = (l31 < CG) ? pb[(kh * T::PW + kw) * PP] : 0.f;
+                mfma_32x32x2(a, bv, acc[tap]);
+            }
+        }
+    }
+    // reduce the 4 waves through LDS (all waves store their accumulator of one tap, then every thread sums 4 copies of 4 elements), then
+    // one partial panel per block: part[block][tap][co (32)][ci (32)]
+    __syncthreads();                               // the MFMAs are done with patch / dyt: their memory is reused as red[4][32][33]
+    float* red = patch;                            // 4 * 32 * 33 floats = 16.5 KB <= the patch + dyt allocation that follows it
+    for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int i = (e & 3) + 8 * (e >> 2) + 4 * hi;
+            red[(wave * 32 + i) * 33 + l31] = acc[tap][e];
+        }
+        __syncthreads();
+        for (int i = tid; i < 1024; i += 256) {
+            const int o = (i >> 5) * 33 + (i & 31);
+            part[((long)blockIdx.x * 9 + tap) * 1024 + i] = (red[o] + red[32 * 33 + o]) + (red[2 * 32 * 33 + o] + red[3 * 32 * 33 + o]);
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(256) conv3x3_grouped_wgrad_reduce_kernel(const float* __restrict__ part, int nb, float* __restrict__ dw, int accumulate) {
+    const int grp = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;   // (tap, co, ci) over 9 x 32 x 32
+    if (i >= 9 * 1024) return;
+    const int ci = i & 31, co = (i >> 5) & 31, tap = i >> 10;
+    if (co >= CG || ci >= CG) return;
+    float s = 0.f;
+    for (int b = 0; b < nb; ++b) s += part[((long)(grp * nb + b)) * 9216 + i];
+    float* d = dw + (((long)grp * CG + co) * 9 + tap) * CG + ci;
+    *d = accumulate ? *d + s : s;
+}
+
+constexpr int kMaxBlocks = 768;     // persistent grid: up to 3 blocks per CU
+
+inline GcGeom make_geom(int B, int H, int W, int C, int TW, int max_blocks = kMaxBlocks) {
+    GcGeom g; g.B = B; g.H = H; g.W = W; g.C = C; g.G = C / CG;
+    const int th = TW == 16 ? 8 : 4;
+    g.tiles_h = cdiv(H, th); g.tiles_w = cdiv(W, TW); g.ntiles = B * g.tiles_h * g.tiles_w;
+    int nb = max_blocks / g.G;
+    if (nb < 1) nb = 1;
+    if (nb > g.ntiles) nb = g.ntiles;
+    g.nb = nb;
+    return g;
+}
+// tile width with the least padding (ties -> 32: longer contiguous rows)
+inline int pick_tw(int H, int W) {
+    const long p16 = (long)cdiv(H, 8) * 8 * cdiv(W, 16) * 16, p32 = (long)cdiv(H, 4) * 4 * cdiv(W, 32) * 32;
+    return p16 < p32 ? 16 : 32;
+}
+inline bool args_ok(const void* a, const void* b, const void* c, int B, int H, int W, int C) {
+    return a && b && c && B > 0 && H > 0 && W > 0 && C > 0 && C % CG == 0 && aligned16(a) && aligned16(c);
+}
+
+}  // namespace
+
+extern "C" int tf_conv3x3_grouped_fwd_f32(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int C, int relu, void* stream) {
+    TF_REQUIRE(args_ok(x, w, y, B, H, W, C), "tf_conv3x3_grouped_fwd_f32: needs NHWC tensors with C %% 24 == 0 (group width 24), 16-byte aligned");
+    const int tw = pick_tw(H, W);
+    GcGeom g = make_geom(B, H, W, C, tw);
+    if (tw == 16) TF_LAUNCH(conv3x3_grouped_kernel<16>, dim3(g.G * g.nb), dim3(256), stream, x, w, bias, y, g, 0, relu, 0);
+    else TF_LAUNCH(conv3x3_grouped_kernel<32>, dim3(g.G * g.nb), dim3(256), stream, x, w, bias, y, g, 0, relu, 0);
+    return launch_status("tf_conv3x3_grouped_fwd_f32");
+}
+
+extern "C" int tf_conv3x3_grouped_dgrad_f32(const float* dy, const float* w, float* dx, int B, int H, int W, int C, int accumulate, void* stream) {
+    TF_REQUIRE(args_ok(dy, w, dx, B, H, W, C), "tf_conv3x3_grouped_dgrad_f32: needs NHWC tensors with C %% 24 == 0 (group width 24), 16-byte aligned");
+    const int tw = pick_tw(H, W);
+    GcGeom g = make_geom(B, H, W, C, tw);
+    if (tw == 16) TF_LAUNCH(conv3x3_grouped_kernel<16>, dim3(g.G * g.nb), dim3(256), stream, dy, w, (const float*)nullptr, dx, g, 1, 0, accumulate);
+    else TF_LAUNCH(conv3x3_grouped_kernel<32>, dim3(g.G * g.nb), dim3(256), stream, dy, w, (const float*)nullptr, dx, g, 1, 0, accumulate);
+    return launch_status("tf_conv3x3_grouped_dgrad_f32");
+}
+
+extern "C" long tf_conv3x3_grouped_wgrad_ws_floats(void) { return (long)(kMaxBlocks + 64) * 9216; }
+
+extern "C" int tf_conv3x3_grouped_wgrad_f32(const float* dy, const float* x, float* dw, int B, int H, int W, int C, int accumulate, float* ws, void* stream) {
+    TF_REQUIRE(args_ok(dy, x, dw, B, H, W, C) && ws, "tf_conv3x3_grouped_wgrad_f32: needs C %% 24 == 0 and ws of tf_conv3x3_grouped_wgrad_ws_floats() floats");
+    const int tw = pick_tw(H, W);
+    // every block ends with a 36 KB partial panel + the cross-wave reduction: give a block ~6+ tiles of work (one block per CU)
+    GcGeom g = make_geom(B, H, W, C, tw, 256);
+    if (g.nb > 1 && g.ntiles / g.nb < 6) { g.nb = g.ntiles / 6; if (g.nb < 1) g.nb = 1; }
+    TF_REQUIRE((long)g.G * g.nb * 9216 <= tf_conv3x3_grouped_wgrad_ws_floats(), "tf_conv3x3_grouped_wgrad_f32: %d groups exceed the workspace", g.G);
+    if (tw == 16) TF_LAUNCH(conv3x3_grouped_wgrad_kernel<16>, dim3(g.G * g.nb), dim3(256), stream, x, dy, ws, g);
+    else TF_LAUNCH(conv3x3_grouped_wgrad_kernel<32>, dim3(g.G * g.nb), dim3(256), stream, x, dy, ws, g);
+    TF_LAUNCH(conv3x3_grouped_wgrad_reduce_kernel, dim3(36, g.G), dim3(256), stream, (const float*)ws, g.nb, dw, accumulate);
+    return launch_status("tf_conv3x3_grouped_wgrad_f32");
+}

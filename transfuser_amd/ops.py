@@ -238,6 +238,24 @@ def _direct_ok(shape, cout, cin, ks, stride, pad, groups):
 
 
 _DIRECT = bool(int(__import__("os").environ.get("TF_DIRECT_CONV", "1")))
+_GROUPED = bool(int(__import__("os").environ.get("TF_GROUPED_CONV", "1")))
+_gws_cache = {}
+
+
+def _grouped_ok(shape, cout, cin, ks, stride, pad, groups):
+    """RegNetY bottleneck convolution: 3x3 / s1 / p1, group width 24 on both sides -> the per-group direct kernels (csrc/conv_grouped.cpp).
+    The stride-2 first block of every stage stays on the implicit-GEMM engine."""
+    return _GROUPED and ks == 3 and stride == 1 and pad == 1 and groups > 1 and cin == cout == groups * 24 and shape[1] >= 4 and shape[2] >= 8
+
+
+def _grouped_ws(device):
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream if getattr(device, "type", str(device)[:4]) == "cuda" else 0)
+    ws = _gws_cache.get(key)
+    if ws is None:
+        L().tf_conv3x3_grouped_wgrad_ws_floats.restype = ctypes.c_long
+        ws = torch.empty(L().tf_conv3x3_grouped_wgrad_ws_floats(), dtype=torch.float32, device=device)
+        _gws_cache[key] = ws
+    return ws
 _DIRECT_WGRAD_MAX_COUT = 32  # measured (tools/conv_bench.py): 421-425 us for every Cout at 256x704 vs 674-752 us through the engine's split-K path
 
 
@@ -251,6 +269,10 @@ def conv_fwd(x, w, bias=None, stride=1, pad=None, groups=1, relu=False):
         check(L().tf_conv3x3_small_fwd_f32(ptr(_c(x)), wptr(w), ptr(bias), ptr(y), g.B, g.Hi, g.Wi, g.Cin, g.Cout, int(relu), stream_of(x)),
               "tf_conv3x3_small_fwd_f32")
         _census_end(_e, "conv fwd*", _gshape(g), _gflops(g))
+        return y
+    if _grouped_ok(x.shape, g.Cout, g.Cin, ks, stride, pad, groups):
+        check(L().tf_conv3x3_grouped_fwd_f32(ptr(_c(x)), wptr(w), ptr(bias), ptr(y), g.B, g.Hi, g.Wi, g.Cin, int(relu), stream_of(x)), "tf_conv3x3_grouped_fwd_f32")
+        _census_end(_e, "conv fwd g", _gshape(g), _gflops(g))
         return y
     check(L().tf_conv2d_fwd_f32(byref(g), ptr(_c(x)), wptr(w), ptr(bias), ptr(y), int(relu), stream_of(x)), "tf_conv2d_fwd_f32")
     _census_end(_e, "conv fwd", _gshape(g), _gflops(g))
@@ -269,6 +291,10 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=None, groups=1, out=None, accumulat
               "tf_conv3x3_small_dgrad_f32")
         _census_end(_e, "conv dgrad*", _gshape(g), _gflops(g))
         return out
+    if _grouped_ok(x_shape, g.Cout, g.Cin, ks, stride, pad, groups):
+        check(L().tf_conv3x3_grouped_dgrad_f32(ptr(_c(dy)), wptr(w), ptr(_c(out)), g.B, g.Hi, g.Wi, g.Cin, int(accumulate), stream_of(dy)), "tf_conv3x3_grouped_dgrad_f32")
+        _census_end(_e, "conv dgrad g", _gshape(g), _gflops(g))
+        return out
     check(L().tf_conv2d_dgrad_f32(byref(g), ptr(_c(dy)), wptr(w), ptr(_c(out)), int(accumulate), stream_of(dy)), "tf_conv2d_dgrad_f32")
     _census_end(_e, "conv dgrad", _gshape(g), _gflops(g))
     return out
@@ -283,6 +309,11 @@ def conv_wgrad(dy, x, dw, stride=1, pad=None, groups=1, accumulate=True):
         check(L().tf_conv3x3_small_wgrad_f32(ptr(_c(dy)), ptr(_c(x)), wptr(dw), g.B, g.Hi, g.Wi, g.Cin, g.Cout, int(accumulate), ptr(workspace(x.device)),
                                              stream_of(dy)), "tf_conv3x3_small_wgrad_f32")
         _census_end(_e, "conv wgrad*", _gshape(g), _gflops(g))
+        return dw
+    if _grouped_ok(x.shape, g.Cout, g.Cin, ks, stride, pad, groups):
+        check(L().tf_conv3x3_grouped_wgrad_f32(ptr(_c(dy)), ptr(_c(x)), wptr(dw), g.B, g.Hi, g.Wi, g.Cin, int(accumulate), ptr(_grouped_ws(x.device)),
+                                               stream_of(dy)), "tf_conv3x3_grouped_wgrad_f32")
+        _census_end(_e, "conv wgrad g", _gshape(g), _gflops(g))
         return dw
     check(L().tf_conv2d_wgrad_f32(byref(g), ptr(_c(dy)), ptr(_c(x)), wptr(dw), int(accumulate), stream_of(dy)), "tf_conv2d_wgrad_f32")
     _census_end(_e, "conv wgrad", _gshape(g), _gflops(g))
