@@ -249,6 +249,17 @@ int tf_pillar_canvas_f32(const float* pillar_feat, const int32_t* cellkey, int P
 int tf_pillar_canvas_bwd_f32(const float* dout_nhwc, const int32_t* owner, const int32_t* cellkey, const int32_t* inv, const int32_t* arg,
                              int64_t N, int C, int Cs, int GX, int GY, int H, int W, float* dz, void* stream);
 
+/* GPU-side batch preparation: the per-sample numpy work of team_code_transfuser/data.py after file decoding, batched.
+ * tf_lidar_align_hist_f64: align (data.py:411-444: q = T (x, -y, z, 1), y' = -q1; T (B,16) row-major fp64) fused with the 2-bin height histogram
+ *   (data.py:446-470) of the transformed cloud; optional aligned cloud output (B, max_points, 4) fp32 for PointPillars (data.py:247-251).
+ * tf_image_prep_u8: centre crop with per-sample x shift of an HWC uint8 batch; mode 0 -> CHW float (crop_image_cv2, data.py:536-553), 1 -> get_depth
+ *   (data.py:358-372), 2 -> crop_seg + class LUT (data.py:176-177).  tf_bev_prep_u8: decode_pil_to_npy + load_crop_bev_npy (data.py:844-856,586-612). */
+int tf_lidar_align_hist_f64(const float* points, const int32_t* num_points, int B, int max_points, int point_stride, const double* transforms, float* out,
+                            float* aligned_or_null, void* stream);
+int tf_image_prep_u8(const uint8_t* src, int B, int Hs, int Ws, int C, int crop_h, int crop_w, int start_y, const int32_t* start_x, int mode, const uint8_t* lut,
+                     void* out, void* stream);
+int tf_bev_prep_u8(const uint8_t* encoded, int B, int S, const float* degrees_or_null, int64_t* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

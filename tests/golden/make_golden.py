@@ -276,6 +276,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "point_pillar.npz"), **pillar_golden(ref_pp))
     import model as ref_model            # the reference module, unmodified (cv2 / torchvision / mmcv / mmdet = oracle/mm_shim)
     np.savez_compressed(os.path.join(HERE, "lidar_centernet_tiny.npz"), **model_golden(ref_model))
+    np.savez_compressed(os.path.join(HERE, "dataprep.npz"), **dataprep_golden())
     # H1: numpy.histogramdd (the reference's algorithm, data.py:446-470) on a seeded cloud with edge cases -> sparse golden
     rng = np.random.default_rng(3)
     pts = np.stack([rng.uniform(-20, 20, 20000), rng.uniform(-36, 4, 20000), rng.uniform(-4, 1, 20000)], 1).astype(np.float32)
@@ -285,6 +286,88 @@ def main():
     idx = np.nonzero(h)
     np.savez_compressed(os.path.join(HERE, "lidar_hist.npz"), points=pts, idx=np.stack(idx).astype(np.int16), val=(h[idx] * 5).round().astype(np.uint8))
     print("wrote", sorted(os.listdir(HERE)))
+
+
+# ---------------------------------------------------------------- data.py per-sample preparation
+def reference_data_functions():
+    """Functions of the reference's data.py / utils.py EXECUTED FROM THEIR OWN SOURCE (ast-extracted, so the module-level imports of cv2 /
+    ujson / skimage - absent here - are never run).  ``rotate`` (skimage) is only provided as the identity: angle-0 cases."""
+    import ast
+    from copy import deepcopy
+    ns = {"np": np, "deepcopy": deepcopy, "rotate": lambda img, deg: img}
+    want = {"utils.py": None, "data.py": {"get_depth", "align", "lidar_to_histogram_features", "decode_pil_to_npy", "crop_image_cv2", "crop_seg", "load_crop_bev_npy",
+                                          "get_bbox_label", "parse_labels", "get_waypoints", "transform_waypoints"}}
+    for fn, names in want.items():
+        src = open(os.path.join("/root/reference/team_code_transfuser", fn)).read()
+        for node in ast.parse(src).body:
+            if isinstance(node, ast.FunctionDef) and (names is None or node.name in names):
+                exec(compile(ast.Module([node], []), fn, "exec"), ns)
+    return ns
+
+
+def dataprep_raw(B=2, seed=5, Hs=48, Ws=160, S=500, N=3000):
+    """Raw decoded arrays of B frames (what CARLA_Data.__getitem__ returns, small images) + label / measurement dicts."""
+    rng = np.random.default_rng(seed)
+    raw = dict(rgb_u8=rng.integers(0, 256, (B, Hs, Ws, 3), dtype=np.uint8), depth_u8=rng.integers(0, 256, (B, Hs, Ws, 3), dtype=np.uint8),
+               sem_u8=rng.integers(0, 28, (B, Hs, Ws, 1), dtype=np.uint8), bev_u8=rng.integers(0, 256, (B, S, S, 3), dtype=np.uint8))
+    raw["depth_u8"][:, :, : Ws // 2, 0] = 0          # small depths (< 50 m) in half of the image, so the clip is exercised on both sides
+    raw["depth_u8"][:, :, : Ws // 4, 1] = rng.integers(0, 13, (B, Hs, Ws // 4), dtype=np.uint8)
+    pts = np.stack([rng.uniform(-25, 25, (B, N)), rng.uniform(-40, 8, (B, N)), rng.uniform(-4, 1, (B, N)), rng.uniform(0, 1, (B, N))], -1).astype(np.float32)
+    pts[0, :50, :2] = np.round(pts[0, :50, :2] * 8) / 8
+    raw["lidar_raw"] = pts
+    raw["num_points"] = np.array([N, N - 700], np.int32)[:B]
+    def pose(th, x, y):
+        m = np.eye(4); m[0, 0] = m[1, 1] = np.cos(th); m[0, 1] = -np.sin(th); m[1, 0] = np.sin(th); m[0, 3] = x; m[1, 3] = y
+        return m
+    raw["ego_matrix"] = np.stack([pose(0.3 + 0.1 * b, 10.0 + b, -4.0) for b in range(B)])
+    labels, meas = [], []
+    for b in range(B):
+        fr = []
+        for t in range(5):
+            objs = [dict(id=7, ego_matrix=pose(0.3 + 0.1 * b + 0.02 * t, 10.0 + b + 1.5 * t, -4.0 + 0.2 * t).tolist(), extent=[0.7, 2.4, 1.0], position=[0.0, 0.0, 0.0],
+                         yaw=0.0, speed=3.0, brake=0.0, num_points=50, distance=0.0)]
+            for j in range(6):
+                objs.append(dict(id=100 + j, ego_matrix=pose(0.1 * j, 3.0 * j, 2.0).tolist(), extent=[0.8, 2.0 + 0.1 * j, 0.9], position=[float(rng.uniform(-20, 20)), float(rng.uniform(-2, 36)), 0.0],
+                                 yaw=float(rng.uniform(-3, 3)), speed=float(rng.uniform(0, 8)), brake=float(j % 2), num_points=int(j), distance=5.0))
+            fr.append(objs)
+        labels.append(fr)
+        meas.append(dict(theta=0.3 + 0.1 * b, x=10.0 + b, y=-4.0, x_command=30.0, y_command=5.0 - b, speed=3.5 + b, ego_matrix=raw["ego_matrix"][b].tolist()))
+    return raw, labels, meas
+
+
+def dataprep_golden():
+    """Outputs of the reference's own functions (no augmentation: degree 0) on dataprep_raw()."""
+    f = reference_data_functions()
+    raw, labels, meas = dataprep_raw()
+    B = raw["rgb_u8"].shape[0]
+    crop = (16, 64)
+    out = dict(rgb=[], depth=[], semantic=[], bev=[], lidar=[], label=[], ego_waypoint=[], target_point=[])
+    conv = np.uint8([0, 0, 0, 0, 4, 0, 5, 2, 6, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 3, 3, 0, 0, 5])
+    for b in range(B):
+        out["rgb"].append(f["crop_image_cv2"](raw["rgb_u8"][b], crop=crop, crop_shift=0))
+        out["depth"].append(f["get_depth"](f["crop_image_cv2"](raw["depth_u8"][b], crop=crop, crop_shift=0)))
+        out["semantic"].append(conv[f["crop_seg"](raw["sem_u8"][b][..., 0], crop=crop, crop_shift=0)])
+        enc = np.moveaxis(raw["bev_u8"][b], -1, 0)
+        out["bev"].append(f["load_crop_bev_npy"](f["decode_pil_to_npy"](enc).astype(np.uint8), 0))
+        n = int(raw["num_points"][b])
+        lid = f["align"](raw["lidar_raw"][b, :n].copy(), meas[b], meas[b], degree=0)
+        out["lidar"].append(f["lidar_to_histogram_features"](lid))
+        boxes = f["parse_labels"](labels[b][0], rad=-0.0)
+        wps = f["transform_waypoints"](f["get_waypoints"](labels[b], 5))
+        ego = np.array([m[:2, 3] for m, flag in wps[7][1:]])
+        lab = np.zeros((20, 7), np.float32)
+        arr = np.array(list(boxes.values()))
+        if arr.shape[0]:
+            lab[:arr.shape[0]] = arr
+        out["label"].append(lab); out["ego_waypoint"].append(ego)
+        th = meas[b]["theta"]
+        R = np.array([[np.cos(np.pi / 2 + th), -np.sin(np.pi / 2 + th)], [np.sin(np.pi / 2 + th), np.cos(np.pi / 2 + th)]])
+        out["target_point"].append(R.T.dot(np.array([meas[b]["x_command"] - meas[b]["x"], meas[b]["y_command"] - meas[b]["y"]])))
+    res = {"dp_" + k: np.stack(v) for k, v in out.items()}
+    idx = np.nonzero(res["dp_lidar"])
+    res["dp_lidar_idx"] = np.stack(idx).astype(np.int16); res["dp_lidar_val"] = (res.pop("dp_lidar")[idx] * 5).round().astype(np.uint8)
+    res["dp_depth"] = res["dp_depth"].astype(np.float64)
+    return res
 
 
 if __name__ == "__main__":

@@ -159,3 +159,72 @@ def _engine_worker(rank, world, port, tmp):
 def test_engine_overlap_plain_zero_world2_gloo(tmp_path):
     port = 31500 + (os.getpid() % 2000)
     mp.spawn(_engine_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+
+
+def _ddp_worker(rank, world, port):
+    """The reference's OWN wrappers around the product module (train.py:132-146): torch DistributedDataParallel(find_unused_parameters=False,
+    broadcast_buffers=False), SyncBatchNorm.convert_sync_batchnorm, ZeroRedundancyOptimizer(AdamW) - the block Functions hand their parameter
+    gradients back to autograd, so DDP's reducer hooks fire and the averaged gradients land in p.grad."""
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import ctypes
+    import build_emu
+    from transfuser_amd import _lib
+    _lib._install_test_backend(ctypes.CDLL(build_emu.build()))
+    import model_cases as mc
+    from torch.distributed.optim import ZeroRedundancyOptimizer
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    cfg = mc.tiny_config(n_layer=1)
+    call = lambda m, b: m(b['rgb'], b['lidar'], ego_waypoint=b['ego_waypoint'], target_point=b['target_point'], target_point_image=b['target_point_image'],
+                          ego_vel=b['ego_vel'].reshape(-1, 1), bev=b['bev'], label=b['label'], depth=b['depth'], semantic=b['semantic'])
+    w = dict(zip(cfg.detailed_losses, [1.0, 1.0, 1.0, 1.0, 0.2, 0.2, 0.2, 0.2, 0.2, 0.3, 0.4]))
+    batch = mc.small_batch(1, 32, 64, 64, 40, seed=20 + rank)
+    # local gradients of the un-wrapped model (same weights on both ranks)
+    prod, _ = mc.build_pair(cfg, "regnety_tiny", "cpu", seed=0)
+    prod.train()
+    sum(w[k] * v for k, v in call(prod, batch).items()).backward()
+    local = {n: p.grad.detach().clone() for n, p in prod.named_parameters()}
+    for p in prod.parameters():
+        p.grad = None
+    for b in prod.buffers():                                   # undo the running-stat update of the probe pass
+        if b.dtype.is_floating_point:
+            pass
+    ddp = torch.nn.parallel.DistributedDataParallel(prod, broadcast_buffers=False, find_unused_parameters=False)
+    opt = ZeroRedundancyOptimizer(ddp.parameters(), optimizer_class=torch.optim.AdamW, lr=1e-3)
+    losses = call(ddp, batch)
+    assert set(losses) == set(cfg.detailed_losses)
+    sum(w[k] * v for k, v in losses.items()).backward()
+    for n, p in prod.named_parameters():
+        assert p.grad is not None, n
+        both = [torch.zeros_like(local[n]) for _ in range(world)]
+        dist.all_gather(both, local[n].contiguous())
+        want = (both[0] + both[1]) / world
+        assert torch.allclose(p.grad, want, atol=1e-6 + 1e-5 * want.abs().max().item()), (n, (p.grad - want).abs().max().item())
+    before = prod.head.heatmap_head[0].weight.detach().clone()
+    opt.step()
+    assert not torch.equal(before, prod.head.heatmap_head[0].weight)
+    opt.consolidate_state_dict(0)                               # train.py:206-207
+    if rank == 0:
+        assert len(opt.state_dict()["state"]) > 100
+    assert any(k.startswith("module._model.") for k in ddp.state_dict())      # checkpoints carry DDP's prefix (train.py:381-384)
+    # SyncBatchNorm.convert_sync_batchnorm: every BatchNorm is replaced by torch's SyncBatchNorm module; our kernels detect it
+    from transfuser_amd import functions as F_
+    conv = torch.nn.SyncBatchNorm.convert_sync_batchnorm(mc.build_pair(cfg, "regnety_tiny", "cpu", seed=0)[0])
+    conv.train()
+    assert isinstance(conv._model.image_encoder.features.bn1, torch.nn.SyncBatchNorm) and isinstance(conv._model._img_stem.bn, torch.nn.SyncBatchNorm)
+    calls = []
+    orig = F_._bn_sync_fwd
+    F_._bn_sync_fwd = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        lc = call(conv, batch)
+        sum(w[k] * v for k, v in lc.items()).backward()
+    finally:
+        F_._bn_sync_fwd = orig
+    assert len(calls) > 10 and all(torch.isfinite(v) for v in lc.values())
+    dist.destroy_process_group()
+
+
+def test_torch_ddp_syncbn_zero_wrappers_world2_gloo():
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(_ddp_worker, args=(2, port), nprocs=2, join=True)

@@ -174,3 +174,9 @@ def test_bench_shape_gemms_with_tuned_plans(case, tuned_plans):
 @pytest.mark.parametrize("case", kc.BENCH_CONVS, ids=str)
 def test_bench_shape_convs_with_tuned_plans(case, tuned_plans):
     kc.check_bench_conv("cuda", *case)
+
+
+def test_dataprep_matches_reference_functions():
+    """GPU-side batch preparation vs the reference's own data.py functions (tests/golden/dataprep.npz)."""
+    import dataprep_cases as dc
+    dc.check_dataprep("cuda")

@@ -382,3 +382,25 @@ def test_full_size_step_properties():
     assert float(tot) < first, (first, float(tot))
     g = model.head.velocity_head[2].weight.grad
     assert float(g.abs().max()) == 0.0
+
+
+def test_train_cli_epochs_schedule_validate_save(tmp_path):
+    """transfuser_amd.train.main with the reference's flags (train.py:30-70) on the synthetic dataset: 2 epochs of hipGraph steps, the LR drop
+    (train.py:194-199), validation (setting != 'all', train.py:201-202, 321-342), per-epoch checkpoints + args.txt + the loss log; the
+    checkpoint loads back into a fresh model and resumes (--load_file / --start_epoch)."""
+    import json
+    import os
+    from transfuser_amd import train
+    argv = ["--id", "t", "--logdir", str(tmp_path), "--root_dir", "synthetic:8", "--batch_size", "2", "--epochs", "2", "--schedule_reduce_epoch_01", "1",
+            "--setting", "02_05_withheld", "--val_every", "1", "--parallel_training", "0", "--num_workers", "0"]
+    tr = train.main(argv)
+    d = os.path.join(str(tmp_path), "t")
+    assert tr.cur_epoch == 2 and abs(float(tr.eng.optimizer.state[1]) - 1e-5) < 1e-9 and float(tr.eng.optimizer.state[0]) == 8.0   # 2 epochs x 4 steps; lr x0.1 once
+    assert json.load(open(os.path.join(d, "args.txt")))["backbone"] == "transFuser"
+    rows = [json.loads(l) for l in open(os.path.join(d, "losses.jsonl"))]
+    assert any("val_loss_total" in r for r in rows) and sum("loss_total" in r for r in rows) == 2
+    assert all(v == v for r in rows for v in r.values())
+    for e in (1, 2):
+        assert os.path.exists(os.path.join(d, "model_%d.pth" % e)) and os.path.exists(os.path.join(d, "optimizer_%d.pth" % e))
+    tr2 = train.main(argv[:-2] + ["--num_workers", "0", "--epochs", "3", "--start_epoch", "2", "--load_file", os.path.join(d, "model_2.pth")])
+    assert tr2.cur_epoch == 3 and float(tr2.eng.optimizer.state[0]) == 12.0        # AdamW step counter continued from the checkpoint

@@ -5,10 +5,10 @@ layer, a loss...) as a hand-ordered sequence of HIP launches and implements its 
 same way.  PyTorch only links the blocks (a few dozen autograd nodes per step), owns the memory
 and provides the stream; no ATen compute kernel is used inside a block.
 
-Parameter gradients are ACCUMULATED by the kernels straight into ``param.grad`` (views of the
-flat gradient arena when the model is driven by ``transfuser_amd.train.Engine``), so the
-Functions return ``None`` for parameter inputs: there is no per-parameter AccumulateGrad pass
-and the arena can be all-reduced / fed to the fused AdamW kernel as one buffer.
+Parameter gradients: by default every block Function returns them to autograd (plain PyTorch semantics: ``loss.backward()`` fills
+``p.grad``, DDP / ZeroRedundancyOptimizer / SyncBatchNorm wrappers work - the reference's unmodified train.py loop).  Inside
+``transfuser_amd.train.Engine`` they are ACCUMULATED by the kernels straight into ``param.grad`` (views of the flat gradient arena) and the
+Functions return ``None`` for parameter inputs: no per-parameter AccumulateGrad pass, one buffer for the all-reduce and the fused AdamW.
 """
 import math
 
@@ -17,11 +17,65 @@ import torch
 from . import ops
 
 
+# ---- where parameter gradients go.
+# torch mode (default): a Function's backward RETURNS the gradients of the parameters it received as inputs, like any autograd node, so
+#   AccumulateGrad runs for every parameter: ``loss.backward()`` fills ``p.grad``, DistributedDataParallel's reducer hooks fire, ``optim.AdamW``
+#   / ``ZeroRedundancyOptimizer`` / ``zero_grad(set_to_none=True)`` behave as with the reference's modules (train.py:132-146,304-316).
+# in-place mode (inside train.Engine, ``with inplace_param_grads():``): the kernels accumulate straight into ``p.grad`` - views of the flat
+#   gradient arena - and the Functions return None for parameters: no per-parameter AccumulateGrad pass, one buffer for RCCL and AdamW.
+_INPLACE = False
+_collect = None
+
+
+class inplace_param_grads:
+    def __enter__(self):
+        global _INPLACE
+        self.prev, _INPLACE = _INPLACE, True
+
+    def __exit__(self, *a):
+        global _INPLACE
+        _INPLACE = self.prev
+
+
 def gbuf(p):
-    """Gradient accumulation buffer of a parameter (allocated zero-filled on first use)."""
+    """Gradient accumulation buffer of a parameter: the per-backward collector's zero-filled tensor (torch mode) or ``p.grad`` (in-place mode)."""
+    if _collect is not None:
+        t = _collect.get(id(p))
+        if t is None:
+            t = _collect[id(p)] = torch.zeros_like(p)      # keeps the memory format (channels_last conv weights)
+        return t
     if p.grad is None:
         p.grad = torch.zeros_like(p)
     return p.grad
+
+
+def routes_param_grads(cls):
+    """Class decorator for the block Functions: in torch mode the parameter gradients the kernels accumulated during ``backward`` are handed
+    back to autograd in the positions of the nn.Parameter inputs."""
+    fwd, bwd = cls.forward, cls.backward
+
+    def forward(ctx, *args):
+        ctx._tf_ppos = [(i, a) for i, a in enumerate(args) if isinstance(a, torch.nn.Parameter)]
+        return fwd(ctx, *args)
+
+    def backward(ctx, *grads):
+        global _collect
+        if _INPLACE:
+            return bwd(ctx, *grads)
+        prev, _collect = _collect, {}
+        try:
+            out = bwd(ctx, *grads)
+            out = list(out) if isinstance(out, tuple) else [out]
+            for i, prm in ctx._tf_ppos:
+                g = _collect.get(id(prm))
+                if g is not None and i < len(out):
+                    out[i] = g
+            return tuple(out)
+        finally:
+            _collect = prev
+
+    cls.forward, cls.backward = staticmethod(forward), staticmethod(backward)
+    return cls
 
 
 def w2d(w):
@@ -35,6 +89,10 @@ def bias_grad(dy2d, b, mask2d=None):
 
 def _bn(x, bn, res=None, relu=False):
     grp = getattr(bn, "_sync_group", None)
+    if grp is None and isinstance(bn, torch.nn.SyncBatchNorm) and bn.training:     # torch.nn.SyncBatchNorm.convert_sync_batchnorm(model) (train.py:133)
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(bn.process_group) > 1:
+            grp = bn.process_group if bn.process_group is not None else dist.group.WORLD
     if grp is not None and bn.training:
         return _bn_sync_fwd(x, bn, res, relu, grp)
     y, sm, si = ops.bn_fwd(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, res, relu, bn.training, bn.momentum, bn.eps)
@@ -108,6 +166,7 @@ def _bn_sync_bwd(dz, z, x, bn, st, want_dres):
 
 
 # ============================================================================================ stem
+@routes_param_grads
 class StemFn(torch.autograd.Function):
     """conv3x3/s2 (no bias) + BatchNormAct2d on the NCHW model input (transfuser.py:136-143)."""
 
@@ -127,6 +186,7 @@ class StemFn(torch.autograd.Function):
 
 
 # ============================================================================================ RegNetY block
+@routes_param_grads
 class YBlockFn(torch.autograd.Function):
     """timm Bottleneck: 1x1 -> BN/ReLU -> grouped 3x3 (stride) -> BN/ReLU -> SE ->
     1x1 -> BN (+ shortcut / 1x1-s2 downsample BN) -> ReLU."""
@@ -234,6 +294,7 @@ def _attn_ctx(att, qkv, B, T, C, nh, Tp):
     return y
 
 
+@routes_param_grads
 class GPTStageFn(torch.autograd.Function):
     """One fusion stage (transfuser.py:150-157 + GPT.forward :333-366): adaptive pools -> tokens + pos_emb
     -> n_layer Blocks -> ln_f -> raw view (quirk Q1) -> bilinear up-sample -> residual add, for both branches."""
@@ -393,6 +454,7 @@ def _mlp_bwd(dh, acts, seq):
     return dh
 
 
+@routes_param_grads
 class GeoStageFn(torch.autograd.Function):
     """One geometric-fusion stage for both branches (geometric_fusion.py:125-166 and the three copies below it):
     1x1 conv C->E + adaptive pool, gather the 5 correspondences of every cell from the OTHER branch (kernel G1), sum, 3-layer
@@ -487,6 +549,7 @@ class GeoStageFn(torch.autograd.Function):
 
 
 # ============================================================================================ generic conv / resample
+@routes_param_grads
 class ConvFn(torch.autograd.Function):
     """conv (1x1 or 3x3, stride 1, bias) (+ReLU) on NHWC: decoders, heads, FPN, channel reducers."""
 
@@ -604,6 +667,7 @@ class CenterNetLossFn(torch.autograd.Function):
 
 
 # ============================================================================================ waypoint head
+@routes_param_grads
 class WaypointFn(torch.autograd.Function):
     """join MLP 512->256->128->64 (+ReLU) on the MFMA engine, then the fused auto-regressive GRU decoder
     (model.py:592-605,611-646) -> pred_wp (B, pred_len, 2)."""

@@ -74,6 +74,7 @@ class LidarCenterNetHead(nn.Module):
         return [getattr(self, n) for n in HEAD_ORDER]
 
 
+@F_.routes_param_grads
 class HeadsFn(torch.autograd.Function):
     """The 7 CenterNet heads + pred_bev on p2 in one autograd node (model.py:127-147,581-585,759):
     8 x [conv3x3 64->64 + ReLU + conv1x1]; head outputs are packed as (B,h,w,9+bins) logits

@@ -743,3 +743,38 @@ def pillar_canvas_bwd(dout, owner, cellkey, inv, arg, C, GX, GY):
     check(L().tf_pillar_canvas_bwd_f32(ptr(_c(dout)), ptr(owner), ptr(cellkey), ptr(inv), ptr(arg), ctypes.c_int64(N), C, Cs, GX, GY, H, W, ptr(dz),
                                        stream_of(dout)), "tf_pillar_canvas_bwd_f32")
     return dz
+
+
+# ------------------------------------------------------------------------------------------ GPU-side batch preparation (csrc/dataprep.cpp)
+def lidar_align_hist(points, transforms, num_points=None, return_aligned=False):
+    """align (data.py:411-444) + lidar_to_histogram_features (:446-470) for a batch: points (B, N, >=4) float32 as loaded (y negated),
+    transforms (B, 4, 4) float64 -> (B, 2, 256, 256) float32 [, aligned cloud (B, N, 4) float32]."""
+    B, N, S = points.shape
+    out = torch.empty(B, 2, 256, 256, dtype=torch.float32, device=points.device)
+    al = torch.empty(B, N, 4, dtype=torch.float32, device=points.device) if return_aligned else None
+    t = transforms.to(device=points.device, dtype=torch.float64).contiguous()
+    check(L().tf_lidar_align_hist_f64(ptr(_c(points)), ptr(num_points), B, N, S, ctypes.c_void_p(t.data_ptr()), ptr(out), ptr(al), stream_of(points)),
+          "tf_lidar_align_hist_f64")
+    return (out, al) if return_aligned else out
+
+
+def image_prep(src, crop_hw, start_y, start_x, mode, lut=None):
+    """src (B, Hs, Ws, C) uint8 HWC; mode "rgb" -> (B, C, h, w) float32; "depth" -> (B, h, w) float32 (get_depth); "seg" -> (B, h, w) int64 (LUT)."""
+    B, Hs, Ws, C = src.shape
+    h, w = crop_hw
+    m = {"rgb": 0, "depth": 1, "seg": 2}[mode]
+    out = torch.empty((B, C, h, w) if m == 0 else (B, h, w), dtype=torch.int64 if m == 2 else torch.float32, device=src.device)
+    sx = start_x.to(device=src.device, dtype=torch.int32).contiguous()
+    check(L().tf_image_prep_u8(ctypes.c_void_p(src.contiguous().data_ptr()), B, Hs, Ws, C, h, w, int(start_y), ptr(sx), m,
+                               ctypes.c_void_p(lut.data_ptr()) if lut is not None else ctypes.c_void_p(0), ctypes.c_void_p(out.data_ptr()), stream_of(src)),
+          "tf_image_prep_u8")
+    return out
+
+
+def bev_prep(encoded, degrees=None):
+    """encoded (B, S, S, 3) uint8 RGB top-down image -> (B, 160, 160) int64 labels (decode_pil_to_npy + load_crop_bev_npy, data.py:844-856,586-612)."""
+    B, S = encoded.shape[0], encoded.shape[1]
+    out = torch.empty(B, 160, 160, dtype=torch.int64, device=encoded.device)
+    d = degrees.to(device=encoded.device, dtype=torch.float32).contiguous() if degrees is not None else None
+    check(L().tf_bev_prep_u8(ctypes.c_void_p(encoded.contiguous().data_ptr()), B, S, ptr(d), ctypes.c_void_p(out.data_ptr()), stream_of(encoded)), "tf_bev_prep_u8")
+    return out

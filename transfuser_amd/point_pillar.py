@@ -23,6 +23,7 @@ class DynamicPointNet(nn.Module):
         self.net = nn.Sequential(*L)
 
 
+@F_.routes_param_grads
 class PillarFn(torch.autograd.Function):
     """points (B, Nmax, 4) + num_points -> NHWC (B, nx, ny, C [+ extra channels]) = rot90(PointPillarNet(points), -1) ++ extra."""
 
@@ -59,6 +60,7 @@ class PillarFn(torch.autograd.Function):
         return (None,) * (4 + len(ctx.needs_input_grad) - 4)
 
 
+@F_.routes_param_grads
 class PillarStemFn(torch.autograd.Function):
     """LiDAR stem (conv3x3/s2 without bias + BatchNormAct2d, transfuser.py:140-143) on the NHWC pillar canvas; unlike StemFn the
     input carries a gradient (into the point net)."""

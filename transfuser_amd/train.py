@@ -23,6 +23,7 @@ import torch
 import torch.distributed as dist
 
 from . import ops
+from . import functions as _F
 
 _ALIGN = 64  # floats (256 B): keeps every parameter 16-byte aligned for float4 / buffer loads
 
@@ -333,6 +334,14 @@ class Engine:
         return len(self.cuts) + 1
 
     def _piece0(self, data):
+        with _F.inplace_param_grads():
+            return self._piece0_impl(data)
+
+    def _piece(self, i):
+        with _F.inplace_param_grads():
+            return self._piece_impl(i)
+
+    def _piece0_impl(self, data):
         self.optimizer.zero_grad()
         losses = self.load_data_compute_loss(data)
         loss = None
@@ -344,7 +353,7 @@ class Engine:
         assert len(self._pending) == len(self.cuts), "backbone recorded %d boundaries for %d cuts" % (len(self._pending), len(self.cuts))
         return loss.detach(), {k: v.detach() for k, v in losses.items()}
 
-    def _piece(self, i):
+    def _piece_impl(self, i):
         outs, leaves = self._pending[len(self._pending) - i]        # boundaries were recorded in forward order; backward walks them in reverse
         torch.autograd.backward(list(outs), [l.grad for l in leaves])
         if i == len(self._pending):
@@ -450,3 +459,220 @@ class Engine:
         if self.reducer.world == 1 or dist.get_rank(self.reducer.group) == 0:
             torch.save(self.model.state_dict(), "%s/model_%d.pth" % (path_prefix, epoch))
             torch.save({k: (v.cpu() if torch.is_tensor(v) else v) for k, v in osd.items()}, "%s/optimizer_%d.pth" % (path_prefix, epoch))
+
+
+# ================================================================================================ command line (train.py:27-211, 295-384)
+def seed_worker(worker_id):
+    """train.py:386-391."""
+    import random
+    import numpy as np
+    worker_seed = torch.initial_seed() % 2 ** 32
+    np.random.seed(worker_seed)
+    random.seed(worker_seed)
+
+
+class Trainer:
+    """The reference's epoch-level ``Engine`` (train.py:213-384) around the step ``Engine`` above: ``train()`` one epoch over the loader
+    (H2D, step, running sums), ``validate()`` (eval mode, inference_mode, same weighted sums), ``log_losses`` (averages gathered on
+    rank 0 with ``gather_object``; TensorBoard scalars when tensorboard is importable, always ``losses.jsonl``), ``save`` (model_%d.pth +
+    optimizer_%d.pth, DDP's ``module.`` key prefix under parallel training for checkpoint interchange with the reference agent)."""
+
+    def __init__(self, step_engine, dataloader_train, dataloader_val, args, config, device, rank=0, world_size=1, parallel=False, cur_epoch=0):
+        self.eng, self.dataloader_train, self.dataloader_val = step_engine, dataloader_train, dataloader_val
+        self.args, self.config, self.device, self.rank, self.world_size, self.parallel = args, config, device, rank, world_size, parallel
+        self.cur_epoch = cur_epoch
+        self.detailed_losses = config.detailed_losses
+        self.writer = None
+        if rank == 0:
+            try:
+                from torch.utils.tensorboard import SummaryWriter
+                self.writer = SummaryWriter(log_dir=args.logdir)
+            except Exception:   # tensorboard is optional here; the JSONL log below always exists
+                self.writer = None
+
+    def _to_device(self, data):
+        """train.py:246-271: H2D + dtype casts of one collated batch."""
+        f32 = ("rgb", "lidar", "ego_waypoint", "target_point", "target_point_image", "ego_vel", "label", "depth")
+        i64 = ("bev", "semantic", "bev_points", "cam_points")
+        out = {}
+        for k, v in data.items():
+            if k in f32:
+                out[k] = v.to(self.device, dtype=torch.float32, non_blocking=True)
+            elif k in i64:
+                out[k] = v.to(self.device, dtype=torch.long, non_blocking=True)
+            elif k == "num_points":
+                out[k] = v.to(self.device, dtype=torch.int32, non_blocking=True)
+        return out
+
+    def train(self):
+        self.eng.model.train()
+        num_batches, loss_epoch = 0, torch.zeros((), device=self.device)
+        detailed = {k: torch.zeros((), device=self.device) for k in self.detailed_losses}
+        for data in self.dataloader_train:
+            tot, det = self.eng.train_step(self._to_device(data))
+            loss_epoch += tot                                   # device-side accumulation: no .item() sync per step (train.py:312-314 syncs 12x)
+            for k, v in det.items():
+                detailed[k] += self.eng.detailed_weights[k] * v
+            num_batches += 1
+        self.log_losses(float(loss_epoch), {k: float(v) for k, v in detailed.items()}, max(num_batches, 1), '')
+        self.cur_epoch += 1
+
+    @torch.inference_mode()
+    def validate(self):
+        self.eng.model.eval()
+        num_batches, loss_epoch = 0, 0.0
+        detailed = {k: 0.0 for k in self.detailed_losses}
+        for data in self.dataloader_val:
+            losses = self.eng.load_data_compute_loss(self._to_device(data))
+            for k, v in losses.items():
+                val = self.eng.detailed_weights[k] * float(v)
+                detailed[k] += val
+                loss_epoch += val
+            num_batches += 1
+        self.log_losses(loss_epoch, detailed, max(num_batches, 1), 'val_')
+        self.eng.model.train()
+
+    def log_losses(self, loss_epoch, detailed_losses_epoch, num_batches, prefix=''):
+        import json
+        loss_epoch = loss_epoch / num_batches
+        detailed = {k: v / num_batches for k, v in detailed_losses_epoch.items()}
+        gathered_detailed, gathered_loss = [None] * self.world_size, [None] * self.world_size
+        if self.parallel and self.world_size > 1:
+            dist.gather_object(detailed, gathered_detailed if self.rank == 0 else None, dst=0)
+            dist.gather_object(loss_epoch, gathered_loss if self.rank == 0 else None, dst=0)
+        else:
+            gathered_detailed[0], gathered_loss[0] = detailed, loss_epoch
+        if self.rank == 0:
+            rec = {prefix + "loss_total": sum(gathered_loss) / len(gathered_loss)}
+            for k in detailed:
+                rec[prefix + k] = sum(g[k] for g in gathered_detailed) / self.world_size
+            if self.writer is not None:
+                for k, v in rec.items():
+                    self.writer.add_scalar(k, v, self.cur_epoch)
+            with open(os.path.join(self.args.logdir, "losses.jsonl"), "a") as f:
+                f.write(json.dumps(dict(epoch=self.cur_epoch, **rec)) + "\n")
+            print("epoch %d %s" % (self.cur_epoch, " ".join("%s=%.4f" % kv for kv in rec.items())), flush=True)
+
+    def save(self):
+        """train.py:204-210,381-384."""
+        osd = self.eng.optimizer.state_dict(self.eng.reducer.group)         # collective under ZeRO (consolidate_state_dict)
+        if self.rank == 0:
+            sd = self.eng.model.state_dict()
+            if self.parallel:   # the reference saves the DDP-wrapped module: keys carry 'module.' (submission_agent.py:94-96 strips it)
+                sd = {"module." + k: v for k, v in sd.items()}
+            torch.save(sd, os.path.join(self.args.logdir, 'model_%d.pth' % self.cur_epoch))
+            torch.save({k: (v.cpu() if torch.is_tensor(v) else v) for k, v in osd.items()}, os.path.join(self.args.logdir, 'optimizer_%d.pth' % self.cur_epoch))
+
+
+def build_parser():
+    import argparse
+    p = argparse.ArgumentParser(description="MI355X-native TransFuser training (flags of team_code_transfuser/train.py:30-70)")
+    p.add_argument('--id', type=str, default='transfuser')
+    p.add_argument('--epochs', type=int, default=41)
+    p.add_argument('--lr', type=float, default=1e-4)
+    p.add_argument('--batch_size', type=int, default=12, help='per GPU; effective batch = batch_size * num_gpus (the lr is NOT scaled, as in the reference)')
+    p.add_argument('--logdir', type=str, default='log')
+    p.add_argument('--load_file', type=str, default=None)
+    p.add_argument('--start_epoch', type=int, default=0)
+    p.add_argument('--setting', type=str, default='all')
+    p.add_argument('--root_dir', type=str, default='synthetic:64', help="dataset root in the reference's on-disk format, or 'synthetic:N' (N seeded samples of the dataset's shapes)")
+    p.add_argument('--schedule', type=int, default=1)
+    p.add_argument('--schedule_reduce_epoch_01', type=int, default=30)
+    p.add_argument('--schedule_reduce_epoch_02', type=int, default=40)
+    p.add_argument('--backbone', type=str, default='transFuser')
+    p.add_argument('--image_architecture', type=str, default='regnety_032')
+    p.add_argument('--lidar_architecture', type=str, default='regnety_032')
+    p.add_argument('--use_velocity', type=int, default=0)
+    p.add_argument('--n_layer', type=int, default=4)
+    p.add_argument('--wp_only', type=int, default=0)
+    p.add_argument('--use_target_point_image', type=int, default=1)
+    p.add_argument('--use_point_pillars', type=int, default=0)
+    p.add_argument('--parallel_training', type=int, default=1, help='1: launched by torchrun (RANK / LOCAL_RANK / WORLD_SIZE in the environment); 0: single process')
+    p.add_argument('--val_every', type=int, default=5)
+    p.add_argument('--no_bev_loss', type=int, default=0)
+    p.add_argument('--sync_batch_norm', type=int, default=0)
+    p.add_argument('--zero_redundancy_optimizer', type=int, default=0)
+    p.add_argument('--use_disk_cache', type=int, default=0, help='accepted for command-line compatibility; the synthetic / GPU-prepared loaders do not need it')
+    # additions of this framework
+    p.add_argument('--use_graph', type=int, default=1, help='capture the step into hipGraphs (falls back to eager where a flag requires it)')
+    p.add_argument('--precision', type=str, default='fp32', choices=['fp32', 'bf16'])
+    p.add_argument('--height', type=int, default=160, help="RGB height of the synthetic samples (the dataset's crop is 160 x 704)")
+    p.add_argument('--num_workers', type=int, default=None)
+    p.add_argument('--width', type=int, default=704)
+    return p
+
+
+def main(argv=None):
+    import datetime
+    import json
+    from torch.utils.data import DataLoader
+    from .config import GlobalConfig
+    from .data import make_datasets
+    from .model import LidarCenterNet
+    args = build_parser().parse_args(argv)
+    args.logdir = os.path.join(args.logdir, args.id)
+    parallel = bool(args.parallel_training) and "RANK" in os.environ
+    cuda = torch.cuda.is_available()
+    if parallel:   # train.py:94-106
+        rank, local_rank, world_size = int(os.environ["RANK"]), int(os.environ["LOCAL_RANK"]), int(os.environ["WORLD_SIZE"])
+        if cuda:
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend='nccl' if cuda else 'gloo', init_method='env://', world_size=world_size, rank=rank, timeout=datetime.timedelta(minutes=15))
+        dist.barrier()
+    else:
+        rank, local_rank, world_size = 0, 0, 1
+    device = torch.device('cuda:%d' % local_rank) if cuda else torch.device('cpu')
+    config = GlobalConfig(root_dir=args.root_dir if os.path.isdir(args.root_dir) else '', setting=args.setting)   # train.py:113-121
+    config.use_target_point_image = bool(args.use_target_point_image)
+    config.n_layer = args.n_layer
+    config.use_point_pillars = bool(args.use_point_pillars)
+    config.backbone = args.backbone
+    if bool(args.no_bev_loss):
+        config.detailed_losses_weights[config.detailed_losses.index("loss_bev")] = 0.0
+    model = LidarCenterNet(config, device, args.backbone, args.image_architecture, args.lidar_architecture, bool(args.use_velocity)).to(device)
+    print('Total trainable parameters: ', sum(p.numel() for p in model.parameters() if p.requires_grad))
+    if args.load_file is not None:      # train.py:180-183 (accepts checkpoints with or without DDP's 'module.' prefix)
+        model.load_reference_checkpoint(args.load_file) if hasattr(model, "load_reference_checkpoint") else model.load_state_dict(torch.load(args.load_file, map_location=device))
+    eng = Engine(model, config, lr=args.lr, use_graph=bool(args.use_graph) and cuda, wp_only=bool(args.wp_only),
+                 zero_redundancy_optimizer=bool(args.zero_redundancy_optimizer), sync_batch_norm=bool(args.sync_batch_norm), precision=args.precision if cuda else None)
+    if args.load_file is not None and os.path.exists(args.load_file.replace("model_", "optimizer_")):
+        eng.optimizer.load_state_dict(torch.load(args.load_file.replace("model_", "optimizer_"), map_location=device))
+    train_set, val_set = make_datasets(args.root_dir, config, height=args.height, width=args.width)
+    g = torch.Generator(device='cpu')
+    g.manual_seed(torch.initial_seed())
+    nw = args.num_workers if args.num_workers is not None else (8 if parallel else 0)
+    if parallel:    # train.py:156-161
+        sampler_train = torch.utils.data.distributed.DistributedSampler(train_set, shuffle=True, num_replicas=world_size, rank=rank)
+        sampler_val = torch.utils.data.distributed.DistributedSampler(val_set, shuffle=True, num_replicas=world_size, rank=rank)
+        dl_train = DataLoader(train_set, sampler=sampler_train, batch_size=args.batch_size, worker_init_fn=seed_worker, generator=g, num_workers=nw, pin_memory=cuda, drop_last=bool(args.use_graph))
+        dl_val = DataLoader(val_set, sampler=sampler_val, batch_size=args.batch_size, worker_init_fn=seed_worker, generator=g, num_workers=nw, pin_memory=cuda)
+    else:
+        sampler_train = None
+        dl_train = DataLoader(train_set, shuffle=True, batch_size=args.batch_size, worker_init_fn=seed_worker, generator=g, num_workers=nw, pin_memory=cuda, drop_last=bool(args.use_graph))
+        dl_val = DataLoader(val_set, shuffle=True, batch_size=args.batch_size, worker_init_fn=seed_worker, generator=g, num_workers=nw, pin_memory=cuda)
+    if rank == 0:
+        os.makedirs(args.logdir, exist_ok=True)
+        with open(os.path.join(args.logdir, 'args.txt'), 'w') as f:      # train.py:172-175 (the agent reads it back, submission_agent.py:41-60)
+            json.dump(args.__dict__, f, indent=2)
+    if parallel:
+        dist.barrier()
+    trainer = Trainer(eng, dl_train, dl_val, args, config, device, rank, world_size, parallel, cur_epoch=args.start_epoch)
+    lr = args.lr
+    for epoch in range(trainer.cur_epoch, args.epochs):
+        if parallel:
+            sampler_train.set_epoch(epoch)        # train.py:191-193
+        if epoch in (args.schedule_reduce_epoch_01, args.schedule_reduce_epoch_02) and args.schedule == 1:      # train.py:194-199
+            lr *= 0.1
+            print("Reduce learning rate by factor 10 to:", lr)
+            eng.optimizer.set_lr(lr)
+        trainer.train()
+        if args.setting != 'all' and epoch % args.val_every == 0:
+            trainer.validate()
+        trainer.save()                            # every rank: the ZeRO state is gathered collectively, rank 0 writes
+    if parallel:
+        dist.destroy_process_group()
+    return trainer
+
+
+if __name__ == "__main__":
+    main()

@@ -123,8 +123,18 @@ class GPT(nn.Module):
 class _Stem:
     """First conv + BN of a trunk as StemFn sees them (the modules stay registered under the reference's names)."""
 
-    def __init__(self, conv, bn, normalize):
-        self.conv, self.bn, self.normalize = conv, bn, normalize
+    def __init__(self, conv, bn, normalize, owner=None, names=None):
+        """``owner`` / ``names`` = (module, (conv attribute, bn attribute)): when given the two layers are looked up at every call, so a
+        BatchNorm replaced after construction (torch.nn.SyncBatchNorm.convert_sync_batchnorm, train.py:133) is picked up."""
+        self._conv, self._bn, self.normalize, self._owner, self._names = conv, bn, normalize, owner, names
+
+    @property
+    def conv(self):
+        return getattr(self._owner, self._names[0]) if self._owner is not None else self._conv
+
+    @property
+    def bn(self):
+        return getattr(self._owner, self._names[1]) if self._owner is not None else self._bn
 
     def __call__(self, s0, s1=None):
         return F_.StemFn.apply(s0, s1, self, self.conv.weight, self.bn.weight, self.bn.bias)
@@ -192,8 +202,8 @@ class _FusionBackbone(nn.Module):
         self.up_conv4 = nn.Conv2d(channel, channel, (1, 1))
         self.up_conv3 = nn.Conv2d(channel, channel, (1, 1))
         self.c5_conv = nn.Conv2d(pf, channel, (1, 1))
-        self._img_stem = _Stem(self.image_encoder.features.conv1, self.image_encoder.features.bn1, True)
-        self._lid_stem = _Stem(self.lidar_encoder._model.conv1, self.lidar_encoder._model.bn1, False)
+        self._img_stem = _Stem(None, None, True, self.image_encoder.features, ("conv1", "bn1"))
+        self._lid_stem = _Stem(None, None, False, self.lidar_encoder._model, ("conv1", "bn1"))
 
     def _side_stream(self, device):
         st = getattr(self, "_side", None)
@@ -339,8 +349,8 @@ class LateFusionBackbone(_FusionBackbone):
         self.up_conv3 = nn.Conv2d(channel, channel, (1, 1))
         self.c5_conv = nn.Conv2d(pf, channel, (1, 1))
         im, li = self.image_encoder.features, self.lidar_encoder._model
-        self._img_stem = _Stem(im.stem.conv, im.stem.bn, True)
-        self._lid_stem = _Stem(li.stem.conv, li.stem.bn, False)
+        self._img_stem = _Stem(None, None, True, im.stem, ("conv", "bn"))
+        self._lid_stem = _Stem(None, None, False, li.stem, ("conv", "bn"))
 
     def forward_nhwc(self, image, lidar, velocity, lidar_extra=None, lidar_nhwc=None):
         feats, grid, fused = self._run(image, lidar, lidar_extra, lambda i, x, y: (x, y), lidar_nhwc)
