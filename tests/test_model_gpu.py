@@ -180,7 +180,7 @@ def test_engine_graph_replay_matches_eager(dropout):
     rel = ((outs[0] - outs[1]).abs() / outs[0].abs().clamp_min(1e-3)).max().item()
     print("  graph vs eager: max relative loss difference over 5 steps x 12 values: %.2e; params max abs diff %.2e, mean %.2e" %
           (rel, (params[0] - params[1]).abs().max().item(), (params[0] - params[1]).abs().mean().item()))
-    assert rel <= 2e-4, (rel, outs[0][:, 0], outs[1][:, 0])
+    assert rel <= (2e-4 if dropout == 0 else 5e-3), (rel, outs[0][:, 0], outs[1][:, 0])      # a stray update shifts the sequence by ~2 % per step
     # with dropout more weight-gradient entries sit at round-off level (sign flips move them by 2 lr each): measured mean 1.6e-5 at p = 0.1; a
     # stray optimizer update would move EVERY weight by ~lr = 1e-3
     assert (params[0] - params[1]).abs().mean().item() <= (2e-6 if dropout == 0 else 1e-4) and (rmean[0] - rmean[1]).abs().max().item() <= 1e-4
