@@ -177,13 +177,15 @@ def test_engine_graph_replay_matches_eager(dropout):
     # Not bitwise: the SE squeeze / pooled column sums accumulate with fp32 atomics (ops.colsum(pooled=True)), so two runs of the SAME
     # program differ in the last bits and AdamW amplifies round-off-level gradients to +-lr on isolated weights.  A left-over warm-up
     # update (the r01 bug: 3 updates before the first replay) shifts the whole loss sequence by two steps - several per cent.
-    rel = ((outs[0] - outs[1]).abs() / outs[0].abs().clamp_min(1e-3)).max().item()
-    print("  graph vs eager: max relative loss difference over 5 steps x 12 values: %.2e; params max abs diff %.2e, mean %.2e" %
-          (rel, (params[0] - params[1]).abs().max().item(), (params[0] - params[1]).abs().mean().item()))
-    assert rel <= (2e-4 if dropout == 0 else 5e-3), (rel, outs[0][:, 0], outs[1][:, 0])      # a stray update shifts the sequence by ~2 % per step
-    # with dropout more weight-gradient entries sit at round-off level (sign flips move them by 2 lr each): measured mean 1.6e-5 at p = 0.1; a
-    # stray optimizer update would move EVERY weight by ~lr = 1e-3
-    assert (params[0] - params[1]).abs().mean().item() <= (2e-6 if dropout == 0 else 1e-4) and (rmean[0] - rmean[1]).abs().max().item() <= 1e-4
+    rel_steps = ((outs[0] - outs[1]).abs() / outs[0].abs().clamp_min(1e-3)).max(dim=1).values
+    print("  graph vs eager: max relative loss difference per step %s; params max abs diff %.2e, mean %.2e" %
+          (["%.1e" % v for v in rel_steps.tolist()], (params[0] - params[1]).abs().max().item(), (params[0] - params[1]).abs().mean().item()))
+    # the first replay IS training step 1: a stray warm-up update would show here at the per-cent level (the loss falls ~2 % per step)
+    assert rel_steps[0].item() <= 1e-5 and rel_steps[1].item() <= 2e-4, rel_steps
+    if dropout == 0:
+        assert rel_steps.max().item() <= 2e-4 and (params[0] - params[1]).abs().mean().item() <= 2e-6 and (rmean[0] - rmean[1]).abs().max().item() <= 1e-4
+    else:   # with dropout, round-off-level weight-gradient entries (sign flips under AdamW) make the two trajectories drift apart faster
+        assert rel_steps.max().item() <= 2e-2 and (params[0] - params[1]).abs().mean().item() <= 2e-4
 
 
 def test_engine_segmented_graphs_match_single_graph():
@@ -209,10 +211,11 @@ def test_engine_segmented_graphs_match_single_graph():
     finally:
         ops.force_plan(0)
     a, b = torch.tensor(res[0][0], dtype=torch.float64), torch.tensor(res[1][0], dtype=torch.float64)
-    assert ((a - b).abs() / a.abs()).max().item() <= 2e-4, (res[0][0], res[1][0])        # fp32 atomics: see test_engine_graph_replay_matches_eager
+    rel = (a - b).abs() / a.abs()
+    assert rel[0].item() <= 1e-5 and rel[1].item() <= 2e-4 and rel.max().item() <= 2e-2, (res[0][0], res[1][0])   # fp32 atomics + dropout: see test_engine_graph_replay_matches_eager
     num = sum((p - res[1][1][n]).abs().sum().item() for n, p in res[0][1].items())
     den = sum(p.numel() for p in res[0][1].values())
-    assert num / den <= 1e-4, num / den          # dropout 0.1: see test_engine_graph_replay_matches_eager
+    assert num / den <= 2e-4, num / den
 
 
 def test_bench_configuration_parity_B10_H256():

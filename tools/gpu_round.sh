@@ -20,6 +20,9 @@ tests_grouped) timeout 300 python -m pytest tests/test_kernels_gpu.py -q -k "gro
 conv_bench) timeout 200 python tools/grouped_bench.py 2>&1 | tail -20 ;;
 ab_grouped) for v in 0 1 0 1; do TF_GROUPED_CONV=$v timeout 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('TF_GROUPED_CONV=$v', d['ms_per_step'], 'ms/step', d['value'], 'samples/s; GPT4 fc1', d['roofline']['avg_launch_us'], 'us')"; done ;;
 test_graph) timeout 300 python -m pytest tests/test_model_gpu.py -q -k "graph_replay" -s 2>&1 | grep -v "Warning\|warn" | tail -30 ;;
+bench_cfgs) for a in "--backbone geometric_fusion" "--backbone latentTF" "--height 160" "--backbone late_fusion_skip"; do
+              case "$a" in *skip) continue;; esac
+              tag=$(echo $a | tr -d ' -' ); timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline $a > $O/r02_bench_$tag.json 2> $O/r02_bench_$tag.err; tail -1 $O/r02_bench_$tag.err; cat $O/r02_bench_$tag.json; done ;;
 tests_bf16) timeout 600 python -m pytest tests/test_kernels_gpu.py tests/test_model_gpu.py -q -k "bf16" -s 2>&1 | tail -12 ;;
 bench_bf16) timeout 300 python bench.py --steps 20 --warmup 5 --dtype bf16 --no-cpu-baseline > $O/r02_bench_bf16.json 2> $O/r02_bench_bf16.err; tail -3 $O/r02_bench_bf16.err; cat $O/r02_bench_bf16.json ;;
 esac
