@@ -180,6 +180,7 @@ class StemFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dz):
         s0, s1, stem, w, y, z, st = ctx.saved
+        ctx.saved = None        # z is also this node's output: drop the ctx <-> output cycle now instead of waiting for the cyclic GC (~150 MB / step)
         dy, _ = _bn_bwd(dz.contiguous(), z, y, stem.bn, st)
         ops.stem_conv_wgrad(dy, s0, s1, gbuf(w), stem.normalize)
         return (None,) * 6
