@@ -788,3 +788,29 @@ def check_conv_grouped(dev, B, H, W, C):
         ops.conv_wgrad(dyh, xh, dw2, 1, None, groups)
         close(dw2, gw, what="ops.conv_wgrad -> grouped")
         close(ops.conv_dgrad(dyh, wh, xh.shape, 1, None, groups).permute(0, 3, 1, 2), gx, what="ops.conv_dgrad -> grouped")
+
+
+def check_bf16_direct(dev):
+    """The LDS-tiled direct convolutions (decoder tails, RegNetY grouped 3x3) in bf16-MFMA mode: == fp32 convolution of bf16-rounded operands."""
+    old = ops._DIRECT_MIN_PIXELS
+    ops._DIRECT_MIN_PIXELS = 0
+    ops.set_precision("bf16")
+    try:
+        for (B, H, W, Cin, Cout, groups) in ((2, 10, 70, 32, 32, 1), (1, 9, 33, 32, 7, 1), (1, 12, 64, 8, 32, 1), (2, 16, 44, 72, 72, 3), (1, 9, 13, 48, 48, 2)):
+            x = R(B, Cin, H, W, dev="cpu").requires_grad_(True)
+            w = (R(Cout, Cin // groups, 3, 3, dev="cpu") * 0.1).requires_grad_(True)
+            dy = R(B, Cout, H, W, seed=1, dev="cpu")
+            y = F.conv2d(_bf(x), _bf(w), None, 1, 1, 1, groups)
+            gx = torch.autograd.grad(F.conv2d(x, _bf(w), None, 1, 1, 1, groups), x, _bf(dy))[0]
+            gw = torch.autograd.grad(F.conv2d(_bf(x), w, None, 1, 1, 1, groups), w, _bf(dy))[0]
+            xh, wh = x.detach().permute(0, 2, 3, 1).contiguous().to(dev), cl(w.detach()).to(dev)
+            dyh = dy.permute(0, 2, 3, 1).contiguous().to(dev)
+            assert ops._direct_ok(xh.shape, Cout, Cin, 3, 1, 1, groups) or ops._grouped_ok(xh.shape, Cout, Cin, 3, 1, 1, groups)
+            close(ops.conv_fwd(xh, wh, None, 1, None, groups).permute(0, 3, 1, 2), y, tol=1e-4, what="bf16 direct fwd")
+            close(ops.conv_dgrad(dyh, wh, xh.shape, 1, None, groups).permute(0, 3, 1, 2), gx, tol=1e-4, what="bf16 direct dgrad")
+            dw = torch.zeros_like(wh)
+            ops.conv_wgrad(dyh, xh, dw, 1, None, groups)
+            close(dw, gw, tol=1e-4, what="bf16 direct wgrad")
+    finally:
+        ops.set_precision("fp32")
+        ops._DIRECT_MIN_PIXELS = old

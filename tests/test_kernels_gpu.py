@@ -116,6 +116,10 @@ def test_grouped_conv_direct(case):
     kc.check_conv_grouped("cuda", *case)
 
 
+def test_bf16_mfma_mode_direct_convs():
+    kc.check_bf16_direct("cuda")
+
+
 @pytest.mark.parametrize("case", kc.GATHER_CASES, ids=str)
 def test_gather_sum(case):
     kc.check_gather_sum("cuda", *case)

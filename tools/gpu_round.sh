@@ -12,13 +12,14 @@ bench)      timeout 420 python bench.py --steps 20 --warmup 5 > $O/r02_bench_n1.
 bench_fast) timeout 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/r02_bench_fast.json 2> $O/r02_bench_fast.err; tail -2 $O/r02_bench_fast.err; cat $O/r02_bench_fast.json ;;
 pmc)        timeout 600 bash tools/pmc_roofline.sh 2>&1 | tail -20 ;;
 hbm)        timeout 200 python tools/hbm_bench.py > $O/r02_hbm_kernels.txt 2>&1; cat $O/r02_hbm_kernels.txt ;;
-trace)      (cd /tmp && export TMPDIR=/tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $O/trace_r02 -o step --output-format csv -- python $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline > $O/r02_trace_bench.log 2>&1)
-            python tools/trace_csv_stats.py $O/trace_r02 > $O/r02_kernel_trace_graph.txt 2>&1; head -60 $O/r02_kernel_trace_graph.txt
+trace)      (cd /tmp && export TMPDIR=/tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $O/trace_r02 -o step --output-format csv -- python $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline $BENCH_ARGS > $O/r02_trace_bench.log 2>&1)
+            python tools/trace_csv_stats.py $O/trace_r02 > $O/r02_kernel_trace_graph${TRACE_TAG}.txt 2>&1; head -45 $O/r02_kernel_trace_graph${TRACE_TAG}.txt
             cp $O/trace_r02/*kernel_stats.csv $O/r02_kernel_stats.csv 2>/dev/null; rm -rf $O/trace_r02 ;;
 tune)       timeout 400 python tools/tune.py $O/mi355x_r02.txt 10 256,160 fp32,bf16 2>&1 | tail -6; cp $O/mi355x_r02.txt transfuser_amd/plans/mi355x.txt ;;
 tests_grouped) timeout 300 python -m pytest tests/test_kernels_gpu.py -q -k "grouped_conv or bench_shape_convs" 2>&1 | tail -5 ;;
 conv_bench) timeout 200 python tools/grouped_bench.py 2>&1 | tail -20 ;;
 ab_grouped) for v in 0 1 0 1; do TF_GROUPED_CONV=$v timeout 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('TF_GROUPED_CONV=$v', d['ms_per_step'], 'ms/step', d['value'], 'samples/s; GPT4 fc1', d['roofline']['avg_launch_us'], 'us')"; done ;;
+ab_bf16)    for v in "1 1" "0 1" "1 0" "0 0"; do set -- $v; TF_GROUPED_CONV=$1 TF_DIRECT_CONV=$2 timeout 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --dtype bf16 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('bf16 TF_GROUPED_CONV=$1 TF_DIRECT_CONV=$2', d['ms_per_step'], 'ms/step', d['value'], 'samples/s')"; done ;;
 test_graph) timeout 300 python -m pytest tests/test_model_gpu.py -q -k "graph_replay" -s 2>&1 | grep -v "Warning\|warn" | tail -30 ;;
 bench_cfgs) for a in "--backbone geometric_fusion" "--backbone latentTF" "--height 160" "--backbone late_fusion_skip"; do
               case "$a" in *skip) continue;; esac

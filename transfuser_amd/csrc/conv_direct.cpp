@@ -10,6 +10,7 @@
 #include "../../include/transfuser_hip.h"
 
 using namespace tf;
+namespace tf { int gemm_precision(); }   // api.cpp (tf_set_precision): 1 = bf16-MFMA contractions
 
 namespace {
 
@@ -52,7 +53,7 @@ __device__ __forceinline__ void store_patch_slot(float* patch, int s, const floa
 }
 
 // y = conv3x3(x, W) (+bias) (relu) (+= when accumulate).  dgrad != 0: x is dY (Ci = W's Cout), y is dX (Co = W's Cin).
-template <bool VEC>
+template <bool VEC, bool BF16>
 __global__ void __launch_bounds__(256, 2) conv3x3_small_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                                float* __restrict__ y, DcGeom g, int CoW, int CiW, int dgrad, int relu, int accumulate) {
     __shared__ float patch[PH * PW * PP];
@@ -79,11 +80,27 @@ __global__ void __launch_bounds__(256, 2) conv3x3_small_kernel(const float* __re
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        if constexpr (BF16) {      // bf16 MFMA (tf_set_precision(1)): channels are zero-padded to 32 in both LDS tiles -> two 16-deep groups per tap
+            for (int tap = 0; tap < 9; ++tap) {
+                const int kh = tap / 3, kw = tap - kh * 3;
+                const float* pa = patch + ((wave + kh) * PW + l31 + kw) * PP;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    if (16 * q >= g.Ci) break;
+                    float a[8], b[8];
+                    const int k0 = 16 * q + 8 * hi;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { a[j] = pa[k0 + j]; b[j] = wl[tap * 32 + k0 + j][l31]; }
+                    mfma_32x32x16_bf16(a, b, acc);
+                }
+            }
+        } else {
         for (int tap = 0; tap < 9; ++tap) {        // (explicit operand prefetch + scheduling fences measured slower here: 463 vs 366 us)
             const int kh = tap / 3, kw = tap - kh * 3;
             const float* pa = patch + ((wave + kh) * PW + l31 + kw) * PP + hi;
             const float* pb = &wl[tap * 32 + hi][l31];
             for (int kk = 0; kk < kpairs; ++kk) mfma_32x32x2(pa[2 * kk], pb[2 * kk * WP], acc);
+        }
         }
         const int b = tile / (g.tiles_h * g.tiles_w), r = tile - b * (g.tiles_h * g.tiles_w);
         const int h = (r / g.tiles_w) * TH + wave, w0 = (r % g.tiles_w) * TW;
@@ -105,7 +122,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_small_kernel(const float* __re
 
 // dW[co][tap][ci] (+)= sum_pixels dY[p][co] * X[p + tap][ci]: per wave a row of 32 pixels as the K dimension, 9 accumulators (one per
 // tap, 32 co x 32 ci); blocks are persistent, their partial panels are summed by conv3x3_small_wgrad_reduce_kernel.
-template <bool VEC>
+template <bool VEC, bool BF16>
 __global__ void __launch_bounds__(256, 1) conv3x3_small_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part,
                                                                      DcGeom g) {
     __shared__ float patch[PH * PW * PP];
@@ -147,6 +164,21 @@ __global__ void __launch_bounds__(256, 1) conv3x3_small_wgrad_kernel(const float
         // the tap -> 9 independent accumulator chains per k step
         const float* pa = dyt + (wave * TW + hi) * PP + l31;
         const float* pb = patch + (wave * PW + hi) * PP + l31;
+        if constexpr (BF16) {      // bf16 MFMA: the row's 32 pixels = two 16-deep K groups; lane half hi owns pixels 16 q + 8 hi .. + 7
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                float a[8], b[9][8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int pi = 16 * q + 8 * hi + j;
+                    a[j] = dyt[(wave * TW + pi) * PP + l31];
+#pragma unroll
+                    for (int tap = 0; tap < 9; ++tap) b[tap][j] = patch[((wave + tap / 3) * PW + pi + tap % 3) * PP + l31];
+                }
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) mfma_32x32x16_bf16(a, b[tap], acc[tap]);
+            }
+        } else {
 #pragma unroll 2
         for (int kk = 0; kk < TW / 2; ++kk) {
             const float a = pa[2 * kk * PP];
@@ -155,6 +187,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_small_wgrad_kernel(const float
                 const int kh = tap / 3, kw = tap - kh * 3;
                 mfma_32x32x2(a, pb[((kh * PW + kw) + 2 * kk) * PP], acc[tap]);
             }
+        }
         }
     }
     // reduce the 4 waves through LDS (patch + dyt are free now), then one partial panel per block: part[block][tap][co][ci]
@@ -202,8 +235,11 @@ extern "C" int tf_conv3x3_small_fwd_f32(const float* x, const float* w, const fl
     TF_REQUIRE(x && w && y && B > 0 && H > 0 && W > 0 && Cin > 0 && Cin <= 32 && Cout > 0 && Cout <= 32, "tf_conv3x3_small_fwd_f32: needs Cin, Cout <= 32");
     DcGeom g = make_geom(B, H, W, Cin, Cout);
     const int grid = g.ntiles < 512 ? g.ntiles : 512;
-    if (Cin % 4 == 0 && aligned16(x)) TF_LAUNCH(conv3x3_small_kernel<true>, dim3(grid), dim3(256), stream, x, w, bias, y, g, Cout, Cin, 0, relu, 0);
-    else TF_LAUNCH(conv3x3_small_kernel<false>, dim3(grid), dim3(256), stream, x, w, bias, y, g, Cout, Cin, 0, relu, 0);
+    const bool vec = Cin % 4 == 0 && aligned16(x), lowp = tf::gemm_precision() != 0;
+    if (vec && !lowp) TF_LAUNCH((conv3x3_small_kernel<true, false>), dim3(grid), dim3(256), stream, x, w, bias, y, g, Cout, Cin, 0, relu, 0);
+    else if (!vec && !lowp) TF_LAUNCH((conv3x3_small_kernel<false, false>), dim3(grid), dim3(256), stream, x, w, bias, y, g, Cout, Cin, 0, relu, 0);
+    else if (vec) TF_LAUNCH((conv3x3_small_kernel<true, true>), dim3(grid), dim3(256), stream, x, w, bias, y, g, Cout, Cin, 0, relu, 0);
+    else TF_LAUNCH((conv3x3_small_kernel<false, true>), dim3(grid), dim3(256), stream, x, w, bias, y, g, Cout, Cin, 0, relu, 0);
     return launch_status("tf_conv3x3_small_fwd_f32");
 }
 
@@ -211,8 +247,12 @@ extern "C" int tf_conv3x3_small_dgrad_f32(const float* dy, const float* w, float
     TF_REQUIRE(dy && w && dx && B > 0 && H > 0 && W > 0 && Cin > 0 && Cin <= 32 && Cout > 0 && Cout <= 32, "tf_conv3x3_small_dgrad_f32: needs Cin, Cout <= 32");
     DcGeom g = make_geom(B, H, W, Cout, Cin);      // the "input" of this pass is dY (Cout channels), the output dX (Cin channels)
     const int grid = g.ntiles < 512 ? g.ntiles : 512;
-    if (Cout % 4 == 0 && aligned16(dy)) TF_LAUNCH(conv3x3_small_kernel<true>, dim3(grid), dim3(256), stream, dy, w, (const float*)nullptr, dx, g, Cout, Cin, 1, 0, accumulate);
-    else TF_LAUNCH(conv3x3_small_kernel<false>, dim3(grid), dim3(256), stream, dy, w, (const float*)nullptr, dx, g, Cout, Cin, 1, 0, accumulate);
+    const bool vec = Cout % 4 == 0 && aligned16(dy), lowp = tf::gemm_precision() != 0;
+    const float* nob = nullptr;
+    if (vec && !lowp) TF_LAUNCH((conv3x3_small_kernel<true, false>), dim3(grid), dim3(256), stream, dy, w, nob, dx, g, Cout, Cin, 1, 0, accumulate);
+    else if (!vec && !lowp) TF_LAUNCH((conv3x3_small_kernel<false, false>), dim3(grid), dim3(256), stream, dy, w, nob, dx, g, Cout, Cin, 1, 0, accumulate);
+    else if (vec) TF_LAUNCH((conv3x3_small_kernel<true, true>), dim3(grid), dim3(256), stream, dy, w, nob, dx, g, Cout, Cin, 1, 0, accumulate);
+    else TF_LAUNCH((conv3x3_small_kernel<false, true>), dim3(grid), dim3(256), stream, dy, w, nob, dx, g, Cout, Cin, 1, 0, accumulate);
     return launch_status("tf_conv3x3_small_dgrad_f32");
 }
 
@@ -224,8 +264,11 @@ extern "C" int tf_conv3x3_small_wgrad_f32(const float* dy, const float* x, float
                "tf_conv3x3_small_wgrad_f32: needs Cin, Cout <= 32 and ws of tf_conv3x3_small_wgrad_ws_floats() floats");
     DcGeom g = make_geom(B, H, W, Cin, Cout);
     const int grid = g.ntiles < 256 ? g.ntiles : 256;
-    if (Cin % 4 == 0 && aligned16(x)) TF_LAUNCH(conv3x3_small_wgrad_kernel<true>, dim3(grid), dim3(256), stream, x, dy, ws, g);
-    else TF_LAUNCH(conv3x3_small_wgrad_kernel<false>, dim3(grid), dim3(256), stream, x, dy, ws, g);
+    const bool vec = Cin % 4 == 0 && aligned16(x), lowp = tf::gemm_precision() != 0;
+    if (vec && !lowp) TF_LAUNCH((conv3x3_small_wgrad_kernel<true, false>), dim3(grid), dim3(256), stream, x, dy, ws, g);
+    else if (!vec && !lowp) TF_LAUNCH((conv3x3_small_wgrad_kernel<false, false>), dim3(grid), dim3(256), stream, x, dy, ws, g);
+    else if (vec) TF_LAUNCH((conv3x3_small_wgrad_kernel<true, true>), dim3(grid), dim3(256), stream, x, dy, ws, g);
+    else TF_LAUNCH((conv3x3_small_wgrad_kernel<false, true>), dim3(grid), dim3(256), stream, x, dy, ws, g);
     TF_LAUNCH(conv3x3_small_wgrad_reduce_kernel, dim3(36), dim3(256), stream, (const float*)ws, grid, dw, Cout, Cin, accumulate);
     return launch_status("tf_conv3x3_small_wgrad_f32");
 }

@@ -14,6 +14,7 @@
 #include "../../include/transfuser_hip.h"
 
 using namespace tf;
+namespace tf { int gemm_precision(); }   // api.cpp (tf_set_precision): 1 = bf16-MFMA contractions
 
 namespace {
 
@@ -62,7 +63,7 @@ __device__ __forceinline__ void store_patch_slot(float* patch, int s, const floa
 // y[.., g*24 + co] = sum_{tap, ci} x[.. + tap, g*24 + ci] * W  (+ bias) (relu) (+= when accumulate); dgrad != 0: x is dY, y is dX
 template <int TW>
 __global__ void __launch_bounds__(256, 2) conv3x3_grouped_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-                                                                 float* __restrict__ y, GcGeom g, int dgrad, int relu, int accumulate) {
+                                                                 float* __restrict__ y, GcGeom g, int dgrad, int relu, int accumulate, int prec) {
     typedef Tile<TW> T;
     __shared__ float patch[T::NPIX * PP];
     __shared__ float wl[9 * CG][WP];
@@ -90,6 +91,27 @@ __global__ void __launch_bounds__(256, 2) conv3x3_grouped_kernel(const float* __
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        if (prec) {
+            // bf16 MFMA (tf_set_precision(1)): per tap two 16-deep groups over the 24 (zero-padded to 32) input channels; lane half hi
+            // owns channels 16 q + 8 hi .. + 7, so the upper half of the second group is all zeros
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int kh = tap / 3, kw = tap - kh * 3;
+                const float* pa = patch + ((prow + kh) * T::PW + pcol + kw) * PP;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    float a[8], b[8];
+                    const bool live = (q == 0) || (hi == 0);
+                    const int k0 = 16 * q + 8 * hi;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        a[j] = live ? pa[k0 + j] : 0.f;
+                        b[j] = live ? wl[tap * CG + k0 + j][l31] : 0.f;
+                    }
+                    mfma_32x32x16_bf16(a, b, acc);
+                }
+            }
+        } else {
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int kh = tap / 3, kw = tap - kh * 3;
@@ -97,6 +119,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_grouped_kernel(const float* __
             const float* pb = &wl[tap * CG + hi][l31];
 #pragma unroll
             for (int kk = 0; kk < CG / 2; ++kk) mfma_32x32x2(pa[2 * kk], pb[2 * kk * WP], acc);
+        }
         }
         const int b = tile / (g.tiles_h * g.tiles_w), r = tile - b * (g.tiles_h * g.tiles_w);
         const int h0 = (r / g.tiles_w) * T::TH, w0 = (r % g.tiles_w) * TW;
@@ -119,7 +142,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_grouped_kernel(const float* __
 
 // dW[g*24 + co][tap][ci] (+)= sum_pixels dY[p][g*24 + co] * X[p + tap][g*24 + ci]: per wave 32 pixels as K, 9 accumulators (one per tap);
 // part[(grp * nb + sub)][tap][32][32] partial panels, summed by conv3x3_grouped_wgrad_reduce_kernel.
-template <int TW>
+template <int TW, bool BF16>
 __global__ void __launch_bounds__(256, 1) conv3x3_grouped_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part, GcGeom g) {
     typedef Tile<TW> T;
     __shared__ float lds[T::NPIX * PP + 128 * PP];
@@ -162,6 +185,22 @@ __global__ void __launch_bounds__(256, 1) conv3x3_grouped_wgrad_kernel(const flo
         __syncthreads();
         if (tile + g.nb < g.ntiles) fetch(tile + g.nb);
         // k = pixel 2 kk + hi of this wave's 32: A[i = co][k] = dyt (shared by the 9 taps), B[k][j = ci] = patch shifted by the tap
+        if constexpr (BF16) {      // bf16 MFMA: the wave's 32 pixels = two 16-deep K groups; lane half hi owns pixels 16 q + 8 hi .. + 7
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                float a[8], b[9][8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int pi = 16 * q + 8 * hi + j, prow = wave * T::RW + pi / TW, pcol = pi % TW;
+                    a[j] = (l31 < CG) ? dyt[(wave * 32 + pi) * PP + l31] : 0.f;
+                    const float* pb = patch + (prow * T::PW + pcol) * PP + (l31 < CG ? l31 : 0);
+#pragma unroll
+                    for (int tap = 0; tap < 9; ++tap) b[tap][j] = (l31 < CG) ? pb[((tap / 3) * T::PW + (tap % 3)) * PP] : 0.f;
+                }
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) mfma_32x32x16_bf16(a, b[tap], acc[tap]);
+            }
+        } else {
 #pragma unroll 2
         for (int kk = 0; kk < 16; ++kk) {
             const int pi = 2 * kk + hi, prow = wave * T::RW + pi / TW, pcol = pi % TW;
@@ -173,6 +212,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_grouped_wgrad_kernel(const flo
                 const float bv = (l31 < CG) ? pb[(kh * T::PW + kw) * PP] : 0.f;
                 mfma_32x32x2(a, bv, acc[tap]);
             }
+        }
         }
     }
     // reduce the 4 waves through LDS (all waves store their accumulator of one tap, then every thread sums 4 copies of 4 elements), then
@@ -233,8 +273,8 @@ extern "C" int tf_conv3x3_grouped_fwd_f32(const float* x, const float* w, const 
     TF_REQUIRE(args_ok(x, w, y, B, H, W, C), "tf_conv3x3_grouped_fwd_f32: needs NHWC tensors with C %% 24 == 0 (group width 24), 16-byte aligned");
     const int tw = pick_tw(H, W);
     GcGeom g = make_geom(B, H, W, C, tw);
-    if (tw == 16) TF_LAUNCH(conv3x3_grouped_kernel<16>, dim3(g.G * g.nb), dim3(256), stream, x, w, bias, y, g, 0, relu, 0);
-    else TF_LAUNCH(conv3x3_grouped_kernel<32>, dim3(g.G * g.nb), dim3(256), stream, x, w, bias, y, g, 0, relu, 0);
+    if (tw == 16) TF_LAUNCH(conv3x3_grouped_kernel<16>, dim3(g.G * g.nb), dim3(256), stream, x, w, bias, y, g, 0, relu, 0, tf::gemm_precision());
+    else TF_LAUNCH(conv3x3_grouped_kernel<32>, dim3(g.G * g.nb), dim3(256), stream, x, w, bias, y, g, 0, relu, 0, tf::gemm_precision());
     return launch_status("tf_conv3x3_grouped_fwd_f32");
 }
 
@@ -242,8 +282,8 @@ extern "C" int tf_conv3x3_grouped_dgrad_f32(const float* dy, const float* w, flo
     TF_REQUIRE(args_ok(dy, w, dx, B, H, W, C), "tf_conv3x3_grouped_dgrad_f32: needs NHWC tensors with C %% 24 == 0 (group width 24), 16-byte aligned");
     const int tw = pick_tw(H, W);
     GcGeom g = make_geom(B, H, W, C, tw);
-    if (tw == 16) TF_LAUNCH(conv3x3_grouped_kernel<16>, dim3(g.G * g.nb), dim3(256), stream, dy, w, (const float*)nullptr, dx, g, 1, 0, accumulate);
-    else TF_LAUNCH(conv3x3_grouped_kernel<32>, dim3(g.G * g.nb), dim3(256), stream, dy, w, (const float*)nullptr, dx, g, 1, 0, accumulate);
+    if (tw == 16) TF_LAUNCH(conv3x3_grouped_kernel<16>, dim3(g.G * g.nb), dim3(256), stream, dy, w, (const float*)nullptr, dx, g, 1, 0, accumulate, tf::gemm_precision());
+    else TF_LAUNCH(conv3x3_grouped_kernel<32>, dim3(g.G * g.nb), dim3(256), stream, dy, w, (const float*)nullptr, dx, g, 1, 0, accumulate, tf::gemm_precision());
     return launch_status("tf_conv3x3_grouped_dgrad_f32");
 }
 
@@ -256,8 +296,11 @@ extern "C" int tf_conv3x3_grouped_wgrad_f32(const float* dy, const float* x, flo
     GcGeom g = make_geom(B, H, W, C, tw, 256);
     if (g.nb > 1 && g.ntiles / g.nb < 6) { g.nb = g.ntiles / 6; if (g.nb < 1) g.nb = 1; }
     TF_REQUIRE((long)g.G * g.nb * 9216 <= tf_conv3x3_grouped_wgrad_ws_floats(), "tf_conv3x3_grouped_wgrad_f32: %d groups exceed the workspace", g.G);
-    if (tw == 16) TF_LAUNCH(conv3x3_grouped_wgrad_kernel<16>, dim3(g.G * g.nb), dim3(256), stream, x, dy, ws, g);
-    else TF_LAUNCH(conv3x3_grouped_wgrad_kernel<32>, dim3(g.G * g.nb), dim3(256), stream, x, dy, ws, g);
+    const bool lowp = tf::gemm_precision() != 0;
+    if (tw == 16 && !lowp) TF_LAUNCH((conv3x3_grouped_wgrad_kernel<16, false>), dim3(g.G * g.nb), dim3(256), stream, x, dy, ws, g);
+    else if (tw == 16) TF_LAUNCH((conv3x3_grouped_wgrad_kernel<16, true>), dim3(g.G * g.nb), dim3(256), stream, x, dy, ws, g);
+    else if (!lowp) TF_LAUNCH((conv3x3_grouped_wgrad_kernel<32, false>), dim3(g.G * g.nb), dim3(256), stream, x, dy, ws, g);
+    else TF_LAUNCH((conv3x3_grouped_wgrad_kernel<32, true>), dim3(g.G * g.nb), dim3(256), stream, x, dy, ws, g);
     TF_LAUNCH(conv3x3_grouped_wgrad_reduce_kernel, dim3(36, g.G), dim3(256), stream, (const float*)ws, g.nb, dw, accumulate);
     return launch_status("tf_conv3x3_grouped_wgrad_f32");
 }
