@@ -407,3 +407,61 @@ def test_train_cli_epochs_schedule_validate_save(tmp_path):
         assert os.path.exists(os.path.join(d, "model_%d.pth" % e)) and os.path.exists(os.path.join(d, "optimizer_%d.pth" % e))
     tr2 = train.main(argv[:-2] + ["--num_workers", "0", "--epochs", "3", "--start_epoch", "2", "--load_file", os.path.join(d, "model_2.pth")])
     assert tr2.cur_epoch == 3 and float(tr2.eng.optimizer.state[0]) == 12.0        # AdamW step counter continued from the checkpoint
+
+
+def test_engine_overlap_path_on_real_rccl_single_rank():
+    """The multi-GPU step on REAL RCCL with the one GPU this box has: a world-size-1 "nccl" process group, backward cut into 4 hipGraph pieces,
+    and the reducer forced to behave as on 2 ranks (all-reduce of every segment's arena range on the side stream between the graph replays,
+    x 1/2 scale, AdamW graph waiting for the side stream).  With one rank the all-reduce is the identity, so every gradient arrives halved -
+    and AdamW is invariant to a constant gradient scale (up to eps = 1e-8): the trajectory must match the plain single-GPU engine.  Also runs
+    SyncBatchNorm's collectives (all_gather / all_reduce of the statistics) on RCCL: identical to local BatchNorm at world size 1."""
+    import os
+    import torch.distributed as dist
+    from transfuser_amd import ops, functions as F_, transfuser as ptf
+    from transfuser_amd.train import Engine
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 300))
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1)
+        created = True
+    try:
+        cfg = mc.tiny_config(n_layer=2, lidar_res=128)
+        batch = {k: v.cuda() for k, v in mc.small_batch(2, 160, 352, 128, 40).items()}
+        res = []
+        ops.force_plan(64, 64, 16, 1)
+        try:
+            for fake_world in (1, 2):
+                ptf.GPT._site_base = 0
+                prod, _ = mc.build_pair(cfg, "regnety_tiny", "cuda")
+                prod.train()
+                eng = Engine(prod, cfg, lr=1e-3, use_graph=True, autotune=False, cuts=(3, 2, 1))
+                eng.reducer.world = fake_world
+                losses = [float(eng.train_step(batch)[0]) for _ in range(4)]
+                torch.cuda.synchronize()
+                res.append((losses, {n: p.detach().clone() for n, p in prod.named_parameters()}, eng.arena.grads.abs().sum().item()))
+        finally:
+            ops.force_plan(0)
+        a, b = torch.tensor(res[0][0], dtype=torch.float64), torch.tensor(res[1][0], dtype=torch.float64)
+        rel = (a - b).abs() / a.abs()
+        assert rel[0].item() <= 1e-5 and rel.max().item() <= 5e-3, (res[0][0], res[1][0])
+        assert abs(res[1][2] / res[0][2] - 0.5) < 0.02, (res[0][2], res[1][2])          # the arena really went through all-reduce + scale
+        num = sum((p - res[1][1][n]).abs().sum().item() for n, p in res[0][1].items())
+        den = sum(p.numel() for p in res[0][1].values())
+        assert num / den <= 1e-4, num / den
+        # SyncBatchNorm over RCCL (world size 1): same losses as local BatchNorm
+        ptf.GPT._site_base = 0
+        p1, _ = mc.build_pair(cfg, "regnety_tiny", "cuda")
+        p2, _ = mc.build_pair(cfg, "regnety_tiny", "cuda")
+        F_.convert_sync_batchnorm(p2)
+        p1.train(); p2.train()
+        call = lambda m: m(batch['rgb'], batch['lidar'], ego_waypoint=batch['ego_waypoint'], target_point=batch['target_point'],
+                           target_point_image=batch['target_point_image'], ego_vel=batch['ego_vel'].reshape(-1, 1), bev=batch['bev'], label=batch['label'],
+                           depth=batch['depth'], semantic=batch['semantic'])
+        l1, l2 = call(p1), call(p2)
+        sum(l2.values()).backward()
+        for k in l1:
+            assert abs(float(l1[k]) - float(l2[k])) <= 1e-4 * max(1.0, abs(float(l1[k]))), k
+    finally:
+        if created:
+            dist.destroy_process_group()
