@@ -42,8 +42,10 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: 10 transFuser, 12 geometric_fusion, 16 latentTF)")
     ap.add_argument("--height", type=int, default=None, help="RGB height (default 256; geometric_fusion only runs at 160)")
     ap.add_argument("--backbone", default="transFuser", choices=["transFuser", "geometric_fusion", "latentTF"])
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
-                    help="f32 = the reference's arithmetic (headline); bf16 = bf16-MFMA contractions with fp32 accumulate/storage/master weights (BASELINE configs[2])")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f32x3", "bf16"],
+                    help="f32 = exact fp32 MFMA, the reference's arithmetic (headline); f32x3 = the same fp32 data with every contraction as an exact "
+                         "3-way bf16 split on the bf16 MFMA (six partial products, fp32-accurate; priced against the bf16 peak / 6); "
+                         "bf16 = bf16-MFMA contractions with fp32 accumulate/storage/master weights (BASELINE configs[2])")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dropout", type=float, default=0.1)
@@ -214,8 +216,8 @@ def main():
     hist_fn = lambda pts: ops.lidar_hist(torch.from_numpy(pts).to(dev)[None])[0].cpu().numpy()
     batch = {k: v.to(dev) for k, v in synthetic_batch(B, H, W, seed=rank, hist_fn=hist_fn).items()}
     log("model + batch on device")
-    eng = Engine(model, cfg, lr=cfg.lr, use_graph=not args.no_graph, precision={"f32": "fp32", "bf16": "bf16"}[args.dtype])
-    peak = PEAK_BF16_MFMA_TF if args.dtype == "bf16" else PEAK_F32_MFMA_TF
+    eng = Engine(model, cfg, lr=cfg.lr, use_graph=not args.no_graph, precision={"f32": "fp32", "f32x3": "f32x3", "bf16": "bf16"}[args.dtype])
+    peak = {"f32": PEAK_F32_MFMA_TF, "f32x3": round(PEAK_BF16_MFMA_TF / 6, 1), "bf16": PEAK_BF16_MFMA_TF}[args.dtype]
     log("engine ready (arena %.1f M floats, %d backward piece(s))" % (eng.arena.numel / 1e6, eng.n_pieces()))
 
     def sync():
@@ -254,7 +256,8 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "%s LidarCenterNet (RegNetY-3.2GF x2, %.1f M params) full train step, B=%d/GPU, 3x%dx%d RGB + 3x256x256 BEV, "
                                    "%s, dropout %.2f, %s" % (names[backbone], nparam / 1e6, B, H, W,
-                                                             "fp32" if args.dtype == "f32" else "bf16 MFMA contractions (fp32 accumulate, fp32 activations / master weights / AdamW)", args.dropout,
+                                                             {"f32": "fp32", "f32x3": "fp32 storage/accumulate, contractions as exact bf16x3 splits on the bf16 MFMA (6 partial products, fp32-accurate)",
+                                                              "bf16": "bf16 MFMA contractions (fp32 accumulate, fp32 activations / master weights / AdamW)"}[args.dtype], args.dropout,
                                                                "hipGraph replay" if not args.no_graph else "eager"),
                        "global_batch": B * world, "parallelism": "dp%d" % world, "final_loss": round(loss, 4),
                        "grad_allreduce": ("RCCL, %d backward segments, bucket all-reduce overlapped on a side stream" % eng.n_pieces()) if world > 1 else "none (1 rank)"},

@@ -750,6 +750,91 @@ def check_bf16_mode(dev, kind, plan, shapes=((130, 216, 40), (200, 92, 152))):
         ops.set_precision("fp32")
 
 
+# ---------------------------------------------------------------- f32x3 compute mode (tf_set_precision(2)): bf16x3 split, fp32-ACCURATE
+def _err64(got, ref64):
+    """max |got - ref| / max |ref| against a float64 reference"""
+    got = got.detach().double().cpu()
+    return ((got - ref64).abs().max() / ref64.abs().max().clamp_min(1e-30)).item()
+
+
+def check_f32x3_mode(dev, kind, plan, shapes=((130, 216, 40), (200, 92, 152), (96, 160, 1100))):
+    """Engine contractions in bf16x3-split mode: every fp32 operand is split exactly into three bf16 terms (x = h + m + l) and the six leading
+    partial products are accumulated in fp32 on the bf16 MFMA.  The claim is fp32 ACCURACY, so the reference is float64 and the bound is the
+    one the exact fp32-MFMA path itself meets: relative max error <= 2e-6 (K <= 1100), and never worse than 3x the fp32-MFMA path's error
+    measured on the same inputs (+ 2e-7).  All operand layouts, masked (im2col) loaders, batched element-wise loaders, wide dynamic range."""
+    (ops.force_dma if kind == "dma" else ops.force_plan)(*plan)
+    BOUND = 2e-6
+
+    def both(fn):
+        ops.set_precision("fp32")
+        a = fn()
+        ops.set_precision("f32x3")
+        b = fn()
+        return a, b
+
+    def judge(pair, ref64, what):
+        e32, e3 = _err64(pair[0], ref64), _err64(pair[1], ref64)
+        assert e3 <= BOUND and e3 <= 3.0 * e32 + 2e-7, "%s: f32x3 err %.3e vs fp32-MFMA err %.3e" % (what, e3, e32)
+
+    try:
+        for (m, n, k) in shapes:
+            # wide dynamic range: per-row / per-column scales over 2^+-20 (a bf16-rounded operand would be off by 4e-3 relative)
+            sx = torch.exp2(torch.randint(-20, 21, (m, 1), generator=torch.Generator().manual_seed(m)).float()).to(dev)
+            x, w, b, r = R(m, k, dev=dev) * sx, R(n, k, dev=dev), R(n, dev=dev), R(m, n, dev=dev)
+            xd, wd = x.double().cpu(), w.double().cpu()
+            judge(both(lambda: ops.linear_fwd(x, w, None)), xd @ wd.t(), "x3 fwd (nt)")
+            dy = R(m, n, seed=1, dev=dev)
+            dyd = dy.double().cpu()
+            judge(both(lambda: ops.linear_dgrad(dy, w)), dyd @ wd, "x3 dgrad (nn)")
+            judge(both(lambda: ops.linear_wgrad(dy, x, torch.zeros(n, k, device=dev), accumulate=True)), dyd.t() @ xd, "x3 wgrad (tn)")
+            a, bb = R(m, k, dev=dev), R(n, k, seed=4, dev=dev)
+            at = a.t().contiguous()
+
+            def tt():
+                c = torch.empty(m, n, device=dev)
+                ops.gemm(at, bb, c, m, n, k, m, k, n, a_trans=True)
+                return c
+            judge(both(tt), a.double().cpu() @ bb.double().cpu().t(), "x3 tt")
+            # epilogue (bias + residual + ReLU) on top of the split product
+            ops.set_precision("f32x3")
+            y = ops.linear_fwd(x, w, b, relu=True, res=r)
+            ref = torch.relu(xd @ wd.t() + b.double().cpu() + r.double().cpu())
+            assert _err64(y, ref) <= BOUND, "x3 fwd epilogue"
+        # grouped / strided 3x3 convolution through the im2col loaders
+        B, Hi, Wi, Cin, Cout, groups, stride = 2, 9, 11, 48, 48, 2, 2
+        x = R(B, Cin, Hi, Wi, dev="cpu").double().requires_grad_(True)
+        w = (R(Cout, Cin // groups, 3, 3, dev="cpu") * 0.1).double().requires_grad_(True)
+        y = F.conv2d(x, w, None, stride, 1, 1, groups)
+        dy = R(*y.shape, seed=1, dev="cpu").double()
+        gx, gw = torch.autograd.grad(y, [x, w], dy)
+        xh, wh = x.detach().float().permute(0, 2, 3, 1).contiguous().to(dev), cl(w.detach().float()).to(dev)
+        dyh = dy.float().permute(0, 2, 3, 1).contiguous().to(dev)
+        judge(both(lambda: ops.conv_fwd(xh, wh, None, stride, None, groups).permute(0, 3, 1, 2)), y.detach(), "x3 conv fwd")
+        judge(both(lambda: ops.conv_dgrad(dyh, wh, xh.shape, stride, None, groups).permute(0, 3, 1, 2)), gx, "x3 conv dgrad")
+
+        def wg():
+            dw = torch.zeros_like(wh)
+            ops.conv_wgrad(dyh, xh, dw, stride, None, groups)
+            return dw
+        judge(both(wg), gw, "x3 conv wgrad")
+        # attention-style batched GEMM with head size 18 (element-wise loaders)
+        B_, nh, T, hs = 1, 2, 50, 18
+        C = nh * hs
+        qkv = R(B_, T, 3 * C, dev=dev, scale=0.5)
+        q, kk = qkv[..., :C], qkv[..., C:2 * C]
+        sa = (T * 3 * C, hs)
+
+        def bat():
+            att = torch.zeros(B_ * nh, T, 52, device=dev)
+            ops.gemm(q, kk, att, T, T, hs, 3 * C, 3 * C, 52, alpha=0.5, batch=B_ * nh, inner=nh, sa=sa, sb=sa, sc=(nh * T * 52, T * 52))
+            return att[:, :, :T].reshape(B_, nh, T, T)
+        qh, kh = [t.double().cpu().reshape(B_, T, nh, hs).transpose(1, 2) for t in (q, kk)]
+        judge(both(bat), 0.5 * (qh @ kh.transpose(-2, -1)), "x3 batched")
+    finally:
+        ops.force_plan(0)
+        ops.set_precision("fp32")
+
+
 # ---------------------------------------------------------------- grouped 3x3 direct kernels (csrc/conv_grouped.cpp), group width 24
 GROUPED_CONV_CASES = [(2, 16, 44, 72), (1, 9, 13, 48), (2, 8, 16, 24), (1, 5, 70, 72), (3, 4, 8, 48), (1, 33, 31, 24)]
 

@@ -111,6 +111,11 @@ def test_bf16_mfma_mode(cfg):
     kc.check_bf16_mode("cuda", cfg[0], cfg[1])
 
 
+@pytest.mark.parametrize("cfg", kc.BF16_PLANS, ids=str)
+def test_f32x3_split_mode(cfg):
+    kc.check_f32x3_mode("cuda", cfg[0], cfg[1])
+
+
 @pytest.mark.parametrize("case", kc.GROUPED_CONV_CASES, ids=str)
 def test_grouped_conv_direct(case):
     kc.check_conv_grouped("cuda", *case)

@@ -26,5 +26,10 @@ bench_cfgs) for a in "--backbone geometric_fusion" "--backbone latentTF" "--heig
               tag=$(echo $a | tr -d ' -' ); timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline $a > $O/r02_bench_$tag.json 2> $O/r02_bench_$tag.err; tail -1 $O/r02_bench_$tag.err; cat $O/r02_bench_$tag.json; done ;;
 tests_bf16) timeout 600 python -m pytest tests/test_kernels_gpu.py tests/test_model_gpu.py -q -k "bf16" -s 2>&1 | tail -12 ;;
 bench_bf16) timeout 300 python bench.py --steps 20 --warmup 5 --dtype bf16 --no-cpu-baseline > $O/r02_bench_bf16.json 2> $O/r02_bench_bf16.err; tail -3 $O/r02_bench_bf16.err; cat $O/r02_bench_bf16.json ;;
+x3_tests)   timeout 600 python -m pytest tests/test_kernels_gpu.py -q -k "f32x3 or gemm_dma" 2>&1 | tail -8 ;;
+x3_bench)   timeout 400 python tools/x3_bench.py 10 > $O/r02_x3_bench.txt 2>&1; grep BEST $O/r02_x3_bench.txt ;;
+x3_tune)    TF_RETUNE=0 timeout 400 python tools/tune.py $O/mi355x_x3.txt 10 256,160 f32x3 2>&1 | tail -4 ;;
+x3_ab)      for d in f32 f32x3 f32 f32x3; do TF_PLANS=$O/mi355x_x3.txt timeout 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --dtype $d 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('dtype $d', d['ms_per_step'], 'ms/step', d['value'], 'samples/s; loss', d['config']['final_loss'], '; GPT4 fc1', d['roofline']['avg_launch_us'], 'us', d['roofline']['achieved'], 'TF/s; engine', d['roofline']['engine_ms_per_step'], 'ms')"; done ;;
+x3_model)   timeout 900 python -m pytest tests/test_model_gpu.py -q -k "f32x3" -s 2>&1 | grep -v "Warning\|warn" | tail -25 ;;
 esac
 done

@@ -235,7 +235,7 @@ extern "C" int tf_conv3x3_small_fwd_f32(const float* x, const float* w, const fl
     TF_REQUIRE(x && w && y && B > 0 && H > 0 && W > 0 && Cin > 0 && Cin <= 32 && Cout > 0 && Cout <= 32, "tf_conv3x3_small_fwd_f32: needs Cin, Cout <= 32");
     DcGeom g = make_geom(B, H, W, Cin, Cout);
     const int grid = g.ntiles < 512 ? g.ntiles : 512;
-    const bool vec = Cin % 4 == 0 && aligned16(x), lowp = tf::gemm_precision() != 0;
+    const bool vec = Cin % 4 == 0 && aligned16(x), lowp = tf::gemm_precision() == 1;   // precision 2 (bf16x3) keeps these kernels on the exact fp32 MFMA
     if (vec && !lowp) TF_LAUNCH((conv3x3_small_kernel<true, false>), dim3(grid), dim3(256), stream, x, w, bias, y, g, Cout, Cin, 0, relu, 0);
     else if (!vec && !lowp) TF_LAUNCH((conv3x3_small_kernel<false, false>), dim3(grid), dim3(256), stream, x, w, bias, y, g, Cout, Cin, 0, relu, 0);
     else if (vec) TF_LAUNCH((conv3x3_small_kernel<true, true>), dim3(grid), dim3(256), stream, x, w, bias, y, g, Cout, Cin, 0, relu, 0);
@@ -247,7 +247,7 @@ extern "C" int tf_conv3x3_small_dgrad_f32(const float* dy, const float* w, float
     TF_REQUIRE(dy && w && dx && B > 0 && H > 0 && W > 0 && Cin > 0 && Cin <= 32 && Cout > 0 && Cout <= 32, "tf_conv3x3_small_dgrad_f32: needs Cin, Cout <= 32");
     DcGeom g = make_geom(B, H, W, Cout, Cin);      // the "input" of this pass is dY (Cout channels), the output dX (Cin channels)
     const int grid = g.ntiles < 512 ? g.ntiles : 512;
-    const bool vec = Cout % 4 == 0 && aligned16(dy), lowp = tf::gemm_precision() != 0;
+    const bool vec = Cout % 4 == 0 && aligned16(dy), lowp = tf::gemm_precision() == 1;   // precision 2 (bf16x3) keeps these kernels on the exact fp32 MFMA
     const float* nob = nullptr;
     if (vec && !lowp) TF_LAUNCH((conv3x3_small_kernel<true, false>), dim3(grid), dim3(256), stream, dy, w, nob, dx, g, Cout, Cin, 1, 0, accumulate);
     else if (!vec && !lowp) TF_LAUNCH((conv3x3_small_kernel<false, false>), dim3(grid), dim3(256), stream, dy, w, nob, dx, g, Cout, Cin, 1, 0, accumulate);
@@ -264,7 +264,7 @@ extern "C" int tf_conv3x3_small_wgrad_f32(const float* dy, const float* x, float
                "tf_conv3x3_small_wgrad_f32: needs Cin, Cout <= 32 and ws of tf_conv3x3_small_wgrad_ws_floats() floats");
     DcGeom g = make_geom(B, H, W, Cin, Cout);
     const int grid = g.ntiles < 256 ? g.ntiles : 256;
-    const bool vec = Cin % 4 == 0 && aligned16(x), lowp = tf::gemm_precision() != 0;
+    const bool vec = Cin % 4 == 0 && aligned16(x), lowp = tf::gemm_precision() == 1;   // precision 2 (bf16x3) keeps these kernels on the exact fp32 MFMA
     if (vec && !lowp) TF_LAUNCH((conv3x3_small_wgrad_kernel<true, false>), dim3(grid), dim3(256), stream, x, dy, ws, g);
     else if (!vec && !lowp) TF_LAUNCH((conv3x3_small_wgrad_kernel<false, false>), dim3(grid), dim3(256), stream, x, dy, ws, g);
     else if (vec) TF_LAUNCH((conv3x3_small_wgrad_kernel<true, true>), dim3(grid), dim3(256), stream, x, dy, ws, g);

@@ -273,8 +273,8 @@ extern "C" int tf_conv3x3_grouped_fwd_f32(const float* x, const float* w, const 
     TF_REQUIRE(args_ok(x, w, y, B, H, W, C), "tf_conv3x3_grouped_fwd_f32: needs NHWC tensors with C %% 24 == 0 (group width 24), 16-byte aligned");
     const int tw = pick_tw(H, W);
     GcGeom g = make_geom(B, H, W, C, tw);
-    if (tw == 16) TF_LAUNCH(conv3x3_grouped_kernel<16>, dim3(g.G * g.nb), dim3(256), stream, x, w, bias, y, g, 0, relu, 0, tf::gemm_precision());
-    else TF_LAUNCH(conv3x3_grouped_kernel<32>, dim3(g.G * g.nb), dim3(256), stream, x, w, bias, y, g, 0, relu, 0, tf::gemm_precision());
+    if (tw == 16) TF_LAUNCH(conv3x3_grouped_kernel<16>, dim3(g.G * g.nb), dim3(256), stream, x, w, bias, y, g, 0, relu, 0, tf::gemm_precision() == 1);
+    else TF_LAUNCH(conv3x3_grouped_kernel<32>, dim3(g.G * g.nb), dim3(256), stream, x, w, bias, y, g, 0, relu, 0, tf::gemm_precision() == 1);
     return launch_status("tf_conv3x3_grouped_fwd_f32");
 }
 
@@ -282,8 +282,8 @@ extern "C" int tf_conv3x3_grouped_dgrad_f32(const float* dy, const float* w, flo
     TF_REQUIRE(args_ok(dy, w, dx, B, H, W, C), "tf_conv3x3_grouped_dgrad_f32: needs NHWC tensors with C %% 24 == 0 (group width 24), 16-byte aligned");
     const int tw = pick_tw(H, W);
     GcGeom g = make_geom(B, H, W, C, tw);
-    if (tw == 16) TF_LAUNCH(conv3x3_grouped_kernel<16>, dim3(g.G * g.nb), dim3(256), stream, dy, w, (const float*)nullptr, dx, g, 1, 0, accumulate, tf::gemm_precision());
-    else TF_LAUNCH(conv3x3_grouped_kernel<32>, dim3(g.G * g.nb), dim3(256), stream, dy, w, (const float*)nullptr, dx, g, 1, 0, accumulate, tf::gemm_precision());
+    if (tw == 16) TF_LAUNCH(conv3x3_grouped_kernel<16>, dim3(g.G * g.nb), dim3(256), stream, dy, w, (const float*)nullptr, dx, g, 1, 0, accumulate, tf::gemm_precision() == 1);
+    else TF_LAUNCH(conv3x3_grouped_kernel<32>, dim3(g.G * g.nb), dim3(256), stream, dy, w, (const float*)nullptr, dx, g, 1, 0, accumulate, tf::gemm_precision() == 1);
     return launch_status("tf_conv3x3_grouped_dgrad_f32");
 }
 
@@ -296,7 +296,7 @@ extern "C" int tf_conv3x3_grouped_wgrad_f32(const float* dy, const float* x, flo
     GcGeom g = make_geom(B, H, W, C, tw, 256);
     if (g.nb > 1 && g.ntiles / g.nb < 6) { g.nb = g.ntiles / 6; if (g.nb < 1) g.nb = 1; }
     TF_REQUIRE((long)g.G * g.nb * 9216 <= tf_conv3x3_grouped_wgrad_ws_floats(), "tf_conv3x3_grouped_wgrad_f32: %d groups exceed the workspace", g.G);
-    const bool lowp = tf::gemm_precision() != 0;
+    const bool lowp = tf::gemm_precision() == 1;   // precision 2 (bf16x3) keeps these kernels on the exact fp32 MFMA
     if (tw == 16 && !lowp) TF_LAUNCH((conv3x3_grouped_wgrad_kernel<16, false>), dim3(g.G * g.nb), dim3(256), stream, x, dy, ws, g);
     else if (tw == 16) TF_LAUNCH((conv3x3_grouped_wgrad_kernel<16, true>), dim3(g.G * g.nb), dim3(256), stream, x, dy, ws, g);
     else if (!lowp) TF_LAUNCH((conv3x3_grouped_wgrad_kernel<32, false>), dim3(g.G * g.nb), dim3(256), stream, x, dy, ws, g);

@@ -84,7 +84,7 @@ struct DmaCfg {
     static_assert(LDS_BYTES <= 64 * 1024, "M0 LDS base is kept within 64 KiB");
 };
 
-template <int TM, int TN, int WAVES_M, int WAVES_N, int BK, int STAGES, bool A_KC, bool B_KC>
+template <int TM, int TN, int WAVES_M, int WAVES_N, int BK, int STAGES, bool A_KC, bool B_KC, bool X3>
 __device__ __forceinline__ void gemm_dma_tile(const PlainOp& la_in, const PlainOp& lb_in, const GemmEpi& ep, int M, int N, int K, int tiles_m,
                                               int tiles_n, int kchunk, float* smem) {
     typedef DmaCfg<TM, TN, WAVES_M, WAVES_N, BK, STAGES, A_KC, B_KC> C;
@@ -220,7 +220,7 @@ __device__ __forceinline__ void gemm_dma_tile(const PlainOp& la_in, const PlainO
         }
     };
 
-    // bf16-MFMA variant (ep.prec != 0): lane half hi owns k = 8 hi .. 8 hi + 7 of every 16-deep group = logical chunks 2 hi, 2 hi + 1 of a
+    // bf16-MFMA variants (ep.prec 1: rounded operands; X3 instantiation: bf16x3 split, fp32-accurate - tf_prims.h): lane half hi owns k = 8 hi .. 8 hi + 7 of every 16-deep group = logical chunks 2 hi, 2 hi + 1 of a
     // KC row (two b128 reads) or 8 k-rows of an IC tile; fp32 values are rounded to bf16 in registers, one MFMA per 32x32 tile and group.
     auto compute_bf16 = [&](int slot) {
         const float* As = smem + slot * C::STAGE_FL;
@@ -256,10 +256,13 @@ __device__ __forceinline__ void gemm_dma_tile(const PlainOp& la_in, const PlainO
                     for (int j = 0; j < 8; ++j) b[t][j] = p[j * BN];
                 }
             }
+            if constexpr (X3) mfma_tiles_x3<TM, TN>(a, b, acc);
+            else {
 #pragma unroll
-            for (int t = 0; t < TM; ++t)
+                for (int t = 0; t < TM; ++t)
 #pragma unroll
-                for (int u = 0; u < TN; ++u) mfma_32x32x16_bf16(a[t], b[u], acc[t][u]);
+                    for (int u = 0; u < TN; ++u) mfma_32x32x16_bf16(a[t], b[u], acc[t][u]);
+            }
         }
     };
     const bool lowp = ep.prec != 0;
@@ -274,7 +277,8 @@ __device__ __forceinline__ void gemm_dma_tile(const PlainOp& la_in, const PlainO
         lds_wait();
         dma_barrier<NW>();
         issue(kt + STAGES - 1, nxt);
-        if (lowp) compute_bf16(cur); else compute(cur);
+        if constexpr (X3) compute_bf16(cur);
+        else { if (lowp) compute_bf16(cur); else compute(cur); }
         cur = cur + 1 == STAGES ? 0 : cur + 1;
         nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
     }
@@ -283,12 +287,13 @@ __device__ __forceinline__ void gemm_dma_tile(const PlainOp& la_in, const PlainO
     gemm_epilogue<TM, TN>(acc, ep, M, N, i0, j0, BM, BN, wm0, wn0, z);
 }
 
-template <int TM, int TN, int WAVES_M, int WAVES_N, int BK, int STAGES, bool A_KC, bool B_KC, int OCC>
+// X3 = the bf16x3-split instantiation (tf_set_precision(2)): a separate kernel, so the fp32 / bf16 binary keeps its register allocation
+template <int TM, int TN, int WAVES_M, int WAVES_N, int BK, int STAGES, bool A_KC, bool B_KC, int OCC, bool X3 = false>
 __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, OCC)
 gemm_dma_kernel(PlainOp la, PlainOp lb, GemmEpi ep, int M, int N, int K, int tiles_m, int tiles_n, int kchunk) {
     typedef DmaCfg<TM, TN, WAVES_M, WAVES_N, BK, STAGES, A_KC, B_KC> C;
     __shared__ __attribute__((aligned(1024))) float smem[STAGES * C::STAGE_FL];
-    gemm_dma_tile<TM, TN, WAVES_M, WAVES_N, BK, STAGES, A_KC, B_KC>(la, lb, ep, M, N, K, tiles_m, tiles_n, kchunk, smem);
+    gemm_dma_tile<TM, TN, WAVES_M, WAVES_N, BK, STAGES, A_KC, B_KC, X3>(la, lb, ep, M, N, K, tiles_m, tiles_n, kchunk, smem);
 }
 
 // can this problem run on the DMA kernels?  (vector-aligned plain operands, 32-bit addressable)
@@ -316,8 +321,12 @@ inline void launch_dma_cfg(const PlainOp& la, const PlainOp& lb, const GemmEpi& 
         if (g > tiles_m) g = tiles_m;
         epg.group_m = (g >= 2 && tiles_n >= 4) ? g : 1;
     }
-    TF_LAUNCH((gemm_dma_kernel<TM, TN, WAVES_M, WAVES_N, BK, STAGES, A_KC, B_KC, OCC>), grid, dim3(C::NT), stream, la, lb, epg, M, N, K, tiles_m,
-              tiles_n, kchunk);
+    if (epg.prec == 2)
+        TF_LAUNCH((gemm_dma_kernel<TM, TN, WAVES_M, WAVES_N, BK, STAGES, A_KC, B_KC, OCC, true>), grid, dim3(C::NT), stream, la, lb, epg, M, N, K,
+                  tiles_m, tiles_n, kchunk);
+    else
+        TF_LAUNCH((gemm_dma_kernel<TM, TN, WAVES_M, WAVES_N, BK, STAGES, A_KC, B_KC, OCC, false>), grid, dim3(C::NT), stream, la, lb, epg, M, N, K,
+                  tiles_m, tiles_n, kchunk);
 }
 
 }  // namespace tf

@@ -243,7 +243,7 @@ struct GemmEpi {
     float alpha; int relu; int mode; // mode 0: store, 1: +=, 2: atomicAdd
     int group_m = 1;                 // tile rasterisation: rows of tiles walked together (set by launch_cfg)
     const float* mask = nullptr; long ldmask = 0;   // optional ReLU mask of a backward GEMM: element (i, j) is zeroed unless mask(i, j) > 0
-    int prec = 0;                    // 0: exact fp32 MFMA; 1: operands rounded to bf16 on the LDS->register path, bf16 MFMA, fp32 accumulate (set by launch_cfg)
+    int prec = 0;                    // 0: exact fp32 MFMA; 1: operands rounded to bf16 on the LDS->register path, bf16 MFMA, fp32 accumulate; 2: bf16x3 split (fp32-accurate, 6 bf16 MFMAs) (set by launch_cfg)
 };
 
 int gemm_precision();   // api.cpp: process-wide compute precision of the engine (tf_set_precision)
@@ -552,7 +552,7 @@ __device__ __forceinline__ void gemm_tile(LA& la, LB& lb, const GemmEpi& ep, int
                 for (int u = 0; u < TN; ++u) mfma_32x32x16_bf16(a[t], b[u], acc[t][u]);
         }
     };
-    const bool lowp = ep.prec != 0;
+    const bool lowp = ep.prec == 1;      // precision 2 (bf16x3 split) exists in the LDS-DMA kernels only: this kernel then stays on the exact fp32 MFMA
     auto mult = [&](int cur) { if (lowp) compute_bf16(cur); else compute(cur); };
 
     if constexpr (CANFAST) {

@@ -72,6 +72,20 @@ __forceinline__ void mfma_32x32x16_bf16(const float (&a)[8], const float (&b)[8]
         emu::wave_barrier();
     }
 }
+// bf16x3 split ("f32x3" precision): x = h + m + l with h = bf16(x), m = bf16(x - h), l = bf16(x - h - m) (both residuals are exact in fp32,
+// |x - (h + m + l)| <= 2^-27 |x|); a product keeps the six terms of weight >= 2^-18: hh + hm + mh + mm + hl + lh (dropped: <= 2^-26 |xy|).
+struct Bf16x3 { float h[8], m[8], l[8]; };
+__forceinline__ Bf16x3 split_bf16x3(const float (&a)[8]) {
+    Bf16x3 f;
+    for (int j = 0; j < 8; ++j) {
+        f.h[j] = emu_bf16_round(a[j]);
+        const float r1 = a[j] - f.h[j];
+        f.m[j] = emu_bf16_round(r1);
+        f.l[j] = emu_bf16_round(r1 - f.m[j]);
+    }
+    return f;
+}
+__forceinline__ void mfma_bf16_raw(const float (&a)[8], const float (&b)[8], f32x16& acc) { mfma_32x32x16_bf16(a, b, acc); }   // operands are bf16 values: re-rounding is the identity
 __forceinline__ float shfl(float v, int src) {
     float* s = emu::wave_scratch();
     s[128 + lane_id()] = v;
@@ -96,10 +110,62 @@ __device__ __forceinline__ void mfma_32x32x16_bf16(const float (&a)[8], const fl
     for (int j = 0; j < 8; ++j) { x[j] = a[j]; y[j] = b[j]; }
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_convertvector(x, bf16x8), __builtin_convertvector(y, bf16x8), acc, 0, 0, 0);
 }
+// bf16x3 split ("f32x3" precision, tf_set_precision(2)): fp32-accurate contraction on the bf16 MFMA pipe (16x the fp32 MFMA rate on gfx950).
+// x = h + m + l with h = bf16(x), m = bf16(x - h), l = bf16(x - h - m), round-to-nearest-even (both residuals are exact in fp32,
+// |x - (h + m + l)| <= 2^-27 |x|); a product keeps the six terms of weight >= 2^-18: hh + hm + mh + mm + hl + lh (dropped: <= 2^-26 |xy|,
+// below the fp32 half-ulp), accumulated in fp32 by the MFMA.  v_cvt_pk_bf16_f32 + shift/and + v_pk_add_f32: 4.5 VALU ops per element.
+struct Bf16x3 { bf16x8 h, m, l; };
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t bf16_pack_rne(f32x2 v) { return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2)); }   // one v_cvt_pk_bf16_f32
+__device__ __forceinline__ f32x2 bf16_unpack(uint32_t p) {
+    f32x2 r;
+    r.x = __builtin_bit_cast(float, p << 16);
+    r.y = __builtin_bit_cast(float, p & 0xffff0000u);
+    return r;
+}
+__device__ __forceinline__ Bf16x3 split_bf16x3(const float (&a)[8]) {
+    u32x4 h, m, l;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f32x2 x;
+        x.x = a[2 * i]; x.y = a[2 * i + 1];
+        h[i] = bf16_pack_rne(x);
+        const f32x2 r1 = x - bf16_unpack(h[i]);
+        m[i] = bf16_pack_rne(r1);
+        const f32x2 r2 = r1 - bf16_unpack(m[i]);
+        l[i] = bf16_pack_rne(r2);
+    }
+    Bf16x3 f;
+    f.h = __builtin_bit_cast(bf16x8, h);
+    f.m = __builtin_bit_cast(bf16x8, m);
+    f.l = __builtin_bit_cast(bf16x8, l);
+    return f;
+}
+__device__ __forceinline__ void mfma_bf16_raw(const bf16x8& a, const bf16x8& b, f32x16& acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+}
 __device__ __forceinline__ float shfl(float v, int src) { return __shfl(v, src, 64); }
 __device__ __forceinline__ float shfl_xor(float v, int m) { return __shfl_xor(v, m, 64); }
 __device__ __forceinline__ float shfl_down(float v, int d) { return __shfl_down(v, d, 64); }
 #endif
+
+// TM x TN tiles of one 16-deep k group in bf16x3-split precision: fragments split once, six bf16 MFMAs per tile issued term-major so that
+// consecutive MFMAs hit different accumulators (smallest terms first).
+template <int TM, int TN>
+__device__ __forceinline__ void mfma_tiles_x3(const float (&a)[TM][8], const float (&b)[TN][8], f32x16 (&acc)[TM][TN]) {
+    Bf16x3 fa[TM], fb[TN];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) fa[t] = split_bf16x3(a[t]);
+#pragma unroll
+    for (int u = 0; u < TN; ++u) fb[u] = split_bf16x3(b[u]);
+#define TF_X3_TERM(P, Q)                                                       \
+    _Pragma("unroll") for (int t = 0; t < TM; ++t)                             \
+        _Pragma("unroll") for (int u = 0; u < TN; ++u) mfma_bf16_raw(fa[t].P, fb[u].Q, acc[t][u]);
+    TF_X3_TERM(l, h) TF_X3_TERM(h, l) TF_X3_TERM(m, m) TF_X3_TERM(m, h) TF_X3_TERM(h, m) TF_X3_TERM(h, h)
+#undef TF_X3_TERM
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

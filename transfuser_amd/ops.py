@@ -39,13 +39,17 @@ def autotune(enable):
 
 
 def set_precision(mode):
-    """"fp32" (exact fp32 MFMA, default) or "bf16" (bf16 MFMA operands, fp32 accumulate + storage) for every engine contraction."""
-    m = {"fp32": 0, "f32": 0, 0: 0, "bf16": 1, 1: 1}[mode]
+    """Compute precision of every MFMA-engine contraction (storage, accumulation, epilogues stay fp32 in all modes):
+    "fp32"  exact fp32 MFMA (v_mfma_f32_32x32x2_f32; default - the reference's arithmetic);
+    "f32x3" bf16x3 split: every fp32 operand is split exactly into three bf16 terms in registers and the six leading partial products run on
+            the bf16 MFMA (16x the fp32 MFMA rate on gfx950) - fp32-ACCURATE (dropped terms <= 2^-26 |xy|), not a reduced-precision mode;
+    "bf16"  operands rounded to bf16 (one bf16 MFMA per tile) - BASELINE configs[2]."""
+    m = {"fp32": 0, "f32": 0, 0: 0, "bf16": 1, 1: 1, "f32x3": 2, "fp32x3": 2, "bf16x3": 2, 2: 2}[mode]
     check(L().tf_set_precision(m), "tf_set_precision")
 
 
 def get_precision():
-    return "bf16" if L().tf_get_precision() else "fp32"
+    return ("fp32", "bf16", "f32x3")[L().tf_get_precision()]
 
 
 def force_plan(bm=0, bn=0, bk=0, splitk=1):

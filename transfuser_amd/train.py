@@ -280,11 +280,11 @@ class Engine:
         ``precision``: compute precision of every MFMA-engine contraction (process-wide, ops.set_precision); None keeps the current one."""
         self.model = model
         self.config = config
-        if precision is not None:   # "fp32" (exact fp32 MFMA: the reference's arithmetic) | "bf16" (bf16 MFMA operands, fp32 accumulate / storage / master weights)
+        if precision is not None:   # "fp32" (exact fp32 MFMA: the reference's arithmetic) | "f32x3" (bf16x3 split on the bf16 MFMA, fp32-accurate) | "bf16" (bf16 MFMA operands, fp32 accumulate / storage / master weights)
             ops.set_precision(precision)
         self._autotune_pending = bool(autotune) and next(model.parameters()).is_cuda
         if plan_file is None:   # tilings tuned offline on an MI355X for the bench / reference shapes (tools/tune.py); unknown shapes are tuned on first use
-            plan_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "plans", "mi355x.txt")
+            plan_file = os.environ.get("TF_PLANS") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "plans", "mi355x.txt")
         if next(model.parameters()).is_cuda and os.path.exists(plan_file):
             ops.plans_load(plan_file)
         world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
@@ -595,7 +595,7 @@ def build_parser():
     p.add_argument('--use_disk_cache', type=int, default=0, help='accepted for command-line compatibility; the synthetic / GPU-prepared loaders do not need it')
     # additions of this framework
     p.add_argument('--use_graph', type=int, default=1, help='capture the step into hipGraphs (falls back to eager where a flag requires it)')
-    p.add_argument('--precision', type=str, default='fp32', choices=['fp32', 'bf16'])
+    p.add_argument('--precision', type=str, default='fp32', choices=['fp32', 'f32x3', 'bf16'])
     p.add_argument('--height', type=int, default=160, help="RGB height of the synthetic samples (the dataset's crop is 160 x 704)")
     p.add_argument('--num_workers', type=int, default=None)
     p.add_argument('--width', type=int, default=704)
