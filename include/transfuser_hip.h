@@ -34,7 +34,7 @@ int tf_set_precision(int mode);
 int tf_get_precision(void);
 int tf_autotune(int enable);
 int tf_force_plan(int bm, int bn, int bk, int splitk); /* tests: pin one tiling of the register-staged kernel (bm = 0 clears) */
-int tf_force_dma(int kind, int splitk);                /* tests: pin LDS-DMA configuration `kind` (1..5, tf_gemm_dma.h) for every eligible call */
+int tf_force_dma(int kind, int splitk);                /* tests: pin LDS-DMA configuration `kind` (1..8, tf_gemm_dma.h) for every eligible call */
 int tf_plans_count(void);
 int tf_plans_clear(void);
 int tf_plans_save(const char* path);

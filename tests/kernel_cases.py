@@ -572,7 +572,7 @@ def check_engine_plan(dev, bm, bn, bk, splitk):
 
 
 # ---------------------------------------------------------------- LDS-DMA GEMM configurations (tf_gemm_dma.h), kind 1..5 (+ split-K)
-DMA_KINDS = [(1, 1), (2, 1), (3, 1), (4, 1), (5, 1), (2, 3), (1, 2)]
+DMA_KINDS = [(1, 1), (2, 1), (3, 1), (4, 1), (5, 1), (2, 3), (1, 2), (6, 1), (7, 1), (8, 2)]
 DMA_SHAPES_SMALL = [(130, 216, 40), (200, 92, 152), (70, 36, 20)]
 DMA_SHAPES_GPU = [(1740, 1512, 576), (333, 700, 1028), (130, 216, 40), (64, 64, 16), (1740, 216, 864)]
 
@@ -695,7 +695,7 @@ def check_bench_conv(dev, B, H, W, Cin, Cout):
 
 # ---------------------------------------------------------------- bf16-MFMA compute mode (tf_set_precision(1), BASELINE configs[2])
 BF16_PLANS = [("plan", (64, 64, 16, 1)), ("plan", (128, 128, 32, 1)), ("plan", (128, 32, 16, 2)), ("plan", (64, 128, 32, 1)), ("dma", (1, 1)), ("dma", (2, 2)),
-              ("dma", (4, 1)), ("dma", (5, 1))]
+              ("dma", (4, 1)), ("dma", (5, 1)), ("dma", (6, 1)), ("dma", (7, 2)), ("dma", (8, 1))]
 
 
 def _bf(t):
@@ -896,6 +896,38 @@ def check_bf16_direct(dev):
             dw = torch.zeros_like(wh)
             ops.conv_wgrad(dyh, xh, dw, 1, None, groups)
             close(dw, gw, tol=1e-4, what="bf16 direct wgrad")
+    finally:
+        ops.set_precision("fp32")
+        ops._DIRECT_MIN_PIXELS = old
+
+
+def check_f32x3_direct(dev):
+    """The LDS-tiled direct convolutions (decoder tails, RegNetY grouped 3x3) in f32x3 mode: float64 reference, the fp32-accuracy bound of
+    check_f32x3_mode (<= 2e-6 relative, <= 3x the exact-fp32-MFMA kernels' own error + 2e-7)."""
+    old = ops._DIRECT_MIN_PIXELS
+    ops._DIRECT_MIN_PIXELS = 0
+    try:
+        for (B, H, W, Cin, Cout, groups) in ((2, 10, 70, 32, 32, 1), (1, 9, 33, 32, 7, 1), (1, 12, 64, 8, 32, 1), (2, 16, 44, 72, 72, 3), (1, 9, 13, 48, 48, 2)):
+            x = R(B, Cin, H, W, dev="cpu").double().requires_grad_(True)
+            w = (R(Cout, Cin // groups, 3, 3, dev="cpu") * 0.1).double().requires_grad_(True)
+            dy = R(B, Cout, H, W, seed=1, dev="cpu").double()
+            y = F.conv2d(x, w, None, 1, 1, 1, groups)
+            gx, gw = torch.autograd.grad(y, [x, w], dy)
+            xh, wh = x.detach().float().permute(0, 2, 3, 1).contiguous().to(dev), cl(w.detach().float()).to(dev)
+            dyh = dy.float().permute(0, 2, 3, 1).contiguous().to(dev)
+            assert ops._direct_ok(xh.shape, Cout, Cin, 3, 1, 1, groups) or ops._grouped_ok(xh.shape, Cout, Cin, 3, 1, 1, groups)
+
+            def wg():
+                dw = torch.zeros_like(wh)
+                ops.conv_wgrad(dyh, xh, dw, 1, None, groups)
+                return dw
+            for what, fn, ref in (("fwd", lambda: ops.conv_fwd(xh, wh, None, 1, None, groups).permute(0, 3, 1, 2), y.detach()),
+                                  ("dgrad", lambda: ops.conv_dgrad(dyh, wh, xh.shape, 1, None, groups).permute(0, 3, 1, 2), gx), ("wgrad", wg, gw)):
+                ops.set_precision("fp32")
+                e32 = _err64(fn(), ref)
+                ops.set_precision("f32x3")
+                e3 = _err64(fn(), ref)
+                assert e3 <= 2e-6 and e3 <= 3.0 * e32 + 2e-7, "x3 direct %s %s: err %.3e vs fp32-MFMA err %.3e" % (what, (B, H, W, Cin, Cout, groups), e3, e32)
     finally:
         ops.set_precision("fp32")
         ops._DIRECT_MIN_PIXELS = old

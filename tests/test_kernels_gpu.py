@@ -121,6 +121,10 @@ def test_grouped_conv_direct(case):
     kc.check_conv_grouped("cuda", *case)
 
 
+def test_f32x3_split_mode_direct_convs():
+    kc.check_f32x3_direct("cuda")
+
+
 def test_bf16_mfma_mode_direct_convs():
     kc.check_bf16_direct("cuda")
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Per-shape census of the MFMA-engine calls of ONE eager training step (HIP-event timed):
-which GEMM / conv shapes the step spends its time in and at what TFLOP/s.  python tools/census.py [B H]"""
+which GEMM / conv shapes the step spends its time in and at what TFLOP/s.  python tools/census.py [B H precision]"""
 import collections
 import os
 import sys
@@ -17,13 +17,14 @@ from transfuser_amd.train import Engine  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 H = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+PREC = sys.argv[3] if len(sys.argv) > 3 else "fp32"
 dev = torch.device("cuda", 0)
 cfg = GlobalConfig(); cfg.n_layer = 4; cfg.use_target_point_image = True
 torch.manual_seed(0)
 model = LidarCenterNet(cfg, dev, 'transFuser', 'regnety_032', 'regnety_032', use_velocity=False).train()
 hist_fn = lambda pts: ops.lidar_hist(torch.from_numpy(pts).to(dev)[None])[0].cpu().numpy()
 batch = {k: v.to(dev) for k, v in synthetic_batch(B, H, 704, seed=0, hist_fn=hist_fn).items()}
-eng = Engine(model, cfg)
+eng = Engine(model, cfg, precision=PREC)
 for _ in range(2):
     eng.train_step(batch)
 torch.cuda.synchronize()
@@ -37,6 +38,7 @@ for kind, shape, flops, a, b in rows:
     v = agg.setdefault(k, [0, 0.0, 0.0])
     v[0] += 1; v[1] += a.elapsed_time(b) * 1e3; v[2] += flops
 tot_us = sum(v[1] for v in agg.values()); tot_fl = sum(v[2] for v in agg.values())
+print("# precision %s" % PREC)
 print("# census of one eager step B=%d H=%d: %d engine calls, %.1f ms in the engine (event-timed, incl. launch gaps), %.1f GFLOP -> %.1f TFLOP/s; step wall %.1f ms" %
       (B, H, len(rows), tot_us / 1e3, tot_fl / 1e9, tot_fl / tot_us / 1e6, e0.elapsed_time(e1)))
 print("# %-12s %-44s %6s %10s %8s %8s %6s" % ("kind", "shape (m,n,k,batch | B,Hi,Wi,Cin,Cout,ks,s,g)", "calls", "total_us", "avg_us", "TFLOP/s", "pct"))

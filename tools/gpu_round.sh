@@ -31,5 +31,10 @@ x3_bench)   timeout 400 python tools/x3_bench.py 10 > $O/r02_x3_bench.txt 2>&1; 
 x3_tune)    TF_RETUNE=0 timeout 400 python tools/tune.py $O/mi355x_x3.txt 10 256,160 f32x3 2>&1 | tail -4 ;;
 x3_ab)      for d in f32 f32x3 f32 f32x3; do TF_PLANS=$O/mi355x_x3.txt timeout 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --dtype $d 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('dtype $d', d['ms_per_step'], 'ms/step', d['value'], 'samples/s; loss', d['config']['final_loss'], '; GPT4 fc1', d['roofline']['avg_launch_us'], 'us', d['roofline']['achieved'], 'TF/s; engine', d['roofline']['engine_ms_per_step'], 'ms')"; done ;;
 x3_model)   timeout 900 python -m pytest tests/test_model_gpu.py -q -k "f32x3" -s 2>&1 | grep -v "Warning\|warn" | tail -25 ;;
+x3_retune)  awk -F';' '/^#/ || $6<8' transfuser_amd/plans/mi355x.txt > $O/plans_nox3.txt; cp $O/plans_nox3.txt transfuser_amd/plans/mi355x.txt
+            TF_RETUNE=0 timeout 500 python tools/tune.py $O/mi355x_x3.txt 10 256,160 f32x3 2>&1 | tail -4 ;;
+x3_ab2)     for v in "f32x3 1" "f32x3 0" "f32 1" "f32x3 1" "f32x3 0"; do set -- $v; TF_X3_DIRECT=$2 TF_PLANS=$O/mi355x_x3.txt timeout 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-alt --dtype $1 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('dtype $1 TF_X3_DIRECT=$2', d['ms_per_step'], 'ms/step', d['value'], 'samples/s; loss', d['config']['final_loss'], '; GPT4 fc1', d['roofline']['avg_launch_us'], 'us', d['roofline']['achieved'], 'TF/s; engine', d['roofline']['engine_ms_per_step'], 'ms')"; done ;;
+x3_tests2)  timeout 600 python -m pytest tests/test_kernels_gpu.py -q -k "f32x3 or gemm_dma or bf16" 2>&1 | tail -8 ;;
+census_x3)  timeout 300 python tools/census.py 10 256 f32x3 > $O/r02_census_f32x3.txt 2>&1; head -70 $O/r02_census_f32x3.txt ;;
 esac
 done

@@ -14,7 +14,7 @@ iters = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 dev = "cuda"
 SHAPES = [("nt", 1740, 6048, 1512), ("nn", 1740, 1512, 6048), ("tn", 6048, 1512, 1740), ("nt", 1740, 4536, 1512), ("nt", 7040, 576, 576),
           ("tn", 576, 576, 7040), ("nt", 2560, 576, 576), ("nt", 28160, 216, 216), ("nt", 4096, 4096, 4096)]
-KINDS = {1: "128x128x16", 2: "64x64x16", 3: "128x64x16", 4: "64x128x16", 5: "128x128x32"}
+KINDS = {1: "128x128x16", 2: "64x64x16", 3: "128x64x16", 4: "64x128x16", 5: "128x128x32", 6: "64x64 w1", 7: "64x128 w2", 8: "128x64 w2"}
 
 
 def make(form, m, n, k):

@@ -7,10 +7,11 @@
 // MFMA (v_mfma_f32_32x32x2_f32): per wave one row of 32 output pixels x 32 output channels (channel counts are zero-padded to 32).
 // Blocks are persistent over tiles so the 9 x 32 x 32 weight panel is staged once per block.
 #include "tf_common.h"
+#include <stdlib.h>
 #include "../../include/transfuser_hip.h"
 
 using namespace tf;
-namespace tf { int gemm_precision(); }   // api.cpp (tf_set_precision): 1 = bf16-MFMA contractions
+namespace tf { int gemm_precision(); }   // api.cpp (tf_set_precision): 1 = bf16-MFMA contractions, 2 = bf16x3 split (fp32-accurate) on the bf16 MFMA
 
 namespace {
 
@@ -53,7 +54,7 @@ __device__ __forceinline__ void store_patch_slot(float* patch, int s, const floa
 }
 
 // y = conv3x3(x, W) (+bias) (relu) (+= when accumulate).  dgrad != 0: x is dY (Ci = W's Cout), y is dX (Co = W's Cin).
-template <bool VEC, bool BF16>
+template <bool VEC, int PREC>
 __global__ void __launch_bounds__(256, 2) conv3x3_small_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                                float* __restrict__ y, DcGeom g, int CoW, int CiW, int dgrad, int relu, int accumulate) {
     __shared__ float patch[PH * PW * PP];
@@ -80,7 +81,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_small_kernel(const float* __re
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        if constexpr (BF16) {      // bf16 MFMA (tf_set_precision(1)): channels are zero-padded to 32 in both LDS tiles -> two 16-deep groups per tap
+        if constexpr (PREC != 0) { // bf16 MFMA (PREC 1: rounded operands, 2: bf16x3 split): channels are zero-padded to 32 in both LDS tiles -> two 16-deep groups per tap
             for (int tap = 0; tap < 9; ++tap) {
                 const int kh = tap / 3, kw = tap - kh * 3;
                 const float* pa = patch + ((wave + kh) * PW + l31 + kw) * PP;
@@ -91,7 +92,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_small_kernel(const float* __re
                     const int k0 = 16 * q + 8 * hi;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) { a[j] = pa[k0 + j]; b[j] = wl[tap * 32 + k0 + j][l31]; }
-                    mfma_32x32x16_bf16(a, b, acc);
+                    if constexpr (PREC == 2) mfma_32x32x16_x3(a, b, acc); else mfma_32x32x16_bf16(a, b, acc);
                 }
             }
         } else {
@@ -122,7 +123,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_small_kernel(const float* __re
 
 // dW[co][tap][ci] (+)= sum_pixels dY[p][co] * X[p + tap][ci]: per wave a row of 32 pixels as the K dimension, 9 accumulators (one per
 // tap, 32 co x 32 ci); blocks are persistent, their partial panels are summed by conv3x3_small_wgrad_reduce_kernel.
-template <bool VEC, bool BF16>
+template <bool VEC, int PREC>
 __global__ void __launch_bounds__(256, 1) conv3x3_small_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part,
                                                                      DcGeom g) {
     __shared__ float patch[PH * PW * PP];
@@ -164,7 +165,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_small_wgrad_kernel(const float
         // the tap -> 9 independent accumulator chains per k step
         const float* pa = dyt + (wave * TW + hi) * PP + l31;
         const float* pb = patch + (wave * PW + hi) * PP + l31;
-        if constexpr (BF16) {      // bf16 MFMA: the row's 32 pixels = two 16-deep K groups; lane half hi owns pixels 16 q + 8 hi .. + 7
+        if constexpr (PREC != 0) { // bf16 MFMA: the row's 32 pixels = two 16-deep K groups; lane half hi owns pixels 16 q + 8 hi .. + 7
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 float a[8], b[9][8];
@@ -175,8 +176,14 @@ __global__ void __launch_bounds__(256, 1) conv3x3_small_wgrad_kernel(const float
 #pragma unroll
                     for (int tap = 0; tap < 9; ++tap) b[tap][j] = patch[((wave + tap / 3) * PW + pi + tap % 3) * PP + l31];
                 }
+                if constexpr (PREC == 2) {      // the dY fragment is split once and shared by the 9 taps
+                    const Bf16x3 fa = split_bf16x3(a);
 #pragma unroll
-                for (int tap = 0; tap < 9; ++tap) mfma_32x32x16_bf16(a, b[tap], acc[tap]);
+                    for (int tap = 0; tap < 9; ++tap) mfma_x3_presplit(fa, split_bf16x3(b[tap]), acc[tap]);
+                } else {
+#pragma unroll
+                    for (int tap = 0; tap < 9; ++tap) mfma_32x32x16_bf16(a, b[tap], acc[tap]);
+                }
             }
         } else {
 #pragma unroll 2
@@ -222,6 +229,13 @@ __global__ void __launch_bounds__(256) conv3x3_small_wgrad_reduce_kernel(const f
     *d = accumulate ? *d + s : s;
 }
 
+// compute precision of these kernels; TF_X3_DIRECT=0 keeps them on the exact fp32 MFMA in f32x3 mode (A/B switch)
+inline int direct_prec() {
+    static const bool x3 = [] { const char* e = getenv("TF_X3_DIRECT"); return !e || atoi(e) != 0; }();
+    const int p = tf::gemm_precision();
+    return (p == 2 && !x3) ? 0 : p;
+}
+
 inline DcGeom make_geom(int B, int H, int W, int Ci, int Co) {
     DcGeom g; g.B = B; g.H = H; g.W = W; g.Ci = Ci; g.Co = Co;
     g.tiles_h = cdiv(H, TH); g.tiles_w = cdiv(W, TW); g.ntiles = B * g.tiles_h * g.tiles_w;
@@ -235,11 +249,11 @@ extern "C" int tf_conv3x3_small_fwd_f32(const float* x, const float* w, const fl
     TF_REQUIRE(x && w && y && B > 0 && H > 0 && W > 0 && Cin > 0 && Cin <= 32 && Cout > 0 && Cout <= 32, "tf_conv3x3_small_fwd_f32: needs Cin, Cout <= 32");
     DcGeom g = make_geom(B, H, W, Cin, Cout);
     const int grid = g.ntiles < 512 ? g.ntiles : 512;
-    const bool vec = Cin % 4 == 0 && aligned16(x), lowp = tf::gemm_precision() == 1;   // precision 2 (bf16x3) keeps these kernels on the exact fp32 MFMA
-    if (vec && !lowp) TF_LAUNCH((conv3x3_small_kernel<true, false>), dim3(grid), dim3(256), stream, x, w, bias, y, g, Cout, Cin, 0, relu, 0);
-    else if (!vec && !lowp) TF_LAUNCH((conv3x3_small_kernel<false, false>), dim3(grid), dim3(256), stream, x, w, bias, y, g, Cout, Cin, 0, relu, 0);
-    else if (vec) TF_LAUNCH((conv3x3_small_kernel<true, true>), dim3(grid), dim3(256), stream, x, w, bias, y, g, Cout, Cin, 0, relu, 0);
-    else TF_LAUNCH((conv3x3_small_kernel<false, true>), dim3(grid), dim3(256), stream, x, w, bias, y, g, Cout, Cin, 0, relu, 0);
+    const bool vec = Cin % 4 == 0 && aligned16(x);
+    const int prec = direct_prec();
+    if (prec == 2) { if (vec) TF_LAUNCH((conv3x3_small_kernel<true, 2>), dim3(grid), dim3(256), stream, x, w, bias, y, g, Cout, Cin, 0, relu, 0); else TF_LAUNCH((conv3x3_small_kernel<false, 2>), dim3(grid), dim3(256), stream, x, w, bias, y, g, Cout, Cin, 0, relu, 0); }
+    else if (prec == 1) { if (vec) TF_LAUNCH((conv3x3_small_kernel<true, 1>), dim3(grid), dim3(256), stream, x, w, bias, y, g, Cout, Cin, 0, relu, 0); else TF_LAUNCH((conv3x3_small_kernel<false, 1>), dim3(grid), dim3(256), stream, x, w, bias, y, g, Cout, Cin, 0, relu, 0); }
+    else { if (vec) TF_LAUNCH((conv3x3_small_kernel<true, 0>), dim3(grid), dim3(256), stream, x, w, bias, y, g, Cout, Cin, 0, relu, 0); else TF_LAUNCH((conv3x3_small_kernel<false, 0>), dim3(grid), dim3(256), stream, x, w, bias, y, g, Cout, Cin, 0, relu, 0); }
     return launch_status("tf_conv3x3_small_fwd_f32");
 }
 
@@ -247,12 +261,12 @@ extern "C" int tf_conv3x3_small_dgrad_f32(const float* dy, const float* w, float
     TF_REQUIRE(dy && w && dx && B > 0 && H > 0 && W > 0 && Cin > 0 && Cin <= 32 && Cout > 0 && Cout <= 32, "tf_conv3x3_small_dgrad_f32: needs Cin, Cout <= 32");
     DcGeom g = make_geom(B, H, W, Cout, Cin);      // the "input" of this pass is dY (Cout channels), the output dX (Cin channels)
     const int grid = g.ntiles < 512 ? g.ntiles : 512;
-    const bool vec = Cout % 4 == 0 && aligned16(dy), lowp = tf::gemm_precision() == 1;   // precision 2 (bf16x3) keeps these kernels on the exact fp32 MFMA
+    const bool vec = Cout % 4 == 0 && aligned16(dy);
+    const int prec = direct_prec();
     const float* nob = nullptr;
-    if (vec && !lowp) TF_LAUNCH((conv3x3_small_kernel<true, false>), dim3(grid), dim3(256), stream, dy, w, nob, dx, g, Cout, Cin, 1, 0, accumulate);
-    else if (!vec && !lowp) TF_LAUNCH((conv3x3_small_kernel<false, false>), dim3(grid), dim3(256), stream, dy, w, nob, dx, g, Cout, Cin, 1, 0, accumulate);
-    else if (vec) TF_LAUNCH((conv3x3_small_kernel<true, true>), dim3(grid), dim3(256), stream, dy, w, nob, dx, g, Cout, Cin, 1, 0, accumulate);
-    else TF_LAUNCH((conv3x3_small_kernel<false, true>), dim3(grid), dim3(256), stream, dy, w, nob, dx, g, Cout, Cin, 1, 0, accumulate);
+    if (prec == 2) { if (vec) TF_LAUNCH((conv3x3_small_kernel<true, 2>), dim3(grid), dim3(256), stream, dy, w, nob, dx, g, Cout, Cin, 1, 0, accumulate); else TF_LAUNCH((conv3x3_small_kernel<false, 2>), dim3(grid), dim3(256), stream, dy, w, nob, dx, g, Cout, Cin, 1, 0, accumulate); }
+    else if (prec == 1) { if (vec) TF_LAUNCH((conv3x3_small_kernel<true, 1>), dim3(grid), dim3(256), stream, dy, w, nob, dx, g, Cout, Cin, 1, 0, accumulate); else TF_LAUNCH((conv3x3_small_kernel<false, 1>), dim3(grid), dim3(256), stream, dy, w, nob, dx, g, Cout, Cin, 1, 0, accumulate); }
+    else { if (vec) TF_LAUNCH((conv3x3_small_kernel<true, 0>), dim3(grid), dim3(256), stream, dy, w, nob, dx, g, Cout, Cin, 1, 0, accumulate); else TF_LAUNCH((conv3x3_small_kernel<false, 0>), dim3(grid), dim3(256), stream, dy, w, nob, dx, g, Cout, Cin, 1, 0, accumulate); }
     return launch_status("tf_conv3x3_small_dgrad_f32");
 }
 
@@ -264,11 +278,11 @@ extern "C" int tf_conv3x3_small_wgrad_f32(const float* dy, const float* x, float
                "tf_conv3x3_small_wgrad_f32: needs Cin, Cout <= 32 and ws of tf_conv3x3_small_wgrad_ws_floats() floats");
     DcGeom g = make_geom(B, H, W, Cin, Cout);
     const int grid = g.ntiles < 256 ? g.ntiles : 256;
-    const bool vec = Cin % 4 == 0 && aligned16(x), lowp = tf::gemm_precision() == 1;   // precision 2 (bf16x3) keeps these kernels on the exact fp32 MFMA
-    if (vec && !lowp) TF_LAUNCH((conv3x3_small_wgrad_kernel<true, false>), dim3(grid), dim3(256), stream, x, dy, ws, g);
-    else if (!vec && !lowp) TF_LAUNCH((conv3x3_small_wgrad_kernel<false, false>), dim3(grid), dim3(256), stream, x, dy, ws, g);
-    else if (vec) TF_LAUNCH((conv3x3_small_wgrad_kernel<true, true>), dim3(grid), dim3(256), stream, x, dy, ws, g);
-    else TF_LAUNCH((conv3x3_small_wgrad_kernel<false, true>), dim3(grid), dim3(256), stream, x, dy, ws, g);
+    const bool vec = Cin % 4 == 0 && aligned16(x);
+    const int prec = direct_prec();
+    if (prec == 2) { if (vec) TF_LAUNCH((conv3x3_small_wgrad_kernel<true, 2>), dim3(grid), dim3(256), stream, x, dy, ws, g); else TF_LAUNCH((conv3x3_small_wgrad_kernel<false, 2>), dim3(grid), dim3(256), stream, x, dy, ws, g); }
+    else if (prec == 1) { if (vec) TF_LAUNCH((conv3x3_small_wgrad_kernel<true, 1>), dim3(grid), dim3(256), stream, x, dy, ws, g); else TF_LAUNCH((conv3x3_small_wgrad_kernel<false, 1>), dim3(grid), dim3(256), stream, x, dy, ws, g); }
+    else { if (vec) TF_LAUNCH((conv3x3_small_wgrad_kernel<true, 0>), dim3(grid), dim3(256), stream, x, dy, ws, g); else TF_LAUNCH((conv3x3_small_wgrad_kernel<false, 0>), dim3(grid), dim3(256), stream, x, dy, ws, g); }
     TF_LAUNCH(conv3x3_small_wgrad_reduce_kernel, dim3(36), dim3(256), stream, (const float*)ws, grid, dw, Cout, Cin, accumulate);
     return launch_status("tf_conv3x3_small_wgrad_f32");
 }

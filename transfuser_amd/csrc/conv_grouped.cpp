@@ -11,10 +11,11 @@
 // 9 accumulators (one per tap, 24 x 24 used of 32 x 32) per wave with the tile's pixels as the K dimension, reduced over the block's
 // waves through LDS and over a group's blocks by a second tiny kernel (deterministic, no atomics).
 #include "tf_common.h"
+#include <stdlib.h>
 #include "../../include/transfuser_hip.h"
 
 using namespace tf;
-namespace tf { int gemm_precision(); }   // api.cpp (tf_set_precision): 1 = bf16-MFMA contractions
+namespace tf { int gemm_precision(); }   // api.cpp (tf_set_precision): 1 = bf16-MFMA contractions, 2 = bf16x3 split (fp32-accurate) on the bf16 MFMA
 
 namespace {
 
@@ -61,7 +62,8 @@ __device__ __forceinline__ void store_patch_slot(float* patch, int s, const floa
 }
 
 // y[.., g*24 + co] = sum_{tap, ci} x[.. + tap, g*24 + ci] * W  (+ bias) (relu) (+= when accumulate); dgrad != 0: x is dY, y is dX
-template <int TW>
+// X3 = the bf16x3-split instantiation (tf_set_precision(2)); the default binary holds the fp32 path and the runtime-selected bf16 path
+template <int TW, bool X3 = false>
 __global__ void __launch_bounds__(256, 2) conv3x3_grouped_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                                  float* __restrict__ y, GcGeom g, int dgrad, int relu, int accumulate, int prec) {
     typedef Tile<TW> T;
@@ -91,8 +93,8 @@ __global__ void __launch_bounds__(256, 2) conv3x3_grouped_kernel(const float* __
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        if (prec) {
-            // bf16 MFMA (tf_set_precision(1)): per tap two 16-deep groups over the 24 (zero-padded to 32) input channels; lane half hi
+        if (X3 || prec) {
+            // bf16 MFMA (tf_set_precision(1); X3: bf16x3 split): per tap two 16-deep groups over the 24 (zero-padded to 32) input channels; lane half hi
             // owns channels 16 q + 8 hi .. + 7, so the upper half of the second group is all zeros
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
@@ -108,10 +110,10 @@ __global__ void __launch_bounds__(256, 2) conv3x3_grouped_kernel(const float* __
                         a[j] = live ? pa[k0 + j] : 0.f;
                         b[j] = live ? wl[tap * CG + k0 + j][l31] : 0.f;
                     }
-                    mfma_32x32x16_bf16(a, b, acc);
+                    if constexpr (X3) mfma_32x32x16_x3(a, b, acc); else mfma_32x32x16_bf16(a, b, acc);
                 }
             }
-        } else {
+        } else if constexpr (!X3) {
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int kh = tap / 3, kw = tap - kh * 3;
@@ -142,7 +144,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_grouped_kernel(const float* __
 
 // dW[g*24 + co][tap][ci] (+)= sum_pixels dY[p][g*24 + co] * X[p + tap][g*24 + ci]: per wave 32 pixels as K, 9 accumulators (one per tap);
 // part[(grp * nb + sub)][tap][32][32] partial panels, summed by conv3x3_grouped_wgrad_reduce_kernel.
-template <int TW, bool BF16>
+template <int TW, int PREC>
 __global__ void __launch_bounds__(256, 1) conv3x3_grouped_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part, GcGeom g) {
     typedef Tile<TW> T;
     __shared__ float lds[T::NPIX * PP + 128 * PP];
@@ -185,7 +187,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_grouped_wgrad_kernel(const flo
         __syncthreads();
         if (tile + g.nb < g.ntiles) fetch(tile + g.nb);
         // k = pixel 2 kk + hi of this wave's 32: A[i = co][k] = dyt (shared by the 9 taps), B[k][j = ci] = patch shifted by the tap
-        if constexpr (BF16) {      // bf16 MFMA: the wave's 32 pixels = two 16-deep K groups; lane half hi owns pixels 16 q + 8 hi .. + 7
+        if constexpr (PREC != 0) { // bf16 MFMA (PREC 1: rounded operands, 2: bf16x3 split): the wave's 32 pixels = two 16-deep K groups; lane half hi owns pixels 16 q + 8 hi .. + 7
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 float a[8], b[9][8];
@@ -197,8 +199,14 @@ __global__ void __launch_bounds__(256, 1) conv3x3_grouped_wgrad_kernel(const flo
 #pragma unroll
                     for (int tap = 0; tap < 9; ++tap) b[tap][j] = (l31 < CG) ? pb[((tap / 3) * T::PW + (tap % 3)) * PP] : 0.f;
                 }
+                if constexpr (PREC == 2) {      // the dY fragment is split once and shared by the 9 taps
+                    const Bf16x3 fa = split_bf16x3(a);
 #pragma unroll
-                for (int tap = 0; tap < 9; ++tap) mfma_32x32x16_bf16(a, b[tap], acc[tap]);
+                    for (int tap = 0; tap < 9; ++tap) mfma_x3_presplit(fa, split_bf16x3(b[tap]), acc[tap]);
+                } else {
+#pragma unroll
+                    for (int tap = 0; tap < 9; ++tap) mfma_32x32x16_bf16(a, b[tap], acc[tap]);
+                }
             }
         } else {
 #pragma unroll 2
@@ -248,6 +256,13 @@ __global__ void __launch_bounds__(256) conv3x3_grouped_wgrad_reduce_kernel(const
 
 constexpr int kMaxBlocks = 768;     // persistent grid: up to 3 blocks per CU
 
+// compute precision of these kernels; TF_X3_DIRECT=0 keeps them on the exact fp32 MFMA in f32x3 mode (A/B switch)
+inline int direct_prec() {
+    static const bool x3 = [] { const char* e = getenv("TF_X3_DIRECT"); return !e || atoi(e) != 0; }();
+    const int p = tf::gemm_precision();
+    return (p == 2 && !x3) ? 0 : p;
+}
+
 inline GcGeom make_geom(int B, int H, int W, int C, int TW, int max_blocks = kMaxBlocks) {
     GcGeom g; g.B = B; g.H = H; g.W = W; g.C = C; g.G = C / CG;
     const int th = TW == 16 ? 8 : 4;
@@ -273,8 +288,12 @@ extern "C" int tf_conv3x3_grouped_fwd_f32(const float* x, const float* w, const 
     TF_REQUIRE(args_ok(x, w, y, B, H, W, C), "tf_conv3x3_grouped_fwd_f32: needs NHWC tensors with C %% 24 == 0 (group width 24), 16-byte aligned");
     const int tw = pick_tw(H, W);
     GcGeom g = make_geom(B, H, W, C, tw);
-    if (tw == 16) TF_LAUNCH(conv3x3_grouped_kernel<16>, dim3(g.G * g.nb), dim3(256), stream, x, w, bias, y, g, 0, relu, 0, tf::gemm_precision() == 1);
-    else TF_LAUNCH(conv3x3_grouped_kernel<32>, dim3(g.G * g.nb), dim3(256), stream, x, w, bias, y, g, 0, relu, 0, tf::gemm_precision() == 1);
+    const int prec = direct_prec();
+    if (prec == 2) {
+        if (tw == 16) TF_LAUNCH((conv3x3_grouped_kernel<16, true>), dim3(g.G * g.nb), dim3(256), stream, x, w, bias, y, g, 0, relu, 0, 2);
+        else TF_LAUNCH((conv3x3_grouped_kernel<32, true>), dim3(g.G * g.nb), dim3(256), stream, x, w, bias, y, g, 0, relu, 0, 2);
+    } else if (tw == 16) TF_LAUNCH((conv3x3_grouped_kernel<16, false>), dim3(g.G * g.nb), dim3(256), stream, x, w, bias, y, g, 0, relu, 0, prec);
+    else TF_LAUNCH((conv3x3_grouped_kernel<32, false>), dim3(g.G * g.nb), dim3(256), stream, x, w, bias, y, g, 0, relu, 0, prec);
     return launch_status("tf_conv3x3_grouped_fwd_f32");
 }
 
@@ -282,8 +301,13 @@ extern "C" int tf_conv3x3_grouped_dgrad_f32(const float* dy, const float* w, flo
     TF_REQUIRE(args_ok(dy, w, dx, B, H, W, C), "tf_conv3x3_grouped_dgrad_f32: needs NHWC tensors with C %% 24 == 0 (group width 24), 16-byte aligned");
     const int tw = pick_tw(H, W);
     GcGeom g = make_geom(B, H, W, C, tw);
-    if (tw == 16) TF_LAUNCH(conv3x3_grouped_kernel<16>, dim3(g.G * g.nb), dim3(256), stream, dy, w, (const float*)nullptr, dx, g, 1, 0, accumulate, tf::gemm_precision() == 1);
-    else TF_LAUNCH(conv3x3_grouped_kernel<32>, dim3(g.G * g.nb), dim3(256), stream, dy, w, (const float*)nullptr, dx, g, 1, 0, accumulate, tf::gemm_precision() == 1);
+    const int prec = direct_prec();
+    const float* nob = nullptr;
+    if (prec == 2) {
+        if (tw == 16) TF_LAUNCH((conv3x3_grouped_kernel<16, true>), dim3(g.G * g.nb), dim3(256), stream, dy, w, nob, dx, g, 1, 0, accumulate, 2);
+        else TF_LAUNCH((conv3x3_grouped_kernel<32, true>), dim3(g.G * g.nb), dim3(256), stream, dy, w, nob, dx, g, 1, 0, accumulate, 2);
+    } else if (tw == 16) TF_LAUNCH((conv3x3_grouped_kernel<16, false>), dim3(g.G * g.nb), dim3(256), stream, dy, w, nob, dx, g, 1, 0, accumulate, prec);
+    else TF_LAUNCH((conv3x3_grouped_kernel<32, false>), dim3(g.G * g.nb), dim3(256), stream, dy, w, nob, dx, g, 1, 0, accumulate, prec);
     return launch_status("tf_conv3x3_grouped_dgrad_f32");
 }
 
@@ -296,11 +320,11 @@ extern "C" int tf_conv3x3_grouped_wgrad_f32(const float* dy, const float* x, flo
     GcGeom g = make_geom(B, H, W, C, tw, 256);
     if (g.nb > 1 && g.ntiles / g.nb < 6) { g.nb = g.ntiles / 6; if (g.nb < 1) g.nb = 1; }
     TF_REQUIRE((long)g.G * g.nb * 9216 <= tf_conv3x3_grouped_wgrad_ws_floats(), "tf_conv3x3_grouped_wgrad_f32: %d groups exceed the workspace", g.G);
-    const bool lowp = tf::gemm_precision() == 1;   // precision 2 (bf16x3) keeps these kernels on the exact fp32 MFMA
-    if (tw == 16 && !lowp) TF_LAUNCH((conv3x3_grouped_wgrad_kernel<16, false>), dim3(g.G * g.nb), dim3(256), stream, x, dy, ws, g);
-    else if (tw == 16) TF_LAUNCH((conv3x3_grouped_wgrad_kernel<16, true>), dim3(g.G * g.nb), dim3(256), stream, x, dy, ws, g);
-    else if (!lowp) TF_LAUNCH((conv3x3_grouped_wgrad_kernel<32, false>), dim3(g.G * g.nb), dim3(256), stream, x, dy, ws, g);
-    else TF_LAUNCH((conv3x3_grouped_wgrad_kernel<32, true>), dim3(g.G * g.nb), dim3(256), stream, x, dy, ws, g);
+    const int prec = direct_prec();
+#define TF_GW(TW_, P_) TF_LAUNCH((conv3x3_grouped_wgrad_kernel<TW_, P_>), dim3(g.G * g.nb), dim3(256), stream, x, dy, ws, g)
+    if (tw == 16) { if (prec == 2) TF_GW(16, 2); else if (prec == 1) TF_GW(16, 1); else TF_GW(16, 0); }
+    else { if (prec == 2) TF_GW(32, 2); else if (prec == 1) TF_GW(32, 1); else TF_GW(32, 0); }
+#undef TF_GW
     TF_LAUNCH(conv3x3_grouped_wgrad_reduce_kernel, dim3(36, g.G), dim3(256), stream, (const float*)ws, g.nb, dw, accumulate);
     return launch_status("tf_conv3x3_grouped_wgrad_f32");
 }

@@ -639,10 +639,11 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 2 : ((BM * BN >= 128 * 96) ? 3
 struct GemmPlan { int bm, bn, bk, splitk; int kind = 0; };
 
 // LDS-DMA configurations (tf_gemm_dma.h); the launchers live in gemm_dma_{nt,nn,tn,tt}.cpp (one translation unit per operand layout)
-constexpr int kDmaKinds = 5;
+constexpr int kDmaKinds = 8;
 struct DmaKindInfo { int bm, bn, bk; };
 inline DmaKindInfo dma_kind_info(int kind) {
-    static const DmaKindInfo t[kDmaKinds + 1] = {{0, 0, 0}, {128, 128, 16}, {64, 64, 16}, {128, 64, 16}, {64, 128, 16}, {128, 128, 32}};
+    static const DmaKindInfo t[kDmaKinds + 1] = {{0, 0, 0}, {128, 128, 16}, {64, 64, 16}, {128, 64, 16}, {64, 128, 16}, {128, 128, 32},
+                                                 {64, 64, 16}, {64, 128, 16}, {128, 64, 16}};   // 6-8: one 64x64 accumulator block per wave (1 / 2 / 2 waves)
     return t[(kind >= 1 && kind <= kDmaKinds) ? kind : 0];
 }
 template <bool A_KC, bool B_KC>

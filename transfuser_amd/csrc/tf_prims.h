@@ -167,6 +167,15 @@ __device__ __forceinline__ void mfma_tiles_x3(const float (&a)[TM][8], const flo
 #undef TF_X3_TERM
 }
 
+// single-tile forms for the direct convolution kernels: both operands split in registers / a pre-split A fragment shared by several tiles
+__device__ __forceinline__ void mfma_x3_presplit(const Bf16x3& fa, const Bf16x3& fb, f32x16& acc) {
+    mfma_bf16_raw(fa.l, fb.h, acc); mfma_bf16_raw(fa.h, fb.l, acc); mfma_bf16_raw(fa.m, fb.m, acc);
+    mfma_bf16_raw(fa.m, fb.h, acc); mfma_bf16_raw(fa.h, fb.m, acc); mfma_bf16_raw(fa.h, fb.h, acc);
+}
+__device__ __forceinline__ void mfma_32x32x16_x3(const float (&a)[8], const float (&b)[8], f32x16& acc) {
+    mfma_x3_presplit(split_bf16x3(a), split_bf16x3(b), acc);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += shfl_xor(v, m);
