@@ -50,7 +50,11 @@ int tf_plans_load(const char* path);
  *   b_trans = 0: B(k,j) = b[j*ldb + k]  (torch Linear / conv weight [out][in])
  *   b_trans = 1: B(k,j) = b[k*ldb + j]
  *   batch z in [0,batch): offset = (z / inner) * s?_outer + (z % inner) * s?_inner
- *   accumulate: 0 store, 1 C += (split-K with fp32 atomics may be used) */
+ *   accumulate: 0 store, 1 C += (split-K with fp32 atomics may be used)
+ *   splitk_ws / splitk_ws_floats: optional caller-owned scratch (stream-ordered with this call).  When given, GEMMs whose output has too few
+ *   tiles to fill the 256 CUs (e.g. the GPT-4 [1740 x 6048] . [6048 x 1512] MLP contraction: 168 tiles of 128 x 128) may run as a
+ *   deterministic TWO-PASS split-K: S k-slices write partial tiles into the scratch, a fix-up kernel sums them in slice order and applies the
+ *   epilogue (alpha, bias, residual, ReLU, mask, store / +=).  Needs S * m * round_up(n, 4) floats (S <= 4); NULL disables it. */
 typedef struct {
     const float* a; const float* b; float* c; const float* bias; const float* res;
     int m, n, k;
@@ -61,6 +65,7 @@ typedef struct {
     float alpha; int relu; int accumulate;
     const float* mask; int64_t ldmask;   /* optional (batch == 1, store mode): c(i,j) is zeroed unless mask[i*ldmask + j] > 0 - the ReLU
                                           * mask of a backward GEMM (dX = (dY W) * [act > 0]) fused into the epilogue */
+    float* splitk_ws; int64_t splitk_ws_floats;
 } tf_gemm_desc;
 int tf_gemm_f32(const tf_gemm_desc* d, void* stream);
 

@@ -572,8 +572,8 @@ def check_engine_plan(dev, bm, bn, bk, splitk):
 
 
 # ---------------------------------------------------------------- LDS-DMA GEMM configurations (tf_gemm_dma.h), kind 1..5 (+ split-K)
-DMA_KINDS = [(1, 1), (2, 1), (3, 1), (4, 1), (5, 1), (2, 3), (1, 2), (6, 1), (7, 1), (8, 2)]
-DMA_SHAPES_SMALL = [(130, 216, 40), (200, 92, 152), (70, 36, 20)]
+DMA_KINDS = [(1, 1), (2, 1), (3, 1), (4, 1), (5, 1), (2, 3), (1, 2), (6, 1), (7, 1), (8, 2), (2, 320), (6, 160)]   # (kind, atomic split-K count); counts >= 100 once collided with the two-pass encoding
+DMA_SHAPES_SMALL = [(130, 216, 40), (200, 92, 152), (70, 36, 20), (64, 64, 2600)]
 DMA_SHAPES_GPU = [(1740, 1512, 576), (333, 700, 1028), (130, 216, 40), (64, 64, 16), (1740, 216, 864)]
 
 
@@ -931,3 +931,32 @@ def check_f32x3_direct(dev):
     finally:
         ops.set_precision("fp32")
         ops._DIRECT_MIN_PIXELS = old
+
+
+# ---------------------------------------------------------------- deterministic two-pass split-K (few-tile outputs, csrc/gemm_fixup.cpp)
+TWO_PASS = 1000000       # tf_gemm_engine.h kTwoPass: splitk = TWO_PASS + S
+TWO_PASS_CASES = [(1, TWO_PASS + 2), (2, TWO_PASS + 3), (5, TWO_PASS + 4), (6, TWO_PASS + 3), (8, TWO_PASS + 2)]
+
+
+def check_two_pass_splitk(dev, kind, sk):
+    """k-slices store partial tiles into caller scratch, the fix-up pass sums them in order and applies the epilogue: every epilogue form
+    (bias + residual + ReLU; ReLU mask; accumulate), all four operand layouts, ragged N (scalar fix-up path), bitwise run-to-run equal."""
+    ops.force_dma(kind, sk)
+    try:
+        for (m, n, k) in ((200, 92, 600), (130, 216, 1030), (257, 130, 520)):
+            x, w, b, r = R(m, k, dev=dev), R(n, k, dev=dev), R(n, dev=dev), R(m, n, dev=dev)
+            y = ops.linear_fwd(x, w, b, relu=True, res=r)
+            close(y, torch.relu(x @ w.t() + b + r), what="two-pass fwd")
+            assert torch.equal(y, ops.linear_fwd(x, w, b, relu=True, res=r)), "two-pass split-K must be run-to-run deterministic"
+            dy, act = R(m, n, seed=1, dev=dev), R(m, k, seed=5, dev=dev)
+            if n % 4 == 0:
+                close(ops.linear_dgrad(dy, w, mask=act), (dy @ w) * (act > 0), what="two-pass dgrad + mask")
+            dw0 = R(n, k, seed=2, dev=dev)
+            close(ops.linear_wgrad(dy, x, dw0.clone(), accumulate=True), dw0 + dy.t() @ x, what="two-pass wgrad (+=)") if (n % 4 == 0) else None
+            a, bb = R(m, k, dev=dev), R(n, k, seed=4, dev=dev)
+            if m % 4 == 0:
+                c = torch.empty(m, n, device=dev)
+                ops.gemm(a.t().contiguous(), bb, c, m, n, k, m, k, n, a_trans=True, alpha=0.5)
+                close(c, 0.5 * (a @ bb.t()), what="two-pass tt")
+    finally:
+        ops.force_plan(0)

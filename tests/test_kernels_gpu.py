@@ -121,6 +121,11 @@ def test_grouped_conv_direct(case):
     kc.check_conv_grouped("cuda", *case)
 
 
+@pytest.mark.parametrize("cfg", kc.TWO_PASS_CASES, ids=str)
+def test_two_pass_splitk(cfg):
+    kc.check_two_pass_splitk("cuda", *cfg)
+
+
 def test_f32x3_split_mode_direct_convs():
     kc.check_f32x3_direct("cuda")
 

@@ -36,5 +36,12 @@ x3_retune)  awk -F';' '/^#/ || $6<8' transfuser_amd/plans/mi355x.txt > $O/plans_
 x3_ab2)     for v in "f32x3 1" "f32x3 0" "f32 1" "f32x3 1" "f32x3 0"; do set -- $v; TF_X3_DIRECT=$2 TF_PLANS=$O/mi355x_x3.txt timeout 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-alt --dtype $1 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('dtype $1 TF_X3_DIRECT=$2', d['ms_per_step'], 'ms/step', d['value'], 'samples/s; loss', d['config']['final_loss'], '; GPT4 fc1', d['roofline']['avg_launch_us'], 'us', d['roofline']['achieved'], 'TF/s; engine', d['roofline']['engine_ms_per_step'], 'ms')"; done ;;
 x3_tests2)  timeout 600 python -m pytest tests/test_kernels_gpu.py -q -k "f32x3 or gemm_dma or bf16" 2>&1 | tail -8 ;;
 census_x3)  timeout 300 python tools/census.py 10 256 f32x3 > $O/r02_census_f32x3.txt 2>&1; head -70 $O/r02_census_f32x3.txt ;;
+tp_tests)   timeout 600 python -m pytest tests/test_kernels_gpu.py -q -k "two_pass or gemm_dma or test_gemm or bench_shape" 2>&1 | tail -8 ;;
+retune_all) TF_RETUNE=1 timeout 900 python tools/tune.py $O/mi355x_r02b.txt 10 256,160 fp32,f32x3,bf16 2>&1 | tail -8 ;;
+ab_tp)      for v in "f32 1" "f32 0" "f32x3 1" "f32x3 0" "f32 1" "f32x3 1"; do set -- $v; TF_TWO_PASS_SPLITK=$2 TF_PLANS=$O/mi355x_r02b.txt timeout 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-alt --dtype $1 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('dtype $1 TWO_PASS=$2', d['ms_per_step'], 'ms/step', d['value'], 'samples/s; loss', d['config']['final_loss'], '; GPT4 fc1', d['roofline']['avg_launch_us'], 'us', d['roofline']['achieved'], 'TF/s; engine', d['roofline']['engine_ms_per_step'], 'ms')"; done ;;
+diag_tp)    TF_TWO_PASS_SPLITK=0 TF_RETUNE=1 timeout 150 python tools/tune.py $O/diag_notp.txt 10 256 fp32 2>&1 | tail -3
+            TF_TRACE_GEMM=1 TF_RETUNE=1 timeout 200 python tools/tune.py $O/diag_tp.txt 10 256 fp32 > $O/diag_tp.log 2>&1; tail -6 $O/diag_tp.log | cut -c1-300 ;;
+diag_tp2)   TF_TRACE_CALLS=1 TF_TRACE_GEMM=1 TF_RETUNE=1 timeout 250 python tools/tune.py $O/diag_tp.txt 10 256 fp32 > $O/diag_tp.log 2>&1; tail -12 $O/diag_tp.log | cut -c1-300 ;;
+diag_tp3)   TF_TRACE_TUNE=1 TF_RETUNE=1 timeout 250 python tools/tune.py $O/diag_tp.txt 10 256 fp32 > $O/diag_tp.log 2>&1; grep -v "ok$" $O/diag_tp.log | tail -8 | cut -c1-300; tail -5 $O/diag_tp.log | cut -c1-300 ;;
 esac
 done

@@ -27,7 +27,8 @@ class GemmDesc(ctypes.Structure):
                 ("lda", c_l), ("ldb", c_l), ("ldc", c_l), ("ldres", c_l),
                 ("batch", c_i), ("inner", c_i),
                 ("sa_outer", c_l), ("sa_inner", c_l), ("sb_outer", c_l), ("sb_inner", c_l), ("sc_outer", c_l), ("sc_inner", c_l),
-                ("alpha", c_f), ("relu", c_i), ("accumulate", c_i), ("mask", c_p), ("ldmask", c_l)]
+                ("alpha", c_f), ("relu", c_i), ("accumulate", c_i), ("mask", c_p), ("ldmask", c_l),
+                ("splitk_ws", c_p), ("splitk_ws_floats", c_l)]
 
 
 class ConvGeom(ctypes.Structure):
@@ -61,7 +62,14 @@ def is_test_backend():
     return _test_backend
 
 
+_TRACE = os.environ.get("TF_TRACE_CALLS", "0") == "1"
+
+
 def check(rc, what=""):
+    if _TRACE:      # debugging aid: wait for every C-ABI call and name it once it has COMPLETED (a GPU fault then belongs to the next call)
+        torch.cuda.synchronize()
+        import sys
+        print("[done] %s" % what, file=sys.stderr, flush=True)
     if rc != 0:
         raise RuntimeError("transfuser_hip %s failed (%d): %s" % (what, rc, load().tf_last_error().decode()))
 

@@ -77,7 +77,7 @@ extern "C" int tf_plans_save(const char* path) {
     std::lock_guard<std::mutex> lk(tf::g_plan_mu);
     FILE* f = fopen(path, "w");
     if (!f) { tf::set_error("tf_plans_save: cannot open %s", path); return -1; }
-    fprintf(f, "# transfuser_hip GEMM plans: site;M;N;K;batch;acc;bm;bn;bk;splitk;kind   (kind 0 = register-staged kernel, >= 1 = LDS-DMA configuration)\n");
+    fprintf(f, "# transfuser_hip GEMM plans: site;M;N;K;batch;acc;bm;bn;bk;splitk;kind   (kind 0 = register-staged kernel, >= 1 = LDS-DMA configuration; splitk >= 1000000 = deterministic two-pass split-K with splitk - 1000000 slices)\n");
     for (auto& kv : tf::g_plans)
         fprintf(f, "%s;%d;%d;%d;%d;%d;%d;%d;%d;%d;%d\n", std::get<0>(kv.first).c_str(), std::get<1>(kv.first), std::get<2>(kv.first), std::get<3>(kv.first),
                 std::get<4>(kv.first), std::get<5>(kv.first), kv.second.bm, kv.second.bn, kv.second.bk, kv.second.splitk, kv.second.kind);

@@ -40,6 +40,7 @@ extern "C" int tf_gemm_f32(const tf_gemm_desc* d, void* stream) {
     ep.bias = d->bias; ep.sbias = 0; ep.res = d->res; ep.ldres = d->ldres; ep.alpha = d->alpha; ep.relu = d->relu;
     ep.mode = d->accumulate ? 1 : 0;
     ep.mask = d->mask; ep.ldmask = d->ldmask;
+    ep.sk_ws = d->splitk_ws; ep.sk_ws_floats = d->splitk_ws ? d->splitk_ws_floats : 0;
     TF_REQUIRE(!d->mask || (d->batch == 1 && !d->accumulate), "tf_gemm_f32: mask needs batch == 1 and a plain store");
     // A: KC when stored [m][k] (rows = i), IC when stored [k][m] (rows = k)
     PlainOp A = d->a_trans ? make_plain(d->a, d->lda, d->k, d->m, d->sa_outer, d->sa_inner, inner, d->batch)

@@ -284,7 +284,9 @@ __device__ __forceinline__ void gemm_dma_tile(const PlainOp& la_in, const PlainO
     }
     dma_wait<0>();      // drain the (all-zero) tail requests before the epilogue's own loads / the end of the block
 
-    gemm_epilogue<TM, TN>(acc, ep, M, N, i0, j0, BM, BN, wm0, wn0, z);
+    GemmEpi epo = ep;
+    epo.C += (long)blockIdx.y * ep.sk_stride;       // two-pass split-K: this k-slice's partial tile (sk_stride = 0 otherwise)
+    gemm_epilogue<TM, TN>(acc, epo, M, N, i0, j0, BM, BN, wm0, wn0, z);
 }
 
 // X3 = the bf16x3-split instantiation (tf_set_precision(2)): a separate kernel, so the fp32 / bf16 binary keeps its register allocation
@@ -308,12 +310,19 @@ template <int TM, int TN, int WAVES_M, int WAVES_N, int BK, int STAGES, bool A_K
 inline void launch_dma_cfg(const PlainOp& la, const PlainOp& lb, const GemmEpi& ep, int M, int N, int K, int batch, int splitk, void* stream) {
     typedef DmaCfg<TM, TN, WAVES_M, WAVES_N, BK, STAGES, A_KC, B_KC> C;
     const int tiles_m = cdiv(M, C::BM), tiles_n = cdiv(N, C::BN);
+    const bool twopass = splitk >= kTwoPass;       // eligibility was checked by launch_gemm (twopass_ok)
+    if (twopass) splitk -= kTwoPass;
     int kchunk = cdiv(cdiv(K, splitk), BK) * BK;
     if (kchunk < BK) kchunk = BK;
     const int nsplit = cdiv(K, kchunk);
     dim3 grid(tiles_m * tiles_n, nsplit > 0 ? nsplit : 1, batch);
     GemmEpi epg = ep;
     epg.prec = gemm_precision();
+    const int ldws = twopass_ldws(N);
+    if (twopass) {      // slices store raw partial sums [M][ldws] into the caller's scratch; the epilogue proper runs in the fix-up pass
+        epg.C = ep.sk_ws; epg.ldc = ldws; epg.ldcj = 1; epg.sc_outer = epg.sc_inner = 0; epg.inner = 1; epg.bias = nullptr; epg.res = nullptr;
+        epg.mask = nullptr; epg.alpha = 1.f; epg.relu = 0; epg.mode = 0; epg.sk_stride = (long)M * ldws;
+    }
     {
         long panel = (long)C::BM * (kchunk < K ? kchunk : K) * 4;
         int g = (int)((2L << 20) / (panel > 0 ? panel : 1));
@@ -327,6 +336,7 @@ inline void launch_dma_cfg(const PlainOp& la, const PlainOp& lb, const GemmEpi& 
     else
         TF_LAUNCH((gemm_dma_kernel<TM, TN, WAVES_M, WAVES_N, BK, STAGES, A_KC, B_KC, OCC, false>), grid, dim3(C::NT), stream, la, lb, epg, M, N, K,
                   tiles_m, tiles_n, kchunk);
+    if (twopass) launch_splitk_fixup(ep.sk_ws, nsplit, (long)M * ldws, ldws, ep, M, N, stream);
 }
 
 }  // namespace tf

@@ -243,6 +243,8 @@ struct GemmEpi {
     float alpha; int relu; int mode; // mode 0: store, 1: +=, 2: atomicAdd
     int group_m = 1;                 // tile rasterisation: rows of tiles walked together (set by launch_cfg)
     const float* mask = nullptr; long ldmask = 0;   // optional ReLU mask of a backward GEMM: element (i, j) is zeroed unless mask(i, j) > 0
+    long sk_stride = 0;              // two-pass split-K: k-slice blockIdx.y stores its partial tile at C + blockIdx.y * sk_stride (LDS-DMA kernels)
+    float* sk_ws = nullptr; long sk_ws_floats = 0;   // host side only: caller-owned scratch that makes the two-pass split-K eligible (tf_gemm_desc)
     int prec = 0;                    // 0: exact fp32 MFMA; 1: operands rounded to bf16 on the LDS->register path, bf16 MFMA, fp32 accumulate; 2: bf16x3 split (fp32-accurate, 6 bf16 MFMAs) (set by launch_cfg)
 };
 
@@ -650,6 +652,15 @@ template <bool A_KC, bool B_KC>
 void launch_dma_plan(int kind, const PlainOp& la, const PlainOp& lb, const GemmEpi& ep, int M, int N, int K, int batch, int splitk, void* stream);
 bool dma_eligible(const PlainOp& a, const PlainOp& b);
 
+// two-pass split-K (gemm_fixup.cpp): C (op)= epilogue(sum_s ws[s]) with the slices summed in order; ws slices are [M][ldws] row-major
+void launch_splitk_fixup(const float* ws, int nsplit, long sk_stride, int ldws, const GemmEpi& ep, int M, int N, void* stream);
+constexpr int kTwoPass = 1000000;  // GemmPlan.splitk >= kTwoPass: two-pass split-K with S = splitk - kTwoPass slices (LDS-DMA kinds only); atomic split counts stay far below
+inline int twopass_ldws(int N) { return (N + 3) & ~3; }
+// eligibility of the two-pass split for this call: plain row-major single-batch output and enough caller scratch for S slices
+inline bool twopass_ok(const GemmEpi& ep, int M, int N, int batch, int S) {
+    return ep.sk_ws && batch == 1 && ep.ldcj == 1 && (ep.mode == 0 || ep.mode == 1) && S >= 2 && S <= 4 && (long)S * M * twopass_ldws(N) <= ep.sk_ws_floats;
+}
+
 // plan cache + autotuner state (api.cpp)
 bool plan_lookup(const char* what, int M, int N, int K, int batch, int acc, GemmPlan* out);
 void plan_store(const char* what, int M, int N, int K, int batch, int acc, const GemmPlan& p);
@@ -717,10 +728,11 @@ inline void launch_plan(const GemmPlan& p, const LA& la, const LB& lb, const Gem
             return;
         }
     }
+    const int sk = p.splitk >= kTwoPass ? 1 : p.splitk;       // the two-pass split exists in the LDS-DMA kernels only
 #define TF_CFG(BM_, BN_, WM_)                                                                                      \
     do {                                                                                                           \
-        if (p.bk == 32) launch_cfg<BM_, BN_, WM_, 32, LA, A_KC, LB, B_KC>(la, lb, ep, M, N, K, batch, p.splitk, stream); \
-        else launch_cfg<BM_, BN_, WM_, 16, LA, A_KC, LB, B_KC>(la, lb, ep, M, N, K, batch, p.splitk, stream);       \
+        if (p.bk == 32) launch_cfg<BM_, BN_, WM_, 32, LA, A_KC, LB, B_KC>(la, lb, ep, M, N, K, batch, sk, stream); \
+        else launch_cfg<BM_, BN_, WM_, 16, LA, A_KC, LB, B_KC>(la, lb, ep, M, N, K, batch, sk, stream);       \
     } while (0)
     if (p.bm == 128) {
         if (p.bn == 32) TF_CFG(128, 32, 4);
@@ -736,6 +748,14 @@ inline void launch_plan(const GemmPlan& p, const LA& la, const LB& lb, const Gem
 }
 
 #ifndef TF_EMU
+// TF_TRACE_TUNE=1: name every autotune candidate before it is launched and wait for it (debugging aid: a GPU fault then names its plan)
+inline bool trace_tune() { static const bool on = [] { const char* e = getenv("TF_TRACE_TUNE"); return e && atoi(e) != 0; }(); return on; }
+inline void trace_candidate(const GemmPlan& p, int M, int N, int K, int batch, int mode, void* stream, bool before) {
+    if (!trace_tune()) return;
+    if (before) fprintf(stderr, "[tune] %dx%dx%d batch %d: tile %dx%dx%d splitk %d kind %d mode %d ...", M, N, K, batch, p.bm, p.bn, p.bk, p.splitk, p.kind, mode);
+    else { hipError_t e = hipStreamSynchronize((hipStream_t)stream); fprintf(stderr, " %s\n", e == hipSuccess ? "ok" : hipGetErrorString(e)); }
+    fflush(stderr);
+}
 // cudnn.benchmark-style tuning (the reference enables it, train.py:115): time every candidate tiling of this exact
 // problem ONCE with HIP events during eager warm-up; the winner goes into the plan cache.  Trial launches of
 // accumulating epilogues run with alpha = 0 so the destination is left unchanged.
@@ -763,7 +783,9 @@ inline GemmPlan autotune_gemm(const LA& la, const LB& lb, const GemmEpi& ep, int
                 GemmPlan p{bm, bn, bk, sks[s], 0};
                 GemmEpi e = trial;
                 if (p.splitk > 1) { if (ep.mode == 0) continue; e.mode = 2; }
+                trace_candidate(p, M, N, K, batch, e.mode, stream, true);
                 launch_plan<LA, A_KC, LB, B_KC>(p, la, lb, e, M, N, K, batch, stream);   // warm
+                trace_candidate(p, M, N, K, batch, e.mode, stream, false);
                 float ms = 1e30f;
                 for (int pass = 0; pass < 3; ++pass) {     // best of three groups of 4 launches: one noisy group must not decide a plan
                     hipEventRecord(e0, (hipStream_t)stream);
@@ -789,11 +811,18 @@ inline GemmPlan autotune_gemm(const LA& la, const LB& lb, const GemmEpi& ep, int
                     const int h = heuristic_splitk(M, N, K, batch, ki.bm, ki.bn, ki.bk);
                     if (h > 1) { sks[nsk++] = h; if (h >= 4) sks[nsk++] = h / 2; }
                 }
-                for (int s = 0; s < nsk; ++s) {
-                    GemmPlan p{ki.bm, ki.bn, ki.bk, sks[s], kind};
+                int cand[8], nc = 0;
+                for (int s = 0; s < nsk; ++s) cand[nc++] = sks[s];
+                if ((long)cdiv(M, ki.bm) * cdiv(N, ki.bn) < 512 && K >= 32 * ki.bk)      // too few tiles for the 256 CUs: deterministic two-pass split
+                    for (int S = 2; S <= 4; ++S)
+                        if (twopass_ok(ep, M, N, batch, S)) cand[nc++] = kTwoPass + S;
+                for (int s = 0; s < nc; ++s) {
+                    GemmPlan p{ki.bm, ki.bn, ki.bk, cand[s], kind};
                     GemmEpi e = trial;
-                    if (p.splitk > 1) { if (ep.mode == 0) continue; e.mode = 2; }
+                    if (p.splitk > 1 && p.splitk < kTwoPass) { if (ep.mode == 0) continue; e.mode = 2; }
+                    trace_candidate(p, M, N, K, batch, e.mode, stream, true);
                     launch_plan<LA, A_KC, LB, B_KC>(p, la, lb, e, M, N, K, batch, stream);
+                    trace_candidate(p, M, N, K, batch, e.mode, stream, false);
                     float ms = 1e30f;
                     for (int pass = 0; pass < 3; ++pass) {
                         hipEventRecord(e0, (hipStream_t)stream);
@@ -823,7 +852,7 @@ inline int launch_gemm(const LA& la, const LB& lb, GemmEpi ep, int M, int N, int
     const int acc = (ep.mode != 0 ? (sk_ok ? 2 : 1) : 0) + 4 * gemm_precision();   // plans are tuned per compute precision
     GemmPlan p;
     if (forced_plan(&p)) {
-        if (!sk_ok) p.splitk = 1;
+        if (!sk_ok && p.splitk < kTwoPass) p.splitk = 1;
     } else if (!plan_lookup(what, M, N, K, batch, acc, &p)) {
 #ifndef TF_EMU
         if (autotune_enabled()) {
@@ -833,8 +862,12 @@ inline int launch_gemm(const LA& la, const LB& lb, GemmEpi ep, int M, int N, int
 #endif
             p = plan_gemm(M, N, K, batch, sk_ok);
     }
-    if (!sk_ok) p.splitk = 1;
-    if (p.splitk > 1) ep.mode = 2;
+    if (p.splitk >= kTwoPass) {
+        if (p.kind < 1 || !twopass_ok(ep, M, N, batch, p.splitk - kTwoPass)) p.splitk = 1;     // no scratch on this call / not a plain output
+    } else {
+        if (!sk_ok) p.splitk = 1;
+        if (p.splitk > 1) ep.mode = 2;
+    }
     launch_plan<LA, A_KC, LB, B_KC>(p, la, lb, ep, M, N, K, batch, stream);
     return launch_status(what);
 }
