@@ -107,15 +107,16 @@ def dominant_kernel_roofline(eng, batch, dev, log, peak=PEAK_F32_MFMA_TF):
     roof.update(engine_calls=len(rows), engine_ms_per_step=round(tot_s * 1e3, 2), engine_tflops=round(tot_fl / tot_s / 1e12, 2),
                 engine_frac=round(tot_fl / tot_s / 1e12 / PEAK, 4))
     roof["traffic"], roof["traffic_source"] = None, "no PMC summary committed"
-    if os.path.exists(PMC_FILE) and dom and peak == PEAK_F32_MFMA_TF:
+    pmc_file = PMC_FILE if peak == PEAK_F32_MFMA_TF else PMC_FILE.replace(".json", "_f32x3.json") if peak < PEAK_BF16_MFMA_TF else ""
+    if pmc_file and os.path.exists(pmc_file) and dom:
         try:
-            pmc = json.load(open(PMC_FILE))
+            pmc = json.load(open(pmc_file))
             roof["traffic"] = int(pmc["traffic_bytes_per_launch"])
-            roof["traffic_source"] = "profiles/%s: %s" % (os.path.basename(PMC_FILE), pmc.get("note", ""))
+            roof["traffic_source"] = "profiles/%s: %s" % (os.path.basename(pmc_file), pmc.get("note", ""))
             if pmc.get("mfma_busy_frac") is not None:
                 roof["mfma_busy_frac_pmc"] = pmc["mfma_busy_frac"]
         except Exception as e:   # a malformed summary must not kill the bench line
-            roof["traffic_source"] = "unreadable %s: %s" % (PMC_FILE, e)
+            roof["traffic_source"] = "unreadable %s: %s" % (pmc_file, e)
     log("in-step roofline census done (%d engine launches)" % len(rows))
     return roof
 

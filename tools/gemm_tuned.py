@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Launches ONE GEMM shape under the shipped tuned plan (transfuser_amd/plans/mi355x.txt) - the PMC target of tools/pmc_roofline.sh.
-python tools/gemm_tuned.py M N K [form nt|nn|tn] [iters]"""
+python tools/gemm_tuned.py M N K [form nt|nn|tn] [iters] [precision fp32|f32x3|bf16]"""
 import os, sys, torch
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, ROOT)
@@ -8,6 +8,7 @@ from transfuser_amd import ops
 M, N, K = [int(v) for v in sys.argv[1:4]]
 form = sys.argv[4] if len(sys.argv) > 4 else "nt"
 iters = int(sys.argv[5]) if len(sys.argv) > 5 else 10
+ops.set_precision(sys.argv[6] if len(sys.argv) > 6 else "fp32")
 ops.plans_load(os.path.join(ROOT, "transfuser_amd", "plans", "mi355x.txt"))
 dev = "cuda"
 x = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev) * 0.02; b = torch.zeros(N, device=dev); out = torch.empty(M, N, device=dev)

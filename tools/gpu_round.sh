@@ -10,7 +10,8 @@ tests_new)  timeout 900 python -m pytest tests/test_model_gpu.py -q -k "graph or
 tests_all)  timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -25 > $O/r02_gpu_tests.log; tail -8 $O/r02_gpu_tests.log ;;
 bench)      timeout 420 python bench.py --steps 20 --warmup 5 > $O/r02_bench_n1.json 2> $O/r02_bench_n1.err; tail -4 $O/r02_bench_n1.err; cat $O/r02_bench_n1.json ;;
 bench_fast) timeout 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/r02_bench_fast.json 2> $O/r02_bench_fast.err; tail -2 $O/r02_bench_fast.err; cat $O/r02_bench_fast.json ;;
-pmc)        timeout 600 bash tools/pmc_roofline.sh 2>&1 | tail -20 ;;
+pmc)        timeout 600 bash tools/pmc_roofline.sh fp32 2>&1 | tail -12 ;;
+pmc_x3)     timeout 600 bash tools/pmc_roofline.sh f32x3 2>&1 | tail -12 ;;
 hbm)        timeout 200 python tools/hbm_bench.py > $O/r02_hbm_kernels.txt 2>&1; cat $O/r02_hbm_kernels.txt ;;
 trace)      (cd /tmp && export TMPDIR=/tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $O/trace_r02 -o step --output-format csv -- python $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline $BENCH_ARGS > $O/r02_trace_bench.log 2>&1)
             python tools/trace_csv_stats.py $O/trace_r02 > $O/r02_kernel_trace_graph${TRACE_TAG}.txt 2>&1; head -45 $O/r02_kernel_trace_graph${TRACE_TAG}.txt

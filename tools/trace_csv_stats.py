@@ -25,7 +25,7 @@ for name, s, e in seg:
     agg[name][0] += 1; agg[name][1] += e - s
 fam = collections.defaultdict(float)
 for name, (c, t) in agg.items():
-    key = "gemm engine (gemm_kernel / gemm_dma_kernel)" if "gemm_kernel" in name or "gemm_dma" in name else "direct conv" if "conv3x3_small" in name else \
+    key = "gemm engine (gemm_kernel / gemm_dma_kernel)" if "gemm_kernel" in name or "gemm_dma" in name else "direct conv" if ("conv3x3_small" in name or "conv3x3_grouped" in name) else \
         "batchnorm" if ("bn_" in name or "BnStat" in name or "BnBwd" in name) else "other"
     fam[key] += t / n / 1e6
 print("families (ms/step):", ", ".join("%s %.2f" % kv for kv in sorted(fam.items(), key=lambda kv: -kv[1])))
