@@ -907,7 +907,8 @@ def check_f32x3_direct(dev):
     old = ops._DIRECT_MIN_PIXELS
     ops._DIRECT_MIN_PIXELS = 0
     try:
-        for (B, H, W, Cin, Cout, groups) in ((2, 10, 70, 32, 32, 1), (1, 9, 33, 32, 7, 1), (1, 12, 64, 8, 32, 1), (2, 16, 44, 72, 72, 3), (1, 9, 13, 48, 48, 2)):
+        for (B, H, W, Cin, Cout, groups) in ((2, 10, 70, 32, 32, 1), (1, 9, 33, 32, 7, 1), (1, 12, 64, 8, 32, 1), (1, 19, 37, 12, 20, 1), (2, 16, 44, 72, 72, 3),
+                                             (1, 9, 13, 48, 48, 2)):
             x = R(B, Cin, H, W, dev="cpu").double().requires_grad_(True)
             w = (R(Cout, Cin // groups, 3, 3, dev="cpu") * 0.1).double().requires_grad_(True)
             dy = R(B, Cout, H, W, seed=1, dev="cpu").double()

@@ -44,5 +44,8 @@ diag_tp)    TF_TWO_PASS_SPLITK=0 TF_RETUNE=1 timeout 150 python tools/tune.py $O
             TF_TRACE_GEMM=1 TF_RETUNE=1 timeout 200 python tools/tune.py $O/diag_tp.txt 10 256 fp32 > $O/diag_tp.log 2>&1; tail -6 $O/diag_tp.log | cut -c1-300 ;;
 diag_tp2)   TF_TRACE_CALLS=1 TF_TRACE_GEMM=1 TF_RETUNE=1 timeout 250 python tools/tune.py $O/diag_tp.txt 10 256 fp32 > $O/diag_tp.log 2>&1; tail -12 $O/diag_tp.log | cut -c1-300 ;;
 diag_tp3)   TF_TRACE_TUNE=1 TF_RETUNE=1 timeout 250 python tools/tune.py $O/diag_tp.txt 10 256 fp32 > $O/diag_tp.log 2>&1; grep -v "ok$" $O/diag_tp.log | tail -8 | cut -c1-300; tail -5 $O/diag_tp.log | cut -c1-300 ;;
+ps_tests)   timeout 300 python -m pytest tests/test_kernels_gpu.py -q -k "direct" 2>&1 | tail -4 ;;
+ab_ps)      for v in 1 0 1 0; do TF_X3_PRESPLIT=$v timeout 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-alt --dtype f32x3 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('f32x3 PRESPLIT=$v', d['ms_per_step'], 'ms/step', d['value'], 'samples/s; loss', d['config']['final_loss'])"; done
+            for v in 1 0; do TF_X3_PRESPLIT=$v timeout 100 python tools/conv_bench_x3.py 2>&1 | tail -4; done ;;
 esac
 done

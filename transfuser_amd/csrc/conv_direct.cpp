@@ -121,6 +121,103 @@ __global__ void __launch_bounds__(256, 2) conv3x3_small_kernel(const float* __re
     }
 }
 
+// ---- f32x3 (bf16x3 split) forward / dgrad with PRE-SPLIT operands: the in-register split of conv3x3_small_kernel<VEC, 2> re-splits every patch
+// element once per tap (9x) and every weight once per tile, which makes a single 32x32 tile VALU-bound (288 VALU vs 192 MFMA cycles per
+// 16-deep group).  Here both operands are split ONCE on their way into LDS and live there as three packed-bf16 planes (h, m, l):
+//   patch planes  xp[plane][pixel][20 dwords]  (16 dwords = 32 channels, 80-byte pitch: conflict-free ds_read_b128 of 8 channels)
+//   weight planes wq[plane][(tap, q, hi)][n = 32][4 dwords]   (k = 16 q + 8 hi + 2 d + {0, 1} in dword d; lane-contiguous b128 reads)
+// so the tap loop is 6 x ds_read_b128 + 6 x v_mfma_f32_32x32x16_bf16 per 16-deep group and nothing else.  8 waves / block (8 x 32 output
+// pixels, one row per wave), 137 KB of LDS -> one block per CU, persistent over tiles with register prefetch of the next patch.
+constexpr int XH = 8, XPH = XH + 2;            // tile rows / patch rows (tile and patch width = TW, PW)
+constexpr int XPL = 20;                        // dwords per patch pixel per plane
+constexpr int XNV = (XPH * PW * 8 + 511) / 512;
+constexpr int XPLANE_P = XPH * PW * XPL;       // dwords per patch plane
+constexpr int XPLANE_W = 9 * 2 * 2 * 32 * 4;   // dwords per weight plane
+
+__global__ void __launch_bounds__(512, 1) conv3x3_small_x3_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                                  float* __restrict__ y, DcGeom g, int CoW, int CiW, int dgrad, int relu, int accumulate) {
+    __shared__ __attribute__((aligned(16))) uint32_t xp[3 * XPLANE_P];
+    __shared__ __attribute__((aligned(16))) uint32_t wq[3 * XPLANE_W];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    // weights: dword (tap, q, hi, n, d) holds k = 16 q + 8 hi + 2 d and k + 1 of column n (same (tap, k, n) convention as load_weights)
+    for (int i = tid; i < XPLANE_W; i += 512) {
+        const int d = i & 3, n = (i >> 2) & 31, grp = i >> 7, tap = grp >> 2, k = 16 * ((grp >> 1) & 1) + 8 * (grp & 1) + 2 * d;
+        float v[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int kk = k + e;
+            v[e] = 0.f;
+            if (!dgrad) { if (n < CoW && kk < CiW) v[e] = w[((long)n * 9 + tap) * CiW + kk]; }
+            else { if (kk < CoW && n < CiW) v[e] = w[((long)kk * 9 + (8 - tap)) * CiW + n]; }
+        }
+        split_pair_bf16x3(v[0], v[1], wq[i], wq[XPLANE_W + i], wq[2 * XPLANE_W + i]);
+    }
+    const int tiles_h = (g.H + XH - 1) / XH, ntiles = g.B * tiles_h * g.tiles_w;
+    float4 pre[XNV];
+    auto fetch = [&](int t) {
+        const int b = t / (tiles_h * g.tiles_w), r = t - b * (tiles_h * g.tiles_w);
+        const int h0 = (r / g.tiles_w) * XH, w0 = (r % g.tiles_w) * TW;
+#pragma unroll
+        for (int p = 0; p < XNV; ++p) {
+            const int s = tid + p * 512, pix = s >> 3, c = (s & 7) * 4;
+            const int ph = pix / PW, pw = pix - ph * PW;
+            const int h = h0 - 1 + ph, ww = w0 - 1 + pw;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pix < XPH * PW && (unsigned)h < (unsigned)g.H && (unsigned)ww < (unsigned)g.W && c < g.Ci)
+                v = *reinterpret_cast<const float4*>(x + (((long)b * g.H + h) * g.W + ww) * g.Ci + c);
+            pre[p] = v;
+        }
+    };
+    int tile = blockIdx.x;
+    if (tile < ntiles) fetch(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+        __syncthreads();                           // previous tile's MFMAs are done with the patch planes (and the weights are staged)
+#pragma unroll
+        for (int p = 0; p < XNV; ++p) {
+            const int s = tid + p * 512, pix = s >> 3, c = (s & 7) * 4;
+            if (pix < XPH * PW) {
+                uint32_t* q = xp + pix * XPL + (c >> 1);
+                split_pair_bf16x3(pre[p].x, pre[p].y, q[0], q[XPLANE_P], q[2 * XPLANE_P]);
+                split_pair_bf16x3(pre[p].z, pre[p].w, q[1], q[XPLANE_P + 1], q[2 * XPLANE_P + 1]);
+            }
+        }
+        __syncthreads();
+        const int nxt = tile + gridDim.x;
+        if (nxt < ntiles) fetch(nxt);              // next patch travels while this one is multiplied
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int kh = tap / 3, kw = tap - kh * 3;
+            const uint32_t* pa = xp + ((wave + kh) * PW + l31 + kw) * XPL + 4 * hi;
+            const uint32_t* pb = wq + ((tap * 4 + hi) * 32 + l31) * 4;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                if (16 * q >= g.Ci) break;
+                const Bf16x3 fa = frag_from_planes(pa + 8 * q, pa + 8 * q + XPLANE_P, pa + 8 * q + 2 * XPLANE_P);
+                const Bf16x3 fb = frag_from_planes(pb + q * 256, pb + q * 256 + XPLANE_W, pb + q * 256 + 2 * XPLANE_W);
+                mfma_x3_presplit(fa, fb, acc);
+            }
+        }
+        const int b = tile / (tiles_h * g.tiles_w), r = tile - b * (tiles_h * g.tiles_w);
+        const int h = (r / g.tiles_w) * XH + wave, w0 = (r % g.tiles_w) * TW;
+        if (h < g.H && l31 < g.Co) {
+            const float bj = bias ? bias[l31] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int wv = w0 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+                if (wv < g.W) {
+                    float* dst = y + (((long)b * g.H + h) * g.W + wv) * g.Co + l31;
+                    float v = acc[e] + bj;
+                    if (relu) v = fmaxf(v, 0.f);
+                    *dst = accumulate ? *dst + v : v;
+                }
+            }
+        }
+    }
+}
+
 // dW[co][tap][ci] (+)= sum_pixels dY[p][co] * X[p + tap][ci]: per wave a row of 32 pixels as the K dimension, 9 accumulators (one per
 // tap, 32 co x 32 ci); blocks are persistent, their partial panels are summed by conv3x3_small_wgrad_reduce_kernel.
 template <bool VEC, int PREC>
@@ -236,6 +333,8 @@ inline int direct_prec() {
     return (p == 2 && !x3) ? 0 : p;
 }
 
+inline bool presplit_enabled() { static const bool on = [] { const char* e = getenv("TF_X3_PRESPLIT"); return !e || atoi(e) != 0; }(); return on; }
+
 inline DcGeom make_geom(int B, int H, int W, int Ci, int Co) {
     DcGeom g; g.B = B; g.H = H; g.W = W; g.Ci = Ci; g.Co = Co;
     g.tiles_h = cdiv(H, TH); g.tiles_w = cdiv(W, TW); g.ntiles = B * g.tiles_h * g.tiles_w;
@@ -251,6 +350,11 @@ extern "C" int tf_conv3x3_small_fwd_f32(const float* x, const float* w, const fl
     const int grid = g.ntiles < 512 ? g.ntiles : 512;
     const bool vec = Cin % 4 == 0 && aligned16(x);
     const int prec = direct_prec();
+    if (prec == 2 && vec && presplit_enabled()) {      // f32x3 with pre-split LDS planes: 8-row tiles, one 512-thread block per CU
+        const int nt = B * cdiv(H, XH) * g.tiles_w;
+        TF_LAUNCH(conv3x3_small_x3_kernel, dim3(nt < 256 ? nt : 256), dim3(512), stream, x, w, bias, y, g, Cout, Cin, 0, relu, 0);
+        return launch_status("tf_conv3x3_small_fwd_f32[x3]");
+    }
     if (prec == 2) { if (vec) TF_LAUNCH((conv3x3_small_kernel<true, 2>), dim3(grid), dim3(256), stream, x, w, bias, y, g, Cout, Cin, 0, relu, 0); else TF_LAUNCH((conv3x3_small_kernel<false, 2>), dim3(grid), dim3(256), stream, x, w, bias, y, g, Cout, Cin, 0, relu, 0); }
     else if (prec == 1) { if (vec) TF_LAUNCH((conv3x3_small_kernel<true, 1>), dim3(grid), dim3(256), stream, x, w, bias, y, g, Cout, Cin, 0, relu, 0); else TF_LAUNCH((conv3x3_small_kernel<false, 1>), dim3(grid), dim3(256), stream, x, w, bias, y, g, Cout, Cin, 0, relu, 0); }
     else { if (vec) TF_LAUNCH((conv3x3_small_kernel<true, 0>), dim3(grid), dim3(256), stream, x, w, bias, y, g, Cout, Cin, 0, relu, 0); else TF_LAUNCH((conv3x3_small_kernel<false, 0>), dim3(grid), dim3(256), stream, x, w, bias, y, g, Cout, Cin, 0, relu, 0); }
@@ -262,8 +366,15 @@ extern "C" int tf_conv3x3_small_dgrad_f32(const float* dy, const float* w, float
     DcGeom g = make_geom(B, H, W, Cout, Cin);      // the "input" of this pass is dY (Cout channels), the output dX (Cin channels)
     const int grid = g.ntiles < 512 ? g.ntiles : 512;
     const bool vec = Cout % 4 == 0 && aligned16(dy);
-    const int prec = direct_prec();
+    int prec = direct_prec();
+    if (prec == 2 && Cout < 16) prec = 0;     // few input channels (the 32 -> 7 / 32 -> 1 layers' gradients): the fp32 kernel multiplies only ceil(Cout / 2) k-steps per tap
+                                              // and beats a zero-padded 16-deep bf16x3 group (measured 238 / 122 us vs 271 / 210)
     const float* nob = nullptr;
+    if (prec == 2 && vec && presplit_enabled()) {
+        const int nt = B * cdiv(H, XH) * g.tiles_w;
+        TF_LAUNCH(conv3x3_small_x3_kernel, dim3(nt < 256 ? nt : 256), dim3(512), stream, dy, w, nob, dx, g, Cout, Cin, 1, 0, accumulate);
+        return launch_status("tf_conv3x3_small_dgrad_f32[x3]");
+    }
     if (prec == 2) { if (vec) TF_LAUNCH((conv3x3_small_kernel<true, 2>), dim3(grid), dim3(256), stream, dy, w, nob, dx, g, Cout, Cin, 1, 0, accumulate); else TF_LAUNCH((conv3x3_small_kernel<false, 2>), dim3(grid), dim3(256), stream, dy, w, nob, dx, g, Cout, Cin, 1, 0, accumulate); }
     else if (prec == 1) { if (vec) TF_LAUNCH((conv3x3_small_kernel<true, 1>), dim3(grid), dim3(256), stream, dy, w, nob, dx, g, Cout, Cin, 1, 0, accumulate); else TF_LAUNCH((conv3x3_small_kernel<false, 1>), dim3(grid), dim3(256), stream, dy, w, nob, dx, g, Cout, Cin, 1, 0, accumulate); }
     else { if (vec) TF_LAUNCH((conv3x3_small_kernel<true, 0>), dim3(grid), dim3(256), stream, dy, w, nob, dx, g, Cout, Cin, 1, 0, accumulate); else TF_LAUNCH((conv3x3_small_kernel<false, 0>), dim3(grid), dim3(256), stream, dy, w, nob, dx, g, Cout, Cin, 1, 0, accumulate); }

@@ -263,6 +263,15 @@ inline int direct_prec() {
     return (p == 2 && !x3) ? 0 : p;
 }
 
+// f32x3 mode: the forward / input-gradient kernels hold ONE 32x32 tile per wave, where the in-register split is VALU-bound and measured slower
+// than the exact fp32 MFMA (46 vs 41 us at 16x44x576, 78 vs 69 us at 64x176x72); only the weight gradient (a dY fragment shared by 9 taps)
+// gains (43 vs 60, 86 vs 115 us).  TF_X3_GROUPED_FWD=1 re-enables the X3 instantiation for A/B runs.
+inline int fwd_prec() {
+    static const bool x3 = [] { const char* e = getenv("TF_X3_GROUPED_FWD"); return e && atoi(e) != 0; }();
+    const int p = direct_prec();
+    return (p == 2 && !x3) ? 0 : p;
+}
+
 inline GcGeom make_geom(int B, int H, int W, int C, int TW, int max_blocks = kMaxBlocks) {
     GcGeom g; g.B = B; g.H = H; g.W = W; g.C = C; g.G = C / CG;
     const int th = TW == 16 ? 8 : 4;
@@ -288,7 +297,7 @@ extern "C" int tf_conv3x3_grouped_fwd_f32(const float* x, const float* w, const 
     TF_REQUIRE(args_ok(x, w, y, B, H, W, C), "tf_conv3x3_grouped_fwd_f32: needs NHWC tensors with C %% 24 == 0 (group width 24), 16-byte aligned");
     const int tw = pick_tw(H, W);
     GcGeom g = make_geom(B, H, W, C, tw);
-    const int prec = direct_prec();
+    const int prec = fwd_prec();
     if (prec == 2) {
         if (tw == 16) TF_LAUNCH((conv3x3_grouped_kernel<16, true>), dim3(g.G * g.nb), dim3(256), stream, x, w, bias, y, g, 0, relu, 0, 2);
         else TF_LAUNCH((conv3x3_grouped_kernel<32, true>), dim3(g.G * g.nb), dim3(256), stream, x, w, bias, y, g, 0, relu, 0, 2);
@@ -301,7 +310,7 @@ extern "C" int tf_conv3x3_grouped_dgrad_f32(const float* dy, const float* w, flo
     TF_REQUIRE(args_ok(dy, w, dx, B, H, W, C), "tf_conv3x3_grouped_dgrad_f32: needs NHWC tensors with C %% 24 == 0 (group width 24), 16-byte aligned");
     const int tw = pick_tw(H, W);
     GcGeom g = make_geom(B, H, W, C, tw);
-    const int prec = direct_prec();
+    const int prec = fwd_prec();
     const float* nob = nullptr;
     if (prec == 2) {
         if (tw == 16) TF_LAUNCH((conv3x3_grouped_kernel<16, true>), dim3(g.G * g.nb), dim3(256), stream, dy, w, nob, dx, g, 1, 0, accumulate, 2);

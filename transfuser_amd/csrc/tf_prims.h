@@ -86,6 +86,27 @@ __forceinline__ Bf16x3 split_bf16x3(const float (&a)[8]) {
     return f;
 }
 __forceinline__ void mfma_bf16_raw(const float (&a)[8], const float (&b)[8], f32x16& acc) { mfma_32x32x16_bf16(a, b, acc); }   // operands are bf16 values: re-rounding is the identity
+// packed bf16 planes (pre-split operands kept in LDS): one dword = two consecutive k elements, element 0 in the low half
+__forceinline__ uint32_t emu_bf16_bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u >> 16; }
+__forceinline__ float emu_bf16_from_bits(uint32_t b) { uint32_t u = b << 16; float f; memcpy(&f, &u, 4); return f; }
+__forceinline__ void split_pair_bf16x3(float a, float b, uint32_t& h, uint32_t& m, uint32_t& l) {
+    const float ha = emu_bf16_round(a), hb = emu_bf16_round(b);
+    const float ra = a - ha, rb = b - hb;
+    const float ma = emu_bf16_round(ra), mb = emu_bf16_round(rb);
+    const float la = emu_bf16_round(ra - ma), lb = emu_bf16_round(rb - mb);
+    h = emu_bf16_bits(ha) | (emu_bf16_bits(hb) << 16);
+    m = emu_bf16_bits(ma) | (emu_bf16_bits(mb) << 16);
+    l = emu_bf16_bits(la) | (emu_bf16_bits(lb) << 16);
+}
+__forceinline__ Bf16x3 frag_from_planes(const uint32_t* h, const uint32_t* m, const uint32_t* l) {   // 4 dwords (8 elements) per plane
+    Bf16x3 f;
+    for (int d = 0; d < 4; ++d) {
+        f.h[2 * d] = emu_bf16_from_bits(h[d] & 0xffffu); f.h[2 * d + 1] = emu_bf16_from_bits(h[d] >> 16);
+        f.m[2 * d] = emu_bf16_from_bits(m[d] & 0xffffu); f.m[2 * d + 1] = emu_bf16_from_bits(m[d] >> 16);
+        f.l[2 * d] = emu_bf16_from_bits(l[d] & 0xffffu); f.l[2 * d + 1] = emu_bf16_from_bits(l[d] >> 16);
+    }
+    return f;
+}
 __forceinline__ float shfl(float v, int src) {
     float* s = emu::wave_scratch();
     s[128 + lane_id()] = v;
@@ -141,6 +162,23 @@ __device__ __forceinline__ Bf16x3 split_bf16x3(const float (&a)[8]) {
     f.h = __builtin_bit_cast(bf16x8, h);
     f.m = __builtin_bit_cast(bf16x8, m);
     f.l = __builtin_bit_cast(bf16x8, l);
+    return f;
+}
+// packed bf16 planes (pre-split operands kept in LDS): one dword = two consecutive k elements, element 0 in the low half
+__device__ __forceinline__ void split_pair_bf16x3(float a, float b, uint32_t& h, uint32_t& m, uint32_t& l) {
+    f32x2 x;
+    x.x = a; x.y = b;
+    h = bf16_pack_rne(x);
+    const f32x2 r1 = x - bf16_unpack(h);
+    m = bf16_pack_rne(r1);
+    const f32x2 r2 = r1 - bf16_unpack(m);
+    l = bf16_pack_rne(r2);
+}
+__device__ __forceinline__ Bf16x3 frag_from_planes(const uint32_t* h, const uint32_t* m, const uint32_t* l) {   // 16-byte aligned: one ds_read_b128 per plane
+    Bf16x3 f;
+    f.h = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(h));
+    f.m = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(m));
+    f.l = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(l));
     return f;
 }
 __device__ __forceinline__ void mfma_bf16_raw(const bf16x8& a, const bf16x8& b, f32x16& acc) {
