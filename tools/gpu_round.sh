@@ -47,5 +47,9 @@ diag_tp3)   TF_TRACE_TUNE=1 TF_RETUNE=1 timeout 250 python tools/tune.py $O/diag
 ps_tests)   timeout 300 python -m pytest tests/test_kernels_gpu.py -q -k "direct" 2>&1 | tail -4 ;;
 ab_ps)      for v in 1 0 1 0; do TF_X3_PRESPLIT=$v timeout 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-alt --dtype f32x3 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('f32x3 PRESPLIT=$v', d['ms_per_step'], 'ms/step', d['value'], 'samples/s; loss', d['config']['final_loss'])"; done
             for v in 1 0; do TF_X3_PRESPLIT=$v timeout 100 python tools/conv_bench_x3.py 2>&1 | tail -4; done ;;
+tune_cfgs)  cp transfuser_amd/plans/mi355x.txt $O/mi355x_r02c.txt
+            for a in "12 160 geometric_fusion" "16 256 latentTF"; do set -- $a; TF_PLANS=$O/mi355x_r02c.txt TF_RETUNE=0 timeout 300 python tools/tune.py $O/mi355x_r02c.txt $1 $2 fp32,f32x3,bf16 $3 2>&1 | grep "H=\|saved"; done ;;
+bench_cfgs2) for a in "--backbone geometric_fusion" "--backbone latentTF" "--height 160" "--dtype bf16"; do
+              tag=$(echo $a | tr -d ' -' ); TF_PLANS=$O/mi355x_r02c.txt timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline $a > $O/r02_bench_$tag.json 2> $O/r02_bench_$tag.err; tail -1 $O/r02_bench_$tag.err; python -c "import sys,json; d=json.load(open('$O/r02_bench_$tag.json')); print('$a', d['ms_per_step'], 'ms/step', d['value'], 'samples/s', ('; f32x3 %s ms %s samples/s' % (d['f32x3']['ms_per_step'], d['f32x3']['value'])) if 'f32x3' in d and 'value' in d['f32x3'] else '')"; done ;;
 esac
 done

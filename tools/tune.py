@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Autotune the MFMA-engine tilings for the bench workload on this GPU and save the plan cache.
-   python tools/tune.py [out_path] [B] [H]      (cudnn.benchmark analogue; ~10 s)"""
+   python tools/tune.py [out_path] [B] [H,H] [prec,prec] [backbone]      (cudnn.benchmark analogue; ~10 s per precision and height;
+   backbone = transFuser (default) | geometric_fusion (B = 12, H = 160 only) | latentTF (B = 16); TF_RETUNE=0 keeps the plans already loaded)"""
 import os
 import sys
 import time
@@ -19,10 +20,11 @@ out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "transfuser_amd",
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 hs = [int(h) for h in sys.argv[3].split(",")] if len(sys.argv) > 3 else [256, 160]
 precs = sys.argv[4].split(",") if len(sys.argv) > 4 else ["fp32"]     # e.g. fp32,bf16: plans are keyed by compute precision, one file holds both
+backbone = sys.argv[5] if len(sys.argv) > 5 else "transFuser"
 dev = torch.device("cuda", 0)
 cfg = GlobalConfig(); cfg.n_layer = 4; cfg.use_target_point_image = True
 torch.manual_seed(0)
-model = LidarCenterNet(cfg, dev, 'transFuser', 'regnety_032', 'regnety_032', use_velocity=False).train()
+model = LidarCenterNet(cfg, dev, backbone, 'regnety_032', 'regnety_032', use_velocity=False).train()
 hist_fn = lambda pts: ops.lidar_hist(torch.from_numpy(pts).to(dev)[None])[0].cpu().numpy()
 eng = Engine(model, cfg, autotune=False)
 if os.environ.get("TF_RETUNE", "1") == "1":
