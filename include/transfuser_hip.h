@@ -210,6 +210,8 @@ int tf_axpby_f32(const float* a, const float* b, float* out, float alpha, float 
 /* nn.Dropout with a counter-based RNG keyed by (*seed_dev, site, index); calling it on dy with the
  * same key is the backward (transfuser.py:311,504-505,542). */
 int tf_dropout_f32(const float* x, float* y, int64_t n, const uint32_t* seed_dev, uint32_t site, float p, void* stream);
+/* y = res + dropout(x) with the mask of tf_dropout_f32(site): x + resid_drop(...) of transfuser.py:543-544 in one pass (y may alias x or res) */
+int tf_dropout_add_f32(const float* x, const float* res, float* y, int64_t n, const uint32_t* seed_dev, uint32_t site, float p, void* stream);
 /* Waypoint decoder (model.py:611-646): pred_len x { GRUCell(4|2 -> 64), Linear(64,3), running sum } fused
  * into one launch per direction.  cache: tf_gru_waypoints_cache_floats(B, pred_len) floats kept for the
  * backward, which ACCUMULATES the parameter gradients and writes dz0 (grad of the join-MLP output). */

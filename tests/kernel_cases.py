@@ -465,6 +465,8 @@ def check_misc(dev):
     close(y[y != 0], torch.full_like(y[y != 0], 1 / 0.9), what="dropout scale")
     assert torch.equal(y, ops.dropout(x, seed, 3, 0.1)), "dropout mask must be reproducible (backward regenerates it)"
     assert not torch.equal(y, ops.dropout(x, seed, 4, 0.1))
+    r = R(*x.shape, seed=9, dev=dev)
+    assert torch.equal(ops.dropout_add(x, r, seed, 3, 0.1), r + y), "dropout_add == residual + dropout with the same mask"
 
 
 def check_adamw(dev, n):

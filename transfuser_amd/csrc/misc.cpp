@@ -33,6 +33,14 @@ __global__ void __launch_bounds__(256) dropout_kernel(const float* __restrict__ 
         y[i] = dropout_keep(sd, site, (uint32_t)i, thresh) ? x[i] * keep_scale : 0.f;
 }
 
+// y = res + dropout(x): the residual adds behind resid_drop (transfuser.py:543-544) in one pass; same element -> mask mapping as dropout_kernel
+__global__ void __launch_bounds__(256) dropout_add_kernel(const float* __restrict__ x, const float* __restrict__ res, float* __restrict__ y, long n,
+                                                          const uint32_t* __restrict__ seed, uint32_t site, uint32_t thresh, float keep_scale) {
+    const uint32_t sd = *seed;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+        y[i] = res[i] + (dropout_keep(sd, site, (uint32_t)i, thresh) ? x[i] * keep_scale : 0.f);
+}
+
 // torch.optim.AdamW (train.py:142: lr 1e-4, betas (.9,.999), eps 1e-8, weight_decay 0.01, decoupled),
 // ONE launch over the flat parameter arena.  state[0] = step (float), state[1] = lr; the step is
 // advanced by adamw_tick_kernel so a captured graph replays correctly.
@@ -127,6 +135,13 @@ extern "C" int tf_dropout_f32(const float* x, float* y, int64_t n, const uint32_
     const uint32_t thresh = (uint32_t)((double)p * 4294967296.0);
     TF_LAUNCH(dropout_kernel, dim3(ew_blocks(n)), dim3(256), stream, x, y, (long)n, seed_dev, site, thresh, 1.f / (1.f - p));
     return launch_status("tf_dropout_f32");
+}
+extern "C" int tf_dropout_add_f32(const float* x, const float* res, float* y, int64_t n, const uint32_t* seed_dev, uint32_t site, float p, void* stream) {
+    TF_REQUIRE(x && res && y && seed_dev && n >= 0 && p >= 0.f && p < 1.f, "tf_dropout_add_f32: bad arguments");
+    if (n == 0) return 0;
+    const uint32_t thresh = (uint32_t)((double)p * 4294967296.0);
+    TF_LAUNCH(dropout_add_kernel, dim3(ew_blocks(n)), dim3(256), stream, x, res, y, (long)n, seed_dev, site, thresh, 1.f / (1.f - p));
+    return launch_status("tf_dropout_add_f32");
 }
 extern "C" int tf_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, float* state_dev, float beta1, float beta2, float eps,
                             float weight_decay, void* stream) {

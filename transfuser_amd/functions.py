@@ -336,14 +336,14 @@ class GPTStageFn(torch.autograd.Function):
             y_att = _attn_ctx(att_d, qkv, B, T, C, nh, Tp)
             if drop and gpt.resid_pdrop > 0:
                 pr = ops.linear_fwd(y_att, blk.attn.proj.weight, blk.attn.proj.bias)
-                x_mid = ops.axpby(ops.dropout(pr, gpt.seed, gpt.site(4 * li + 2), gpt.resid_pdrop, out=pr), x)
+                x_mid = ops.dropout_add(pr, x, gpt.seed, gpt.site(4 * li + 2), gpt.resid_pdrop, out=pr)
             else:
                 x_mid = ops.linear_fwd(y_att, blk.attn.proj.weight, blk.attn.proj.bias, res=x)
             h2, m2, r2 = ops.layernorm_fwd(x_mid, blk.ln2.weight, blk.ln2.bias, blk.ln2.eps)
             a1 = ops.linear_fwd(h2, blk.mlp[0].weight, blk.mlp[0].bias, relu=True)
             if drop and gpt.resid_pdrop > 0:
                 f2 = ops.linear_fwd(a1, blk.mlp[2].weight, blk.mlp[2].bias)
-                x_out = ops.axpby(ops.dropout(f2, gpt.seed, gpt.site(4 * li + 3), gpt.resid_pdrop, out=f2), x_mid)
+                x_out = ops.dropout_add(f2, x_mid, gpt.seed, gpt.site(4 * li + 3), gpt.resid_pdrop, out=f2)
             else:
                 x_out = ops.linear_fwd(a1, blk.mlp[2].weight, blk.mlp[2].bias, res=x_mid)
             saved.append((x, h1, m1, r1, qkv, att, att_d, Tp, y_att, x_mid, h2, m2, r2, a1))

@@ -669,6 +669,15 @@ def dropout(x, seed, site, p, out=None):
     return out
 
 
+def dropout_add(x, res, seed, site, p, out=None):
+    """res + dropout(x) in one launch (same mask as dropout(x, seed, site, p))."""
+    if out is None:
+        out = torch.empty_like(x)
+    check(L().tf_dropout_add_f32(ptr(_c(x)), ptr(_c(res)), ptr(out), ctypes.c_int64(x.numel()), ptr(seed), ctypes.c_uint32(site), ctypes.c_float(p),
+                                 stream_of(x)), "tf_dropout_add_f32")
+    return out
+
+
 def gru_waypoints_fwd(z0, target_point, gru, outl, pred_len, shift_x):
     B, H = z0.shape
     nin = gru.weight_ih.shape[1]
