@@ -115,6 +115,10 @@ int tf_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, co
 /* F.softmax over attention rows (transfuser.py:520), in place; bwd turns dP into dS in place. */
 int tf_softmax_fwd_f32(float* s, int rows, int n, int ld, void* stream);
 int tf_softmax_bwd_f32(const float* p, float* dp, int rows, int n, int ld, void* stream);
+/* softmax + attn_drop fused (transfuser.py:520-521): fwd writes the probabilities in place (kept for the backward) and the dropped
+ * probabilities to sd; bwd takes the gradient w.r.t. the dropped probabilities.  Mask = tf_dropout_f32(site) over the flat (rows x ld) tensor. */
+int tf_softmax_dropout_fwd_f32(float* s, float* sd, int rows, int n, int ld, const uint32_t* seed_dev, uint32_t site, float p, void* stream);
+int tf_softmax_dropout_bwd_f32(const float* p, float* dp, int rows, int n, int ld, const uint32_t* seed_dev, uint32_t site, float pdrop, void* stream);
 
 /* ---- per-channel reductions / BatchNorm / Squeeze-Excite ------------------------------------- */
 

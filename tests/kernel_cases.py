@@ -467,6 +467,18 @@ def check_misc(dev):
     assert not torch.equal(y, ops.dropout(x, seed, 4, 0.1))
     r = R(*x.shape, seed=9, dev=dev)
     assert torch.equal(ops.dropout_add(x, r, seed, 3, 0.1), r + y), "dropout_add == residual + dropout with the same mask"
+    # softmax + attn_drop fused (forward and backward) == the two separate launches, bitwise on the live columns
+    rows, n, ld = 70, 174, 176
+    sc = R(rows, ld, seed=11, dev=dev)
+    p_ref = ops.softmax_fwd_(sc.clone(), rows, n, ld)
+    pd_ref = ops.dropout(p_ref, seed, 7, 0.1)
+    p_f = sc.clone()
+    pd_f = ops.softmax_dropout_fwd_(p_f, rows, n, ld, seed, 7, 0.1)
+    assert torch.equal(p_f[:, :n], p_ref[:, :n]) and torch.equal(pd_f[:, :n], pd_ref[:, :n]), "fused softmax + dropout forward"
+    dpd = R(rows, ld, seed=12, dev=dev)
+    g_ref = ops.softmax_bwd_(p_ref, ops.dropout(dpd, seed, 7, 0.1), rows, n, ld)
+    g_f = ops.softmax_dropout_bwd_(p_ref, dpd.clone(), rows, n, ld, seed, 7, 0.1)
+    assert torch.equal(g_f[:, :n], g_ref[:, :n]), "fused softmax + dropout backward"
 
 
 def check_adamw(dev, n):

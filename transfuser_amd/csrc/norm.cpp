@@ -115,7 +115,11 @@ extern "C" int tf_layernorm_bwd_f32(const float* dy, const float* x, const float
 // Row length n <= 64 * SM_MAXV (T = 174 here); row stride ld >= n.  In place.
 constexpr int SM_MAXV = 8;
 
-__global__ void __launch_bounds__(256) softmax_fwd_kernel(float* __restrict__ s, int rows, int n, int ld) {
+// DROP: additionally writes attn_drop(probabilities) to sd (transfuser.py:521; mask = tf_dropout_f32's for the flat index row * ld + column)
+template <bool DROP>
+__global__ void __launch_bounds__(256) softmax_fwd_kernel(float* __restrict__ s, int rows, int n, int ld, float* __restrict__ sd = nullptr,
+                                                          const uint32_t* __restrict__ seed = nullptr, uint32_t site = 0, uint32_t thresh = 0,
+                                                          float keep_scale = 1.f) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const bool live = row < rows;
@@ -139,15 +143,28 @@ __global__ void __launch_bounds__(256) softmax_fwd_kernel(float* __restrict__ s,
     sum = wave_sum(sum);
     if (!live) return;
     const float inv = 1.0f / sum;
+    uint32_t sdv = 0;
+    if constexpr (DROP) sdv = *seed;
 #pragma unroll
     for (int i = 0; i < SM_MAXV; ++i) {
         const int c = lane + i * 64;
-        if (c < n) p[c] = v[i] * inv;
+        if (c < n) {
+            const float pr = v[i] * inv;
+            p[c] = pr;
+            if constexpr (DROP) {
+                const long o = (long)row * ld + c;
+                sd[o] = dropout_keep(sdv, site, (uint32_t)o, thresh) ? pr * keep_scale : 0.f;
+            }
+        }
     }
 }
 
 // In: p = probabilities, dp = dL/dp.  Out (in place in dp): dL/ds = p * (dp - sum(dp * p)).
-__global__ void __launch_bounds__(256) softmax_bwd_kernel(const float* __restrict__ p, float* __restrict__ dp, int rows, int n, int ld) {
+// DROP: dp is the gradient w.r.t. the DROPPED probabilities; the attn_drop backward (same mask) is applied on load
+template <bool DROP>
+__global__ void __launch_bounds__(256) softmax_bwd_kernel(const float* __restrict__ p, float* __restrict__ dp, int rows, int n, int ld,
+                                                          const uint32_t* __restrict__ seed = nullptr, uint32_t site = 0, uint32_t thresh = 0,
+                                                          float keep_scale = 1.f) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const bool live = row < rows;
@@ -160,6 +177,7 @@ __global__ void __launch_bounds__(256) softmax_bwd_kernel(const float* __restric
         const bool ok = live && c < n;
         y[i] = ok ? p[o + c] : 0.f;
         g[i] = ok ? dp[o + c] : 0.f;
+        if constexpr (DROP) g[i] = (ok && dropout_keep(*seed, site, (uint32_t)(o + c), thresh)) ? g[i] * keep_scale : 0.f;
         dot += y[i] * g[i];
     }
     dot = wave_sum(dot);
@@ -174,13 +192,33 @@ __global__ void __launch_bounds__(256) softmax_bwd_kernel(const float* __restric
 extern "C" int tf_softmax_fwd_f32(float* s, int rows, int n, int ld, void* stream) {
     TF_REQUIRE(s && rows >= 0 && n > 0 && n <= 64 * SM_MAXV && ld >= n, "tf_softmax_fwd_f32: bad arguments (n=%d)", n);
     if (rows == 0) return 0;
-    TF_LAUNCH(softmax_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), stream, s, rows, n, ld);
+    TF_LAUNCH(softmax_fwd_kernel<false>, dim3(cdiv(rows, 4)), dim3(256), stream, s, rows, n, ld, (float*)nullptr, (const uint32_t*)nullptr, 0u, 0u, 1.f);
     return launch_status("tf_softmax_fwd_f32");
 }
 
 extern "C" int tf_softmax_bwd_f32(const float* p, float* dp, int rows, int n, int ld, void* stream) {
     TF_REQUIRE(p && dp && rows >= 0 && n > 0 && n <= 64 * SM_MAXV && ld >= n, "tf_softmax_bwd_f32: bad arguments (n=%d)", n);
     if (rows == 0) return 0;
-    TF_LAUNCH(softmax_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), stream, p, dp, rows, n, ld);
+    TF_LAUNCH(softmax_bwd_kernel<false>, dim3(cdiv(rows, 4)), dim3(256), stream, p, dp, rows, n, ld, (const uint32_t*)nullptr, 0u, 0u, 1.f);
     return launch_status("tf_softmax_bwd_f32");
+}
+
+// softmax + attn_drop in one pass (transfuser.py:520-521): s <- probabilities (kept for the backward), sd <- dropped probabilities
+extern "C" int tf_softmax_dropout_fwd_f32(float* s, float* sd, int rows, int n, int ld, const uint32_t* seed_dev, uint32_t site, float p, void* stream) {
+    TF_REQUIRE(s && sd && seed_dev && rows >= 0 && n > 0 && n <= 64 * SM_MAXV && ld >= n && p >= 0.f && p < 1.f && (long)rows * ld < (1L << 32),
+               "tf_softmax_dropout_fwd_f32: bad arguments (n=%d)", n);
+    if (rows == 0) return 0;
+    const uint32_t thresh = (uint32_t)((double)p * 4294967296.0);
+    TF_LAUNCH(softmax_fwd_kernel<true>, dim3(cdiv(rows, 4)), dim3(256), stream, s, rows, n, ld, sd, seed_dev, site, thresh, 1.f / (1.f - p));
+    return launch_status("tf_softmax_dropout_fwd_f32");
+}
+// backward of the pair: dp (gradient w.r.t. the dropped probabilities) -> dL/d(scores), in place
+extern "C" int tf_softmax_dropout_bwd_f32(const float* p, float* dp, int rows, int n, int ld, const uint32_t* seed_dev, uint32_t site, float pdrop,
+                                          void* stream) {
+    TF_REQUIRE(p && dp && seed_dev && rows >= 0 && n > 0 && n <= 64 * SM_MAXV && ld >= n && pdrop >= 0.f && pdrop < 1.f && (long)rows * ld < (1L << 32),
+               "tf_softmax_dropout_bwd_f32: bad arguments (n=%d)", n);
+    if (rows == 0) return 0;
+    const uint32_t thresh = (uint32_t)((double)pdrop * 4294967296.0);
+    TF_LAUNCH(softmax_bwd_kernel<true>, dim3(cdiv(rows, 4)), dim3(256), stream, p, dp, rows, n, ld, seed_dev, site, thresh, 1.f / (1.f - pdrop));
+    return launch_status("tf_softmax_dropout_bwd_f32");
 }

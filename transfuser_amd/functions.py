@@ -275,14 +275,17 @@ class YBlockFn(torch.autograd.Function):
 
 
 # ============================================================================================ GPT fusion stage
-def _attn_fwd(qkv, B, T, C, nh):
-    """qkv (B*T, 3C) = [key | query | value] (transfuser.py:500-502 order). Returns probs (B*nh, T, Tp), y (B*T, C)."""
+def _attn_fwd(qkv, B, T, C, nh, drop=None):
+    """qkv (B*T, 3C) = [key | query | value] (transfuser.py:500-502 order). Returns probs (B*nh, T, Tp), Tp [, dropped probs when
+    ``drop`` = (seed, site, p): softmax + attn_drop in one launch]."""
     hs = C // nh
     Tp = (T + 3) // 4 * 4
     att = torch.empty(B * nh, T, Tp, dtype=torch.float32, device=qkv.device)
     k, q, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
     sq, sp = (T * 3 * C, hs), (nh * T * Tp, T * Tp)
     ops.gemm(q, k, att, T, T, hs, 3 * C, 3 * C, Tp, alpha=1.0 / math.sqrt(hs), batch=B * nh, inner=nh, sa=sq, sb=sq, sc=sp)
+    if drop is not None:
+        return att, Tp, ops.softmax_dropout_fwd_(att, B * nh * T, T, Tp, *drop)
     ops.softmax_fwd_(att, B * nh * T, T, Tp)
     return att, Tp
 
@@ -329,10 +332,11 @@ class GPTStageFn(torch.autograd.Function):
             else:
                 for j, lin in enumerate((blk.attn.key, blk.attn.query, blk.attn.value)):
                     ops.linear_fwd(h1, lin.weight, lin.bias, out=qkv[:, j * C:(j + 1) * C])
-            att, Tp = _attn_fwd(qkv, B, T, C, nh)
-            att_d = att
             if drop and gpt.attn_pdrop > 0:
-                att_d = ops.dropout(att, gpt.seed, gpt.site(4 * li + 1), gpt.attn_pdrop)
+                att, Tp, att_d = _attn_fwd(qkv, B, T, C, nh, drop=(gpt.seed, gpt.site(4 * li + 1), gpt.attn_pdrop))
+            else:
+                att, Tp = _attn_fwd(qkv, B, T, C, nh)
+                att_d = att
             y_att = _attn_ctx(att_d, qkv, B, T, C, nh, Tp)
             if drop and gpt.resid_pdrop > 0:
                 pr = ops.linear_fwd(y_att, blk.attn.proj.weight, blk.attn.proj.bias)
@@ -402,8 +406,9 @@ class GPTStageFn(torch.autograd.Function):
             ops.gemm(att_d, dy, dqkv[:, 2 * C:], T, hs, T, Tp, C, 3 * C, a_trans=True, b_trans=True, batch=B * nh, inner=nh,
                      sa=sp, sb=sy, sc=sq)                                                                                     # dV = P^T dY
             if drop and gpt.attn_pdrop > 0:
-                ops.dropout(datt, gpt.seed, gpt.site(4 * li + 1), gpt.attn_pdrop, out=datt)
-            ops.softmax_bwd_(att, datt, B * nh * T, T, Tp)
+                ops.softmax_dropout_bwd_(att, datt, B * nh * T, T, Tp, gpt.seed, gpt.site(4 * li + 1), gpt.attn_pdrop)
+            else:
+                ops.softmax_bwd_(att, datt, B * nh * T, T, Tp)
             ops.gemm(datt, k, dqkv[:, C:2 * C], T, hs, T, Tp, 3 * C, 3 * C, b_trans=True, alpha=alpha, batch=B * nh, inner=nh,
                      sa=sp, sb=sq, sc=sq)                                                                                     # dQ = dS K
             ops.gemm(datt, q, dqkv[:, :C], T, hs, T, Tp, 3 * C, 3 * C, a_trans=True, b_trans=True, alpha=alpha, batch=B * nh, inner=nh,

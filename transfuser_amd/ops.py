@@ -388,6 +388,20 @@ def softmax_fwd_(s, rows, n, ld):
     return s
 
 
+def softmax_dropout_fwd_(s, rows, n, ld, seed, site, p):
+    """softmax in place + attn_drop into a new tensor, one launch; returns the dropped probabilities."""
+    sd = torch.empty_like(s)
+    check(L().tf_softmax_dropout_fwd_f32(ptr(s), ptr(sd), rows, n, ld, ptr(seed), ctypes.c_uint32(site), ctypes.c_float(p), stream_of(s)),
+          "tf_softmax_dropout_fwd_f32")
+    return sd
+
+
+def softmax_dropout_bwd_(p, dp, rows, n, ld, seed, site, pdrop):
+    check(L().tf_softmax_dropout_bwd_f32(ptr(p), ptr(dp), rows, n, ld, ptr(seed), ctypes.c_uint32(site), ctypes.c_float(pdrop), stream_of(p)),
+          "tf_softmax_dropout_bwd_f32")
+    return dp
+
+
 def softmax_bwd_(p, dp, rows, n, ld):
     check(L().tf_softmax_bwd_f32(ptr(p), ptr(dp), rows, n, ld, stream_of(p)), "tf_softmax_bwd_f32")
     return dp
