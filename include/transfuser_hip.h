@@ -148,9 +148,9 @@ int tf_se_scale_bwd_x_f32(const float* dy, const float* gate, const float* dmean
  *   bwd: given dgate (B, C): dW2 += dgate^T g1, db2 += sum_b dgate, dg1 = (dgate W2) * (g1 > 0), dW1 += dg1^T s, db1 += sum_b dg1,
  *        ds (B, C) = dg1 W1.  All parameter gradients are ACCUMULATED; scratch = B*Cr floats. */
 int tf_se_excite_fwd_f32(const float* s, const float* W1, const float* b1, const float* W2, const float* b2, int B, int C, int Cr, float* g1,
-                         float* gate, void* stream);
+                         float* gate, float* bwd_scratch /* optional (B, Cr): cleared here for tf_se_excite_bwd_f32(scratch_is_zero = 1) */, void* stream);
 int tf_se_excite_bwd_f32(const float* dgate, const float* s, const float* g1, const float* W1, const float* W2, int B, int C, int Cr, float* dW1,
-                         float* db1, float* dW2, float* db2, float* ds, float* scratch, void* stream);
+                         float* db1, float* dW2, float* db2, float* ds, float* scratch, int scratch_is_zero, void* stream);
 
 /* ---- resampling ------------------------------------------------------------------------------ */
 

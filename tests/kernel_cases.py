@@ -399,6 +399,10 @@ def check_se_excite(dev, B, C, Cr):
     close(ds, gs, what="se excite ds")
     for o, a, g, n in zip(out, acc, (gw1, gb1, gw2, gb2), ("dW1", "db1", "dW2", "db2")):
         close(o, a + g, what="se excite " + n)
+    # a second backward on the same g1 (the forward-cleared scratch is spent): the kernel clears its own scratch
+    out2 = [a.clone() for a in acc]
+    close(ops.se_excite_bwd(dgate, s.detach(), g1, w1.detach(), w2.detach(), *out2), gs, what="se excite ds (2nd backward)")
+    close(out2[0], acc[0] + gw1, what="se excite dW1 (2nd backward)")
 
 
 # ---------------------------------------------------------------- losses

@@ -22,7 +22,7 @@ __device__ __forceinline__ float dot4(const float4 a, const float4 b) { return a
 template <bool V4>
 __global__ void __launch_bounds__(1024) se_excite_fwd_kernel(const float* __restrict__ s, const float* __restrict__ W1, const float* __restrict__ b1,
                                                              const float* __restrict__ W2, const float* __restrict__ b2, int C, int Cr,
-                                                             float* __restrict__ g1, float* __restrict__ gate) {
+                                                             float* __restrict__ g1, float* __restrict__ gate, float* __restrict__ zs) {
     __shared__ __attribute__((aligned(16))) float ss[SE_MAXC];
     __shared__ __attribute__((aligned(16))) float hh[SE_MAXR];
     const int b = blockIdx.x, part = blockIdx.y;
@@ -57,7 +57,10 @@ __global__ void __launch_bounds__(1024) se_excite_fwd_kernel(const float* __rest
             if (lane == 0 && j < Cr) {
                 const float v = fmaxf(a + (b1 ? b1[j] : 0.f), 0.f);
                 hh[j] = v;
-                if (part == 0) g1[(long)b * Cr + j] = v;
+                if (part == 0) {
+                    g1[(long)b * Cr + j] = v;
+                    if (zs) zs[(long)b * Cr + j] = 0.f;      // the backward's (B, Cr) atomic accumulator, cleared here instead of by its own launch
+                }
             }
         }
     }
@@ -194,20 +197,20 @@ __global__ void __launch_bounds__(256) se_excite_bwd1_kernel(const float* __rest
 }  // namespace
 
 extern "C" int tf_se_excite_fwd_f32(const float* s, const float* W1, const float* b1, const float* W2, const float* b2, int B, int C, int Cr, float* g1,
-                                    float* gate, void* stream) {
+                                    float* gate, float* bwd_scratch, void* stream) {
     TF_REQUIRE(s && W1 && W2 && g1 && gate && B > 0 && C > 0 && Cr > 0 && C <= SE_MAXC && Cr <= SE_MAXR,
                "tf_se_excite_fwd_f32: bad arguments (C <= 4096, Cr <= 1024)");
     const bool v4 = C % 4 == 0 && Cr % 4 == 0 && aligned16(W1) && aligned16(W2);
-    if (v4) TF_LAUNCH(se_excite_fwd_kernel<true>, dim3(B, SE_SPLIT), dim3(1024), stream, s, W1, b1, W2, b2, C, Cr, g1, gate);
-    else TF_LAUNCH(se_excite_fwd_kernel<false>, dim3(B, SE_SPLIT), dim3(1024), stream, s, W1, b1, W2, b2, C, Cr, g1, gate);
+    if (v4) TF_LAUNCH(se_excite_fwd_kernel<true>, dim3(B, SE_SPLIT), dim3(1024), stream, s, W1, b1, W2, b2, C, Cr, g1, gate, bwd_scratch);
+    else TF_LAUNCH(se_excite_fwd_kernel<false>, dim3(B, SE_SPLIT), dim3(1024), stream, s, W1, b1, W2, b2, C, Cr, g1, gate, bwd_scratch);
     return launch_status("tf_se_excite_fwd_f32");
 }
 
 extern "C" int tf_se_excite_bwd_f32(const float* dgate, const float* s, const float* g1, const float* W1, const float* W2, int B, int C, int Cr,
-                                    float* dW1, float* db1, float* dW2, float* db2, float* ds, float* scratch, void* stream) {
+                                    float* dW1, float* db1, float* dW2, float* db2, float* ds, float* scratch, int scratch_is_zero, void* stream) {
     TF_REQUIRE(dgate && s && g1 && W1 && W2 && dW1 && dW2 && ds && scratch && B > 0 && B <= SE_MAXB && C > 0 && Cr > 0 &&
                    (long)B * Cr <= SE_MAXB * SE_MAXR / 2, "tf_se_excite_bwd_f32: bad arguments (B <= 16, B*Cr <= 8192)");
-    TF_LAUNCH(se_zero_kernel, dim3(cdiv((long)B * Cr, 256)), dim3(256), stream, scratch, B * Cr);
+    if (!scratch_is_zero) TF_LAUNCH(se_zero_kernel, dim3(cdiv((long)B * Cr, 256)), dim3(256), stream, scratch, B * Cr);
     TF_LAUNCH(se_excite_bwd2_kernel, dim3(cdiv(C, SE_ROWS)), dim3(256), stream, dgate, g1, W2, B, C, Cr, dW2, db2, scratch);
     TF_LAUNCH(se_excite_bwd1_kernel, dim3(cdiv(C, 32)), dim3(256), stream, (const float*)scratch, g1, s, W1, B, C, Cr, dW1, db1, ds);
     return launch_status("tf_se_excite_bwd_f32");

@@ -508,9 +508,12 @@ def se_excite_fwd(s, w1, b1, w2, b2):
     """Fused SE excitation: returns (g1 (B, Cr) post-ReLU, gate (B, C) pre-sigmoid)."""
     B, C = s.shape
     Cr = w1.shape[0]
-    g1 = torch.empty(B, Cr, dtype=torch.float32, device=s.device)
+    buf = torch.empty(2, B, Cr, dtype=torch.float32, device=s.device)
+    g1 = buf[0]
+    g1._bwd_scratch = buf[1]            # (B, Cr) accumulator of the backward, cleared by the forward kernel (saves one launch per SE block)
     gate = torch.empty(B, C, dtype=torch.float32, device=s.device)
-    check(L().tf_se_excite_fwd_f32(ptr(_c(s)), wptr(w1), ptr(b1), wptr(w2), ptr(b2), B, C, Cr, ptr(g1), ptr(gate), stream_of(s)), "tf_se_excite_fwd_f32")
+    check(L().tf_se_excite_fwd_f32(ptr(_c(s)), wptr(w1), ptr(b1), wptr(w2), ptr(b2), B, C, Cr, ptr(g1), ptr(gate), ptr(buf[1]), stream_of(s)),
+          "tf_se_excite_fwd_f32")
     return g1, gate
 
 
@@ -519,9 +522,14 @@ def se_excite_bwd(dgate, s, g1, w1, w2, dw1, db1, dw2, db2):
     B, C = s.shape
     Cr = w1.shape[0]
     ds = torch.empty(B, C, dtype=torch.float32, device=s.device)
-    scratch = torch.empty(B, Cr, dtype=torch.float32, device=s.device)
+    scratch = getattr(g1, "_bwd_scratch", None)      # cleared by se_excite_fwd; valid for ONE backward
+    zeroed = scratch is not None
+    if zeroed:
+        g1._bwd_scratch = None
+    else:
+        scratch = torch.empty(B, Cr, dtype=torch.float32, device=s.device)
     check(L().tf_se_excite_bwd_f32(ptr(_c(dgate)), ptr(_c(s)), ptr(_c(g1)), wptr(w1), wptr(w2), B, C, Cr, wptr(dw1), ptr(db1), wptr(dw2), ptr(db2),
-                                   ptr(ds), ptr(scratch), stream_of(s)), "tf_se_excite_bwd_f32")
+                                   ptr(ds), ptr(scratch), int(zeroed), stream_of(s)), "tf_se_excite_bwd_f32")
     return ds
 
 
