@@ -959,9 +959,14 @@ TWO_PASS_CASES = [(1, TWO_PASS + 2), (2, TWO_PASS + 3), (5, TWO_PASS + 4), (6, T
 
 def check_two_pass_splitk(dev, kind, sk):
     """k-slices store partial tiles into caller scratch, the fix-up pass sums them in order and applies the epilogue: every epilogue form
-    (bias + residual + ReLU; ReLU mask; accumulate), all four operand layouts, ragged N (scalar fix-up path), bitwise run-to-run equal."""
+    (bias + residual + ReLU; ReLU mask; accumulate), all four operand layouts, ragged N (scalar fix-up path), bitwise run-to-run equal;
+    once more in the f32x3 compute mode (the X3 kernel instantiations store their slices the same way)."""
     ops.force_dma(kind, sk)
     try:
+        ops.set_precision("f32x3")
+        x, w, b, r = R(200, 600, dev=dev), R(92, 600, dev=dev), R(92, dev=dev), R(200, 92, dev=dev)
+        close(ops.linear_fwd(x, w, b, relu=True, res=r), torch.relu(x @ w.t() + b + r), what="two-pass fwd (f32x3)")
+        ops.set_precision("fp32")
         for (m, n, k) in ((200, 92, 600), (130, 216, 1030), (257, 130, 520)):
             x, w, b, r = R(m, k, dev=dev), R(n, k, dev=dev), R(n, dev=dev), R(m, n, dev=dev)
             y = ops.linear_fwd(x, w, b, relu=True, res=r)
@@ -978,4 +983,5 @@ def check_two_pass_splitk(dev, kind, sk):
                 ops.gemm(a.t().contiguous(), bb, c, m, n, k, m, k, n, a_trans=True, alpha=0.5)
                 close(c, 0.5 * (a @ bb.t()), what="two-pass tt")
     finally:
+        ops.set_precision("fp32")
         ops.force_plan(0)
