@@ -252,7 +252,9 @@ def test_dropout_paths_match_oracle_with_the_same_masks():
     site, laid out like the product's tensors), so all 11 losses and every parameter gradient must agree as in the p = 0 tests."""
     import torch.nn as nn
     from transfuser_amd import ops
+    import transfuser_amd.transfuser as ptf
     cfg = mc.tiny_config(n_layer=2, dropout=0.1)
+    ptf.GPT._site_base = 0          # dropout sites are numbered per constructed GPT (class counter): the same masks whatever ran before
     prod, ref = mc.build_pair(cfg, "regnety_tiny", "cpu")
 
     class MaskDrop(nn.Module):
