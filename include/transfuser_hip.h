@@ -68,6 +68,10 @@ typedef struct {
     float* splitk_ws; int64_t splitk_ws_floats;
 } tf_gemm_desc;
 int tf_gemm_f32(const tf_gemm_desc* d, void* stream);
+/* Floats of splitk_ws this call can use: 0 unless the cached (or about-to-be-tuned) plan of the call's shape is a two-pass split-K plan, so
+ * the caller only allocates scratch for the few GEMMs that want it (the reference's addmm never needs caller scratch: torch's cuBLAS
+ * workspace plays this role, transfuser.py:500-507,539-541). */
+long tf_gemm_splitk_ws_floats(const tf_gemm_desc* d);
 
 /* 2-D convolution as implicit GEMM (im2col gather -> LDS -> MFMA): kernel 1x1 or 3x3, stride 1/2,
  * pad, groups.  Replaces cuDNN conv fwd/bwd of the RegNetY trunks (timm regnety_032 via

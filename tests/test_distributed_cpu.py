@@ -127,7 +127,8 @@ def _engine_worker(rank, world, port, tmp):
         prod, _ = mc.build_pair(cfg, "regnety_tiny", "cpu", seed=rank)  # different init per rank: the engine's broadcast equalises
         prod.train()
         eng = Engine(prod, cfg, lr=1e-3, **kw)
-        assert eng.cuts == (() if tag == "plain" else (3, 2, 1)) and eng.n_pieces() == len(eng.cuts) + 1
+        # DEFAULT_CUTS minus the cuts in front of GPT-4 Blocks 1..3 (n_layer = 1 here): after stages 3, 2, 1 + between the stage-3 trunks and GPT-3
+        assert eng.cuts == (() if tag == "plain" else ((3, 2, 0), (3, 0, 0), (2, 2, 0), (1, 2, 0))) and eng.n_pieces() == len(eng.cuts) + 1
         for _ in range(2):
             eng.train_step(batch)
         finals[tag] = (eng.arena, eng)

@@ -1,67 +1,99 @@
 #!/usr/bin/env python
 """Achieved HBM GB/s of the bandwidth-bound kernels north_star names (LayerNorm, softmax, BatchNorm, the H1 LiDAR histogram scatter, the
 H2 pillar index scan, AdamW) at the bench workload's shapes, HIP-event timed over repeated launches, against the algorithmic bytes of
-SURVEY.md section 8(d).  python tools/hbm_bench.py > profiles/r02_hbm_kernels.txt"""
-import os, sys, torch
+SURVEY.md section 8(d).
+
+  python tools/hbm_bench.py > profiles/r03_hbm_kernels.txt
+  python tools/hbm_bench.py --pmc --iters 8 --meta cases.json     (under rocprofv3 --pmc: tools/pmc_hbm.sh)
+
+--pmc: a marker kernel (tf_sigmoid_f32 on one element, used by no case) is launched before and after every case so tools/pmc_hbm_summary.py can
+cut the dispatch list of the counter CSV into cases (and drop the set-up kernels between two cases); --meta writes {case name, algorithmic bytes, calls} in launch order."""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, ROOT)
-from transfuser_amd import ops
-from transfuser_amd.data import synthetic_cloud
+from transfuser_amd import ops  # noqa: E402
+from transfuser_amd.data import synthetic_cloud  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--pmc", action="store_true")
+ap.add_argument("--iters", type=int, default=50)
+ap.add_argument("--meta", default=None)
+args = ap.parse_args()
 dev = "cuda"
 PEAK, ACHIEVABLE = 8.0e12, 6.3e12
+WARM = 5
+meta = []
+_marker = torch.zeros(1, device=dev)
 
 
-def timeit(fn, iters=50):
-    for _ in range(5):
+def timeit(fn, iters):
+    if args.pmc:
+        ops.sigmoid(_marker)
+    for _ in range(WARM):
         fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
         fn()
     e1.record(); e1.synchronize()
+    if args.pmc:
+        ops.sigmoid(_marker)      # end-of-case marker: the set-up kernels of the next case fall between two markers and are dropped
     return e0.elapsed_time(e1) * 1e-3 / iters
 
 
-def row(name, bytes_, sec):
-    print("%-62s %9.2f MB %9.1f us %8.2f TB/s  %5.1f %% of 8.0 TB/s  %5.1f %% of 6.3 achievable" %
+def row(name, bytes_, fn, iters=None):
+    iters = iters or args.iters
+    sec = timeit(fn, iters)
+    meta.append(dict(name=name, algorithmic_bytes=bytes_, calls=WARM + iters, event_us=sec * 1e6))
+    print("%-74s %9.2f MB %9.1f us %8.2f TB/s  %5.1f %% of 8.0 TB/s  %5.1f %% of 6.3 achievable" %
           (name, bytes_ / 1e6, sec * 1e6, bytes_ / sec / 1e12, 100 * bytes_ / sec / PEAK, 100 * bytes_ / sec / ACHIEVABLE), flush=True)
 
 
-print("# bandwidth-bound kernels at the B=10, 256x704 workload: algorithmic bytes (SURVEY.md 8d) / HIP-event time per launch, back-to-back launches")
+print("# bandwidth-bound kernels at the B=10, 256x704 workload: algorithmic bytes (SURVEY.md 8d) / HIP-event time per call, back-to-back calls")
 print("# (working sets below ~200 MB stay in the 256 MB Infinity Cache between launches, so small kernels measure on-die bandwidth + launch latency)")
 for C in (1512, 576, 216, 72):
     M = 1740
     x, g, b = torch.randn(M, C, device=dev), torch.ones(C, device=dev), torch.zeros(C, device=dev)
-    t = timeit(lambda: ops.layernorm_fwd(x, g, b))
-    row("layernorm_fwd  [1740 x %d]  (2 M C 4 B)" % C, 2 * M * C * 4, t)
+    row("layernorm_fwd  [1740 x %d]  (2 M C 4 B)" % C, 2 * M * C * 4, lambda: ops.layernorm_fwd(x, g, b))
     y, m, r = ops.layernorm_fwd(x, g, b)
     dg, db, dy = torch.zeros(C, device=dev), torch.zeros(C, device=dev), torch.randn(M, C, device=dev)
-    t = timeit(lambda: ops.layernorm_bwd(dy, x, g, m, r, dg, db))
-    row("layernorm_bwd  [1740 x %d]  (3 M C 4 B)" % C, 3 * M * C * 4, t)
+    row("layernorm_bwd  [1740 x %d]  (3 M C 4 B)" % C, 3 * M * C * 4, lambda: ops.layernorm_bwd(dy, x, g, m, r, dg, db))
 T, Tp, rows = 174, 176, 10 * 4 * 174
 att = torch.randn(10 * 4, T, Tp, device=dev)
-row("softmax_fwd    [B*4*174 x 174]  (2 B 4 174^2 4 B)", 2 * rows * T * 4, timeit(lambda: ops.softmax_fwd_(att, rows, T, Tp)))
+row("softmax_fwd    [B*4*174 x 174]  (2 B 4 174^2 4 B)", 2 * rows * T * 4, lambda: ops.softmax_fwd_(att, rows, T, Tp))
 p, dp = torch.softmax(torch.randn(10 * 4, T, Tp, device=dev), -1), torch.randn(10 * 4, T, Tp, device=dev)
-row("softmax_bwd    [B*4*174 x 174]  (3 B 4 174^2 4 B)", 3 * rows * T * 4, timeit(lambda: ops.softmax_bwd_(p, dp, rows, T, Tp)))
+row("softmax_bwd    [B*4*174 x 174]  (3 B 4 174^2 4 B)", 3 * rows * T * 4, lambda: ops.softmax_bwd_(p, dp, rows, T, Tp))
 for shape in ((10, 128, 352, 32), (10, 64, 176, 72), (10, 16, 44, 576)):
     x = torch.randn(*shape, device=dev)
     C = shape[-1]
     g, b, rm, rv = torch.ones(C, device=dev), torch.zeros(C, device=dev), torch.zeros(C, device=dev), torch.ones(C, device=dev)
     E = x.numel()
-    row("batchnorm fwd (stats + apply + ReLU) %s  (3 E 4 B)" % (shape,), 3 * E * 4, timeit(lambda: ops.bn_fwd(x, g, b, rm, rv, None, True)))
+    row("batchnorm fwd (stats + apply + ReLU) %s  (3 E 4 B)" % (shape,), 3 * E * 4, lambda: ops.bn_fwd(x, g, b, rm, rv, None, True))
     y, sm, si = ops.bn_fwd(x, g, b, rm, rv, None, True)
     dz, dg, db = torch.randn_like(x), torch.zeros(C, device=dev), torch.zeros(C, device=dev)
-    row("batchnorm bwd (reduce + apply)       %s  (5 E 4 B)" % (shape,), 5 * E * 4, timeit(lambda: ops.bn_bwd(dz, y, x, g, sm, si, dg, db)))
+    row("batchnorm bwd (reduce + apply)       %s  (5 E 4 B)" % (shape,), 5 * E * 4, lambda: ops.bn_bwd(dz, y, x, g, sm, si, dg, db))
 pts = torch.from_numpy(synthetic_cloud(10, 32768, 0)).to(dev)
-row("H1 lidar_hist  10 x 32768 points  (N 16 B read + 512 KB written / sample)", 10 * (32768 * 16 + 2 * 256 * 256 * 4), timeit(lambda: ops.lidar_hist(pts)))
+row("H1 lidar_hist  10 x 32768 points  (N 16 B read + 512 KB written / sample)", 10 * (32768 * 16 + 2 * 256 * 256 * 4), lambda: ops.lidar_hist(pts))
 raw = torch.zeros(10, 40000, 4, device=dev); raw[:, :32768] = pts
 num = torch.full((10,), 32768, dtype=torch.int32, device=dev)
-row("H2 pillar_index 10 x 40000 points (16 B / point + 4 B / grid cell read)", 10 * (32768 * 16 + 257 * 257 * 4), timeit(lambda: ops.pillar_index(raw, num, -16, 16, -32, 0, 8), iters=10))
+row("H2 pillar_index 10 x 40000 points (16 B / point + 4 B / grid cell read)", 10 * (32768 * 16 + 257 * 257 * 4),
+    lambda: ops.pillar_index(raw, num, -16, 16, -32, 0, 8), iters=min(10, args.iters))
 n = 168018327
-p_, g_, m_, v_ = [torch.randn(n, device=dev) * 0.01 for _ in range(4)]
+# ONE allocation cut into 4 arenas, like train.ParamArena / FlatAdamW (4 separate torch.randn(n) tensors were what r02 timed)
+buf = torch.randn(4, (n + 63) // 64 * 64, device=dev) * 0.01
+p_, g_, m_, v_ = buf[0, :n], buf[1, :n], buf[2, :n], buf[3, :n]
 v_.abs_()
 st = torch.tensor([0.0, 1e-4], device=dev)
-row("adamw_kernel   168.0 M parameters  (28 B / parameter)", 28 * n, timeit(lambda: ops.adamw_(p_, g_, m_, v_, st), iters=10))
+row("adamw_kernel   168.0 M parameters  (28 B / parameter)", 28 * n, lambda: ops.adamw_(p_, g_, m_, v_, st), iters=min(10, args.iters))
 x = torch.randn(10 * 174, 1512, device=dev)
 seed = torch.zeros(1, dtype=torch.int32, device=dev)
-row("dropout_kernel [1740 x 1512]  (2 M C 4 B)", 2 * x.numel() * 4, timeit(lambda: ops.dropout(x, seed, 3, 0.1)))
+row("dropout_kernel [1740 x 1512]  (2 M C 4 B)", 2 * x.numel() * 4, lambda: ops.dropout(x, seed, 3, 0.1))
+torch.cuda.synchronize()
+if args.meta:
+    json.dump(meta, open(args.meta, "w"), indent=1)

@@ -2,11 +2,14 @@
 
 Same attribute names and defaults as the reference's ``GlobalConfig`` for every field the
 training hot path reads (model.py:549-609, transfuser.py:19-109,221-243,326-331,
-train.py:118-125).  Dataset-folder enumeration (config.py:206-247) and the CARLA agent / PID /
-camera fields that only ``submission_agent.py`` uses are out of scope (SURVEY.md section 8);
-``setting`` is accepted and ignored so ``GlobalConfig(setting='eval')`` keeps working.
+train.py:118-125) and the dataset-folder enumeration of config.py:206-247 (``train_data`` / ``val_data`` for the settings 'all' and
+'02_05_withheld'; 'eval' touches no files).  The CARLA agent / camera fields that only ``submission_agent.py`` uses are out of scope
+(SURVEY.md section 8).
 Any reference ``GlobalConfig`` instance can be passed to our constructors instead.
 """
+
+
+import os
 
 
 class GlobalConfig:
@@ -122,6 +125,23 @@ class GlobalConfig:
         self.root_dir = root_dir
         self.setting = setting
         self.train_data, self.val_data = [], []
+        if root_dir and os.path.isdir(root_dir) and setting in ('all', '02_05_withheld'):
+            # config.py:206-243: root_dir/<scenario folder>/<town folder>/<route>/...; train_data / val_data list the TOWN folders.
+            # 'all': every town trains, the first scenario folder doubles as validation; '02_05_withheld': Town02 / Town05 folders are
+            # validation only.  (Sorted here - os.listdir order is file-system dependent in the reference.)
+            scenarios = sorted(d for d in os.listdir(root_dir) if os.path.isdir(os.path.join(root_dir, d)))
+            self.train_towns = scenarios
+            self.val_towns = scenarios[:1] if setting == 'all' else scenarios
+            for scn, dst, is_val in [(t, self.train_data, False) for t in self.train_towns] + [(t, self.val_data, True) for t in self.val_towns]:
+                for town in sorted(os.listdir(os.path.join(root_dir, scn))):
+                    if not os.path.isdir(os.path.join(root_dir, scn, town)):
+                        continue
+                    held = ('Town02' in town) or ('Town05' in town)
+                    if setting == '02_05_withheld' and held != is_val:
+                        continue
+                    dst.append(os.path.join(root_dir, scn, town))
+        elif setting not in ('all', '02_05_withheld', 'eval'):
+            print("Error: Selected setting: ", setting, " does not exist.")     # config.py:246
         # class-level lists are copied so per-instance edits (train.py:122-125) stay local
         self.detailed_losses_weights = list(type(self).detailed_losses_weights)
         for k, v in kwargs.items():

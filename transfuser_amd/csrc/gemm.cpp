@@ -21,6 +21,23 @@ static PlainOp make_plain(const float* p, long ld, int rows, int cols, long so, 
     return o;
 }
 
+// Scratch floats tf_gemm_f32 can use for this call's deterministic two-pass split-K (tf_gemm_desc.splitk_ws): 0 when the cached plan of the
+// call's site / shape is not a two-pass plan (so the caller need not allocate anything), the S-slice size when it is, and the 4-slice
+// maximum while the autotuner is on or a test pins a two-pass plan (the candidates need the scratch to be tried at all).
+extern "C" long tf_gemm_splitk_ws_floats(const tf_gemm_desc* d) {
+    if (!d || d->batch != 1 || d->m <= 0 || d->n <= 0 || d->k <= 0) return 0;
+    const long slice = (long)d->m * twopass_ldws(d->n);
+    GemmPlan p;
+    if (forced_plan(&p)) return p.splitk >= kTwoPass ? 4 * slice : 0;
+    const char* site = !d->a_trans ? (d->b_trans ? "tf_gemm_f32[nn]" : "tf_gemm_f32[nt]") : (d->b_trans ? "tf_gemm_f32[tn]" : "tf_gemm_f32[tt]");
+    int M = d->m, N = d->n;
+    if (d->a_trans && d->b_trans && d->m <= 32 && d->n >= 2 * d->m && !d->bias && !d->res && !d->relu) return 0;       // swapped (column-strided) output: no two-pass
+    const bool sk_ok = d->accumulate && !d->bias && !d->res && !d->relu;
+    const int acc = (d->accumulate ? (sk_ok ? 2 : 1) : 0) + 4 * gemm_precision();
+    if (plan_lookup(site, M, N, d->k, 1, acc, &p)) return p.splitk >= kTwoPass ? (long)(p.splitk - kTwoPass) * slice : 0;
+    return autotune_enabled() ? 4 * slice : 0;
+}
+
 extern "C" int tf_gemm_f32(const tf_gemm_desc* d, void* stream) {
     TF_REQUIRE(d && d->a && d->b && d->c, "tf_gemm_f32: null operand");
     TF_REQUIRE(d->m >= 0 && d->n >= 0 && d->k >= 0 && d->batch >= 1, "tf_gemm_f32: bad sizes m=%d n=%d k=%d batch=%d", d->m, d->n,

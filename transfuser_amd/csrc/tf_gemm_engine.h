@@ -758,12 +758,25 @@ inline void trace_candidate(const GemmPlan& p, int M, int N, int K, int batch, i
 }
 // cudnn.benchmark-style tuning (the reference enables it, train.py:115): time every candidate tiling of this exact
 // problem ONCE with HIP events during eager warm-up; the winner goes into the plan cache.  Trial launches of
-// accumulating epilogues run with alpha = 0 so the destination is left unchanged.
+// accumulating epilogues write into a scratch copy of the destination extent, so the live accumulator is left unchanged.
 template <class LA, bool A_KC, class LB, bool B_KC>
 inline GemmPlan autotune_gemm(const LA& la, const LB& lb, const GemmEpi& ep, int M, int N, int K, int batch, bool allow_splitk, void* stream) {
     static const int tiles[6][2] = {{128, 128}, {128, 96}, {128, 64}, {128, 32}, {64, 128}, {64, 64}};
     GemmEpi trial = ep;
-    if (ep.mode != 0) { trial.alpha = 0.f; trial.bias = nullptr; trial.res = nullptr; trial.relu = 0; trial.mask = nullptr; }   // accumulating trials add exactly +0
+    float* trial_scratch = nullptr;
+    if (ep.mode != 0) {
+        // accumulating epilogues (weight gradients into the gradient arena): the trials write to a SCRATCH copy of the destination extent, never
+        // to the live accumulator (a trial that multiplied the accumulator by alpha = 0 would turn an Inf / NaN already in it into NaN for good)
+        const long zo = (long)((batch - 1) / ep.inner), zi = (long)((batch - 1) % ep.inner);
+        const long extent = zo * (ep.sc_outer > 0 ? ep.sc_outer : 0) + zi * (ep.sc_inner > 0 ? ep.sc_inner : 0) + (long)(M - 1) * ep.ldc + (long)(N - 1) * ep.ldcj + 1;
+        if (ep.sc_outer >= 0 && ep.sc_inner >= 0 && hipMalloc((void**)&trial_scratch, (size_t)extent * sizeof(float)) == hipSuccess) {
+            hipMemsetAsync(trial_scratch, 0, (size_t)extent * sizeof(float), (hipStream_t)stream);
+            trial.C = trial_scratch;
+        } else {                                     // cannot allocate: fall back to the untimed heuristic plan, the accumulator stays untouched
+            (void)hipGetLastError();
+            return plan_gemm(M, N, K, batch, allow_splitk);
+        }
+    }
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     GemmPlan best = plan_gemm(M, N, K, batch, allow_splitk);
@@ -839,6 +852,7 @@ inline GemmPlan autotune_gemm(const LA& la, const LB& lb, const GemmEpi& ep, int
         }
     }
     hipEventDestroy(e0); hipEventDestroy(e1);
+    if (trial_scratch) { hipStreamSynchronize((hipStream_t)stream); hipFree(trial_scratch); }
     return best;
 }
 #endif

@@ -100,8 +100,14 @@ class CARLA_Data(torch.utils.data.Dataset):
     ``__getitem__`` only DECODES (PIL / numpy / json - the CPU part that cannot move) and returns raw arrays; alignment, histogram, crops,
     depth / class / BEV decoding and the augmentation geometry are applied to the whole collated batch on the GPU by ``GpuBatchPrep``."""
 
-    def __init__(self, root, config):
+    def __init__(self, root, config, shared_dict=None):
+        """``shared_dict``: the reference's ``--use_disk_cache 1`` (train.py:77-90, data.py:133-153: a diskcache.Cache under $SCRATCH holding
+        the decoded sample) - here a directory path: the DECODED raw item of every index is stored there once (torch.save, atomic rename)
+        and read back on later epochs / by the other ranks instead of decoding PNG / JSON / NPY from the slow storage again."""
         self.config = config
+        self.cache_dir = shared_dict
+        if self.cache_dir:
+            os.makedirs(self.cache_dir, exist_ok=True)
         self.seq_len, self.pred_len = int(config.seq_len), int(config.pred_len)
         assert self.seq_len == 1, "seq_len 1 (the reference's only configuration, config.py:14)"
         self.frames = []
@@ -118,6 +124,23 @@ class CARLA_Data(torch.utils.data.Dataset):
         return len(self.frames)
 
     def __getitem__(self, index):
+        if not self.cache_dir:
+            return self._decode(index)
+        route_dir, seq = self.frames[index]
+        import hashlib
+        path = os.path.join(self.cache_dir, "%s_%04d.pt" % (hashlib.sha1(route_dir.encode()).hexdigest()[:16], seq))
+        if os.path.exists(path):
+            item = torch.load(path)
+        else:
+            item = self._decode(index, augment=False)
+            tmp = "%s.%d.tmp" % (path, os.getpid())
+            torch.save(item, tmp)
+            os.replace(tmp, path)          # atomic: concurrent DataLoader workers / ranks never read a partial file
+        # the augmentation draw is per access (data.py:213-220 draws it after the cache lookup), so it is re-done on the cached labels
+        item.update(host_sample_geometry(item.pop("_labels"), item.pop("_meas"), self.config, self.pred_len))
+        return item
+
+    def _decode(self, index, augment=True):
         import json
         from PIL import Image
         route_dir, seq = self.frames[index]
@@ -135,7 +158,7 @@ class CARLA_Data(torch.utils.data.Dataset):
         pts[:n] = lidar[:n, :4]
         sem = np.asarray(Image.open(os.path.join(route_dir, "semantics", "%04d.png" % seq)))
         sem = sem[..., 0] if sem.ndim == 3 else sem
-        host = host_sample_geometry(labels, meas, self.config, self.pred_len)
+        host = host_sample_geometry(labels, meas, self.config, self.pred_len) if augment else dict(_labels=labels, _meas=meas)
         return dict(rgb_u8=torch.from_numpy(rd("rgb", "%04d.png" % seq).copy()), depth_u8=torch.from_numpy(rd("depth", "%04d.png" % seq).copy()),
                     sem_u8=torch.from_numpy(sem.copy()[..., None]), bev_u8=torch.from_numpy(rd("topdown", "encoded_%04d.png" % seq).copy()),
                     lidar_raw=torch.from_numpy(pts), num_points=torch.tensor(n, dtype=torch.int32),
@@ -252,13 +275,20 @@ def _tp_pixel(target_point):
     return int(p[0]), int(p[1])
 
 
-def make_datasets(root_dir, config, height=160, width=704):
-    """(train_set, val_set) for train.main: 'synthetic:N' -> seeded SyntheticDataset (7/8 train, 1/8 val); a directory -> CARLA_Data over its
-    town folders (config.train_towns / val_towns when set, train.py:148-149)."""
+def make_datasets(root_dir, config, height=160, width=704, shared_dict=None):
+    """(train_set, val_set) for train.main (train.py:148-149): 'synthetic:N' -> seeded SyntheticDataset (7/8 train, 1/8 val); a directory ->
+    ``CARLA_Data(root=config.train_data)`` / ``config.val_data``, the town folders GlobalConfig enumerated from the reference layout
+    root/<scenario>/<town>/<route> (config.py:209-243).  A directory whose children are town folders directly (no scenario level) is
+    accepted too: its town folders then train and the first one validates."""
     if str(root_dir).startswith("synthetic"):
         n = int(str(root_dir).split(":")[1]) if ":" in str(root_dir) else 64
         return SyntheticDataset(n, height, width, seed=0), SyntheticDataset(max(1, n // 8), height, width, seed=1)
-    towns = sorted(os.path.join(root_dir, t) for t in os.listdir(root_dir) if os.path.isdir(os.path.join(root_dir, t)))
-    train = getattr(config, "train_data", None) or towns
-    val = getattr(config, "val_data", None) or towns[:1]
-    return CARLA_Data(train, config), CARLA_Data(val, config)
+    train, val = list(getattr(config, "train_data", None) or []), list(getattr(config, "val_data", None) or [])
+    has_routes = lambda d: any(os.path.isdir(os.path.join(d, r, "lidar")) for r in os.listdir(d))
+    if not any(has_routes(d) for d in train):      # no scenario level: root/<town>/<route>
+        towns = sorted(os.path.join(root_dir, t) for t in os.listdir(root_dir) if os.path.isdir(os.path.join(root_dir, t)))
+        train, val = towns, towns[:1]
+    tr, va = CARLA_Data(train, config, shared_dict), CARLA_Data(val, config, shared_dict)
+    if len(tr) == 0:
+        raise RuntimeError("no training frames found under %s (expected <root>/<scenario>/<town>/<route>/{rgb,lidar,label_raw,...}, config.py:209-243)" % root_dir)
+    return tr, va

@@ -298,6 +298,161 @@ def _attn_ctx(att, qkv, B, T, C, nh, Tp):
     return y
 
 
+# The stage is written as three helpers per direction (embed, one Block, output) that BOTH the one-node GPTStageFn (single GPU: the whole
+# stage is one autograd node) and the split Functions below (multi-GPU: train.Engine may cut the backward between two Blocks of a
+# stage, so that the 27.5 M-parameter Blocks of GPT-4 are all-reduced one by one while the next one is differentiated) run.
+def _gpt_dims(gpt, s_img, s_lid):
+    cfg = gpt.geom
+    n_img, n_lid = cfg.ih * cfg.iw, cfg.lh * cfg.lw
+    return cfg, s_img[0], s_img[3], n_img, n_lid, n_img + n_lid
+
+
+def _gpt_embed_fwd(gpt, x_img, x_lid, velocity):
+    cfg, B, C, n_img, n_lid, T = _gpt_dims(gpt, x_img.shape, x_lid.shape)
+    tok = torch.empty(B, T, C, dtype=torch.float32, device=x_img.device)
+    bvec = None
+    if gpt.use_velocity:
+        bvec = ops.linear_fwd(velocity, gpt.vel_emb.weight, gpt.vel_emb.bias)
+    ops.pool_tokens_fwd(x_img, cfg.ih, cfg.iw, gpt.pos_emb, tok, 0, bvec)
+    ops.pool_tokens_fwd(x_lid, cfg.lh, cfg.lw, gpt.pos_emb, tok, n_img, bvec)
+    x = tok.view(B * T, C)
+    if gpt.training and gpt.pdrop_any and gpt.embd_pdrop > 0:
+        x = ops.dropout(x, gpt.seed, gpt.site(0), gpt.embd_pdrop)
+    return x
+
+
+def _gpt_embed_bwd(gpt, dx, s_img, s_lid, velocity, drop, add_img=None, add_lid=None):
+    """dx (B*T, C) is consumed (modified in place).  Returns the gradients of the two feature maps: add_* + pool^T(dtok)."""
+    cfg, B, C, n_img, n_lid, T = _gpt_dims(gpt, s_img, s_lid)
+    if drop and gpt.embd_pdrop > 0:
+        ops.dropout(dx, gpt.seed, gpt.site(0), gpt.embd_pdrop, out=dx)
+    dtok = dx.view(B, T, C)
+    ops.colsum(dtok, 1, B, T * C, 1.0, out=gbuf(gpt.pos_emb).view(1, -1), accumulate=True)
+    if gpt.use_velocity:
+        db = ops.colsum(dtok, B, T, C, 1.0)
+        ops.linear_wgrad(db, velocity, gbuf(gpt.vel_emb.weight))
+        bias_grad(db, gpt.vel_emb.bias)
+    dx_img = ops.pool_tokens_bwd(dtok, s_img, cfg.ih, cfg.iw, 0, add=add_img)
+    dx_lid = ops.pool_tokens_bwd(dtok, s_lid, cfg.lh, cfg.lw, n_img, add=add_lid)
+    return dx_img, dx_lid
+
+
+def _gpt_block_fwd(gpt, li, x, B, T, drop):
+    """One transformer Block (transfuser.py:545-549) on x (B*T, C); returns (x_out, saved)."""
+    blk = gpt.blocks[li]
+    C, nh, dev = x.shape[1], gpt.n_head, x.device
+    h1, m1, r1 = ops.layernorm_fwd(x, blk.ln1.weight, blk.ln1.bias, blk.ln1.eps)
+    qkv = torch.empty(B * T, 3 * C, dtype=torch.float32, device=dev)
+    fw = blk.attn.fused()
+    if fw is not None:
+        ops.linear_fwd(h1, fw[0], fw[1], out=qkv)
+    else:
+        for j, lin in enumerate((blk.attn.key, blk.attn.query, blk.attn.value)):
+            ops.linear_fwd(h1, lin.weight, lin.bias, out=qkv[:, j * C:(j + 1) * C])
+    if drop and gpt.attn_pdrop > 0:
+        att, Tp, att_d = _attn_fwd(qkv, B, T, C, nh, drop=(gpt.seed, gpt.site(4 * li + 1), gpt.attn_pdrop))
+    else:
+        att, Tp = _attn_fwd(qkv, B, T, C, nh)
+        att_d = att
+    y_att = _attn_ctx(att_d, qkv, B, T, C, nh, Tp)
+    if drop and gpt.resid_pdrop > 0:
+        pr = ops.linear_fwd(y_att, blk.attn.proj.weight, blk.attn.proj.bias)
+        x_mid = ops.dropout_add(pr, x, gpt.seed, gpt.site(4 * li + 2), gpt.resid_pdrop, out=pr)
+    else:
+        x_mid = ops.linear_fwd(y_att, blk.attn.proj.weight, blk.attn.proj.bias, res=x)
+    h2, m2, r2 = ops.layernorm_fwd(x_mid, blk.ln2.weight, blk.ln2.bias, blk.ln2.eps)
+    a1 = ops.linear_fwd(h2, blk.mlp[0].weight, blk.mlp[0].bias, relu=True)
+    if drop and gpt.resid_pdrop > 0:
+        f2 = ops.linear_fwd(a1, blk.mlp[2].weight, blk.mlp[2].bias)
+        x_out = ops.dropout_add(f2, x_mid, gpt.seed, gpt.site(4 * li + 3), gpt.resid_pdrop, out=f2)
+    else:
+        x_out = ops.linear_fwd(a1, blk.mlp[2].weight, blk.mlp[2].bias, res=x_mid)
+    return x_out, (x, h1, m1, r1, qkv, att, att_d, Tp, y_att, x_mid, h2, m2, r2, a1)
+
+
+def _gpt_block_bwd(gpt, li, saved, dx, B, T, drop):
+    """Backward of one Block: dx (B*T, C) = gradient of the Block's output, updated IN PLACE to the gradient of its input."""
+    blk = gpt.blocks[li]
+    x, h1, m1, r1, qkv, att, att_d, Tp, y_att, x_mid, h2, m2, r2, a1 = saved
+    C, nh = x.shape[1], gpt.n_head
+    hs = C // nh
+    alpha = 1.0 / math.sqrt(hs)
+    fc1, fc2, proj = blk.mlp[0], blk.mlp[2], blk.attn.proj
+    # ---- MLP: x_out = x_mid + drop(fc2(relu(fc1(ln2(x_mid)))))
+    dres = dx
+    if drop and gpt.resid_pdrop > 0:
+        dres = ops.dropout(dx, gpt.seed, gpt.site(4 * li + 3), gpt.resid_pdrop)
+    ops.linear_wgrad(dres, a1, gbuf(fc2.weight))
+    bias_grad(dres, fc2.bias)
+    da1 = ops.linear_dgrad(dres, fc2.weight, mask=a1)     # ReLU backward fused into the dgrad epilogue
+    ops.linear_wgrad(da1, h2, gbuf(fc1.weight))
+    bias_grad(da1, fc1.bias)
+    dh2 = ops.linear_dgrad(da1, fc1.weight)
+    # dx_mid = dx + ln2_bwd(dh2): accumulate in place into dx
+    ops.layernorm_bwd(dh2, x_mid, blk.ln2.weight, m2, r2, gbuf(blk.ln2.weight), gbuf(blk.ln2.bias), dx=dx, accumulate=True)
+    # ---- attention: x_mid = x + drop(proj(att @ v))
+    dres = dx
+    if drop and gpt.resid_pdrop > 0:
+        dres = ops.dropout(dx, gpt.seed, gpt.site(4 * li + 2), gpt.resid_pdrop)
+    ops.linear_wgrad(dres, y_att, gbuf(proj.weight))
+    bias_grad(dres, proj.bias)
+    dy = ops.linear_dgrad(dres, proj.weight)
+    dqkv = torch.empty_like(qkv)
+    datt = torch.empty_like(att)
+    k, q, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+    sq, sp, sy = (T * 3 * C, hs), (nh * T * Tp, T * Tp), (T * C, hs)
+    ops.gemm(dy, v, datt, T, T, hs, C, 3 * C, Tp, batch=B * nh, inner=nh, sa=sy, sb=sq, sc=sp)                       # dP = dY V^T
+    ops.gemm(att_d, dy, dqkv[:, 2 * C:], T, hs, T, Tp, C, 3 * C, a_trans=True, b_trans=True, batch=B * nh, inner=nh,
+             sa=sp, sb=sy, sc=sq)                                                                                     # dV = P^T dY
+    if drop and gpt.attn_pdrop > 0:
+        ops.softmax_dropout_bwd_(att, datt, B * nh * T, T, Tp, gpt.seed, gpt.site(4 * li + 1), gpt.attn_pdrop)
+    else:
+        ops.softmax_bwd_(att, datt, B * nh * T, T, Tp)
+    ops.gemm(datt, k, dqkv[:, C:2 * C], T, hs, T, Tp, 3 * C, 3 * C, b_trans=True, alpha=alpha, batch=B * nh, inner=nh,
+             sa=sp, sb=sq, sc=sq)                                                                                     # dQ = dS K
+    ops.gemm(datt, q, dqkv[:, :C], T, hs, T, Tp, 3 * C, 3 * C, a_trans=True, b_trans=True, alpha=alpha, batch=B * nh, inner=nh,
+             sa=sp, sb=sq, sc=sq)                                                                                     # dK = dS^T Q
+    fw = blk.attn.fused()
+    if fw is not None:
+        ops.linear_wgrad(dqkv, h1, fw[2])
+        ops.colsum(dqkv, 1, B * T, 3 * C, 1.0, out=fw[3].view(1, -1), accumulate=True)
+        dh1 = ops.linear_dgrad(dqkv, fw[0])
+    else:
+        dh1 = None
+        for j, lin in enumerate((blk.attn.key, blk.attn.query, blk.attn.value)):
+            dj = dqkv[:, j * C:(j + 1) * C]
+            ops.linear_wgrad(dj, h1, gbuf(lin.weight))
+            dh1 = ops.linear_dgrad(dj, lin.weight, out=dh1, accumulate=dh1 is not None)
+        b3 = ops.colsum(dqkv, 1, B * T, 3 * C, 1.0)
+        for j, lin in enumerate((blk.attn.key, blk.attn.query, blk.attn.value)):
+            ops.axpby(gbuf(lin.bias), b3[0, j * C:(j + 1) * C], 1.0, 1.0, out=gbuf(lin.bias))
+    ops.layernorm_bwd(dh1, x, blk.ln1.weight, m1, r1, gbuf(blk.ln1.weight), gbuf(blk.ln1.bias), dx=dx, accumulate=True)
+    return dx
+
+
+def _gpt_out_fwd(gpt, x, x_img, x_lid):
+    """ln_f -> raw view (quirk Q1) -> bilinear up-sample -> residual add, for both branches."""
+    cfg, B, C, n_img, n_lid, T = _gpt_dims(gpt, x_img.shape, x_lid.shape)
+    _, Hi, Wi, _ = x_img.shape
+    _, Hl, Wl, _ = x_lid.shape
+    xf, mf, rf = ops.layernorm_fwd(x, gpt.ln_f.weight, gpt.ln_f.bias, gpt.ln_f.eps)
+    # Q1: token memory (hw, C) of each sample is re-read as (C, h, w); strides relative to the slice start
+    out_img = ops.bilinear_fwd(xf, B, C, cfg.ih, cfg.iw, Hi, Wi, add=x_img, in_strides=(T * C, cfg.ih * cfg.iw, cfg.iw, 1))
+    out_lid = ops.bilinear_fwd(xf[n_img:], B, C, cfg.lh, cfg.lw, Hl, Wl, add=x_lid, in_strides=(T * C, cfg.lh * cfg.lw, cfg.lw, 1))
+    return out_img, out_lid, mf, rf
+
+
+def _gpt_out_bwd(gpt, d_img, d_lid, x_last, mf, rf, s_img, s_lid):
+    """(d_img, d_lid contiguous) -> gradient of the token matrix entering ln_f (a fresh tensor the Block backwards update in place)."""
+    cfg, B, C, n_img, n_lid, T = _gpt_dims(gpt, s_img, s_lid)
+    _, Hi, Wi, _ = s_img
+    _, Hl, Wl, _ = s_lid
+    dxf = torch.empty(B * T, C, dtype=torch.float32, device=d_img.device)
+    ops.bilinear_bwd(d_img, B, C, cfg.ih, cfg.iw, Hi, Wi, out=dxf, in_strides=(T * C, cfg.ih * cfg.iw, cfg.iw, 1), in_nhwc=False)
+    ops.bilinear_bwd(d_lid, B, C, cfg.lh, cfg.lw, Hl, Wl, out=dxf[n_img:], in_strides=(T * C, cfg.lh * cfg.lw, cfg.lw, 1), in_nhwc=False)
+    return ops.layernorm_bwd(dxf, x_last, gpt.ln_f.weight, mf, rf, gbuf(gpt.ln_f.weight), gbuf(gpt.ln_f.bias))
+
+
 @routes_param_grads
 class GPTStageFn(torch.autograd.Function):
     """One fusion stage (transfuser.py:150-157 + GPT.forward :333-366): adaptive pools -> tokens + pos_emb
@@ -305,141 +460,105 @@ class GPTStageFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x_img, x_lid, gpt, velocity, *params):
-        cfg = gpt.geom
-        B, Hi, Wi, C = x_img.shape
-        _, Hl, Wl, _ = x_lid.shape
-        n_img, n_lid = cfg.ih * cfg.iw, cfg.lh * cfg.lw
-        T = n_img + n_lid
-        nh = gpt.n_head
-        dev = x_img.device
-        tok = torch.empty(B, T, C, dtype=torch.float32, device=dev)
-        bvec = None
-        if gpt.use_velocity:
-            bvec = ops.linear_fwd(velocity, gpt.vel_emb.weight, gpt.vel_emb.bias)
-        ops.pool_tokens_fwd(x_img, cfg.ih, cfg.iw, gpt.pos_emb, tok, 0, bvec)
-        ops.pool_tokens_fwd(x_lid, cfg.lh, cfg.lw, gpt.pos_emb, tok, n_img, bvec)
+        B, T = x_img.shape[0], gpt.geom.ih * gpt.geom.iw + gpt.geom.lh * gpt.geom.lw
         drop = gpt.training and gpt.pdrop_any
-        x = tok.view(B * T, C)
-        if drop and gpt.embd_pdrop > 0:
-            x = ops.dropout(x, gpt.seed, gpt.site(0), gpt.embd_pdrop)
+        x = _gpt_embed_fwd(gpt, x_img, x_lid, velocity)
         saved = []
-        for li, blk in enumerate(gpt.blocks):
-            h1, m1, r1 = ops.layernorm_fwd(x, blk.ln1.weight, blk.ln1.bias, blk.ln1.eps)
-            qkv = torch.empty(B * T, 3 * C, dtype=torch.float32, device=dev)
-            fw = blk.attn.fused()
-            if fw is not None:
-                ops.linear_fwd(h1, fw[0], fw[1], out=qkv)
-            else:
-                for j, lin in enumerate((blk.attn.key, blk.attn.query, blk.attn.value)):
-                    ops.linear_fwd(h1, lin.weight, lin.bias, out=qkv[:, j * C:(j + 1) * C])
-            if drop and gpt.attn_pdrop > 0:
-                att, Tp, att_d = _attn_fwd(qkv, B, T, C, nh, drop=(gpt.seed, gpt.site(4 * li + 1), gpt.attn_pdrop))
-            else:
-                att, Tp = _attn_fwd(qkv, B, T, C, nh)
-                att_d = att
-            y_att = _attn_ctx(att_d, qkv, B, T, C, nh, Tp)
-            if drop and gpt.resid_pdrop > 0:
-                pr = ops.linear_fwd(y_att, blk.attn.proj.weight, blk.attn.proj.bias)
-                x_mid = ops.dropout_add(pr, x, gpt.seed, gpt.site(4 * li + 2), gpt.resid_pdrop, out=pr)
-            else:
-                x_mid = ops.linear_fwd(y_att, blk.attn.proj.weight, blk.attn.proj.bias, res=x)
-            h2, m2, r2 = ops.layernorm_fwd(x_mid, blk.ln2.weight, blk.ln2.bias, blk.ln2.eps)
-            a1 = ops.linear_fwd(h2, blk.mlp[0].weight, blk.mlp[0].bias, relu=True)
-            if drop and gpt.resid_pdrop > 0:
-                f2 = ops.linear_fwd(a1, blk.mlp[2].weight, blk.mlp[2].bias)
-                x_out = ops.dropout_add(f2, x_mid, gpt.seed, gpt.site(4 * li + 3), gpt.resid_pdrop, out=f2)
-            else:
-                x_out = ops.linear_fwd(a1, blk.mlp[2].weight, blk.mlp[2].bias, res=x_mid)
-            saved.append((x, h1, m1, r1, qkv, att, att_d, Tp, y_att, x_mid, h2, m2, r2, a1))
-            x = x_out
-        xf, mf, rf = ops.layernorm_fwd(x, gpt.ln_f.weight, gpt.ln_f.bias, gpt.ln_f.eps)
-        # Q1: token memory (hw, C) of each sample is re-read as (C, h, w); strides relative to the slice start
-        out_img = ops.bilinear_fwd(xf, B, C, cfg.ih, cfg.iw, Hi, Wi, add=x_img, in_strides=(T * C, cfg.ih * cfg.iw, cfg.iw, 1))
-        out_lid = ops.bilinear_fwd(xf[n_img:], B, C, cfg.lh, cfg.lw, Hl, Wl, add=x_lid, in_strides=(T * C, cfg.lh * cfg.lw, cfg.lw, 1))
+        for li in range(len(gpt.blocks)):
+            x, sv = _gpt_block_fwd(gpt, li, x, B, T, drop)
+            saved.append(sv)
+        out_img, out_lid, mf, rf = _gpt_out_fwd(gpt, x, x_img, x_lid)
         ctx.saved = (gpt, x_img.shape, x_lid.shape, saved, x, mf, rf, drop, velocity)
         return out_img, out_lid
 
     @staticmethod
     def backward(ctx, d_img, d_lid):
         gpt, s_img, s_lid, saved, x_last, mf, rf, drop, velocity = ctx.saved
-        cfg = gpt.geom
-        B, Hi, Wi, C = s_img
-        _, Hl, Wl, _ = s_lid
-        n_img, n_lid = cfg.ih * cfg.iw, cfg.lh * cfg.lw
-        T = n_img + n_lid
-        nh, hs = gpt.n_head, C // gpt.n_head
+        B, T = s_img[0], gpt.geom.ih * gpt.geom.iw + gpt.geom.lh * gpt.geom.lw
         d_img, d_lid = d_img.contiguous(), d_lid.contiguous()
-        dev = d_img.device
-        dxf = torch.empty(B * T, C, dtype=torch.float32, device=dev)
-        ops.bilinear_bwd(d_img, B, C, cfg.ih, cfg.iw, Hi, Wi, out=dxf, in_strides=(T * C, cfg.ih * cfg.iw, cfg.iw, 1), in_nhwc=False)
-        ops.bilinear_bwd(d_lid, B, C, cfg.lh, cfg.lw, Hl, Wl, out=dxf[n_img:], in_strides=(T * C, cfg.lh * cfg.lw, cfg.lw, 1), in_nhwc=False)
-        dx = ops.layernorm_bwd(dxf, x_last, gpt.ln_f.weight, mf, rf, gbuf(gpt.ln_f.weight), gbuf(gpt.ln_f.bias))
-        alpha = 1.0 / math.sqrt(hs)
+        dx = _gpt_out_bwd(gpt, d_img, d_lid, x_last, mf, rf, s_img, s_lid)
         for li in range(len(gpt.blocks) - 1, -1, -1):
-            blk = gpt.blocks[li]
-            x, h1, m1, r1, qkv, att, att_d, Tp, y_att, x_mid, h2, m2, r2, a1 = saved[li]
-            fc1, fc2, proj = blk.mlp[0], blk.mlp[2], blk.attn.proj
-            # ---- MLP: x_out = x_mid + drop(fc2(relu(fc1(ln2(x_mid)))))
-            dres = dx
-            if drop and gpt.resid_pdrop > 0:
-                dres = ops.dropout(dx, gpt.seed, gpt.site(4 * li + 3), gpt.resid_pdrop)
-            ops.linear_wgrad(dres, a1, gbuf(fc2.weight))
-            bias_grad(dres, fc2.bias)
-            da1 = ops.linear_dgrad(dres, fc2.weight, mask=a1)     # ReLU backward fused into the dgrad epilogue
-            ops.linear_wgrad(da1, h2, gbuf(fc1.weight))
-            bias_grad(da1, fc1.bias)
-            dh2 = ops.linear_dgrad(da1, fc1.weight)
-            # dx_mid = dx + ln2_bwd(dh2): accumulate in place into dx
-            ops.layernorm_bwd(dh2, x_mid, blk.ln2.weight, m2, r2, gbuf(blk.ln2.weight), gbuf(blk.ln2.bias), dx=dx, accumulate=True)
-            # ---- attention: x_mid = x + drop(proj(att @ v))
-            dres = dx
-            if drop and gpt.resid_pdrop > 0:
-                dres = ops.dropout(dx, gpt.seed, gpt.site(4 * li + 2), gpt.resid_pdrop)
-            ops.linear_wgrad(dres, y_att, gbuf(proj.weight))
-            bias_grad(dres, proj.bias)
-            dy = ops.linear_dgrad(dres, proj.weight)
-            dqkv = torch.empty_like(qkv)
-            datt = torch.empty_like(att)
-            k, q, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
-            sq, sp, sy = (T * 3 * C, hs), (nh * T * Tp, T * Tp), (T * C, hs)
-            ops.gemm(dy, v, datt, T, T, hs, C, 3 * C, Tp, batch=B * nh, inner=nh, sa=sy, sb=sq, sc=sp)                       # dP = dY V^T
-            ops.gemm(att_d, dy, dqkv[:, 2 * C:], T, hs, T, Tp, C, 3 * C, a_trans=True, b_trans=True, batch=B * nh, inner=nh,
-                     sa=sp, sb=sy, sc=sq)                                                                                     # dV = P^T dY
-            if drop and gpt.attn_pdrop > 0:
-                ops.softmax_dropout_bwd_(att, datt, B * nh * T, T, Tp, gpt.seed, gpt.site(4 * li + 1), gpt.attn_pdrop)
-            else:
-                ops.softmax_bwd_(att, datt, B * nh * T, T, Tp)
-            ops.gemm(datt, k, dqkv[:, C:2 * C], T, hs, T, Tp, 3 * C, 3 * C, b_trans=True, alpha=alpha, batch=B * nh, inner=nh,
-                     sa=sp, sb=sq, sc=sq)                                                                                     # dQ = dS K
-            ops.gemm(datt, q, dqkv[:, :C], T, hs, T, Tp, 3 * C, 3 * C, a_trans=True, b_trans=True, alpha=alpha, batch=B * nh, inner=nh,
-                     sa=sp, sb=sq, sc=sq)                                                                                     # dK = dS^T Q
-            fw = blk.attn.fused()
-            if fw is not None:
-                ops.linear_wgrad(dqkv, h1, fw[2])
-                ops.colsum(dqkv, 1, B * T, 3 * C, 1.0, out=fw[3].view(1, -1), accumulate=True)
-                dh1 = ops.linear_dgrad(dqkv, fw[0])
-            else:
-                dh1 = None
-                for j, lin in enumerate((blk.attn.key, blk.attn.query, blk.attn.value)):
-                    dj = dqkv[:, j * C:(j + 1) * C]
-                    ops.linear_wgrad(dj, h1, gbuf(lin.weight))
-                    dh1 = ops.linear_dgrad(dj, lin.weight, out=dh1, accumulate=dh1 is not None)
-                b3 = ops.colsum(dqkv, 1, B * T, 3 * C, 1.0)
-                for j, lin in enumerate((blk.attn.key, blk.attn.query, blk.attn.value)):
-                    ops.axpby(gbuf(lin.bias), b3[0, j * C:(j + 1) * C], 1.0, 1.0, out=gbuf(lin.bias))
-            ops.layernorm_bwd(dh1, x, blk.ln1.weight, m1, r1, gbuf(blk.ln1.weight), gbuf(blk.ln1.bias), dx=dx, accumulate=True)
-        if drop and gpt.embd_pdrop > 0:
-            ops.dropout(dx, gpt.seed, gpt.site(0), gpt.embd_pdrop, out=dx)
-        dtok = dx.view(B, T, C)
-        ops.colsum(dtok, 1, B, T * C, 1.0, out=gbuf(gpt.pos_emb).view(1, -1), accumulate=True)
-        if gpt.use_velocity:
-            db = ops.colsum(dtok, B, T, C, 1.0)
-            ops.linear_wgrad(db, velocity, gbuf(gpt.vel_emb.weight))
-            bias_grad(db, gpt.vel_emb.bias)
-        dx_img = ops.pool_tokens_bwd(dtok, s_img, cfg.ih, cfg.iw, 0, add=d_img)
-        dx_lid = ops.pool_tokens_bwd(dtok, s_lid, cfg.lh, cfg.lw, n_img, add=d_lid)
+            _gpt_block_bwd(gpt, li, saved[li], dx, B, T, drop)
+        dx_img, dx_lid = _gpt_embed_bwd(gpt, dx, s_img, s_lid, velocity, drop, add_img=d_img, add_lid=d_lid)
         ctx.saved = None
         return (dx_img, dx_lid, None, None) + (None,) * (len(ctx.needs_input_grad) - 4)
+
+
+# ---- the same stage as separate autograd nodes (embed | Block x n | output): used for a stage that train.Engine cuts BETWEEN Blocks
+@routes_param_grads
+class GPTEmbedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x_img, x_lid, gpt, velocity, *params):
+        ctx.saved = (gpt, x_img.shape, x_lid.shape, velocity, gpt.training and gpt.pdrop_any)
+        return _gpt_embed_fwd(gpt, x_img, x_lid, velocity)
+
+    @staticmethod
+    def backward(ctx, dx):
+        gpt, s_img, s_lid, velocity, drop = ctx.saved
+        dx_img, dx_lid = _gpt_embed_bwd(gpt, dx.contiguous(), s_img, s_lid, velocity, drop)
+        return (dx_img, dx_lid, None, None) + (None,) * (len(ctx.needs_input_grad) - 4)
+
+
+@routes_param_grads
+class GPTBlockFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gpt, li, B, T, *params):
+        drop = gpt.training and gpt.pdrop_any
+        x_out, sv = _gpt_block_fwd(gpt, li, x, B, T, drop)
+        ctx.saved = (gpt, li, sv, B, T, drop)
+        return x_out
+
+    @staticmethod
+    def backward(ctx, dx):
+        if ctx.saved is None:
+            raise RuntimeError("GPTBlockFn: backward through the graph a second time (the saved activations were freed after the first backward)")
+        gpt, li, sv, B, T, drop = ctx.saved
+        ctx.saved = None
+        # the incoming gradient is owned by this chain (produced by the next Block's / the output node's backward, one consumer): updated in place
+        dx = _gpt_block_bwd(gpt, li, sv, dx.contiguous(), B, T, drop)
+        return (dx, None, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 5)
+
+
+@routes_param_grads
+class GPTOutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, x_img, x_lid, gpt, *params):
+        out_img, out_lid, mf, rf = _gpt_out_fwd(gpt, x, x_img, x_lid)
+        ctx.saved = (gpt, x, mf, rf, x_img.shape, x_lid.shape)
+        return out_img, out_lid
+
+    @staticmethod
+    def backward(ctx, d_img, d_lid):
+        gpt, x_last, mf, rf, s_img, s_lid = ctx.saved
+        d_img, d_lid = d_img.contiguous(), d_lid.contiguous()
+        dx = _gpt_out_bwd(gpt, d_img, d_lid, x_last, mf, rf, s_img, s_lid)
+        return (dx, d_img, d_lid, None) + (None,) * (len(ctx.needs_input_grad) - 4)     # residual adds: the maps' gradients pass through
+
+
+def gpt_stage(gpt, x_img, x_lid, velocity, cut=None):
+    """Run one fusion stage.  ``cut(j, tensors, leaves=None) -> tensors`` is the backbone's hook for a backward cut in front of Block j
+    (j = 0: between the embedding and Block 0; ``cut(j, None)`` only asks whether j is a cut); None, a stage without inner cuts or a
+    forward that records no graph runs as the single node GPTStageFn.
+
+    The residual adds at the end of the stage (out = up(tokens) + x) connect the stage's output straight to its input maps, so cutting
+    the token chain alone would not sever the autograd graph: the maps reach GPTOutFn through detached leaves, and the FIRST inner cut
+    (the last one the backward passes) hands their gradients back together with the token gradient - the trunks before the stage are
+    differentiated once, with the sum."""
+    inner = cut is not None and torch.is_grad_enabled() and x_img.requires_grad and any(cut(j, None) for j in range(len(gpt.blocks)))
+    if not inner:
+        return GPTStageFn.apply(x_img, x_lid, gpt, velocity, *gpt.parameters())
+    B, T = x_img.shape[0], gpt.geom.ih * gpt.geom.iw + gpt.geom.lh * gpt.geom.lw
+    emb = [gpt.pos_emb] + (list(gpt.vel_emb.parameters()) if gpt.use_velocity else [])
+    first = min(j for j in range(len(gpt.blocks)) if cut(j, None))
+    r_img, r_lid = x_img.detach().requires_grad_(True), x_lid.detach().requires_grad_(True)
+    x = GPTEmbedFn.apply(x_img, x_lid, gpt, velocity, *emb)
+    for j, blk in enumerate(gpt.blocks):
+        if j == first:
+            x = cut(j, (x, x_img, x_lid), (None, r_img, r_lid))[0]
+        elif cut(j, None):
+            (x,) = cut(j, (x,))
+        x = GPTBlockFn.apply(x, gpt, j, B, T, *blk.parameters())
+    return GPTOutFn.apply(x, r_img, r_lid, gpt, *gpt.ln_f.parameters())
 
 
 # ============================================================================================ geometric-fusion stage (C4)

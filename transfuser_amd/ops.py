@@ -170,6 +170,17 @@ _TRACE_GEMM = os.environ.get("TF_TRACE_GEMM", "0") == "1"
 _TWO_PASS_MAX_ELEMS = 4300000      # <= ~256 tiles of 128 x 128
 
 
+_wsq = None
+
+
+def _ws_query():
+    global _wsq
+    if _wsq is None:
+        _wsq = L().tf_gemm_splitk_ws_floats
+        _wsq.restype = ctypes.c_long
+    return _wsq
+
+
 def gemm(a, b, c, m, n, k, lda, ldb, ldc, a_trans=False, b_trans=False, bias=None, res=None, ldres=0, alpha=1.0, relu=False,
          accumulate=False, batch=1, inner=1, sa=(0, 0), sb=(0, 0), sc=(0, 0), mask=None):
     if _CHECK and c.is_cuda:
@@ -178,13 +189,16 @@ def gemm(a, b, c, m, n, k, lda, ldb, ldc, a_trans=False, b_trans=False, bias=Non
         ref = _gemm_reference(a, b, old, m, n, k, lda, ldb, ldc, a_trans, b_trans, bias, res, ldres, alpha, relu, accumulate, batch, inner, sa, sb, sc)
     # outputs with too few tiles for the 256 CUs (e.g. the GPT-4 MLP's [1740 x 6048] . [6048 x 1512]: 168 tiles) may run as a deterministic
     # two-pass split-K: the scratch for <= 4 k-slices comes from the caching allocator (stream-ordered, reused inside a captured graph)
-    skws = None
-    if TWO_PASS_SPLITK and batch == 1 and k >= 512 and 128 * 128 <= m * n <= _TWO_PASS_MAX_ELEMS:
-        skws = torch.empty(4 * m * ((n + 3) // 4 * 4), dtype=torch.float32, device=c.device)
     d = GemmDesc(a=ptr(a), b=ptr(b), c=ptr(c), bias=ptr(bias), res=ptr(res), m=m, n=n, k=k, a_trans=int(a_trans), b_trans=int(b_trans),
                  lda=lda, ldb=ldb, ldc=ldc, ldres=ldres, batch=batch, inner=inner, sa_outer=sa[0], sa_inner=sa[1], sb_outer=sb[0],
                  sb_inner=sb[1], sc_outer=sc[0], sc_inner=sc[1], alpha=alpha, relu=int(relu), accumulate=int(accumulate), mask=ptr(mask),
-                 ldmask=mask.stride(0) if mask is not None else 0, splitk_ws=ptr(skws), splitk_ws_floats=skws.numel() if skws is not None else 0)
+                 ldmask=mask.stride(0) if mask is not None else 0, splitk_ws=c_p(0), splitk_ws_floats=0)
+    skws = None
+    if TWO_PASS_SPLITK and batch == 1 and k >= 512 and 128 * 128 <= m * n <= _TWO_PASS_MAX_ELEMS:
+        need = _ws_query()(byref(d))          # > 0 only when the plan of THIS shape is a two-pass plan (or the autotuner wants to try one)
+        if need > 0:
+            skws = torch.empty(need, dtype=torch.float32, device=c.device)
+            d.splitk_ws, d.splitk_ws_floats = ptr(skws), need
     _e = _census_begin()
     if _TRACE_GEMM:      # debugging aid: name every call before it runs and wait for it (TF_TRACE_GEMM=1)
         print("[gemm] m=%d n=%d k=%d a_trans=%d b_trans=%d lda=%d ldb=%d ldc=%d batch=%d acc=%d relu=%d bias=%d res=%d mask=%d ws=%s" % (

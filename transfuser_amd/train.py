@@ -39,23 +39,45 @@ def _group_key(name):
     return name, 0
 
 
-_STAGE_RE = __import__("re").compile(r"(?:^|\.)(?:image_encoder\.features|lidar_encoder\._model)\.(?:s|layer)([1-4])\.|(?:^|\.)transformer([1-4])\.")
-_STEM_RE = __import__("re").compile(r"(?:^|\.)(?:image_encoder\.features|lidar_encoder\._model)\.(?:stem|conv1|bn1)\.")
+_STAGE_RE = __import__("re").compile(r"(?:^|\.)(?:image_encoder\.features|lidar_encoder\._model)\.(?:s|layer)([1-4])\.|(?:^|\.)transformer([1-4])\.(?:(blocks)\.(\d+)\.|(ln_f)\.)?")
+_STEM_RE = __import__("re").compile(r"(?:^|\.)(?:image_encoder\.features|lidar_encoder\._model)\.(?:stem|conv1|bn1)\.|(?:^|\.)point_pillar_net\.")
+_LAST = 1 << 20
+
+
+def param_key(name):
+    """Where in the forward pass a parameter is used, as a tuple that sorts in forward order - the same keys the backbone's cut points
+    use (transfuser._FusionBackbone._cuts): (i, 0, 0) = RegNet stage i of either trunk; (i, 1, 0) = GPT i's embedding (pos_emb, vel_emb);
+    (i, 1, j + 1) = Block j of GPT i; (i, 1, _LAST) = its ln_f; (0, 0, 0) = the two stems AND everything upstream of them (the PointPillars
+    point net, model.py:736-738: its gradients are produced by the very LAST backward piece, through the LiDAR stem); (5, 0, 0) = everything
+    after the backbone's last stage (channel reducers, FPN, decoders, heads, join / GRU).  The backward produces gradients in DEcreasing key
+    order, and a segment's arena range is all-reduced as soon as its piece is enqueued - a parameter filed later than the point that
+    produces its gradient would be reduced while still zero and then diverge between the replicas."""
+    m = _STAGE_RE.search(name)
+    if m:
+        if m.group(1):
+            return (int(m.group(1)), 0, 0)
+        i = int(m.group(2))
+        if m.group(3):
+            return (i, 1, int(m.group(4)) + 1)
+        return (i, 1, _LAST if m.group(5) else 0)
+    return (0, 0, 0) if _STEM_RE.search(name) else (5, 0, 0)
 
 
 def param_stage(name):
-    """Fusion stage a parameter belongs to: 1..4 = RegNet stage k of either trunk / GPT k, 0 = the two stems, 5 = everything after the
-    backbone's last stage (channel reducers, FPN, decoders, heads, join / GRU).  Backward produces gradients in DEcreasing stage order."""
-    m = _STAGE_RE.search(name)
-    if m:
-        return int(m.group(1) or m.group(2))
-    return 0 if _STEM_RE.search(name) else 5
+    """Fusion stage of a parameter (first component of param_key): 1..4 = RegNet stage k of either trunk / GPT k, 0 = stems (+ point net), 5 = heads."""
+    return param_key(name)[0]
+
+
+def cut_key(c):
+    """A backward cut as a key tuple; an int c means "after fusion stage c" = (c, 2, 0)."""
+    return (int(c), 2, 0) if isinstance(c, int) else tuple(int(v) for v in c)
 
 
 class ParamArena:
     def __init__(self, model, cuts=()):
-        """``cuts`` = fusion stages after which the backward is cut (e.g. (3, 2, 1)): parameters are then grouped by backward segment,
-        first-finished segment first, and ``segment_ranges`` lists each segment's [lo, hi) float range of the arena."""
+        """``cuts`` = points at which the backward is cut (cut_key: ints = after fusion stage c, tuples = the backbone's finer cut points,
+        e.g. (4, 1, 2) = inside GPT-4 in front of Block 2): parameters are then grouped by backward segment, first-finished segment first, and
+        ``segment_ranges`` lists each segment's [lo, hi) float range of the arena."""
         named, seen = [], set()
         for n, p in model.named_parameters(remove_duplicate=True):
             if id(p) not in seen:
@@ -65,8 +87,8 @@ class ParamArena:
         # (no weight decay either): they go to the END of the arena, outside the range the optimizer updates.
         unused = {id(p) for m in model.modules() if hasattr(m, "unused_parameters") for p in m.unused_parameters()}
         named = [t for t in named if id(t[1]) not in unused] + [t for t in named if id(t[1]) in unused]
-        cuts = sorted(set(int(c) for c in cuts), reverse=True)
-        seg_of = lambda name: sum(1 for c in cuts if param_stage(name) <= c)      # 0 = produced first in the backward
+        cuts = sorted(set(cut_key(c) for c in cuts), reverse=True)
+        seg_of = lambda name: sum(1 for c in cuts if param_key(name) <= c)       # 0 = produced first in the backward
         if cuts:   # stable sort by segment; the never-reached parameters stay at the very end
             live = [t for t in named if id(t[1]) not in unused]
             named = sorted(live, key=lambda t: seg_of(t[0])) + [t for t in named if id(t[1]) in unused]
@@ -149,10 +171,17 @@ class FlatAdamW:
         ops.adamw_(a.params[self.lo:self.hi], a.grads[self.lo:self.hi], self.exp_avg, self.exp_avg_sq, self.state, self.betas[0], self.betas[1],
                    self.eps, self.weight_decay)
 
+    def _layout(self):
+        """[(parameter name, arena offset, numel)] of the parameters the optimizer updates: what makes a saved state independent of the
+        arena ORDER (which depends on the backward cuts, i.e. on the world size the run used)."""
+        n = self.arena.active_numel
+        return [(name, off, p.numel()) for name, p, off in self.arena.layout if off < n]
+
     def state_dict(self, group=None):
-        """FULL optimizer state (moments over the whole active arena, {step, lr}).  With a sharded optimizer every rank must call this
-        (collective): the slices are gathered first - the reference's ``optimizer.consolidate_state_dict(0)`` before saving
-        (train.py:206-207) - so a checkpoint never depends on the world size it was written with."""
+        """FULL optimizer state (moments over the whole active arena, {step, lr}) plus the (name, offset, numel) layout they were written
+        in.  With a sharded optimizer every rank must call this (collective): the slices are gathered first - the reference's
+        ``optimizer.consolidate_state_dict(0)`` before saving (train.py:206-207).  ``load_state_dict`` re-maps the moments PER PARAMETER
+        NAME, so a checkpoint depends neither on the world size nor on the backward cuts it was written with."""
         ea, es = self.exp_avg, self.exp_avg_sq
         if hasattr(self, "shard_size") and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             world, per, n = dist.get_world_size(group), self.shard_size, self.arena.active_numel
@@ -164,18 +193,42 @@ class FlatAdamW:
                 dist.all_gather(parts, mine, group=group)
                 full.append(torch.cat(parts)[:n].clone())
             ea, es = full
-        return dict(exp_avg=ea, exp_avg_sq=es, state=self.state, active_numel=self.arena.active_numel)
+        return dict(exp_avg=ea, exp_avg_sq=es, state=self.state, active_numel=self.arena.active_numel, layout=self._layout())
 
     def load_state_dict(self, sd):
-        """Accepts the full state written by ``state_dict`` on any world size; a sharded optimizer keeps its own slice."""
+        """Accepts the full state written by ``state_dict`` on any world size / with any backward cuts: the moments are copied parameter
+        by parameter (matched by name); a sharded optimizer keeps its own slice.  A state without a layout (written before the layout
+        was recorded) is only accepted when this arena has no cuts - its order is then the one those files were written in on one GPU;
+        anything else raises instead of silently assigning moments to the wrong parameters."""
         n = self.arena.active_numel
+        mine = self._layout()
+        theirs = sd.get("layout")
+        if theirs is None:
+            if len(self.arena.segment_ranges) > 1:
+                raise ValueError("optimizer state has no parameter layout (written by an older build) and this arena is laid out for %d backward "
+                                 "segments: the flat order cannot be matched - re-save the checkpoint with the current build" % len(self.arena.segment_ranges))
+            theirs = mine
+        theirs = [tuple(t) for t in theirs]
+        same = theirs == [tuple(t) for t in mine]
+        if not same:
+            a, b = {t[0]: t for t in theirs}, {t[0]: t for t in mine}
+            missing = [k for k in b if k not in a or a[k][2] != b[k][2]]
+            if missing or len(a) != len(b):
+                raise ValueError("optimizer state does not match this model: %d parameters differ (e.g. %s)" % (max(len(missing), abs(len(a) - len(b))), missing[:3]))
         for name, dst in (("exp_avg", self.exp_avg), ("exp_avg_sq", self.exp_avg_sq)):
-            src = sd[name]
-            if src.numel() == n and dst.numel() != n:
-                src = src[self.lo:self.hi]
-            if src.numel() != dst.numel():
-                raise ValueError("optimizer state %s has %d elements, expected %d (full) or %d (this rank's shard)" % (name, sd[name].numel(), n, dst.numel()))
-            dst.copy_(src)
+            src = sd[name].to(dst.device)
+            if src.numel() != sd.get("active_numel", n):
+                raise ValueError("optimizer state %s has %d elements, its header says %d" % (name, src.numel(), sd.get("active_numel", n)))
+            if same:
+                full = src
+            else:           # re-map by parameter name into this arena's order (padding between groups stays zero)
+                full = torch.zeros(n, dtype=dst.dtype, device=dst.device)
+                off_theirs = {t[0]: t[1] for t in theirs}
+                for pname, off, cnt in mine:
+                    full[off:off + cnt] = src[off_theirs[pname]:off_theirs[pname] + cnt]
+            if full.numel() != n:
+                raise ValueError("optimizer state %s has %d elements, expected %d" % (name, full.numel(), n))
+            dst.copy_(full[self.lo:self.hi] if dst.numel() != n else full)
         self.state.copy_(sd["state"])
 
 
@@ -270,13 +323,17 @@ class Engine:
 
     BATCH_KEYS = ("rgb", "lidar", "ego_waypoint", "target_point", "target_point_image", "ego_vel", "bev", "label", "depth", "semantic")
     GEO_KEYS = ("bev_points", "cam_points")   # train.py:280-288 (geometric_fusion only)
-    DEFAULT_CUTS = (3, 2, 1)                  # backward segments: [heads + stage 4] [stage 3] [stage 2] [stage 1 + stems]
+    # backward pieces with more than one rank (8): [heads + neck + GPT-4 ln_f / Block 3] [GPT-4 Block 2] [Block 1] [Block 0 + embedding +
+    # stage-4 trunks] [GPT-3] [stage-3 trunks] [stage 2] [stage 1 + stems].  GPT-4 holds 110 M of the 168 M gradients (27.5 M per Block):
+    # cutting between its Blocks lets the first 190 MB leave for the all-reduce after ~15 % of the backward instead of after stage 4.
+    DEFAULT_CUTS = ((4, 1, 3), (4, 1, 2), (4, 1, 1), 3, (3, 0, 0), 2, 1)
 
     def __init__(self, model, config, lr=1e-4, use_graph=False, group=None, bucket_mb=64.0, wp_only=False, autotune=True, plan_file=None,
                  zero_redundancy_optimizer=False, sync_batch_norm=False, cuts=None, precision=None):
-        """``cuts``: fusion stages after which the backward is cut into separately enqueued (and separately captured) segments whose
-        gradient ranges are all-reduced while the next segment runs.  None = DEFAULT_CUTS when there is more than one rank (and the
-        backbone is a chain: transFuser / latentTF), no cut on a single GPU; () = never cut.
+        """``cuts``: points (cut_key: int c = after fusion stage c; (i, 0, 0) = between the stage-i trunks and GPT i; (i, 1, j) = inside GPT i
+        in front of Block j) at which the backward is cut into separately enqueued (and separately captured) segments whose gradient
+        ranges are all-reduced while the next segment runs.  None = DEFAULT_CUTS when there is more than one rank (and the backbone is a
+        chain: transFuser / latentTF), no cut on a single GPU; () = never cut.
         ``precision``: compute precision of every MFMA-engine contraction (process-wide, ops.set_precision); None keeps the current one."""
         self.model = model
         self.config = config
@@ -296,7 +353,9 @@ class Engine:
         can_cut = getattr(model, "backbone", "") in ("transFuser", "latentTF") and hasattr(backbone, "_cuts")
         if cuts is None:
             cuts = self.DEFAULT_CUTS if world > 1 else ()
-        self.cuts = tuple(sorted(set(int(c) for c in cuts), reverse=True)) if can_cut else ()
+        nblk = int(getattr(config, "n_layer", 0))
+        keys = sorted(set(cut_key(c) for c in cuts), reverse=True) if can_cut else []
+        self.cuts = tuple(k for k in keys if not (k[1] == 1 and k[2] >= nblk))       # a cut in front of a Block the model does not have is dropped
         if can_cut:
             backbone._cuts = frozenset(self.cuts)
         self.arena = ParamArena(model, self.cuts)
@@ -355,7 +414,9 @@ class Engine:
 
     def _piece_impl(self, i):
         outs, leaves = self._pending[len(self._pending) - i]        # boundaries were recorded in forward order; backward walks them in reverse
-        torch.autograd.backward(list(outs), [l.grad for l in leaves])
+        pairs = [(o, l.grad) for o, l in zip(outs, leaves) if l.grad is not None]      # a boundary tensor nothing downstream differentiated has no gradient
+        if pairs:
+            torch.autograd.backward([o for o, _ in pairs], [g for _, g in pairs])
         if i == len(self._pending):
             self._pending = []
             self.model._model._boundaries = []
@@ -491,7 +552,13 @@ class Trainer:
                 self.writer = None
 
     def _to_device(self, data):
-        """train.py:246-271: H2D + dtype casts of one collated batch."""
+        """train.py:246-271: H2D + dtype casts of one collated batch.  A RAW batch (``CARLA_Data`` items: uint8 images, the padded cloud,
+        poses) first goes through ``GpuBatchPrep``: one H2D copy, then alignment / histogram / crops / decoding in HIP kernels."""
+        if "rgb_u8" in data:
+            if getattr(self, "_prep", None) is None:
+                from .data import GpuBatchPrep
+                self._prep = GpuBatchPrep(self.config, self.device)
+            data = self._prep(data)                 # with --use_point_pillars data["lidar"] is then the aligned cloud (train.py:258-260) + num_points
         f32 = ("rgb", "lidar", "ego_waypoint", "target_point", "target_point_image", "ego_vel", "label", "depth")
         i64 = ("bev", "semantic", "bev_points", "cam_points")
         out = {}
@@ -592,7 +659,7 @@ def build_parser():
     p.add_argument('--no_bev_loss', type=int, default=0)
     p.add_argument('--sync_batch_norm', type=int, default=0)
     p.add_argument('--zero_redundancy_optimizer', type=int, default=0)
-    p.add_argument('--use_disk_cache', type=int, default=0, help='accepted for command-line compatibility; the synthetic / GPU-prepared loaders do not need it')
+    p.add_argument('--use_disk_cache', type=int, default=0, help='1: cache the decoded samples under $SCRATCH/dataset_cache (train.py:77-90); needs a real --root_dir')
     # additions of this framework
     p.add_argument('--use_graph', type=int, default=1, help='capture the step into hipGraphs (falls back to eager where a flag requires it)')
     p.add_argument('--precision', type=str, default='fp32', choices=['fp32', 'f32x3', 'bf16'])
@@ -637,7 +704,14 @@ def main(argv=None):
                  zero_redundancy_optimizer=bool(args.zero_redundancy_optimizer), sync_batch_norm=bool(args.sync_batch_norm), precision=args.precision if cuda else None)
     if args.load_file is not None and os.path.exists(args.load_file.replace("model_", "optimizer_")):
         eng.optimizer.load_state_dict(torch.load(args.load_file.replace("model_", "optimizer_"), map_location=device))
-    train_set, val_set = make_datasets(args.root_dir, config, height=args.height, width=args.width)
+    shared_dict = None
+    if bool(args.use_disk_cache):       # train.py:77-90: decoded samples cached on the fast local storage ($SCRATCH), shared by all ranks
+        if str(args.root_dir).startswith("synthetic"):
+            raise ValueError("--use_disk_cache 1 caches samples decoded from a dataset directory; --root_dir %s has nothing to cache" % args.root_dir)
+        import tempfile
+        shared_dict = os.path.join(os.environ.get('SCRATCH') or tempfile.gettempdir(), "dataset_cache")
+        print("Tmp folder for dataset cache: ", shared_dict)
+    train_set, val_set = make_datasets(args.root_dir, config, height=args.height, width=args.width, shared_dict=shared_dict)
     g = torch.Generator(device='cpu')
     g.manual_seed(torch.initial_seed())
     nw = args.num_workers if args.num_workers is not None else (8 if parallel else 0)

@@ -115,9 +115,10 @@ class GPT(nn.Module):
     def site(self, i):
         return self.site_base + i
 
-    def forward(self, image_nhwc, lidar_nhwc, velocity):
+    def forward(self, image_nhwc, lidar_nhwc, velocity, cut=None):
+        """``cut``: the backbone's backward-cut hook for this stage (functions.gpt_stage); None = one autograd node."""
         assert image_nhwc.shape[-1] == self.n_embd and lidar_nhwc.shape[-1] == self.n_embd
-        return F_.GPTStageFn.apply(image_nhwc, lidar_nhwc, self, velocity, *self.parameters())
+        return F_.gpt_stage(self, image_nhwc, lidar_nhwc, velocity, cut)
 
 
 class _Stem:
@@ -175,7 +176,29 @@ class _FusionBackbone(nn.Module):
     (transfuser.py:91-118) and the two-stream execution of the trunks."""
 
     _reducers = ("change_channel_conv_image", "change_channel_conv_lidar")
-    _cuts = frozenset()      # fusion stages after which train.Engine cuts the backward (set by the engine; () = one autograd graph)
+    # Backward cuts (set by train.Engine; empty = one autograd graph).  A cut is a key (stage, where, j):
+    #   (i, 2, 0)  after fusion stage i (both maps);  (i, 0, 0)  between the trunks' stage i and GPT i (both maps);
+    #   (i, 1, j)  inside GPT i in front of Block j (the token matrix; j = 0: between the embedding and Block 0).
+    # Forward order of the keys = their tuple order; an int c is shorthand for (c, 2, 0).
+    _cuts = frozenset()
+
+    @staticmethod
+    def cut_key(c):
+        return (int(c), 2, 0) if isinstance(c, int) else tuple(int(v) for v in c)
+
+    def _cut(self, key, tensors, leaves=None):
+        """The backward is severed at ``tensors`` when ``key`` is one of the engine's cuts: values are untouched (same memory, no copy);
+        the engine restarts the backward of everything before the cut from the detached leaves, with the gradients that arrived at them,
+        after it has handed the later segments' gradient range to the all-reduce.  tensors=None only asks whether the key is a cut;
+        ``leaves`` may name leaves that already stand in for some of the tensors downstream (functions.gpt_stage's residual maps)."""
+        hit = key in self._cuts
+        if tensors is None:
+            return hit
+        if not (hit and torch.is_grad_enabled() and tensors[0].requires_grad):
+            return tensors
+        leaves = tuple(l if l is not None else t.detach().requires_grad_(True) for t, l in zip(tensors, leaves or (None,) * len(tensors)))
+        self._boundaries.append((tuple(tensors), leaves))
+        return leaves
 
     def _build_common(self, config, image_architecture, lidar_architecture):
         self.config = config
@@ -259,7 +282,6 @@ class _FusionBackbone(nn.Module):
             y = lidar_branch(lambda: self._lid_stem(lidar.contiguous(), lidar_extra.contiguous() if lidar_extra is not None else None))
         x = self._img_stem(image.contiguous())
         self._boundaries = []
-        cuts = getattr(self, "_cuts", frozenset())
         stage = lambda net, i: getattr(net, "layer%d" % i, None) or getattr(net, "s%d" % i)    # re-labelled (transfuser.py) or plain timm names (late_fusion.py)
         for i in range(1, 5):
             y = lidar_branch(lambda y=y, i=i: stage(li, i)(y))
@@ -267,14 +289,9 @@ class _FusionBackbone(nn.Module):
             if side is not None:
                 main.wait_stream(side)          # join: the fusion stage consumes both branches on the main stream
                 y.record_stream(main)
+            x, y = self._cut((i, 0, 0), (x, y))
             x, y = fuse(i, x, y)
-            if i in cuts and torch.is_grad_enabled() and x.requires_grad:
-                # backward cut (train.Engine): the autograd graph is severed here; the engine restarts the backward of the earlier stages
-                # from these tensors with the gradients that arrive at the detached leaves, after it has handed the later stages'
-                # gradient range to the all-reduce.  Values are untouched - same memory, no copy.
-                xd, yd = x.detach().requires_grad_(True), y.detach().requires_grad_(True)
-                self._boundaries.append(((x, y), (xd, yd)))
-                x, y = xd, yd
+            x, y = self._cut((i, 2, 0), (x, y))
             if side is not None:
                 y.record_stream(side)
         x = self._conv(getattr(self, self._reducers[0]), x)
@@ -304,7 +321,7 @@ class TransfuserBackbone(_FusionBackbone):
         def fuse(i, x, y):
             gpt = getattr(self, "transformer%d" % i)
             gpt.seed = self.dropout_seed
-            return gpt(x, y, velocity)
+            return gpt(x, y, velocity, cut=lambda j, t, l=None, i=i: self._cut((i, 1, j), t, l))
         return self._run(image, lidar, lidar_extra, fuse, lidar_nhwc)
 
     def forward(self, image, lidar, velocity):
