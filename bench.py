@@ -46,6 +46,10 @@ def parse_args():
                     help="f32 = exact fp32 MFMA, the reference's arithmetic (headline); f32x3 = the same fp32 data with every contraction as an exact "
                          "3-way bf16 split on the bf16 MFMA (six partial products, fp32-accurate; priced against the bf16 peak / 6); "
                          "bf16 = bf16-MFMA contractions with fp32 accumulate/storage/master weights (BASELINE configs[2])")
+    ap.add_argument("--check", action="store_true",
+                    help="after the timed region: one more step with the optimizer's wait for the all-reduce stream event-timed (per-rank allreduce_exposed_ms), "
+                         "then all-gather a checksum of the parameter arena and ASSERT that every replica holds the same parameters (self-diagnosing --gpus N run)")
+    ap.add_argument("--grad-dtype", default="fp32", choices=["fp32", "bf16"], help="payload of the gradient all-reduce buckets (bf16 halves the xGMI bytes; the arena stays fp32)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra f32x3 measurement that the default f32 line embeds (N=1 only)")
@@ -119,6 +123,34 @@ def dominant_kernel_roofline(eng, batch, dev, log, peak=PEAK_F32_MFMA_TF):
             roof["traffic_source"] = "unreadable %s: %s" % (pmc_file, e)
     log("in-step roofline census done (%d engine launches)" % len(rows))
     return roof
+
+
+def replica_check(eng, batch, rank, world, dev, log):
+    """--check: (1) one more training step with the optimizer's wait for the all-reduce side stream bracketed by timing events - the time the
+    main stream stalls there is the part of the gradient all-reduce the backward did NOT hide; (2) a checksum of the parameter arena (fp64
+    sum + exact int64 sum of the raw bits) all-gathered over the ranks: data parallelism (train.py:134) keeps the replicas bit-identical, so
+    any difference is a reduction bug and the run FAILS.  Every rank prints its own line to stderr; rank 0 puts the summary into the JSON."""
+    import torch
+    import torch.distributed as dist
+    eng.reducer.time_waits = True
+    eng.train_step(batch)
+    torch.cuda.synchronize()
+    exposed = eng.reducer.exposed_ms()
+    eng.reducer.time_waits = False
+    p = eng.arena.params[:eng.arena.active_numel]
+    mine = torch.stack([p.double().sum(), p.view(torch.int32).to(torch.int64).sum().double(), torch.tensor(exposed, dtype=torch.float64, device=dev)])
+    rows = [torch.zeros_like(mine) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(rows, mine)
+    else:
+        rows = [mine]
+    rows = [r.cpu().tolist() for r in rows]
+    print("[bench check] rank %d: allreduce_exposed_ms %.3f, param checksum %.9e / bits %d" % (rank, exposed, rows[rank][0], int(rows[rank][1])), file=sys.stderr, flush=True)
+    equal = all(r[0] == rows[0][0] and r[1] == rows[0][1] for r in rows)
+    assert equal, "replicas diverged: per-rank parameter checksums %s" % [(r[0], int(r[1])) for r in rows]
+    log("replica check: %d rank(s) bit-identical; exposed all-reduce ms per rank %s" % (world, [round(r[2], 3) for r in rows]))
+    return {"replicas_equal": True, "n_ranks": world, "allreduce_exposed_ms": [round(r[2], 3) for r in rows], "param_checksum": rows[0][0],
+            "backward_pieces": eng.n_pieces(), "grad_dtype": "bf16" if eng.reducer.bf16 else "fp32"}
 
 
 def cpu_baseline(make_cfg, backbone, H, W, budget_s=110.0):
@@ -242,7 +274,7 @@ def main():
     hist_fn = lambda pts: ops.lidar_hist(torch.from_numpy(pts).to(dev)[None])[0].cpu().numpy()
     batch = {k: v.to(dev) for k, v in synthetic_batch(B, H, W, seed=rank, hist_fn=hist_fn).items()}
     log("model + batch on device")
-    eng = Engine(model, cfg, lr=cfg.lr, use_graph=not args.no_graph, precision={"f32": "fp32", "f32x3": "f32x3", "bf16": "bf16"}[args.dtype])
+    eng = Engine(model, cfg, lr=cfg.lr, use_graph=not args.no_graph, precision={"f32": "fp32", "f32x3": "f32x3", "bf16": "bf16"}[args.dtype], grad_dtype=args.grad_dtype)
     peak = {"f32": PEAK_F32_MFMA_TF, "f32x3": round(PEAK_BF16_MFMA_TF / 6, 1), "bf16": PEAK_BF16_MFMA_TF}[args.dtype]
     log("engine ready (arena %.1f M floats, %d backward piece(s))" % (eng.arena.numel / 1e6, eng.n_pieces()))
 
@@ -270,6 +302,9 @@ def main():
     loss = float(tot)
     log("timed region done: %.2f ms/step" % (dt / args.steps * 1e3))
     assert loss == loss, "NaN loss"
+    check = None
+    if args.check:      # outside the timed region
+        check = replica_check(eng, batch, rank, world, dev, log)
     roof = dominant_kernel_roofline(eng, batch, dev, log, peak)      # every rank runs the census step (it contains the collectives); rank 0 reports
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -286,8 +321,10 @@ def main():
                                                               "bf16": "bf16 MFMA contractions (fp32 accumulate, fp32 activations / master weights / AdamW)"}[args.dtype], args.dropout,
                                                                "hipGraph replay" if not args.no_graph else "eager"),
                        "global_batch": B * world, "parallelism": "dp%d" % world, "final_loss": round(loss, 4),
-                       "grad_allreduce": ("RCCL, %d backward segments, bucket all-reduce overlapped on a side stream" % eng.n_pieces()) if world > 1 else "none (1 rank)"},
+                       "grad_allreduce": ("RCCL, %d backward segments, %s bucket all-reduce overlapped on a side stream" % (eng.n_pieces(), args.grad_dtype)) if world > 1 else "none (1 rank)"},
         }
+        if check is not None:
+            res["check"] = check
         if gf:
             step_tf = value / world * gf / 1e3
             roof["step_achieved_tflops"] = round(step_tf, 2)

@@ -66,6 +66,12 @@ typedef struct {
     const float* mask; int64_t ldmask;   /* optional (batch == 1, store mode): c(i,j) is zeroed unless mask[i*ldmask + j] > 0 - the ReLU
                                           * mask of a backward GEMM (dX = (dY W) * [act > 0]) fused into the epilogue */
     float* splitk_ws; int64_t splitk_ws_floats;
+    /* optional: train-mode BatchNorm statistics of the OUTPUT fused into the epilogue (timm ConvBnAct = bias-free conv + BatchNormAct2d,
+     * transfuser.py:380,442; point_pillar.py:15-25 Linear + BatchNorm1d).  colstat: device buffer of >= 3 * n * ceil(m / 32) floats that
+     * receives per-part Welford triples [part][{count, mean, M2}][n]; *colstat_nparts (HOST int, written before the call returns) = number
+     * of parts written, 0 when the plan chosen for this call cannot produce them (the caller then reduces separately).  Needs batch == 1,
+     * a_trans == 0, store mode, no residual / ReLU / mask.  Consumed by tf_bn_fwd_parts_f32. */
+    float* colstat; int* colstat_nparts;
 } tf_gemm_desc;
 int tf_gemm_f32(const tf_gemm_desc* d, void* stream);
 /* Floats of splitk_ws this call can use: 0 unless the cached (or about-to-be-tuned) plan of the call's shape is a two-pass split-K plan, so
@@ -81,6 +87,9 @@ typedef struct {
     int B, Hi, Wi, Cin, Ho, Wo, Cout, ksize, stride, pad, groups;
 } tf_conv_geom;
 int tf_conv2d_fwd_f32(const tf_conv_geom* g, const float* x, const float* w, const float* bias, float* y, int relu, void* stream);
+/* the same with the output's BatchNorm statistics fused into the epilogue (see tf_gemm_desc.colstat; colstat holds >= 3 * Cout * ceil(B Ho Wo / 32) floats) */
+int tf_conv2d_fwd_colstat_f32(const tf_conv_geom* g, const float* x, const float* w, const float* bias, float* y, float* colstat, int* colstat_nparts,
+                              void* stream);
 int tf_conv2d_dgrad_f32(const tf_conv_geom* g, const float* dy, const float* w, float* dx, int accumulate, void* stream);
 int tf_conv2d_wgrad_f32(const tf_conv_geom* g, const float* dy, const float* x, float* dw, int accumulate, void* stream);
 
@@ -98,6 +107,10 @@ int tf_conv3x3_small_wgrad_f32(const float* dy, const float* x, float* dw, int B
  * NHWC (B, H, W, C); w / dw: (C, 3, 3, 24) = the channels-last storage of a (C, 24, 3, 3) parameter.  wgrad needs
  * tf_conv3x3_grouped_wgrad_ws_floats() floats of scratch.  Stride-2 grouped convolutions use tf_conv2d_*. */
 int tf_conv3x3_grouped_fwd_f32(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int C, int relu, void* stream);
+/* the same with the output's BatchNorm statistics: every block merges the Welford triples of the tiles it walks; colstat holds >= 3 * C *
+ * tf_conv3x3_grouped_colstat_parts() floats, *colstat_nparts (host) receives the number of parts written */
+int tf_conv3x3_grouped_colstat_parts(void);
+int tf_conv3x3_grouped_fwd_colstat_f32(const float* x, const float* w, float* y, int B, int H, int W, int C, float* colstat, int* colstat_nparts, void* stream);
 int tf_conv3x3_grouped_dgrad_f32(const float* dy, const float* w, float* dx, int B, int H, int W, int C, int accumulate, void* stream);
 long tf_conv3x3_grouped_wgrad_ws_floats(void);
 int tf_conv3x3_grouped_wgrad_f32(const float* dy, const float* x, float* dw, int B, int H, int W, int C, int accumulate, float* ws, void* stream);
@@ -124,10 +137,29 @@ int tf_softmax_bwd_f32(const float* p, float* dp, int rows, int n, int ld, void*
 int tf_softmax_dropout_fwd_f32(float* s, float* sd, int rows, int n, int ld, const uint32_t* seed_dev, uint32_t site, float p, void* stream);
 int tf_softmax_dropout_bwd_f32(const float* p, float* dp, int rows, int n, int ld, const uint32_t* seed_dev, uint32_t site, float pdrop, void* stream);
 
+/* Fused self-attention of one GPT Block (SelfAttention.forward, transfuser.py:510-527): y = attn_drop(softmax(q k^T / sqrt(hs))) v for every
+ * (sample, head), the (B, nh, T, T) scores never leave the CU.  qkv: (B*T, 3C) rows = [key | query | value] (transfuser.py:500-502), head h owns
+ * columns h*hs .. (h+1)*hs of each third; y: (B*T, C) heads merged (transfuser.py:523); lse: (B*nh*T) row-wise log-sum-exp kept for the
+ * backward, which RECOMPUTES the probabilities.  attn_drop mask = tf_dropout_f32's for the flat index ((b nh + h) T + i) Tp + j, Tp = T
+ * rounded up to 4 (pdrop = 0: no dropout, seed_dev may be NULL).  bwd: dqkv (B*T, 3C) = gradients of [key | query | value]; dsum: (B*nh*T)
+ * scratch.  Limits: T <= 192, hs <= 384 (tf_attention_supported); the model has T = 174, hs in {18, 54, 144, 378}. */
+int tf_attention_supported(int T, int C, int nh);
+int tf_attention_fwd_f32(const float* qkv, float* y, float* lse, int B, int T, int C, int nh, const uint32_t* seed_dev, uint32_t site, float pdrop,
+                         void* stream);
+int tf_attention_bwd_f32(const float* qkv, const float* dy, const float* lse, float* dqkv, float* dsum, int B, int T, int C, int nh,
+                         const uint32_t* seed_dev, uint32_t site, float pdrop, void* stream);
+
 /* ---- per-channel reductions / BatchNorm / Squeeze-Excite ------------------------------------- */
 
 /* scratch every reduction entry point needs (one buffer per stream is enough) */
 long tf_workspace_bytes(void);
+/* Train-mode BatchNorm forward whose batch statistics were gathered by the PRODUCING convolution's epilogue (tf_gemm_desc.colstat,
+ * tf_conv2d_fwd_colstat_f32, tf_conv3x3_grouped_fwd_colstat_f32: per-part Welford triples [part][{count, mean, M2}][C]): merges the parts
+ * (Chan's formula), updates the running statistics, writes save_mean / save_invstd and applies y = bn(x) (+res) (relu) - the moments pass
+ * over x of tf_bn_fwd_f32 is gone (timm BatchNormAct2d behind every RegNetY convolution, transfuser.py:380,442). */
+int tf_bn_fwd_parts_f32(const float* x, int rows, int C, const float* parts, int nparts, const float* gamma, const float* beta, float* running_mean,
+                        float* running_var, float momentum, float eps, const float* res, int relu, float* y, float* save_mean, float* save_invstd,
+                        float* ws, void* stream);
 /* timm BatchNormAct2d on NHWC (rows = B*H*W): y = bn(x) (+res) (relu); training uses batch statistics
  * and updates the running buffers (momentum, unbiased var).  bwd accumulates dgamma/dbeta.
  * zacc: optional tf_bn_zacc_floats(C) floats that the CALLER has zeroed (e.g. a slice of a scratch arena cleared once per step): the statistics are then
@@ -230,6 +262,10 @@ int tf_gru_waypoints_fwd_f32(const float* z0, const float* target_point, const f
 int tf_gru_waypoints_bwd_f32(const float* dwp, const float* cache, const float* w_ih, const float* w_hh, const float* w_out, int B, int hidden,
                              int pred_len, int nin, float* dz0, float* dw_ih, float* dw_hh, float* db_ih, float* db_hh, float* dw_out, float* db_out,
                              void* stream);
+/* fp32 <-> bf16 (round to nearest even; y = x * scale on the way back): optional bf16 gradient buckets of the data-parallel all-reduce
+ * (DistributedDataParallel's bucketed all-reduce, train.py:134, reduces fp32; halving the xGMI payload is an opt-in of this framework). */
+int tf_cast_f32_bf16(const float* x, uint16_t* y, int64_t n, void* stream);
+int tf_cast_bf16_f32(const uint16_t* x, float* y, int64_t n, float scale, void* stream);
 /* torch.optim.AdamW (train.py:142) over a flat arena in one launch; state_dev = {step, lr} floats
  * on the device (step is advanced by the call, so a captured hipGraph replays correctly). */
 int tf_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, float* state_dev, float beta1, float beta2, float eps, float weight_decay,

@@ -985,3 +985,129 @@ def check_two_pass_splitk(dev, kind, sk):
     finally:
         ops.set_precision("fp32")
         ops.force_plan(0)
+
+
+# ---------------------------------------------------------------- BatchNorm statistics fused into the producing convolution
+def _bn_from_parts(dev, y_nhwc, cs, relu=True, res=None):
+    """BN forward through ops.bn_fwd_parts (statistics from the producer's epilogue) vs F.batch_norm on the same conv output."""
+    C = y_nhwc.shape[-1]
+    assert cs is not None and cs.nparts.value > 0, "the producer did not write statistics"
+    n = cs.nparts.value
+    cnt = cs.buf.view(-1, 3, C)[:n, 0].sum(0)
+    assert torch.all(cnt == y_nhwc.numel() // C), ("part counts must add up to the row count", cnt[:4], y_nhwc.numel() // C)
+    g, b = R(C, seed=11, dev=dev) * 0.3 + 1, R(C, seed=12, dev=dev)
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    z, sm, si = ops.bn_fwd_parts(y_nhwc, cs, g, b, rm, rv, res, relu)
+    rm2, rv2 = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    flat = y_nhwc.reshape(-1, C)
+    want = F.batch_norm(flat, rm2, rv2, g, b, True, 0.1, 1e-5)
+    if res is not None:
+        want = want + res.reshape(-1, C)
+    if relu:
+        want = torch.relu(want)
+    close(z.reshape(-1, C), want, what="bn from fused statistics")
+    close(rm, rm2, what="running mean (fused statistics)")
+    close(rv, rv2, what="running var (fused statistics)")
+    close(sm, flat.mean(0), what="save_mean")
+    close(si, 1.0 / torch.sqrt(flat.var(0, unbiased=False) + 1e-5), what="save_invstd")
+
+
+def check_bn_fused_stats(dev, plans=((0, 64, 64, 16), (0, 128, 32, 16), (0, 128, 128, 32), (0, 64, 128, 16), (2, 0, 0, 0), (1, 0, 0, 0), (6, 0, 0, 0), (8, 0, 0, 0))):
+    """The producers of a BatchNorm input write per-part Welford triples from their epilogue: 1x1 conv as GEMM under every engine tiling /
+    LDS-DMA kind (rows per wave 32 / 64, ragged M and N, activations with a LARGE mean: the shifted / Welford form must not cancel),
+    Linear + bias (PointPillars), strided grouped + 1x1 / s2 convs through the implicit-GEMM engine, the direct grouped 3x3 kernel (both
+    tile shapes, ragged borders), and the fall-back when a two-pass split-K plan cannot produce them."""
+    old_fuse, old_rows = ops.FUSE_BN_STATS, ops._COLSTAT_MAX_ROWS
+    ops.FUSE_BN_STATS = True
+    try:
+        for kind, bm, bn, bk in plans:
+            if kind:
+                ops.force_dma(kind, 1)
+            else:
+                ops.force_plan(bm, bn, bk, 1)
+            try:
+                for (m, n, k) in ((203, 72, 40), (130, 216, 64), (97, 24, 36)):
+                    x = R(m, k, dev=dev) + 3.0                      # mean >> spread on purpose
+                    w = R(n, k, seed=5, dev=dev) * 0.2
+                    y, cs = ops.linear_fwd(x, w, colstat=True)
+                    close(y, x @ w.t(), what="linear with colstat")
+                    _bn_from_parts(dev, y.view(1, 1, m, n), cs, relu=(n != 24), res=R(1, 1, m, n, seed=8, dev=dev) if n == 72 else None)
+                bias = R(32, seed=6, dev=dev)
+                x = R(150, 9, dev=dev)
+                w = R(32, 9, seed=7, dev=dev)
+                y, cs = ops.linear_fwd(x, w, bias, colstat=True)        # point_pillar.py:15-25: Linear(9, 32) with bias + BatchNorm1d (unaligned K: engine path)
+                close(y, x @ w.t() + bias, what="linear + bias with colstat")
+                _bn_from_parts(dev, y.view(1, 1, 150, 32), cs)
+            finally:
+                ops.force_plan(0)
+        # implicit-GEMM convolutions: stride-2 grouped 3x3 (first block of a stage), 1x1 / s2 downsample
+        for (B, H, W, Cin, Cout, ks, stride, groups) in ((2, 10, 12, 48, 48, 3, 2, 2), (2, 9, 11, 24, 72, 1, 2, 1), (1, 12, 16, 72, 72, 3, 2, 3)):
+            xc = R(B, Cin, H, W, dev="cpu") + 1.5
+            wc = R(Cout, Cin // groups, ks, ks, seed=3, dev="cpu") * 0.2
+            want = F.conv2d(xc, wc, None, stride, ks // 2, 1, groups)
+            y, cs = ops.conv_fwd(xc.permute(0, 2, 3, 1).contiguous().to(dev), cl(wc).to(dev), None, stride, ks // 2, groups, colstat=True)
+            close(y.permute(0, 3, 1, 2), want, what="conv with colstat")
+            _bn_from_parts(dev, y, cs)
+        # direct grouped kernel: 8x16 and 4x32 tiles, ragged in both directions, 1..3 groups, several tiles per block
+        for (B, H, W, C) in ((2, 9, 44, 72), (3, 16, 16, 48), (2, 5, 37, 24), (2, 20, 70, 72)):
+            xc = R(B, C, H, W, dev="cpu") - 2.0
+            wc = R(C, 24, 3, 3, seed=3, dev="cpu") * 0.1
+            want = F.conv2d(xc, wc, None, 1, 1, 1, C // 24)
+            y, cs = ops.conv_fwd(xc.permute(0, 2, 3, 1).contiguous().to(dev), cl(wc).to(dev), None, 1, 1, C // 24, colstat=True)
+            close(y.permute(0, 3, 1, 2), want, what="grouped conv with colstat")
+            if C // 24 > 1:
+                _bn_from_parts(dev, y, cs)
+            else:
+                assert cs is None or cs.nparts.value > 0
+        # maps above the row threshold keep the streaming reduction: no statistics requested
+        ops._COLSTAT_MAX_ROWS = 100
+        y, cs = ops.linear_fwd(R(203, 40, dev=dev), R(72, 40, seed=5, dev=dev), colstat=True)
+        assert cs is None
+        ops._COLSTAT_MAX_ROWS = old_rows
+        # a two-pass split-K plan cannot fuse them: nparts = 0 -> None, the output is still right
+        ops.force_dma(2, 1000002)
+        try:
+            x, w = R(260, 640, dev=dev), R(136, 640, seed=5, dev=dev) * 0.1
+            y, cs = ops.linear_fwd(x, w, colstat=True)
+            close(y, x @ w.t(), what="two-pass GEMM with a statistics request")
+            assert cs is None
+        finally:
+            ops.force_plan(0)
+    finally:
+        ops.FUSE_BN_STATS, ops._COLSTAT_MAX_ROWS = old_fuse, old_rows
+
+
+# ---------------------------------------------------------------- fused attention (csrc/attention.cpp)
+FUSED_ATTENTION_CASES = [(2, 4, 174, 18, 0.1), (1, 4, 174, 54, 0.0), (2, 2, 50, 24, 0.1), (1, 3, 192, 40, 0.1), (2, 1, 33, 7, 0.0)]
+FUSED_ATTENTION_CASES_GPU = [(10, 4, 174, 378, 0.1), (3, 4, 174, 144, 0.1), (2, 4, 174, 54, 0.0), (2, 4, 174, 18, 0.1), (1, 1, 192, 384, 0.1), (2, 3, 97, 33, 0.1)]
+
+
+def check_fused_attention(dev, B, nh, T, hs, p):
+    """tf_attention_fwd / bwd vs PyTorch (SelfAttention.forward, transfuser.py:510-527: softmax(q k^T / sqrt(hs)) -> attn_drop -> @ v, heads
+    merged) on the same qkv, with the PRODUCT's dropout mask (flat index over (B nh, T, Tp)) applied by the reference; y, and dq / dk / dv."""
+    C = nh * hs
+    qkv = R(B * T, 3 * C, dev="cpu", scale=0.7)
+    qkv.requires_grad_(True)
+    k, q, v = [qkv[:, j * C:(j + 1) * C].view(B, T, nh, hs).transpose(1, 2) for j in range(3)]
+    att = torch.softmax((q @ k.transpose(-2, -1)) * (1.0 / math.sqrt(hs)), dim=-1)
+    seed = torch.full((1,), 777, dtype=torch.int32, device=dev)
+    site = 13
+    Tp = (T + 3) // 4 * 4
+    if p > 0:
+        mask = ops.dropout(torch.ones(B * nh, T, Tp, device=dev), seed, site, p)[:, :, :T].reshape(B, nh, T, T).cpu()
+        assert 0.5 * p < float((mask == 0).float().mean()) < 1.5 * p + 0.02
+        att = att * mask
+    y = (att @ v).transpose(1, 2).contiguous().view(B * T, C)
+    dy = R(B * T, C, seed=9, dev="cpu")
+    (g,) = torch.autograd.grad(y, qkv, dy)
+    drop = (seed, site, p) if p > 0 else None
+    qd = qkv.detach().to(dev)
+    assert ops.attention_supported(T, C, nh)
+    yh, lse = ops.attention_fwd(qd, B, T, C, nh, drop)
+    close(yh, y, what="fused attention fwd")
+    s = (q @ k.transpose(-2, -1)).detach() * (1.0 / math.sqrt(hs))
+    close(lse.view(B, nh, T), torch.logsumexp(s, -1), what="fused attention log-sum-exp")
+    dq = ops.attention_bwd(qd, dy.to(dev), lse, B, T, C, nh, drop)
+    close(dq[:, C:2 * C], g[:, C:2 * C], what="fused attention dQ")
+    close(dq[:, :C], g[:, :C], what="fused attention dK")
+    close(dq[:, 2 * C:], g[:, 2 * C:], what="fused attention dV")

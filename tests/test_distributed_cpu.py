@@ -57,6 +57,19 @@ def _worker(rank, world, port):
     red.reduce()
     assert torch.allclose(arena.grads, (both[0] + both[1]) / world, atol=1e-6)
     assert torch.allclose(net.head.weight.grad, ((both[0] + both[1]) / world)[net.head.weight.grad.storage_offset():][:60].view(5, 12), atol=1e-6)
+    # opt-in bf16 gradient buckets: every bucket rounded to bf16 (RNE, our kernel), summed, widened x 1/world; replicas still identical
+    arena.grads.copy_(mine)
+    red16 = GradReducer(arena, bucket_mb=0.0005, grad_dtype="bf16")
+    red16.reduce()
+    want16 = (both[0].bfloat16() + both[1].bfloat16()).float() / world
+    assert torch.allclose(arena.grads, want16, atol=2e-2, rtol=1e-2), (arena.grads - want16).abs().max()
+    assert torch.allclose(arena.grads, (both[0] + both[1]) / world, atol=3e-2, rtol=2e-2)
+    g16 = [torch.zeros_like(arena.grads) for _ in range(world)]
+    dist.all_gather(g16, arena.grads)
+    assert torch.equal(g16[0], g16[1])
+    from transfuser_amd import ops
+    xs_ = torch.tensor([1.0, 1.00390625, 1.01171875, -3.3e38, 1e-40, float("inf")])       # ties-to-even, overflow to inf, denormal, inf
+    assert torch.equal(ops.cast_bf16(xs_), xs_.bfloat16())
     # ZeRO-1 (--zero_redundancy_optimizer 1, train.py:138-140): sharded AdamW + slice broadcast == full AdamW on every rank
     from transfuser_amd.train import FlatAdamW
     p0 = arena.params.clone()
@@ -154,7 +167,77 @@ def _engine_worker(rank, world, port, tmp):
     shard = FlatAdamW(ez.arena, lr=1e-3, shard=(rank, world))           # ... or sharded
     shard.load_state_dict(sd)
     assert torch.equal(shard.exp_avg, sd["exp_avg"][shard.lo:shard.hi])
+    # a state written with backward cuts (multi-GPU arena order) resumed WITHOUT cuts (single-GPU order) and back: moments follow their
+    # parameter by NAME (the flat vector alone would silently assign them to the wrong parameters)
+    ep = finals["plain"][1]
+    assert [t[0] for t in sd["layout"]] != [t[0] for t in ep.optimizer._layout()]
+    moved = FlatAdamW(ep.arena, lr=1e-3)
+    moved.load_state_dict(sd)
+    off_p = {n: o for n, o, _ in ep.optimizer._layout()}
+    for n, o, cnt in sd["layout"]:
+        assert torch.equal(moved.exp_avg[off_p[n]:off_p[n] + cnt], sd["exp_avg"][o:o + cnt]), n
+    assert torch.allclose(moved.exp_avg, ep.optimizer.exp_avg, atol=1e-7)      # == the moments the uncut engine accumulated itself
+    back = FlatAdamW(eo.arena, lr=1e-3)
+    back.load_state_dict(moved.state_dict())
+    assert torch.equal(back.exp_avg, fresh.exp_avg) and torch.equal(back.exp_avg_sq, fresh.exp_avg_sq)
+    legacy = {k: v for k, v in sd.items() if k != "layout"}
+    try:
+        FlatAdamW(eo.arena, lr=1e-3).load_state_dict(legacy)
+        raise AssertionError("a layout-less state must not load into a segmented arena")
+    except ValueError:
+        pass
+    FlatAdamW(ep.arena, lr=1e-3).load_state_dict({k: v for k, v in moved.state_dict().items() if k != "layout"})     # uncut arena: legacy files load
     dist.destroy_process_group()
+
+
+def _pillar_worker(rank, world, port):
+    """--use_point_pillars 1 with the overlapped reduction: the point net's gradients are produced by the LAST backward piece
+    (through the LiDAR stem), so its parameters must live in the LAST arena segment - overlap path == plain path bitwise, replicas equal."""
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import ctypes
+    import build_emu
+    from transfuser_amd import _lib
+    _lib._install_test_backend(ctypes.CDLL(build_emu.build()))
+    import model_cases as mc
+    from transfuser_amd.data import synthetic_cloud
+    from transfuser_amd.train import Engine
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    cfg = mc.tiny_config(n_layer=1)
+    cfg.use_point_pillars = True
+    cfg.min_x, cfg.max_x, cfg.min_y, cfg.max_y = -4, 4, -8, 0          # 64 x 64 canvas at 8 px / m
+    batch = mc.small_batch(1, 32, 64, 64, 40, seed=30 + rank)
+    pts = torch.from_numpy(synthetic_cloud(1, 1500, seed=rank))
+    pts[..., :2] *= 0.25                                                # into the small canvas (some points stay outside)
+    batch["lidar"] = torch.nn.functional.pad(pts, (0, 0, 0, 548))       # (1, 2048, 4) padded cloud
+    batch["num_points"] = torch.full((1,), 1500, dtype=torch.int32)
+    finals = {}
+    for tag, kw in (("overlap", {}), ("plain", dict(cuts=()))):
+        prod, _ = mc.build_pair(cfg, "regnety_tiny", "cpu", seed=rank)
+        prod.train()
+        eng = Engine(prod, cfg, lr=1e-3, **kw)
+        if tag == "overlap":
+            assert eng.n_pieces() > 1
+            lo, hi = eng.arena.segment_ranges[-1]
+            offs = [o for n, p, o in eng.arena.layout if n.startswith("point_pillar_net.")]
+            assert offs and all(lo <= o < hi for o in offs), (offs, lo, hi)          # reduced after the piece that produces them
+        for _ in range(2):
+            eng.train_step(batch)
+        both = [torch.zeros_like(eng.arena.params) for _ in range(world)]
+        dist.all_gather(both, eng.arena.params)
+        assert torch.equal(both[0], both[1]), tag
+        finals[tag] = {n: p.detach().clone() for n, p, _ in eng.arena.layout}
+        g = dict(prod.named_parameters())["point_pillar_net.point_net.net.0.weight"].grad
+        assert g.abs().sum() > 0                                                     # the point net really trains
+    for n in finals["overlap"]:
+        assert torch.equal(finals["overlap"][n], finals["plain"][n]), n
+    dist.destroy_process_group()
+
+
+def test_engine_point_pillars_overlap_world2_gloo():
+    port = 35500 + (os.getpid() % 2000)
+    mp.spawn(_pillar_worker, args=(2, port), nprocs=2, join=True)
 
 
 def test_engine_overlap_plain_zero_world2_gloo(tmp_path):

@@ -27,6 +27,11 @@ def test_conv(case):
     kc.check_conv("cpu", *case)
 
 
+@pytest.mark.parametrize("case", kc.FUSED_ATTENTION_CASES, ids=str)
+def test_fused_attention(case):
+    kc.check_fused_attention("cpu", *case)
+
+
 def test_stem_conv():
     kc.check_stem("cpu", 2, 12, 20)
 
@@ -43,6 +48,10 @@ def test_softmax():
 @pytest.mark.parametrize("case", [(2, 6, 7, 72, True, True), (1, 5, 5, 216, False, False), (3, 4, 4, 32, True, False), (2, 3, 5, 7, False, True)], ids=str)
 def test_batchnorm(case):
     kc.check_bn("cpu", *case)
+
+
+def test_bn_statistics_fused_into_the_producing_conv():
+    kc.check_bn_fused_stats("cpu")
 
 
 def test_bn_eval():

@@ -34,6 +34,11 @@ def test_conv(case):
     kc.check_conv("cuda", *case)
 
 
+@pytest.mark.parametrize("case", kc.FUSED_ATTENTION_CASES + kc.FUSED_ATTENTION_CASES_GPU, ids=str)
+def test_fused_attention(case):
+    kc.check_fused_attention("cuda", *case)
+
+
 def test_stem_conv():
     kc.check_stem("cuda", 2, 12, 20)
 
@@ -50,6 +55,10 @@ def test_softmax():
 @pytest.mark.parametrize("case", [(2, 6, 7, 72, True, True), (1, 5, 5, 216, False, False), (3, 4, 4, 32, True, False), (2, 3, 5, 7, False, True)], ids=str)
 def test_batchnorm(case):
     kc.check_bn("cuda", *case)
+
+
+def test_bn_statistics_fused_into_the_producing_conv():
+    kc.check_bn_fused_stats("cuda")
 
 
 def test_bn_eval():

@@ -259,42 +259,6 @@ def test_late_fusion_backbone_matches_oracle():
 def test_dropout_paths_match_oracle_with_the_same_masks():
     """Training-mode dropout (embd / attention / both residual sites: fused dropout+residual and softmax+attn_drop kernels, masks regenerated
     in the backward): the oracle's nn.Dropout modules are replaced by modules that apply the PRODUCT's masks (counter RNG keyed by seed and
-    site, laid out like the product's tensors), so all 11 losses and every parameter gradient must agree as in the p = 0 tests."""
-    import torch.nn as nn
-    from transfuser_amd import ops
-    import transfuser_amd.transfuser as ptf
-    cfg = mc.tiny_config(n_layer=2, dropout=0.1)
-    ptf.GPT._site_base = 0          # dropout sites are numbered per constructed GPT (class counter): the same masks whatever ran before
-    prod, ref = mc.build_pair(cfg, "regnety_tiny", "cpu")
-
-    class MaskDrop(nn.Module):
-        def __init__(self, seed, site, p, attn):
-            super().__init__()
-            self.seed, self.site, self.p, self.attn = seed, site, p, attn
-
-        def forward(self, x):
-            if self.attn:                      # product layout: (B * nh, T, Tp) with the rows padded to a multiple of 4
-                B, nh, T, _ = x.shape
-                Tp = (T + 3) // 4 * 4
-                m = ops.dropout(torch.ones(B * nh, T, Tp), self.seed, self.site, self.p)[:, :, :T].reshape(B, nh, T, T)
-            else:
-                m = ops.dropout(torch.ones(x.numel()), self.seed, self.site, self.p).view_as(x)
-            dropped.append(float((m == 0).float().mean()))
-            return x * m
-
-    dropped, n = [], 0
-    for name in ("transformer1", "transformer2", "transformer3", "transformer4"):
-        gp, gr = getattr(prod._model, name), getattr(ref._model, name)
-        seed = prod._model.dropout_seed          # the backbone hands this buffer to every GPT stage at call time
-        assert gp.pdrop_any
-        gr.drop = MaskDrop(seed, gp.site(0), gp.embd_pdrop, False)
-        for li, blk in enumerate(gr.blocks):
-            blk.attn.attn_drop = MaskDrop(seed, gp.site(4 * li + 1), gp.attn_pdrop, True)
-            blk.attn.resid_drop = MaskDrop(seed, gp.site(4 * li + 2), gp.resid_pdrop, False)
-            blk.mlp[3] = MaskDrop(seed, gp.site(4 * li + 3), gp.resid_pdrop, False)
-            n += 3
-    assert n == 24
-    batch = mc.small_batch(2, 32, 64, 64, 40)
-    lp, lr = mc.run_pair(prod, ref, cfg, batch, "cpu")
-    mc.compare(prod, ref, lp, lr)
-    assert len(dropped) == 28 and all(0.03 < d < 0.25 for d in dropped), dropped     # every site really dropped ~10 % of its elements
+    site, laid out like the product's tensors), so all 11 losses and every parameter gradient must agree as in the p = 0 tests.  The same
+    check runs on the MI355X (tests/test_model_gpu.py), where the bench times exactly this p = 0.1 path."""
+    mc.check_dropout_model("cpu")

@@ -221,44 +221,28 @@ def test_engine_segmented_graphs_match_single_graph():
 def test_bench_configuration_parity_B10_H256():
     """Parity ON the benchmarked configuration (BASELINE configs[1]: B=10, 3x256x704 + 3x256x256, RegNetY-3.2GF x2, 4x4 GPT layers, fp32,
     dropout 0, the shipped tuned plans): the 11 losses and the forward outputs within 1e-3 of the fp32 CPU oracle, and every parameter
-    gradient against the oracle's fp32 gradient in relative L2.  fp32 gradients of this network carry ~1e-2 of round-off noise per tensor
-    on ANY implementation (ReLU-mask flips, see compare_vs_fp64), so the per-tensor bound is 5e-2, the median bound 1.5e-2 - a wrong
-    kernel / tile plan at these exact shapes gives O(1)."""
-    import os
-    from oracle import hist
-    from transfuser_amd import ops
-    from transfuser_amd.data import synthetic_batch
-    ops.plans_load(os.path.join(os.path.dirname(os.path.abspath(ops.__file__)), "plans", "mi355x.txt"))
-    cfg = mc.full_config()
-    prod, ref = mc.build_pair(cfg, "regnety_032", "cuda")
-    batch = synthetic_batch(10, 256, 704, seed=0, hist_fn=hist.lidar_to_histogram_features, n_points=8192)
-    batch = {k: batch[k] for k in ("rgb", "lidar", "ego_waypoint", "target_point", "target_point_image", "ego_vel", "bev", "label", "depth", "semantic")}
-    torch.set_num_threads(min(64, torch.get_num_threads() * 4, __import__("os").cpu_count()))
-    lp, lr = mc.run_pair(prod, ref, cfg, batch, "cuda")
-    for k in lr:
-        a, b = float(lp[k]), float(lr[k])
-        assert abs(a - b) <= 1e-3 * max(1.0, abs(b)), "loss %s: hip %g vs oracle %g" % (k, a, b)
-    o, r = prod._last, ref._last
-    for name, a, b in [("pred_wp", o["pred_wp"], r["pred_wp"]), ("fused_features", o["fused"], r["fused"]),
-                       ("image_features_grid", o["grid"].permute(0, 3, 1, 2), r["grid"]), ("p2", o["features"][0].permute(0, 3, 1, 2), r["features"][0]),
-                       ("pred_bev", o["bev_up"].permute(0, 3, 1, 2), r["pred_bev"])]:
-        a, b = a.detach().cpu(), b.detach()
-        err = (a - b).abs().max().item()
-        assert err <= 1e-3 * max(1.0, b.abs().max().item()), "output %s: max err %.3e" % (name, err)
-    rp = dict(ref.named_parameters())
-    errs = []
-    for n, p in prod.named_parameters():
-        g = rp[n].grad
-        if g is None or g.norm().item() < 1e-12:
-            continue
-        errs.append(((p.grad.detach().cpu().double() - g.double()).norm().item() / g.double().norm().item(), n))
-    errs.sort(reverse=True)
-    med = errs[len(errs) // 2][0]
-    print("  B=10 H=256 gradient rel-L2 vs fp32 oracle: median %.2e, worst %s" % (med, [("%.2e" % e, n) for e, n in errs[:4]]))
-    noise_only = ("attn.key.bias",)                        # true gradient is zero up to round-off (softmax shift invariance)
-    bad = [(e, n) for e, n in errs if e > 5e-2 and not any(t in n for t in noise_only)]
-    assert med <= 1.5e-2 and len(bad) <= 3, (med, bad[:6])
-    ops.L().tf_plans_clear()
+    gradient against the oracle's fp32 gradient in relative L2 (see mc.check_full_size_vs_fp32_oracle for the bounds)."""
+    mc.check_full_size_vs_fp32_oracle("transFuser", 10, 256)
+
+
+def test_dropout_paths_match_oracle_on_gpu():
+    """p = 0.1 - the bench's setting - on the MI355X against the ORACLE (not against the unfused product kernels): the whole tiny model
+    (28 dropout sites: embd_drop, attn_drop inside the softmax kernels, the two fused dropout + residual adds per Block, masks regenerated in
+    the backward) with the oracle's nn.Dropout modules applying the product's masks, then one fusion stage at the GPT-4 width
+    (C = 1512, T = 174) where outputs, input gradients and every parameter gradient must agree within 1e-3."""
+    mc.check_dropout_model("cuda", lidar_res=128, H=160, W=352, grad_tol=5e-3, metric="l2")
+    mc.check_dropout_gpt_stage("cuda", C=1512, B=3, n_layer=1, p=0.1)
+    mc.check_dropout_gpt_stage("cuda", C=216, B=2, n_layer=2, p=0.1)
+
+
+def test_latentTF_full_size_B16_H256_parity():
+    """BASELINE configs[4] at its own batch size (latentTF.py:118-217, bs=16/GPU, 3x256x704): real RegNetY-3.2GF trunks, shipped plans."""
+    mc.check_full_size_vs_fp64("latentTF", 16, 256)
+
+
+def test_geometric_fusion_full_size_B12_H160_parity():
+    """BASELINE configs[3] at its own batch size (geometric_fusion.py:93-288, bs=12/GPU, its only valid resolution 160x704)."""
+    mc.check_full_size_vs_fp64("geometric_fusion", 12, 160)
 
 
 def test_single_block_gradients_within_1e3():
@@ -380,6 +364,72 @@ def test_bf16_mfma_mode_model_parity():
     # this network amplifies round-off ~1e5x into its gradients (fp32 vs fp64: 1e-2 per tensor, see compare_vs_fp64), so bf16 operand
     # rounding (4e-3) cannot give per-tensor agreement; what low-precision training needs is the descent DIRECTION: global cosine >= 0.9
     assert cos >= 0.9 and errs[len(errs) // 2] <= 0.6, (cos, errs[len(errs) // 2])
+
+
+def _precision_engine_run(precision, steps, B=10, H=256, dropout=0.1, lr=1e-4):
+    from transfuser_amd import ops, transfuser as ptf
+    from transfuser_amd.data import synthetic_batch
+    from transfuser_amd.model import LidarCenterNet
+    from transfuser_amd.train import Engine
+    cfg = mc.full_config(dropout=dropout)
+    ptf.GPT._site_base = 0
+    torch.manual_seed(0)
+    model = LidarCenterNet(cfg, "cuda", "transFuser", "regnety_032", "regnety_032", use_velocity=False)
+    mc.randomize(model)
+    model.train()
+    hist_fn = lambda pts: ops.lidar_hist(torch.from_numpy(pts).cuda()[None])[0].cpu().numpy()
+    batch = {k: v.cuda() for k, v in synthetic_batch(B, H, 704, seed=0, hist_fn=hist_fn).items()}
+    eng = Engine(model, cfg, lr=lr, precision=precision)
+    try:
+        out = []
+        for _ in range(steps):
+            tot, det = eng.train_step(batch)
+            out.append([float(tot)] + [float(det[k]) for k in cfg.detailed_losses])
+        torch.cuda.synchronize()
+    finally:
+        ops.set_precision("fp32")
+    del eng, model
+    torch.cuda.empty_cache()
+    return torch.tensor(out, dtype=torch.float64)
+
+
+def test_bf16_full_size_parity_and_training_trajectory():
+    """BASELINE configs[2] (bf16 contractions, fp32 master weights / AdamW) on the REAL model at the bench shape.
+    (a) forward: the 11 losses of the 168 M-parameter model at 256x704 within 3e-2 (relative, stated tolerance of the bf16 mode: 8-bit
+        mantissa operands, fp32 accumulation, ~60 layers) of the fp32 CPU oracle;
+    (b) training: 20 AdamW steps (B=10, 256x704, dropout 0.1 with identical masks, lr 1e-4) in bf16 against the same 20 steps in exact fp32:
+        the total loss stays within 5 % of the fp32 curve at EVERY step and falls by at least 80 % of what the fp32 run gains."""
+    from oracle import hist
+    from transfuser_amd import ops
+    from transfuser_amd.data import synthetic_batch
+    cfg = mc.full_config()
+    prod, ref = mc.build_pair(cfg, "regnety_032", "cuda")
+    batch = synthetic_batch(1, 256, 704, seed=0, hist_fn=hist.lidar_to_histogram_features, n_points=8192)
+    ops.set_precision("bf16")
+    try:
+        lp, lr = mc.run_pair(prod, ref, cfg, batch, "cuda")
+        torch.cuda.synchronize()
+    finally:
+        ops.set_precision("fp32")
+    for k in lr:
+        a, b = float(lp[k].detach()), float(lr[k].detach())
+        assert abs(a - b) <= 3e-2 * max(1.0, abs(b)), "loss %s: bf16 %g vs fp32 oracle %g" % (k, a, b)
+    rp = dict(ref.named_parameters())
+    gp = torch.cat([p.grad.detach().cpu().double().flatten() for n, p in prod.named_parameters() if rp[n].grad is not None])
+    gr = torch.cat([rp[n].grad.double().flatten() for n, p in prod.named_parameters() if rp[n].grad is not None])
+    cos = float(torch.dot(gp, gr) / (gp.norm() * gr.norm()))
+    print("  bf16 full size (B=1, 256x704): max loss deviation %.2e, gradient global cosine vs fp32 oracle %.4f" %
+          (max(abs(float(lp[k]) - float(lr[k])) / max(1.0, abs(float(lr[k]))) for k in lr), cos))
+    assert cos >= 0.9, cos
+    del prod, ref
+    torch.cuda.empty_cache()
+    c32 = _precision_engine_run("fp32", 20)
+    c16 = _precision_engine_run("bf16", 20)
+    rel = ((c16[:, 0] - c32[:, 0]).abs() / c32[:, 0].abs())
+    print("  20-step trajectory: fp32 loss %.4f -> %.4f, bf16 %.4f -> %.4f; max relative deviation of the total loss %.2e (step %d)" %
+          (c32[0, 0], c32[-1, 0], c16[0, 0], c16[-1, 0], rel.max().item(), int(rel.argmax())))
+    assert rel.max().item() <= 5e-2, rel.tolist()
+    assert (c16[0, 0] - c16[-1, 0]) >= 0.8 * (c32[0, 0] - c32[-1, 0]) > 0, (c32[:, 0].tolist(), c16[:, 0].tolist())
 
 
 def test_full_size_step_properties():

@@ -28,7 +28,7 @@ class GemmDesc(ctypes.Structure):
                 ("batch", c_i), ("inner", c_i),
                 ("sa_outer", c_l), ("sa_inner", c_l), ("sb_outer", c_l), ("sb_inner", c_l), ("sc_outer", c_l), ("sc_inner", c_l),
                 ("alpha", c_f), ("relu", c_i), ("accumulate", c_i), ("mask", c_p), ("ldmask", c_l),
-                ("splitk_ws", c_p), ("splitk_ws_floats", c_l)]
+                ("splitk_ws", c_p), ("splitk_ws_floats", c_l), ("colstat", c_p), ("colstat_nparts", ctypes.POINTER(ctypes.c_int))]
 
 
 class ConvGeom(ctypes.Structure):
@@ -85,5 +85,5 @@ def stream_of(t):
 def ptr(t):
     if t is None:
         return c_p(0)
-    assert t.dtype in (torch.float32, torch.int32, torch.int64, torch.uint8), t.dtype
+    assert t.dtype in (torch.float32, torch.int32, torch.int64, torch.uint8, torch.bfloat16), t.dtype
     return c_p(t.data_ptr())

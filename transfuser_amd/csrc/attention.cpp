@@ -1,0 +1,371 @@
+// Fused self-attention of the GPT fusion stages (transfuser.py:510-527): for one (sample, head) and a tile of 32 token rows a workgroup
+// computes  S = q k^T / sqrt(hs)  ->  softmax  ->  attn_drop  ->  @ v  without the (B, nh, T, T) score matrix ever leaving the CU
+// (before: 2 batched GEMM launches + a softmax launch per layer forward, 5 GEMMs + softmax backward, scores / probabilities
+// / dropped probabilities round-tripping HBM).  T <= 192 (the model has T = 5 x 22 + 8 x 8 = 174), hs <= 384 (18 / 54 / 144 / 378).
+//
+// All three kernels share one skeleton, on a tile of 32 "row" tokens against ALL T "column" tokens:
+//   phase A  one or two score-shaped products [32 x 192] contracted over hs (operands streamed global -> registers -> LDS in 16-deep,
+//            K-major tiles, double-buffered, register prefetch; six waves, one 32 x 32 fp32-MFMA accumulator per product each);
+//   middle   the score rows live in LDS ([32][193] floats): softmax / its backward / dropout mask regenerated from the counter RNG;
+//   phase B  one or two [32 x hs] products contracted over T with the LDS-resident scores as the A operand (B operand streamed).
+// forward:   rows = queries: S = Q K^T; P = softmax(S); Y = drop(P) V; saves only L_i = max_i + log(sum_i) per row (T floats per head).
+// backward dq:   rows = queries: recomputes P = exp(S - L), dPd = dY V^T, D_i = sum_j dP_ij P_ij, dS = P (dP - D); dQ = dS K / sqrt(hs).
+// backward dkv:  rows = keys: the transposed products K Q^T, V dY^T; dS^T with L_i, D_i per COLUMN; dK = dS^T Q / sqrt(hs), dV = Pd^T dY.
+// The dropout mask of element (query i, key j) is the one tf_dropout_f32 draws for the flat index ((b nh + h) T + i) Tp + j of the
+// (B nh, T, Tp) probability tensor (Tp = T rounded up to 4), i.e. the unfused path's mask - parity tests share their masks.
+// Exact fp32 MFMA in every precision mode: the contraction is 1.5 % of the step's FLOPs, its cost was launches and HBM round trips.
+#include "tf_common.h"
+#include "../../include/transfuser_hip.h"
+
+using namespace tf;
+
+namespace {
+
+constexpr int kR = 32;             // row tokens per workgroup
+constexpr int kNC = 192;           // column tokens (T padded)
+constexpr int kNW = 6;             // waves: one 32-column tile of the scores each
+constexpr int kNT = 64 * kNW;
+constexpr int kBK = 16;            // contraction chunk
+constexpr int kAP = kR + 4;        // pitch of a K-major row-operand tile  [kBK][36]
+constexpr int kBP = kNC + 4;       //                 column-operand tile  [kBK][196]
+constexpr int kSP = kNC + 1;       // score matrix pitch [32][193]: conflict-free as MFMA A operand (lane = row) and as row-wise softmax input
+constexpr int kHS = 384;           // max head size
+constexpr int kHP = kHS + 4;       // phase-B operand tile [kBK][388]
+constexpr int kATile = kBK * kAP + kBK * kBP;          // floats of one (row, column) operand pair of phase A
+constexpr int kUnion = 2 * 2 * kATile;                 // phase A: 2 buffers x up to 2 products (>= phase B: 2 buffers x kBK x kHP)
+static_assert(kUnion >= 2 * kBK * kHP, "phase B tiles must fit the phase A region");
+constexpr int kSmem = 2 * kR * kSP + kUnion;           // 27200 floats = 106 KiB: one workgroup per CU
+
+struct AtGeom {
+    int B, nh, T, hs, C, Tp;
+    float alpha, keep_scale;
+    uint32_t site, thresh;
+};
+
+__device__ __forceinline__ int acc_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+// ---- phase A: acc[p] (32 x 32 per wave) = sum_k R_p[row0 + i][k] * C_p[wave * 32 + j][k], p < NP; both operands row-major, k contiguous
+template <int NP>
+__device__ __forceinline__ void phase_a(f32x16 (&acc)[NP], const float* const (&rsrc)[NP], const long (&rld)[NP], const float* const (&csrc)[NP],
+                                        const long (&cld)[NP], int row0, int T, int hs, float* U) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    constexpr int SA = (kR * kBK + kNT - 1) / kNT;      // 2 row-operand slots per thread
+    constexpr int SB = (kNC * kBK) / kNT;               // 8 column-operand slots per thread
+    float ra[NP][SA], rb[NP][SB];
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+#pragma unroll
+            for (int s = 0; s < SA; ++s) {
+                const int idx = tid + s * kNT, r = idx >> 4, k = idx & 15;
+                const bool ok = idx < kR * kBK && row0 + r < T && k0 + k < hs;
+                ra[p][s] = ok ? rsrc[p][(long)(row0 + r) * rld[p] + k0 + k] : 0.f;
+            }
+#pragma unroll
+            for (int s = 0; s < SB; ++s) {
+                const int idx = tid + s * kNT, r = idx >> 4, k = idx & 15;
+                const bool ok = r < T && k0 + k < hs;
+                rb[p][s] = ok ? csrc[p][(long)r * cld[p] + k0 + k] : 0.f;
+            }
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            float* As = U + (buf * NP + p) * kATile;
+            float* Bs = As + kBK * kAP;
+#pragma unroll
+            for (int s = 0; s < SA; ++s) {
+                const int idx = tid + s * kNT, r = idx >> 4, k = idx & 15;
+                if (idx < kR * kBK) As[k * kAP + r] = ra[p][s];
+            }
+#pragma unroll
+            for (int s = 0; s < SB; ++s) {
+                const int idx = tid + s * kNT, r = idx >> 4, k = idx & 15;
+                Bs[k * kBP + r] = rb[p][s];
+            }
+        }
+    };
+    const int nch = (hs + kBK - 1) / kBK;
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int c = 0; c < nch; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nch) fetch((c + 1) * kBK);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const float* As = U + (buf * NP + p) * kATile;
+            const float* Bs = As + kBK * kAP;
+#pragma unroll
+            for (int kk = 0; kk < kBK / 2; ++kk)
+                mfma_32x32x2(As[(2 * kk + hi) * kAP + l31], Bs[(2 * kk + hi) * kBP + wave * 32 + l31], acc[p]);
+        }
+        if (c + 1 < nch) stash(buf ^ 1);
+        __syncthreads();
+    }
+}
+
+// the wave's accumulator tile -> score matrix Sm[i][wave * 32 + j] (x scale)
+__device__ __forceinline__ void put_scores(float* Sm, const f32x16& acc, float scale) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Sm[acc_row(r, hi) * kSP + wave * 32 + l31] = acc[r] * scale;
+}
+
+// ---- phase B: out[row0 + i][c] = scale * sum_t Sm[i][t] * bsrc[t][c], c < hs; wave w owns the column tiles w and w + 6
+__device__ __forceinline__ void phase_b(const float* Sm, const float* bsrc, long bld, int T, int hs, float* U, float* out, long old, int row0,
+                                        float scale) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int ntile = (hs + 31) >> 5, ncv = ntile * 32;
+    constexpr int SLOTS = (kBK * kHS) / kNT;            // 16
+    float rb[SLOTS];
+    f32x16 acc[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
+    const int total = kBK * ncv;
+    // slot s of this thread: flat index tid + s * kNT over [kBK][ncv]; (t, c) computed once (ncv is a run-time multiple of 32)
+    int st[SLOTS], sc[SLOTS];
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        const int idx = tid + s * kNT;
+        st[s] = idx / ncv;
+        sc[s] = idx - st[s] * ncv;
+    }
+    auto fetch = [&](int t0) {
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+            const bool ok = tid + s * kNT < total && t0 + st[s] < T && sc[s] < hs;
+            rb[s] = ok ? bsrc[(long)(t0 + st[s]) * bld + sc[s]] : 0.f;
+        }
+    };
+    auto stash = [&](int buf) {
+        float* Bs = U + buf * kBK * kHP;
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s)
+            if (tid + s * kNT < total) Bs[st[s] * kHP + sc[s]] = rb[s];
+    };
+    const int nch = (T + kBK - 1) / kBK;
+    const bool own0 = wave < ntile, own1 = wave + kNW < ntile;
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int c = 0; c < nch; ++c) {
+        const int buf = c & 1, t0 = c * kBK;
+        if (c + 1 < nch) fetch(t0 + kBK);
+        const float* Bs = U + buf * kBK * kHP;
+        if (own0) {       // wave-uniform
+#pragma unroll
+            for (int kk = 0; kk < kBK / 2; ++kk) {
+                const float a = Sm[l31 * kSP + t0 + 2 * kk + hi];
+                mfma_32x32x2(a, Bs[(2 * kk + hi) * kHP + wave * 32 + l31], acc[0]);
+                if (own1) mfma_32x32x2(a, Bs[(2 * kk + hi) * kHP + (wave + kNW) * 32 + l31], acc[1]);
+            }
+        }
+        if (c + 1 < nch) stash(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int col = (wave + u * kNW) * 32 + l31;
+        if (col < hs) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + acc_row(r, hi);
+                if (row < T) out[(long)row * old + col] = acc[u][r] * scale;
+            }
+        }
+    }
+}
+
+// qkv: (B*T, 3C) = [key | query | value] (transfuser.py:500-502 order); head h owns columns h*hs .. of each third
+__global__ void __launch_bounds__(kNT, 2) attention_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ y, float* __restrict__ lse, AtGeom g,
+                                                               const uint32_t* __restrict__ seed) {
+    __shared__ __attribute__((aligned(16))) float smem[kSmem];
+    float* Sm = smem;
+    float* U = smem + 2 * kR * kSP;
+    const int bh = blockIdx.y, b = bh / g.nh, h = bh - b * g.nh, row0 = blockIdx.x * kR;
+    const long ld3 = 3L * g.C;
+    const float* kp = qkv + (long)b * g.T * ld3 + (long)h * g.hs;
+    const float* qp = kp + g.C;
+    const float* vp = kp + 2 * g.C;
+    f32x16 acc[1];
+    const float* const rs[1] = {qp};
+    const float* const cs[1] = {kp};
+    const long rl[1] = {ld3}, cl[1] = {ld3};
+    phase_a<1>(acc, rs, rl, cs, cl, row0, g.T, g.hs, U);
+    put_scores(Sm, acc[0], g.alpha);
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t sd = g.thresh ? *seed : 0u;
+    for (int i = wave; i < kR; i += kNW) {
+        float* srow = Sm + i * kSP;
+        float v[3];
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int j = lane + 64 * q;
+            v[q] = j < g.T ? srow[j] : -3.0e38f;
+            mx = fmaxf(mx, v[q]);
+        }
+        mx = wave_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int j = lane + 64 * q;
+            v[q] = j < g.T ? expf(v[q] - mx) : 0.f;
+            sum += v[q];
+        }
+        sum = wave_sum(sum);
+        const float inv = 1.0f / sum;
+        const int row = row0 + i;
+        const uint32_t base = (uint32_t)(((long)bh * g.T + row) * g.Tp);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int j = lane + 64 * q;
+            float p = v[q] * inv;
+            if (g.thresh) p = dropout_keep(sd, g.site, base + (uint32_t)j, g.thresh) ? p * g.keep_scale : 0.f;
+            srow[j] = j < g.T ? p : 0.f;
+        }
+        if (lane == 0 && row < g.T) lse[(long)bh * g.T + row] = mx + logf(sum);
+    }
+    __syncthreads();
+    phase_b(Sm, vp, ld3, g.T, g.hs, U, y + (long)b * g.T * g.C + (long)h * g.hs, g.C, row0, 1.f);
+}
+
+// rows = queries: dQ, and D_i = sum_j dP_ij P_ij for the dkv kernel
+__global__ void __launch_bounds__(kNT, 2) attention_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ dy, const float* __restrict__ lse,
+                                                                  float* __restrict__ dqkv, float* __restrict__ dsum, AtGeom g,
+                                                                  const uint32_t* __restrict__ seed) {
+    __shared__ __attribute__((aligned(16))) float smem[kSmem];
+    float* S0 = smem;
+    float* S1 = smem + kR * kSP;
+    float* U = smem + 2 * kR * kSP;
+    const int bh = blockIdx.y, b = bh / g.nh, h = bh - b * g.nh, row0 = blockIdx.x * kR;
+    const long ld3 = 3L * g.C;
+    const float* kp = qkv + (long)b * g.T * ld3 + (long)h * g.hs;
+    const float* qp = kp + g.C;
+    const float* vp = kp + 2 * g.C;
+    const float* dyp = dy + (long)b * g.T * g.C + (long)h * g.hs;
+    f32x16 acc[2];
+    const float* const rs[2] = {qp, dyp};
+    const float* const cs[2] = {kp, vp};
+    const long rl[2] = {ld3, (long)g.C}, cl[2] = {ld3, ld3};
+    phase_a<2>(acc, rs, rl, cs, cl, row0, g.T, g.hs, U);       // S = Q K^T, dPd = dY V^T
+    put_scores(S0, acc[0], g.alpha);
+    put_scores(S1, acc[1], 1.f);
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t sd = g.thresh ? *seed : 0u;
+    for (int i = wave; i < kR; i += kNW) {
+        const int row = row0 + i;
+        const float L = row < g.T ? lse[(long)bh * g.T + row] : 0.f;
+        const uint32_t base = (uint32_t)(((long)bh * g.T + row) * g.Tp);
+        float p[3], dp[3];
+        float dot = 0.f;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int j = lane + 64 * q;
+            const bool ok = j < g.T;
+            p[q] = ok ? expf(S0[i * kSP + j] - L) : 0.f;
+            dp[q] = ok ? S1[i * kSP + j] : 0.f;
+            if (g.thresh) dp[q] = (ok && dropout_keep(sd, g.site, base + (uint32_t)j, g.thresh)) ? dp[q] * g.keep_scale : 0.f;
+            dot += p[q] * dp[q];
+        }
+        dot = wave_sum(dot);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) S0[i * kSP + lane + 64 * q] = p[q] * (dp[q] - dot);
+        if (lane == 0 && row < g.T) dsum[(long)bh * g.T + row] = dot;
+    }
+    __syncthreads();
+    phase_b(S0, kp, ld3, g.T, g.hs, U, dqkv + (long)b * g.T * ld3 + g.C + (long)h * g.hs, ld3, row0, g.alpha);      // dQ = dS K / sqrt(hs)
+}
+
+// rows = keys: dK, dV
+__global__ void __launch_bounds__(kNT, 2) attention_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ dy, const float* __restrict__ lse,
+                                                                   const float* __restrict__ dsum, float* __restrict__ dqkv, AtGeom g,
+                                                                   const uint32_t* __restrict__ seed) {
+    __shared__ __attribute__((aligned(16))) float smem[kSmem];
+    float* S0 = smem;
+    float* S1 = smem + kR * kSP;
+    float* U = smem + 2 * kR * kSP;
+    const int bh = blockIdx.y, b = bh / g.nh, h = bh - b * g.nh, row0 = blockIdx.x * kR;
+    const long ld3 = 3L * g.C;
+    const float* kp = qkv + (long)b * g.T * ld3 + (long)h * g.hs;
+    const float* qp = kp + g.C;
+    const float* vp = kp + 2 * g.C;
+    const float* dyp = dy + (long)b * g.T * g.C + (long)h * g.hs;
+    f32x16 acc[2];
+    const float* const rs[2] = {kp, vp};
+    const float* const cs[2] = {qp, dyp};
+    const long rl[2] = {ld3, ld3}, cl[2] = {ld3, (long)g.C};
+    phase_a<2>(acc, rs, rl, cs, cl, row0, g.T, g.hs, U);       // S^T = K Q^T, dPd^T = V dY^T
+    put_scores(S0, acc[0], g.alpha);
+    put_scores(S1, acc[1], 1.f);
+    __syncthreads();
+    const uint32_t sd = g.thresh ? *seed : 0u;
+    const float* Lp = lse + (long)bh * g.T;
+    const float* Dp = dsum + (long)bh * g.T;
+    for (int idx = threadIdx.x; idx < kR * kNC; idx += kNT) {
+        const int jj = idx / kNC, i = idx - jj * kNC;           // key row0 + jj (tile row), query i (column)
+        float ds = 0.f, pd = 0.f;
+        if (i < g.T) {
+            const float p = expf(S0[jj * kSP + i] - Lp[i]);
+            float dp = S1[jj * kSP + i];
+            pd = p;
+            if (g.thresh) {
+                const bool keep = dropout_keep(sd, g.site, (uint32_t)(((long)bh * g.T + i) * g.Tp + row0 + jj), g.thresh);
+                dp = keep ? dp * g.keep_scale : 0.f;
+                pd = keep ? p * g.keep_scale : 0.f;
+            }
+            ds = p * (dp - Dp[i]);
+        }
+        S0[jj * kSP + i] = ds;
+        S1[jj * kSP + i] = pd;
+    }
+    __syncthreads();
+    float* dk = dqkv + (long)b * g.T * ld3 + (long)h * g.hs;
+    phase_b(S0, qp, ld3, g.T, g.hs, U, dk, ld3, row0, g.alpha);                 // dK = dS^T Q / sqrt(hs)
+    phase_b(S1, dyp, g.C, g.T, g.hs, U, dk + 2 * g.C, ld3, row0, 1.f);          // dV = Pd^T dY
+}
+
+inline int make_geom(AtGeom& g, int B, int T, int C, int nh, uint32_t site, float pdrop, const char* who) {
+    TF_REQUIRE(B > 0 && T > 0 && T <= kNC && nh > 0 && C % nh == 0 && C / nh <= kHS, "%s: needs T <= %d and head size <= %d (got T=%d, hs=%d)", who, kNC, kHS, T,
+               nh > 0 ? C / nh : -1);
+    TF_REQUIRE(pdrop >= 0.f && pdrop < 1.f && (long)B * nh * T * ((T + 3) / 4 * 4) < (1L << 32), "%s: bad dropout probability / index range", who);
+    g.B = B; g.nh = nh; g.T = T; g.hs = C / nh; g.C = C; g.Tp = (T + 3) / 4 * 4;
+    g.alpha = 1.0f / sqrtf((float)g.hs);
+    g.site = site;
+    g.thresh = (uint32_t)((double)pdrop * 4294967296.0);
+    g.keep_scale = 1.f / (1.f - pdrop);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int tf_attention_supported(int T, int C, int nh) { return (T > 0 && T <= kNC && nh > 0 && C % nh == 0 && C / nh <= kHS) ? 1 : 0; }
+
+extern "C" int tf_attention_fwd_f32(const float* qkv, float* y, float* lse, int B, int T, int C, int nh, const uint32_t* seed_dev, uint32_t site, float pdrop,
+                                    void* stream) {
+    TF_REQUIRE(qkv && y && lse && (pdrop == 0.f || seed_dev), "tf_attention_fwd_f32: null argument");
+    AtGeom g;
+    if (int e = make_geom(g, B, T, C, nh, site, pdrop, "tf_attention_fwd_f32")) return e;
+    TF_LAUNCH(attention_fwd_kernel, dim3(cdiv(T, kR), B * nh), dim3(kNT), stream, qkv, y, lse, g, seed_dev);
+    return launch_status("tf_attention_fwd_f32");
+}
+
+extern "C" int tf_attention_bwd_f32(const float* qkv, const float* dy, const float* lse, float* dqkv, float* dsum, int B, int T, int C, int nh,
+                                    const uint32_t* seed_dev, uint32_t site, float pdrop, void* stream) {
+    TF_REQUIRE(qkv && dy && lse && dqkv && dsum && (pdrop == 0.f || seed_dev), "tf_attention_bwd_f32: null argument");
+    AtGeom g;
+    if (int e = make_geom(g, B, T, C, nh, site, pdrop, "tf_attention_bwd_f32")) return e;
+    TF_LAUNCH(attention_bwd_dq_kernel, dim3(cdiv(T, kR), B * nh), dim3(kNT), stream, qkv, dy, lse, dqkv, dsum, g, seed_dev);
+    TF_LAUNCH(attention_bwd_dkv_kernel, dim3(cdiv(T, kR), B * nh), dim3(kNT), stream, qkv, dy, lse, (const float*)dsum, dqkv, g, seed_dev);
+    return launch_status("tf_attention_bwd_f32");
+}

@@ -63,9 +63,13 @@ __device__ __forceinline__ void store_patch_slot(float* patch, int s, const floa
 
 // y[.., g*24 + co] = sum_{tap, ci} x[.. + tap, g*24 + ci] * W  (+ bias) (relu) (+= when accumulate); dgrad != 0: x is dY, y is dX
 // X3 = the bf16x3-split instantiation (tf_set_precision(2)); the default binary holds the fp32 path and the runtime-selected bf16 path
-template <int TW, bool X3 = false>
+// STAT: the forward also produces the BatchNorm statistics of its output (timm ConvBnAct: conv2 is followed by BatchNormAct2d): every wave
+// keeps a running Welford triple (n, mean, M2) per channel over the tiles it computes, the block's 4 waves are merged through LDS at
+// the end and ONE triple per (block, channel) goes to stat[(sub * 3 + {0,1,2}) * C + channel] - plain stores, nb parts per channel.
+template <int TW, bool X3 = false, bool STAT = false>
 __global__ void __launch_bounds__(256, 2) conv3x3_grouped_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-                                                                 float* __restrict__ y, GcGeom g, int dgrad, int relu, int accumulate, int prec) {
+                                                                 float* __restrict__ y, GcGeom g, int dgrad, int relu, int accumulate, int prec,
+                                                                 float* __restrict__ stat = nullptr) {
     typedef Tile<TW> T;
     __shared__ float patch[T::NPIX * PP];
     __shared__ float wl[9 * CG][WP];
@@ -83,6 +87,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_grouped_kernel(const float* __
     if (tile < g.ntiles) fetch(tile);
     // this lane's pixel inside the wave's 32: (row, col) of the tile
     const int prow = wave * T::RW + l31 / TW, pcol = l31 % TW;
+    float st_n = 0.f, st_mean = 0.f, st_m2 = 0.f;      // STAT: running triple of channel l31 over this wave's pixels (same in both lane halves)
     for (; tile < g.ntiles; tile += g.nb) {
         __syncthreads();                           // previous tile's MFMAs are done with the patch (and the weights are staged)
 #pragma unroll
@@ -138,6 +143,55 @@ __global__ void __launch_bounds__(256, 2) conv3x3_grouped_kernel(const float* __
                     *dst = accumulate ? *dst + v : v;
                 }
             }
+        }
+        if constexpr (STAT) {       // all 64 lanes take part in the shuffles; the padding columns (l31 >= 24) carry zeros and are never stored
+            float s = 0.f, cnt = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int i = (e & 3) + 8 * (e >> 2) + 4 * hi;
+                const bool ok = (h0 + wave * T::RW + i / TW) < g.H && (w0 + i % TW) < g.W;
+                s += ok ? acc[e] : 0.f;
+                cnt += ok ? 1.f : 0.f;
+            }
+            s += shfl_xor(s, 32);
+            cnt += shfl_xor(cnt, 32);
+            if (cnt > 0.f) {                                             // wave-uniform (pixel validity does not depend on the channel)
+                const float m_t = s / cnt;
+                float q = 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int i = (e & 3) + 8 * (e >> 2) + 4 * hi;
+                    const bool ok = (h0 + wave * T::RW + i / TW) < g.H && (w0 + i % TW) < g.W;
+                    const float d = acc[e] - m_t;
+                    q += ok ? d * d : 0.f;
+                }
+                q += shfl_xor(q, 32);
+                const float n_new = st_n + cnt, delta = m_t - st_mean;       // Chan's pairwise merge of (st_n, st_mean, st_m2) and (cnt, m_t, q)
+                st_mean += delta * (cnt / n_new);
+                st_m2 += q + delta * delta * (st_n * cnt / n_new);
+                st_n = n_new;
+            }
+        }
+    }
+    if constexpr (STAT) {
+        __syncthreads();                                                 // every wave is done with the patch: its memory carries the 4 triples
+        float* red = patch;                                              // [wave][3][32]
+        if (hi == 0) { red[(wave * 3 + 0) * 32 + l31] = st_n; red[(wave * 3 + 1) * 32 + l31] = st_mean; red[(wave * 3 + 2) * 32 + l31] = st_m2; }
+        __syncthreads();
+        if (tid < CG) {
+            float n = 0.f, mean = 0.f, m2 = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < 4; ++wv) {
+                const float nb_ = red[(wv * 3 + 0) * 32 + tid], mb = red[(wv * 3 + 1) * 32 + tid], qb = red[(wv * 3 + 2) * 32 + tid];
+                if (nb_ > 0.f) {
+                    const float n_new = n + nb_, delta = mb - mean;
+                    mean += delta * (nb_ / n_new);
+                    m2 += qb + delta * delta * (n * nb_ / n_new);
+                    n = n_new;
+                }
+            }
+            float* o = stat + (long)sub * 3 * g.C + coff + tid;
+            o[0] = n; o[g.C] = mean; o[2 * (long)g.C] = m2;
         }
     }
 }
@@ -299,11 +353,29 @@ extern "C" int tf_conv3x3_grouped_fwd_f32(const float* x, const float* w, const 
     GcGeom g = make_geom(B, H, W, C, tw);
     const int prec = fwd_prec();
     if (prec == 2) {
-        if (tw == 16) TF_LAUNCH((conv3x3_grouped_kernel<16, true>), dim3(g.G * g.nb), dim3(256), stream, x, w, bias, y, g, 0, relu, 0, 2);
-        else TF_LAUNCH((conv3x3_grouped_kernel<32, true>), dim3(g.G * g.nb), dim3(256), stream, x, w, bias, y, g, 0, relu, 0, 2);
-    } else if (tw == 16) TF_LAUNCH((conv3x3_grouped_kernel<16, false>), dim3(g.G * g.nb), dim3(256), stream, x, w, bias, y, g, 0, relu, 0, prec);
-    else TF_LAUNCH((conv3x3_grouped_kernel<32, false>), dim3(g.G * g.nb), dim3(256), stream, x, w, bias, y, g, 0, relu, 0, prec);
+        if (tw == 16) TF_LAUNCH((conv3x3_grouped_kernel<16, true>), dim3(g.G * g.nb), dim3(256), stream, x, w, bias, y, g, 0, relu, 0, 2, (float*)nullptr);
+        else TF_LAUNCH((conv3x3_grouped_kernel<32, true>), dim3(g.G * g.nb), dim3(256), stream, x, w, bias, y, g, 0, relu, 0, 2, (float*)nullptr);
+    } else if (tw == 16) TF_LAUNCH((conv3x3_grouped_kernel<16, false>), dim3(g.G * g.nb), dim3(256), stream, x, w, bias, y, g, 0, relu, 0, prec, (float*)nullptr);
+    else TF_LAUNCH((conv3x3_grouped_kernel<32, false>), dim3(g.G * g.nb), dim3(256), stream, x, w, bias, y, g, 0, relu, 0, prec, (float*)nullptr);
     return launch_status("tf_conv3x3_grouped_fwd_f32");
+}
+
+extern "C" int tf_conv3x3_grouped_colstat_parts(void) { return kMaxBlocks; }
+
+extern "C" int tf_conv3x3_grouped_fwd_colstat_f32(const float* x, const float* w, float* y, int B, int H, int W, int C, float* colstat, int* colstat_nparts,
+                                                  void* stream) {
+    TF_REQUIRE(args_ok(x, w, y, B, H, W, C) && colstat && colstat_nparts, "tf_conv3x3_grouped_fwd_colstat_f32: needs NHWC tensors with C %% 24 == 0, colstat and colstat_nparts");
+    const int tw = pick_tw(H, W);
+    GcGeom g = make_geom(B, H, W, C, tw);
+    const int prec = fwd_prec();
+    const float* nob = nullptr;
+    *colstat_nparts = g.nb;
+    if (prec == 2) {
+        if (tw == 16) TF_LAUNCH((conv3x3_grouped_kernel<16, true, true>), dim3(g.G * g.nb), dim3(256), stream, x, w, nob, y, g, 0, 0, 0, 2, colstat);
+        else TF_LAUNCH((conv3x3_grouped_kernel<32, true, true>), dim3(g.G * g.nb), dim3(256), stream, x, w, nob, y, g, 0, 0, 0, 2, colstat);
+    } else if (tw == 16) TF_LAUNCH((conv3x3_grouped_kernel<16, false, true>), dim3(g.G * g.nb), dim3(256), stream, x, w, nob, y, g, 0, 0, 0, prec, colstat);
+    else TF_LAUNCH((conv3x3_grouped_kernel<32, false, true>), dim3(g.G * g.nb), dim3(256), stream, x, w, nob, y, g, 0, 0, 0, prec, colstat);
+    return launch_status("tf_conv3x3_grouped_fwd_colstat_f32");
 }
 
 extern "C" int tf_conv3x3_grouped_dgrad_f32(const float* dy, const float* w, float* dx, int B, int H, int W, int C, int accumulate, void* stream) {
@@ -313,10 +385,10 @@ extern "C" int tf_conv3x3_grouped_dgrad_f32(const float* dy, const float* w, flo
     const int prec = fwd_prec();
     const float* nob = nullptr;
     if (prec == 2) {
-        if (tw == 16) TF_LAUNCH((conv3x3_grouped_kernel<16, true>), dim3(g.G * g.nb), dim3(256), stream, dy, w, nob, dx, g, 1, 0, accumulate, 2);
-        else TF_LAUNCH((conv3x3_grouped_kernel<32, true>), dim3(g.G * g.nb), dim3(256), stream, dy, w, nob, dx, g, 1, 0, accumulate, 2);
-    } else if (tw == 16) TF_LAUNCH((conv3x3_grouped_kernel<16, false>), dim3(g.G * g.nb), dim3(256), stream, dy, w, nob, dx, g, 1, 0, accumulate, prec);
-    else TF_LAUNCH((conv3x3_grouped_kernel<32, false>), dim3(g.G * g.nb), dim3(256), stream, dy, w, nob, dx, g, 1, 0, accumulate, prec);
+        if (tw == 16) TF_LAUNCH((conv3x3_grouped_kernel<16, true>), dim3(g.G * g.nb), dim3(256), stream, dy, w, nob, dx, g, 1, 0, accumulate, 2, (float*)nullptr);
+        else TF_LAUNCH((conv3x3_grouped_kernel<32, true>), dim3(g.G * g.nb), dim3(256), stream, dy, w, nob, dx, g, 1, 0, accumulate, 2, (float*)nullptr);
+    } else if (tw == 16) TF_LAUNCH((conv3x3_grouped_kernel<16, false>), dim3(g.G * g.nb), dim3(256), stream, dy, w, nob, dx, g, 1, 0, accumulate, prec, (float*)nullptr);
+    else TF_LAUNCH((conv3x3_grouped_kernel<32, false>), dim3(g.G * g.nb), dim3(256), stream, dy, w, nob, dx, g, 1, 0, accumulate, prec, (float*)nullptr);
     return launch_status("tf_conv3x3_grouped_dgrad_f32");
 }
 

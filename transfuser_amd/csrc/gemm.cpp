@@ -44,7 +44,7 @@ extern "C" int tf_gemm_f32(const tf_gemm_desc* d, void* stream) {
                d->k, d->batch);
     const int inner = d->inner > 0 ? d->inner : 1;
     // per-sample matmuls (SE excitation, join MLP): rows = batch <= 16 -> streaming kernels instead of a 128-row MFMA tile
-    if (d->batch == 1 && d->alpha == 1.0f && d->m > 0 && d->n > 0 && d->k > 0 && !d->mask) {
+    if (d->batch == 1 && d->alpha == 1.0f && d->m > 0 && d->n > 0 && d->k > 0 && !d->mask && !d->colstat) {
         if (!d->a_trans && !d->b_trans && d->m <= 16 && !d->accumulate)
             return smallm_fwd(d->a, d->lda, d->b, d->ldb, d->bias, d->res, d->ldres, d->c, d->ldc, d->m, d->n, d->k, d->relu, stream);
         if (!d->a_trans && d->b_trans && d->m <= 16 && !d->bias && !d->relu && !(d->accumulate && d->res))
@@ -58,6 +58,12 @@ extern "C" int tf_gemm_f32(const tf_gemm_desc* d, void* stream) {
     ep.mode = d->accumulate ? 1 : 0;
     ep.mask = d->mask; ep.ldmask = d->ldmask;
     ep.sk_ws = d->splitk_ws; ep.sk_ws_floats = d->splitk_ws ? d->splitk_ws_floats : 0;
+    if (d->colstat) {
+        TF_REQUIRE(d->colstat_nparts && d->batch == 1 && !d->accumulate && !d->res && !d->relu && !d->mask && !d->a_trans,
+                   "tf_gemm_f32: colstat needs a plain store (batch 1, no residual / ReLU / mask / accumulate), row-major A and colstat_nparts");
+        ep.stat = d->colstat; ep.stat_ld = d->n; ep.stat_nparts = d->colstat_nparts;
+        *d->colstat_nparts = 0;
+    }
     TF_REQUIRE(!d->mask || (d->batch == 1 && !d->accumulate), "tf_gemm_f32: mask needs batch == 1 and a plain store");
     // A: KC when stored [m][k] (rows = i), IC when stored [k][m] (rows = k)
     PlainOp A = d->a_trans ? make_plain(d->a, d->lda, d->k, d->m, d->sa_outer, d->sa_inner, inner, d->batch)

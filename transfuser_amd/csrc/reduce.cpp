@@ -210,6 +210,49 @@ __global__ void __launch_bounds__(256) bn_fwd_finalize_kernel(const float* __res
         rvar[c] = (1.f - momentum) * rvar[c] + momentum * unb;
     }
 }
+// The same from per-part Welford triples written by the PRODUCING convolution's epilogue (tf_gemm_desc.colstat, tf_conv*_colstat_f32):
+// parts[(p * 3 + {0: count, 1: mean, 2: M2}) * C + c].  One wave per channel: lanes stride over the parts, first the count-weighted mean, then
+// M2 = sum_p M2_p + n_p (mean_p - mean)^2 (Chan et al.) - no cancellation, whatever the mean / spread ratio of the activations.
+__global__ void __launch_bounds__(256) bn_fwd_finalize_parts_kernel(const float* __restrict__ parts, int nparts, const float* __restrict__ gamma,
+                                                                    const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
+                                                                    float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                                                    float* __restrict__ coef, int C, float n, float momentum, float eps) {
+    const int c0 = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const bool live = c0 < C;
+    const int c = live ? c0 : 0;
+    const long ps = 3L * C;
+    float sn = 0.f, sm = 0.f;
+    if (live)
+        for (int p = lane; p < nparts; p += 64) {
+            const float np = parts[p * ps + c];
+            sn += np;
+            sm += np * parts[p * ps + C + c];
+        }
+    sn = wave_sum(sn);
+    sm = wave_sum(sm);
+    const float mean = sn > 0.f ? sm / sn : 0.f;
+    float m2 = 0.f;
+    if (live)
+        for (int p = lane; p < nparts; p += 64) {
+            const float np = parts[p * ps + c], d = parts[p * ps + C + c] - mean;
+            m2 += parts[p * ps + 2L * C + c] + np * d * d;
+        }
+    m2 = wave_sum(m2);
+    if (!live || lane != 0) return;
+    float var = m2 / n;
+    if (var < 0.f) var = 0.f;
+    const float invstd = 1.0f / sqrtf(var + eps);
+    save_mean[c] = mean;
+    save_invstd[c] = invstd;
+    const float sc = gamma[c] * invstd;
+    coef[c] = sc;
+    coef[C + c] = beta[c] - mean * sc;
+    if (rmean) {
+        rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+        const float unb = (n > 1.f) ? var * (n / (n - 1.f)) : var;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * unb;
+    }
+}
 __global__ void bn_eval_coef_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ rmean,
                                     const float* __restrict__ rvar, float* __restrict__ coef, int C, float eps) {
     const int c = blockIdx.x * 256 + threadIdx.x;
@@ -471,6 +514,22 @@ extern "C" int tf_bn_fwd_f32(const float* x, int rows, int C, const float* gamma
     if (v4) TF_LAUNCH(bn_apply_kernel<4>, dim3(ew_blocks(n / 4)), dim3(256), stream, x, (const float*)coef, res, y, n / 4, C, relu);
     else TF_LAUNCH(bn_apply_kernel<1>, dim3(ew_blocks(n)), dim3(256), stream, x, (const float*)coef, res, y, n, C, relu);
     return launch_status("tf_bn_fwd_f32");
+}
+
+// Train-mode BatchNorm2d forward when the statistics of x were already gathered by the kernel that PRODUCED x (per-part Welford triples,
+// see bn_fwd_finalize_parts_kernel): finalize + apply, no pass over x for the moments.  y = bn(x) (+res) (relu).
+extern "C" int tf_bn_fwd_parts_f32(const float* x, int rows, int C, const float* parts, int nparts, const float* gamma, const float* beta,
+                                   float* running_mean, float* running_var, float momentum, float eps, const float* res, int relu, float* y,
+                                   float* save_mean, float* save_invstd, float* ws, void* stream) {
+    TF_REQUIRE(x && parts && nparts > 0 && gamma && beta && y && save_mean && save_invstd && ws && rows > 0 && C > 0, "tf_bn_fwd_parts_f32: bad arguments");
+    float* coef = ws + kWsFloats / 2;
+    TF_LAUNCH(bn_fwd_finalize_parts_kernel, dim3(cdiv(C, 4)), dim3(256), stream, parts, nparts, gamma, beta, running_mean, running_var, save_mean,
+              save_invstd, coef, C, (float)rows, momentum, eps);
+    const bool v4 = (C % 4 == 0) && aligned16(x) && aligned16(y) && (!res || aligned16(res));
+    const long n = (long)rows * C;
+    if (v4) TF_LAUNCH(bn_apply_kernel<4>, dim3(ew_blocks(n / 4)), dim3(256), stream, x, (const float*)coef, res, y, n / 4, C, relu);
+    else TF_LAUNCH(bn_apply_kernel<1>, dim3(ew_blocks(n)), dim3(256), stream, x, (const float*)coef, res, y, n, C, relu);
+    return launch_status("tf_bn_fwd_parts_f32");
 }
 
 // BatchNorm2d backward (training statistics).  dz: grad of the (post-residual, post-ReLU) output;

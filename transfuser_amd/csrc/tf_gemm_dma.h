@@ -330,6 +330,8 @@ inline void launch_dma_cfg(const PlainOp& la, const PlainOp& lb, const GemmEpi& 
         if (g > tiles_m) g = tiles_m;
         epg.group_m = (g >= 2 && tiles_n >= 4) ? g : 1;
     }
+    if (twopass || nsplit > 1) epg.stat = nullptr;          // (launch_gemm never sends a statistics request down a k-split plan)
+    if (epg.stat_nparts) *epg.stat_nparts = epg.stat ? cdiv(M, 32 * TM) : 0;
     if (epg.prec == 2)
         TF_LAUNCH((gemm_dma_kernel<TM, TN, WAVES_M, WAVES_N, BK, STAGES, A_KC, B_KC, OCC, true>), grid, dim3(C::NT), stream, la, lb, epg, M, N, K,
                   tiles_m, tiles_n, kchunk);

@@ -245,6 +245,12 @@ struct GemmEpi {
     const float* mask = nullptr; long ldmask = 0;   // optional ReLU mask of a backward GEMM: element (i, j) is zeroed unless mask(i, j) > 0
     long sk_stride = 0;              // two-pass split-K: k-slice blockIdx.y stores its partial tile at C + blockIdx.y * sk_stride (LDS-DMA kernels)
     float* sk_ws = nullptr; long sk_ws_floats = 0;   // host side only: caller-owned scratch that makes the two-pass split-K eligible (tf_gemm_desc)
+    // BatchNorm statistics of the OUTPUT, fused into the epilogue (train-mode BN behind a bias-free conv, timm BatchNormAct2d via
+    // transfuser.py:380,442): every wave writes, for each of its columns, the Welford triple (n, mean, M2) of the rows it owns into
+    // stat[(part * 3 + {0,1,2}) * stat_ld + column], part = first row / rows per wave - plain stores, no atomics; a finalize kernel
+    // merges the parts (Chan's formula).  Only for plain stores (mode 0, no residual / ReLU / mask / split-K).  stat_nparts: HOST pointer,
+    // set at launch time to the number of parts this launch writes (0: the chosen plan cannot produce them - caller falls back).
+    float* stat = nullptr; long stat_ld = 0; int* stat_nparts = nullptr;
     int prec = 0;                    // 0: exact fp32 MFMA; 1: operands rounded to bf16 on the LDS->register path, bf16 MFMA, fp32 accumulate; 2: bf16x3 split (fp32-accurate, 6 bf16 MFMAs) (set by launch_cfg)
 };
 
@@ -297,6 +303,46 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[TM][TN], const
     if (ep.mode == 0) by_res(std::integral_constant<int, 0>());
     else if (ep.mode == 1) by_res(std::integral_constant<int, 1>());
     else by_res(std::integral_constant<int, 2>());
+    if (ep.stat) {      // wave-uniform: column statistics of the stored values over this wave's 32 * TM rows
+        constexpr int WMR = 32 * TM;
+        const int r0 = i0 + wm0;
+        int nrow = M - r0;
+        nrow = nrow < 0 ? 0 : (nrow > WMR ? WMR : nrow);
+        if (nrow > 0) {
+            const int part = r0 / WMR;
+            const float inv_n = 1.0f / (float)nrow;
+#pragma unroll
+            for (int u = 0; u < TN; ++u) {
+                const int j = j0 + wn0 + u * 32 + l31;
+                const bool jok = j < N;
+                const float bj = (bias && jok) ? bias[j] : 0.f;
+                float s = 0.f;
+#pragma unroll
+                for (int t = 0; t < TM; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int i = r0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        s += (i < M) ? ep.alpha * acc[t][u][r] + bj : 0.f;
+                    }
+                s += shfl_xor(s, 32);
+                const float mean = s * inv_n;
+                float q = 0.f;
+#pragma unroll
+                for (int t = 0; t < TM; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int i = r0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        const float d = (ep.alpha * acc[t][u][r] + bj) - mean;
+                        q += (i < M) ? d * d : 0.f;
+                    }
+                q += shfl_xor(q, 32);
+                if (hi == 0 && jok) {
+                    float* st = ep.stat + (long)part * 3 * ep.stat_ld + cz + j;
+                    st[0] = (float)nrow; st[ep.stat_ld] = mean; st[2 * ep.stat_ld] = q;
+                }
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------- kernel
@@ -714,6 +760,7 @@ inline void launch_cfg(const LA& la, const LB& lb, const GemmEpi& ep, int M, int
         if (g > tiles_m) g = tiles_m;
         epg.group_m = (g >= 2 && tiles_n >= 4) ? g : 1;
     }
+    if (epg.stat_nparts) *epg.stat_nparts = epg.stat ? cdiv(M, BM / WAVES_M) : 0;
     if (la.vec && lb.vec)
         TF_LAUNCH((gemm_kernel<BM, BN, WAVES_M, BK, LA, A_KC, LB, B_KC, true, NT, PF>), grid, dim3(NT), stream, la, lb, epg, M, N, K, tiles_m, tiles_n, kchunk);
     else
@@ -875,6 +922,14 @@ inline int launch_gemm(const LA& la, const LB& lb, GemmEpi ep, int M, int N, int
         } else
 #endif
             p = plan_gemm(M, N, K, batch, sk_ok);
+    }
+    if (ep.stat) {
+        // fused output statistics need the whole reduction in one block: no k-split.  A cached two-pass plan keeps its speed and reports
+        // "no statistics" (nparts 0): the caller runs its separate reduction for this (rare: <= 256-tile) output
+        if (p.splitk >= kTwoPass && p.kind >= 1 && twopass_ok(ep, M, N, batch, p.splitk - kTwoPass)) ep.stat = nullptr;
+        else if (p.splitk > 1) p.splitk = 1;
+        if (ep.mode != 0 || ep.res || ep.relu || ep.mask) ep.stat = nullptr;
+        if (!ep.stat && ep.stat_nparts) *ep.stat_nparts = 0;
     }
     if (p.splitk >= kTwoPass) {
         if (p.kind < 1 || !twopass_ok(ep, M, N, batch, p.splitk - kTwoPass)) p.splitk = 1;     // no scratch on this call / not a plain output

@@ -87,7 +87,8 @@ def bias_grad(dy2d, b, mask2d=None):
     ops.colsum(dy2d, 1, dy2d.shape[0], dy2d.shape[1], 1.0, mask=mask2d, out=gbuf(b).view(1, -1), accumulate=True)
 
 
-def _bn(x, bn, res=None, relu=False):
+def _bn(x, bn, res=None, relu=False, stat=None):
+    """``stat``: ops.ColStat gathered by the epilogue of the kernel that produced x (train mode, local statistics only)."""
     grp = getattr(bn, "_sync_group", None)
     if grp is None and isinstance(bn, torch.nn.SyncBatchNorm) and bn.training:     # torch.nn.SyncBatchNorm.convert_sync_batchnorm(model) (train.py:133)
         import torch.distributed as dist
@@ -95,6 +96,9 @@ def _bn(x, bn, res=None, relu=False):
             grp = bn.process_group if bn.process_group is not None else dist.group.WORLD
     if grp is not None and bn.training:
         return _bn_sync_fwd(x, bn, res, relu, grp)
+    if stat is not None and bn.training:
+        y, sm, si = ops.bn_fwd_parts(x, stat, bn.weight, bn.bias, bn.running_mean, bn.running_var, res, relu, bn.momentum, bn.eps)
+        return y, (sm, si)
     y, sm, si = ops.bn_fwd(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, res, relu, bn.training, bn.momentum, bn.eps)
     return y, (sm, si)
 
@@ -179,6 +183,9 @@ class StemFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dz):
+        if ctx.saved is None:
+            raise RuntimeError("StemFn: trying to backward through the graph a second time: the saved activations are freed by the first backward "
+                               "(retain_graph is not supported by the block Functions)")
         s0, s1, stem, w, y, z, st = ctx.saved
         ctx.saved = None        # z is also this node's output: drop the ctx <-> output cycle now instead of waiting for the cyclic GC (~150 MB / step)
         dy, _ = _bn_bwd(dz.contiguous(), z, y, stem.bn, st)
@@ -197,10 +204,11 @@ class YBlockFn(torch.autograd.Function):
         B, H, W, Cin = x.shape
         C = blk.out_chs
         x2 = x.view(-1, Cin)
-        y1 = ops.linear_fwd(x2, w2d(blk.conv1.conv.weight)).view(B, H, W, C)
-        z1, st1 = _bn(y1, blk.conv1.bn, relu=True)
-        y2 = ops.conv_fwd(z1, blk.conv2.conv.weight, None, blk.stride, 1, blk.groups)
-        z2, st2 = _bn(y2, blk.conv2.bn, relu=True)
+        y1, cs1 = ops.linear_fwd(x2, w2d(blk.conv1.conv.weight), colstat=True)      # BN statistics gathered by the GEMM epilogue
+        y1 = y1.view(B, H, W, C)
+        z1, st1 = _bn(y1, blk.conv1.bn, relu=True, stat=cs1)
+        y2, cs2 = ops.conv_fwd(z1, blk.conv2.conv.weight, None, blk.stride, 1, blk.groups, colstat=True)
+        z2, st2 = _bn(y2, blk.conv2.bn, relu=True, stat=cs2)
         _, Ho, Wo, _ = y2.shape
         s = ops.colsum(z2, B, Ho * Wo, C, 1.0 / (Ho * Wo))
         if B <= 16:
@@ -209,22 +217,27 @@ class YBlockFn(torch.autograd.Function):
             g1 = ops.linear_fwd(s, w2d(blk.se.fc1.weight), blk.se.fc1.bias, relu=True)
             gate = ops.linear_fwd(g1, w2d(blk.se.fc2.weight), blk.se.fc2.bias)
         z2s = ops.se_scale_fwd(z2, gate)
-        y3 = ops.linear_fwd(z2s.view(-1, C), w2d(blk.conv3.conv.weight)).view(B, Ho, Wo, C)
+        y3, cs3 = ops.linear_fwd(z2s.view(-1, C), w2d(blk.conv3.conv.weight), colstat=True)
+        y3 = y3.view(B, Ho, Wo, C)
         yd = std = None
         if blk.downsample is not None:
             if blk.stride == 1:
-                yd = ops.linear_fwd(x2, w2d(blk.downsample.conv.weight)).view(B, H, W, C)
+                yd, csd = ops.linear_fwd(x2, w2d(blk.downsample.conv.weight), colstat=True)
+                yd = yd.view(B, H, W, C)
             else:
-                yd = ops.conv_fwd(x, blk.downsample.conv.weight, None, blk.stride, 0, 1)
-            sc, std = _bn(yd, blk.downsample.bn, relu=False)
+                yd, csd = ops.conv_fwd(x, blk.downsample.conv.weight, None, blk.stride, 0, 1, colstat=True)
+            sc, std = _bn(yd, blk.downsample.bn, relu=False, stat=csd)
         else:
             sc = x
-        out, st3 = _bn(y3, blk.conv3.bn, res=sc, relu=True)
+        out, st3 = _bn(y3, blk.conv3.bn, res=sc, relu=True, stat=cs3)
         ctx.saved = (x, blk, y1, z1, st1, y2, z2, st2, s, g1, gate, z2s, y3, st3, yd, std, out)
         return out
 
     @staticmethod
     def backward(ctx, dout):
+        if ctx.saved is None:
+            raise RuntimeError("YBlockFn: trying to backward through the graph a second time: the saved activations are freed by the first backward "
+                               "(retain_graph is not supported by the block Functions)")
         x, blk, y1, z1, st1, y2, z2, st2, s, g1, gate, z2s, y3, st3, yd, std, out = ctx.saved
         B, H, W, Cin = x.shape
         _, Ho, Wo, C = out.shape
@@ -349,12 +362,18 @@ def _gpt_block_fwd(gpt, li, x, B, T, drop):
     else:
         for j, lin in enumerate((blk.attn.key, blk.attn.query, blk.attn.value)):
             ops.linear_fwd(h1, lin.weight, lin.bias, out=qkv[:, j * C:(j + 1) * C])
-    if drop and gpt.attn_pdrop > 0:
-        att, Tp, att_d = _attn_fwd(qkv, B, T, C, nh, drop=(gpt.seed, gpt.site(4 * li + 1), gpt.attn_pdrop))
+    adrop = (gpt.seed, gpt.site(4 * li + 1), gpt.attn_pdrop) if (drop and gpt.attn_pdrop > 0) else None
+    if ops.attention_supported(T, C, nh):
+        # one launch: QK^T -> softmax -> attn_drop -> PV per (sample, head, 32-query tile); only the row-wise log-sum-exp is kept
+        y_att, att = ops.attention_fwd(qkv, B, T, C, nh, adrop)
+        att_d, Tp = None, 0
+    elif adrop is not None:
+        att, Tp, att_d = _attn_fwd(qkv, B, T, C, nh, drop=adrop)
+        y_att = _attn_ctx(att_d, qkv, B, T, C, nh, Tp)
     else:
         att, Tp = _attn_fwd(qkv, B, T, C, nh)
         att_d = att
-    y_att = _attn_ctx(att_d, qkv, B, T, C, nh, Tp)
+        y_att = _attn_ctx(att_d, qkv, B, T, C, nh, Tp)
     if drop and gpt.resid_pdrop > 0:
         pr = ops.linear_fwd(y_att, blk.attn.proj.weight, blk.attn.proj.bias)
         x_mid = ops.dropout_add(pr, x, gpt.seed, gpt.site(4 * li + 2), gpt.resid_pdrop, out=pr)
@@ -397,21 +416,25 @@ def _gpt_block_bwd(gpt, li, saved, dx, B, T, drop):
     ops.linear_wgrad(dres, y_att, gbuf(proj.weight))
     bias_grad(dres, proj.bias)
     dy = ops.linear_dgrad(dres, proj.weight)
-    dqkv = torch.empty_like(qkv)
-    datt = torch.empty_like(att)
-    k, q, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
-    sq, sp, sy = (T * 3 * C, hs), (nh * T * Tp, T * Tp), (T * C, hs)
-    ops.gemm(dy, v, datt, T, T, hs, C, 3 * C, Tp, batch=B * nh, inner=nh, sa=sy, sb=sq, sc=sp)                       # dP = dY V^T
-    ops.gemm(att_d, dy, dqkv[:, 2 * C:], T, hs, T, Tp, C, 3 * C, a_trans=True, b_trans=True, batch=B * nh, inner=nh,
-             sa=sp, sb=sy, sc=sq)                                                                                     # dV = P^T dY
-    if drop and gpt.attn_pdrop > 0:
-        ops.softmax_dropout_bwd_(att, datt, B * nh * T, T, Tp, gpt.seed, gpt.site(4 * li + 1), gpt.attn_pdrop)
+    if att_d is None:       # fused attention: att is the log-sum-exp; probabilities are recomputed inside the two backward kernels
+        adrop = (gpt.seed, gpt.site(4 * li + 1), gpt.attn_pdrop) if (drop and gpt.attn_pdrop > 0) else None
+        dqkv = ops.attention_bwd(qkv, dy, att, B, T, C, nh, adrop)
     else:
-        ops.softmax_bwd_(att, datt, B * nh * T, T, Tp)
-    ops.gemm(datt, k, dqkv[:, C:2 * C], T, hs, T, Tp, 3 * C, 3 * C, b_trans=True, alpha=alpha, batch=B * nh, inner=nh,
-             sa=sp, sb=sq, sc=sq)                                                                                     # dQ = dS K
-    ops.gemm(datt, q, dqkv[:, :C], T, hs, T, Tp, 3 * C, 3 * C, a_trans=True, b_trans=True, alpha=alpha, batch=B * nh, inner=nh,
-             sa=sp, sb=sq, sc=sq)                                                                                     # dK = dS^T Q
+        dqkv = torch.empty_like(qkv)
+        datt = torch.empty_like(att)
+        k, q, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+        sq, sp, sy = (T * 3 * C, hs), (nh * T * Tp, T * Tp), (T * C, hs)
+        ops.gemm(dy, v, datt, T, T, hs, C, 3 * C, Tp, batch=B * nh, inner=nh, sa=sy, sb=sq, sc=sp)                       # dP = dY V^T
+        ops.gemm(att_d, dy, dqkv[:, 2 * C:], T, hs, T, Tp, C, 3 * C, a_trans=True, b_trans=True, batch=B * nh, inner=nh,
+                 sa=sp, sb=sy, sc=sq)                                                                                     # dV = P^T dY
+        if drop and gpt.attn_pdrop > 0:
+            ops.softmax_dropout_bwd_(att, datt, B * nh * T, T, Tp, gpt.seed, gpt.site(4 * li + 1), gpt.attn_pdrop)
+        else:
+            ops.softmax_bwd_(att, datt, B * nh * T, T, Tp)
+        ops.gemm(datt, k, dqkv[:, C:2 * C], T, hs, T, Tp, 3 * C, 3 * C, b_trans=True, alpha=alpha, batch=B * nh, inner=nh,
+                 sa=sp, sb=sq, sc=sq)                                                                                     # dQ = dS K
+        ops.gemm(datt, q, dqkv[:, :C], T, hs, T, Tp, 3 * C, 3 * C, a_trans=True, b_trans=True, alpha=alpha, batch=B * nh, inner=nh,
+                 sa=sp, sb=sq, sc=sq)                                                                                     # dK = dS^T Q
     fw = blk.attn.fused()
     if fw is not None:
         ops.linear_wgrad(dqkv, h1, fw[2])

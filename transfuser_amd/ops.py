@@ -182,7 +182,8 @@ def _ws_query():
 
 
 def gemm(a, b, c, m, n, k, lda, ldb, ldc, a_trans=False, b_trans=False, bias=None, res=None, ldres=0, alpha=1.0, relu=False,
-         accumulate=False, batch=1, inner=1, sa=(0, 0), sb=(0, 0), sc=(0, 0), mask=None):
+         accumulate=False, batch=1, inner=1, sa=(0, 0), sb=(0, 0), sc=(0, 0), mask=None, colstat=None):
+    """colstat: a ColStat request (see linear_fwd(..., colstat=True)): the epilogue also writes the BatchNorm statistics of the output."""
     if _CHECK and c.is_cuda:
         cview = lambda: torch.as_strided(c, (batch // inner, inner, m, n), (sc[0], sc[1], ldc, 1))
         old = cview().double().clone() if accumulate else None
@@ -193,6 +194,8 @@ def gemm(a, b, c, m, n, k, lda, ldb, ldc, a_trans=False, b_trans=False, bias=Non
                  lda=lda, ldb=ldb, ldc=ldc, ldres=ldres, batch=batch, inner=inner, sa_outer=sa[0], sa_inner=sa[1], sb_outer=sb[0],
                  sb_inner=sb[1], sc_outer=sc[0], sc_inner=sc[1], alpha=alpha, relu=int(relu), accumulate=int(accumulate), mask=ptr(mask),
                  ldmask=mask.stride(0) if mask is not None else 0, splitk_ws=c_p(0), splitk_ws_floats=0)
+    if colstat is not None:
+        d.colstat, d.colstat_nparts = ptr(colstat.buf), ctypes.pointer(colstat.nparts)
     skws = None
     if TWO_PASS_SPLITK and batch == 1 and k >= 512 and 128 * 128 <= m * n <= _TWO_PASS_MAX_ELEMS:
         need = _ws_query()(byref(d))          # > 0 only when the plan of THIS shape is a two-pass plan (or the autotuner wants to try one)
@@ -222,14 +225,42 @@ def gemm(a, b, c, m, n, k, lda, ldb, ldc, a_trans=False, b_trans=False, bias=Non
     return c
 
 
-def linear_fwd(x, w, bias=None, relu=False, res=None, out=None):
-    """y = x @ w.T + bias (+res) (relu); x (M, K) row-major (row stride may exceed K), w (N, K)."""
+# ---- BatchNorm statistics fused into the PRODUCING convolution (verdict r2 item 1).  The layers below a few ten-thousand rows (stages 2-4 of
+# both trunks: 120 of the 136 BatchNorm layers) are latency-, not bandwidth-bound: their separate moments pass is 6-12 us of launch + a
+# re-read of the conv output.  The epilogue of the producing GEMM / grouped convolution writes per-part Welford triples instead; larger maps
+# keep the streaming reduction (thousands of parts per channel would make the merge the slow part).
+FUSE_BN_STATS = os.environ.get("TF_FUSE_BN_STATS", "1") != "0"
+_COLSTAT_MAX_ROWS = 40000
+
+
+class ColStat:
+    """Per-part Welford triples [part][{count, mean, M2}][C] written by a producer's epilogue; ``nparts`` is filled in (on the host, at
+    launch time) by the C library: 0 = this launch could not produce them."""
+
+    def __init__(self, rows, C, device, max_parts=None):
+        self.nparts = ctypes.c_int(0)
+        self.rows, self.C = rows, C
+        self.buf = torch.empty(3 * C * (max_parts or (rows + 31) // 32), dtype=torch.float32, device=device)
+
+    def __bool__(self):
+        return self.nparts.value > 0
+
+
+def want_colstat(rows):
+    return FUSE_BN_STATS and rows <= _COLSTAT_MAX_ROWS
+
+
+def linear_fwd(x, w, bias=None, relu=False, res=None, out=None, colstat=False):
+    """y = x @ w.T + bias (+res) (relu); x (M, K) row-major (row stride may exceed K), w (N, K).
+    colstat=True: returns (y, ColStat) - the epilogue also gathers the BatchNorm statistics of y (None when not worthwhile / not possible)."""
     M, K = x.shape
     N = w.shape[0]
     if out is None:
         out = torch.empty(M, N, dtype=torch.float32, device=x.device)
-    return gemm(x, w, out, M, N, K, x.stride(0), w.stride(0), out.stride(0), bias=bias, res=res,
-                ldres=res.stride(0) if res is not None else 0, relu=relu)
+    cs = ColStat(M, N, x.device) if (colstat and want_colstat(M) and res is None and not relu) else None
+    y = gemm(x, w, out, M, N, K, x.stride(0), w.stride(0), out.stride(0), bias=bias, res=res,
+             ldres=res.stride(0) if res is not None else 0, relu=relu, colstat=cs)
+    return (y, cs if cs else None) if colstat else y
 
 
 def linear_dgrad(dy, w, out=None, accumulate=False, res=None, mask=None):
@@ -296,12 +327,29 @@ def _grouped_ws(device):
 _DIRECT_WGRAD_MAX_COUT = 32  # measured (tools/conv_bench.py): 421-425 us for every Cout at 256x704 vs 674-752 us through the engine's split-K path
 
 
-def conv_fwd(x, w, bias=None, stride=1, pad=None, groups=1, relu=False):
+def conv_fwd(x, w, bias=None, stride=1, pad=None, groups=1, relu=False, colstat=False):
+    """colstat=True (bias-free, no ReLU: a conv followed by BatchNorm): returns (y, ColStat or None), see linear_fwd."""
     ks = w.shape[2]
     pad = ks // 2 if pad is None else pad
     g = conv_geom(x.shape, w.shape[0], ks, stride, pad, groups)
     y = torch.empty(g.B, g.Ho, g.Wo, g.Cout, dtype=torch.float32, device=x.device)
     _e = _census_begin()
+    if colstat:
+        rows = g.B * g.Ho * g.Wo
+        cs = None
+        if want_colstat(rows) and bias is None and not relu and not _direct_ok(x.shape, g.Cout, g.Cin, ks, stride, pad, groups):
+            if _grouped_ok(x.shape, g.Cout, g.Cin, ks, stride, pad, groups):
+                cs = ColStat(rows, g.Cout, x.device, max_parts=L().tf_conv3x3_grouped_colstat_parts())
+                check(L().tf_conv3x3_grouped_fwd_colstat_f32(ptr(_c(x)), wptr(w), ptr(y), g.B, g.Hi, g.Wi, g.Cin, ptr(cs.buf), byref(cs.nparts), stream_of(x)),
+                      "tf_conv3x3_grouped_fwd_colstat_f32")
+                _census_end(_e, "conv fwd g", _gshape(g), _gflops(g))
+            else:
+                cs = ColStat(rows, g.Cout, x.device)
+                check(L().tf_conv2d_fwd_colstat_f32(byref(g), ptr(_c(x)), wptr(w), c_p(0), ptr(y), ptr(cs.buf), byref(cs.nparts), stream_of(x)),
+                      "tf_conv2d_fwd_colstat_f32")
+                _census_end(_e, "conv fwd", _gshape(g), _gflops(g))
+            return y, (cs if cs else None)
+        return conv_fwd(x, w, bias, stride, pad, groups, relu), None
     if _direct_ok(x.shape, g.Cout, g.Cin, ks, stride, pad, groups):
         check(L().tf_conv3x3_small_fwd_f32(ptr(_c(x)), wptr(w), ptr(bias), ptr(y), g.B, g.Hi, g.Wi, g.Cin, g.Cout, int(relu), stream_of(x)),
               "tf_conv3x3_small_fwd_f32")
@@ -421,6 +469,34 @@ def softmax_bwd_(p, dp, rows, n, ld):
     return dp
 
 
+# ---- fused attention (csrc/attention.cpp)
+FUSED_ATTENTION = os.environ.get("TF_FUSED_ATTENTION", "1") != "0"
+
+
+def attention_supported(T, C, nh):
+    return FUSED_ATTENTION and bool(L().tf_attention_supported(T, C, nh))
+
+
+def attention_fwd(qkv, B, T, C, nh, drop=None):
+    """qkv (B*T, 3C) = [key | query | value] -> (y (B*T, C), lse (B*nh*T)); drop = (seed, site, p) or None."""
+    y = torch.empty(B * T, C, dtype=torch.float32, device=qkv.device)
+    lse = torch.empty(B * nh * T, dtype=torch.float32, device=qkv.device)
+    seed, site, p = drop if drop is not None else (None, 0, 0.0)
+    check(L().tf_attention_fwd_f32(ptr(_c(qkv)), ptr(y), ptr(lse), B, T, C, nh, ptr(seed), ctypes.c_uint32(site), ctypes.c_float(p), stream_of(qkv)),
+          "tf_attention_fwd_f32")
+    return y, lse
+
+
+def attention_bwd(qkv, dy, lse, B, T, C, nh, drop=None):
+    """-> dqkv (B*T, 3C): gradients of [key | query | value]; the probabilities are recomputed from qkv and lse."""
+    dqkv = torch.empty_like(qkv)
+    dsum = torch.empty_like(lse)
+    seed, site, p = drop if drop is not None else (None, 0, 0.0)
+    check(L().tf_attention_bwd_f32(ptr(_c(qkv)), ptr(_c(dy)), ptr(lse), ptr(dqkv), ptr(dsum), B, T, C, nh, ptr(seed), ctypes.c_uint32(site),
+                                   ctypes.c_float(p), stream_of(qkv)), "tf_attention_bwd_f32")
+    return dqkv
+
+
 # ---- zero arena: a device buffer cleared ONCE per training step (zero_scratch_reset, called by LidarCenterNet.forward) from which
 # kernels that accumulate with atomics (BatchNorm statistics, SE squeeze) take pre-zeroed slices - instead of one memset / finalize
 # launch each.  Slices stay valid until the next reset (the next forward); when the pool runs dry a fresh torch.zeros is returned.
@@ -467,6 +543,19 @@ def bn_fwd(x, gamma, beta, rmean, rvar, res=None, relu=False, training=True, mom
     check(L().tf_bn_fwd_f32(ptr(_c(x)), rows, C, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), ctypes.c_float(momentum), ctypes.c_float(eps),
                             ptr(res), int(relu), ptr(y), ptr(sm), ptr(si), ptr(workspace(x.device)), int(training), ptr(zacc), stream_of(x)),
           "tf_bn_fwd_f32")
+    return y, sm, si
+
+
+def bn_fwd_parts(x, cs, gamma, beta, rmean, rvar, res=None, relu=False, momentum=0.1, eps=1e-5):
+    """Train-mode BatchNorm forward from the statistics the producer of x gathered (ColStat): finalize + apply, no moments pass over x."""
+    C = x.shape[-1]
+    rows = x.numel() // C
+    assert cs and cs.C == C and cs.rows == rows
+    y = torch.empty_like(x)
+    sm = torch.empty(C, dtype=torch.float32, device=x.device)
+    si = torch.empty_like(sm)
+    check(L().tf_bn_fwd_parts_f32(ptr(_c(x)), rows, C, ptr(cs.buf), cs.nparts.value, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), ctypes.c_float(momentum),
+                                  ctypes.c_float(eps), ptr(res), int(relu), ptr(y), ptr(sm), ptr(si), ptr(workspace(x.device)), stream_of(x)), "tf_bn_fwd_parts_f32")
     return y, sm, si
 
 
@@ -737,6 +826,20 @@ def gru_waypoints_bwd(dwp, cache, gru, outl, grads, B, H, pred_len):
 def adamw_(p, g, m, v, state, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.01):
     check(L().tf_adamw_f32(ptr(p), ptr(g), ptr(m), ptr(v), ctypes.c_int64(p.numel()), ptr(state), ctypes.c_float(beta1), ctypes.c_float(beta2),
                            ctypes.c_float(eps), ctypes.c_float(weight_decay), stream_of(p)), "tf_adamw_f32")
+
+
+def cast_bf16(x, out=None):
+    """fp32 -> bf16 (round to nearest even)."""
+    if out is None:
+        out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    check(L().tf_cast_f32_bf16(ptr(_c(x)), ptr(_c(out)), ctypes.c_int64(x.numel()), stream_of(x)), "tf_cast_f32_bf16")
+    return out
+
+
+def cast_f32(x, out, scale=1.0):
+    """bf16 -> fp32 with a scale (out = x * scale)."""
+    check(L().tf_cast_bf16_f32(ptr(_c(x)), ptr(_c(out)), ctypes.c_int64(x.numel()), ctypes.c_float(scale), stream_of(x)), "tf_cast_bf16_f32")
+    return out
 
 
 def lidar_hist(points, num_points=None):

@@ -237,9 +237,11 @@ class GradReducer:
 
     The flat gradient arena is all-reduced in ``bucket_mb`` buckets.  On RCCL the collectives run on
     a side stream, ordered after the backward by an event, and the optimizer waits for the last
-    bucket; on MI355X xGMI (7 links/GPU, point-to-point) large buckets keep every link busy."""
+    bucket; on MI355X xGMI (7 links/GPU, point-to-point) large buckets keep every link busy.
+    ``grad_dtype="bf16"`` (opt-in; the reference reduces fp32): every bucket is rounded to bf16 on its way out and widened (x 1/world) on
+    its way back, halving the xGMI payload (336 MB instead of 672 MB per step); the arena itself stays fp32."""
 
-    def __init__(self, arena, group=None, bucket_mb=64.0):
+    def __init__(self, arena, group=None, bucket_mb=64.0, grad_dtype="fp32"):
         self.arena = arena
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
@@ -247,6 +249,11 @@ class GradReducer:
         per = max(_ALIGN, int(bucket_mb * (1 << 20) / 4) // _ALIGN * _ALIGN)
         self.buckets = [(s, min(n, s + per)) for s in range(0, n, per)]
         self.stream = torch.cuda.Stream() if arena.grads.is_cuda else None
+        assert grad_dtype in ("fp32", "bf16"), grad_dtype
+        self.bf16 = grad_dtype == "bf16"
+        self._half = torch.empty(min(per, n), dtype=torch.bfloat16, device=arena.grads.device) if self.bf16 and self.world > 1 else None
+        self._wait_events = None       # (before, after) timing events around the optimizer's wait for the side stream: the EXPOSED all-reduce time
+        self.time_waits = False        # bench.py --check turns the event pair on
 
     def broadcast_params(self, src=0):
         """DDP's initial parameter broadcast (rank 0 -> all)."""
@@ -263,46 +270,63 @@ class GradReducer:
             if hi > lo:
                 dist.broadcast(p[lo:hi], r, group=self.group)
 
+    def _reduce_range(self, lo, hi):
+        """sum over the ranks, then x 1/world, of grads[lo:hi], bucket by bucket on the current stream."""
+        g = self.arena.grads
+        per = self.buckets[0][1] - self.buckets[0][0]
+        for s in range(lo, hi, per):
+            e = min(hi, s + per)
+            if self.bf16:
+                h = self._half[:e - s]
+                ops.cast_bf16(g[s:e], out=h)
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+                ops.cast_f32(h, g[s:e], 1.0 / self.world)
+            else:
+                dist.all_reduce(g[s:e], op=dist.ReduceOp.SUM, group=self.group)
+                ops.scale_dev_(g[s:e], None, None, 1.0 / self.world)
+
     def reduce_async(self, lo, hi):
         """All-reduce (mean) the gradient range [lo, hi) on the side stream, ordered after everything enqueued so far on the current
         stream - call it right after the backward segment that produces the range; the current stream keeps running the next segment."""
         if self.world == 1 or hi <= lo:
             return
-        g = self.arena.grads
-        per = self.buckets[0][1] - self.buckets[0][0]
         if self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.stream):
-                for s in range(lo, hi, per):
-                    e = min(hi, s + per)
-                    dist.all_reduce(g[s:e], op=dist.ReduceOp.SUM, group=self.group)
-                    ops.scale_dev_(g[s:e], None, None, 1.0 / self.world)
+                self._reduce_range(lo, hi)
         else:
-            for s in range(lo, hi, per):
-                e = min(hi, s + per)
-                dist.all_reduce(g[s:e], op=dist.ReduceOp.SUM, group=self.group)
-                ops.scale_dev_(g[s:e], None, None, 1.0 / self.world)
+            self._reduce_range(lo, hi)
 
     def finish(self):
         """The optimizer (current stream) waits for every pending bucket."""
         if self.world > 1 and self.stream is not None:
-            torch.cuda.current_stream().wait_stream(self.stream)
+            cur = torch.cuda.current_stream()
+            if self.time_waits:
+                ev = self._wait_events = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record(cur)
+                cur.wait_stream(self.stream)
+                ev[1].record(cur)
+            else:
+                cur.wait_stream(self.stream)
+
+    def exposed_ms(self):
+        """Time the current stream stalled in the last ``finish()`` = the part of the all-reduce the backward did NOT hide (needs
+        ``time_waits``; synchronises).  0.0 on one rank."""
+        if self._wait_events is None:
+            return 0.0
+        self._wait_events[1].synchronize()
+        return float(self._wait_events[0].elapsed_time(self._wait_events[1]))
 
     def reduce(self):
         if self.world == 1:
             return
-        g = self.arena.grads
         if self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.stream):
-                for s, e in self.buckets:
-                    dist.all_reduce(g[s:e], op=dist.ReduceOp.SUM, group=self.group)
-                ops.scale_dev_(g, None, None, 1.0 / self.world)
+                self._reduce_range(0, self.arena.numel)
             torch.cuda.current_stream().wait_stream(self.stream)
         else:
-            for s, e in self.buckets:
-                dist.all_reduce(g[s:e], op=dist.ReduceOp.SUM, group=self.group)
-            ops.scale_dev_(g, None, None, 1.0 / self.world)
+            self._reduce_range(0, self.arena.numel)
 
 
 def init_distributed():
@@ -329,7 +353,7 @@ class Engine:
     DEFAULT_CUTS = ((4, 1, 3), (4, 1, 2), (4, 1, 1), 3, (3, 0, 0), 2, 1)
 
     def __init__(self, model, config, lr=1e-4, use_graph=False, group=None, bucket_mb=64.0, wp_only=False, autotune=True, plan_file=None,
-                 zero_redundancy_optimizer=False, sync_batch_norm=False, cuts=None, precision=None):
+                 zero_redundancy_optimizer=False, sync_batch_norm=False, cuts=None, precision=None, grad_dtype="fp32"):
         """``cuts``: points (cut_key: int c = after fusion stage c; (i, 0, 0) = between the stage-i trunks and GPT i; (i, 1, j) = inside GPT i
         in front of Block j) at which the backward is cut into separately enqueued (and separately captured) segments whose gradient
         ranges are all-reduced while the next segment runs.  None = DEFAULT_CUTS when there is more than one rank (and the backbone is a
@@ -359,7 +383,7 @@ class Engine:
         if can_cut:
             backbone._cuts = frozenset(self.cuts)
         self.arena = ParamArena(model, self.cuts)
-        self.reducer = GradReducer(self.arena, group, bucket_mb)
+        self.reducer = GradReducer(self.arena, group, bucket_mb, grad_dtype)
         self.zero = bool(zero_redundancy_optimizer) and self.reducer.world > 1      # train.py:143-146
         rank = dist.get_rank(group) if self.zero else 0
         self.optimizer = FlatAdamW(self.arena, lr=lr, shard=(rank, self.reducer.world) if self.zero else None)
