@@ -102,6 +102,19 @@ int tf_conv3x3_small_dgrad_f32(const float* dy, const float* w, float* dx, int B
 long tf_conv3x3_small_wgrad_ws_floats(void);
 int tf_conv3x3_small_wgrad_f32(const float* dy, const float* x, float* dw, int B, int H, int W, int Cin, int Cout, int accumulate, float* ws, void* stream);
 
+/* The same layer shape with a THIN output: Cin == 32, 1 <= Cout <= 7 (the decoders' last convolution, transfuser.py:237,272: 32 -> 7 / 32 -> 1
+ * at 256 x 704).  The 9 taps are folded into the GEMM's N (forward) / K (dgrad) / M (wgrad) dimension, so the launches are bandwidth-bound like
+ * the layer itself instead of costing a 32 -> 32 convolution.  dgrad: relu_mask (optional, same shape as dx) = the forward OUTPUT of the
+ * preceding ReLU layer (this layer's input): dx is zeroed where it is <= 0, i.e. dx is already that layer's masked gradient.
+ * wgrad: dbias (optional, Cout floats) is ALWAYS accumulated into; ws = tf_conv3x3_thin_wgrad_ws_floats() floats. */
+int tf_conv3x3_thin_supported(int Cin, int Cout);
+int tf_conv3x3_thin_fwd_f32(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Cin, int Cout, void* stream);
+int tf_conv3x3_thin_dgrad_f32(const float* dy, const float* w, const float* relu_mask, float* dx, int B, int H, int W, int Cin, int Cout, int accumulate,
+                              void* stream);
+long tf_conv3x3_thin_wgrad_ws_floats(void);
+int tf_conv3x3_thin_wgrad_f32(const float* dy, const float* x, float* dw, float* dbias, int B, int H, int W, int Cin, int Cout, int accumulate, float* ws,
+                              void* stream);
+
 /* Grouped 3x3 / stride 1 / pad 1 convolution with group width 24 (C / 24 groups of 24 -> 24 channels): the timm regnety_032 bottleneck
  * convolution (transfuser.py:380,442; timm 0.5.4 regnet.py Bottleneck.conv2) and its gradients as per-group direct kernels.  x, y, dy, dx:
  * NHWC (B, H, W, C); w / dw: (C, 3, 3, 24) = the channels-last storage of a (C, 24, 3, 3) parameter.  wgrad needs

@@ -145,6 +145,51 @@ def check_conv_direct(dev, B, H, W, Cin, Cout):
         ops._DIRECT_MIN_PIXELS = old
 
 
+THIN_CONV_CASES = [(1, 9, 33, 7), (2, 5, 40, 1), (1, 16, 64, 3), (2, 7, 31, 5), (1, 3, 30, 7), (1, 15, 29, 1)]
+
+
+def check_conv_thin(dev, B, H, W, Cout):
+    """Thin-output 3x3 convolutions (32 -> Cout <= 7, csrc/conv_thin.cpp): forward with bias, input gradient with the fused ReLU mask of the
+    preceding layer (+ accumulate), weight gradient with the bias gradient riding along (+ accumulate) vs PyTorch."""
+    old = ops._DIRECT_MIN_PIXELS
+    ops._DIRECT_MIN_PIXELS = 0
+    try:
+        Cin = 32
+        assert ops._thin_ok((B, H, W, Cin), Cout, Cin, 3, 1, 1, 1)
+        x = R(B, Cin, H, W, dev=dev).requires_grad_(True)
+        w = (R(Cout, Cin, 3, 3, dev=dev) * 0.1).requires_grad_(True)
+        b = R(Cout, dev=dev).requires_grad_(True)
+        y = F.conv2d(x, w, b, 1, 1)
+        dy = R(*y.shape, seed=1, dev=dev)
+        gx, gw, gb = torch.autograd.grad(y, [x, w, b], dy)
+        xh = x.detach().permute(0, 2, 3, 1).contiguous()
+        wh = cl(w.detach())
+        dyh = dy.permute(0, 2, 3, 1).contiguous()
+        yh = ops.conv_fwd(xh, wh, b.detach(), 1, None, 1, relu=False)
+        close(yh.permute(0, 3, 1, 2), y, what="thin fwd")
+        close(ops.conv_fwd(xh, wh, None, 1, None, 1), F.conv2d(x, w, None, 1, 1).permute(0, 2, 3, 1), what="thin fwd no bias")
+        dx = ops.conv_dgrad(dyh, wh, xh.shape, 1, None, 1)
+        close(dx.permute(0, 3, 1, 2), gx, what="thin dgrad")
+        mask = R(B, H, W, Cin, seed=9, dev=dev)
+        dxm = ops.conv_dgrad(dyh, wh, xh.shape, 1, None, 1, mask=mask)
+        assert torch.equal(dxm, dx * (mask > 0)), "thin dgrad fused mask"
+        base = R(B, H, W, Cin, seed=6, dev=dev)
+        close(ops.conv_dgrad(dyh, wh, xh.shape, 1, None, 1, out=base.clone(), accumulate=True), base + dx, what="thin dgrad accumulate")
+        tol = 2e-5 * max(1.0, B * H * W / 500.0)
+        dw = torch.zeros_like(wh)
+        db = R(Cout, seed=8, dev=dev)
+        db0 = db.clone()
+        assert ops.conv_wgrad_takes_bias(xh.shape, Cout, 3)
+        ops.conv_wgrad(dyh, xh, dw, 1, None, 1, accumulate=False, dbias=db)
+        close(dw, gw, what="thin wgrad", tol=tol)
+        close(db, db0 + gb, what="thin bias grad", tol=tol)
+        basew = cl(R(Cout, Cin, 3, 3, seed=7, dev=dev))
+        dw1 = ops.conv_wgrad(dyh, xh, basew.clone(), 1, None, 1, accumulate=True)
+        close(dw1, basew + dw, what="thin wgrad accumulate", tol=tol)
+    finally:
+        ops._DIRECT_MIN_PIXELS = old
+
+
 def check_stem(dev, B, H, W):
     rgb = torch.randint(0, 256, (B, 3, H, W), generator=torch.Generator().manual_seed(0)).float().to(dev)
     w = (R(32, 3, 3, 3, dev=dev) * 0.2).requires_grad_(True)
@@ -1078,8 +1123,8 @@ def check_bn_fused_stats(dev, plans=((0, 64, 64, 16), (0, 128, 32, 16), (0, 128,
 
 
 # ---------------------------------------------------------------- fused attention (csrc/attention.cpp)
-FUSED_ATTENTION_CASES = [(2, 4, 174, 18, 0.1), (1, 4, 174, 54, 0.0), (2, 2, 50, 24, 0.1), (1, 3, 192, 40, 0.1), (2, 1, 33, 7, 0.0)]
-FUSED_ATTENTION_CASES_GPU = [(10, 4, 174, 378, 0.1), (3, 4, 174, 144, 0.1), (2, 4, 174, 54, 0.0), (2, 4, 174, 18, 0.1), (1, 1, 192, 384, 0.1), (2, 3, 97, 33, 0.1)]
+FUSED_ATTENTION_CASES = [(2, 4, 174, 18, 0.1), (1, 4, 174, 54, 0.0), (2, 2, 50, 24, 0.1), (1, 3, 192, 40, 0.1), (2, 1, 33, 6, 0.0)]
+FUSED_ATTENTION_CASES_GPU = [(10, 4, 174, 378, 0.1), (3, 4, 174, 144, 0.1), (2, 4, 174, 54, 0.0), (2, 4, 174, 18, 0.1), (1, 1, 192, 384, 0.1), (2, 3, 97, 34, 0.1)]
 
 
 def check_fused_attention(dev, B, nh, T, hs, p):

@@ -158,6 +158,11 @@ def test_se_excite_fused(case):
     kc.check_se_excite("cuda", *case)
 
 
+@pytest.mark.parametrize("case", kc.THIN_CONV_CASES, ids=str)
+def test_conv_thin_output(case):
+    kc.check_conv_thin("cuda", *case)
+
+
 @pytest.mark.parametrize("case", kc.DIRECT_CONV_CASES, ids=str)
 def test_conv_direct_small_channels(case):
     kc.check_conv_direct("cuda", *case)

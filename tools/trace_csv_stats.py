@@ -20,15 +20,16 @@ for s, e in ev[1:]:
 busy += ce - cs
 tot = sum(r[2] - r[1] for r in seg)
 print("last %d steps: wall %.2f ms/step, GPU busy (union) %.2f ms/step, sum of kernel durations %.2f ms/step, %d kernels/step" % (n, wall / n / 1e6, busy / n / 1e6, tot / n / 1e6, len(seg) // n))
-agg = collections.defaultdict(lambda: [0, 0])
+agg = collections.defaultdict(lambda: [0, 0, 1 << 60, 0])
 for name, s, e in seg:
-    agg[name][0] += 1; agg[name][1] += e - s
+    a = agg[name]
+    a[0] += 1; a[1] += e - s; a[2] = min(a[2], e - s); a[3] = max(a[3], e - s)
 fam = collections.defaultdict(float)
-for name, (c, t) in agg.items():
+for name, (c, t, _, _) in agg.items():
     key = "gemm engine (gemm_kernel / gemm_dma_kernel)" if "gemm_kernel" in name or "gemm_dma" in name else "direct conv" if ("conv3x3_small" in name or "conv3x3_grouped" in name) else \
         "batchnorm" if ("bn_" in name or "BnStat" in name or "BnBwd" in name) else "other"
     fam[key] += t / n / 1e6
 print("families (ms/step):", ", ".join("%s %.2f" % kv for kv in sorted(fam.items(), key=lambda kv: -kv[1])))
-print("per kernel (ms/step, calls/step, avg us):")
-for name, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:70]:
-    print("%9.3f %6d %8.1f  %s" % (t / n / 1e6, c // n, t / c / 1e3, name[:150]))
+print("per kernel (ms/step, calls/step, avg us, min us, max us):")
+for name, (c, t, lo, hi) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:90]:
+    print("%9.3f %6d %8.1f %7.1f %7.1f  %s" % (t / n / 1e6, c // n, t / c / 1e3, lo / 1e3, hi / 1e3, name[:130]))

@@ -4,10 +4,13 @@
 // / dropped probabilities round-tripping HBM).  T <= 192 (the model has T = 5 x 22 + 8 x 8 = 174), hs <= 384 (18 / 54 / 144 / 378).
 //
 // All three kernels share one skeleton, on a tile of 32 "row" tokens against ALL T "column" tokens:
-//   phase A  one or two score-shaped products [32 x 192] contracted over hs (operands streamed global -> registers -> LDS in 16-deep,
-//            K-major tiles, double-buffered, register prefetch; six waves, one 32 x 32 fp32-MFMA accumulator per product each);
+//   phase A  one or two score-shaped products [32 x 192] contracted over hs: six waves, one 32 x 32 fp32-MFMA accumulator per product each;
+//            every lane fetches its own MFMA fragments straight from global memory (8-byte loads, k slots permuted so that a lane half
+//            owns consecutive channels), double-buffered in registers - no LDS staging, no barrier (round 3, second version: the first one
+//            staged 16-deep operand tiles through LDS with a barrier per chunk and one 106 KB workgroup per CU; it was latency-bound and
+//            no faster than the five batched GEMMs + softmax it replaced);
 //   middle   the score rows live in LDS ([32][193] floats): softmax / its backward / dropout mask regenerated from the counter RNG;
-//   phase B  one or two [32 x hs] products contracted over T with the LDS-resident scores as the A operand (B operand streamed).
+//   phase B  one or two [32 x hs] products contracted over T with the LDS-resident scores as the A operand, B fragments from global memory.
 // forward:   rows = queries: S = Q K^T; P = softmax(S); Y = drop(P) V; saves only L_i = max_i + log(sum_i) per row (T floats per head).
 // backward dq:   rows = queries: recomputes P = exp(S - L), dPd = dY V^T, D_i = sum_j dP_ij P_ij, dS = P (dP - D); dQ = dS K / sqrt(hs).
 // backward dkv:  rows = keys: the transposed products K Q^T, V dY^T; dS^T with L_i, D_i per COLUMN; dK = dS^T Q / sqrt(hs), dV = Pd^T dY.
@@ -25,16 +28,10 @@ constexpr int kR = 32;             // row tokens per workgroup
 constexpr int kNC = 192;           // column tokens (T padded)
 constexpr int kNW = 6;             // waves: one 32-column tile of the scores each
 constexpr int kNT = 64 * kNW;
-constexpr int kBK = 16;            // contraction chunk
-constexpr int kAP = kR + 4;        // pitch of a K-major row-operand tile  [kBK][36]
-constexpr int kBP = kNC + 4;       //                 column-operand tile  [kBK][196]
+constexpr int kKH = 8;             // phase A: contraction elements per lane half and chunk (chunk = 16 channels, 8 MFMA k-steps)
 constexpr int kSP = kNC + 1;       // score matrix pitch [32][193]: conflict-free as MFMA A operand (lane = row) and as row-wise softmax input
 constexpr int kHS = 384;           // max head size
-constexpr int kHP = kHS + 4;       // phase-B operand tile [kBK][388]
-constexpr int kATile = kBK * kAP + kBK * kBP;          // floats of one (row, column) operand pair of phase A
-constexpr int kUnion = 2 * 2 * kATile;                 // phase A: 2 buffers x up to 2 products (>= phase B: 2 buffers x kBK x kHP)
-static_assert(kUnion >= 2 * kBK * kHP, "phase B tiles must fit the phase A region");
-constexpr int kSmem = 2 * kR * kSP + kUnion;           // 27200 floats = 106 KiB: one workgroup per CU
+constexpr int kTB = 16;            // phase B: k-steps (token pairs) per register chunk
 
 struct AtGeom {
     int B, nh, T, hs, C, Tp;
@@ -44,69 +41,77 @@ struct AtGeom {
 
 __device__ __forceinline__ int acc_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
-// ---- phase A: acc[p] (32 x 32 per wave) = sum_k R_p[row0 + i][k] * C_p[wave * 32 + j][k], p < NP; both operands row-major, k contiguous
+// ---- phase A: acc[p] (32 x 32 per wave) = sum_k R_p[row0 + i][k] * C_p[wave * 32 + j][k], p < NP; both operands row-major, k contiguous.
+// No LDS and no barrier: the operands are tiny (<= 192 x 384) and every wave multiplies ONE 32 x 32 tile, so each lane fetches its own MFMA
+// fragments straight from global memory (L2 / L1 resident after the first touch).  The MFMA's k slots are permuted so that lane half `hi`
+// owns kKH CONSECUTIVE channels of a 16-channel chunk: a fragment row is four 8-byte loads (head offsets h * hs are only 8-byte aligned:
+// hs = 18 / 54 / 378), the next chunk's loads are in flight while the current one is multiplied.  hs must be even (pairs are all-or-nothing).
 template <int NP>
 __device__ __forceinline__ void phase_a(f32x16 (&acc)[NP], const float* const (&rsrc)[NP], const long (&rld)[NP], const float* const (&csrc)[NP],
-                                        const long (&cld)[NP], int row0, int T, int hs, float* U) {
+                                        const long (&cld)[NP], int row0, int T, int hs) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
-    constexpr int SA = (kR * kBK + kNT - 1) / kNT;      // 2 row-operand slots per thread
-    constexpr int SB = (kNC * kBK) / kNT;               // 8 column-operand slots per thread
-    float ra[NP][SA], rb[NP][SB];
+    const int rrow = row0 + l31, crow = wave * 32 + l31;
+    const bool rok = rrow < T, cok = crow < T;
+    const float* rp[NP];
+    const float* cp[NP];
 #pragma unroll
-    for (int p = 0; p < NP; ++p)
+    for (int p = 0; p < NP; ++p) {
+        rp[p] = rsrc[p] + (long)(rok ? rrow : 0) * rld[p];
+        cp[p] = csrc[p] + (long)(cok ? crow : 0) * cld[p];
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
-    auto fetch = [&](int k0) {
+    }
+    // Loads must be UNCONDITIONAL for the prefetch to overlap: with predicated loads (or a select / factor applied at fetch time) hipcc waits
+    // for every load before the MFMA group, i.e. the next chunk's latency is exposed once per chunk (first version: no faster than the
+    // LDS-staged kernel).  So: out-of-range rows fetch row 0 (finite garbage - their score rows / columns are masked by every consumer and
+    // never stored), full 16-channel chunks are fetched bare, and only the ragged last chunk zeroes its dead channels (one exposed wait).
+    float2 fa[2][NP][kKH / 2], fb[2][NP][kKH / 2];
+    auto fetch = [&](int buf, int k0) {
 #pragma unroll
-        for (int p = 0; p < NP; ++p) {
+        for (int p = 0; p < NP; ++p)
 #pragma unroll
-            for (int s = 0; s < SA; ++s) {
-                const int idx = tid + s * kNT, r = idx >> 4, k = idx & 15;
-                const bool ok = idx < kR * kBK && row0 + r < T && k0 + k < hs;
-                ra[p][s] = ok ? rsrc[p][(long)(row0 + r) * rld[p] + k0 + k] : 0.f;
+            for (int q = 0; q < kKH / 2; ++q) {
+                const int k = k0 + kKH * hi + 2 * q;
+                fa[buf][p][q] = *reinterpret_cast<const float2*>(rp[p] + k);
+                fb[buf][p][q] = *reinterpret_cast<const float2*>(cp[p] + k);
             }
-#pragma unroll
-            for (int s = 0; s < SB; ++s) {
-                const int idx = tid + s * kNT, r = idx >> 4, k = idx & 15;
-                const bool ok = r < T && k0 + k < hs;
-                rb[p][s] = ok ? csrc[p][(long)r * cld[p] + k0 + k] : 0.f;
-            }
-        }
     };
-    auto stash = [&](int buf) {
+    auto mma = [&](int buf) {
 #pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            float* As = U + (buf * NP + p) * kATile;
-            float* Bs = As + kBK * kAP;
+        for (int p = 0; p < NP; ++p)
 #pragma unroll
-            for (int s = 0; s < SA; ++s) {
-                const int idx = tid + s * kNT, r = idx >> 4, k = idx & 15;
-                if (idx < kR * kBK) As[k * kAP + r] = ra[p][s];
+            for (int q = 0; q < kKH / 2; ++q) {
+                mfma_32x32x2(fa[buf][p][q].x, fb[buf][p][q].x, acc[p]);
+                mfma_32x32x2(fa[buf][p][q].y, fb[buf][p][q].y, acc[p]);
             }
-#pragma unroll
-            for (int s = 0; s < SB; ++s) {
-                const int idx = tid + s * kNT, r = idx >> 4, k = idx & 15;
-                Bs[k * kBP + r] = rb[p][s];
-            }
-        }
     };
-    const int nch = (hs + kBK - 1) / kBK;
-    fetch(0);
-    stash(0);
-    __syncthreads();
-    for (int c = 0; c < nch; ++c) {
-        const int buf = c & 1;
-        if (c + 1 < nch) fetch((c + 1) * kBK);
+    // straight-line trips (every fetch unconditional, the chunk index clamped instead): hipcc then waits with counted vmcnt(N), i.e. only for
+    // the buffer it is about to multiply - a conditional fetch makes the wait a vmcnt(0) at the join
+    const int nfull = hs / (2 * kKH), npair = nfull >> 1;
+    if (nfull > 0) fetch(0, 0);
+    for (int i = 0; i < npair; ++i) {
+        fetch(1, (2 * i + 1) * 2 * kKH);
+        mma(0);
+        const int nx = 2 * i + 2 < nfull ? 2 * i + 2 : nfull - 1;
+        fetch(0, nx * 2 * kKH);
+        mma(1);
+    }
+    if (nfull & 1) mma(0);                                // buffer 0 holds chunk nfull - 1
+    if (hs - nfull * 2 * kKH > 0) {                       // ragged tail: dead channels read channel 0 and are zeroed on the row operand
+        const int k0 = nfull * 2 * kKH;
 #pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            const float* As = U + (buf * NP + p) * kATile;
-            const float* Bs = As + kBK * kAP;
+        for (int p = 0; p < NP; ++p)
 #pragma unroll
-            for (int kk = 0; kk < kBK / 2; ++kk)
-                mfma_32x32x2(As[(2 * kk + hi) * kAP + l31], Bs[(2 * kk + hi) * kBP + wave * 32 + l31], acc[p]);
-        }
-        if (c + 1 < nch) stash(buf ^ 1);
-        __syncthreads();
+            for (int q = 0; q < kKH / 2; ++q) {
+                const int k = k0 + kKH * hi + 2 * q;
+                const bool kok = k < hs;
+                const int kc = kok ? k : 0;
+                const float2 va = *reinterpret_cast<const float2*>(rp[p] + kc);
+                const float m = kok ? 1.f : 0.f;
+                fa[0][p][q] = make_float2(va.x * m, va.y * m);
+                fb[0][p][q] = *reinterpret_cast<const float2*>(cp[p] + kc);
+            }
+        mma(0);
     }
 }
 
@@ -117,79 +122,58 @@ __device__ __forceinline__ void put_scores(float* Sm, const f32x16& acc, float s
     for (int r = 0; r < 16; ++r) Sm[acc_row(r, hi) * kSP + wave * 32 + l31] = acc[r] * scale;
 }
 
-// ---- phase B: out[row0 + i][c] = scale * sum_t Sm[i][t] * bsrc[t][c], c < hs; wave w owns the column tiles w and w + 6
-__device__ __forceinline__ void phase_b(const float* Sm, const float* bsrc, long bld, int T, int hs, float* U, float* out, long old, int row0,
-                                        float scale) {
+// ---- phase B: out[row0 + i][c] = scale * sum_t Sm[i][t] * bsrc[t][c], c < hs; wave w owns the column tiles w and w + 6.  The A operand is
+// the LDS-resident score tile; the B fragments (lane = output column, one token per k slot) come straight from global memory: a half wave
+// reads one 128-byte line of a token row per k-step, kTB k-steps in flight ahead of the MFMAs.  No barrier inside.
+__device__ __forceinline__ void phase_b(const float* Sm, const float* bsrc, long bld, int T, int hs, float* out, long old, int row0, float scale) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
-    const int ntile = (hs + 31) >> 5, ncv = ntile * 32;
-    constexpr int SLOTS = (kBK * kHS) / kNT;            // 16
-    float rb[SLOTS];
-    f32x16 acc[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
-    const int total = kBK * ncv;
-    // slot s of this thread: flat index tid + s * kNT over [kBK][ncv]; (t, c) computed once (ncv is a run-time multiple of 32)
-    int st[SLOTS], sc[SLOTS];
-#pragma unroll
-    for (int s = 0; s < SLOTS; ++s) {
-        const int idx = tid + s * kNT;
-        st[s] = idx / ncv;
-        sc[s] = idx - st[s] * ncv;
-    }
-    auto fetch = [&](int t0) {
-#pragma unroll
-        for (int s = 0; s < SLOTS; ++s) {
-            const bool ok = tid + s * kNT < total && t0 + st[s] < T && sc[s] < hs;
-            rb[s] = ok ? bsrc[(long)(t0 + st[s]) * bld + sc[s]] : 0.f;
-        }
-    };
-    auto stash = [&](int buf) {
-        float* Bs = U + buf * kBK * kHP;
-#pragma unroll
-        for (int s = 0; s < SLOTS; ++s)
-            if (tid + s * kNT < total) Bs[st[s] * kHP + sc[s]] = rb[s];
-    };
-    const int nch = (T + kBK - 1) / kBK;
-    const bool own0 = wave < ntile, own1 = wave + kNW < ntile;
-    fetch(0);
-    stash(0);
-    __syncthreads();
-    for (int c = 0; c < nch; ++c) {
-        const int buf = c & 1, t0 = c * kBK;
-        if (c + 1 < nch) fetch(t0 + kBK);
-        const float* Bs = U + buf * kBK * kHP;
-        if (own0) {       // wave-uniform
-#pragma unroll
-            for (int kk = 0; kk < kBK / 2; ++kk) {
-                const float a = Sm[l31 * kSP + t0 + 2 * kk + hi];
-                mfma_32x32x2(a, Bs[(2 * kk + hi) * kHP + wave * 32 + l31], acc[0]);
-                if (own1) mfma_32x32x2(a, Bs[(2 * kk + hi) * kHP + (wave + kNW) * 32 + l31], acc[1]);
-            }
-        }
-        if (c + 1 < nch) stash(buf ^ 1);
-        __syncthreads();
-    }
-#pragma unroll
+    const int ntile = (hs + 31) >> 5;
     for (int u = 0; u < 2; ++u) {
-        const int col = (wave + u * kNW) * 32 + l31;
-        if (col < hs) {
+        const int tile = wave + u * kNW;
+        if (tile >= ntile) break;                               // wave-uniform
+        const int col = tile * 32 + l31;
+        const bool colok = col < hs;
+        const float* bp = bsrc + (colok ? col : 0);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        float fb[2][kTB];
+        auto fetch = [&](int buf, int t0) {            // unconditional (see phase_a): tokens >= T read token T - 1; their score column is exactly 0
+#pragma unroll
+            for (int q = 0; q < kTB; ++q) {
+                const int t = t0 + 2 * q + hi;
+                fb[buf][q] = bp[(long)(t < T ? t : T - 1) * bld];
+            }
+        };
+        const int nch = (T + 2 * kTB - 1) / (2 * kTB), npair = nch >> 1;
+        const float* ap = Sm + l31 * kSP + hi;
+        auto mma = [&](int buf, int c) {
+#pragma unroll
+            for (int q = 0; q < kTB; ++q) mfma_32x32x2(ap[c * 2 * kTB + 2 * q], fb[buf][q], acc);
+        };
+        fetch(0, 0);
+        for (int i = 0; i < npair; ++i) {                       // straight-line trips, see phase_a
+            fetch(1, (2 * i + 1) * 2 * kTB);
+            mma(0, 2 * i);
+            const int nx = 2 * i + 2 < nch ? 2 * i + 2 : nch - 1;
+            fetch(0, nx * 2 * kTB);
+            mma(1, 2 * i + 1);
+        }
+        if (nch & 1) mma(0, nch - 1);
+        if (colok) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = row0 + acc_row(r, hi);
-                if (row < T) out[(long)row * old + col] = acc[u][r] * scale;
+                if (row < T) out[(long)row * old + col] = acc[r] * scale;
             }
         }
     }
 }
 
 // qkv: (B*T, 3C) = [key | query | value] (transfuser.py:500-502 order); head h owns columns h*hs .. of each third
-__global__ void __launch_bounds__(kNT, 2) attention_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ y, float* __restrict__ lse, AtGeom g,
+__global__ void __launch_bounds__(kNT, 1) attention_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ y, float* __restrict__ lse, AtGeom g,
                                                                const uint32_t* __restrict__ seed) {
-    __shared__ __attribute__((aligned(16))) float smem[kSmem];
-    float* Sm = smem;
-    float* U = smem + 2 * kR * kSP;
+    __shared__ float Sm[kR * kSP];          // 24.7 KB: several workgroups per CU
     const int bh = blockIdx.y, b = bh / g.nh, h = bh - b * g.nh, row0 = blockIdx.x * kR;
     const long ld3 = 3L * g.C;
     const float* kp = qkv + (long)b * g.T * ld3 + (long)h * g.hs;
@@ -199,7 +183,7 @@ __global__ void __launch_bounds__(kNT, 2) attention_fwd_kernel(const float* __re
     const float* const rs[1] = {qp};
     const float* const cs[1] = {kp};
     const long rl[1] = {ld3}, cl[1] = {ld3};
-    phase_a<1>(acc, rs, rl, cs, cl, row0, g.T, g.hs, U);
+    phase_a<1>(acc, rs, rl, cs, cl, row0, g.T, g.hs);
     put_scores(Sm, acc[0], g.alpha);
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -236,17 +220,15 @@ __global__ void __launch_bounds__(kNT, 2) attention_fwd_kernel(const float* __re
         if (lane == 0 && row < g.T) lse[(long)bh * g.T + row] = mx + logf(sum);
     }
     __syncthreads();
-    phase_b(Sm, vp, ld3, g.T, g.hs, U, y + (long)b * g.T * g.C + (long)h * g.hs, g.C, row0, 1.f);
+    phase_b(Sm, vp, ld3, g.T, g.hs, y + (long)b * g.T * g.C + (long)h * g.hs, g.C, row0, 1.f);
 }
 
 // rows = queries: dQ, and D_i = sum_j dP_ij P_ij for the dkv kernel
-__global__ void __launch_bounds__(kNT, 2) attention_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ dy, const float* __restrict__ lse,
+__global__ void __launch_bounds__(kNT, 1) attention_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ dy, const float* __restrict__ lse,
                                                                   float* __restrict__ dqkv, float* __restrict__ dsum, AtGeom g,
                                                                   const uint32_t* __restrict__ seed) {
-    __shared__ __attribute__((aligned(16))) float smem[kSmem];
-    float* S0 = smem;
-    float* S1 = smem + kR * kSP;
-    float* U = smem + 2 * kR * kSP;
+    __shared__ float S0[kR * kSP];
+    __shared__ float S1[kR * kSP];
     const int bh = blockIdx.y, b = bh / g.nh, h = bh - b * g.nh, row0 = blockIdx.x * kR;
     const long ld3 = 3L * g.C;
     const float* kp = qkv + (long)b * g.T * ld3 + (long)h * g.hs;
@@ -257,7 +239,7 @@ __global__ void __launch_bounds__(kNT, 2) attention_bwd_dq_kernel(const float* _
     const float* const rs[2] = {qp, dyp};
     const float* const cs[2] = {kp, vp};
     const long rl[2] = {ld3, (long)g.C}, cl[2] = {ld3, ld3};
-    phase_a<2>(acc, rs, rl, cs, cl, row0, g.T, g.hs, U);       // S = Q K^T, dPd = dY V^T
+    phase_a<2>(acc, rs, rl, cs, cl, row0, g.T, g.hs);       // S = Q K^T, dPd = dY V^T
     put_scores(S0, acc[0], g.alpha);
     put_scores(S1, acc[1], 1.f);
     __syncthreads();
@@ -284,17 +266,15 @@ __global__ void __launch_bounds__(kNT, 2) attention_bwd_dq_kernel(const float* _
         if (lane == 0 && row < g.T) dsum[(long)bh * g.T + row] = dot;
     }
     __syncthreads();
-    phase_b(S0, kp, ld3, g.T, g.hs, U, dqkv + (long)b * g.T * ld3 + g.C + (long)h * g.hs, ld3, row0, g.alpha);      // dQ = dS K / sqrt(hs)
+    phase_b(S0, kp, ld3, g.T, g.hs, dqkv + (long)b * g.T * ld3 + g.C + (long)h * g.hs, ld3, row0, g.alpha);      // dQ = dS K / sqrt(hs)
 }
 
 // rows = keys: dK, dV
-__global__ void __launch_bounds__(kNT, 2) attention_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ dy, const float* __restrict__ lse,
+__global__ void __launch_bounds__(kNT, 1) attention_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ dy, const float* __restrict__ lse,
                                                                    const float* __restrict__ dsum, float* __restrict__ dqkv, AtGeom g,
                                                                    const uint32_t* __restrict__ seed) {
-    __shared__ __attribute__((aligned(16))) float smem[kSmem];
-    float* S0 = smem;
-    float* S1 = smem + kR * kSP;
-    float* U = smem + 2 * kR * kSP;
+    __shared__ float S0[kR * kSP];
+    __shared__ float S1[kR * kSP];
     const int bh = blockIdx.y, b = bh / g.nh, h = bh - b * g.nh, row0 = blockIdx.x * kR;
     const long ld3 = 3L * g.C;
     const float* kp = qkv + (long)b * g.T * ld3 + (long)h * g.hs;
@@ -305,7 +285,7 @@ __global__ void __launch_bounds__(kNT, 2) attention_bwd_dkv_kernel(const float* 
     const float* const rs[2] = {kp, vp};
     const float* const cs[2] = {qp, dyp};
     const long rl[2] = {ld3, ld3}, cl[2] = {ld3, (long)g.C};
-    phase_a<2>(acc, rs, rl, cs, cl, row0, g.T, g.hs, U);       // S^T = K Q^T, dPd^T = V dY^T
+    phase_a<2>(acc, rs, rl, cs, cl, row0, g.T, g.hs);       // S^T = K Q^T, dPd^T = V dY^T
     put_scores(S0, acc[0], g.alpha);
     put_scores(S1, acc[1], 1.f);
     __syncthreads();
@@ -331,13 +311,13 @@ __global__ void __launch_bounds__(kNT, 2) attention_bwd_dkv_kernel(const float* 
     }
     __syncthreads();
     float* dk = dqkv + (long)b * g.T * ld3 + (long)h * g.hs;
-    phase_b(S0, qp, ld3, g.T, g.hs, U, dk, ld3, row0, g.alpha);                 // dK = dS^T Q / sqrt(hs)
-    phase_b(S1, dyp, g.C, g.T, g.hs, U, dk + 2 * g.C, ld3, row0, 1.f);          // dV = Pd^T dY
+    phase_b(S0, qp, ld3, g.T, g.hs, dk, ld3, row0, g.alpha);                 // dK = dS^T Q / sqrt(hs)
+    phase_b(S1, dyp, g.C, g.T, g.hs, dk + 2 * g.C, ld3, row0, 1.f);          // dV = Pd^T dY
 }
 
 inline int make_geom(AtGeom& g, int B, int T, int C, int nh, uint32_t site, float pdrop, const char* who) {
-    TF_REQUIRE(B > 0 && T > 0 && T <= kNC && nh > 0 && C % nh == 0 && C / nh <= kHS, "%s: needs T <= %d and head size <= %d (got T=%d, hs=%d)", who, kNC, kHS, T,
-               nh > 0 ? C / nh : -1);
+    TF_REQUIRE(B > 0 && T > 0 && T <= kNC && nh > 0 && C % nh == 0 && C / nh <= kHS && (C / nh) % 2 == 0, "%s: needs T <= %d and an even head size <= %d (got T=%d, hs=%d)",
+               who, kNC, kHS, T, nh > 0 ? C / nh : -1);
     TF_REQUIRE(pdrop >= 0.f && pdrop < 1.f && (long)B * nh * T * ((T + 3) / 4 * 4) < (1L << 32), "%s: bad dropout probability / index range", who);
     g.B = B; g.nh = nh; g.T = T; g.hs = C / nh; g.C = C; g.Tp = (T + 3) / 4 * 4;
     g.alpha = 1.0f / sqrtf((float)g.hs);
@@ -349,7 +329,7 @@ inline int make_geom(AtGeom& g, int B, int T, int C, int nh, uint32_t site, floa
 
 }  // namespace
 
-extern "C" int tf_attention_supported(int T, int C, int nh) { return (T > 0 && T <= kNC && nh > 0 && C % nh == 0 && C / nh <= kHS) ? 1 : 0; }
+extern "C" int tf_attention_supported(int T, int C, int nh) { return (T > 0 && T <= kNC && nh > 0 && C % nh == 0 && C / nh <= kHS && (C / nh) % 2 == 0) ? 1 : 0; }
 
 extern "C" int tf_attention_fwd_f32(const float* qkv, float* y, float* lse, int B, int T, int C, int nh, const uint32_t* seed_dev, uint32_t site, float pdrop,
                                     void* stream) {

@@ -314,16 +314,20 @@ __global__ void __launch_bounds__(256, 1) conv3x3_small_wgrad_kernel(const float
     }
 }
 
+// one WAVE per (tap, co, ci): the lanes stride over the blocks' panels, then a shuffle tree (a serial loop over 256 panels per thread measured 60 us)
 __global__ void __launch_bounds__(256) conv3x3_small_wgrad_reduce_kernel(const float* __restrict__ part, int nblocks, float* __restrict__ dw, int Co, int Ci,
                                                                          int accumulate) {
-    const int i = blockIdx.x * 256 + threadIdx.x;   // (tap, co, ci) over 9 x 32 x 32
-    if (i >= 9 * 1024) return;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;   // (tap, co, ci) over 9 x 32 x 32
     const int ci = i & 31, co = (i >> 5) & 31, tap = i >> 10;
-    if (co >= Co || ci >= Ci) return;
+    const bool live = i < 9 * 1024 && co < Co && ci < Ci;      // wave-uniform
     float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += part[(long)b * 9216 + i];
-    float* d = dw + ((long)co * 9 + tap) * Ci + ci;
-    *d = accumulate ? *d + s : s;
+    if (live)
+        for (int b = lane; b < nblocks; b += 64) s += part[(long)b * 9216 + i];
+    s = wave_sum(s);
+    if (live && lane == 0) {
+        float* d = dw + ((long)co * 9 + tap) * Ci + ci;
+        *d = accumulate ? *d + s : s;
+    }
 }
 
 // compute precision of these kernels; TF_X3_DIRECT=0 keeps them on the exact fp32 MFMA in f32x3 mode (A/B switch)
@@ -394,6 +398,6 @@ extern "C" int tf_conv3x3_small_wgrad_f32(const float* dy, const float* x, float
     if (prec == 2) { if (vec) TF_LAUNCH((conv3x3_small_wgrad_kernel<true, 2>), dim3(grid), dim3(256), stream, x, dy, ws, g); else TF_LAUNCH((conv3x3_small_wgrad_kernel<false, 2>), dim3(grid), dim3(256), stream, x, dy, ws, g); }
     else if (prec == 1) { if (vec) TF_LAUNCH((conv3x3_small_wgrad_kernel<true, 1>), dim3(grid), dim3(256), stream, x, dy, ws, g); else TF_LAUNCH((conv3x3_small_wgrad_kernel<false, 1>), dim3(grid), dim3(256), stream, x, dy, ws, g); }
     else { if (vec) TF_LAUNCH((conv3x3_small_wgrad_kernel<true, 0>), dim3(grid), dim3(256), stream, x, dy, ws, g); else TF_LAUNCH((conv3x3_small_wgrad_kernel<false, 0>), dim3(grid), dim3(256), stream, x, dy, ws, g); }
-    TF_LAUNCH(conv3x3_small_wgrad_reduce_kernel, dim3(36), dim3(256), stream, (const float*)ws, grid, dw, Cout, Cin, accumulate);
+    TF_LAUNCH(conv3x3_small_wgrad_reduce_kernel, dim3(9 * 1024 / 4), dim3(256), stream, (const float*)ws, grid, dw, Cout, Cin, accumulate);
     return launch_status("tf_conv3x3_small_wgrad_f32");
 }

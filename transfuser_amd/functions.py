@@ -699,38 +699,41 @@ class GeoStageFn(torch.autograd.Function):
 # ============================================================================================ generic conv / resample
 @routes_param_grads
 class ConvFn(torch.autograd.Function):
-    """conv (1x1 or 3x3, stride 1, bias) (+ReLU) on NHWC: decoders, heads, FPN, channel reducers."""
+    """conv (1x1 or 3x3, stride 1, bias) (+ReLU) on NHWC: decoders, heads, FPN, channel reducers.
+    ``link``: 0 plain; 1 = this (ReLU) layer's ONLY consumer is a ConvFn with link 2, which hands back an already ReLU-masked gradient;
+    2 = the input is the output of a link-1 layer: the input gradient is masked with it (fused into the dgrad epilogue where the kernel can)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, relu):
+    def forward(ctx, x, w, b, relu, link=0):
         B, H, W, Cin = x.shape
         if w.shape[2] == 1:
             y = ops.linear_fwd(x.view(-1, Cin), w2d(w), b, relu=relu).view(B, H, W, w.shape[0])
         else:
             y = ops.conv_fwd(x, w, b, 1, 1, 1, relu)
-        ctx.saved = (x, w, b, relu, y)
+        ctx.saved = (x, w, b, relu, y, link)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w, b, relu, y = ctx.saved
+        x, w, b, relu, y, link = ctx.saved
         B, H, W, Cin = x.shape
         Cout = w.shape[0]
         dy = dy.contiguous()
-        g = ops.relu_mask(dy, y) if relu else dy
-        if b is not None:
+        g = ops.relu_mask(dy, y) if (relu and link != 1) else dy
+        fused_bias = b is not None and w.shape[2] == 3 and ops.conv_wgrad_takes_bias(x.shape, Cout, 3)
+        if b is not None and not fused_bias:
             bias_grad(g.view(-1, Cout), b)
         dx = None
         if w.shape[2] == 1:
             ops.linear_wgrad(g.view(-1, Cout), x.view(-1, Cin), w2d(gbuf(w)))
             if ctx.needs_input_grad[0]:
-                dx = ops.linear_dgrad(g.view(-1, Cout), w2d(w)).view(B, H, W, Cin)
+                dx = ops.linear_dgrad(g.view(-1, Cout), w2d(w), mask=x.view(-1, Cin) if link == 2 else None).view(B, H, W, Cin)
         else:
-            ops.conv_wgrad(g, x, gbuf(w), 1, 1, 1)
+            ops.conv_wgrad(g, x, gbuf(w), 1, 1, 1, dbias=gbuf(b) if fused_bias else None)
             if ctx.needs_input_grad[0]:
-                dx = ops.conv_dgrad(g, w, x.shape, 1, 1, 1)
+                dx = ops.conv_dgrad(g, w, x.shape, 1, 1, 1, mask=x if link == 2 else None)
         ctx.saved = None
-        return dx, None, None, None
+        return dx, None, None, None, None
 
 
 class UpsampleFn(torch.autograd.Function):

@@ -306,6 +306,12 @@ def _direct_ok(shape, cout, cin, ks, stride, pad, groups):
 
 
 _DIRECT = bool(int(__import__("os").environ.get("TF_DIRECT_CONV", "1")))
+_THIN = bool(int(__import__("os").environ.get("TF_THIN_CONV", "1")))
+
+
+def _thin_ok(shape, cout, cin, ks, stride, pad, groups):
+    """The decoders' last layer (32 -> 7 / 32 -> 1 at full resolution): taps folded into the GEMM dimensions (csrc/conv_thin.cpp)."""
+    return _THIN and _direct_ok(shape, cout, cin, ks, stride, pad, groups) and cin == 32 and cout <= 7
 _GROUPED = bool(int(__import__("os").environ.get("TF_GROUPED_CONV", "1")))
 _gws_cache = {}
 
@@ -350,6 +356,10 @@ def conv_fwd(x, w, bias=None, stride=1, pad=None, groups=1, relu=False, colstat=
                 _census_end(_e, "conv fwd", _gshape(g), _gflops(g))
             return y, (cs if cs else None)
         return conv_fwd(x, w, bias, stride, pad, groups, relu), None
+    if not relu and _thin_ok(x.shape, g.Cout, g.Cin, ks, stride, pad, groups):
+        check(L().tf_conv3x3_thin_fwd_f32(ptr(_c(x)), wptr(w), ptr(bias), ptr(y), g.B, g.Hi, g.Wi, g.Cin, g.Cout, stream_of(x)), "tf_conv3x3_thin_fwd_f32")
+        _census_end(_e, "conv fwd t", _gshape(g), _gflops(g))
+        return y
     if _direct_ok(x.shape, g.Cout, g.Cin, ks, stride, pad, groups):
         check(L().tf_conv3x3_small_fwd_f32(ptr(_c(x)), wptr(w), ptr(bias), ptr(y), g.B, g.Hi, g.Wi, g.Cin, g.Cout, int(relu), stream_of(x)),
               "tf_conv3x3_small_fwd_f32")
@@ -364,13 +374,23 @@ def conv_fwd(x, w, bias=None, stride=1, pad=None, groups=1, relu=False, colstat=
     return y
 
 
-def conv_dgrad(dy, w, x_shape, stride=1, pad=None, groups=1, out=None, accumulate=False):
+def conv_dgrad(dy, w, x_shape, stride=1, pad=None, groups=1, out=None, accumulate=False, mask=None):
+    """mask (optional, shape of dx): the forward output of the ReLU layer that produced this convolution's input - dx is zeroed where it is
+    <= 0 (that layer's ReLU backward; fused into the epilogue of the thin-output kernels, one extra launch otherwise)."""
     ks = w.shape[2]
     pad = ks // 2 if pad is None else pad
     g = conv_geom(x_shape, w.shape[0], ks, stride, pad, groups)
     if out is None:
         out = torch.empty(tuple(x_shape), dtype=torch.float32, device=dy.device)
     _e = _census_begin()
+    if _thin_ok(x_shape, g.Cout, g.Cin, ks, stride, pad, groups):
+        check(L().tf_conv3x3_thin_dgrad_f32(ptr(_c(dy)), wptr(w), ptr(_c(mask)) if mask is not None else c_p(0), ptr(_c(out)), g.B, g.Hi, g.Wi, g.Cin, g.Cout,
+                                            int(accumulate), stream_of(dy)), "tf_conv3x3_thin_dgrad_f32")
+        _census_end(_e, "conv dgrad t", _gshape(g), _gflops(g))
+        return out
+    if mask is not None:
+        assert not accumulate, "conv_dgrad: mask + accumulate needs the fused kernel"
+        return relu_mask(conv_dgrad(dy, w, x_shape, stride, pad, groups, out=out), mask, out=out)
     if _direct_ok(x_shape, g.Cout, g.Cin, ks, stride, pad, groups):
         check(L().tf_conv3x3_small_dgrad_f32(ptr(_c(dy)), wptr(w), ptr(_c(out)), g.B, g.Hi, g.Wi, g.Cin, g.Cout, int(accumulate), stream_of(dy)),
               "tf_conv3x3_small_dgrad_f32")
@@ -385,11 +405,31 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=None, groups=1, out=None, accumulat
     return out
 
 
-def conv_wgrad(dy, x, dw, stride=1, pad=None, groups=1, accumulate=True):
+_thin_ws_cache = {}
+
+
+def _thin_ws(device):
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream if getattr(device, "type", str(device)[:4]) == "cuda" else 0)
+    ws = _thin_ws_cache.get(key)
+    if ws is None:
+        L().tf_conv3x3_thin_wgrad_ws_floats.restype = ctypes.c_long
+        ws = _thin_ws_cache[key] = torch.empty(L().tf_conv3x3_thin_wgrad_ws_floats(), dtype=torch.float32, device=device)
+    return ws
+
+
+def conv_wgrad(dy, x, dw, stride=1, pad=None, groups=1, accumulate=True, dbias=None):
+    """dbias (optional, (Cout,) accumulator): the bias gradient sum(dy) is added to it by the same launch where the kernel can (thin-output
+    layers); returns dw - callers test ``conv_wgrad_takes_bias`` to know whether dbias was consumed."""
     ks = dw.shape[2]
     pad = ks // 2 if pad is None else pad
     g = conv_geom(x.shape, dw.shape[0], ks, stride, pad, groups)
     _e = _census_begin()
+    if _thin_ok(x.shape, g.Cout, g.Cin, ks, stride, pad, groups):
+        check(L().tf_conv3x3_thin_wgrad_f32(ptr(_c(dy)), ptr(_c(x)), wptr(dw), ptr(dbias), g.B, g.Hi, g.Wi, g.Cin, g.Cout, int(accumulate), ptr(_thin_ws(x.device)),
+                                            stream_of(dy)), "tf_conv3x3_thin_wgrad_f32")
+        _census_end(_e, "conv wgrad t", _gshape(g), _gflops(g))
+        return dw
+    assert dbias is None, "conv_wgrad: dbias is only fused by the thin-output kernels (check conv_wgrad_takes_bias first)"
     if _direct_ok(x.shape, g.Cout, g.Cin, ks, stride, pad, groups) and (g.Cout <= _DIRECT_WGRAD_MAX_COUT or _DIRECT_MIN_PIXELS == 0):
         check(L().tf_conv3x3_small_wgrad_f32(ptr(_c(dy)), ptr(_c(x)), wptr(dw), g.B, g.Hi, g.Wi, g.Cin, g.Cout, int(accumulate), ptr(workspace(x.device)),
                                              stream_of(dy)), "tf_conv3x3_small_wgrad_f32")
@@ -403,6 +443,10 @@ def conv_wgrad(dy, x, dw, stride=1, pad=None, groups=1, accumulate=True):
     check(L().tf_conv2d_wgrad_f32(byref(g), ptr(_c(dy)), ptr(_c(x)), wptr(dw), int(accumulate), stream_of(dy)), "tf_conv2d_wgrad_f32")
     _census_end(_e, "conv wgrad", _gshape(g), _gflops(g))
     return dw
+
+
+def conv_wgrad_takes_bias(x_shape, cout, ks, stride=1, pad=None, groups=1):
+    return _thin_ok(x_shape, cout, x_shape[3], ks, stride, ks // 2 if pad is None else pad, groups)
 
 
 def stem_conv_fwd(s0, s1, w, normalize):

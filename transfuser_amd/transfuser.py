@@ -421,12 +421,13 @@ class _Decoder(nn.Module):
 
     def forward_nhwc(self, x):
         cfg = self.config
-        cv = lambda c, t, r: F_.ConvFn.apply(t, c.weight, c.bias, r)
+        cv = lambda c, t, r, link=0: F_.ConvFn.apply(t, c.weight, c.bias, r, link)
         x = cv(self.deconv1[2], cv(self.deconv1[0], x, True), True)
         x = F_.UpsampleFn.apply(x, x.shape[1] * int(cfg.deconv_scale_factor_1), x.shape[2] * int(cfg.deconv_scale_factor_1), False)
         x = cv(self.deconv2[2], cv(self.deconv2[0], x, True), True)
         x = F_.UpsampleFn.apply(x, x.shape[1] * int(cfg.deconv_scale_factor_2), x.shape[2] * int(cfg.deconv_scale_factor_2), False)
-        return cv(self.deconv3[2], cv(self.deconv3[0], x, True), False)
+        # the last ReLU's backward rides in the epilogue of the final layer's input-gradient kernel (one pass over the full-resolution map less)
+        return cv(self.deconv3[2], cv(self.deconv3[0], x, True, 1), False, 2)
 
 
 class SegDecoder(_Decoder):
