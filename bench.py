@@ -42,7 +42,7 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: 10 transFuser, 12 geometric_fusion, 16 latentTF)")
     ap.add_argument("--height", type=int, default=None, help="RGB height (default 256; geometric_fusion only runs at 160)")
     ap.add_argument("--backbone", default="transFuser", choices=["transFuser", "geometric_fusion", "latentTF"])
-    ap.add_argument("--dtype", default="f32", choices=["f32", "f32x3", "bf16"],
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f32x3", "bf16", "fp16"],
                     help="f32 = exact fp32 MFMA, the reference's arithmetic (headline); f32x3 = the same fp32 data with every contraction as an exact "
                          "3-way bf16 split on the bf16 MFMA (six partial products, fp32-accurate; priced against the bf16 peak / 6); "
                          "bf16 = bf16-MFMA contractions with fp32 accumulate/storage/master weights (BASELINE configs[2])")
@@ -94,6 +94,9 @@ def dominant_kernel_roofline(eng, batch, dev, log, peak=PEAK_F32_MFMA_TF):
     torch.cuda.synchronize()
     rows, ops.census = ops.census, None
     dom = [(a.elapsed_time(b) * 1e-3, fl) for kind, shape, fl, a, b in rows if (kind, tuple(shape)) == DOMINANT]
+    dom16 = not dom
+    if dom16:   # 16-bit storage modes: the same product runs as tf_gemm16_nt_f32 (mlp.0 forward and mlp.2's input gradient share the shape)
+        dom = [(a.elapsed_time(b) * 1e-3, fl) for kind, shape, fl, a, b in rows if kind == "gemm16 nt" and tuple(shape) == DOMINANT[1]]
     tot_s = sum(a.elapsed_time(b) for _, _, _, a, b in rows) * 1e-3
     tot_fl = sum(fl for _, _, fl, _, _ in rows)
     PEAK = peak
@@ -101,7 +104,8 @@ def dominant_kernel_roofline(eng, batch, dev, log, peak=PEAK_F32_MFMA_TF):
     if dom:
         sec = sum(t for t, _ in dom) / len(dom)
         ach = dom[0][1] / sec / 1e12
-        roof.update(kernel="tf::gemm_kernel / tf::gemm_dma_kernel (autotuned plan) on GPT4 mlp.0 forward: [1740x1512].[1512x6048], bias+ReLU epilogue; "
+        roof.update(kernel=("tf::gemm_dma_kernel on 16-bit STORED operands (tf_gemm16_nt_f32) on GPT4 [1740x1512].[1512x6048] (mlp.0 forward, mlp.2 input gradient); "
+                            if dom16 else "tf::gemm_kernel / tf::gemm_dma_kernel (autotuned plan) on GPT4 mlp.0 forward: [1740x1512].[1512x6048], bias+ReLU epilogue; ") +
                            "average of its %d launches inside one eager training step" % len(dom),
                     achieved=round(ach, 2), frac=round(ach / PEAK, 4), flops_per_launch=dom[0][1], avg_launch_us=round(sec * 1e6, 2))
     else:   # other backbones / shapes: the engine aggregate is the roofline entry
@@ -274,8 +278,8 @@ def main():
     hist_fn = lambda pts: ops.lidar_hist(torch.from_numpy(pts).to(dev)[None])[0].cpu().numpy()
     batch = {k: v.to(dev) for k, v in synthetic_batch(B, H, W, seed=rank, hist_fn=hist_fn).items()}
     log("model + batch on device")
-    eng = Engine(model, cfg, lr=cfg.lr, use_graph=not args.no_graph, precision={"f32": "fp32", "f32x3": "f32x3", "bf16": "bf16"}[args.dtype], grad_dtype=args.grad_dtype)
-    peak = {"f32": PEAK_F32_MFMA_TF, "f32x3": round(PEAK_BF16_MFMA_TF / 6, 1), "bf16": PEAK_BF16_MFMA_TF}[args.dtype]
+    eng = Engine(model, cfg, lr=cfg.lr, use_graph=not args.no_graph, precision={"f32": "fp32", "f32x3": "f32x3", "bf16": "bf16", "fp16": "fp16"}[args.dtype], grad_dtype=args.grad_dtype)
+    peak = {"f32": PEAK_F32_MFMA_TF, "f32x3": round(PEAK_BF16_MFMA_TF / 6, 1), "bf16": PEAK_BF16_MFMA_TF, "fp16": PEAK_BF16_MFMA_TF}[args.dtype]
     log("engine ready (arena %.1f M floats, %d backward piece(s))" % (eng.arena.numel / 1e6, eng.n_pieces()))
 
     def sync():
@@ -318,7 +322,8 @@ def main():
             "config": {"workload": "%s LidarCenterNet (RegNetY-3.2GF x2, %.1f M params) full train step, B=%d/GPU, 3x%dx%d RGB + 3x256x256 BEV, "
                                    "%s, dropout %.2f, %s" % (names[backbone], nparam / 1e6, B, H, W,
                                                              {"f32": "fp32", "f32x3": "fp32 storage/accumulate, contractions as exact bf16x3 splits on the bf16 MFMA (6 partial products, fp32-accurate)",
-                                                              "bf16": "bf16 MFMA contractions (fp32 accumulate, fp32 activations / master weights / AdamW)"}[args.dtype], args.dropout,
+                                                              "bf16": "bf16 MFMA contractions (fp32 accumulate / master weights / AdamW; GPT linear layers on bf16-STORED operands, other contractions round fp32 operands in registers)",
+                                                              "fp16": "fp16 MFMA contractions, static loss scale 1024 (fp32 accumulate / master weights / AdamW; GPT linear layers on half-STORED operands, other contractions round fp32 operands in registers)"}[args.dtype], args.dropout,
                                                                "hipGraph replay" if not args.no_graph else "eager"),
                        "global_batch": B * world, "parallelism": "dp%d" % world, "final_loss": round(loss, 4),
                        "grad_allreduce": ("RCCL, %d backward segments, %s bucket all-reduce overlapped on a side stream" % (eng.n_pieces(), args.grad_dtype)) if world > 1 else "none (1 rank)"},

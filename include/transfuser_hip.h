@@ -29,7 +29,8 @@ const char* tf_last_error(void);
 /* Compute precision of every MFMA-engine contraction (GEMMs and implicit-GEMM convolutions): 0 = exact fp32 MFMA (the reference's
  * arithmetic, config.py:55 trains fp32; default), 1 = operands rounded to bf16 (RNE) on the LDS->register path and multiplied on the bf16
  * MFMA (v_mfma_f32_32x32x16_bf16), fp32 accumulation, fp32 storage of activations / weights / gradients - the MI355X counterpart of
- * torch.autocast(bfloat16) with fp32 master weights (BASELINE configs[2]).  Tuned plans are kept per precision. */
+ * torch.autocast(bfloat16) with fp32 master weights (BASELINE configs[2]); 3 = the same with IEEE-half operands (v_mfma_f32_32x32x16_f16,
+ * BASELINE configs[4]; pair it with a loss scale, tf_adamw_scaled_f32).  Tuned plans are kept per precision (3 shares the plans of 1). */
 int tf_set_precision(int mode);
 int tf_get_precision(void);
 int tf_autotune(int enable);
@@ -101,6 +102,19 @@ int tf_conv3x3_small_fwd_f32(const float* x, const float* w, const float* bias, 
 int tf_conv3x3_small_dgrad_f32(const float* dy, const float* w, float* dx, int B, int H, int W, int Cin, int Cout, int accumulate, void* stream);
 long tf_conv3x3_small_wgrad_ws_floats(void);
 int tf_conv3x3_small_wgrad_f32(const float* dy, const float* x, float* dw, int B, int H, int W, int Cin, int Cout, int accumulate, float* ws, void* stream);
+
+/* ---- 16-bit operand STORAGE path (BASELINE configs[2] "bf16", configs[4] "fp16 MFMA"; the reference trains fp32 only, config.py:55).
+ * tf_cast16_f32: x (rows x cols fp32, row stride ldx) -> y16 (rows x cols, row stride ldy, pad columns zeroed) and / or y16t (cols x rows: the
+ * TRANSPOSE, row stride ldyt % 8 == 0, rows zero-padded to a multiple of 8); dtype 1 = bf16, 2 = IEEE half, round to nearest even.
+ * tf_gemm16_nt_f32: C (m x n fp32) (op)= alpha A16 (m x k) . B16 (n x k)^T with the fp32 epilogue of tf_gemm_f32 (bias, residual, ReLU, mask,
+ * accumulate); k, lda, ldb % 8 == 0; dtype as above (+ 16 x kind pins LDS-DMA tile configuration kind = 1..8: tests / tuning).  With the transposed copies every contraction of a linear layer (transfuser.py:500-527,540-547:
+ * y = x W^T, dx = dy W, dW = dy^T x) is such an NT product. */
+int tf_cast16_f32(const float* x, int rows, int cols, int ldx, void* y16, int ldy, void* y16t, int ldyt, int dtype, void* stream);
+int tf_gemm16_nt_f32(const void* a16, const void* b16, float* c, int m, int n, int k, int lda, int ldb, int ldc, const float* bias, const float* res, int ldres,
+                     float alpha, int relu, int accumulate, const float* mask, int ldmask, int dtype, void* stream);
+/* dst[b][2 i][2 j][:] += src[b][i][j][:] (NHWC, C % 4 == 0): the scatter half of a 1x1 / stride-2 convolution's input gradient (the RegNet
+ * downsample branches, timm Bottleneck via transfuser.py:380,442); the other half is a plain GEMM over the B Ho Wo output pixels. */
+int tf_add_strided2_f32(const float* src, float* dst, int B, int Ho, int Wo, int C, int Hi, int Wi, void* stream);
 
 /* The same layer shape with a THIN output: Cin == 32, 1 <= Cout <= 7 (the decoders' last convolution, transfuser.py:237,272: 32 -> 7 / 32 -> 1
  * at 256 x 704).  The 9 taps are folded into the GEMM's N (forward) / K (dgrad) / M (wgrad) dimension, so the launches are bandwidth-bound like
@@ -283,6 +297,9 @@ int tf_cast_bf16_f32(const uint16_t* x, float* y, int64_t n, float scale, void* 
  * on the device (step is advanced by the call, so a captured hipGraph replays correctly). */
 int tf_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, float* state_dev, float beta1, float beta2, float eps, float weight_decay,
                  void* stream);
+/* The same update with the gradients multiplied by grad_scale on the way in (= 1 / loss scale of the fp16 mode; the loss scale seeds the backward). */
+int tf_adamw_scaled_f32(float* p, const float* g, float* m, float* v, int64_t n, float* state_dev, float beta1, float beta2, float eps, float weight_decay,
+                        float grad_scale, void* stream);
 /* lidar_to_histogram_features (data.py:446-470): points (B, max_points, stride>=3) f32 -> (B,2,256,256),
  * integer-exact; num_points may be NULL. */
 int tf_lidar_hist_f32(const float* points, const int32_t* num_points, int B, int max_points, int point_stride, float* out, void* stream);

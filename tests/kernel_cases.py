@@ -765,11 +765,13 @@ def _bf(t):
     return t.bfloat16().float()
 
 
-def check_bf16_mode(dev, kind, plan, shapes=((130, 216, 40), (200, 92, 152))):
+def check_bf16_mode(dev, kind, plan, shapes=((130, 216, 40), (200, 92, 152)), mode="bf16"):
     """Engine contractions in bf16-MFMA mode: every operand is rounded to bf16 (round-to-nearest-even) on its way into the MFMA, products
     are exact, accumulation and epilogue stay fp32 - so the result must equal an fp32 GEMM of the bf16-rounded operands to fp32 summation
-    accuracy (tolerance 1e-4, NOT a loose 'bf16 tolerance').  All layouts, the masked (im2col) loaders, batched non-vector operands."""
-    ops.set_precision("bf16")
+    accuracy (tolerance 1e-4, NOT a loose 'bf16 tolerance').  All layouts, the masked (im2col) loaders, batched non-vector operands.
+    mode="fp16": the same contract with IEEE-half operands (tf_set_precision(3))."""
+    ops.set_precision(mode)
+    _bf = (lambda t: t.bfloat16().float()) if mode == "bf16" else (lambda t: t.half().float())
     (ops.force_dma if kind == "dma" else ops.force_plan)(*plan)
     try:
         for (m, n, k) in shapes:
@@ -814,6 +816,58 @@ def check_bf16_mode(dev, kind, plan, shapes=((130, 216, 40), (200, 92, 152))):
 
 
 # ---------------------------------------------------------------- f32x3 compute mode (tf_set_precision(2)): bf16x3 split, fp32-ACCURATE
+def check_lowp16_storage(dev, mode):
+    """16-bit operand STORAGE path: tf_cast16_f32 (row-major + transposed, zero-padded copies) is torch's round-to-nearest-even cast bit for
+    bit; tf_gemm16_nt_f32 equals an fp32 GEMM of the rounded operands (1e-4) for every tile kind, ragged M / N / K tails and every epilogue
+    form; the three products of a linear layer (y = x W^T, dx = dy W, dW += dy^T x) through the transposed copies."""
+    ops.set_precision(mode)
+    t16 = torch.bfloat16 if mode == "bf16" else torch.float16
+    rnd = lambda t: t.to(t16).float()
+    try:
+        assert ops.lowp_storage() == (1 if mode == "bf16" else 2)
+        for rows, cols, pad in ((70, 40, 0), (130, 216, 8), (5, 8, 0), (64, 64, 0), (1, 24, 0)):
+            x = R(rows, cols + pad, dev=dev, scale=3.0)[:, :cols]              # row stride > cols
+            y, yt = ops.cast16(x)
+            assert y.dtype == t16 and torch.equal(y.cpu(), x.cpu().to(t16)), "cast16 row-major"
+            rows8 = (rows + 7) // 8 * 8
+            assert yt.shape == (cols, rows8) and torch.equal(yt[:, :rows].cpu(), x.cpu().to(t16).t()), "cast16 transposed"
+            assert bool((yt[:, rows:].float() == 0).all()), "cast16: the pad rows of the transposed copy must be zero"
+        for kind in (0, 1, 2, 3, 5):
+            for (m, n, k) in ((130, 216, 40), (200, 96, 152), (33, 72, 8), (260, 136, 264)):
+                x, w, b, r = R(m, k, dev=dev), R(n, k, seed=3, dev=dev), R(n, seed=4, dev=dev), R(m, n, seed=5, dev=dev)
+                x16, x16t = ops.cast16(x)
+                w16, w16t = ops.cast16(w)
+                ref = rnd(x) @ rnd(w).t()
+                out = torch.empty(m, n, device=dev)
+                close(ops.gemm16_nt(x16, w16, out, kind=kind), ref, tol=1e-4, what="gemm16 plain kind %d" % kind)
+                close(ops.gemm16_nt(x16, w16, torch.empty(m, n, device=dev), bias=b, res=r, relu=True, kind=kind), torch.relu(ref + b + r), tol=1e-4, what="gemm16 bias res relu")
+                base = R(m, n, seed=6, dev=dev)
+                close(ops.gemm16_nt(x16, w16, base.clone(), accumulate=True, alpha=0.5, kind=kind), base + 0.5 * ref, tol=1e-4, what="gemm16 accumulate alpha")
+                msk = R(m, n, seed=7, dev=dev)
+                assert torch.equal(ops.gemm16_nt(x16, w16, torch.empty(m, n, device=dev), mask=msk, kind=kind), ops.gemm16_nt(x16, w16, torch.empty(m, n, device=dev), kind=kind) * (msk > 0)), "gemm16 mask"
+                # the linear-layer trio
+                dy = R(m, n, seed=8, dev=dev)
+                d16, d16t = ops.cast16(dy)
+                close(ops.gemm16_nt(d16, w16t, torch.empty(m, k, device=dev), k=n, kind=kind), rnd(dy) @ rnd(w), tol=1e-4, what="gemm16 dgrad")
+                dw0 = R(n, k, seed=9, dev=dev)
+                close(ops.gemm16_nt(d16t, x16t, dw0.clone(), accumulate=True, k=d16t.shape[1], kind=kind), dw0 + rnd(dy).t() @ rnd(x), tol=1e-4, what="gemm16 wgrad")
+    finally:
+        ops.set_precision("fp32")
+
+
+def check_conv1x1_s2_dgrad(dev):
+    """Input gradient of a 1x1 / stride-2 convolution in accumulate mode (the RegNet downsample branch): plain GEMM + scatter-add path."""
+    for (B, Hi, Wi, Cin, Cout) in ((2, 8, 8, 32, 72), (1, 9, 7, 24, 40), (2, 16, 44, 72, 216)):
+        x = R(B, Cin, Hi, Wi, dev=dev).requires_grad_(True)
+        w = (R(Cout, Cin, 1, 1, dev=dev) * 0.1).requires_grad_(True)
+        y = F.conv2d(x, w, None, 2, 0)
+        dy = R(*y.shape, seed=1, dev=dev)
+        gx = torch.autograd.grad(y, x, dy)[0]
+        base = R(B, Hi, Wi, Cin, seed=2, dev=dev)
+        got = ops.conv_dgrad(dy.permute(0, 2, 3, 1).contiguous(), w.detach().contiguous(), (B, Hi, Wi, Cin), 2, 0, 1, out=base.clone(), accumulate=True)
+        close(got, base + gx.permute(0, 2, 3, 1), what="1x1 s2 dgrad (gemm + scatter)")
+
+
 def _err64(got, ref64):
     """max |got - ref| / max |ref| against a float64 reference"""
     got = got.detach().double().cpu()
@@ -948,9 +1002,11 @@ def check_bf16_direct(dev):
             x = R(B, Cin, H, W, dev="cpu").requires_grad_(True)
             w = (R(Cout, Cin // groups, 3, 3, dev="cpu") * 0.1).requires_grad_(True)
             dy = R(B, Cout, H, W, seed=1, dev="cpu")
-            y = F.conv2d(_bf(x), _bf(w), None, 1, 1, 1, groups)
-            gx = torch.autograd.grad(F.conv2d(x, _bf(w), None, 1, 1, 1, groups), x, _bf(dy))[0]
-            gw = torch.autograd.grad(F.conv2d(_bf(x), w, None, 1, 1, 1, groups), w, _bf(dy))[0]
+            # the thin-output kernels (32 -> Cout <= 7, bandwidth-bound) multiply exact fp32 in EVERY precision mode: their reference is unrounded
+            rd = (lambda t: t) if ops._thin_ok((B, H, W, Cin), Cout, Cin, 3, 1, 1, groups) else _bf
+            y = F.conv2d(rd(x), rd(w), None, 1, 1, 1, groups)
+            gx = torch.autograd.grad(F.conv2d(x, rd(w), None, 1, 1, 1, groups), x, rd(dy))[0]
+            gw = torch.autograd.grad(F.conv2d(rd(x), w, None, 1, 1, 1, groups), w, rd(dy))[0]
             xh, wh = x.detach().permute(0, 2, 3, 1).contiguous().to(dev), cl(w.detach()).to(dev)
             dyh = dy.permute(0, 2, 3, 1).contiguous().to(dev)
             assert ops._direct_ok(xh.shape, Cout, Cin, 3, 1, 1, groups) or ops._grouped_ok(xh.shape, Cout, Cin, 3, 1, 1, groups)

@@ -151,6 +151,20 @@ def test_se_excite_fused(case):
     kc.check_se_excite("cpu", *case)
 
 
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+def test_lowp16_storage_cast_and_gemm(mode):
+    kc.check_lowp16_storage("cpu", mode)
+
+
+def test_fp16_mfma_mode():
+    kc.check_bf16_mode("cpu", "plan", (64, 64, 16, 1), mode="fp16")
+    kc.check_bf16_mode("cpu", "dma", (1, 1), mode="fp16")
+
+
+def test_conv1x1_stride2_dgrad_gemm_scatter():
+    kc.check_conv1x1_s2_dgrad("cpu")
+
+
 @pytest.mark.parametrize("case", kc.THIN_CONV_CASES, ids=str)
 def test_conv_thin_output(case):
     kc.check_conv_thin("cpu", *case)

@@ -262,3 +262,38 @@ def test_dropout_paths_match_oracle_with_the_same_masks():
     site, laid out like the product's tensors), so all 11 losses and every parameter gradient must agree as in the p = 0 tests.  The same
     check runs on the MI355X (tests/test_model_gpu.py), where the bench times exactly this p = 0.1 path."""
     mc.check_dropout_model("cpu")
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+def test_lowp_storage_modes_tiny_model(mode):
+    """16-bit operand STORAGE (ops.lowp_storage(): the GPT linear layers run on cast16 / gemm16_nt) end to end on the tiny model: the 11 losses
+    within 3e-2 of the fp32 oracle, the gradient's global cosine with the fp32 oracle's >= 0.98, and the storage path == the in-register
+    rounding path of the same precision (TF_STORE16 off) to fp32 summation accuracy - they round the same operands to the same 16-bit values."""
+    from transfuser_amd import ops
+    cfg = mc.tiny_config(n_layer=2)
+    batch = mc.small_batch(2, 32, 64, 64, 40)
+    res = {}
+    for store in (True, False):
+        prod, ref = mc.build_pair(cfg, "regnety_tiny", "cpu")
+        old = ops._STORE16
+        ops._STORE16 = store
+        ops.set_precision(mode)
+        try:
+            assert bool(ops.lowp_storage()) == store
+            lp, lr = mc.run_pair(prod, ref, cfg, batch, "cpu")
+        finally:
+            ops._STORE16 = old
+            ops.set_precision("fp32")
+        rp = dict(ref.named_parameters())
+        names = [n for n, p in prod.named_parameters() if rp[n].grad is not None]
+        gp = torch.cat([dict(prod.named_parameters())[n].grad.detach().double().flatten() for n in names])
+        gr = torch.cat([rp[n].grad.double().flatten() for n in names])
+        res[store] = ({k: float(v) for k, v in lp.items()}, gp)
+        for k in lr:
+            assert abs(float(lp[k]) - float(lr[k])) <= 3e-2 * max(1.0, abs(float(lr[k]))), (mode, store, k, float(lp[k]), float(lr[k]))
+        cos = float(torch.dot(gp, gr) / (gp.norm() * gr.norm()))
+        assert cos >= 0.98, (mode, store, cos)
+    for k in res[True][0]:
+        assert abs(res[True][0][k] - res[False][0][k]) <= 1e-4 * max(1.0, abs(res[False][0][k])), (k, res[True][0][k], res[False][0][k])
+    rel = float((res[True][1] - res[False][1]).norm() / res[False][1].norm())
+    assert rel <= 2e-3, rel

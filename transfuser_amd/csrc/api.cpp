@@ -65,7 +65,7 @@ static int g_precision = 0;
 int gemm_precision() { return g_precision; }
 }
 extern "C" int tf_set_precision(int mode) {
-    if (mode < 0 || mode > 2) { tf::set_error("tf_set_precision: mode %d (0 = fp32 MFMA, 1 = bf16 MFMA with fp32 storage/accumulate, 2 = bf16x3 split: fp32-accurate on the bf16 MFMA)", mode); return -1; }
+    if (mode < 0 || mode > 3) { tf::set_error("tf_set_precision: mode %d (0 = fp32 MFMA, 1 = bf16 MFMA with fp32 accumulate, 2 = bf16x3 split: fp32-accurate on the bf16 MFMA, 3 = fp16 MFMA with fp32 accumulate)", mode); return -1; }
     tf::g_precision = mode;
     return 0;
 }

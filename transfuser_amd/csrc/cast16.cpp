@@ -1,0 +1,97 @@
+// 16-bit operand copies for the packed-16 GEMM path (tf_gemm16_nt_f32; BASELINE configs[2] "bf16" and configs[4] "fp16 MFMA"):
+// fp32 activations / weights / gradients are written ONCE as bf16 or IEEE-half matrices - row-major and / or TRANSPOSED - so that every
+// contraction of a linear layer is an "NT" GEMM with both operands K-contiguous:
+//   y  = x W^T          : x16  [M][K]   . W16  [N][K]
+//   dx = dy W           : dy16 [M][N]   . W16T [K][N]
+//   dW = dy^T x         : dy16T [N][M]  . x16T [K][M]       (contraction over the M rows: the transposed copies, zero-padded to M % 8 == 0)
+// One pass over the fp32 source produces both copies (64 x 64 tiles, the transpose goes through LDS, 16-byte stores on both sides).
+// Round to nearest even in both formats; the reference trains fp32 (config.py:55) - the 16-bit modes are this framework's own.
+#include "tf_common.h"
+#include "../../include/transfuser_hip.h"
+
+using namespace tf;
+
+namespace {
+
+constexpr int TS = 64;            // tile side
+constexpr int TP = TS + 8;        // LDS row pitch in halves (16-byte aligned rows, bank spread)
+
+// y16[r][c] (ld ldy) and / or y16t[c][r] (ld ldyt) from x[r][c] (ld ldx); pad columns of y16 (cols .. ldy) and pad rows of y16t (rows .. rows8) are zeroed
+__global__ void __launch_bounds__(256) cast16_kernel(const float* __restrict__ x, int rows, int cols, long ldx, uint16_t* __restrict__ y, long ldy,
+                                                     uint16_t* __restrict__ yt, long ldyt, int f16, int vec) {
+    __shared__ __attribute__((aligned(16))) uint16_t T[TS * TP];
+    const int tid = threadIdx.x, r0 = blockIdx.y * TS, c0 = blockIdx.x * TS;
+    const int c4 = (tid & 15) * 4;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int row = it * 16 + (tid >> 4), r = r0 + row, c = c0 + c4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (r < rows) {
+            if (vec && c + 3 < cols) { const float4 q = *reinterpret_cast<const float4*>(x + (long)r * ldx + c); v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w; }
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (c + e < cols) v[e] = x[(long)r * ldx + c + e];
+            }
+        }
+        uint16_t h[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h[e] = cvt16_bits(v[e], f16 != 0);
+        if (y && r < rows) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (c + e < ldy) y[(long)r * ldy + c + e] = (c + e < cols) ? h[e] : (uint16_t)0;
+        }
+        if (yt) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) T[(c4 + e) * TP + row] = h[e];
+        }
+    }
+    if (!yt) return;
+    __syncthreads();
+    const int rows8 = (rows + 7) & ~7;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int id = p * 256 + tid, col = id >> 3, rc = (id & 7) * 8;
+        if (c0 + col < cols && r0 + rc < rows8) {
+            const float4 q = *reinterpret_cast<const float4*>(T + col * TP + rc);      // 8 halves = 16 bytes
+            *reinterpret_cast<float4*>(yt + (long)(c0 + col) * ldyt + r0 + rc) = q;
+        }
+    }
+}
+
+// dst[b][2 i][2 j][:] += src[b][i][j][:]  (input gradient of a 1x1 / stride-2 convolution = a plain GEMM + this scatter)
+__global__ void __launch_bounds__(256) add_strided2_kernel(const float* __restrict__ src, float* __restrict__ dst, int Ho, int Wo, int C4, int Hi, int Wi, long n4) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C4);
+        long p = i / C4;
+        const int j = (int)(p % Wo); p /= Wo;
+        const int ii = (int)(p % Ho);
+        const long b = p / Ho;
+        float4* d = reinterpret_cast<float4*>(dst) + ((b * Hi + 2 * ii) * Wi + 2 * j) * C4 + c;
+        const float4 s = reinterpret_cast<const float4*>(src)[i];
+        float4 v = *d;
+        v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w;
+        *d = v;
+    }
+}
+
+}  // namespace
+
+extern "C" int tf_cast16_f32(const float* x, int rows, int cols, int ldx, void* y16, int ldy, void* y16t, int ldyt, int dtype, void* stream) {
+    TF_REQUIRE(x && rows > 0 && cols > 0 && ldx >= cols && (y16 || y16t) && (dtype == 1 || dtype == 2), "tf_cast16_f32: bad arguments (dtype 1 = bf16, 2 = fp16)");
+    TF_REQUIRE(!y16 || ldy >= cols, "tf_cast16_f32: ldy < cols");
+    TF_REQUIRE(!y16t || (ldyt >= ((rows + 7) & ~7) && ldyt % 8 == 0 && aligned16(y16t)), "tf_cast16_f32: the transposed copy needs ldyt %% 8 == 0, ldyt >= rows rounded up to 8, 16-byte aligned");
+    const int vec = (aligned16(x) && ldx % 4 == 0) ? 1 : 0;
+    TF_LAUNCH(cast16_kernel, dim3(cdiv(cols, TS), cdiv(rows, TS)), dim3(256), stream, x, rows, cols, (long)ldx, (uint16_t*)y16, (long)ldy, (uint16_t*)y16t, (long)ldyt,
+              dtype == 2 ? 1 : 0, vec);
+    return launch_status("tf_cast16_f32");
+}
+
+extern "C" int tf_add_strided2_f32(const float* src, float* dst, int B, int Ho, int Wo, int C, int Hi, int Wi, void* stream) {
+    TF_REQUIRE(src && dst && B > 0 && Ho > 0 && Wo > 0 && C > 0 && C % 4 == 0 && 2 * Ho - 1 <= Hi && 2 * Wo - 1 <= Wi && aligned16(src) && aligned16(dst),
+               "tf_add_strided2_f32: needs C %% 4 == 0, 16-byte aligned tensors and (2 Ho - 1, 2 Wo - 1) <= (Hi, Wi)");
+    const long n4 = (long)B * Ho * Wo * (C / 4);
+    long blocks = (n4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    TF_LAUNCH(add_strided2_kernel, dim3((int)blocks), dim3(256), stream, src, dst, Ho, Wo, C / 4, Hi, Wi, n4);
+    return launch_status("tf_add_strided2_f32");
+}

@@ -21,7 +21,7 @@ constexpr int PP = 33;                         // floats per patch pixel (32 cha
 constexpr int WP = 36;                         // pitch of a weight row (32 output channels + 4)
 constexpr int NV = (PH * PW * 8 + 255) / 256;  // float4 patch slots per thread
 
-struct DcGeom { int B, H, W, Ci, Co, tiles_h, tiles_w, ntiles; };
+struct DcGeom { int B, H, W, Ci, Co, tiles_h, tiles_w, ntiles, f16; };   // f16: the PREC 1 paths use IEEE-half operands (tf_set_precision(3))
 
 // stage W into LDS as wl[(tap, k)][n]: fwd  wl[tap][ci][co] = Wt[co][tap][ci];  dgrad  wl[tap][co][ci] = Wt[co][8 - tap][ci]
 __device__ __forceinline__ void load_weights(float (*wl)[WP], const float* __restrict__ w, int CoW, int CiW, int dgrad) {
@@ -92,7 +92,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_small_kernel(const float* __re
                     const int k0 = 16 * q + 8 * hi;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) { a[j] = pa[k0 + j]; b[j] = wl[tap * 32 + k0 + j][l31]; }
-                    if constexpr (PREC == 2) mfma_32x32x16_x3(a, b, acc); else mfma_32x32x16_bf16(a, b, acc);
+                    if constexpr (PREC == 2) mfma_32x32x16_x3(a, b, acc); else mfma_32x32x16_lp(a, b, acc, g.f16 ? 3 : 1);
                 }
             }
         } else {
@@ -279,7 +279,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_small_wgrad_kernel(const float
                     for (int tap = 0; tap < 9; ++tap) mfma_x3_presplit(fa, split_bf16x3(b[tap]), acc[tap]);
                 } else {
 #pragma unroll
-                    for (int tap = 0; tap < 9; ++tap) mfma_32x32x16_bf16(a, b[tap], acc[tap]);
+                    for (int tap = 0; tap < 9; ++tap) mfma_32x32x16_lp(a, b[tap], acc[tap], g.f16 ? 3 : 1);
                 }
             }
         } else {
@@ -334,13 +334,13 @@ __global__ void __launch_bounds__(256) conv3x3_small_wgrad_reduce_kernel(const f
 inline int direct_prec() {
     static const bool x3 = [] { const char* e = getenv("TF_X3_DIRECT"); return !e || atoi(e) != 0; }();
     const int p = tf::gemm_precision();
-    return (p == 2 && !x3) ? 0 : p;
+    return (p == 2 && !x3) ? 0 : (p == 3 ? 1 : p);      // fp16 mode runs the PREC 1 instantiations with DcGeom.f16 set
 }
 
 inline bool presplit_enabled() { static const bool on = [] { const char* e = getenv("TF_X3_PRESPLIT"); return !e || atoi(e) != 0; }(); return on; }
 
 inline DcGeom make_geom(int B, int H, int W, int Ci, int Co) {
-    DcGeom g; g.B = B; g.H = H; g.W = W; g.Ci = Ci; g.Co = Co;
+    DcGeom g; g.B = B; g.H = H; g.W = W; g.Ci = Ci; g.Co = Co; g.f16 = tf::gemm_precision() == 3 ? 1 : 0;
     g.tiles_h = cdiv(H, TH); g.tiles_w = cdiv(W, TW); g.ntiles = B * g.tiles_h * g.tiles_w;
     return g;
 }

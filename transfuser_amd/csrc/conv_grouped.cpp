@@ -23,7 +23,7 @@ constexpr int CG = 24;              // channels per group (in and out)
 constexpr int PP = 25;              // floats per patch pixel: 24 channels + 1 (odd pitch: conflict-free MFMA A fetch)
 constexpr int WP = 36;              // pitch of a weight row (32 output columns + 4)
 
-struct GcGeom { int B, H, W, C, G, tiles_h, tiles_w, ntiles, nb; };   // C = total channels (pixel stride), nb = blocks per group
+struct GcGeom { int B, H, W, C, G, tiles_h, tiles_w, ntiles, nb, f16; };   // f16: the bf16 paths use IEEE-half operands instead (tf_set_precision(3))   // C = total channels (pixel stride), nb = blocks per group
 
 template <int TW> struct Tile {
     static constexpr int RW = 32 / TW;            // image rows per wave
@@ -115,7 +115,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_grouped_kernel(const float* __
                         a[j] = live ? pa[k0 + j] : 0.f;
                         b[j] = live ? wl[tap * CG + k0 + j][l31] : 0.f;
                     }
-                    if constexpr (X3) mfma_32x32x16_x3(a, b, acc); else mfma_32x32x16_bf16(a, b, acc);
+                    if constexpr (X3) mfma_32x32x16_x3(a, b, acc); else mfma_32x32x16_lp(a, b, acc, prec);
                 }
             }
         } else if constexpr (!X3) {
@@ -259,7 +259,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_grouped_wgrad_kernel(const flo
                     for (int tap = 0; tap < 9; ++tap) mfma_x3_presplit(fa, split_bf16x3(b[tap]), acc[tap]);
                 } else {
 #pragma unroll
-                    for (int tap = 0; tap < 9; ++tap) mfma_32x32x16_bf16(a, b[tap], acc[tap]);
+                    for (int tap = 0; tap < 9; ++tap) mfma_32x32x16_lp(a, b[tap], acc[tap], g.f16 ? 3 : 1);
                 }
             }
         } else {
@@ -327,7 +327,7 @@ inline int fwd_prec() {
 }
 
 inline GcGeom make_geom(int B, int H, int W, int C, int TW, int max_blocks = kMaxBlocks) {
-    GcGeom g; g.B = B; g.H = H; g.W = W; g.C = C; g.G = C / CG;
+    GcGeom g; g.B = B; g.H = H; g.W = W; g.C = C; g.G = C / CG; g.f16 = tf::gemm_precision() == 3 ? 1 : 0;
     const int th = TW == 16 ? 8 : 4;
     g.tiles_h = cdiv(H, th); g.tiles_w = cdiv(W, TW); g.ntiles = B * g.tiles_h * g.tiles_w;
     int nb = max_blocks / g.G;
@@ -403,8 +403,8 @@ extern "C" int tf_conv3x3_grouped_wgrad_f32(const float* dy, const float* x, flo
     TF_REQUIRE((long)g.G * g.nb * 9216 <= tf_conv3x3_grouped_wgrad_ws_floats(), "tf_conv3x3_grouped_wgrad_f32: %d groups exceed the workspace", g.G);
     const int prec = direct_prec();
 #define TF_GW(TW_, P_) TF_LAUNCH((conv3x3_grouped_wgrad_kernel<TW_, P_>), dim3(g.G * g.nb), dim3(256), stream, x, dy, ws, g)
-    if (tw == 16) { if (prec == 2) TF_GW(16, 2); else if (prec == 1) TF_GW(16, 1); else TF_GW(16, 0); }
-    else { if (prec == 2) TF_GW(32, 2); else if (prec == 1) TF_GW(32, 1); else TF_GW(32, 0); }
+    if (tw == 16) { if (prec == 2) TF_GW(16, 2); else if (prec == 1 || prec == 3) TF_GW(16, 1); else TF_GW(16, 0); }
+    else { if (prec == 2) TF_GW(32, 2); else if (prec == 1 || prec == 3) TF_GW(32, 1); else TF_GW(32, 0); }
 #undef TF_GW
     TF_LAUNCH(conv3x3_grouped_wgrad_reduce_kernel, dim3(36, g.G), dim3(256), stream, (const float*)ws, g.nb, dw, accumulate);
     return launch_status("tf_conv3x3_grouped_wgrad_f32");

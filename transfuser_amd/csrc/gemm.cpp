@@ -1,5 +1,6 @@
 // tf_gemm_f32: batched strided fp32 GEMM on the MFMA engine (plain operands).
 #include "tf_gemm_engine.h"
+#include <stdlib.h>
 #include "../../include/transfuser_hip.h"
 
 using namespace tf;
@@ -33,7 +34,7 @@ extern "C" long tf_gemm_splitk_ws_floats(const tf_gemm_desc* d) {
     int M = d->m, N = d->n;
     if (d->a_trans && d->b_trans && d->m <= 32 && d->n >= 2 * d->m && !d->bias && !d->res && !d->relu) return 0;       // swapped (column-strided) output: no two-pass
     const bool sk_ok = d->accumulate && !d->bias && !d->res && !d->relu;
-    const int acc = (d->accumulate ? (sk_ok ? 2 : 1) : 0) + 4 * gemm_precision();
+    const int acc = (d->accumulate ? (sk_ok ? 2 : 1) : 0) + 4 * (gemm_precision() == 3 ? 1 : gemm_precision());
     if (plan_lookup(site, M, N, d->k, 1, acc, &p)) return p.splitk >= kTwoPass ? (long)(p.splitk - kTwoPass) * slice : 0;
     return autotune_enabled() ? 4 * slice : 0;
 }
@@ -84,4 +85,35 @@ extern "C" int tf_gemm_f32(const tf_gemm_desc* d, void* stream) {
         return launch_gemm<PlainOp, false, PlainOp, false>(A, B, ep, d->m, d->n, d->k, d->batch, sk, stream, "tf_gemm_f32[tn]");
     }
     return launch_gemm<PlainOp, false, PlainOp, true>(A, B, ep, d->m, d->n, d->k, d->batch, sk, stream, "tf_gemm_f32[tt]");
+}
+
+// ---- packed 16-bit operands: C (op)= alpha * A16 . B16^T (+ bias) (+ res) (relu) (mask), fp32 accumulate / output.
+// A16 [m][k] and B16 [n][k] are bf16 (dtype 1) or IEEE-half (dtype 2) matrices with k contiguous; k % 8 == 0, lda % 8 == 0, ldb % 8 == 0, 16-byte
+// aligned bases (tf_cast16_f32 produces them).  Runs on the LDS-DMA "nt" kernels: the tiles are moved as bytes (a row of 2 BK halves has the
+// byte geometry of BK floats), every ds_read_b128 fragment is one operand of v_mfma_f32_32x32x16_{bf16,f16}.
+extern "C" int tf_gemm16_nt_f32(const void* a16, const void* b16, float* c, int m, int n, int k, int lda, int ldb, int ldc, const float* bias, const float* res,
+                                int ldres, float alpha, int relu, int accumulate, const float* mask, int ldmask, int dtype, void* stream) {
+    TF_REQUIRE(a16 && b16 && c && m > 0 && n > 0 && k > 0, "tf_gemm16_nt_f32: bad sizes m=%d n=%d k=%d", m, n, k);
+    const int pin = dtype >> 4;        // bits 4..: pin an LDS-DMA tile configuration (tests / tuning); 0 = heuristic
+    dtype &= 15;
+    TF_REQUIRE((dtype == 1 || dtype == 2) && k % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= k && ldb >= k && aligned16(a16) && aligned16(b16),
+               "tf_gemm16_nt_f32: needs dtype 1 (bf16) / 2 (fp16), k, lda, ldb multiples of 8 and 16-byte aligned operands (got k=%d lda=%d ldb=%d)", k, lda, ldb);
+    TF_REQUIRE(!mask || !accumulate, "tf_gemm16_nt_f32: mask needs a plain store");
+    GemmEpi ep;
+    ep.C = c; ep.ldc = ldc; ep.ldcj = 1; ep.sc_outer = 0; ep.sc_inner = 0; ep.inner = 1;
+    ep.bias = bias; ep.sbias = 0; ep.res = res; ep.ldres = ldres; ep.alpha = alpha; ep.relu = relu; ep.mode = accumulate ? 1 : 0;
+    ep.mask = mask; ep.ldmask = ldmask;
+    ep.packed16 = dtype;
+    // the operands in units of 4 bytes
+    PlainOp A = make_plain(reinterpret_cast<const float*>(a16), lda / 2, m, k / 2, 0, 0, 1, 1);
+    PlainOp B = make_plain(reinterpret_cast<const float*>(b16), ldb / 2, n, k / 2, 0, 0, 1, 1);
+    TF_REQUIRE(A.vec && B.vec && dma_eligible(A, B), "tf_gemm16_nt_f32: operands are not LDS-DMA eligible (alignment / 2 GiB)");
+    // tile choice: 128 x 128 (BK = 64 halves, 2 stages) when that fills the 256 CUs, else 128 x 64, else 64 x 64 (TF_G16_KIND pins a kind for experiments)
+    static const int forced = [] { const char* e = getenv("TF_G16_KIND"); return e ? atoi(e) : 0; }();
+    const long t128 = (long)cdiv(m, 128) * cdiv(n, 128), t12864 = (long)cdiv(m, 128) * cdiv(n, 64);
+    int kind = t128 >= 384 ? 5 : (t12864 >= 256 ? 3 : 2);
+    if (forced >= 1 && forced <= kDmaKinds) kind = forced;
+    if (pin >= 1 && pin <= kDmaKinds) kind = pin;
+    launch_dma_plan<true, true>(kind, A, B, ep, m, n, k / 2, 1, 1, stream);
+    return launch_status("tf_gemm16_nt_f32");
 }

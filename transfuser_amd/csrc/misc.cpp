@@ -62,7 +62,7 @@ __global__ void adamw_tick_kernel(float* state) {
     if (threadIdx.x == 0 && blockIdx.x == 0) state[0] += 1.f;
 }
 __global__ void __launch_bounds__(256) adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                                                    long n4, long n, const float* __restrict__ state, float b1, float b2, float eps, float wd) {
+                                                    long n4, long n, const float* __restrict__ state, float b1, float b2, float eps, float wd, float gs) {
     const float step = state[0], lr = state[1];
     const float bc1 = 1.f - powf(b1, step), bc2 = 1.f - powf(b2, step);
     const float step_size = lr / bc1, inv_sq_bc2 = 1.f / sqrtf(bc2), decay = 1.f - lr * wd;
@@ -72,6 +72,7 @@ __global__ void __launch_bounds__(256) adamw_kernel(float* __restrict__ p, const
         float* P = &pp.x; float* G = &gg.x; float* M = &mm.x; float* V = &vv.x;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
+            G[k] *= gs;                 // 1 / loss scale (exactly 1.0f in the fp32 / bf16 modes: bit-identical to the unscaled update)
             P[k] *= decay;
             M[k] = b1 * M[k] + (1.f - b1) * G[k];
             V[k] = b2 * V[k] + (1.f - b2) * G[k] * G[k];
@@ -83,7 +84,7 @@ __global__ void __launch_bounds__(256) adamw_kernel(float* __restrict__ p, const
     }
     // tail
     for (long i = n4 * 4 + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-        float P = p[i] * decay, G = g[i];
+        float P = p[i] * decay, G = g[i] * gs;
         float M = b1 * m[i] + (1.f - b1) * G, V = b2 * v[i] + (1.f - b2) * G * G;
         p[i] = P - step_size * (M / (sqrtf(V) * inv_sq_bc2 + eps));
         m[i] = M; v[i] = V;
@@ -169,13 +170,19 @@ extern "C" int tf_cast_bf16_f32(const uint16_t* x, float* y, int64_t n, float sc
     TF_LAUNCH(cast_bf16_f32_kernel, dim3(ew_blocks(n)), dim3(256), stream, x, y, (long)n, scale);
     return launch_status("tf_cast_bf16_f32");
 }
+extern "C" int tf_adamw_scaled_f32(float* p, const float* g, float* m, float* v, int64_t n, float* state_dev, float beta1, float beta2, float eps,
+                                   float weight_decay, float grad_scale, void* stream);
 extern "C" int tf_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, float* state_dev, float beta1, float beta2, float eps,
                             float weight_decay, void* stream) {
+    return tf_adamw_scaled_f32(p, g, m, v, n, state_dev, beta1, beta2, eps, weight_decay, 1.0f, stream);
+}
+extern "C" int tf_adamw_scaled_f32(float* p, const float* g, float* m, float* v, int64_t n, float* state_dev, float beta1, float beta2, float eps,
+                                   float weight_decay, float grad_scale, void* stream) {
     TF_REQUIRE(p && g && m && v && state_dev && n >= 0, "tf_adamw_f32: bad arguments");
     TF_REQUIRE(aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v), "tf_adamw_f32: arenas must be 16-byte aligned");
     TF_LAUNCH(adamw_tick_kernel, dim3(1), dim3(64), stream, state_dev);
     if (n > 0) TF_LAUNCH(adamw_kernel, dim3(ew_blocks(n / 4 + 1, 8192)), dim3(256), stream, p, g, m, v, (long)(n / 4), (long)n, (const float*)state_dev,
-                         beta1, beta2, eps, weight_decay);
+                         beta1, beta2, eps, weight_decay, grad_scale);
     return launch_status("tf_adamw_f32");
 }
 extern "C" int tf_lidar_hist_f32(const float* points, const int32_t* num_points, int B, int max_points, int point_stride, float* out, void* stream) {

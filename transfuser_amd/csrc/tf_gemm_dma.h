@@ -261,11 +261,33 @@ __device__ __forceinline__ void gemm_dma_tile(const PlainOp& la_in, const PlainO
 #pragma unroll
                 for (int t = 0; t < TM; ++t)
 #pragma unroll
-                    for (int u = 0; u < TN; ++u) mfma_32x32x16_bf16(a[t], b[u], acc[t][u]);
+                    for (int u = 0; u < TN; ++u) mfma_32x32x16_lp(a[t], b[u], acc[t][u], ep.prec);
             }
         }
     };
     const bool lowp = ep.prec != 0;
+    // 16-bit STORAGE operands (ep.packed16; both operands K-contiguous): the tile rows are 2 BK halves long, every b128 fragment read IS the
+    // lane's 8-deep operand of one v_mfma_f32_32x32x16_{bf16,f16} (chunk 2q + hi = k 16 q + 8 hi .. + 7: natural order) - no conversion,
+    // half the L2 / LDS bytes of the fp32-storage modes per MFMA flop
+    auto compute16 = [&](int slot) {
+        if constexpr (A_KC && B_KC) {
+            const float* As = smem + slot * C::STAGE_FL;
+            const float* Bs = As + C::A_FL;
+            const bool f16 = ep.packed16 == 2;
+#pragma unroll
+            for (int q = 0; q < QN; ++q) {
+                float4 a[TM], b[TN];
+#pragma unroll
+                for (int t = 0; t < TM; ++t) a[t] = *reinterpret_cast<const float4*>(As + a_off + t * 32 * BK + (((2 * q + hi) ^ sw) * 4));
+#pragma unroll
+                for (int t = 0; t < TN; ++t) b[t] = *reinterpret_cast<const float4*>(Bs + b_off + t * 32 * BK + (((2 * q + hi) ^ sw) * 4));
+#pragma unroll
+                for (int t = 0; t < TM; ++t)
+#pragma unroll
+                    for (int u = 0; u < TN; ++u) mfma_packed16(a[t], b[u], acc[t][u], f16);
+            }
+        }
+    };
 
     // ---- pipeline: STAGES-1 tiles in flight; iteration t: wait for tile t (counted), barrier (also frees slot (t-1) % STAGES for
     // everyone), request tile t + STAGES - 1 into that slot, multiply tile t.
@@ -278,6 +300,7 @@ __device__ __forceinline__ void gemm_dma_tile(const PlainOp& la_in, const PlainO
         dma_barrier<NW>();
         issue(kt + STAGES - 1, nxt);
         if constexpr (X3) compute_bf16(cur);
+        else if constexpr (A_KC && B_KC) { if (ep.packed16) compute16(cur); else if (lowp) compute_bf16(cur); else compute(cur); }
         else { if (lowp) compute_bf16(cur); else compute(cur); }
         cur = cur + 1 == STAGES ? 0 : cur + 1;
         nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
@@ -317,7 +340,7 @@ inline void launch_dma_cfg(const PlainOp& la, const PlainOp& lb, const GemmEpi& 
     const int nsplit = cdiv(K, kchunk);
     dim3 grid(tiles_m * tiles_n, nsplit > 0 ? nsplit : 1, batch);
     GemmEpi epg = ep;
-    epg.prec = gemm_precision();
+    epg.prec = ep.packed16 ? 0 : gemm_precision();
     const int ldws = twopass_ldws(N);
     if (twopass) {      // slices store raw partial sums [M][ldws] into the caller's scratch; the epilogue proper runs in the fix-up pass
         epg.C = ep.sk_ws; epg.ldc = ldws; epg.ldcj = 1; epg.sc_outer = epg.sc_inner = 0; epg.inner = 1; epg.bias = nullptr; epg.res = nullptr;
@@ -332,7 +355,7 @@ inline void launch_dma_cfg(const PlainOp& la, const PlainOp& lb, const GemmEpi& 
     }
     if (twopass || nsplit > 1) epg.stat = nullptr;          // (launch_gemm never sends a statistics request down a k-split plan)
     if (epg.stat_nparts) *epg.stat_nparts = epg.stat ? cdiv(M, 32 * TM) : 0;
-    if (epg.prec == 2)
+    if (epg.prec == 2 && !ep.packed16)
         TF_LAUNCH((gemm_dma_kernel<TM, TN, WAVES_M, WAVES_N, BK, STAGES, A_KC, B_KC, OCC, true>), grid, dim3(C::NT), stream, la, lb, epg, M, N, K,
                   tiles_m, tiles_n, kchunk);
     else

@@ -251,7 +251,9 @@ struct GemmEpi {
     // merges the parts (Chan's formula).  Only for plain stores (mode 0, no residual / ReLU / mask / split-K).  stat_nparts: HOST pointer,
     // set at launch time to the number of parts this launch writes (0: the chosen plan cannot produce them - caller falls back).
     float* stat = nullptr; long stat_ld = 0; int* stat_nparts = nullptr;
-    int prec = 0;                    // 0: exact fp32 MFMA; 1: operands rounded to bf16 on the LDS->register path, bf16 MFMA, fp32 accumulate; 2: bf16x3 split (fp32-accurate, 6 bf16 MFMAs) (set by launch_cfg)
+    int prec = 0;                    // 0: exact fp32 MFMA; 1: operands rounded to bf16 on the LDS->register path, bf16 MFMA, fp32 accumulate; 2: bf16x3 split (fp32-accurate, 6 bf16 MFMAs); 3: as 1 with IEEE-half operands (set by launch_cfg)
+    int packed16 = 0;                // LDS-DMA kernels, both operands K-contiguous: the operands ARE 16-bit matrices (1: bf16, 2: IEEE half) described in units of
+                                     // 4 bytes (ld, cols, K = halves / 2): tiles are moved as bytes, one ds_read_b128 = one 8-deep MFMA operand (tf_gemm16_nt_f32)
 };
 
 int gemm_precision();   // api.cpp: process-wide compute precision of the engine (tf_set_precision)
@@ -597,10 +599,10 @@ __device__ __forceinline__ void gemm_tile(LA& la, LB& lb, const GemmEpi& ep, int
 #pragma unroll
             for (int t = 0; t < TM; ++t)
 #pragma unroll
-                for (int u = 0; u < TN; ++u) mfma_32x32x16_bf16(a[t], b[u], acc[t][u]);
+                for (int u = 0; u < TN; ++u) mfma_32x32x16_lp(a[t], b[u], acc[t][u], ep.prec);
         }
     };
-    const bool lowp = ep.prec == 1;      // precision 2 (bf16x3 split) exists in the LDS-DMA kernels only: this kernel then stays on the exact fp32 MFMA
+    const bool lowp = ep.prec == 1 || ep.prec == 3;      // precision 2 (bf16x3 split) exists in the LDS-DMA kernels only: this kernel then stays on the exact fp32 MFMA
     auto mult = [&](int cur) { if (lowp) compute_bf16(cur); else compute(cur); };
 
     if constexpr (CANFAST) {
@@ -910,7 +912,7 @@ inline int launch_gemm(const LA& la, const LB& lb, GemmEpi ep, int M, int N, int
     if (M <= 0 || N <= 0 || batch <= 0) return 0;
     // split-K only for pure accumulations (weight gradients into the grad arena): atomic epilogue
     const bool sk_ok = allow_splitk && ep.mode == 1 && !ep.bias && !ep.res && !ep.relu;
-    const int acc = (ep.mode != 0 ? (sk_ok ? 2 : 1) : 0) + 4 * gemm_precision();   // plans are tuned per compute precision
+    const int acc = (ep.mode != 0 ? (sk_ok ? 2 : 1) : 0) + 4 * (gemm_precision() == 3 ? 1 : gemm_precision());   // plans are tuned per compute precision (fp16 shares the bf16 plans)
     GemmPlan p;
     if (forced_plan(&p)) {
         if (!sk_ok && p.splitk < kTwoPass) p.splitk = 1;

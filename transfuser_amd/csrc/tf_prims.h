@@ -86,9 +86,54 @@ __forceinline__ Bf16x3 split_bf16x3(const float (&a)[8]) {
     return f;
 }
 __forceinline__ void mfma_bf16_raw(const float (&a)[8], const float (&b)[8], f32x16& acc) { mfma_32x32x16_bf16(a, b, acc); }   // operands are bf16 values: re-rounding is the identity
-// packed bf16 planes (pre-split operands kept in LDS): one dword = two consecutive k elements, element 0 in the low half
 __forceinline__ uint32_t emu_bf16_bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u >> 16; }
 __forceinline__ float emu_bf16_from_bits(uint32_t b) { uint32_t u = b << 16; float f; memcpy(&f, &u, 4); return f; }
+// IEEE half <-> float (software, round to nearest even) for the fp16 compute / storage mode (tf_set_precision(3))
+__forceinline__ uint16_t emu_f16_bits(float f) { const _Float16 h = (_Float16)f; uint16_t b; memcpy(&b, &h, 2); return b; }
+__forceinline__ float emu_f16_from_bits(uint16_t b) { _Float16 h; memcpy(&h, &b, 2); return (float)h; }
+__forceinline__ float emu_f16_round(float f) { return emu_f16_from_bits(emu_f16_bits(f)); }
+// exact products of the given (already 16-bit representable) operand values, fp32 accumulation in k order: the common tail of the 16-deep MFMAs
+__forceinline__ void emu_mfma16_values(const float (&a)[8], const float (&b)[8], f32x16& acc) {
+    float* s = emu::wave_scratch();
+    const int l = lane_id(), jc = l & 31, hi = l >> 5;
+    for (int j = 0; j < 8; ++j) {
+        s[l] = a[j];
+        s[64 + l] = b[j];
+        emu::wave_barrier();
+        for (int r = 0; r < 16; ++r) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            float c = acc[r];
+            c = fmaf(s[i], s[64 + jc], c);
+            c = fmaf(s[32 + i], s[64 + 32 + jc], c);
+            acc[r] = c;
+        }
+        emu::wave_barrier();
+    }
+}
+// v_mfma_f32_32x32x16_f16 with fp32 inputs rounded to half (RNE); layouts as mfma_32x32x16_bf16
+__forceinline__ void mfma_32x32x16_f16(const float (&a)[8], const float (&b)[8], f32x16& acc) {
+    float x[8], y[8];
+    for (int j = 0; j < 8; ++j) { x[j] = emu_f16_round(a[j]); y[j] = emu_f16_round(b[j]); }
+    emu_mfma16_values(x, y, acc);
+}
+// PACKED 16-bit operands (16-bit STORAGE path): a float4 carries the lane's 8 consecutive k elements, element 0 in the low half of .x
+__forceinline__ void mfma_packed16(const float4& a, const float4& b, f32x16& acc, bool f16) {
+    uint32_t wa[4], wb[4];
+    memcpy(wa, &a, 16); memcpy(wb, &b, 16);
+    float x[8], y[8];
+    for (int d = 0; d < 4; ++d) {
+        if (f16) {
+            x[2 * d] = emu_f16_from_bits((uint16_t)(wa[d] & 0xffffu)); x[2 * d + 1] = emu_f16_from_bits((uint16_t)(wa[d] >> 16));
+            y[2 * d] = emu_f16_from_bits((uint16_t)(wb[d] & 0xffffu)); y[2 * d + 1] = emu_f16_from_bits((uint16_t)(wb[d] >> 16));
+        } else {
+            x[2 * d] = emu_bf16_from_bits(wa[d] & 0xffffu); x[2 * d + 1] = emu_bf16_from_bits(wa[d] >> 16);
+            y[2 * d] = emu_bf16_from_bits(wb[d] & 0xffffu); y[2 * d + 1] = emu_bf16_from_bits(wb[d] >> 16);
+        }
+    }
+    emu_mfma16_values(x, y, acc);
+}
+__forceinline__ uint16_t cvt16_bits(float f, bool f16) { return f16 ? emu_f16_bits(f) : (uint16_t)emu_bf16_bits(emu_bf16_round(f)); }
+// packed bf16 planes (pre-split operands kept in LDS): one dword = two consecutive k elements, element 0 in the low half
 __forceinline__ void split_pair_bf16x3(float a, float b, uint32_t& h, uint32_t& m, uint32_t& l) {
     const float ha = emu_bf16_round(a), hb = emu_bf16_round(b);
     const float ra = a - ha, rb = b - hb;
@@ -184,10 +229,32 @@ __device__ __forceinline__ Bf16x3 frag_from_planes(const uint32_t* h, const uint
 __device__ __forceinline__ void mfma_bf16_raw(const bf16x8& a, const bf16x8& b, f32x16& acc) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
 }
+// fp16 compute mode (tf_set_precision(3)): fp32 operands rounded to IEEE half in registers (v_cvt_f16_f32 / pack, RNE) -> v_mfma_f32_32x32x16_f16
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void mfma_32x32x16_f16(const float (&a)[8], const float (&b)[8], f32x16& acc) {
+    f32x8 x, y;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { x[j] = a[j]; y[j] = b[j]; }
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_convertvector(x, f16x8), __builtin_convertvector(y, f16x8), acc, 0, 0, 0);
+}
+// PACKED 16-bit operands (16-bit STORAGE path): a float4 (one ds_read_b128) carries the lane's 8 consecutive k elements
+__device__ __forceinline__ void mfma_packed16(const float4& a, const float4& b, f32x16& acc, bool f16) {
+    if (f16) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
+    else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+__device__ __forceinline__ uint16_t cvt16_bits(float f, bool f16) {
+    if (f16) return __builtin_bit_cast(uint16_t, (_Float16)f);
+    return __builtin_bit_cast(uint16_t, (__bf16)f);
+}
 __device__ __forceinline__ float shfl(float v, int src) { return __shfl(v, src, 64); }
 __device__ __forceinline__ float shfl_xor(float v, int m) { return __shfl_xor(v, m, 64); }
 __device__ __forceinline__ float shfl_down(float v, int d) { return __shfl_down(v, d, 64); }
 #endif
+
+// 16-deep low-precision MFMA of the compute modes: prec 3 = IEEE half operands, anything else = bf16 (block-uniform branch)
+__device__ __forceinline__ void mfma_32x32x16_lp(const float (&a)[8], const float (&b)[8], f32x16& acc, int prec) {
+    if (prec == 3) mfma_32x32x16_f16(a, b, acc); else mfma_32x32x16_bf16(a, b, acc);
+}
 
 // TM x TN tiles of one 16-deep k group in bf16x3-split precision: fragments split once, six bf16 MFMAs per tile issued term-major so that
 // consecutive MFMAs hit different accumulators (smallest terms first).

@@ -350,14 +350,56 @@ def _gpt_embed_bwd(gpt, dx, s_img, s_lid, velocity, drop, add_img=None, add_lid=
     return dx_img, dx_lid
 
 
+# ---- 16-bit operand STORAGE for the linear layers of a Block (ops.lowp_storage(): precision "bf16" / "fp16").  Every contraction becomes an
+# NT product of 16-bit matrices (ops.gemm16_nt): the forward multiplies the cast activation with the cached 16-bit weight, the backward
+# casts dy once into (dy16, dy16^T) and multiplies dy16^T with the SAVED transposed activation copy (weight gradient) and dy16 with the
+# transposed weight copy (input gradient).  What a Block keeps for its backward is therefore the transposed 16-bit copy, not the fp32 tensor.
+class A16:
+    """Saved-for-backward stand-in of an activation: its transposed 16-bit copy (K, M8) [+ the fp32 tensor when a ReLU mask needs it]."""
+    __slots__ = ("t", "f32")
+
+    def __init__(self, t, f32=None):
+        self.t, self.f32 = t, f32
+
+
+def _lin16_fwd(x16, w, bias=None, relu=False, res=None, out=None):
+    w16, _ = ops.lowp_weight(w)
+    if out is None:
+        out = torch.empty(x16.shape[0], w.shape[0], dtype=torch.float32, device=x16.device)
+    return ops.gemm16_nt(x16, w16, out, bias=bias, res=res, relu=relu)
+
+
+def _lin16_bwd(dy, xa, w, dw, mask=None, out=None, accumulate=False):
+    """dW += dy^T x (x = the A16 saved by the forward), returns dx (+)= dy W (masked by ``mask`` > 0)."""
+    d16, d16t = ops.cast16(dy)
+    ops.gemm16_nt(d16t, xa.t, dw, accumulate=True, k=d16t.shape[1])
+    _, w16t = ops.lowp_weight(w)
+    if out is None:
+        out = torch.empty(dy.shape[0], w.shape[1], dtype=torch.float32, device=dy.device)
+    return ops.gemm16_nt(d16, w16t, out, mask=mask, accumulate=accumulate, k=w.shape[0])
+
+
+def _lowp_block(gpt, blk, C):
+    return bool(ops.lowp_storage()) and C % 8 == 0 and blk.mlp[0].weight.shape[0] % 8 == 0
+
+
 def _gpt_block_fwd(gpt, li, x, B, T, drop):
     """One transformer Block (transfuser.py:545-549) on x (B*T, C); returns (x_out, saved)."""
     blk = gpt.blocks[li]
     C, nh, dev = x.shape[1], gpt.n_head, x.device
+    lowp = _lowp_block(gpt, blk, C)
     h1, m1, r1 = ops.layernorm_fwd(x, blk.ln1.weight, blk.ln1.bias, blk.ln1.eps)
     qkv = torch.empty(B * T, 3 * C, dtype=torch.float32, device=dev)
     fw = blk.attn.fused()
-    if fw is not None:
+    if lowp:
+        h1_16, h1_t = ops.cast16(h1)
+        if fw is not None:
+            _lin16_fwd(h1_16, fw[0], fw[1], out=qkv)
+        else:
+            for j, l3 in enumerate((blk.attn.key, blk.attn.query, blk.attn.value)):
+                _lin16_fwd(h1_16, l3.weight, l3.bias, out=qkv[:, j * C:(j + 1) * C])
+        h1 = A16(h1_t)
+    elif fw is not None:
         ops.linear_fwd(h1, fw[0], fw[1], out=qkv)
     else:
         for j, lin in enumerate((blk.attn.key, blk.attn.query, blk.attn.value)):
@@ -374,19 +416,34 @@ def _gpt_block_fwd(gpt, li, x, B, T, drop):
         att, Tp = _attn_fwd(qkv, B, T, C, nh)
         att_d = att
         y_att = _attn_ctx(att_d, qkv, B, T, C, nh, Tp)
-    if drop and gpt.resid_pdrop > 0:
-        pr = ops.linear_fwd(y_att, blk.attn.proj.weight, blk.attn.proj.bias)
+    rdrop = drop and gpt.resid_pdrop > 0
+    if lowp:
+        ya_16, ya_t = ops.cast16(y_att)
+        y_att = A16(ya_t)
+        lin = lambda a16, layer, **kw: _lin16_fwd(a16, layer.weight, layer.bias, **kw)
+    else:
+        ya_16 = y_att
+        lin = lambda a, layer, **kw: ops.linear_fwd(a, layer.weight, layer.bias, **kw)
+    if rdrop:
+        pr = lin(ya_16, blk.attn.proj)
         x_mid = ops.dropout_add(pr, x, gpt.seed, gpt.site(4 * li + 2), gpt.resid_pdrop, out=pr)
     else:
-        x_mid = ops.linear_fwd(y_att, blk.attn.proj.weight, blk.attn.proj.bias, res=x)
+        x_mid = lin(ya_16, blk.attn.proj, res=x)
     h2, m2, r2 = ops.layernorm_fwd(x_mid, blk.ln2.weight, blk.ln2.bias, blk.ln2.eps)
-    a1 = ops.linear_fwd(h2, blk.mlp[0].weight, blk.mlp[0].bias, relu=True)
-    if drop and gpt.resid_pdrop > 0:
-        f2 = ops.linear_fwd(a1, blk.mlp[2].weight, blk.mlp[2].bias)
+    if lowp:
+        h2_16, h2_t = ops.cast16(h2)
+        a1 = lin(h2_16, blk.mlp[0], relu=True)
+        h2 = A16(h2_t)
+        a1_16, a1_t = ops.cast16(a1)
+        a1s = A16(a1_t, a1)
+    else:
+        a1 = a1_16 = a1s = lin(h2, blk.mlp[0], relu=True)
+    if rdrop:
+        f2 = lin(a1_16, blk.mlp[2])
         x_out = ops.dropout_add(f2, x_mid, gpt.seed, gpt.site(4 * li + 3), gpt.resid_pdrop, out=f2)
     else:
-        x_out = ops.linear_fwd(a1, blk.mlp[2].weight, blk.mlp[2].bias, res=x_mid)
-    return x_out, (x, h1, m1, r1, qkv, att, att_d, Tp, y_att, x_mid, h2, m2, r2, a1)
+        x_out = lin(a1_16, blk.mlp[2], res=x_mid)
+    return x_out, (x, h1, m1, r1, qkv, att, att_d, Tp, y_att, x_mid, h2, m2, r2, a1s)
 
 
 def _gpt_block_bwd(gpt, li, saved, dx, B, T, drop):
@@ -401,21 +458,31 @@ def _gpt_block_bwd(gpt, li, saved, dx, B, T, drop):
     dres = dx
     if drop and gpt.resid_pdrop > 0:
         dres = ops.dropout(dx, gpt.seed, gpt.site(4 * li + 3), gpt.resid_pdrop)
-    ops.linear_wgrad(dres, a1, gbuf(fc2.weight))
-    bias_grad(dres, fc2.bias)
-    da1 = ops.linear_dgrad(dres, fc2.weight, mask=a1)     # ReLU backward fused into the dgrad epilogue
-    ops.linear_wgrad(da1, h2, gbuf(fc1.weight))
-    bias_grad(da1, fc1.bias)
-    dh2 = ops.linear_dgrad(da1, fc1.weight)
+    lowp = isinstance(a1, A16)      # the forward ran on 16-bit stored operands: so does the backward
+    if lowp:
+        bias_grad(dres, fc2.bias)
+        da1 = _lin16_bwd(dres, a1, fc2.weight, gbuf(fc2.weight), mask=a1.f32)     # ReLU backward fused into the dgrad epilogue
+        bias_grad(da1, fc1.bias)
+        dh2 = _lin16_bwd(da1, h2, fc1.weight, gbuf(fc1.weight))
+    else:
+        ops.linear_wgrad(dres, a1, gbuf(fc2.weight))
+        bias_grad(dres, fc2.bias)
+        da1 = ops.linear_dgrad(dres, fc2.weight, mask=a1)     # ReLU backward fused into the dgrad epilogue
+        ops.linear_wgrad(da1, h2, gbuf(fc1.weight))
+        bias_grad(da1, fc1.bias)
+        dh2 = ops.linear_dgrad(da1, fc1.weight)
     # dx_mid = dx + ln2_bwd(dh2): accumulate in place into dx
     ops.layernorm_bwd(dh2, x_mid, blk.ln2.weight, m2, r2, gbuf(blk.ln2.weight), gbuf(blk.ln2.bias), dx=dx, accumulate=True)
     # ---- attention: x_mid = x + drop(proj(att @ v))
     dres = dx
     if drop and gpt.resid_pdrop > 0:
         dres = ops.dropout(dx, gpt.seed, gpt.site(4 * li + 2), gpt.resid_pdrop)
-    ops.linear_wgrad(dres, y_att, gbuf(proj.weight))
     bias_grad(dres, proj.bias)
-    dy = ops.linear_dgrad(dres, proj.weight)
+    if lowp:
+        dy = _lin16_bwd(dres, y_att, proj.weight, gbuf(proj.weight))
+    else:
+        ops.linear_wgrad(dres, y_att, gbuf(proj.weight))
+        dy = ops.linear_dgrad(dres, proj.weight)
     if att_d is None:       # fused attention: att is the log-sum-exp; probabilities are recomputed inside the two backward kernels
         adrop = (gpt.seed, gpt.site(4 * li + 1), gpt.attn_pdrop) if (drop and gpt.attn_pdrop > 0) else None
         dqkv = ops.attention_bwd(qkv, dy, att, B, T, C, nh, adrop)
@@ -436,7 +503,17 @@ def _gpt_block_bwd(gpt, li, saved, dx, B, T, drop):
         ops.gemm(datt, q, dqkv[:, :C], T, hs, T, Tp, 3 * C, 3 * C, a_trans=True, b_trans=True, alpha=alpha, batch=B * nh, inner=nh,
                  sa=sp, sb=sq, sc=sq)                                                                                     # dK = dS^T Q
     fw = blk.attn.fused()
-    if fw is not None:
+    if lowp and fw is not None:
+        ops.colsum(dqkv, 1, B * T, 3 * C, 1.0, out=fw[3].view(1, -1), accumulate=True)
+        dh1 = _lin16_bwd(dqkv, h1, fw[0], fw[2])
+    elif lowp:
+        dh1 = None
+        for j, l3 in enumerate((blk.attn.key, blk.attn.query, blk.attn.value)):
+            dh1 = _lin16_bwd(dqkv[:, j * C:(j + 1) * C], h1, l3.weight, gbuf(l3.weight), out=dh1, accumulate=dh1 is not None)
+        b3 = ops.colsum(dqkv, 1, B * T, 3 * C, 1.0)
+        for j, l3 in enumerate((blk.attn.key, blk.attn.query, blk.attn.value)):
+            ops.axpby(gbuf(l3.bias), b3[0, j * C:(j + 1) * C], 1.0, 1.0, out=gbuf(l3.bias))
+    elif fw is not None:
         ops.linear_wgrad(dqkv, h1, fw[2])
         ops.colsum(dqkv, 1, B * T, 3 * C, 1.0, out=fw[3].view(1, -1), accumulate=True)
         dh1 = ops.linear_dgrad(dqkv, fw[0])

@@ -42,17 +42,94 @@ def autotune(enable):
 
 
 def set_precision(mode):
-    """Compute precision of every MFMA-engine contraction (storage, accumulation, epilogues stay fp32 in all modes):
+    """Compute precision of every MFMA-engine contraction (accumulation, epilogues, master weights, AdamW stay fp32 in all modes):
     "fp32"  exact fp32 MFMA (v_mfma_f32_32x32x2_f32; default - the reference's arithmetic);
     "f32x3" bf16x3 split: every fp32 operand is split exactly into three bf16 terms in registers and the six leading partial products run on
             the bf16 MFMA (16x the fp32 MFMA rate on gfx950) - fp32-ACCURATE (dropped terms <= 2^-26 |xy|), not a reduced-precision mode;
-    "bf16"  operands rounded to bf16 (one bf16 MFMA per tile) - BASELINE configs[2]."""
-    m = {"fp32": 0, "f32": 0, 0: 0, "bf16": 1, 1: 1, "f32x3": 2, "fp32x3": 2, "bf16x3": 2, 2: 2}[mode]
+    "bf16"  bf16 operands (BASELINE configs[2]); "fp16" IEEE-half operands (configs[4]; use a loss scale: train.Engine does).
+    In the two 16-bit modes the linear layers of the GPT fusion stages additionally run on 16-bit STORED operands (``lowp_storage()``;
+    TF_STORE16=0 keeps every operand fp32 in memory and rounds in registers only): activations / gradients / weights are written once as
+    bf16 / half matrices (``cast16``) and multiplied by ``gemm16_nt`` - half the operand bytes through L2 / LDS per MFMA flop."""
+    m = {"fp32": 0, "f32": 0, 0: 0, "bf16": 1, 1: 1, "f32x3": 2, "fp32x3": 2, "bf16x3": 2, 2: 2, "fp16": 3, "f16": 3, "half": 3, 3: 3}[mode]
     check(L().tf_set_precision(m), "tf_set_precision")
+    _lowp["dtype"] = {1: 1, 3: 2}.get(m, 0) if _STORE16 else 0
+    _lowp["w"].clear()
 
 
 def get_precision():
-    return ("fp32", "bf16", "f32x3")[L().tf_get_precision()]
+    return ("fp32", "bf16", "f32x3", "fp16")[L().tf_get_precision()]
+
+
+# ---- 16-bit operand storage (csrc/cast16.cpp, tf_gemm16_nt_f32)
+_STORE16 = os.environ.get("TF_STORE16", "1") != "0"
+_lowp = {"dtype": 0, "managed": False, "w": {}}
+
+
+def lowp_storage():
+    """0: operands are fp32 in memory; 1: bf16 / 2: fp16 copies feed the packed-16 GEMMs of the GPT linear layers."""
+    return _lowp["dtype"]
+
+
+def _t16():
+    return torch.bfloat16 if _lowp["dtype"] == 1 else torch.float16
+
+
+def cast16(x, want=True, want_t=True, out=None, out_t=None):
+    """x (rows, cols) fp32 (row stride may exceed cols) -> (x16 (rows, cols), x16t (cols, rows8)): the 16-bit copy and its TRANSPOSE (rows
+    zero-padded to a multiple of 8), one pass.  Either may be skipped (None)."""
+    rows, cols = x.shape
+    assert x.stride(1) == 1
+    rows8 = (rows + 7) // 8 * 8
+    y = out if out is not None else (torch.empty(rows, cols, dtype=_t16(), device=x.device) if want else None)
+    yt = out_t if out_t is not None else (torch.empty(cols, rows8, dtype=_t16(), device=x.device) if want_t else None)
+    vp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+    check(L().tf_cast16_f32(ptr(x), rows, cols, x.stride(0), vp(y), y.stride(0) if y is not None else 0, vp(yt), yt.stride(0) if yt is not None else 0,
+                            _lowp["dtype"], stream_of(x)), "tf_cast16_f32")
+    return y, yt
+
+
+def gemm16_nt(a16, b16, out, bias=None, res=None, relu=False, accumulate=False, mask=None, alpha=1.0, k=None, kind=0):
+    """out (m, n) fp32 (op)= alpha * a16 (m, k) @ b16 (n, k).T (+bias) (+res) (relu) (mask); 16-bit operands as cast16 writes them
+    (k = the common, 8-aligned contraction length when the buffers are the zero-padded transposed copies).  kind (tests / tuning): pin an
+    LDS-DMA tile configuration 1..8 (0 = the library's choice)."""
+    m, n = out.shape
+    k = k if k is not None else a16.shape[1]
+    assert a16.shape[0] == m and b16.shape[0] == n and a16.shape[1] >= k and b16.shape[1] >= k and k % 8 == 0, (a16.shape, b16.shape, out.shape, k)
+    _e = _census_begin()
+    check(L().tf_gemm16_nt_f32(ctypes.c_void_p(a16.data_ptr()), ctypes.c_void_p(b16.data_ptr()), ptr(out), m, n, k, a16.stride(0), b16.stride(0), out.stride(0),
+                               ptr(bias), ptr(res), res.stride(0) if res is not None else 0, ctypes.c_float(alpha), int(relu), int(accumulate), ptr(mask),
+                               mask.stride(0) if mask is not None else 0, _lowp["dtype"] + 16 * int(kind), stream_of(out)), "tf_gemm16_nt_f32")
+    _census_end(_e, "gemm16 nt", (m, n, k, 1), 2.0 * m * n * k)
+    return out
+
+
+def lowp_weight(w):
+    """(w16 (N, K), w16t (K, N8)) of a linear weight (N, K).  Inside train.Engine the copies are cached and rewritten once per step right after
+    AdamW (``lowp_refresh_weights``); anywhere else they are re-made at every use (the parameter may have changed)."""
+    key = (w.data_ptr(), tuple(w.shape))
+    ent = _lowp["w"].get(key)
+    if ent is None:
+        y, yt = cast16(w.detach())
+        _lowp["w"][key] = (w.detach(), y, yt)
+        return y, yt
+    if not _lowp["managed"]:
+        cast16(ent[0], out=ent[1], out_t=ent[2])
+    return ent[1], ent[2]
+
+
+def lowp_refresh_weights():
+    for src, y, yt in _lowp["w"].values():
+        cast16(src, out=y, out_t=yt)
+
+
+class lowp_managed:
+    """train.Engine: the cached 16-bit weight copies are valid between two AdamW steps."""
+
+    def __enter__(self):
+        self.prev, _lowp["managed"] = _lowp["managed"], True
+
+    def __exit__(self, *a):
+        _lowp["managed"] = self.prev
 
 
 def force_plan(bm=0, bn=0, bk=0, splitk=1):
@@ -307,6 +384,7 @@ def _direct_ok(shape, cout, cin, ks, stride, pad, groups):
 
 _DIRECT = bool(int(__import__("os").environ.get("TF_DIRECT_CONV", "1")))
 _THIN = bool(int(__import__("os").environ.get("TF_THIN_CONV", "1")))
+_S2_GEMM = bool(int(__import__("os").environ.get("TF_S2_GEMM", "1")))
 
 
 def _thin_ok(shape, cout, cin, ks, stride, pad, groups):
@@ -391,6 +469,12 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=None, groups=1, out=None, accumulat
     if mask is not None:
         assert not accumulate, "conv_dgrad: mask + accumulate needs the fused kernel"
         return relu_mask(conv_dgrad(dy, w, x_shape, stride, pad, groups, out=out), mask, out=out)
+    if _S2_GEMM and ks == 1 and stride == 2 and pad == 0 and groups == 1 and accumulate and g.Cin % 4 == 0:
+        # RegNet downsample branch: dx[b, 2i, 2j, :] += dy[b, i, j, :] W - one plain GEMM over the B Ho Wo output pixels + a scatter-add (the
+        # implicit-GEMM path walks all B Hi Wi input pixels, 3/4 of them for nothing, with gathered operands: 190 vs ~40 us at 16 x 44 x 576 -> 1512)
+        tmp = linear_dgrad(dy.view(-1, g.Cout), w.view(g.Cout, g.Cin))
+        check(L().tf_add_strided2_f32(ptr(tmp), ptr(_c(out)), g.B, g.Ho, g.Wo, g.Cin, g.Hi, g.Wi, stream_of(dy)), "tf_add_strided2_f32")
+        return out
     if _direct_ok(x_shape, g.Cout, g.Cin, ks, stride, pad, groups):
         check(L().tf_conv3x3_small_dgrad_f32(ptr(_c(dy)), wptr(w), ptr(_c(out)), g.B, g.Hi, g.Wi, g.Cin, g.Cout, int(accumulate), stream_of(dy)),
               "tf_conv3x3_small_dgrad_f32")
@@ -867,7 +951,12 @@ def gru_waypoints_bwd(dwp, cache, gru, outl, grads, B, H, pred_len):
     return dz0
 
 
-def adamw_(p, g, m, v, state, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.01):
+def adamw_(p, g, m, v, state, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.01, grad_scale=1.0):
+    """grad_scale: the gradients are multiplied by it on the way in (1 / loss scale of the fp16 mode)."""
+    if grad_scale != 1.0:
+        check(L().tf_adamw_scaled_f32(ptr(p), ptr(g), ptr(m), ptr(v), ctypes.c_int64(p.numel()), ptr(state), ctypes.c_float(beta1), ctypes.c_float(beta2),
+                                      ctypes.c_float(eps), ctypes.c_float(weight_decay), ctypes.c_float(grad_scale), stream_of(p)), "tf_adamw_scaled_f32")
+        return
     check(L().tf_adamw_f32(ptr(p), ptr(g), ptr(m), ptr(v), ctypes.c_int64(p.numel()), ptr(state), ctypes.c_float(beta1), ctypes.c_float(beta2),
                            ctypes.c_float(eps), ctypes.c_float(weight_decay), stream_of(p)), "tf_adamw_f32")
 

@@ -169,7 +169,7 @@ class FlatAdamW:
     def step(self):
         a = self.arena
         ops.adamw_(a.params[self.lo:self.hi], a.grads[self.lo:self.hi], self.exp_avg, self.exp_avg_sq, self.state, self.betas[0], self.betas[1],
-                   self.eps, self.weight_decay)
+                   self.eps, self.weight_decay, grad_scale=getattr(self, "grad_scale", 1.0))
 
     def _layout(self):
         """[(parameter name, arena offset, numel)] of the parameters the optimizer updates: what makes a saved state independent of the
@@ -353,12 +353,14 @@ class Engine:
     DEFAULT_CUTS = ((4, 1, 3), (4, 1, 2), (4, 1, 1), 3, (3, 0, 0), 2, 1)
 
     def __init__(self, model, config, lr=1e-4, use_graph=False, group=None, bucket_mb=64.0, wp_only=False, autotune=True, plan_file=None,
-                 zero_redundancy_optimizer=False, sync_batch_norm=False, cuts=None, precision=None, grad_dtype="fp32"):
+                 zero_redundancy_optimizer=False, sync_batch_norm=False, cuts=None, precision=None, grad_dtype="fp32", loss_scale=None):
         """``cuts``: points (cut_key: int c = after fusion stage c; (i, 0, 0) = between the stage-i trunks and GPT i; (i, 1, j) = inside GPT i
         in front of Block j) at which the backward is cut into separately enqueued (and separately captured) segments whose gradient
         ranges are all-reduced while the next segment runs.  None = DEFAULT_CUTS when there is more than one rank (and the backbone is a
         chain: transFuser / latentTF), no cut on a single GPU; () = never cut.
-        ``precision``: compute precision of every MFMA-engine contraction (process-wide, ops.set_precision); None keeps the current one."""
+        ``precision``: compute precision of every MFMA-engine contraction (process-wide, ops.set_precision); None keeps the current one.
+        ``loss_scale``: static loss scale S (the backward is seeded with S instead of 1, AdamW multiplies the gradients by 1 / S); None = 1024
+        in "fp16" precision (half operands flush gradients below 6e-8 to zero) and 1 otherwise.  The reported losses are unscaled."""
         self.model = model
         self.config = config
         if precision is not None:   # "fp32" (exact fp32 MFMA: the reference's arithmetic) | "f32x3" (bf16x3 split on the bf16 MFMA, fp32-accurate) | "bf16" (bf16 MFMA operands, fp32 accumulate / storage / master weights)
@@ -387,6 +389,11 @@ class Engine:
         self.zero = bool(zero_redundancy_optimizer) and self.reducer.world > 1      # train.py:143-146
         rank = dist.get_rank(group) if self.zero else 0
         self.optimizer = FlatAdamW(self.arena, lr=lr, shard=(rank, self.reducer.world) if self.zero else None)
+        if loss_scale is None:
+            loss_scale = 1024.0 if ops.get_precision() == "fp16" else 1.0
+        self.loss_scale = float(loss_scale)
+        self.optimizer.grad_scale = 1.0 / self.loss_scale
+        self._seed_grad = None
         self.reducer.broadcast_params()
         w = [1.0] + [0.0] * 10 if wp_only else list(config.detailed_losses_weights)
         self.detailed_weights = dict(zip(config.detailed_losses, w))
@@ -417,12 +424,18 @@ class Engine:
         return len(self.cuts) + 1
 
     def _piece0(self, data):
-        with _F.inplace_param_grads():
+        with _F.inplace_param_grads(), ops.lowp_managed():
             return self._piece0_impl(data)
 
     def _piece(self, i):
-        with _F.inplace_param_grads():
+        with _F.inplace_param_grads(), ops.lowp_managed():
             return self._piece_impl(i)
+
+    def _opt_step(self):
+        """AdamW over the arena, then the 16-bit weight copies of the storage modes are rewritten from the updated master weights."""
+        self.optimizer.step()
+        if ops.lowp_storage():
+            ops.lowp_refresh_weights()
 
     def _piece0_impl(self, data):
         self.optimizer.zero_grad()
@@ -431,7 +444,12 @@ class Engine:
         for key, value in losses.items():   # train.py:307-311
             term = self.detailed_weights[key] * value
             loss = term if loss is None else loss + term
-        loss.backward()
+        if self.loss_scale != 1.0:
+            if self._seed_grad is None or self._seed_grad.device != loss.device:
+                self._seed_grad = torch.full((), self.loss_scale, dtype=torch.float32, device=loss.device)
+            loss.backward(self._seed_grad)
+        else:
+            loss.backward()
         self._pending = list(getattr(getattr(self.model, "_model", None), "_boundaries", ()) or ()) if self.cuts else []
         assert len(self._pending) == len(self.cuts), "backbone recorded %d boundaries for %d cuts" % (len(self._pending), len(self.cuts))
         return loss.detach(), {k: v.detach() for k, v in losses.items()}
@@ -472,7 +490,7 @@ class Engine:
 
     def _eager_step(self, data):
         out = self._fwd_bwd(data, reduce=True)
-        self.optimizer.step()
+        self._opt_step()
         if self.zero:
             self.reducer.all_gather_params(self.optimizer)
         self._bump_seed()
@@ -524,7 +542,7 @@ class Engine:
         with torch.cuda.graph(self._graphs[0]):
             self._out = self._piece0(self._static)
             if fused_opt:
-                self.optimizer.step()
+                self._opt_step()
                 self._bump_seed()
         pool = self._graphs[0].pool()
         for i in range(1, self.n_pieces()):
@@ -535,7 +553,7 @@ class Engine:
         else:
             self._opt_graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._opt_graph, pool=pool):
-                self.optimizer.step()
+                self._opt_step()
                 self._bump_seed()
 
     def save(self, path_prefix, epoch):
