@@ -139,6 +139,9 @@ int tf_conv3x3_grouped_fwd_f32(const float* x, const float* w, const float* bias
 int tf_conv3x3_grouped_colstat_parts(void);
 int tf_conv3x3_grouped_fwd_colstat_f32(const float* x, const float* w, float* y, int B, int H, int W, int C, float* colstat, int* colstat_nparts, void* stream);
 int tf_conv3x3_grouped_dgrad_f32(const float* dy, const float* w, float* dx, int B, int H, int W, int C, int accumulate, void* stream);
+/* Input gradient of the STRIDE-2 (pad 1) grouped 3x3 convolution - the first block of every RegNetY stage - by sub-pixel decomposition: nine
+ * tap products per dY pixel instead of nine masked taps per pixel of the 4x larger dX grid.  dy is (B, (Hi-1)/2+1, (Wi-1)/2+1, C), dx (B, Hi, Wi, C). */
+int tf_conv3x3_grouped_s2_dgrad_f32(const float* dy, const float* w, float* dx, int B, int Hi, int Wi, int C, int accumulate, void* stream);
 long tf_conv3x3_grouped_wgrad_ws_floats(void);
 int tf_conv3x3_grouped_wgrad_f32(const float* dy, const float* x, float* dw, int B, int H, int W, int C, int accumulate, float* ws, void* stream);
 

@@ -308,6 +308,84 @@ __global__ void __launch_bounds__(256) conv3x3_grouped_wgrad_reduce_kernel(const
     *d = accumulate ? *d + s : s;
 }
 
+// ---- input gradient of the STRIDE-2 grouped 3x3 convolution (first block of every RegNetY stage) by sub-pixel decomposition.
+// dX[2i+a][2j+b] only receives the taps kh = a+1 (mod 2), kw = b+1 (mod 2): one tap for (a, b) = (0, 0), two for (0, 1) / (1, 0), four for (1, 1) -
+// nine tap products per dY pixel in all, each reading dY at (i + dr, j + dc), dr, dc in {0, 1}.  The implicit-GEMM path gathers nine MASKED taps for
+// every pixel of the 4x larger dX grid (6-12 TFLOP/s measured).  Here a wave owns 32 dY pixels and four accumulators (one per parity class);
+// the (TH+1) x (TW+1) dY patch and the group's weight panel are staged as in conv3x3_grouped_kernel.  Tiles run over the dY grid.
+template <int TW>
+__global__ void __launch_bounds__(256, 2) conv3x3_grouped_s2_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, GcGeom g,
+                                                                          int Hi, int Wi, int accumulate) {
+    constexpr int RW = 32 / TW, TH = 4 * RW, PH = TH + 1, PW = TW + 1, NPIX = PH * PW;
+    constexpr int NV = (NPIX * 6 + 255) / 256;
+    __shared__ float patch[NPIX * PP];
+    __shared__ float wl[9 * CG][WP];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int grp = blockIdx.x / g.nb, sub = blockIdx.x - grp * g.nb, coff = grp * CG;
+    load_group_weights(wl, w + (long)grp * CG * 9 * CG, 1);      // wl[tap'][co][ci] = W[co][8 - tap'][ci]: tap (kh, kw) sits at tap' = 8 - (3 kh + kw)
+    float4 pre[NV];
+    auto fetch = [&](int t) {      // dY patch rows h0 .. h0 + TH, columns w0 .. w0 + TW (zero outside the dY map); g.H / g.W = the dY extent
+        const int b = t / (g.tiles_h * g.tiles_w), r = t - b * (g.tiles_h * g.tiles_w);
+        const int h0 = (r / g.tiles_w) * TH, w0 = (r % g.tiles_w) * TW;
+#pragma unroll
+        for (int p = 0; p < NV; ++p) {
+            const int s = tid + p * 256, pix = s / 6, c = (s - pix * 6) * 4;
+            const int ph = pix / PW, pw = pix - ph * PW, h = h0 + ph, ww = w0 + pw;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pix < NPIX && h < g.H && ww < g.W) v = *reinterpret_cast<const float4*>(dy + (((long)b * g.H + h) * g.W + ww) * g.C + coff + c);
+            pre[p] = v;
+        }
+    };
+    int tile = sub;
+    if (tile < g.ntiles) fetch(tile);
+    const int prow = wave * RW + l31 / TW, pcol = l31 % TW;
+    for (; tile < g.ntiles; tile += g.nb) {
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < NV; ++p) {
+            const int s = tid + p * 256, pix = s / 6, c = (s - pix * 6) * 4;
+            if (pix < NPIX) { float* q = patch + pix * PP + c; q[0] = pre[p].x; q[1] = pre[p].y; q[2] = pre[p].z; q[3] = pre[p].w; }
+        }
+        __syncthreads();
+        if (tile + g.nb < g.ntiles) fetch(tile + g.nb);
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b2][r] = 0.f;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int a = (kh + 1) & 1, b2 = (kw + 1) & 1;            // parity class fed by this tap
+                const int dr = (a + 1 - kh) / 2, dc = (b2 + 1 - kw) / 2;    // dY offset: (2i + a + 1 - kh) / 2 = i + dr
+                const float* pa = patch + ((prow + dr) * PW + pcol + dc) * PP + hi;
+                const float* pb = &wl[(8 - (3 * kh + kw)) * CG + hi][l31];
+#pragma unroll
+                for (int kk = 0; kk < CG / 2; ++kk) mfma_32x32x2(pa[2 * kk], pb[2 * kk * WP], acc[a][b2]);
+            }
+        const int b = tile / (g.tiles_h * g.tiles_w), r = tile - b * (g.tiles_h * g.tiles_w);
+        const int h0 = (r / g.tiles_w) * TH, w0 = (r % g.tiles_w) * TW;
+        if (l31 < CG) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int i = (e & 3) + 8 * (e >> 2) + 4 * hi;           // dY pixel inside the wave's 32
+                        const int hh = 2 * (h0 + wave * RW + i / TW) + a, ww = 2 * (w0 + i % TW) + b2;
+                        if (hh < Hi && ww < Wi) {
+                            float* dst = dx + (((long)b * Hi + hh) * Wi + ww) * g.C + coff + l31;
+                            *dst = accumulate ? *dst + acc[a][b2][e] : acc[a][b2][e];
+                        }
+                    }
+        }
+    }
+}
+
 constexpr int kMaxBlocks = 768;     // persistent grid: up to 3 blocks per CU
 
 // compute precision of these kernels; TF_X3_DIRECT=0 keeps them on the exact fp32 MFMA in f32x3 mode (A/B switch)
@@ -408,4 +486,14 @@ extern "C" int tf_conv3x3_grouped_wgrad_f32(const float* dy, const float* x, flo
 #undef TF_GW
     TF_LAUNCH(conv3x3_grouped_wgrad_reduce_kernel, dim3(36, g.G), dim3(256), stream, (const float*)ws, g.nb, dw, accumulate);
     return launch_status("tf_conv3x3_grouped_wgrad_f32");
+}
+
+extern "C" int tf_conv3x3_grouped_s2_dgrad_f32(const float* dy, const float* w, float* dx, int B, int Hi, int Wi, int C, int accumulate, void* stream) {
+    TF_REQUIRE(args_ok(dy, w, dx, B, Hi, Wi, C), "tf_conv3x3_grouped_s2_dgrad_f32: needs NHWC tensors with C %% 24 == 0 (group width 24), 16-byte aligned");
+    const int Ho = (Hi - 1) / 2 + 1, Wo = (Wi - 1) / 2 + 1;        // 3x3 / stride 2 / pad 1
+    const int tw = pick_tw(Ho, Wo);
+    GcGeom g = make_geom(B, Ho, Wo, C, tw);                        // tiles over the dY grid
+    if (tw == 16) TF_LAUNCH((conv3x3_grouped_s2_dgrad_kernel<16>), dim3(g.G * g.nb), dim3(256), stream, dy, w, dx, g, Hi, Wi, accumulate);
+    else TF_LAUNCH((conv3x3_grouped_s2_dgrad_kernel<32>), dim3(g.G * g.nb), dim3(256), stream, dy, w, dx, g, Hi, Wi, accumulate);
+    return launch_status("tf_conv3x3_grouped_s2_dgrad_f32");
 }

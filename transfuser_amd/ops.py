@@ -385,6 +385,7 @@ def _direct_ok(shape, cout, cin, ks, stride, pad, groups):
 _DIRECT = bool(int(__import__("os").environ.get("TF_DIRECT_CONV", "1")))
 _THIN = bool(int(__import__("os").environ.get("TF_THIN_CONV", "1")))
 _S2_GEMM = bool(int(__import__("os").environ.get("TF_S2_GEMM", "1")))
+_S2_SUBPIX = bool(int(__import__("os").environ.get("TF_S2_SUBPIX", "1")))
 
 
 def _thin_ok(shape, cout, cin, ks, stride, pad, groups):
@@ -479,6 +480,11 @@ def conv_dgrad(dy, w, x_shape, stride=1, pad=None, groups=1, out=None, accumulat
         check(L().tf_conv3x3_small_dgrad_f32(ptr(_c(dy)), wptr(w), ptr(_c(out)), g.B, g.Hi, g.Wi, g.Cin, g.Cout, int(accumulate), stream_of(dy)),
               "tf_conv3x3_small_dgrad_f32")
         _census_end(_e, "conv dgrad*", _gshape(g), _gflops(g))
+        return out
+    if _GROUPED and _S2_SUBPIX and ks == 3 and stride == 2 and pad == 1 and groups > 1 and g.Cin == g.Cout == groups * 24:
+        check(L().tf_conv3x3_grouped_s2_dgrad_f32(ptr(_c(dy)), wptr(w), ptr(_c(out)), g.B, g.Hi, g.Wi, g.Cin, int(accumulate), stream_of(dy)),
+              "tf_conv3x3_grouped_s2_dgrad_f32")
+        _census_end(_e, "conv dgrad g2", _gshape(g), _gflops(g))
         return out
     if _grouped_ok(x_shape, g.Cout, g.Cin, ks, stride, pad, groups):
         check(L().tf_conv3x3_grouped_dgrad_f32(ptr(_c(dy)), wptr(w), ptr(_c(out)), g.B, g.Hi, g.Wi, g.Cin, int(accumulate), stream_of(dy)), "tf_conv3x3_grouped_dgrad_f32")
