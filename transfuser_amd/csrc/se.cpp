@@ -106,8 +106,10 @@ __global__ void __launch_bounds__(256) se_zero_kernel(float* __restrict__ p, int
 constexpr int SE_ROWS = 8;
 __global__ void __launch_bounds__(256) se_excite_bwd2_kernel(const float* __restrict__ dgate, const float* __restrict__ g1, const float* __restrict__ W2,
                                                              int B, int C, int Cr, float* __restrict__ dW2, float* __restrict__ db2,
-                                                             float* __restrict__ dg1) {
+                                                             float* __restrict__ dg1, float* __restrict__ ds_zero) {
     __shared__ float dgs[SE_MAXB][SE_ROWS];
+    // ds (B x C) is ACCUMULATED by the j-sliced fc1 pass that follows: cleared here, one slice per block
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (long)B * C; i += (long)gridDim.x * 256) ds_zero[i] = 0.f;
     __shared__ float g1s[SE_MAXB * SE_MAXR / 2];     // B * Cr <= 8192 floats (32 KB): checked on the host
     const int n0 = blockIdx.x * SE_ROWS, tid = threadIdx.x;
     const int rows = (C - n0 < SE_ROWS) ? C - n0 : SE_ROWS;
@@ -144,8 +146,10 @@ __global__ void __launch_bounds__(256) se_excite_bwd2_kernel(const float* __rest
     }
 }
 
-// fc1 pass, one block per 32 columns k of W1:  dg = dg1 * (g1 > 0);  dW1[j][k] += sum_b dg[b][j] s[b][k];  db1[j] += sum_b dg[b][j]
-// (block 0);  ds[b][k] = sum_j dg[b][j] W1[j][k].
+// fc1 pass, one block per (32 columns k of W1, slice of the Cr rows j):  dg = dg1 * (g1 > 0);  dW1[j][k] += sum_b dg[b][j] s[b][k];
+// db1[j] += sum_b dg[b][j] (column block 0);  ds[b][k] += sum_{j in slice} dg[b][j] W1[j][k] (fp32 atomics into the buffer the fc2 pass
+// cleared: SE_JS j-slices give C / 32 x SE_JS blocks instead of 18-47 - the kernel was a 23 us latency chain on a 10 % filled GPU).
+constexpr int SE_JS = 6;
 __global__ void __launch_bounds__(256) se_excite_bwd1_kernel(const float* __restrict__ dg1, const float* __restrict__ g1, const float* __restrict__ s,
                                                              const float* __restrict__ W1, int B, int C, int Cr, float* __restrict__ dW1,
                                                              float* __restrict__ db1, float* __restrict__ ds) {
@@ -154,6 +158,7 @@ __global__ void __launch_bounds__(256) se_excite_bwd1_kernel(const float* __rest
     __shared__ float red[8][SE_MAXB][32];
     const int tid = threadIdx.x, kx = tid & 31, jg = tid >> 5;
     const int k = blockIdx.x * 32 + kx;
+    const int jper = (Cr + SE_JS - 1) / SE_JS, j0 = blockIdx.y * jper, j1 = (j0 + jper < Cr) ? j0 + jper : Cr;
     for (int i = tid; i < B * Cr; i += 256) dgm[i] = g1[i] > 0.f ? dg1[i] : 0.f;
     for (int i = tid; i < B * 32; i += 256) {
         const int b = i >> 5, c = blockIdx.x * 32 + (i & 31);
@@ -164,7 +169,7 @@ __global__ void __launch_bounds__(256) se_excite_bwd1_kernel(const float* __rest
 #pragma unroll
     for (int b = 0; b < SE_MAXB; ++b) acc[b] = 0.f;
     if (k < C)
-        for (int j = jg; j < Cr; j += 8) {
+        for (int j = j0 + jg; j < j1; j += 8) {
             const float w = W1[(long)j * C + k];
             float dw = 0.f;
 #pragma unroll
@@ -184,10 +189,10 @@ __global__ void __launch_bounds__(256) se_excite_bwd1_kernel(const float* __rest
             float v = 0.f;
 #pragma unroll
             for (int g = 0; g < 8; ++g) v += red[g][b][kx];
-            ds[(long)b * C + k] = v;
+            atomicAdd(ds + (long)b * C + k, v);
         }
     if (blockIdx.x == 0 && db1)
-        for (int j = tid; j < Cr; j += 256) {
+        for (int j = j0 + tid; j < j1; j += 256) {
             float v = 0.f;
             for (int b = 0; b < B; ++b) v += dgm[b * Cr + j];
             db1[j] += v;
@@ -211,7 +216,7 @@ extern "C" int tf_se_excite_bwd_f32(const float* dgate, const float* s, const fl
     TF_REQUIRE(dgate && s && g1 && W1 && W2 && dW1 && dW2 && ds && scratch && B > 0 && B <= SE_MAXB && C > 0 && Cr > 0 &&
                    (long)B * Cr <= SE_MAXB * SE_MAXR / 2, "tf_se_excite_bwd_f32: bad arguments (B <= 16, B*Cr <= 8192)");
     if (!scratch_is_zero) TF_LAUNCH(se_zero_kernel, dim3(cdiv((long)B * Cr, 256)), dim3(256), stream, scratch, B * Cr);
-    TF_LAUNCH(se_excite_bwd2_kernel, dim3(cdiv(C, SE_ROWS)), dim3(256), stream, dgate, g1, W2, B, C, Cr, dW2, db2, scratch);
-    TF_LAUNCH(se_excite_bwd1_kernel, dim3(cdiv(C, 32)), dim3(256), stream, (const float*)scratch, g1, s, W1, B, C, Cr, dW1, db1, ds);
+    TF_LAUNCH(se_excite_bwd2_kernel, dim3(cdiv(C, SE_ROWS)), dim3(256), stream, dgate, g1, W2, B, C, Cr, dW2, db2, scratch, ds);
+    TF_LAUNCH(se_excite_bwd1_kernel, dim3(cdiv(C, 32), SE_JS), dim3(256), stream, (const float*)scratch, g1, s, W1, B, C, Cr, dW1, db1, ds);
     return launch_status("tf_se_excite_bwd_f32");
 }

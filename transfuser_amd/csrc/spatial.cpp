@@ -384,7 +384,9 @@ extern "C" int tf_bilinear_bwd_f32(const tf_bilinear_desc* d, const float* dy, f
         return launch_status("tf_bilinear_bwd_f32");
     }
     TF_LAUNCH(bilinear_bwd_kernel, dim3(ew_blocks(n)), dim3(256), stream, *d, dy, dx, bl_scale(d->Hi, d->Ho, d->align_corners),
-              bl_scale(d->Wi, d->Wo, d->align_corners), accumulate, d->sc_i == 1 ? 1 : 0);
+              bl_scale(d->Wi, d->Wo, d->align_corners), accumulate, (d->sc_i == 1 || d->sc_o == 1) ? 1 : 0);   // channel-fastest threads whenever dY is NHWC:
+              // an input element gathers ~(scale + 2)^2 dY values but is written once, so the READS must coalesce (the GPT stages' raw-view
+              // layout, sc_i = ih * iw, ran pixel-fastest: 4-byte reads at stride C, 256 us for the 64 x 176 x 72 map)
     return launch_status("tf_bilinear_bwd_f32");
 }
 
