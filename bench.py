@@ -157,11 +157,11 @@ def replica_check(eng, batch, rank, world, dev, log):
             "backward_pieces": eng.n_pieces(), "grad_dtype": "bf16" if eng.reducer.bf16 else "fp32"}
 
 
-def cpu_baseline(make_cfg, backbone, H, W, budget_s=110.0):
+def cpu_baseline(make_cfg, backbone, H, W, budget_s=135.0):
     """The oracle (CPU restatement of the reference path; its backbone is pinned bit-exact to the reference's own transfuser.py and
     its heads/losses to the reference's model.py) timed on this host with PyTorch-CPU fp32: B=2 (BASELINE configs[0], the reference's
-    CPU-runnable case) with 2 warm-up + 5 timed steps, then B=10 (the workload of the GPU line) with 1 warm-up + up to 3 timed steps
-    inside the time budget.  Thread count: min(64, cores) - measured on the 256-core GPU host: beyond 64 threads the oneDNN / OpenMP
+    CPU-runnable case) with 2 warm-up + 5 timed steps, then B=10 (the workload of the GPU line) with 1 warm-up + up to 5 timed steps
+    inside the time budget (SURVEY 8d asks for >= 5).  Thread count: min(64, cores) - measured on the 256-core GPU host: beyond 64 threads the oneDNN / OpenMP
     kernels of these layer sizes slow down (a 256-thread probe step did not finish in 15 minutes: torch.optim's per-tensor loop and the
     small convolutions thrash), so "all cores" is NOT the fastest configuration of the reference's CPU path; both numbers are stated."""
     import torch
@@ -196,7 +196,7 @@ def cpu_baseline(make_cfg, backbone, H, W, budget_s=110.0):
         b10 = mk(10)
         step(b10)
         t10 = []
-        while len(t10) < 3 and (time.time() - t_start) + (t10[-1] if t10 else 5 * t2[2]) < budget_s + 15:
+        while len(t10) < 5 and (time.time() - t_start) + (t10[-1] if t10 else 5 * t2[2]) < budget_s + 15:
             t10.append(step(b10))
         if t10:
             t10.sort()

@@ -237,6 +237,11 @@ typedef struct {
 } tf_bilinear_desc;
 int tf_bilinear_fwd_f32(const tf_bilinear_desc* d, const float* x, float* y, const float* add, void* stream);
 int tf_bilinear_bwd_f32(const tf_bilinear_desc* d, const float* dy, float* dx, int accumulate, void* stream);
+/* 3x3 / stride 2 / pad 1 max pooling on NHWC maps: ``maxpool`` of the timm ResNet trunks, the reference's DEFAULT architectures
+ * (transfuser.py:15,139,143: image 'resnet34', LiDAR 'resnet18').  idx: one byte per output element = the winning tap 0..8 (first maximum in
+ * (kh, kw) order, as ATen); the backward gathers through it (no atomics).  Output (B, (Hi-1)/2+1, (Wi-1)/2+1, C). */
+int tf_maxpool3x3s2_fwd_f32(const float* x, float* y, unsigned char* idx, int B, int Hi, int Wi, int C, void* stream);
+int tf_maxpool3x3s2_bwd_f32(const float* dy, const unsigned char* idx, float* dx, int B, int Hi, int Wi, int C, void* stream);
 
 /* G1 - geometric-fusion correspondence gather (geometric_fusion.py:134-137,147-150; and :173-176 ... :262-266 for the other
  * stages): out[b, i, :] = sum_k src[b, idx[b,i,k,1] * Ws + idx[b,i,k,0], :].  The reference indexes B x B and keeps the diagonal;

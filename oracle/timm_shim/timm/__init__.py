@@ -1,10 +1,11 @@
 """Minimal ``timm`` stand-in so the reference's transfuser.py (transfuser.py:5,380,442) imports
-unmodified in the authoring container.  Test infrastructure; resolves through oracle.regnet."""
+unmodified in the authoring container.  Test infrastructure; resolves through oracle.regnet / oracle.resnet."""
 import os
 import sys
 
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..", ".."))
 from oracle import regnet as _regnet  # noqa: E402
+from oracle import resnet as _resnet  # noqa: E402
 
 _REGISTRY = {}
 
@@ -23,4 +24,6 @@ def create_model(architecture, pretrained=False, **kw):
             return _REGISTRY[architecture]()
     if architecture == "regnety_032":
         return _regnet.regnety_032(in_chans)  # pretrained weights need network: seeded random init instead
-    raise ValueError("timm shim only provides regnety_032 (+registered test nets), got %r" % architecture)
+    if architecture in _resnet.ARCH:         # the reference's DEFAULT trunks (transfuser.py:15); used under timm's own attribute names
+        return _resnet.ARCH[architecture](in_chans)
+    raise ValueError("timm shim only provides regnety_032, resnet18/34/50 (+registered test nets), got %r" % architecture)

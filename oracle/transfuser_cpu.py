@@ -106,6 +106,12 @@ class _Trunk(nn.Module):
     def __init__(self, net, in_channels=None):
         super().__init__()
         net.fc = None
+        if not hasattr(net, "stem"):        # ResNet (the reference's default architectures): timm's own names, nothing to re-label
+            if in_channels is not None:     # transfuser.py:475-477
+                old = net.conv1
+                net.conv1 = nn.Conv2d(in_channels, old.out_channels, old.kernel_size, old.stride, old.padding, bias=False)
+            self.net = net
+            return
         net.conv1 = net.stem.conv
         net.bn1 = net.stem.bn
         net.act1 = nn.Sequential()
@@ -176,8 +182,8 @@ class TransfuserBackbone(nn.Module):
 
     def forward(self, image, lidar, velocity):
         im, li = self.image_encoder.features, self.lidar_encoder._model
-        x = im.bn1(im.conv1(normalize_imagenet(image)))
-        y = li.bn1(li.conv1(lidar))
+        x = im.maxpool(im.act1(im.bn1(im.conv1(normalize_imagenet(image)))))      # transfuser.py:136-143 (act1 / maxpool are empty for RegNet)
+        y = li.maxpool(li.act1(li.bn1(li.conv1(lidar))))
         for i in range(1, 5):
             x = getattr(im, "layer%d" % i)(x)
             y = getattr(li, "layer%d" % i)(y)
@@ -298,8 +304,8 @@ class GeometricFusionBackbone(TransfuserBackbone):
 
     def forward(self, image, lidar, velocity, bev_points, img_points):
         im, li = self.image_encoder.features, self.lidar_encoder._model
-        x = im.bn1(im.conv1(normalize_imagenet(image)))
-        y = li.bn1(li.conv1(lidar))
+        x = im.maxpool(im.act1(im.bn1(im.conv1(normalize_imagenet(image)))))      # transfuser.py:136-143 (act1 / maxpool are empty for RegNet)
+        y = li.maxpool(li.act1(li.bn1(li.conv1(lidar))))
         lid_embd = {}
         for i in range(1, 5):
             x = getattr(im, "layer%d" % i)(x)

@@ -211,6 +211,37 @@ def check_stem(dev, B, H, W):
     close(ops.stem_conv_fwd(l0, l1, cl(w2), False).permute(0, 3, 1, 2), y2, what="lidar stem fwd")
 
 
+def check_resnet_stem_and_pool(dev):
+    """The ResNet stem pieces (timm resnet18/34/50: the reference's default trunks, transfuser.py:15,136-143): 7x7 / s2 / p3 convolution on the
+    NCHW inputs (with normalize_imagenet folded in, or the LiDAR + target-point channels un-concatenated) and nn.MaxPool2d(3, 2, 1) forward /
+    backward incl. ties (first maximum wins, as ATen) and odd sizes; a dense 3x3 / s2 and 1x1 / s2 convolution through the generic engine."""
+    B, H, W = 2, 20, 26
+    rgb = torch.randint(0, 256, (B, 3, H, W), generator=torch.Generator().manual_seed(0)).float().to(dev)
+    w = (R(16, 3, 7, 7, dev=dev) * 0.1).requires_grad_(True)
+    mean = torch.tensor([0.485, 0.456, 0.406], device=dev).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225], device=dev).view(1, 3, 1, 1)
+    y = F.conv2d((rgb / 255.0 - mean) / std, w, None, 2, 3)
+    dy = R(*y.shape, seed=1, dev=dev)
+    (gw,) = torch.autograd.grad(y, [w], dy)
+    wh = cl(w.detach())
+    close(ops.stem_conv_fwd(rgb, None, wh, True, 2, 3).permute(0, 3, 1, 2), y, what="7x7 stem fwd")
+    dw = torch.zeros_like(wh)
+    ops.stem_conv_wgrad(dy.permute(0, 2, 3, 1).contiguous(), rgb, None, dw, True, stride=2, pad=3)
+    close(dw, gw, what="7x7 stem wgrad", tol=1e-4)
+    l0, l1 = torch.rand(B, 2, H, H, device=dev), torch.rand(B, 1, H, H, device=dev)
+    w2 = R(16, 3, 7, 7, seed=3, dev=dev) * 0.1
+    close(ops.stem_conv_fwd(l0, l1, cl(w2), False, 2, 3).permute(0, 3, 1, 2), F.conv2d(torch.cat((l0, l1), 1), w2, None, 2, 3), what="7x7 lidar stem fwd")
+    for (b, h, wd, c) in ((2, 9, 11, 8), (1, 16, 20, 64), (1, 7, 5, 3)):
+        x = (torch.randint(-3, 4, (b, c, h, wd), generator=torch.Generator().manual_seed(5)).float() * 0.5).to(dev).requires_grad_(True)     # many ties
+        yr = F.max_pool2d(x, 3, 2, 1)
+        g = R(*yr.shape, seed=6, dev=dev)
+        (gx,) = torch.autograd.grad(yr, [x], g)
+        yh, idx = ops.maxpool3x3s2_fwd(x.detach().permute(0, 2, 3, 1).contiguous())
+        assert torch.equal(yh.permute(0, 3, 1, 2), yr.detach()), "maxpool fwd"
+        dx = ops.maxpool3x3s2_bwd(g.permute(0, 2, 3, 1).contiguous(), idx, (b, h, wd, c))
+        close(dx.permute(0, 3, 1, 2), gx, what="maxpool bwd (ties: first maximum)")
+
+
 # ---------------------------------------------------------------- norms
 def check_layernorm(dev, rows, C):
     x = R(rows, C, dev=dev).requires_grad_(True)

@@ -7,13 +7,16 @@ import math
 import numpy as np
 import torch
 
-from oracle import model_cpu, hist, regnet as oracle_regnet
-from transfuser_amd import regnet as prod_regnet
+from oracle import model_cpu, hist, regnet as oracle_regnet, resnet as oracle_resnet
+from transfuser_amd import regnet as prod_regnet, resnet as prod_resnet
 from transfuser_amd.config import GlobalConfig
 from transfuser_amd.model import LidarCenterNet
 
 TINY = dict(widths=[24, 48, 72, 96], depths=[1, 2, 1, 1], group_w=24, se_ratio=0.25)
 prod_regnet.register_arch("regnety_tiny", **TINY)
+RESNET_TINY = dict(layers=(1, 2, 1, 1), widths=(16, 32, 48, 64), stem_width=16)        # BasicBlock; "resnet_tiny50": Bottleneck (expansion 4)
+prod_resnet.register_arch("resnet_tiny", prod_resnet.BasicBlock, RESNET_TINY["layers"], RESNET_TINY["widths"], RESNET_TINY["stem_width"])
+prod_resnet.register_arch("resnet_tiny50", prod_resnet.Bottleneck, (1, 1, 1, 1), (8, 16, 24, 32), 16)
 
 
 def tiny_config(n_layer=2, lidar_res=64, dropout=0.0, use_velocity=False):
@@ -70,7 +73,7 @@ def randomize(model, seed=1):
     g = torch.Generator().manual_seed(seed)
     with torch.no_grad():
         for n, p in model.named_parameters():
-            if n.endswith("bn.weight") or n.endswith("bn1.weight"):
+            if n.endswith(("bn.weight", "bn1.weight", "bn2.weight", "bn3.weight", "downsample.1.weight")):      # incl. the zero-initialised last BN of a residual branch
                 p.copy_(torch.rand(p.shape, generator=g) * 0.5 + 0.75)
             elif "pos_emb" in n:
                 p.copy_(torch.randn(p.shape, generator=g) * 0.05)
@@ -85,6 +88,12 @@ def build_pair(cfg, arch, dev, use_velocity=False, seed=0, backbone='transFuser'
     randomize(prod)
     if arch == "regnety_tiny":
         make_net = lambda in_chans=3: oracle_regnet.RegNet(TINY["widths"], TINY["depths"], TINY["group_w"], TINY["se_ratio"], in_chans)
+    elif arch == "resnet_tiny":
+        make_net = lambda in_chans=3: oracle_resnet.ResNet(oracle_resnet.BasicBlock, RESNET_TINY["layers"], in_chans, RESNET_TINY["widths"], RESNET_TINY["stem_width"])
+    elif arch == "resnet_tiny50":
+        make_net = lambda in_chans=3: oracle_resnet.ResNet(oracle_resnet.Bottleneck, (1, 1, 1, 1), in_chans, (8, 16, 24, 32), 16)
+    elif arch in oracle_resnet.ARCH:
+        make_net = oracle_resnet.ARCH[arch]
     else:
         make_net = oracle_regnet.regnety_032
     ref = model_cpu.LidarCenterNet(cfg, 'cpu', backbone, use_velocity=use_velocity, make_net=make_net)

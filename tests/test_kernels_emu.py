@@ -165,6 +165,10 @@ def test_conv1x1_stride2_dgrad_gemm_scatter():
     kc.check_conv1x1_s2_dgrad("cpu")
 
 
+def test_resnet_stem_conv7x7_and_maxpool():
+    kc.check_resnet_stem_and_pool("cpu")
+
+
 @pytest.mark.parametrize("case", kc.THIN_CONV_CASES, ids=str)
 def test_conv_thin_output(case):
     kc.check_conv_thin("cpu", *case)

@@ -172,6 +172,10 @@ def test_conv1x1_stride2_dgrad_gemm_scatter():
     kc.check_conv1x1_s2_dgrad("cuda")
 
 
+def test_resnet_stem_conv7x7_and_maxpool():
+    kc.check_resnet_stem_and_pool("cuda")
+
+
 @pytest.mark.parametrize("case", kc.THIN_CONV_CASES, ids=str)
 def test_conv_thin_output(case):
     kc.check_conv_thin("cuda", *case)

@@ -297,3 +297,16 @@ def test_lowp_storage_modes_tiny_model(mode):
         assert abs(res[True][0][k] - res[False][0][k]) <= 1e-4 * max(1.0, abs(res[False][0][k])), (k, res[True][0][k], res[False][0][k])
     rel = float((res[True][1] - res[False][1]).norm() / res[False][1].norm())
     assert rel <= 2e-3, rel
+
+
+@pytest.mark.parametrize("arch", ["resnet_tiny", "resnet_tiny50"])
+def test_resnet_trunks_match_oracle(arch):
+    """the ResNet trunks the reference's constructors default to (transfuser.py:15; timm names, no re-labelling: 7x7 / s2 stem +
+    3x3 / s2 max pool, BasicBlock / Bottleneck, 1x1-stride downsample) through the whole model: 11 losses, every parameter gradient, strict
+    state_dict key parity with the oracle (= timm's names)."""
+    cfg = mc.tiny_config(n_layer=1)
+    prod, ref = mc.build_pair(cfg, arch, "cpu")
+    assert any(k.endswith("image_encoder.features.layer2.0.downsample.0.weight") for k in prod.state_dict())
+    batch = mc.small_batch(2, 32, 64, 64, 40)
+    lp, lr = mc.run_pair(prod, ref, cfg, batch, "cpu")
+    mc.compare(prod, ref, lp, lr)

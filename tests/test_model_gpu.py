@@ -50,6 +50,19 @@ def test_regnety032_model_losses_and_grads(H, B):
     mc.compare_vs_fp64(prod, ref, lp, lr, batch, cfg)
 
 
+def test_default_resnet_trunks_reference_resolution():
+    """the reference's DEFAULT trunks (transfuser.py:15: 'resnet34' image / here also LiDAR; timm names, no re-labelling) at the
+    reference resolution 160x704, B = 2: 11 losses within 1e-3 of the CPU oracle, gradients anchored like the RegNet full-size test."""
+    from oracle import hist
+    from transfuser_amd.data import synthetic_batch
+    cfg = mc.full_config()
+    prod, ref = mc.build_pair(cfg, "resnet34", "cuda")
+    assert any(k.endswith("image_encoder.features.layer2.0.downsample.0.weight") for k in prod.state_dict())
+    batch = synthetic_batch(2, 160, 704, seed=0, hist_fn=hist.lidar_to_histogram_features, n_points=8192)
+    lp, lr = mc.run_pair(prod, ref, cfg, batch, "cuda")
+    mc.compare_vs_fp64(prod, ref, lp, lr, batch, cfg)
+
+
 def test_tiny_geometric_fusion_losses_and_grads():
     """BASELINE config 4 backbone (geometric_fusion.py): gather kernel G1, velocity embeddings, quirk Q4."""
     cfg = mc.tiny_config(n_layer=1, lidar_res=96)

@@ -94,6 +94,27 @@ row("adamw_kernel   168.0 M parameters  (28 B / parameter)", 28 * n, lambda: ops
 x = torch.randn(10 * 174, 1512, device=dev)
 seed = torch.zeros(1, dtype=torch.int32, device=dev)
 row("dropout_kernel [1740 x 1512]  (2 M C 4 B)", 2 * x.numel() * 4, lambda: ops.dropout(x, seed, 3, 0.1))
+# round 3: the decoders' thin-output tail (csrc/conv_thin.cpp), the 16-bit operand casts (csrc/cast16.cpp) and the ResNet max pool
+xt = torch.randn(10, 256, 704, 32, device=dev)
+for co in (7, 1):
+    wt = (torch.randn(co, 32, 3, 3, device=dev) * 0.1).contiguous(memory_format=torch.channels_last)
+    bt = torch.zeros(co, device=dev)
+    E, Eo = xt.numel(), 10 * 256 * 704 * co
+    row("conv3x3 thin fwd   32 -> %d at 10 x 256 x 704  (read x, write y)" % co, (E + Eo) * 4, lambda: ops.conv_fwd(xt, wt, bt, 1, None, 1), iters=min(10, args.iters))
+    dyt = torch.randn(10, 256, 704, co, device=dev)
+    dxt = torch.empty_like(xt)
+    row("conv3x3 thin dgrad 32 -> %d (+ ReLU mask)  (read dy, mask, write dx)" % co, (2 * E + Eo) * 4, lambda: ops.conv_dgrad(dyt, wt, xt.shape, 1, None, 1, out=dxt, mask=xt),
+        iters=min(10, args.iters))
+    dwt, dbt = torch.zeros_like(wt), torch.zeros(co, device=dev)
+    row("conv3x3 thin wgrad 32 -> %d (+ bias grad)  (read x, dy)" % co, (E + Eo) * 4, lambda: ops.conv_wgrad(dyt, xt, dwt, 1, None, 1, dbias=dbt), iters=min(10, args.iters))
+del xt, dxt
+ops.set_precision("bf16")
+for (M, C) in ((1740, 6048), (1740, 1512)):
+    xc = torch.randn(M, C, device=dev)
+    row("cast16 (row-major + transposed bf16 copies) [%d x %d]  (4 B read + 2 x 2 B written)" % (M, C), M * C * 8, lambda: ops.cast16(xc))
+ops.set_precision("fp32")
+xm = torch.randn(10, 128, 352, 64, device=dev)
+row("maxpool 3x3/s2 fwd (10, 128, 352, 64)  (read x, write y + 1 B index)", xm.numel() * 4 + xm.numel() // 4 * 5, lambda: ops.maxpool3x3s2_fwd(xm))
 torch.cuda.synchronize()
 if args.meta:
     json.dump(meta, open(args.meta, "w"), indent=1)

@@ -390,6 +390,76 @@ extern "C" int tf_bilinear_bwd_f32(const tf_bilinear_desc* d, const float* dy, f
     return launch_status("tf_bilinear_bwd_f32");
 }
 
+// ---- 3x3 / stride 2 / pad 1 max pooling on NHWC (timm ResNet stem, used by the reference's default resnet34 / resnet18 trunks under their
+// own name ``maxpool``: transfuser.py:139,143).  Forward keeps the winning tap (0..8, first maximum in (kh, kw) scan order like ATen's
+// max_pool2d) as one byte per output element; the backward is a gather over the <= 4 windows that contain an input pixel: deterministic.
+namespace {
+__global__ void __launch_bounds__(256) maxpool3_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, unsigned char* __restrict__ idx, int B, int Hi, int Wi,
+                                                           int C, int Ho, int Wo) {
+    const long total = (long)B * Ho * Wo * C;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        long t = i / C;
+        const int wo = (int)(t % Wo); t /= Wo;
+        const int ho = (int)(t % Ho);
+        const long b = t / Ho;
+        float best = -3.402823466e38f;
+        int arg = 0;
+        bool any = false;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int h = 2 * ho - 1 + kh, w = 2 * wo - 1 + kw;
+                if ((unsigned)h < (unsigned)Hi && (unsigned)w < (unsigned)Wi) {
+                    const float v = x[((b * Hi + h) * Wi + w) * C + c];
+                    if (!any || v > best) { best = v; arg = kh * 3 + kw; any = true; }
+                }
+            }
+        y[i] = best;
+        idx[i] = (unsigned char)arg;
+    }
+}
+__global__ void __launch_bounds__(256) maxpool3_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ idx, float* __restrict__ dx, int B, int Hi,
+                                                           int Wi, int C, int Ho, int Wo) {
+    const long total = (long)B * Hi * Wi * C;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        long t = i / C;
+        const int w = (int)(t % Wi); t /= Wi;
+        const int h = (int)(t % Hi);
+        const long b = t / Hi;
+        float acc = 0.f;
+        for (int ho = (h + 1) / 2 - 1; ho <= (h + 1) / 2; ++ho) {
+            const int kh = h - (2 * ho - 1);
+            if (ho < 0 || ho >= Ho || kh < 0 || kh > 2) continue;
+            for (int wo = (w + 1) / 2 - 1; wo <= (w + 1) / 2; ++wo) {
+                const int kw = w - (2 * wo - 1);
+                if (wo < 0 || wo >= Wo || kw < 0 || kw > 2) continue;
+                const long o = ((b * Ho + ho) * Wo + wo) * C + c;
+                if (idx[o] == kh * 3 + kw) acc += dy[o];
+            }
+        }
+        dx[i] = acc;
+    }
+}
+}  // namespace
+
+extern "C" int tf_maxpool3x3s2_fwd_f32(const float* x, float* y, unsigned char* idx, int B, int Hi, int Wi, int C, void* stream) {
+    TF_REQUIRE(x && y && idx && B > 0 && Hi > 0 && Wi > 0 && C > 0, "tf_maxpool3x3s2_fwd_f32: bad arguments");
+    const int Ho = (Hi - 1) / 2 + 1, Wo = (Wi - 1) / 2 + 1;
+    const long n = (long)B * Ho * Wo * C;
+    TF_LAUNCH(maxpool3_fwd_kernel, dim3(ew_blocks(n)), dim3(256), stream, x, y, idx, B, Hi, Wi, C, Ho, Wo);
+    return launch_status("tf_maxpool3x3s2_fwd_f32");
+}
+extern "C" int tf_maxpool3x3s2_bwd_f32(const float* dy, const unsigned char* idx, float* dx, int B, int Hi, int Wi, int C, void* stream) {
+    TF_REQUIRE(dy && dx && idx && B > 0 && Hi > 0 && Wi > 0 && C > 0, "tf_maxpool3x3s2_bwd_f32: bad arguments");
+    const int Ho = (Hi - 1) / 2 + 1, Wo = (Wi - 1) / 2 + 1;
+    const long n = (long)B * Hi * Wi * C;
+    TF_LAUNCH(maxpool3_bwd_kernel, dim3(ew_blocks(n)), dim3(256), stream, dy, idx, dx, B, Hi, Wi, C, Ho, Wo);
+    return launch_status("tf_maxpool3x3s2_bwd_f32");
+}
+
 extern "C" int tf_gather_sum_fwd_f32(const float* src, const long long* idx, int B, int Hs, int Ws, int E, int n, int K, float* out, void* stream) {
     TF_REQUIRE(src && idx && out && B > 0 && Hs > 0 && Ws > 0 && E > 0 && E % 4 == 0 && n > 0 && K > 0 && aligned16(src) && aligned16(out),
                "tf_gather_sum_fwd_f32: bad arguments (E must be a multiple of 4, pointers 16-byte aligned)");

@@ -172,25 +172,68 @@ def _bn_sync_bwd(dz, z, x, bn, st, want_dres):
 # ============================================================================================ stem
 @routes_param_grads
 class StemFn(torch.autograd.Function):
-    """conv3x3/s2 (no bias) + BatchNormAct2d on the NCHW model input (transfuser.py:136-143)."""
+    """First conv (no bias) + BatchNorm + ReLU on the NCHW model input (transfuser.py:136-143): 3x3 / s2 + BatchNormAct2d for the RegNet trunks,
+    7x7 / s2 / p3 + bn1 + act1 + the 3x3 / s2 max pool for the ResNet trunks (``stem.maxpool``)."""
 
     @staticmethod
     def forward(ctx, s0, s1, stem, w, gamma, beta):
-        y = ops.stem_conv_fwd(s0, s1, w, stem.normalize)
+        conv = stem.conv
+        stride, pad = conv.stride[0], conv.padding[0]
+        y = ops.stem_conv_fwd(s0, s1, w, stem.normalize, stride, pad)
         z, st = _bn(y, stem.bn, relu=True)
-        ctx.saved = (s0, s1, stem, w, y, z, st)
+        out, idx = ops.maxpool3x3s2_fwd(z) if getattr(stem, "maxpool", False) else (z, None)
+        ctx.saved = (s0, s1, stem, w, y, z, st, idx, stride, pad)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        if ctx.saved is None:
+            raise RuntimeError("StemFn: trying to backward through the graph a second time: the saved activations are freed by the first backward "
+                               "(retain_graph is not supported by the block Functions)")
+        s0, s1, stem, w, y, z, st, idx, stride, pad = ctx.saved
+        ctx.saved = None        # z is also this node's output: drop the ctx <-> output cycle now instead of waiting for the cyclic GC (~150 MB / step)
+        dz = dout.contiguous() if idx is None else ops.maxpool3x3s2_bwd(dout.contiguous(), idx, z.shape)
+        dy, _ = _bn_bwd(dz, z, y, stem.bn, st)
+        ops.stem_conv_wgrad(dy, s0, s1, gbuf(w), stem.normalize, stride=stride, pad=pad)
+        return (None,) * 6
+
+
+@routes_param_grads
+class ConvBnFn(torch.autograd.Function):
+    """conv (k x k, stride, no bias, groups 1) -> BatchNorm (+ residual) (+ ReLU) on NHWC: the unit the ResNet trunks are made of
+    (timm BasicBlock / Bottleneck / downsample; the reference's default architectures, transfuser.py:15).  The BatchNorm statistics come
+    from the convolution's epilogue where the engine can produce them."""
+
+    @staticmethod
+    def forward(ctx, x, res, conv, bn, relu, w, gamma, beta):
+        k, stride, pad = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+        B, H, W, Cin = x.shape
+        if k == 1 and stride == 1:
+            y, cs = ops.linear_fwd(x.view(-1, Cin), w2d(w), colstat=True)
+            y = y.view(B, H, W, w.shape[0])
+        else:
+            y, cs = ops.conv_fwd(x, w, None, stride, pad, 1, colstat=True)
+        z, st = _bn(y, bn, res=res, relu=relu, stat=cs)
+        ctx.saved = (x, conv, bn, relu, w, y, z, st, res is not None)
         return z
 
     @staticmethod
     def backward(ctx, dz):
         if ctx.saved is None:
-            raise RuntimeError("StemFn: trying to backward through the graph a second time: the saved activations are freed by the first backward "
-                               "(retain_graph is not supported by the block Functions)")
-        s0, s1, stem, w, y, z, st = ctx.saved
-        ctx.saved = None        # z is also this node's output: drop the ctx <-> output cycle now instead of waiting for the cyclic GC (~150 MB / step)
-        dy, _ = _bn_bwd(dz.contiguous(), z, y, stem.bn, st)
-        ops.stem_conv_wgrad(dy, s0, s1, gbuf(w), stem.normalize)
-        return (None,) * 6
+            raise RuntimeError("ConvBnFn: second backward through the same graph (retain_graph is not supported by the block Functions)")
+        x, conv, bn, relu, w, y, z, st, has_res = ctx.saved
+        ctx.saved = None
+        k, stride, pad = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+        B, H, W, Cin = x.shape
+        Cout = w.shape[0]
+        dy, dres = _bn_bwd(dz.contiguous(), z if relu else None, y, bn, st, want_dres=has_res)
+        if k == 1 and stride == 1:
+            ops.linear_wgrad(dy.view(-1, Cout), x.view(-1, Cin), w2d(gbuf(w)))
+            dx = ops.linear_dgrad(dy.view(-1, Cout), w2d(w)).view(B, H, W, Cin) if ctx.needs_input_grad[0] else None
+        else:
+            ops.conv_wgrad(dy, x, gbuf(w), stride, pad, 1)
+            dx = ops.conv_dgrad(dy, w, x.shape, stride, pad, 1) if ctx.needs_input_grad[0] else None
+        return dx, dres, None, None, None, None, None, None
 
 
 # ============================================================================================ RegNetY block

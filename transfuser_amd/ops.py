@@ -539,24 +539,43 @@ def conv_wgrad_takes_bias(x_shape, cout, ks, stride=1, pad=None, groups=1):
     return _thin_ok(x_shape, cout, x_shape[3], ks, stride, ks // 2 if pad is None else pad, groups)
 
 
-def stem_conv_fwd(s0, s1, w, normalize):
-    """3x3 stride-2 conv on NCHW inputs (s1 optional extra channels) -> NHWC."""
+def stem_conv_fwd(s0, s1, w, normalize, stride=2, pad=None):
+    """k x k conv (3x3 / s2 for RegNet, 7x7 / s2 / p3 for ResNet) on NCHW inputs (s1 optional extra channels) -> NHWC."""
     B, C0, H, W = s0.shape
     C1 = s1.shape[1] if s1 is not None else 0
-    g = conv_geom((B, H, W, C0 + C1), w.shape[0], 3, 2, 1, 1)
+    ks = w.shape[2]
+    g = conv_geom((B, H, W, C0 + C1), w.shape[0], ks, stride, ks // 2 if pad is None else pad, 1)
     y = torch.empty(B, g.Ho, g.Wo, g.Cout, dtype=torch.float32, device=s0.device)
     check(L().tf_stem_conv_fwd_f32(byref(g), ptr(_c(s0)), C0, ptr(_c(s1)) if s1 is not None else c_p(0), C1, int(normalize), wptr(w), ptr(y),
                                    stream_of(s0)), "tf_stem_conv_fwd_f32")
     return y
 
 
-def stem_conv_wgrad(dy, s0, s1, dw, normalize, accumulate=True):
+def stem_conv_wgrad(dy, s0, s1, dw, normalize, accumulate=True, stride=2, pad=None):
     B, C0, H, W = s0.shape
     C1 = s1.shape[1] if s1 is not None else 0
-    g = conv_geom((B, H, W, C0 + C1), dw.shape[0], 3, 2, 1, 1)
+    ks = dw.shape[2]
+    g = conv_geom((B, H, W, C0 + C1), dw.shape[0], ks, stride, ks // 2 if pad is None else pad, 1)
     check(L().tf_stem_conv_wgrad_f32(byref(g), ptr(_c(dy)), ptr(_c(s0)), C0, ptr(_c(s1)) if s1 is not None else c_p(0), C1, int(normalize),
                                      wptr(dw), int(accumulate), stream_of(dy)), "tf_stem_conv_wgrad_f32")
     return dw
+
+
+def maxpool3x3s2_fwd(x):
+    """nn.MaxPool2d(3, 2, 1) on NHWC (timm ResNet stem) -> (y, idx uint8 winning taps)."""
+    B, H, W, C = x.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = torch.empty(B, Ho, Wo, C, dtype=torch.float32, device=x.device)
+    idx = torch.empty(B, Ho, Wo, C, dtype=torch.uint8, device=x.device)
+    check(L().tf_maxpool3x3s2_fwd_f32(ptr(_c(x)), ptr(y), ctypes.c_void_p(idx.data_ptr()), B, H, W, C, stream_of(x)), "tf_maxpool3x3s2_fwd_f32")
+    return y, idx
+
+
+def maxpool3x3s2_bwd(dy, idx, x_shape):
+    B, H, W, C = x_shape
+    dx = torch.empty(tuple(x_shape), dtype=torch.float32, device=dy.device)
+    check(L().tf_maxpool3x3s2_bwd_f32(ptr(_c(dy)), ctypes.c_void_p(idx.data_ptr()), ptr(dx), B, H, W, C, stream_of(dy)), "tf_maxpool3x3s2_bwd_f32")
+    return dx
 
 
 # ------------------------------------------------------------------------------------------ norms

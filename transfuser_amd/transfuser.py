@@ -13,6 +13,7 @@ from torch import nn
 
 from . import functions as F_
 from . import regnet
+from . import resnet
 
 
 def nchw(x):
@@ -124,10 +125,11 @@ class GPT(nn.Module):
 class _Stem:
     """First conv + BN of a trunk as StemFn sees them (the modules stay registered under the reference's names)."""
 
-    def __init__(self, conv, bn, normalize, owner=None, names=None):
+    def __init__(self, conv, bn, normalize, owner=None, names=None, maxpool=False):
         """``owner`` / ``names`` = (module, (conv attribute, bn attribute)): when given the two layers are looked up at every call, so a
         BatchNorm replaced after construction (torch.nn.SyncBatchNorm.convert_sync_batchnorm, train.py:133) is picked up."""
         self._conv, self._bn, self.normalize, self._owner, self._names = conv, bn, normalize, owner, names
+        self.maxpool = bool(maxpool)      # ResNet: the 3x3 / s2 max pool behind act1 (transfuser.py:139,143) runs inside StemFn
 
     @property
     def conv(self):
@@ -153,22 +155,35 @@ def _relabel(net):
     net.head = nn.Sequential()
 
 
+def _create_trunk(architecture, pretrained, in_chans=3):
+    """timm.create_model for the architectures built here: RegNetY (re-labelled like transfuser.py:383-393) and the ResNets the reference's
+    constructors default to (timm's own names: nothing to re-label, transfuser.py:383 falls through)."""
+    if resnet.is_resnet(architecture):
+        net = resnet.create_model(architecture, pretrained=pretrained, in_chans=in_chans)
+        net.fc = None
+        return net
+    if architecture.startswith("convnext"):
+        raise ValueError("transfuser_amd: the ConvNeXt re-labelling branch (transfuser.py:395-416) is not built; RegNetY and ResNet trunks are")
+    net = regnet.create_model(architecture, pretrained=pretrained, in_chans=in_chans)
+    _relabel(net)
+    return net
+
+
 class ImageCNN(nn.Module):
     def __init__(self, architecture, normalize=True, out_features=512):
         super().__init__()
         self.normalize = normalize
-        self.features = regnet.create_model(architecture, pretrained=True)
-        _relabel(self.features)
+        self.features = _create_trunk(architecture, True)
 
 
 class LidarEncoder(nn.Module):
     def __init__(self, architecture, in_channels=2, out_features=512):
         super().__init__()
-        self._model = regnet.create_model(architecture, pretrained=False)
-        _relabel(self._model)
+        self._model = _create_trunk(architecture, False)
         old = self._model.conv1
         self._model.conv1 = nn.Conv2d(in_channels, old.out_channels, kernel_size=old.kernel_size, stride=old.stride, padding=old.padding, bias=False)
-        del self._model.stem.conv  # transfuser.py:482-483
+        if hasattr(self._model, "stem"):
+            del self._model.stem.conv  # transfuser.py:482-483
 
 
 class _FusionBackbone(nn.Module):
@@ -225,8 +240,9 @@ class _FusionBackbone(nn.Module):
         self.up_conv4 = nn.Conv2d(channel, channel, (1, 1))
         self.up_conv3 = nn.Conv2d(channel, channel, (1, 1))
         self.c5_conv = nn.Conv2d(pf, channel, (1, 1))
-        self._img_stem = _Stem(None, None, True, self.image_encoder.features, ("conv1", "bn1"))
-        self._lid_stem = _Stem(None, None, False, self.lidar_encoder._model, ("conv1", "bn1"))
+        has_pool = lambda net: isinstance(getattr(net, "maxpool", None), nn.MaxPool2d)
+        self._img_stem = _Stem(None, None, True, self.image_encoder.features, ("conv1", "bn1"), has_pool(self.image_encoder.features))
+        self._lid_stem = _Stem(None, None, False, self.lidar_encoder._model, ("conv1", "bn1"), has_pool(self.lidar_encoder._model))
 
     def _side_stream(self, device):
         st = getattr(self, "_side", None)
@@ -388,7 +404,8 @@ class latentTFBackbone(TransfuserBackbone):
 
     def __init__(self, config, image_architecture='resnet34', lidar_architecture='resnet18', use_velocity=True):
         super().__init__(config, image_architecture, lidar_architecture, use_velocity)
-        del self.lidar_encoder._model.stem
+        if hasattr(self.lidar_encoder._model, "stem"):
+            del self.lidar_encoder._model.stem
         self._grid = None
 
     def _pos_grid(self, B, device):
