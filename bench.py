@@ -30,7 +30,8 @@ GFLOP_PER_SAMPLE = {("transFuser", 160): 230.3, ("transFuser", 256): 266.6, ("la
                     ("geometric_fusion", 160): 110.2}   # algorithmic training FLOPs (3x forward), SURVEY.md section 8(d)
 PEAK_F32_MFMA_TF = 157.3                                # /opt/skills/guides/MI355X_MICROARCH.md (v_mfma_f32_32x32x2_f32)
 PEAK_BF16_MFMA_TF = 2500.0                              # dense bf16 MFMA peak of the same guide (never the 2:1-sparsity figure)
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_gemm_roofline.json")   # written by tools/pmc_roofline.sh (rocprofv3 --pmc passes)
+PMC_FILE = next((f for f in (os.path.join(ROOT, "profiles", "r03_pmc_gemm_roofline.json"), os.path.join(ROOT, "profiles", "r02_pmc_gemm_roofline.json")) if os.path.exists(f)),
+                os.path.join(ROOT, "profiles", "r03_pmc_gemm_roofline.json"))   # written by tools/pmc_roofline.sh (rocprofv3 --pmc passes); newest committed summary
 DOMINANT = ("gemm a0b0", (1740, 6048, 1512, 1))         # GPT-4 mlp.0 forward: [1740 x 1512] . [1512 x 6048], bias + ReLU epilogue
 
 
