@@ -103,6 +103,23 @@ int tf_conv3x3_small_dgrad_f32(const float* dy, const float* w, float* dx, int B
 long tf_conv3x3_small_wgrad_ws_floats(void);
 int tf_conv3x3_small_wgrad_f32(const float* dy, const float* x, float* dw, int B, int H, int W, int Cin, int Cout, int accumulate, float* ws, void* stream);
 
+/* ---- BatchNorm apply folded into its CONSUMERS (round 3; the conv2 -> BatchNormAct2d -> SEModule -> conv3 segment of every timm RegNetY
+ * bottleneck, transfuser.py:380,442): z = max(x scale + shift, 0) is recomputed from the convolution output wherever it is needed - the SE
+ * squeeze, the SE scale, the gate gradient, the BatchNorm backward's ReLU mask - and never written.  tf_bn_finalize_parts_f32 = the finalize half
+ * of tf_bn_fwd_parts_f32 (coef_out = [scale | shift], 2 C floats owned by the caller: read again in the backward).  The *_parts entry points
+ * leave / take [segment][chunk][C] chunk sums in the reduction workspace (nchunks is returned on the host); the excitation kernels finish them. */
+int tf_bn_finalize_parts_f32(const float* parts, int nparts, int rows, int C, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                             float momentum, float eps, float* save_mean, float* save_invstd, float* coef_out, void* stream);
+int tf_colsum_bnrelu_parts_f32(const float* x, const float* coef, int nseg, int rows_per_seg, int C, float* ws, int* nchunks, void* stream);
+int tf_se_excite_fwd_parts_f32(const float* parts, int nchunks, float scale, const float* W1, const float* b1, const float* W2, const float* b2, int B, int C,
+                               int Cr, float* s_out, float* g1, float* gate, float* bwd_scratch, void* stream);
+int tf_se_scale_bn_fwd_f32(const float* x, const float* coef, const float* gate, float* y, int B, int HW, int C, void* stream);
+int tf_se_gate_grad_parts_f32(const float* dy, const float* x, const float* coef, int B, int HW, int C, float* ws, int* nchunks, void* stream);
+int tf_se_excite_bwd_parts_f32(const float* parts, int nchunks, const float* gate, const float* s, const float* g1, const float* W1, const float* W2, int B,
+                               int C, int Cr, float* dW1, float* db1, float* dW2, float* db2, float* ds, float* scratch, int scratch_is_zero, void* stream);
+int tf_bn_bwd_remask_f32(const float* dz, const float* x, const float* fwd_coef, int rows, int C, const float* gamma, const float* save_mean,
+                         const float* save_invstd, float* dx, float* dgamma, float* dbeta, float* ws, void* stream);
+
 /* ---- 16-bit operand STORAGE path (BASELINE configs[2] "bf16", configs[4] "fp16 MFMA"; the reference trains fp32 only, config.py:55).
  * tf_cast16_f32: x (rows x cols fp32, row stride ldx) -> y16 (rows x cols, row stride ldy, pad columns zeroed) and / or y16t (cols x rows: the
  * TRANSPOSE, row stride ldyt % 8 == 0, rows zero-padded to a multiple of 8); dtype 1 = bf16, 2 = IEEE half, round to nearest even.

@@ -211,6 +211,49 @@ def check_stem(dev, B, H, W):
     close(ops.stem_conv_fwd(l0, l1, cl(w2), False).permute(0, 3, 1, 2), y2, what="lidar stem fwd")
 
 
+def check_bn_se_consumer_fusion(dev, B=3, H=6, W=10, C=48, Cr=12):
+    """BatchNorm apply folded into its consumers (conv2 -> BN -> ReLU -> SE of a RegNetY bottleneck): the fused ops (statistics finalize ->
+    squeeze chunk sums of relu(bn(y)) finished inside the excitation kernel -> BN + ReLU + SE scale in one pass; backward: gate gradient from
+    recomputed z, BatchNorm backward with the recomputed mask) against PyTorch autograd of the same sub-graph."""
+    y = R(B, H, W, C, dev=dev)
+    gamma, beta = (torch.rand(C, device=dev) * 0.5 + 0.75), R(C, seed=2, dev=dev) * 0.3
+    w1, b1 = R(Cr, C, 1, 1, seed=3, dev=dev) * 0.3, R(Cr, seed=4, dev=dev) * 0.1
+    w2, b2 = R(C, Cr, 1, 1, seed=5, dev=dev) * 0.3, R(C, seed=6, dev=dev) * 0.1
+    # reference (PyTorch): batch statistics, biased variance, eps 1e-5
+    yr = y.detach().clone().requires_grad_(True)
+    prm = [t.detach().clone().requires_grad_(True) for t in (gamma, beta, w1, b1, w2, b2)]
+    mean, var = yr.mean((0, 1, 2)), yr.var((0, 1, 2), unbiased=False)
+    z = torch.relu((yr - mean) / torch.sqrt(var + 1e-5) * prm[0] + prm[1])
+    sq = z.mean((1, 2))
+    g1r = torch.relu(sq @ prm[2].view(Cr, C).t() + prm[3])
+    gater = g1r @ prm[4].view(C, Cr).t() + prm[5]
+    zs = z * torch.sigmoid(gater)[:, None, None, :]
+    dzs = R(B, H, W, C, seed=7, dev=dev)
+    grads = torch.autograd.grad(zs, [yr] + prm, dzs)
+    # product: statistics as a producer's epilogue would have written them (one part = the whole tensor, Welford triple)
+    rows = B * H * W
+    cs = ops.ColStat(rows, C, dev, max_parts=1)
+    y2 = y.reshape(rows, C)
+    m = y2.mean(0)
+    cs.buf[:C] = rows; cs.buf[C:2 * C] = m; cs.buf[2 * C:] = ((y2 - m) ** 2).sum(0)
+    cs.nparts.value = 1
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    coef, sm, si = ops.bn_finalize_parts(cs, gamma, beta, rm, rv)
+    close(sm, mean, what="fused bn mean"); close(si, 1.0 / torch.sqrt(var + 1e-5), tol=1e-4, what="fused bn invstd")
+    s_, g1, gate = ops.se_squeeze_excite_bn_fwd(y, coef, w1, b1, w2, b2)
+    close(s_, sq, what="fused squeeze"); close(g1, g1r, what="fused excite g1"); close(gate, gater, what="fused gate")
+    close(ops.se_scale_bn_fwd(y, coef, gate), zs, what="fused bn + relu + se scale")
+    dw1, db1, dw2, db2 = torch.zeros_like(w1), torch.zeros_like(b1), torch.zeros_like(w2), torch.zeros_like(b2)
+    ds = ops.se_gate_excite_bn_bwd(dzs, y, coef, gate, s_, g1, w1, w2, dw1, db1, dw2, db2)
+    for got, ref, what in ((dw1, grads[3], "dW1"), (db1, grads[4], "db1"), (dw2, grads[5], "dW2"), (db2, grads[6], "db2")):
+        close(got, ref, tol=1e-4, what="fused excite bwd " + what)
+    dz = ops.se_scale_bwd_x(dzs, gate, ds, y.shape)
+    dgm, dbt = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    dy = ops.bn_bwd_remask(dz, y, coef, gamma, sm, si, dgm, dbt)
+    close(dy, grads[0], tol=1e-4, what="fused bn bwd (recomputed mask)")
+    close(dgm, grads[1], tol=1e-4, what="fused bn dgamma"); close(dbt, grads[2], tol=1e-4, what="fused bn dbeta")
+
+
 def check_resnet_stem_and_pool(dev):
     """The ResNet stem pieces (timm resnet18/34/50: the reference's default trunks, transfuser.py:15,136-143): 7x7 / s2 / p3 convolution on the
     NCHW inputs (with normalize_imagenet folded in, or the LiDAR + target-point channels un-concatenated) and nn.MaxPool2d(3, 2, 1) forward /

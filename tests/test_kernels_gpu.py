@@ -172,6 +172,11 @@ def test_conv1x1_stride2_dgrad_gemm_scatter():
     kc.check_conv1x1_s2_dgrad("cuda")
 
 
+@pytest.mark.parametrize("case", [(3, 6, 10, 48, 12), (2, 16, 44, 576, 144), (10, 5, 7, 72, 8)], ids=str)
+def test_bn_apply_folded_into_se_consumers(case):
+    kc.check_bn_se_consumer_fusion("cuda", *case)
+
+
 def test_resnet_stem_conv7x7_and_maxpool():
     kc.check_resnet_stem_and_pool("cuda")
 

@@ -54,6 +54,10 @@ inline RedPlan plan_reduce(int rows, int C, int nseg, int nacc, bool allow_vec =
     return p;
 }
 
+inline void cap_chunks(RedPlan& p, int rows, int maxc) {
+    if (p.nchunks > maxc) { p.rows_per_chunk = cdiv(rows, maxc); p.nchunks = cdiv(rows, p.rows_per_chunk); }
+}
+
 // ---- functors: eval(global_row, c, out[NACC]) ------------------------------------------------
 template <int V> struct SumF {
     const float* x; int C;
@@ -94,6 +98,38 @@ template <int V> struct MaskSumF {  // dy * [y > 0] (bias gradient behind a fuse
 #pragma unroll
             for (int i = 0; i < V; ++i) if (!(b.v[i] > 0.f)) a.v[i] = 0.f; }
         o[0] = a;
+    }
+};
+
+// ---- BatchNorm apply folded into its CONSUMERS (the conv2 -> BN -> ReLU -> SE part of a RegNetY bottleneck): z = max(x sc + sh, 0) is
+// recomputed from the convolution output x and the layer's (scale | shift) wherever it is needed and never written to memory.
+// The expression is the one bn_apply_kernel evaluates (multiply, then add: -ffp-contract=off), so a recomputed ReLU mask is bit-identical.
+template <int V> struct BnReluSumF {   // SE squeeze of the BN + ReLU output
+    const float* x; const float* coef; int C;
+    __device__ __forceinline__ void eval(long row, int c, vecf<V>* o) const {
+        vecf<V> a = ldv<V>(x + row * C + c), sc = ldv<V>(coef + c), sh = ldv<V>(coef + C + c);
+#pragma unroll
+        for (int i = 0; i < V; ++i) o[0].v[i] = fmaxf(a.v[i] * sc.v[i] + sh.v[i], 0.f);
+    }
+};
+template <int V> struct BnReluMulF {   // SE gate gradient: dy * z
+    const float* dy; const float* x; const float* coef; int C;
+    __device__ __forceinline__ void eval(long row, int c, vecf<V>* o) const {
+        vecf<V> g = ldv<V>(dy + row * C + c), a = ldv<V>(x + row * C + c), sc = ldv<V>(coef + c), sh = ldv<V>(coef + C + c);
+#pragma unroll
+        for (int i = 0; i < V; ++i) o[0].v[i] = g.v[i] * fmaxf(a.v[i] * sc.v[i] + sh.v[i], 0.f);
+    }
+};
+template <int V> struct BnBwdRemaskF {  // BnBwdF with the ReLU mask recomputed from x: g = dz * [x sc + sh > 0]; (g, g * xhat)
+    const float* dz; const float* x; const float* coef; const float* mean; const float* invstd; int C;
+    __device__ __forceinline__ void eval(long row, int c, vecf<V>* o) const {
+        vecf<V> g = ldv<V>(dz + row * C + c), a = ldv<V>(x + row * C + c), m = ldv<V>(mean + c), s = ldv<V>(invstd + c), sc = ldv<V>(coef + c), sh = ldv<V>(coef + C + c);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            if (!(a.v[i] * sc.v[i] + sh.v[i] > 0.f)) g.v[i] = 0.f;
+            o[0].v[i] = g.v[i];
+            o[1].v[i] = g.v[i] * ((a.v[i] - m.v[i]) * s.v[i]);
+        }
     }
 };
 
@@ -435,6 +471,37 @@ __global__ void __launch_bounds__(256) se_scale_kernel(const float* __restrict__
         stv<V>(y + i * V, a);
     }
 }
+// y = max(x sc + sh, 0) * sigmoid(gate[b][c]): BatchNorm apply + ReLU + SE scale in one pass (the BN output itself is never stored)
+template <int V>
+__global__ void __launch_bounds__(256) se_scale_bn_kernel(const float* __restrict__ x, const float* __restrict__ coef, const float* __restrict__ gate,
+                                                          float* __restrict__ y, long nvec, int C, long vec_per_b) {
+    const int cv = C / V;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % cv) * V;
+        const long b = i / vec_per_b;
+        vecf<V> a = ldv<V>(x + i * V), g = ldv<V>(gate + b * C + c), sc = ldv<V>(coef + c), sh = ldv<V>(coef + C + c);
+#pragma unroll
+        for (int k = 0; k < V; ++k) a.v[k] = fmaxf(a.v[k] * sc.v[k] + sh.v[k], 0.f) * (1.f / (1.f + expf(-g.v[k])));
+        stv<V>(y + i * V, a);
+    }
+}
+// bn_bwd_apply_kernel with the ReLU mask recomputed from x and the forward (scale | shift)
+template <int V>
+__global__ void __launch_bounds__(256) bn_bwd_apply_remask_kernel(const float* __restrict__ dz, const float* __restrict__ x, const float* __restrict__ fcoef,
+                                                                  const float* __restrict__ coef, float* __restrict__ dx, long nvec, int C) {
+    const int cv = C / V;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % cv) * V;
+        vecf<V> g = ldv<V>(dz + i * V), a = ldv<V>(x + i * V), A = ldv<V>(coef + c), Bc = ldv<V>(coef + C + c), Cc = ldv<V>(coef + 2 * C + c);
+        vecf<V> sc = ldv<V>(fcoef + c), sh = ldv<V>(fcoef + C + c);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            if (!(a.v[k] * sc.v[k] + sh.v[k] > 0.f)) g.v[k] = 0.f;
+            a.v[k] = A.v[k] * g.v[k] + Bc.v[k] * a.v[k] + Cc.v[k];
+        }
+        stv<V>(dx + i * V, a);
+    }
+}
 // dx (+)= dy * sigmoid(gate[b][c]) + dmean[b][c] * inv_hw      (either term optional)
 template <int V>
 __global__ void __launch_bounds__(256) se_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ gate, const float* __restrict__ dmean,
@@ -609,4 +676,64 @@ extern "C" int tf_se_scale_bwd_x_f32(const float* dy, const float* gate, const f
     if (v4) TF_LAUNCH(se_bwd_apply_kernel<4>, dim3(ew_blocks(n / 4)), dim3(256), stream, dy, gate, dmean, dx, n / 4, C, (long)HW * C / 4, 1.f / HW, accumulate);
     else TF_LAUNCH(se_bwd_apply_kernel<1>, dim3(ew_blocks(n)), dim3(256), stream, dy, gate, dmean, dx, n, C, (long)HW * C, 1.f / HW, accumulate);
     return launch_status("tf_se_scale_bwd_x_f32");
+}
+
+// ---- BatchNorm apply folded into the consumers (YBlockFn's conv2 -> BN -> ReLU -> SE -> conv3 segment)
+// finalize only: save_mean / save_invstd / running statistics + coef_out = [scale | shift] (2 C floats the CALLER owns: they are read by the
+// consumers of this layer in the forward AND the backward pass)
+extern "C" int tf_bn_finalize_parts_f32(const float* parts, int nparts, int rows, int C, const float* gamma, const float* beta, float* running_mean,
+                                        float* running_var, float momentum, float eps, float* save_mean, float* save_invstd, float* coef_out, void* stream) {
+    TF_REQUIRE(parts && nparts > 0 && gamma && beta && save_mean && save_invstd && coef_out && rows > 0 && C > 0, "tf_bn_finalize_parts_f32: bad arguments");
+    TF_LAUNCH(bn_fwd_finalize_parts_kernel, dim3(cdiv(C, 4)), dim3(256), stream, parts, nparts, gamma, beta, running_mean, running_var, save_mean, save_invstd,
+              coef_out, C, (float)rows, momentum, eps);
+    return launch_status("tf_bn_finalize_parts_f32");
+}
+// partial column sums (one per row chunk) of max(x sc + sh, 0) per segment: ws[(seg * nchunks + chunk) * C + c]; *nchunks is set on the host.
+// The consumer (tf_se_excite_fwd_parts_f32) adds the chunks up itself: no finalize launch.
+extern "C" int tf_colsum_bnrelu_parts_f32(const float* x, const float* coef, int nseg, int rows_per_seg, int C, float* ws, int* nchunks, void* stream) {
+    TF_REQUIRE(x && coef && ws && nchunks && nseg > 0 && rows_per_seg > 0 && C > 0, "tf_colsum_bnrelu_parts_f32: bad arguments");
+    RedPlan p = plan_reduce(rows_per_seg, C, nseg, 1, aligned16(x) && aligned16(coef));
+    cap_chunks(p, rows_per_seg, 8);      // the consumer sums the chunks serially: few, fat chunks (nseg x coltiles x 8 blocks still fill the GPU)
+    BnReluSumF<4> f4{x, coef, C};
+    BnReluSumF<1> f1{x, coef, C};
+    launch_reduce<1>(p, f4, f1, rows_per_seg, C, nseg, ws, stream);
+    *nchunks = p.nchunks;
+    return launch_status("tf_colsum_bnrelu_parts_f32");
+}
+// the same for the SE gate gradient: partial sums over hw of dy * max(x sc + sh, 0) per sample
+extern "C" int tf_se_gate_grad_parts_f32(const float* dy, const float* x, const float* coef, int B, int HW, int C, float* ws, int* nchunks, void* stream) {
+    TF_REQUIRE(dy && x && coef && ws && nchunks && B > 0 && HW > 0 && C > 0, "tf_se_gate_grad_parts_f32: bad arguments");
+    RedPlan p = plan_reduce(HW, C, B, 1, aligned16(x) && aligned16(coef) && aligned16(dy));
+    cap_chunks(p, HW, 8);
+    BnReluMulF<4> f4{dy, x, coef, C};
+    BnReluMulF<1> f1{dy, x, coef, C};
+    launch_reduce<1>(p, f4, f1, HW, C, B, ws, stream);
+    *nchunks = p.nchunks;
+    return launch_status("tf_se_gate_grad_parts_f32");
+}
+extern "C" int tf_se_scale_bn_fwd_f32(const float* x, const float* coef, const float* gate, float* y, int B, int HW, int C, void* stream) {
+    TF_REQUIRE(x && coef && gate && y && B > 0 && HW > 0 && C > 0, "tf_se_scale_bn_fwd_f32: bad arguments");
+    const long n = (long)B * HW * C;
+    if (C % 4 == 0 && aligned16(x) && aligned16(y) && aligned16(gate) && aligned16(coef))
+        TF_LAUNCH(se_scale_bn_kernel<4>, dim3(ew_blocks(n / 4)), dim3(256), stream, x, coef, gate, y, n / 4, C, (long)HW * C / 4);
+    else
+        TF_LAUNCH(se_scale_bn_kernel<1>, dim3(ew_blocks(n)), dim3(256), stream, x, coef, gate, y, n, C, (long)HW * C);
+    return launch_status("tf_se_scale_bn_fwd_f32");
+}
+// BatchNorm backward behind a ReLU whose output was never stored: the mask is [x sc + sh > 0] with the forward's (scale | shift) = fcoef
+extern "C" int tf_bn_bwd_remask_f32(const float* dz, const float* x, const float* fcoef, int rows, int C, const float* gamma, const float* save_mean,
+                                    const float* save_invstd, float* dx, float* dgamma, float* dbeta, float* ws, void* stream) {
+    TF_REQUIRE(dz && x && fcoef && gamma && save_mean && save_invstd && dx && ws && rows > 0 && C > 0, "tf_bn_bwd_remask_f32: bad arguments");
+    float* coef = ws + kWsFloats / 2;
+    const bool v4 = (C % 4 == 0) && aligned16(dz) && aligned16(x) && aligned16(dx) && aligned16(fcoef);
+    RedPlan p = plan_reduce(rows, C, 1, 2, v4);
+    BnBwdRemaskF<4> f4{dz, x, fcoef, save_mean, save_invstd, C};
+    BnBwdRemaskF<1> f1{dz, x, fcoef, save_mean, save_invstd, C};
+    launch_reduce<2>(p, f4, f1, rows, C, 1, ws, stream);
+    TF_LAUNCH(bn_bwd_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), stream, (const float*)ws, gamma, save_mean, save_invstd, dgamma, dbeta, coef, C, p.nchunks,
+              (float)rows);
+    const long n = (long)rows * C;
+    if (v4) TF_LAUNCH(bn_bwd_apply_remask_kernel<4>, dim3(ew_blocks(n / 4)), dim3(256), stream, dz, x, fcoef, (const float*)coef, dx, n / 4, C);
+    else TF_LAUNCH(bn_bwd_apply_remask_kernel<1>, dim3(ew_blocks(n)), dim3(256), stream, dz, x, fcoef, (const float*)coef, dx, n, C);
+    return launch_status("tf_bn_bwd_remask_f32");
 }

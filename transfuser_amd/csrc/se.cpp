@@ -19,15 +19,31 @@ constexpr int SE_MAXC = 4096, SE_MAXR = 1024;
 __device__ __forceinline__ float dot4(const float4 a, const float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 
 // g1[b][j] = relu(b1[j] + sum_k W1[j][k] s[b][k]);   gate[b][n] = b2[n] + sum_j W2[n][j] g1[b][j]
+// nch > 0: ``s`` holds the squeeze as nch partial column sums per sample, [b][chunk][C] (tf_colsum_bnrelu_parts_f32): they are added up here
+// (x scale = 1 / HW) instead of by a finalize launch, and block (b, 0) writes the squeezed vector to s_out for the backward.
 template <bool V4>
 __global__ void __launch_bounds__(1024) se_excite_fwd_kernel(const float* __restrict__ s, const float* __restrict__ W1, const float* __restrict__ b1,
                                                              const float* __restrict__ W2, const float* __restrict__ b2, int C, int Cr,
-                                                             float* __restrict__ g1, float* __restrict__ gate, float* __restrict__ zs) {
+                                                             float* __restrict__ g1, float* __restrict__ gate, float* __restrict__ zs, int nch = 0,
+                                                             float scale = 1.f, float* __restrict__ s_out = nullptr) {
     __shared__ __attribute__((aligned(16))) float ss[SE_MAXC];
     __shared__ __attribute__((aligned(16))) float hh[SE_MAXR];
     const int b = blockIdx.x, part = blockIdx.y;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
-    for (int k = tid; k < C; k += blockDim.x) ss[k] = s[(long)b * C + k];
+    if (nch > 0) {
+        for (int k = tid; k < C; k += blockDim.x) {
+            const float* p = s + (long)b * nch * C + k;
+            float v = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;      // four independent chains: the chunk loads are in flight together
+            int j = 0;
+            for (; j + 3 < nch; j += 4) { v += p[(long)j * C]; v1 += p[(long)(j + 1) * C]; v2 += p[(long)(j + 2) * C]; v3 += p[(long)(j + 3) * C]; }
+            for (; j < nch; ++j) v += p[(long)j * C];
+            v = ((v + v1) + (v2 + v3)) * scale;
+            ss[k] = v;
+            if (part == 0) s_out[(long)b * C + k] = v;
+        }
+    } else {
+        for (int k = tid; k < C; k += blockDim.x) ss[k] = s[(long)b * C + k];
+    }
     __syncthreads();
     // SE_U independent dot products per wave iteration: SE_U x more loads in flight (the weights come from HBM, ~1 us away)
     for (int j0 = wave * SE_U; j0 < Cr; j0 += nw * SE_U) {
@@ -106,7 +122,8 @@ __global__ void __launch_bounds__(256) se_zero_kernel(float* __restrict__ p, int
 constexpr int SE_ROWS = 8;
 __global__ void __launch_bounds__(256) se_excite_bwd2_kernel(const float* __restrict__ dgate, const float* __restrict__ g1, const float* __restrict__ W2,
                                                              int B, int C, int Cr, float* __restrict__ dW2, float* __restrict__ db2,
-                                                             float* __restrict__ dg1, float* __restrict__ ds_zero) {
+                                                             float* __restrict__ dg1, float* __restrict__ ds_zero, int nch = 0,
+                                                             const float* __restrict__ gate = nullptr) {
     __shared__ float dgs[SE_MAXB][SE_ROWS];
     // ds (B x C) is ACCUMULATED by the j-sliced fc1 pass that follows: cleared here, one slice per block
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (long)B * C; i += (long)gridDim.x * 256) ds_zero[i] = 0.f;
@@ -115,7 +132,22 @@ __global__ void __launch_bounds__(256) se_excite_bwd2_kernel(const float* __rest
     const int rows = (C - n0 < SE_ROWS) ? C - n0 : SE_ROWS;
     for (int i = tid; i < B * SE_ROWS; i += 256) {
         const int b = i / SE_ROWS, r = i % SE_ROWS;
-        dgs[b][r] = r < rows ? dgate[(long)b * C + n0 + r] : 0.f;
+        float v = 0.f;
+        if (r < rows) {
+            if (nch > 0) {     // dgate arrives as nch partial sums per sample of sum_hw dy z (tf_se_gate_grad_parts_f32): finish it here, x s (1 - s)
+                const float* p = dgate + (long)b * nch * C + n0 + r;
+                float v1 = 0.f, v2 = 0.f, v3 = 0.f;
+                int j = 0;
+                for (; j + 3 < nch; j += 4) { v += p[(long)j * C]; v1 += p[(long)(j + 1) * C]; v2 += p[(long)(j + 2) * C]; v3 += p[(long)(j + 3) * C]; }
+                for (; j < nch; ++j) v += p[(long)j * C];
+                v = (v + v1) + (v2 + v3);
+                const float sg = 1.f / (1.f + expf(-gate[(long)b * C + n0 + r]));
+                v *= sg * (1.f - sg);
+            } else {
+                v = dgate[(long)b * C + n0 + r];
+            }
+        }
+        dgs[b][r] = v;
     }
     for (int i = tid; i < B * Cr; i += 256) g1s[i] = g1[i];
     __syncthreads();
@@ -219,4 +251,27 @@ extern "C" int tf_se_excite_bwd_f32(const float* dgate, const float* s, const fl
     TF_LAUNCH(se_excite_bwd2_kernel, dim3(cdiv(C, SE_ROWS)), dim3(256), stream, dgate, g1, W2, B, C, Cr, dW2, db2, scratch, ds);
     TF_LAUNCH(se_excite_bwd1_kernel, dim3(cdiv(C, 32), SE_JS), dim3(256), stream, (const float*)scratch, g1, s, W1, B, C, Cr, dW1, db1, ds);
     return launch_status("tf_se_excite_bwd_f32");
+}
+
+// The same two passes fed by PARTIAL sums (the BatchNorm-apply-in-the-consumer path of YBlockFn): the squeeze / the gate gradient arrive as
+// [b][chunk][C] chunk sums in the reduction workspace and are finished inside the kernels (no finalize launches).
+extern "C" int tf_se_excite_fwd_parts_f32(const float* parts, int nchunks, float scale, const float* W1, const float* b1, const float* W2, const float* b2, int B,
+                                          int C, int Cr, float* s_out, float* g1, float* gate, float* bwd_scratch, void* stream) {
+    TF_REQUIRE(parts && nchunks > 0 && W1 && W2 && s_out && g1 && gate && B > 0 && C > 0 && Cr > 0 && C <= SE_MAXC && Cr <= SE_MAXR,
+               "tf_se_excite_fwd_parts_f32: bad arguments (C <= 4096, Cr <= 1024)");
+    const bool v4 = C % 4 == 0 && Cr % 4 == 0 && aligned16(W1) && aligned16(W2);
+    if (v4) TF_LAUNCH(se_excite_fwd_kernel<true>, dim3(B, SE_SPLIT), dim3(1024), stream, parts, W1, b1, W2, b2, C, Cr, g1, gate, bwd_scratch, nchunks, scale, s_out);
+    else TF_LAUNCH(se_excite_fwd_kernel<false>, dim3(B, SE_SPLIT), dim3(1024), stream, parts, W1, b1, W2, b2, C, Cr, g1, gate, bwd_scratch, nchunks, scale, s_out);
+    return launch_status("tf_se_excite_fwd_parts_f32");
+}
+
+extern "C" int tf_se_excite_bwd_parts_f32(const float* parts, int nchunks, const float* gate, const float* s, const float* g1, const float* W1, const float* W2,
+                                          int B, int C, int Cr, float* dW1, float* db1, float* dW2, float* db2, float* ds, float* scratch, int scratch_is_zero,
+                                          void* stream) {
+    TF_REQUIRE(parts && nchunks > 0 && gate && s && g1 && W1 && W2 && dW1 && dW2 && ds && scratch && B > 0 && B <= SE_MAXB && C > 0 && Cr > 0 &&
+                   (long)B * Cr <= SE_MAXB * SE_MAXR / 2, "tf_se_excite_bwd_parts_f32: bad arguments (B <= 16, B*Cr <= 8192)");
+    if (!scratch_is_zero) TF_LAUNCH(se_zero_kernel, dim3(cdiv((long)B * Cr, 256)), dim3(256), stream, scratch, B * Cr);
+    TF_LAUNCH(se_excite_bwd2_kernel, dim3(cdiv(C, SE_ROWS)), dim3(256), stream, parts, g1, W2, B, C, Cr, dW2, db2, scratch, ds, nchunks, gate);
+    TF_LAUNCH(se_excite_bwd1_kernel, dim3(cdiv(C, 32), SE_JS), dim3(256), stream, (const float*)scratch, g1, s, W1, B, C, Cr, dW1, db1, ds);
+    return launch_status("tf_se_excite_bwd_parts_f32");
 }

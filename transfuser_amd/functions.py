@@ -251,15 +251,26 @@ class YBlockFn(torch.autograd.Function):
         y1 = y1.view(B, H, W, C)
         z1, st1 = _bn(y1, blk.conv1.bn, relu=True, stat=cs1)
         y2, cs2 = ops.conv_fwd(z1, blk.conv2.conv.weight, None, blk.stride, 1, blk.groups, colstat=True)
-        z2, st2 = _bn(y2, blk.conv2.bn, relu=True, stat=cs2)
         _, Ho, Wo, _ = y2.shape
-        s = ops.colsum(z2, B, Ho * Wo, C, 1.0 / (Ho * Wo))
-        if B <= 16:
-            g1, gate = ops.se_excite_fwd(s, blk.se.fc1.weight, blk.se.fc1.bias, blk.se.fc2.weight, blk.se.fc2.bias)
+        bn2 = blk.conv2.bn
+        fuse2 = (ops.FUSE_BN_SE and cs2 is not None and bn2.training and B <= 16 and B * blk.se.fc1.weight.shape[0] <= 8192 and
+                 getattr(bn2, "_sync_group", None) is None and not isinstance(bn2, torch.nn.SyncBatchNorm))
+        if fuse2:
+            # BatchNorm apply folded into its consumers: z2 = relu(bn2(y2)) is recomputed by the SE squeeze, the SE scale and (backward) the gate
+            # gradient / the BatchNorm backward's mask - never written; the squeeze's chunk sums are finished inside the excitation kernel
+            coef2, sm2, si2 = ops.bn_finalize_parts(cs2, bn2.weight, bn2.bias, bn2.running_mean, bn2.running_var, bn2.momentum, bn2.eps)
+            st2, z2 = (sm2, si2, coef2), None
+            s, g1, gate = ops.se_squeeze_excite_bn_fwd(y2, coef2, blk.se.fc1.weight, blk.se.fc1.bias, blk.se.fc2.weight, blk.se.fc2.bias)
+            z2s = ops.se_scale_bn_fwd(y2, coef2, gate)
         else:
-            g1 = ops.linear_fwd(s, w2d(blk.se.fc1.weight), blk.se.fc1.bias, relu=True)
-            gate = ops.linear_fwd(g1, w2d(blk.se.fc2.weight), blk.se.fc2.bias)
-        z2s = ops.se_scale_fwd(z2, gate)
+            z2, st2 = _bn(y2, bn2, relu=True, stat=cs2)
+            s = ops.colsum(z2, B, Ho * Wo, C, 1.0 / (Ho * Wo))
+            if B <= 16:
+                g1, gate = ops.se_excite_fwd(s, blk.se.fc1.weight, blk.se.fc1.bias, blk.se.fc2.weight, blk.se.fc2.bias)
+            else:
+                g1 = ops.linear_fwd(s, w2d(blk.se.fc1.weight), blk.se.fc1.bias, relu=True)
+                gate = ops.linear_fwd(g1, w2d(blk.se.fc2.weight), blk.se.fc2.bias)
+            z2s = ops.se_scale_fwd(z2, gate)
         y3, cs3 = ops.linear_fwd(z2s.view(-1, C), w2d(blk.conv3.conv.weight), colstat=True)
         y3 = y3.view(B, Ho, Wo, C)
         yd = std = None
@@ -292,21 +303,28 @@ class YBlockFn(torch.autograd.Function):
         dz2s = ops.linear_dgrad(dy3_2, w2d(w3)).view(B, Ho, Wo, C)
         # squeeze-excite
         se = blk.se
-        dgate = ops.se_scale_bwd_gate(dz2s, z2, gate)
-        if B <= 16 and B * g1.shape[1] <= 8192:
-            ds = ops.se_excite_bwd(dgate, s, g1, se.fc1.weight, se.fc2.weight, gbuf(se.fc1.weight), gbuf(se.fc1.bias), gbuf(se.fc2.weight),
-                                   gbuf(se.fc2.bias))
+        if z2 is None:      # forward ran with the BatchNorm apply folded into the consumers (st2 = (mean, invstd, [scale | shift]))
+            ds = ops.se_gate_excite_bn_bwd(dz2s, y2, st2[2], gate, s, g1, se.fc1.weight, se.fc2.weight, gbuf(se.fc1.weight), gbuf(se.fc1.bias),
+                                           gbuf(se.fc2.weight), gbuf(se.fc2.bias))
+            dz2 = ops.se_scale_bwd_x(dz2s, gate, ds, y2.shape)
+            bn2 = blk.conv2.bn
+            dy2 = ops.bn_bwd_remask(dz2, y2, st2[2], bn2.weight, st2[0], st2[1], gbuf(bn2.weight), gbuf(bn2.bias))
         else:
-            ops.linear_wgrad(dgate, g1, w2d(gbuf(se.fc2.weight)))
-            bias_grad(dgate, se.fc2.bias)
-            dg1 = ops.linear_dgrad(dgate, w2d(se.fc2.weight))
-            dg1 = ops.relu_mask(dg1, g1, out=dg1)
-            ops.linear_wgrad(dg1, s, w2d(gbuf(se.fc1.weight)))
-            bias_grad(dg1, se.fc1.bias)
-            ds = ops.linear_dgrad(dg1, w2d(se.fc1.weight))
-        dz2 = ops.se_scale_bwd_x(dz2s, gate, ds, z2.shape)
+            dgate = ops.se_scale_bwd_gate(dz2s, z2, gate)
+            if B <= 16 and B * g1.shape[1] <= 8192:
+                ds = ops.se_excite_bwd(dgate, s, g1, se.fc1.weight, se.fc2.weight, gbuf(se.fc1.weight), gbuf(se.fc1.bias), gbuf(se.fc2.weight),
+                                       gbuf(se.fc2.bias))
+            else:
+                ops.linear_wgrad(dgate, g1, w2d(gbuf(se.fc2.weight)))
+                bias_grad(dgate, se.fc2.bias)
+                dg1 = ops.linear_dgrad(dgate, w2d(se.fc2.weight))
+                dg1 = ops.relu_mask(dg1, g1, out=dg1)
+                ops.linear_wgrad(dg1, s, w2d(gbuf(se.fc1.weight)))
+                bias_grad(dg1, se.fc1.bias)
+                ds = ops.linear_dgrad(dg1, w2d(se.fc1.weight))
+            dz2 = ops.se_scale_bwd_x(dz2s, gate, ds, z2.shape)
+            dy2, _ = _bn_bwd(dz2, z2, y2, blk.conv2.bn, st2)
         # grouped 3x3
-        dy2, _ = _bn_bwd(dz2, z2, y2, blk.conv2.bn, st2)
         w2 = blk.conv2.conv.weight
         ops.wgrad_fork((dy2, z1), lambda: ops.conv_wgrad(dy2, z1, gbuf(w2), blk.stride, 1, blk.groups))
         dz1 = ops.conv_dgrad(dy2, w2, z1.shape, blk.stride, 1, blk.groups)

@@ -712,6 +712,77 @@ def bn_fwd_parts(x, cs, gamma, beta, rmean, rvar, res=None, relu=False, momentum
     return y, sm, si
 
 
+# ---- BatchNorm apply folded into the consumers (YBlockFn's conv2 -> BN -> ReLU -> SE segment; csrc/reduce.cpp, csrc/se.cpp)
+FUSE_BN_SE = os.environ.get("TF_FUSE_BN_SE", "1") != "0"
+
+
+def bn_finalize_parts(cs, gamma, beta, rmean, rvar, momentum=0.1, eps=1e-5):
+    """The finalize half of bn_fwd_parts: (coef = [scale | shift] (2C,), save_mean, save_invstd); running statistics updated."""
+    C = cs.C
+    coef = torch.empty(2 * C, dtype=torch.float32, device=cs.buf.device)
+    sm = torch.empty(C, dtype=torch.float32, device=cs.buf.device)
+    si = torch.empty_like(sm)
+    check(L().tf_bn_finalize_parts_f32(ptr(cs.buf), cs.nparts.value, cs.rows, C, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), ctypes.c_float(momentum),
+                                       ctypes.c_float(eps), ptr(sm), ptr(si), ptr(coef), stream_of(coef)), "tf_bn_finalize_parts_f32")
+    return coef, sm, si
+
+
+def se_squeeze_excite_bn_fwd(y, coef, w1, b1, w2, b2):
+    """SE squeeze + excitation on z = relu(y * scale + shift) WITHOUT materialising z: chunk sums of z per sample (one launch), finished inside
+    the excitation kernel.  y (B, H, W, C) -> (s (B, C) squeezed means, g1 (B, Cr), gate (B, C) pre-sigmoid)."""
+    B, H, W, C = y.shape
+    Cr = w1.shape[0]
+    nch = ctypes.c_int(0)
+    ws = workspace(y.device)
+    check(L().tf_colsum_bnrelu_parts_f32(ptr(_c(y)), ptr(coef), B, H * W, C, ptr(ws), byref(nch), stream_of(y)), "tf_colsum_bnrelu_parts_f32")
+    s = torch.empty(B, C, dtype=torch.float32, device=y.device)
+    buf = torch.empty(2, B, Cr, dtype=torch.float32, device=y.device)
+    g1 = buf[0]
+    g1._bwd_scratch = buf[1]
+    gate = torch.empty(B, C, dtype=torch.float32, device=y.device)
+    check(L().tf_se_excite_fwd_parts_f32(ptr(ws), nch.value, ctypes.c_float(1.0 / (H * W)), wptr(w1), ptr(b1), wptr(w2), ptr(b2), B, C, Cr, ptr(s), ptr(g1),
+                                         ptr(gate), ptr(buf[1]), stream_of(y)), "tf_se_excite_fwd_parts_f32")
+    return s, g1, gate
+
+
+def se_scale_bn_fwd(y, coef, gate):
+    """relu(y * scale + shift) * sigmoid(gate[b, c]) in one pass."""
+    B, H, W, C = y.shape
+    out = torch.empty_like(y)
+    check(L().tf_se_scale_bn_fwd_f32(ptr(_c(y)), ptr(coef), ptr(_c(gate)), ptr(out), B, H * W, C, stream_of(y)), "tf_se_scale_bn_fwd_f32")
+    return out
+
+
+def se_gate_excite_bn_bwd(dz2s, y, coef, gate, s, g1, w1, w2, dw1, db1, dw2, db2):
+    """Backward of the excitation fed by the gate gradient sum_hw dz2s * relu(y * scale + shift) (chunk sums finished inside the fc2 kernel);
+    accumulates the four parameter gradients, returns ds (B, C)."""
+    B, H, W, C = y.shape
+    Cr = w1.shape[0]
+    nch = ctypes.c_int(0)
+    ws = workspace(y.device)
+    check(L().tf_se_gate_grad_parts_f32(ptr(_c(dz2s)), ptr(_c(y)), ptr(coef), B, H * W, C, ptr(ws), byref(nch), stream_of(y)), "tf_se_gate_grad_parts_f32")
+    ds = torch.empty(B, C, dtype=torch.float32, device=y.device)
+    scratch = getattr(g1, "_bwd_scratch", None)
+    zeroed = scratch is not None
+    if zeroed:
+        g1._bwd_scratch = None
+    else:
+        scratch = torch.empty(B, Cr, dtype=torch.float32, device=y.device)
+    check(L().tf_se_excite_bwd_parts_f32(ptr(ws), nch.value, ptr(_c(gate)), ptr(_c(s)), ptr(_c(g1)), wptr(w1), wptr(w2), B, C, Cr, wptr(dw1), ptr(db1), wptr(dw2),
+                                         ptr(db2), ptr(ds), ptr(scratch), int(zeroed), stream_of(y)), "tf_se_excite_bwd_parts_f32")
+    return ds
+
+
+def bn_bwd_remask(dz, x, coef, gamma, sm, si, dgamma, dbeta):
+    """BatchNorm backward behind a ReLU whose output was never stored (mask = [x * scale + shift > 0])."""
+    C = x.shape[-1]
+    rows = x.numel() // C
+    dx = torch.empty_like(x)
+    check(L().tf_bn_bwd_remask_f32(ptr(_c(dz)), ptr(_c(x)), ptr(coef), rows, C, ptr(gamma), ptr(sm), ptr(si), ptr(dx), ptr(dgamma), ptr(dbeta),
+                                   ptr(workspace(x.device)), stream_of(x)), "tf_bn_bwd_remask_f32")
+    return dx
+
+
 def bn_bwd(dz, z, x, gamma, sm, si, dgamma, dbeta, want_dres=False):
     C = x.shape[-1]
     rows = x.numel() // C
