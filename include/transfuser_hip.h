@@ -120,6 +120,18 @@ int tf_se_excite_bwd_parts_f32(const float* parts, int nchunks, const float* gat
 int tf_bn_bwd_remask_f32(const float* dz, const float* x, const float* fwd_coef, int rows, int C, const float* gamma, const float* save_mean,
                          const float* save_invstd, float* dx, float* dgamma, float* dbeta, float* ws, void* stream);
 
+/* ---- ConvNeXt trunk pieces (timm 0.5.4 convnext_*: the re-labelling branch of ImageCNN / LidarEncoder, transfuser.py:395-416,457-471).
+ * tf_dwconv7_fwd_f32: depthwise 7x7 / pad 3 (+ bias) on NHWC, weights (C, 7, 7) = the (C, 1, 7, 7) parameter; flip != 0 mirrors the taps = the
+ * input gradient (bias ignored); accumulate: y += .  tf_dwconv7_wgrad_f32 ACCUMULATES dw (C, 7, 7) and dbias (optional).  GELU is the exact
+ * (erf) form of nn.GELU.  tf_colscale_add_f32: y = res + gamma[c] x + beta[c] (each of gamma / beta / res optional): layer scale + shortcut,
+ * conv bias.  tf_colsum_mul_f32: out[c] (+)= sum_r a[r][c] b[r][c] (layer-scale gradient). */
+int tf_dwconv7_fwd_f32(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int C, int flip, int accumulate, void* stream);
+int tf_dwconv7_wgrad_f32(const float* dy, const float* x, float* dw, float* dbias, int B, int H, int W, int C, void* stream);
+int tf_gelu_fwd_f32(const float* x, float* y, int64_t n, void* stream);
+int tf_gelu_bwd_f32(const float* dy, const float* x, float* dx, int64_t n, void* stream);
+int tf_colscale_add_f32(const float* x, const float* gamma, const float* beta, const float* res, float* y, int64_t rows, int C, void* stream);
+int tf_colsum_mul_f32(const float* a, const float* b, int rows, int C, float* out, int accumulate, float* ws, void* stream);
+
 /* ---- 16-bit operand STORAGE path (BASELINE configs[2] "bf16", configs[4] "fp16 MFMA"; the reference trains fp32 only, config.py:55).
  * tf_cast16_f32: x (rows x cols fp32, row stride ldx) -> y16 (rows x cols, row stride ldy, pad columns zeroed) and / or y16t (cols x rows: the
  * TRANSPOSE, row stride ldyt % 8 == 0, rows zero-padded to a multiple of 8); dtype 1 = bf16, 2 = IEEE half, round to nearest even.

@@ -6,6 +6,7 @@ import sys
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..", ".."))
 from oracle import regnet as _regnet  # noqa: E402
 from oracle import resnet as _resnet  # noqa: E402
+from oracle import convnext as _convnext  # noqa: E402
 
 _REGISTRY = {}
 
@@ -26,4 +27,6 @@ def create_model(architecture, pretrained=False, **kw):
         return _regnet.regnety_032(in_chans)  # pretrained weights need network: seeded random init instead
     if architecture in _resnet.ARCH:         # the reference's DEFAULT trunks (transfuser.py:15); used under timm's own attribute names
         return _resnet.ARCH[architecture](in_chans)
-    raise ValueError("timm shim only provides regnety_032, resnet18/34/50 (+registered test nets), got %r" % architecture)
+    if architecture in _convnext.ARCH:       # the re-labelling branch of transfuser.py:395-416 / 457-471
+        return _convnext.ARCH[architecture](in_chans)
+    raise ValueError("timm shim only provides regnety_032, resnet18/34/50, convnext_tiny/small/base (+registered test nets), got %r" % architecture)

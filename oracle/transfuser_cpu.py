@@ -106,6 +106,31 @@ class _Trunk(nn.Module):
     def __init__(self, net, in_channels=None):
         super().__init__()
         net.fc = None
+        if hasattr(net, "stages"):          # ConvNeXt: transfuser.py:395-416 (image) / 457-471 (LiDAR), restated line by line
+            net.conv1 = net.stem._modules['0']
+            net.bn1 = net.stem._modules['1']
+            net.act1 = nn.Sequential()
+            net.maxpool = nn.Sequential()
+            for i in range(4):
+                setattr(net, "layer%d" % (i + 1), net.stages._modules[str(i)])
+            net.global_pool = net.head
+            net.global_pool.flatten = nn.Sequential()
+            net.global_pool.fc = nn.Sequential()
+            net.head = nn.Sequential()
+            if in_channels is None:         # ImageCNN only: ConvNeXt has no stem entry in feature_info (transfuser.py:407-411)
+                net.feature_info.append(net.feature_info[3])
+                net.feature_info[3] = net.feature_info[2]
+                net.feature_info[2] = net.feature_info[1]
+                net.feature_info[1] = net.feature_info[0]
+            tmp = net.global_pool.norm
+            net.global_pool.norm = nn.LayerNorm((512, 1, 1), tmp.eps, tmp.elementwise_affine)     # out_features = perception_output_features
+            if in_channels is not None:     # transfuser.py:473-490: new first conv (keeps the old bias parameter), old stem entry deleted
+                old = net.conv1
+                net.conv1 = nn.Conv2d(in_channels, old.out_channels, old.kernel_size, old.stride, old.padding, bias=True)
+                del net.stem._modules['0']
+                net.conv1.bias = old.bias
+            self.net = net
+            return
         if not hasattr(net, "stem"):        # ResNet (the reference's default architectures): timm's own names, nothing to re-label
             if in_channels is not None:     # transfuser.py:475-477
                 old = net.conv1

@@ -254,6 +254,60 @@ def check_bn_se_consumer_fusion(dev, B=3, H=6, W=10, C=48, Cr=12):
     close(dgm, grads[1], tol=1e-4, what="fused bn dgamma"); close(dbt, grads[2], tol=1e-4, what="fused bn dbeta")
 
 
+def check_convnext_pieces(dev):
+    """ConvNeXt block pieces (csrc/convnext.cpp; timm convnext_*, transfuser.py:395-416): depthwise 7x7 (+ bias) forward / input gradient (flipped
+    taps, accumulate) / weight + bias gradient, exact GELU forward / backward, layer scale + shortcut, column sum of a product, the 4x4 / s4 patchify
+    stem on NCHW inputs and the 2x2 / s2 stage-entry convolution through the generic engine - all against PyTorch."""
+    for (B, H, W, C) in ((2, 9, 11, 16), (1, 5, 20, 72), (3, 4, 4, 8)):
+        x = R(B, C, H, W, dev=dev).requires_grad_(True)
+        w = (R(C, 1, 7, 7, seed=2, dev=dev) * 0.2).requires_grad_(True)
+        b = R(C, seed=3, dev=dev).requires_grad_(True)
+        y = F.conv2d(x, w, b, 1, 3, 1, C)
+        dy = R(*y.shape, seed=4, dev=dev)
+        gx, gw, gb = torch.autograd.grad(y, [x, w, b], dy)
+        xh, dyh = x.detach().permute(0, 2, 3, 1).contiguous(), dy.permute(0, 2, 3, 1).contiguous()
+        close(ops.dwconv7(xh, w.detach(), b.detach()).permute(0, 3, 1, 2), y, what="dwconv7 fwd")
+        base = R(B, H, W, C, seed=5, dev=dev)
+        close(ops.dwconv7(dyh, w.detach(), None, flip=True, out=base.clone(), accumulate=True), base + gx.permute(0, 2, 3, 1), what="dwconv7 dgrad (accumulate)")
+        dw, db = torch.zeros_like(w.detach()), torch.zeros(C, device=dev)
+        ops.dwconv7_wgrad(dyh, xh, dw, db)
+        close(dw, gw, tol=1e-4, what="dwconv7 wgrad"); close(db, gb, tol=1e-4, what="dwconv7 bias grad")
+    x = (R(37, 24, dev=dev) * 2).requires_grad_(True)
+    y = F.gelu(x)
+    dy = R(37, 24, seed=1, dev=dev)
+    close(ops.gelu_fwd(x.detach()), y, what="gelu fwd")
+    close(ops.gelu_bwd(dy, x.detach()), torch.autograd.grad(y, x, dy)[0], what="gelu bwd")
+    g, bt, res = R(24, seed=2, dev=dev), R(24, seed=3, dev=dev), R(37, 24, seed=4, dev=dev)
+    close(ops.colscale_add(x.detach(), g, bt, res), res + g * x.detach() + bt, what="colscale_add")
+    close(ops.colscale_add(x.detach(), g), g * x.detach(), what="colscale")
+    out = R(24, seed=5, dev=dev)
+    close(ops.colsum_mul(x.detach(), dy, out.clone()), out + (x.detach() * dy).sum(0), tol=1e-4, what="colsum_mul")
+    # patchify stem (4x4 / s4, pad 0) on NCHW + 2x2 / s2 stage entry
+    rgb = torch.randint(0, 256, (2, 3, 16, 24), generator=torch.Generator().manual_seed(0)).float().to(dev)
+    w4 = (R(16, 3, 4, 4, seed=6, dev=dev) * 0.1).requires_grad_(True)
+    mean = torch.tensor([0.485, 0.456, 0.406], device=dev).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225], device=dev).view(1, 3, 1, 1)
+    y = F.conv2d((rgb / 255.0 - mean) / std, w4, None, 4, 0)
+    dy = R(*y.shape, seed=7, dev=dev)
+    (gw4,) = torch.autograd.grad(y, [w4], dy)
+    close(ops.stem_conv_fwd(rgb, None, cl(w4.detach()), True, 4, 0).permute(0, 3, 1, 2), y, what="4x4 s4 stem fwd")
+    dw4 = torch.zeros_like(cl(w4.detach()))
+    ops.stem_conv_wgrad(dy.permute(0, 2, 3, 1).contiguous(), rgb, None, dw4, True, stride=4, pad=0)
+    close(dw4, gw4, tol=1e-4, what="4x4 s4 stem wgrad")
+    x = R(2, 16, 8, 12, seed=8, dev=dev).requires_grad_(True)
+    w2 = (R(32, 16, 2, 2, seed=9, dev=dev) * 0.2).requires_grad_(True)
+    b2 = R(32, seed=10, dev=dev)
+    y = F.conv2d(x, w2, b2, 2, 0)
+    dy = R(*y.shape, seed=11, dev=dev)
+    gx, gw2 = torch.autograd.grad(y, [x, w2], dy)
+    xh, dyh, wh = x.detach().permute(0, 2, 3, 1).contiguous(), dy.permute(0, 2, 3, 1).contiguous(), cl(w2.detach())
+    close(ops.conv_fwd(xh, wh, b2, 2, 0, 1).permute(0, 3, 1, 2), y, what="2x2 s2 conv fwd")
+    close(ops.conv_dgrad(dyh, wh, xh.shape, 2, 0, 1).permute(0, 3, 1, 2), gx, what="2x2 s2 conv dgrad")
+    dw2 = torch.zeros_like(wh)
+    ops.conv_wgrad(dyh, xh, dw2, 2, 0, 1)
+    close(dw2, gw2, tol=1e-4, what="2x2 s2 conv wgrad")
+
+
 def check_resnet_stem_and_pool(dev):
     """The ResNet stem pieces (timm resnet18/34/50: the reference's default trunks, transfuser.py:15,136-143): 7x7 / s2 / p3 convolution on the
     NCHW inputs (with normalize_imagenet folded in, or the LiDAR + target-point channels un-concatenated) and nn.MaxPool2d(3, 2, 1) forward /

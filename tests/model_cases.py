@@ -7,8 +7,8 @@ import math
 import numpy as np
 import torch
 
-from oracle import model_cpu, hist, regnet as oracle_regnet, resnet as oracle_resnet
-from transfuser_amd import regnet as prod_regnet, resnet as prod_resnet
+from oracle import model_cpu, hist, regnet as oracle_regnet, resnet as oracle_resnet, convnext as oracle_convnext
+from transfuser_amd import regnet as prod_regnet, resnet as prod_resnet, convnext as prod_convnext
 from transfuser_amd.config import GlobalConfig
 from transfuser_amd.model import LidarCenterNet
 
@@ -17,6 +17,8 @@ prod_regnet.register_arch("regnety_tiny", **TINY)
 RESNET_TINY = dict(layers=(1, 2, 1, 1), widths=(16, 32, 48, 64), stem_width=16)        # BasicBlock; "resnet_tiny50": Bottleneck (expansion 4)
 prod_resnet.register_arch("resnet_tiny", prod_resnet.BasicBlock, RESNET_TINY["layers"], RESNET_TINY["widths"], RESNET_TINY["stem_width"])
 prod_resnet.register_arch("resnet_tiny50", prod_resnet.Bottleneck, (1, 1, 1, 1), (8, 16, 24, 32), 16)
+CONVNEXT_TINY = dict(depths=(1, 1, 2, 1), dims=(16, 32, 48, 64))
+prod_convnext.register_arch("convnext_mini", CONVNEXT_TINY["depths"], CONVNEXT_TINY["dims"])
 
 
 def tiny_config(n_layer=2, lidar_res=64, dropout=0.0, use_velocity=False):
@@ -75,6 +77,8 @@ def randomize(model, seed=1):
         for n, p in model.named_parameters():
             if n.endswith(("bn.weight", "bn1.weight", "bn2.weight", "bn3.weight", "downsample.1.weight")):      # incl. the zero-initialised last BN of a residual branch
                 p.copy_(torch.rand(p.shape, generator=g) * 0.5 + 0.75)
+            elif n.endswith(".gamma"):      # ConvNeXt layer scale (initialised to 1e-6): O(1) so the residual branch matters
+                p.copy_(torch.rand(p.shape, generator=g) * 0.5 + 0.25)
             elif "pos_emb" in n:
                 p.copy_(torch.randn(p.shape, generator=g) * 0.05)
             elif n.endswith(".bias") and p.dim() == 1:
@@ -94,6 +98,10 @@ def build_pair(cfg, arch, dev, use_velocity=False, seed=0, backbone='transFuser'
         make_net = lambda in_chans=3: oracle_resnet.ResNet(oracle_resnet.Bottleneck, (1, 1, 1, 1), in_chans, (8, 16, 24, 32), 16)
     elif arch in oracle_resnet.ARCH:
         make_net = oracle_resnet.ARCH[arch]
+    elif arch == "convnext_mini":
+        make_net = lambda in_chans=3: oracle_convnext.ConvNeXt(in_chans, CONVNEXT_TINY["depths"], CONVNEXT_TINY["dims"])
+    elif arch in oracle_convnext.ARCH:
+        make_net = oracle_convnext.ARCH[arch]
     else:
         make_net = oracle_regnet.regnety_032
     ref = model_cpu.LidarCenterNet(cfg, 'cpu', backbone, use_velocity=use_velocity, make_net=make_net)

@@ -177,6 +177,10 @@ def test_bn_apply_folded_into_se_consumers(case):
     kc.check_bn_se_consumer_fusion("cuda", *case)
 
 
+def test_convnext_block_pieces():
+    kc.check_convnext_pieces("cuda")
+
+
 def test_resnet_stem_conv7x7_and_maxpool():
     kc.check_resnet_stem_and_pool("cuda")
 

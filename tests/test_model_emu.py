@@ -310,3 +310,15 @@ def test_resnet_trunks_match_oracle(arch):
     batch = mc.small_batch(2, 32, 64, 64, 40)
     lp, lr = mc.run_pair(prod, ref, cfg, batch, "cpu")
     mc.compare(prod, ref, lp, lr)
+
+
+def test_convnext_trunks_match_oracle():
+    """the ConvNeXt re-labelling branch (transfuser.py:395-416, 457-471: patchify stem + LayerNorm2d as conv1 / bn1, stages as
+    layer1..4, head as global_pool with LayerNorm((512, 1, 1)); timm block = depthwise 7x7 -> LayerNorm -> Linear -> GELU -> Linear -> layer scale)
+    through the whole model: 11 losses, every parameter gradient, strict state_dict key parity (incl. the aliased duplicates)."""
+    cfg = mc.tiny_config(n_layer=1)
+    prod, ref = mc.build_pair(cfg, "convnext_mini", "cpu")
+    assert any(k.endswith("image_encoder.features.global_pool.norm.weight") for k in prod.state_dict())
+    batch = mc.small_batch(2, 32, 64, 64, 40)
+    lp, lr = mc.run_pair(prod, ref, cfg, batch, "cpu")
+    mc.compare(prod, ref, lp, lr)

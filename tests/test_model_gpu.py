@@ -63,6 +63,19 @@ def test_default_resnet_trunks_reference_resolution():
     mc.compare_vs_fp64(prod, ref, lp, lr, batch, cfg)
 
 
+def test_convnext_trunks_reference_resolution():
+    """``convnext_tiny`` trunks (the re-labelling branch transfuser.py:395-416 / 457-471) at the reference resolution 160x704, B = 2:
+    losses within 1e-3 of the CPU oracle, gradients anchored on the fp64 oracle like the RegNet / ResNet full-size tests."""
+    from oracle import hist
+    from transfuser_amd.data import synthetic_batch
+    cfg = mc.full_config()
+    prod, ref = mc.build_pair(cfg, "convnext_tiny", "cuda")
+    assert tuple(dict(prod.named_parameters())["_model.image_encoder.features.global_pool.norm.weight"].shape) == (512, 1, 1)
+    batch = synthetic_batch(2, 160, 704, seed=0, hist_fn=hist.lidar_to_histogram_features, n_points=8192)
+    lp, lr = mc.run_pair(prod, ref, cfg, batch, "cuda")
+    mc.compare_vs_fp64(prod, ref, lp, lr, batch, cfg)
+
+
 def test_tiny_geometric_fusion_losses_and_grads():
     """BASELINE config 4 backbone (geometric_fusion.py): gather kernel G1, velocity embeddings, quirk Q4."""
     cfg = mc.tiny_config(n_layer=1, lidar_res=96)

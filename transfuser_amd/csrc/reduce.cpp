@@ -737,3 +737,14 @@ extern "C" int tf_bn_bwd_remask_f32(const float* dz, const float* x, const float
     else TF_LAUNCH(bn_bwd_apply_remask_kernel<1>, dim3(ew_blocks(n)), dim3(256), stream, dz, x, fcoef, (const float*)coef, dx, n, C);
     return launch_status("tf_bn_bwd_remask_f32");
 }
+
+// out[c] (+)= sum over rows of a[r][c] * b[r][c]  (ConvNeXt layer-scale gradient d gamma = sum dy * branch output, transfuser.py:395 via timm)
+extern "C" int tf_colsum_mul_f32(const float* a, const float* b, int rows, int C, float* out, int accumulate, float* ws, void* stream) {
+    TF_REQUIRE(a && b && out && ws && rows > 0 && C > 0, "tf_colsum_mul_f32: bad arguments");
+    RedPlan p = plan_reduce(rows, C, 1, 1, aligned16(a) && aligned16(b));
+    MulF<4> f4{a, b, C};
+    MulF<1> f1{a, b, C};
+    launch_reduce<1>(p, f4, f1, rows, C, 1, ws, stream);
+    TF_LAUNCH(colsum_finalize_kernel, dim3(cdiv((long)C, 4)), dim3(256), stream, (const float*)ws, out, C, p.nchunks, 1, 1.f, accumulate);
+    return launch_status("tf_colsum_mul_f32");
+}

@@ -236,6 +236,126 @@ class ConvBnFn(torch.autograd.Function):
         return dx, dres, None, None, None, None, None, None
 
 
+# ============================================================================================ ConvNeXt (timm 0.5.4; transfuser.py:395-416 re-labelling branch)
+def _ln_rows(x, ln):
+    """LayerNorm over the channels of an NHWC map (timm LayerNorm2d / the block's channels-last nn.LayerNorm): rows = pixels."""
+    C = x.shape[-1]
+    y, m, r = ops.layernorm_fwd(x.reshape(-1, C), ln.weight.view(-1), ln.bias.view(-1), ln.eps)
+    return y.view(x.shape), m, r
+
+
+@routes_param_grads
+class CnxStemFn(torch.autograd.Function):
+    """Patchify stem on the NCHW model input: conv k x k / stride k (bias) -> LayerNorm2d (``stem.0`` / ``stem.1`` = conv1 / bn1 after the re-labelling)."""
+
+    @staticmethod
+    def forward(ctx, s0, s1, stem, w, b, g, beta):
+        conv, ln = stem.conv, stem.bn
+        y = ops.stem_conv_fwd(s0, s1, w, stem.normalize, conv.stride[0], conv.padding[0])
+        ops.colscale_add(y, None, b, None, out=y)
+        z, m, r = _ln_rows(y, ln)
+        ctx.saved = (s0, s1, stem, w, b, y, m, r)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        s0, s1, stem, w, b, y, m, r = ctx.saved
+        ctx.saved = None
+        conv, ln = stem.conv, stem.bn
+        C = y.shape[-1]
+        dy = ops.layernorm_bwd(dz.contiguous().view(-1, C), y.view(-1, C), ln.weight.view(-1), m, r, gbuf(ln.weight).view(-1), gbuf(ln.bias).view(-1))
+        bias_grad(dy, b)
+        ops.stem_conv_wgrad(dy.view(y.shape), s0, s1, gbuf(w), stem.normalize, stride=conv.stride[0], pad=conv.padding[0])
+        return (None,) * 7
+
+
+@routes_param_grads
+class CnxDownFn(torch.autograd.Function):
+    """Stage entry: LayerNorm2d -> conv 2x2 / stride 2 (bias)  (``stages.i.downsample``)."""
+
+    @staticmethod
+    def forward(ctx, x, ds, lw, lb, w, b):
+        ln, conv = ds[0], ds[1]
+        n, m, r = _ln_rows(x, ln)
+        y = ops.conv_fwd(n, w, b, conv.stride[0], 0, 1)
+        ctx.saved = (x, ds, n, m, r, w, b)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, ds, n, m, r, w, b = ctx.saved
+        ctx.saved = None
+        ln, conv = ds[0], ds[1]
+        dy = dy.contiguous()
+        C = x.shape[-1]
+        bias_grad(dy.view(-1, dy.shape[-1]), b)
+        ops.conv_wgrad(dy, n, gbuf(w), conv.stride[0], 0, 1)
+        dn = ops.conv_dgrad(dy, w, n.shape, conv.stride[0], 0, 1)
+        dx = ops.layernorm_bwd(dn.view(-1, C), x.reshape(-1, C), ln.weight, m, r, gbuf(ln.weight), gbuf(ln.bias))
+        return dx.view(x.shape), None, None, None, None, None
+
+
+@routes_param_grads
+class CnxBlockFn(torch.autograd.Function):
+    """ConvNeXtBlock: depthwise 7x7 (bias) -> LayerNorm (eps 1e-6) -> Linear 4x -> GELU -> Linear -> gamma (layer scale) -> + shortcut."""
+
+    @staticmethod
+    def forward(ctx, x, blk, *params):
+        B, H, W, C = x.shape
+        d = ops.dwconv7(x, blk.conv_dw.weight, blk.conv_dw.bias)
+        n, m, r = _ln_rows(d, blk.norm)
+        n2 = n.view(-1, C)
+        h = ops.linear_fwd(n2, blk.mlp.fc1.weight, blk.mlp.fc1.bias)
+        a = ops.gelu_fwd(h)
+        o = ops.linear_fwd(a, blk.mlp.fc2.weight, blk.mlp.fc2.bias)
+        out = ops.colscale_add(o.view(B, H, W, C), blk.gamma, None, x)
+        ctx.saved = (x, blk, d, m, r, n2, h, a, o)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, blk, d, m, r, n2, h, a, o = ctx.saved
+        ctx.saved = None
+        B, H, W, C = x.shape
+        dout = dout.contiguous()
+        d2 = dout.view(-1, C)
+        ops.colsum_mul(d2, o, gbuf(blk.gamma))
+        do = ops.colscale_add(d2, blk.gamma)
+        fc1, fc2 = blk.mlp.fc1, blk.mlp.fc2
+        ops.linear_wgrad(do, a, gbuf(fc2.weight))
+        bias_grad(do, fc2.bias)
+        da = ops.linear_dgrad(do, fc2.weight)
+        dh = ops.gelu_bwd(da, h, out=da)
+        ops.linear_wgrad(dh, n2, gbuf(fc1.weight))
+        bias_grad(dh, fc1.bias)
+        dn = ops.linear_dgrad(dh, fc1.weight)
+        dd = ops.layernorm_bwd(dn, d.view(-1, C), blk.norm.weight, m, r, gbuf(blk.norm.weight), gbuf(blk.norm.bias)).view(B, H, W, C)
+        ops.dwconv7_wgrad(dd, x, gbuf(blk.conv_dw.weight), gbuf(blk.conv_dw.bias))
+        dx = ops.colscale_add(dout)                     # the shortcut's share (a copy: the depthwise gradient is accumulated into it)
+        ops.dwconv7(dd, blk.conv_dw.weight, None, flip=True, out=dx, accumulate=True)
+        return (dx, None) + (None,) * (len(ctx.needs_input_grad) - 2)
+
+
+@routes_param_grads
+class PoolNormFn(torch.autograd.Function):
+    """global average pool -> LayerNorm over the pooled channel vector (the re-labelled ConvNeXt ``global_pool`` = head: pool + LayerNorm((512, 1, 1)))."""
+
+    @staticmethod
+    def forward(ctx, x, ln, w, b):
+        B, H, W, C = x.shape
+        p = ops.colsum(x, B, H * W, C, 1.0 / (H * W))
+        y, m, r = ops.layernorm_fwd(p, w.view(-1), b.view(-1), ln.eps)
+        ctx.saved = (x.shape, w, b, p, m, r)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        shape, w, b, p, m, r = ctx.saved
+        ctx.saved = None
+        dp = ops.layernorm_bwd(dy.contiguous(), p, w.view(-1), m, r, gbuf(w).view(-1), gbuf(b).view(-1))
+        return ops.se_scale_bwd_x(None, None, dp, shape), None, None, None
+
+
 # ============================================================================================ RegNetY block
 @routes_param_grads
 class YBlockFn(torch.autograd.Function):

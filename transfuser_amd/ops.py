@@ -578,6 +578,54 @@ def maxpool3x3s2_bwd(dy, idx, x_shape):
     return dx
 
 
+# ------------------------------------------------------------------------------------------ ConvNeXt pieces (csrc/convnext.cpp)
+def dwconv7(x, w, bias=None, flip=False, out=None, accumulate=False):
+    """Depthwise 7x7 / pad 3 on NHWC; w = the (C, 1, 7, 7) parameter; flip=True: mirrored taps (= the input gradient of the forward)."""
+    B, H, W, C = x.shape
+    assert tuple(w.shape[-2:]) == (7, 7) and w.shape[0] == C and w.numel() == C * 49 and w.is_contiguous()
+    if out is None:
+        out = torch.empty_like(x)
+    check(L().tf_dwconv7_fwd_f32(ptr(_c(x)), ptr(w), ptr(bias), ptr(out), B, H, W, C, int(flip), int(accumulate), stream_of(x)), "tf_dwconv7_fwd_f32")
+    return out
+
+
+def dwconv7_wgrad(dy, x, dw, dbias=None):
+    """dw (C, 1, 7, 7) += ..., dbias (C,) += ... (accumulating)."""
+    B, H, W, C = x.shape
+    assert dw.is_contiguous()
+    check(L().tf_dwconv7_wgrad_f32(ptr(_c(dy)), ptr(_c(x)), ptr(dw), ptr(dbias), B, H, W, C, stream_of(x)), "tf_dwconv7_wgrad_f32")
+
+
+def gelu_fwd(x):
+    y = torch.empty_like(x)
+    check(L().tf_gelu_fwd_f32(ptr(_c(x)), ptr(y), ctypes.c_int64(x.numel()), stream_of(x)), "tf_gelu_fwd_f32")
+    return y
+
+
+def gelu_bwd(dy, x, out=None):
+    if out is None:
+        out = torch.empty_like(x)
+    check(L().tf_gelu_bwd_f32(ptr(_c(dy)), ptr(_c(x)), ptr(out), ctypes.c_int64(x.numel()), stream_of(x)), "tf_gelu_bwd_f32")
+    return out
+
+
+def colscale_add(x, gamma=None, beta=None, res=None, out=None):
+    """res + gamma[c] * x + beta[c] over the last dimension (each optional)."""
+    C = x.shape[-1]
+    if out is None:
+        out = torch.empty_like(x)
+    check(L().tf_colscale_add_f32(ptr(_c(x)), ptr(gamma), ptr(beta), ptr(_c(res)) if res is not None else c_p(0), ptr(out), ctypes.c_int64(x.numel() // C), C,
+                                  stream_of(x)), "tf_colscale_add_f32")
+    return out
+
+
+def colsum_mul(a, b, out, accumulate=True):
+    """out (C,) (+)= sum over rows of a * b."""
+    C = a.shape[-1]
+    check(L().tf_colsum_mul_f32(ptr(_c(a)), ptr(_c(b)), a.numel() // C, C, ptr(out), int(accumulate), ptr(workspace(a.device)), stream_of(a)), "tf_colsum_mul_f32")
+    return out
+
+
 # ------------------------------------------------------------------------------------------ norms
 def layernorm_fwd(x, gamma, beta, eps=1e-5):
     rows, C = x.shape

@@ -40,6 +40,7 @@ def _group_key(name):
 
 
 _STAGE_RE = __import__("re").compile(r"(?:^|\.)(?:image_encoder\.features|lidar_encoder\._model)\.(?:s|layer)([1-4])\.|(?:^|\.)transformer([1-4])\.(?:(blocks)\.(\d+)\.|(ln_f)\.)?")
+_CNX_STAGE_RE = __import__("re").compile(r"(?:^|\.)(?:image_encoder\.features|lidar_encoder\._model)\.stages\.([0-3])\.")      # ConvNeXt: stages.i is aliased as layer{i+1}
 _STEM_RE = __import__("re").compile(r"(?:^|\.)(?:image_encoder\.features|lidar_encoder\._model)\.(?:stem|conv1|bn1)\.|(?:^|\.)point_pillar_net\.")
 _LAST = 1 << 20
 
@@ -52,6 +53,9 @@ def param_key(name):
     after the backbone's last stage (channel reducers, FPN, decoders, heads, join / GRU).  The backward produces gradients in DEcreasing key
     order, and a segment's arena range is all-reduced as soon as its piece is enqueued - a parameter filed later than the point that
     produces its gradient would be reduced while still zero and then diverge between the replicas."""
+    m = _CNX_STAGE_RE.search(name)
+    if m:
+        return (int(m.group(1)) + 1, 0, 0)
     m = _STAGE_RE.search(name)
     if m:
         if m.group(1):

@@ -14,6 +14,7 @@ from torch import nn
 from . import functions as F_
 from . import regnet
 from . import resnet
+from . import convnext
 
 
 def nchw(x):
@@ -140,6 +141,8 @@ class _Stem:
         return getattr(self._owner, self._names[1]) if self._owner is not None else self._bn
 
     def __call__(self, s0, s1=None):
+        if isinstance(self.bn, nn.LayerNorm):      # ConvNeXt patchify stem: conv (bias) + LayerNorm2d
+            return F_.CnxStemFn.apply(s0, s1, self, self.conv.weight, self.conv.bias, self.bn.weight, self.bn.bias)
         return F_.StemFn.apply(s0, s1, self, self.conv.weight, self.bn.weight, self.bn.bias)
 
 
@@ -155,17 +158,23 @@ def _relabel(net):
     net.head = nn.Sequential()
 
 
-def _create_trunk(architecture, pretrained, in_chans=3):
-    """timm.create_model for the architectures built here: RegNetY (re-labelled like transfuser.py:383-393) and the ResNets the reference's
-    constructors default to (timm's own names: nothing to re-label, transfuser.py:383 falls through)."""
+def _create_trunk(architecture, pretrained, out_features=512, lidar_in_channels=None):
+    """timm.create_model + the reference's re-labelling for the architectures built here: RegNetY (transfuser.py:383-393), ConvNeXt (:395-416)
+    and the ResNets its constructors default to (timm's own names: nothing to re-label).  lidar_in_channels: the LidarEncoder variant
+    (transfuser.py:473-490: new first convolution, old one deleted)."""
+    if convnext.is_convnext(architecture):
+        return convnext.relabel(convnext.create_model(architecture, pretrained=pretrained), out_features, lidar_in_channels)
     if resnet.is_resnet(architecture):
-        net = resnet.create_model(architecture, pretrained=pretrained, in_chans=in_chans)
+        net = resnet.create_model(architecture, pretrained=pretrained)
         net.fc = None
-        return net
-    if architecture.startswith("convnext"):
-        raise ValueError("transfuser_amd: the ConvNeXt re-labelling branch (transfuser.py:395-416) is not built; RegNetY and ResNet trunks are")
-    net = regnet.create_model(architecture, pretrained=pretrained, in_chans=in_chans)
-    _relabel(net)
+    else:
+        net = regnet.create_model(architecture, pretrained=pretrained)
+        _relabel(net)
+    if lidar_in_channels is not None:
+        old = net.conv1
+        net.conv1 = nn.Conv2d(lidar_in_channels, old.out_channels, kernel_size=old.kernel_size, stride=old.stride, padding=old.padding, bias=False)
+        if hasattr(net, "stem"):
+            del net.stem.conv  # transfuser.py:482-483
     return net
 
 
@@ -173,17 +182,13 @@ class ImageCNN(nn.Module):
     def __init__(self, architecture, normalize=True, out_features=512):
         super().__init__()
         self.normalize = normalize
-        self.features = _create_trunk(architecture, True)
+        self.features = _create_trunk(architecture, True, out_features)
 
 
 class LidarEncoder(nn.Module):
     def __init__(self, architecture, in_channels=2, out_features=512):
         super().__init__()
-        self._model = _create_trunk(architecture, False)
-        old = self._model.conv1
-        self._model.conv1 = nn.Conv2d(in_channels, old.out_channels, kernel_size=old.kernel_size, stride=old.stride, padding=old.padding, bias=False)
-        if hasattr(self._model, "stem"):
-            del self._model.stem.conv  # transfuser.py:482-483
+        self._model = _create_trunk(architecture, False, out_features, in_channels)
 
 
 class _FusionBackbone(nn.Module):
@@ -312,7 +317,11 @@ class _FusionBackbone(nn.Module):
                 y.record_stream(side)
         x = self._conv(getattr(self, self._reducers[0]), x)
         y = self._conv(getattr(self, self._reducers[1]), y)
-        fused = F_.GlobalPoolAddFn.apply(x, y)
+        gp_i, gp_l = getattr(im, "global_pool", None), getattr(li, "global_pool", None)
+        if isinstance(getattr(gp_i, "norm", None), nn.LayerNorm):     # ConvNeXt: global_pool = the re-labelled head (pool -> LayerNorm((512, 1, 1)))
+            fused = F_.PoolNormFn.apply(x, gp_i.norm, gp_i.norm.weight, gp_i.norm.bias) + F_.PoolNormFn.apply(y, gp_l.norm, gp_l.norm.weight, gp_l.norm.bias)
+        else:
+            fused = F_.GlobalPoolAddFn.apply(x, y)
         return self.top_down_nhwc(y), x, fused
 
 
@@ -349,8 +358,8 @@ class LateFusionBackbone(_FusionBackbone):
     """team_code_transfuser/late_fusion.py:5-111: both RegNetY trunks run without any exchange between the stages (on two
     HIP streams, like the fused backbones), 1x1 reducers 1512 -> 512, FPN on the LiDAR map, fused = gap(image) + gap(lidar) (+ vel_emb).
     Module / parameter names are the reference's (timm models used as they are: ``features.stem.*`` / ``_model.stem.*`` with in_chans
-    input channels, no conv1/layerN aliases; ``reduce_channels_conv_*``), so late-fusion checkpoints load.  ResNet / ConvNeXt trunks (the
-    re-labelling branches of late_fusion.py:23-33) are not built: RegNetY only, as everywhere on this path."""
+    input channels, no conv1/layerN aliases; ``reduce_channels_conv_*``), so late-fusion checkpoints load.  This backbone keeps RegNetY trunks only
+    (the ResNet / ConvNeXt branches of late_fusion.py:23-33 are not wired here; TransfuserBackbone / latentTF / geometric fusion take all three families)."""
 
     _reducers = ("reduce_channels_conv_image", "reduce_channels_conv_lidar")
 
