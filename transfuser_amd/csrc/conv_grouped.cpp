@@ -315,7 +315,7 @@ __global__ void __launch_bounds__(256) conv3x3_grouped_wgrad_reduce_kernel(const
 // the (TH+1) x (TW+1) dY patch and the group's weight panel are staged as in conv3x3_grouped_kernel.  Tiles run over the dY grid.
 template <int TW>
 __global__ void __launch_bounds__(256, 2) conv3x3_grouped_s2_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, GcGeom g,
-                                                                          int Hi, int Wi, int accumulate) {
+                                                                          int Hi, int Wi, int accumulate, int prec) {
     constexpr int RW = 32 / TW, TH = 4 * RW, PH = TH + 1, PW = TW + 1, NPIX = PH * PW;
     constexpr int NV = (NPIX * 6 + 255) / 256;
     __shared__ float patch[NPIX * PP];
@@ -361,10 +361,27 @@ __global__ void __launch_bounds__(256, 2) conv3x3_grouped_s2_dgrad_kernel(const 
             for (int kw = 0; kw < 3; ++kw) {
                 const int a = (kh + 1) & 1, b2 = (kw + 1) & 1;            // parity class fed by this tap
                 const int dr = (a + 1 - kh) / 2, dc = (b2 + 1 - kw) / 2;    // dY offset: (2i + a + 1 - kh) / 2 = i + dr
-                const float* pa = patch + ((prow + dr) * PW + pcol + dc) * PP + hi;
-                const float* pb = &wl[(8 - (3 * kh + kw)) * CG + hi][l31];
+                if (prec == 1 || prec == 3) {      // bf16 / fp16 compute modes: operands rounded in registers like conv3x3_grouped_kernel (two 16-deep groups over 24 -> 32 channels)
+                    const float* pa = patch + ((prow + dr) * PW + pcol + dc) * PP;
+                    const int tp = (8 - (3 * kh + kw)) * CG;
 #pragma unroll
-                for (int kk = 0; kk < CG / 2; ++kk) mfma_32x32x2(pa[2 * kk], pb[2 * kk * WP], acc[a][b2]);
+                    for (int q = 0; q < 2; ++q) {
+                        float av[8], bv[8];
+                        const bool live = (q == 0) || (hi == 0);
+                        const int k0 = 16 * q + 8 * hi;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            av[j] = live ? pa[k0 + j] : 0.f;
+                            bv[j] = live ? wl[tp + k0 + j][l31] : 0.f;
+                        }
+                        mfma_32x32x16_lp(av, bv, acc[a][b2], prec);
+                    }
+                } else {
+                    const float* pa = patch + ((prow + dr) * PW + pcol + dc) * PP + hi;
+                    const float* pb = &wl[(8 - (3 * kh + kw)) * CG + hi][l31];
+#pragma unroll
+                    for (int kk = 0; kk < CG / 2; ++kk) mfma_32x32x2(pa[2 * kk], pb[2 * kk * WP], acc[a][b2]);
+                }
             }
         const int b = tile / (g.tiles_h * g.tiles_w), r = tile - b * (g.tiles_h * g.tiles_w);
         const int h0 = (r / g.tiles_w) * TH, w0 = (r % g.tiles_w) * TW;
@@ -493,7 +510,8 @@ extern "C" int tf_conv3x3_grouped_s2_dgrad_f32(const float* dy, const float* w, 
     const int Ho = (Hi - 1) / 2 + 1, Wo = (Wi - 1) / 2 + 1;        // 3x3 / stride 2 / pad 1
     const int tw = pick_tw(Ho, Wo);
     GcGeom g = make_geom(B, Ho, Wo, C, tw);                        // tiles over the dY grid
-    if (tw == 16) TF_LAUNCH((conv3x3_grouped_s2_dgrad_kernel<16>), dim3(g.G * g.nb), dim3(256), stream, dy, w, dx, g, Hi, Wi, accumulate);
-    else TF_LAUNCH((conv3x3_grouped_s2_dgrad_kernel<32>), dim3(g.G * g.nb), dim3(256), stream, dy, w, dx, g, Hi, Wi, accumulate);
+    const int prec = tf::gemm_precision();      // 0 / 2 (f32x3: the exact fp32 MFMA is at least as accurate): fp32 path; 1 / 3: bf16 / fp16 operands
+    if (tw == 16) TF_LAUNCH((conv3x3_grouped_s2_dgrad_kernel<16>), dim3(g.G * g.nb), dim3(256), stream, dy, w, dx, g, Hi, Wi, accumulate, prec);
+    else TF_LAUNCH((conv3x3_grouped_s2_dgrad_kernel<32>), dim3(g.G * g.nb), dim3(256), stream, dy, w, dx, g, Hi, Wi, accumulate, prec);
     return launch_status("tf_conv3x3_grouped_s2_dgrad_f32");
 }
