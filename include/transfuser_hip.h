@@ -141,6 +141,9 @@ int tf_colsum_mul_f32(const float* a, const float* b, int rows, int C, float* ou
 int tf_cast16_f32(const float* x, int rows, int cols, int ldx, void* y16, int ldy, void* y16t, int ldyt, int dtype, void* stream);
 int tf_gemm16_nt_f32(const void* a16, const void* b16, float* c, int m, int n, int k, int lda, int ldb, int ldc, const float* bias, const float* res, int ldres,
                      float alpha, int relu, int accumulate, const float* mask, int ldmask, int dtype, void* stream);
+/* plain store + the BatchNorm statistics of the output (tf_gemm_desc.colstat semantics): the RegNetY 1x1 convolutions in the 16-bit storage modes */
+int tf_gemm16_nt_colstat_f32(const void* a16, const void* b16, float* c, int m, int n, int k, int lda, int ldb, int ldc, int dtype, float* colstat,
+                             int* colstat_nparts, void* stream);
 /* dst[b][2 i][2 j][:] += src[b][i][j][:] (NHWC, C % 4 == 0): the scatter half of a 1x1 / stride-2 convolution's input gradient (the RegNet
  * downsample branches, timm Bottleneck via transfuser.py:380,442); the other half is a plain GEMM over the B Ho Wo output pixels. */
 int tf_add_strided2_f32(const float* src, float* dst, int B, int Ho, int Wo, int C, int Hi, int Wi, void* stream);

@@ -979,6 +979,25 @@ def check_lowp16_storage(dev, mode):
                 close(ops.gemm16_nt(d16, w16t, torch.empty(m, k, device=dev), k=n, kind=kind), rnd(dy) @ rnd(w), tol=1e-4, what="gemm16 dgrad")
                 dw0 = R(n, k, seed=9, dev=dev)
                 close(ops.gemm16_nt(d16t, x16t, dw0.clone(), accumulate=True, k=d16t.shape[1], kind=kind), dw0 + rnd(dy).t() @ rnd(x), tol=1e-4, what="gemm16 wgrad")
+        # the RegNetY 1x1 convolutions on stored operands: BatchNorm statistics from the epilogue, and the weight gradient over MANY rows
+        # (tiny output, long contraction: k-slices that atomically add)
+        old_fuse = ops.FUSE_BN_STATS
+        ops.FUSE_BN_STATS = True
+        try:
+            for (m, n, k) in ((2100, 72, 48), (203, 216, 72)):
+                x, w = R(m, k, dev=dev) + 2.0, R(n, k, seed=3, dev=dev) * 0.2
+                x16, x16t = ops.cast16(x)
+                w16, w16t = ops.cast16(w)
+                y, cs = ops.gemm16_nt_colstat(x16, w16, torch.empty(m, n, device=dev))
+                close(y, rnd(x) @ rnd(w).t(), tol=1e-4, what="gemm16 with colstat")
+                assert cs is not None
+                _bn_from_parts(dev, y.view(1, 1, m, n), cs, relu=True)
+                dy = R(m, n, seed=8, dev=dev)
+                d16, d16t = ops.cast16(dy)
+                dw0 = R(n, k, seed=9, dev=dev)
+                close(ops.gemm16_nt(d16t, x16t, dw0.clone(), accumulate=True, k=d16t.shape[1]), dw0 + rnd(dy).t() @ rnd(x), tol=1e-4, what="gemm16 wgrad (k-split)")
+        finally:
+            ops.FUSE_BN_STATS = old_fuse
     finally:
         ops.set_precision("fp32")
 

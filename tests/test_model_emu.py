@@ -266,7 +266,7 @@ def test_dropout_paths_match_oracle_with_the_same_masks():
 
 @pytest.mark.parametrize("mode", ["bf16", "fp16"])
 def test_lowp_storage_modes_tiny_model(mode):
-    """16-bit operand STORAGE (ops.lowp_storage(): the GPT linear layers run on cast16 / gemm16_nt) end to end on the tiny model: the 11 losses
+    """16-bit operand STORAGE (ops.lowp_storage(): the GPT linear layers and the RegNetY 1x1 convolutions run on cast16 / gemm16_nt) end to end on the tiny model: the 11 losses
     within 3e-2 of the fp32 oracle, the gradient's global cosine with the fp32 oracle's >= 0.98, and the storage path == the in-register
     rounding path of the same precision (TF_STORE16 off) to fp32 summation accuracy - they round the same operands to the same 16-bit values."""
     from transfuser_amd import ops
@@ -275,14 +275,17 @@ def test_lowp_storage_modes_tiny_model(mode):
     res = {}
     for store in (True, False):
         prod, ref = mc.build_pair(cfg, "regnety_tiny", "cpu")
-        old = ops._STORE16
+        old, old_min = ops._STORE16, dict(ops.LOWP_CONV1X1_MIN)
         ops._STORE16 = store
+        ops.LOWP_CONV1X1_MIN.update(k=8, m=1)       # the RegNetY 1x1 convolutions of the tiny trunks (24..96 channels) take the storage path too
         ops.set_precision(mode)
         try:
             assert bool(ops.lowp_storage()) == store
+            assert ops.lowp_conv1x1_ok(128, 24, 48) == store
             lp, lr = mc.run_pair(prod, ref, cfg, batch, "cpu")
         finally:
             ops._STORE16 = old
+            ops.LOWP_CONV1X1_MIN.update(old_min)
             ops.set_precision("fp32")
         rp = dict(ref.named_parameters())
         names = [n for n, p in prod.named_parameters() if rp[n].grad is not None]

@@ -6,6 +6,8 @@
 using namespace tf;
 
 namespace tf {
+int gemm16_impl(const void* a16, const void* b16, float* c, int m, int n, int k, int lda, int ldb, int ldc, const float* bias, const float* res, int ldres, float alpha,
+                int relu, int accumulate, const float* mask, int ldmask, int dtype, float* colstat, int* colstat_nparts, void* stream);
 int smallm_fwd(const float* x, long ldx, const float* w, long ldw, const float* bias, const float* res, long ldres, float* y, long ldy, int M, int N,
                int K, int relu, void* stream);
 int smallm_dgrad(const float* dy, long lddy, const float* w, long ldw, const float* res, long ldres, float* dx, long lddx, int M, int N, int K,
@@ -91,8 +93,22 @@ extern "C" int tf_gemm_f32(const tf_gemm_desc* d, void* stream) {
 // A16 [m][k] and B16 [n][k] are bf16 (dtype 1) or IEEE-half (dtype 2) matrices with k contiguous; k % 8 == 0, lda % 8 == 0, ldb % 8 == 0, 16-byte
 // aligned bases (tf_cast16_f32 produces them).  Runs on the LDS-DMA "nt" kernels: the tiles are moved as bytes (a row of 2 BK halves has the
 // byte geometry of BK floats), every ds_read_b128 fragment is one operand of v_mfma_f32_32x32x16_{bf16,f16}.
+extern "C" int tf_gemm16_nt_colstat_f32(const void* a16, const void* b16, float* c, int m, int n, int k, int lda, int ldb, int ldc, int dtype, float* colstat,
+                                        int* colstat_nparts, void* stream);
 extern "C" int tf_gemm16_nt_f32(const void* a16, const void* b16, float* c, int m, int n, int k, int lda, int ldb, int ldc, const float* bias, const float* res,
                                 int ldres, float alpha, int relu, int accumulate, const float* mask, int ldmask, int dtype, void* stream) {
+    return tf::gemm16_impl(a16, b16, c, m, n, k, lda, ldb, ldc, bias, res, ldres, alpha, relu, accumulate, mask, ldmask, dtype, nullptr, nullptr, stream);
+}
+// plain store + the BatchNorm statistics of the output gathered by the epilogue (tf_gemm_desc.colstat semantics): the 1x1 convolutions of the
+// RegNetY bottlenecks in the 16-bit storage modes
+extern "C" int tf_gemm16_nt_colstat_f32(const void* a16, const void* b16, float* c, int m, int n, int k, int lda, int ldb, int ldc, int dtype, float* colstat,
+                                        int* colstat_nparts, void* stream) {
+    TF_REQUIRE(colstat && colstat_nparts, "tf_gemm16_nt_colstat_f32: colstat and colstat_nparts are required");
+    return tf::gemm16_impl(a16, b16, c, m, n, k, lda, ldb, ldc, nullptr, nullptr, 0, 1.f, 0, 0, nullptr, 0, dtype, colstat, colstat_nparts, stream);
+}
+namespace tf {
+int gemm16_impl(const void* a16, const void* b16, float* c, int m, int n, int k, int lda, int ldb, int ldc, const float* bias, const float* res, int ldres, float alpha,
+                int relu, int accumulate, const float* mask, int ldmask, int dtype, float* colstat, int* colstat_nparts, void* stream) {
     TF_REQUIRE(a16 && b16 && c && m > 0 && n > 0 && k > 0, "tf_gemm16_nt_f32: bad sizes m=%d n=%d k=%d", m, n, k);
     const int pin = dtype >> 4;        // bits 4..: pin an LDS-DMA tile configuration (tests / tuning); 0 = heuristic
     dtype &= 15;
@@ -104,6 +120,7 @@ extern "C" int tf_gemm16_nt_f32(const void* a16, const void* b16, float* c, int 
     ep.bias = bias; ep.sbias = 0; ep.res = res; ep.ldres = ldres; ep.alpha = alpha; ep.relu = relu; ep.mode = accumulate ? 1 : 0;
     ep.mask = mask; ep.ldmask = ldmask;
     ep.packed16 = dtype;
+    if (colstat) { ep.stat = colstat; ep.stat_ld = n; ep.stat_nparts = colstat_nparts; *colstat_nparts = 0; }
     // the operands in units of 4 bytes
     PlainOp A = make_plain(reinterpret_cast<const float*>(a16), lda / 2, m, k / 2, 0, 0, 1, 1);
     PlainOp B = make_plain(reinterpret_cast<const float*>(b16), ldb / 2, n, k / 2, 0, 0, 1, 1);
@@ -114,6 +131,20 @@ extern "C" int tf_gemm16_nt_f32(const void* a16, const void* b16, float* c, int 
     int kind = t128 >= 384 ? 5 : (t12864 >= 256 ? 3 : 2);
     if (forced >= 1 && forced <= kDmaKinds) kind = forced;
     if (pin >= 1 && pin <= kDmaKinds) kind = pin;
-    launch_dma_plan<true, true>(kind, A, B, ep, m, n, k / 2, 1, 1, stream);
+    // weight gradients (accumulate, rows contracted: k >> m, n): k-slices that atomically add, enough of them for two workgroups per CU
+    int splitk = 1;
+    if (accumulate && !bias && !res && !relu && !mask && alpha == 1.f) {
+        static const int bm_of[] = {0, 128, 64, 128, 64, 128, 64, 64, 128}, bn_of[] = {0, 128, 64, 64, 128, 128, 64, 128, 64};
+        const int kk = kind >= 1 && kind <= 8 ? kind : 8;
+        const long tiles = (long)cdiv(m, bm_of[kk]) * cdiv(n, bn_of[kk]);
+        if (tiles < 256) {
+            long s = cdiv(512, tiles), smax = (k / 2) / 256;     // slices of >= 512 halves
+            if (s > smax) s = smax;
+            if (s > 128) s = 128;
+            if (s >= 2) { splitk = (int)s; ep.mode = 2; }
+        }
+    }
+    launch_dma_plan<true, true>(kind, A, B, ep, m, n, k / 2, 1, splitk, stream);
     return launch_status("tf_gemm16_nt_f32");
 }
+}  // namespace tf

@@ -356,6 +356,36 @@ class PoolNormFn(torch.autograd.Function):
         return ops.se_scale_bwd_x(None, None, dp, shape), None, None, None
 
 
+# ---- 1x1 convolutions of the trunks on 16-bit STORED operands (precision "bf16" / "fp16", ops.lowp_conv1x1_ok): same scheme as _lin16_* -
+# the forward casts the input once (row-major copy for this product, transposed copy kept for the weight gradient), the backward casts dy once.
+def _c1x1_fwd(x2, w, colstat=True):
+    """y (M, N) = x2 (M, K) @ w (N, K)^T  (+ BatchNorm statistics of y); returns (y, ColStat or None, saved) with saved = A16 or the fp32 x2."""
+    M, K = x2.shape
+    N = w.shape[0]
+    if ops.lowp_conv1x1_ok(M, K, N):
+        x16, x16t = ops.cast16(x2)
+        w16, _ = ops.lowp_weight(w)
+        y = torch.empty(M, N, dtype=torch.float32, device=x2.device)
+        y, cs = ops.gemm16_nt_colstat(x16, w16, y, want_stat=colstat)
+        return y, cs, A16(x16t)
+    if colstat:
+        y, cs = ops.linear_fwd(x2, w, colstat=True)
+        return y, cs, x2
+    return ops.linear_fwd(x2, w), None, x2
+
+
+def _c1x1_bwd(dy2, saved, w, dw, res=None):
+    """dW += dy^T x, returns dx = dy W (+ res)."""
+    if isinstance(saved, A16):
+        d16, d16t = ops.cast16(dy2)
+        ops.gemm16_nt(d16t, saved.t, dw, accumulate=True, k=d16t.shape[1])
+        _, w16t = ops.lowp_weight(w)
+        dx = torch.empty(dy2.shape[0], w.shape[1], dtype=torch.float32, device=dy2.device)
+        return ops.gemm16_nt(d16, w16t, dx, res=res, k=w.shape[0])
+    ops.wgrad_fork((dy2, saved), lambda: ops.linear_wgrad(dy2, saved, dw))
+    return ops.linear_dgrad(dy2, w, res=res)
+
+
 # ============================================================================================ RegNetY block
 @routes_param_grads
 class YBlockFn(torch.autograd.Function):
@@ -367,7 +397,7 @@ class YBlockFn(torch.autograd.Function):
         B, H, W, Cin = x.shape
         C = blk.out_chs
         x2 = x.view(-1, Cin)
-        y1, cs1 = ops.linear_fwd(x2, w2d(blk.conv1.conv.weight), colstat=True)      # BN statistics gathered by the GEMM epilogue
+        y1, cs1, x2s = _c1x1_fwd(x2, w2d(blk.conv1.conv.weight))      # BN statistics gathered by the GEMM epilogue
         y1 = y1.view(B, H, W, C)
         z1, st1 = _bn(y1, blk.conv1.bn, relu=True, stat=cs1)
         y2, cs2 = ops.conv_fwd(z1, blk.conv2.conv.weight, None, blk.stride, 1, blk.groups, colstat=True)
@@ -391,7 +421,9 @@ class YBlockFn(torch.autograd.Function):
                 g1 = ops.linear_fwd(s, w2d(blk.se.fc1.weight), blk.se.fc1.bias, relu=True)
                 gate = ops.linear_fwd(g1, w2d(blk.se.fc2.weight), blk.se.fc2.bias)
             z2s = ops.se_scale_fwd(z2, gate)
-        y3, cs3 = ops.linear_fwd(z2s.view(-1, C), w2d(blk.conv3.conv.weight), colstat=True)
+        y3, cs3, z2ss = _c1x1_fwd(z2s.view(-1, C), w2d(blk.conv3.conv.weight))
+        if isinstance(z2ss, A16):
+            z2s = None          # only its transposed 16-bit copy is needed again (weight gradient of conv3)
         y3 = y3.view(B, Ho, Wo, C)
         yd = std = None
         if blk.downsample is not None:
@@ -404,7 +436,7 @@ class YBlockFn(torch.autograd.Function):
         else:
             sc = x
         out, st3 = _bn(y3, blk.conv3.bn, res=sc, relu=True, stat=cs3)
-        ctx.saved = (x, blk, y1, z1, st1, y2, z2, st2, s, g1, gate, z2s, y3, st3, yd, std, out)
+        ctx.saved = (x, blk, y1, z1, st1, y2, z2, st2, s, g1, gate, z2ss, y3, st3, yd, std, out, x2s)
         return out
 
     @staticmethod
@@ -412,15 +444,14 @@ class YBlockFn(torch.autograd.Function):
         if ctx.saved is None:
             raise RuntimeError("YBlockFn: trying to backward through the graph a second time: the saved activations are freed by the first backward "
                                "(retain_graph is not supported by the block Functions)")
-        x, blk, y1, z1, st1, y2, z2, st2, s, g1, gate, z2s, y3, st3, yd, std, out = ctx.saved
+        x, blk, y1, z1, st1, y2, z2, st2, s, g1, gate, z2ss, y3, st3, yd, std, out, x2s = ctx.saved
         B, H, W, Cin = x.shape
         _, Ho, Wo, C = out.shape
         x2 = x.view(-1, Cin)
         dy3, dsc = _bn_bwd(dout.contiguous(), out, y3, blk.conv3.bn, st3, want_dres=True)
         dy3_2 = dy3.view(-1, C)
         w3 = blk.conv3.conv.weight
-        ops.wgrad_fork((dy3, z2s), lambda: ops.linear_wgrad(dy3_2, z2s.view(-1, C), w2d(gbuf(w3))))
-        dz2s = ops.linear_dgrad(dy3_2, w2d(w3)).view(B, Ho, Wo, C)
+        dz2s = _c1x1_bwd(dy3_2, z2ss, w2d(w3), w2d(gbuf(w3))).view(B, Ho, Wo, C)
         # squeeze-excite
         se = blk.se
         if z2 is None:      # forward ran with the BatchNorm apply folded into the consumers (st2 = (mean, invstd, [scale | shift]))
@@ -451,11 +482,10 @@ class YBlockFn(torch.autograd.Function):
         dy1, _ = _bn_bwd(dz1, z1, y1, blk.conv1.bn, st1)
         dy1_2 = dy1.view(-1, C)
         w1 = blk.conv1.conv.weight
-        ops.wgrad_fork((dy1, x), lambda: ops.linear_wgrad(dy1_2, x2, w2d(gbuf(w1))))
         if blk.downsample is None:
-            dx = ops.linear_dgrad(dy1_2, w2d(w1), res=dsc.view(-1, Cin))
+            dx = _c1x1_bwd(dy1_2, x2s, w2d(w1), w2d(gbuf(w1)), res=dsc.view(-1, Cin))
         else:
-            dx = ops.linear_dgrad(dy1_2, w2d(w1))
+            dx = _c1x1_bwd(dy1_2, x2s, w2d(w1), w2d(gbuf(w1)))
             dyd, _ = _bn_bwd(dsc, None, yd, blk.downsample.bn, std)
             wd = blk.downsample.conv.weight
             if blk.stride == 1:

@@ -103,6 +103,29 @@ def gemm16_nt(a16, b16, out, bias=None, res=None, relu=False, accumulate=False, 
     return out
 
 
+def gemm16_nt_colstat(a16, b16, out, want_stat=True):
+    """out = a16 @ b16.T (plain store) + the BatchNorm statistics of out from the epilogue (ColStat or None)."""
+    m, n = out.shape
+    k = a16.shape[1]
+    cs = ColStat(m, n, out.device) if (want_stat and want_colstat(m)) else None
+    if cs is None:
+        return gemm16_nt(a16, b16, out), None
+    _e = _census_begin()
+    check(L().tf_gemm16_nt_colstat_f32(ctypes.c_void_p(a16.data_ptr()), ctypes.c_void_p(b16.data_ptr()), ptr(out), m, n, k, a16.stride(0), b16.stride(0), out.stride(0),
+                                       _lowp["dtype"], ptr(cs.buf), byref(cs.nparts), stream_of(out)), "tf_gemm16_nt_colstat_f32")
+    _census_end(_e, "gemm16 nt", (m, n, k, 1), 2.0 * m * n * k)
+    return out, (cs if cs else None)
+
+
+LOWP_CONV1X1 = os.environ.get("TF_STORE16_CONV", "1") != "0"
+LOWP_CONV1X1_MIN = {"k": 64, "m": 512}        # (tests lower these to reach the path on the tiny models)
+
+
+def lowp_conv1x1_ok(M, K, N):
+    """1x1 convolutions of the trunks on 16-bit stored operands: worth the cast passes from a few hundred rows / 64 channels on."""
+    return bool(_lowp["dtype"]) and LOWP_CONV1X1 and K % 8 == 0 and N % 8 == 0 and K >= LOWP_CONV1X1_MIN["k"] and M >= LOWP_CONV1X1_MIN["m"]
+
+
 def lowp_weight(w):
     """(w16 (N, K), w16t (K, N8)) of a linear weight (N, K).  Inside train.Engine the copies are cached and rewritten once per step right after
     AdamW (``lowp_refresh_weights``); anywhere else they are re-made at every use (the parameter may have changed)."""
