@@ -213,7 +213,9 @@ int tf_attention_bwd_f32(const float* qkv, const float* dy, const float* lse, fl
 
 /* ---- per-channel reductions / BatchNorm / Squeeze-Excite ------------------------------------- */
 
-/* scratch every reduction entry point needs (one buffer per stream is enough) */
+/* scratch every reduction entry point needs (one buffer per stream is enough).  The buffer must be ZERO-INITIALISED once by its owner before
+ * its first use: its last 16 KB hold the arrival counters of the fused reduce + finalize kernels (the block that draws a column tile's last
+ * ticket sums the chunk partials in a fixed order and resets the counter, so the buffer stays valid for the next launch on that stream). */
 long tf_workspace_bytes(void);
 /* Train-mode BatchNorm forward whose batch statistics were gathered by the PRODUCING convolution's epilogue (tf_gemm_desc.colstat,
  * tf_conv2d_fwd_colstat_f32, tf_conv3x3_grouped_fwd_colstat_f32: per-part Welford triples [part][{count, mean, M2}][C]): merges the parts

@@ -413,6 +413,43 @@ def check_colsum(dev):
     close(ops.colsum(x3, 4, 33, 1512), x3.sum(1), what="colsum wide")
 
 
+def check_fused_finalize(dev):
+    """The reduce kernels finish their own reduction (the block that draws a column tile's last ticket sums the chunk partials): many chunks,
+    ragged row counts, several segments and column tiles; bitwise run-to-run reproducible; the arrival counters at the end of the workspace
+    are back at zero after every launch (so the next launch on the stream starts clean)."""
+    L = ops.L()
+    L.tf_workspace_bytes.restype = __import__("ctypes").c_long
+    nws = L.tf_workspace_bytes() // 4
+    for (nseg, rows, C) in [(1, 5000, 576), (3, 777, 72), (2, 1301, 1512), (1, 4099, 7), (5, 64, 216)]:
+        x = R(nseg, rows, C, dev=dev)
+        m = R(nseg, rows, C, seed=1, dev=dev)
+        want = (x.double() * (m > 0)).sum(1)
+        outs = [ops.colsum(x, nseg, rows, C, mask=m) for _ in range(3)]
+        close(outs[0], want, tol=2e-5, what="fused finalize colsum %s" % ((nseg, rows, C),))
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), "fused finalize: not run-to-run reproducible"
+        acc = R(nseg, C, seed=2, dev=dev)
+        close(ops.colsum(x, nseg, rows, C, scale=0.5, out=acc.clone(), accumulate=True), acc.double() + 0.5 * x.double().sum(1), tol=2e-5, what="fused finalize colsum acc")
+        ws = ops.workspace(x.device)
+        assert ws.numel() == nws and int(ws[-4096:].view(torch.int32).abs().max()) == 0, "arrival counters not reset"
+    # BatchNorm backward through the fused finalize: dgamma / dbeta accumulate, coefficients feed the apply pass
+    B, H, W, C = 4, 37, 29, 216
+    xb = R(B, H, W, C, dev=dev)
+    g, b = R(C, seed=3, dev=dev), R(C, seed=4, dev=dev)
+    y, sm, si = ops.bn_fwd(xb, g, b, torch.zeros(C, device=dev), torch.ones(C, device=dev), relu=True)
+    dz = R(B, H, W, C, seed=5, dev=dev)
+    res = []
+    for _ in range(2):
+        dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+        dx, _ = ops.bn_bwd(dz, y, xb, g, sm, si, dg, db)
+        res.append((dx, dg, db))
+    assert all(torch.equal(a, b_) for a, b_ in zip(res[0], res[1])), "fused finalize BatchNorm backward: not reproducible"
+    xr = xb.double().requires_grad_(True); gr = g.double().requires_grad_(True); br = b.double().requires_grad_(True)
+    yr = torch.relu(F.batch_norm(xr.permute(0, 3, 1, 2), None, None, gr, br, True, 0.1, 1e-5)).permute(0, 2, 3, 1)
+    gx, gg, gb = torch.autograd.grad(yr, [xr, gr, br], dz.double())
+    close(res[0][0], gx, tol=2e-4, what="fused finalize bn dx"); close(res[0][1], gg, tol=2e-4, what="fused finalize bn dgamma"); close(res[0][2], gb, tol=2e-4, what="fused finalize bn dbeta")
+    assert int(ops.workspace(xb.device)[-4096:].view(torch.int32).abs().max()) == 0
+
+
 def check_se(dev, B, H, W, C):
     x = R(B, H, W, C, dev=dev).requires_grad_(True)
     gate = R(B, C, seed=1, dev=dev).requires_grad_(True)

@@ -65,6 +65,18 @@ def test_bn_eval():
     kc.check_bn_eval("cuda")
 
 
+def test_reduce_with_fused_finalize():
+    """The opt-in fused reduce + finalize path (TF_FUSE_FINALIZE=1, read when the library loads: run in a child process), and the default
+    path through the same checks."""
+    import os, subprocess, sys
+    kc.check_fused_finalize("cuda")
+    env = dict(os.environ, TF_FUSE_FINALIZE="1")
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = "import sys; sys.path[:0] = [%r, %r]; import kernel_cases as kc; kc.check_fused_finalize('cuda'); print('fused finalize ok')" % (here, os.path.dirname(here))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "fused finalize ok" in r.stdout, r.stdout + r.stderr
+
+
 def test_colsum_and_se():
     kc.check_colsum("cuda")
     kc.check_se("cuda", 3, 5, 6, 72)

@@ -275,8 +275,9 @@ def test_lowp_storage_modes_tiny_model(mode):
     res = {}
     for store in (True, False):
         prod, ref = mc.build_pair(cfg, "regnety_tiny", "cpu")
-        old, old_min = ops._STORE16, dict(ops.LOWP_CONV1X1_MIN)
+        old, old_min, old_conv = ops._STORE16, dict(ops.LOWP_CONV1X1_MIN), ops.LOWP_CONV1X1
         ops._STORE16 = store
+        ops.LOWP_CONV1X1 = True                     # off by default (measured: the cast passes cost more than the packed GEMMs gain), tested all the same
         ops.LOWP_CONV1X1_MIN.update(k=8, m=1)       # the RegNetY 1x1 convolutions of the tiny trunks (24..96 channels) take the storage path too
         ops.set_precision(mode)
         try:
