@@ -46,6 +46,9 @@ def compile_objects(cc, flags, objdir, verbose=True):
         if verbose:
             print("  cc", os.path.basename(src), flush=True)
 
+    # the engine instantiations (conv_*, gemm_plain_*, gemm_dma_*) take minutes each: start them first so they are not the tail of the build
+    heavy = ("conv_fwd", "conv_dgrad", "conv_wgrad", "conv_stem", "gemm_plain_", "gemm_dma_", "gemm.", "conv_direct", "conv_grouped", "attention")
+    jobs.sort(key=lambda j: next((i for i, h in enumerate(heavy) if os.path.basename(j[0]).startswith(h)), len(heavy)))
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
         list(ex.map(run, jobs))
     return [os.path.join(objdir, os.path.basename(s)[:-4] + ".o") for s in sources()]

@@ -8,6 +8,11 @@ using namespace tf;
 namespace tf {
 int gemm16_impl(const void* a16, const void* b16, float* c, int m, int n, int k, int lda, int ldb, int ldc, const float* bias, const float* res, int ldres, float alpha,
                 int relu, int accumulate, const float* mask, int ldmask, int dtype, float* colstat, int* colstat_nparts, void* stream);
+// the four operand layouts of the register-staged engine: one translation unit each (gemm_plain_{nt,nn,tn,tt}.cpp) so hipcc compiles them in parallel
+int gemm_plain_nt(const PlainOp& a, const PlainOp& b, const GemmEpi& ep, int M, int N, int K, int batch, bool allow_splitk, void* stream, const char* what);
+int gemm_plain_nn(const PlainOp& a, const PlainOp& b, const GemmEpi& ep, int M, int N, int K, int batch, bool allow_splitk, void* stream, const char* what);
+int gemm_plain_tn(const PlainOp& a, const PlainOp& b, const GemmEpi& ep, int M, int N, int K, int batch, bool allow_splitk, void* stream, const char* what);
+int gemm_plain_tt(const PlainOp& a, const PlainOp& b, const GemmEpi& ep, int M, int N, int K, int batch, bool allow_splitk, void* stream, const char* what);
 int smallm_fwd(const float* x, long ldx, const float* w, long ldw, const float* bias, const float* res, long ldres, float* y, long ldy, int M, int N,
                int K, int relu, void* stream);
 int smallm_dgrad(const float* dy, long lddy, const float* w, long ldw, const float* res, long ldres, float* dx, long lddx, int M, int N, int K,
@@ -75,18 +80,18 @@ extern "C" int tf_gemm_f32(const tf_gemm_desc* d, void* stream) {
     PlainOp B = d->b_trans ? make_plain(d->b, d->ldb, d->k, d->n, d->sb_outer, d->sb_inner, inner, d->batch)
                            : make_plain(d->b, d->ldb, d->n, d->k, d->sb_outer, d->sb_inner, inner, d->batch);
     const bool sk = d->accumulate != 0;
-    if (!d->a_trans && !d->b_trans) return launch_gemm<PlainOp, true, PlainOp, true>(A, B, ep, d->m, d->n, d->k, d->batch, sk, stream, "tf_gemm_f32[nt]");
-    if (!d->a_trans && d->b_trans) return launch_gemm<PlainOp, true, PlainOp, false>(A, B, ep, d->m, d->n, d->k, d->batch, sk, stream, "tf_gemm_f32[nn]");
+    if (!d->a_trans && !d->b_trans) return gemm_plain_nt(A, B, ep, d->m, d->n, d->k, d->batch, sk, stream, "tf_gemm_f32[nt]");
+    if (!d->a_trans && d->b_trans) return gemm_plain_nn(A, B, ep, d->m, d->n, d->k, d->batch, sk, stream, "tf_gemm_f32[nn]");
     if (d->a_trans && d->b_trans) {
         // weight gradient with few output rows (m = out features <= 32 << n): compute C^T so the short side becomes the
         // 32-wide column tile instead of a 128-row tile (4x less MFMA padding); stores go through the column stride.
         if (d->m <= 32 && d->n >= 2 * d->m && !d->bias && !d->res && !d->relu) {
             ep.ldc = 1; ep.ldcj = d->ldc;
-            return launch_gemm<PlainOp, false, PlainOp, false>(B, A, ep, d->n, d->m, d->k, d->batch, sk, stream, "tf_gemm_f32[tn,swapped]");
+            return gemm_plain_tn(B, A, ep, d->n, d->m, d->k, d->batch, sk, stream, "tf_gemm_f32[tn,swapped]");
         }
-        return launch_gemm<PlainOp, false, PlainOp, false>(A, B, ep, d->m, d->n, d->k, d->batch, sk, stream, "tf_gemm_f32[tn]");
+        return gemm_plain_tn(A, B, ep, d->m, d->n, d->k, d->batch, sk, stream, "tf_gemm_f32[tn]");
     }
-    return launch_gemm<PlainOp, false, PlainOp, true>(A, B, ep, d->m, d->n, d->k, d->batch, sk, stream, "tf_gemm_f32[tt]");
+    return gemm_plain_tt(A, B, ep, d->m, d->n, d->k, d->batch, sk, stream, "tf_gemm_f32[tt]");
 }
 
 // ---- packed 16-bit operands: C (op)= alpha * A16 . B16^T (+ bias) (+ res) (relu) (mask), fp32 accumulate / output.
