@@ -131,6 +131,10 @@ int tf_gelu_fwd_f32(const float* x, float* y, int64_t n, void* stream);
 int tf_gelu_bwd_f32(const float* dy, const float* x, float* dx, int64_t n, void* stream);
 int tf_colscale_add_f32(const float* x, const float* gamma, const float* beta, const float* res, float* y, int64_t rows, int C, void* stream);
 int tf_colsum_mul_f32(const float* a, const float* b, int rows, int C, float* out, int accumulate, float* ws, void* stream);
+/* out_e[c] += sum_r x_e[r][c] for n <= 8 matrices with the same row count in ONE single-pass launch (no workspace, no finalize, bitwise
+ * reproducible): the bias gradients of a transformer Block's four nn.Linear layers (transfuser.py:500-507,539-541).  C_e % 4 == 0, row strides
+ * ld_e (floats) % 4 == 0, 16-byte aligned bases. */
+int tf_colsum_multi_f32(int n, const float* const* xs, const int* Cs, const long* lds, float* const* outs, int rows, void* stream);
 
 /* ---- 16-bit operand STORAGE path (BASELINE configs[2] "bf16", configs[4] "fp16 MFMA"; the reference trains fp32 only, config.py:55).
  * tf_cast16_f32: x (rows x cols fp32, row stride ldx) -> y16 (rows x cols, row stride ldy, pad columns zeroed) and / or y16t (cols x rows: the

@@ -450,6 +450,27 @@ def check_fused_finalize(dev):
     assert int(ops.workspace(xb.device)[-4096:].view(torch.int32).abs().max()) == 0
 
 
+def check_colsum_multi(dev):
+    """Several column sums over the same rows in one single-pass launch (the bias gradients of a transformer Block): ragged strips (C % 32 != 0),
+    strided views, accumulation into non-zero destinations, bitwise reproducible; the non-vector layout falls back to colsum."""
+    for rows in (1740, 33, 1):
+        big = R(rows, 3 * 72 + 40, dev=dev)
+        xs = [R(rows, 72, seed=1, dev=dev), R(rows, 288, seed=2, dev=dev), big[:, 40:40 + 216], R(rows, 1512, seed=3, dev=dev), R(rows, 4, seed=4, dev=dev)]
+        init = [R(x.shape[1], seed=10 + i, dev=dev) for i, x in enumerate(xs)]
+        outs = []
+        for _ in range(2):
+            o = [t.clone() for t in init]
+            ops.colsum_multi(list(zip(xs, o)))
+            outs.append(o)
+        for x, t, a, b in zip(xs, init, outs[0], outs[1]):
+            close(a, t.double() + x.double().sum(0), tol=2e-5, what="colsum_multi rows=%d C=%d" % (rows, x.shape[1]))
+            assert torch.equal(a, b), "colsum_multi: not reproducible"
+    x5 = R(50, 6, dev=dev)                      # C % 4 != 0: per-pair fallback
+    o5 = torch.zeros(6, device=dev)
+    ops.colsum_multi([(x5, o5)])
+    close(o5, x5.double().sum(0), tol=2e-5, what="colsum_multi fallback")
+
+
 def check_se(dev, B, H, W, C):
     x = R(B, H, W, C, dev=dev).requires_grad_(True)
     gate = R(B, C, seed=1, dev=dev).requires_grad_(True)

@@ -77,6 +77,10 @@ def test_reduce_with_fused_finalize():
     assert r.returncode == 0 and "fused finalize ok" in r.stdout, r.stdout + r.stderr
 
 
+def test_colsum_multi():
+    kc.check_colsum_multi("cuda")
+
+
 def test_colsum_and_se():
     kc.check_colsum("cuda")
     kc.check_se("cuda", 3, 5, 6, 72)

@@ -266,41 +266,48 @@ def test_dropout_paths_match_oracle_with_the_same_masks():
 
 @pytest.mark.parametrize("mode", ["bf16", "fp16"])
 def test_lowp_storage_modes_tiny_model(mode):
-    """16-bit operand STORAGE (ops.lowp_storage(): the GPT linear layers and the RegNetY 1x1 convolutions run on cast16 / gemm16_nt) end to end on the tiny model: the 11 losses
+    """16-bit operand STORAGE (ops.lowp_storage(): the GPT linear layers run on cast16 / gemm16_nt) end to end on the tiny model: the 11 losses
     within 3e-2 of the fp32 oracle, the gradient's global cosine with the fp32 oracle's >= 0.98, and the storage path == the in-register
-    rounding path of the same precision (TF_STORE16 off) to fp32 summation accuracy - they round the same operands to the same 16-bit values."""
+    rounding path of the same precision (TF_STORE16 off) to fp32 summation accuracy - they round the same operands to the same 16-bit values
+    (measured 9e-9 of the gradient norm).  The opt-in storage path of the trunk 1x1 convolutions (TF_STORE16_CONV=1, off by default: measured
+    slower) is held to the oracle-relative bars only: through ~20 small-batch BatchNorm layers its different fp32 summation order is amplified
+    to 3e-3 (bf16) / 1.4e-2 (fp16) of the gradient norm, concentrated in the first trunk layers."""
     from transfuser_amd import ops
     cfg = mc.tiny_config(n_layer=2)
     batch = mc.small_batch(2, 32, 64, 64, 40)
     res = {}
-    for store in (True, False):
+    for store, conv in ((True, False), (False, False), (True, True)):
         prod, ref = mc.build_pair(cfg, "regnety_tiny", "cpu")
         old, old_min, old_conv = ops._STORE16, dict(ops.LOWP_CONV1X1_MIN), ops.LOWP_CONV1X1
         ops._STORE16 = store
-        ops.LOWP_CONV1X1 = True                     # off by default (measured: the cast passes cost more than the packed GEMMs gain), tested all the same
-        ops.LOWP_CONV1X1_MIN.update(k=8, m=1)       # the RegNetY 1x1 convolutions of the tiny trunks (24..96 channels) take the storage path too
+        ops.LOWP_CONV1X1 = conv
+        ops.LOWP_CONV1X1_MIN.update(k=8, m=1)       # the RegNetY 1x1 convolutions of the tiny trunks (24..96 channels) reach the storage path too
         ops.set_precision(mode)
         try:
             assert bool(ops.lowp_storage()) == store
-            assert ops.lowp_conv1x1_ok(128, 24, 48) == store
+            assert ops.lowp_conv1x1_ok(128, 24, 48) == (store and conv)
             lp, lr = mc.run_pair(prod, ref, cfg, batch, "cpu")
         finally:
             ops._STORE16 = old
+            ops.LOWP_CONV1X1 = old_conv
             ops.LOWP_CONV1X1_MIN.update(old_min)
             ops.set_precision("fp32")
         rp = dict(ref.named_parameters())
         names = [n for n, p in prod.named_parameters() if rp[n].grad is not None]
         gp = torch.cat([dict(prod.named_parameters())[n].grad.detach().double().flatten() for n in names])
         gr = torch.cat([rp[n].grad.double().flatten() for n in names])
-        res[store] = ({k: float(v) for k, v in lp.items()}, gp)
+        res[(store, conv)] = ({k: float(v) for k, v in lp.items()}, gp)
         for k in lr:
-            assert abs(float(lp[k]) - float(lr[k])) <= 3e-2 * max(1.0, abs(float(lr[k]))), (mode, store, k, float(lp[k]), float(lr[k]))
+            assert abs(float(lp[k]) - float(lr[k])) <= 3e-2 * max(1.0, abs(float(lr[k]))), (mode, store, conv, k, float(lp[k]), float(lr[k]))
         cos = float(torch.dot(gp, gr) / (gp.norm() * gr.norm()))
-        assert cos >= 0.98, (mode, store, cos)
-    for k in res[True][0]:
-        assert abs(res[True][0][k] - res[False][0][k]) <= 1e-4 * max(1.0, abs(res[False][0][k])), (k, res[True][0][k], res[False][0][k])
-    rel = float((res[True][1] - res[False][1]).norm() / res[False][1].norm())
-    assert rel <= 2e-3, rel
+        assert cos >= 0.98, (mode, store, conv, cos)
+    a, b = res[(True, False)], res[(False, False)]
+    for k in a[0]:
+        assert abs(a[0][k] - b[0][k]) <= 1e-5 * max(1.0, abs(b[0][k])), (k, a[0][k], b[0][k])
+    rel = float((a[1] - b[1]).norm() / b[1].norm())
+    assert rel <= 1e-5, rel
+    for k in a[0]:
+        assert abs(res[(True, True)][0][k] - b[0][k]) <= 1e-4 * max(1.0, abs(b[0][k])), (k, res[(True, True)][0][k], b[0][k])
 
 
 @pytest.mark.parametrize("arch", ["resnet_tiny", "resnet_tiny50"])

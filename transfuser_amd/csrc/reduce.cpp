@@ -694,6 +694,48 @@ inline int ew_blocks(long nvec) {
     return (int)b;
 }
 
+// ---- several column sums over the SAME rows in ONE single-pass launch (the four bias gradients of a transformer Block, transfuser.py:500-541:
+// fc2 / fc1 / proj / key-query-value): out_e[c] += sum_r x_e[r][c].  A block owns one 32-column strip (one 128-byte line per row) of one
+// entry and ALL the rows: 8 column threads x 32 row lanes, 8 loads in flight per thread, the row lanes are combined through LDS in a fixed
+// order - no second stage, no atomics, bitwise reproducible.  Replaces 2 launches (reduce + finalize) per bias on the single-stream
+// critical path of the GPT stages.
+constexpr int kMultiMax = 8;
+struct MultiSum { const float* x[kMultiMax]; float* out[kMultiMax]; int C[kMultiMax]; long ld[kMultiMax]; int strip0[kMultiMax + 1]; int n; };
+__global__ void __launch_bounds__(256) colsum_multi_kernel(MultiSum d, int rows) {
+    __shared__ float4 red[32][8];
+    int e = 0;
+#pragma unroll
+    for (int i = 1; i < kMultiMax; ++i)
+        if (i < d.n && (int)blockIdx.x >= d.strip0[i]) e = i;
+    const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
+    const int C = d.C[e];
+    const int c = ((int)blockIdx.x - d.strip0[e]) * 32 + tx * 4;
+    const bool live = c < C;                        // C % 4 == 0: a float4 is all in or all out
+    const float* p = d.x[e] + (live ? c : 0);
+    const long ld = d.ld[e];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int r = ty;
+    for (; r + 7 * 32 < rows; r += 8 * 32) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(p + (long)(r + 32 * u) * ld);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+    }
+    for (; r < rows; r += 32) {
+        const float4 v = *reinterpret_cast<const float4*>(p + (long)r * ld);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    red[ty][tx] = acc;
+    __syncthreads();
+    if (ty == 0 && live) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < 32; ++j) { const float4 v = red[j][tx]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+        float* o = d.out[e] + c;
+        o[0] += t.x; o[1] += t.y; o[2] += t.z; o[3] += t.w;
+    }
+}
+
 }  // namespace
 
 extern "C" long tf_workspace_bytes(void) { return (kWsFloats + kTickets) * 4; }
@@ -914,4 +956,26 @@ extern "C" int tf_colsum_mul_f32(const float* a, const float* b, int rows, int C
         TF_LAUNCH(colsum_finalize_kernel, dim3(cdiv((long)C, 4)), dim3(256), stream, (const float*)ws, out, C, p.nchunks, 1, 1.f, accumulate);
     }
     return launch_status("tf_colsum_mul_f32");
+}
+
+// out_e[c] += sum over the rows of x_e[r][c] for n <= 8 matrices with the SAME row count (ld_e = row stride in floats, C_e % 4 == 0, 16-byte
+// aligned bases and strides): one single-pass launch - the bias gradients of a transformer Block (nn.Linear biases, transfuser.py:500-541).
+extern "C" int tf_colsum_multi_f32(int n, const float* const* xs, const int* Cs, const long* lds, float* const* outs, int rows, void* stream) {
+    TF_REQUIRE(n >= 1 && n <= kMultiMax && xs && Cs && lds && outs && rows > 0, "tf_colsum_multi_f32: 1 <= n <= %d matrices with rows > 0", kMultiMax);
+    MultiSum d;
+    d.n = n;
+    int strips = 0;
+    for (int i = 0; i < kMultiMax; ++i) {
+        const int j = i < n ? i : n - 1;
+        d.x[i] = xs[j]; d.out[i] = outs[j]; d.C[i] = Cs[j]; d.ld[i] = lds[j];
+        d.strip0[i] = strips;
+        if (i < n) {
+            TF_REQUIRE(xs[i] && outs[i] && Cs[i] > 0 && Cs[i] % 4 == 0 && lds[i] % 4 == 0 && lds[i] >= Cs[i] && aligned16(xs[i]),
+                       "tf_colsum_multi_f32: entry %d needs C %% 4 == 0, ld %% 4 == 0, ld >= C and a 16-byte aligned base", i);
+            strips += cdiv(Cs[i], 32);
+        }
+    }
+    d.strip0[kMultiMax] = strips;
+    TF_LAUNCH(colsum_multi_kernel, dim3(strips), dim3(256), stream, d, rows);
+    return launch_status("tf_colsum_multi_f32");
 }

@@ -665,22 +665,33 @@ def _gpt_block_bwd(gpt, li, saved, dx, B, T, drop):
     hs = C // nh
     alpha = 1.0 / math.sqrt(hs)
     fc1, fc2, proj = blk.mlp[0], blk.mlp[2], blk.attn.proj
+    # The four bias gradients of the Block are column sums over the same B*T rows: they are collected and reduced by ONE single-pass launch
+    # at the end (ops.colsum_multi) instead of a reduce + finalize pair each.  A gradient that aliases dx (no residual dropout) is summed
+    # right away: dx is updated in place further down.
+    pending = []
+
+    def bias_later(dy2d, b, fresh=True):
+        if fresh and ops.COLSUM_MULTI:
+            pending.append((dy2d, gbuf(b).view(-1)))
+        else:
+            bias_grad(dy2d, b)
+
     # ---- MLP: x_out = x_mid + drop(fc2(relu(fc1(ln2(x_mid)))))
     dres = dx
     if drop and gpt.resid_pdrop > 0:
         dres = ops.dropout(dx, gpt.seed, gpt.site(4 * li + 3), gpt.resid_pdrop)
     lowp = isinstance(a1, A16)      # the forward ran on 16-bit stored operands: so does the backward
     if lowp:
-        bias_grad(dres, fc2.bias)
+        bias_later(dres, fc2.bias, dres is not dx)
         da1 = _lin16_bwd(dres, a1, fc2.weight, gbuf(fc2.weight), mask=a1.f32)     # ReLU backward fused into the dgrad epilogue
-        bias_grad(da1, fc1.bias)
+        bias_later(da1, fc1.bias)
         dh2 = _lin16_bwd(da1, h2, fc1.weight, gbuf(fc1.weight))
     else:
         ops.linear_wgrad(dres, a1, gbuf(fc2.weight))
-        bias_grad(dres, fc2.bias)
+        bias_later(dres, fc2.bias, dres is not dx)
         da1 = ops.linear_dgrad(dres, fc2.weight, mask=a1)     # ReLU backward fused into the dgrad epilogue
         ops.linear_wgrad(da1, h2, gbuf(fc1.weight))
-        bias_grad(da1, fc1.bias)
+        bias_later(da1, fc1.bias)
         dh2 = ops.linear_dgrad(da1, fc1.weight)
     # dx_mid = dx + ln2_bwd(dh2): accumulate in place into dx
     ops.layernorm_bwd(dh2, x_mid, blk.ln2.weight, m2, r2, gbuf(blk.ln2.weight), gbuf(blk.ln2.bias), dx=dx, accumulate=True)
@@ -688,7 +699,7 @@ def _gpt_block_bwd(gpt, li, saved, dx, B, T, drop):
     dres = dx
     if drop and gpt.resid_pdrop > 0:
         dres = ops.dropout(dx, gpt.seed, gpt.site(4 * li + 2), gpt.resid_pdrop)
-    bias_grad(dres, proj.bias)
+    bias_later(dres, proj.bias, dres is not dx)
     if lowp:
         dy = _lin16_bwd(dres, y_att, proj.weight, gbuf(proj.weight))
     else:
@@ -715,7 +726,10 @@ def _gpt_block_bwd(gpt, li, saved, dx, B, T, drop):
                  sa=sp, sb=sq, sc=sq)                                                                                     # dK = dS^T Q
     fw = blk.attn.fused()
     if lowp and fw is not None:
-        ops.colsum(dqkv, 1, B * T, 3 * C, 1.0, out=fw[3].view(1, -1), accumulate=True)
+        if ops.COLSUM_MULTI:
+            pending.append((dqkv, fw[3].view(-1)))
+        else:
+            ops.colsum(dqkv, 1, B * T, 3 * C, 1.0, out=fw[3].view(1, -1), accumulate=True)
         dh1 = _lin16_bwd(dqkv, h1, fw[0], fw[2])
     elif lowp:
         dh1 = None
@@ -726,7 +740,10 @@ def _gpt_block_bwd(gpt, li, saved, dx, B, T, drop):
             ops.axpby(gbuf(l3.bias), b3[0, j * C:(j + 1) * C], 1.0, 1.0, out=gbuf(l3.bias))
     elif fw is not None:
         ops.linear_wgrad(dqkv, h1, fw[2])
-        ops.colsum(dqkv, 1, B * T, 3 * C, 1.0, out=fw[3].view(1, -1), accumulate=True)
+        if ops.COLSUM_MULTI:
+            pending.append((dqkv, fw[3].view(-1)))
+        else:
+            ops.colsum(dqkv, 1, B * T, 3 * C, 1.0, out=fw[3].view(1, -1), accumulate=True)
         dh1 = ops.linear_dgrad(dqkv, fw[0])
     else:
         dh1 = None
@@ -738,6 +755,8 @@ def _gpt_block_bwd(gpt, li, saved, dx, B, T, drop):
         for j, lin in enumerate((blk.attn.key, blk.attn.query, blk.attn.value)):
             ops.axpby(gbuf(lin.bias), b3[0, j * C:(j + 1) * C], 1.0, 1.0, out=gbuf(lin.bias))
     ops.layernorm_bwd(dh1, x, blk.ln1.weight, m1, r1, gbuf(blk.ln1.weight), gbuf(blk.ln1.bias), dx=dx, accumulate=True)
+    if pending:
+        ops.colsum_multi(pending)
     return dx
 
 

@@ -866,6 +866,27 @@ def bn_bwd(dz, z, x, gamma, sm, si, dgamma, dbeta, want_dres=False):
     return dx, dres
 
 
+COLSUM_MULTI = os.environ.get("TF_COLSUM_MULTI", "1") != "0"      # the Block's bias gradients in one launch (A/B switch)
+
+
+def colsum_multi(pairs):
+    """out += x.sum(0) for every (x (rows, C) row-major view, out (C,)) pair in ONE launch (same row count; the bias gradients of a Block).
+    Falls back to one colsum per pair when a matrix does not meet the vector layout (C % 4, 16-byte alignment)."""
+    rows = pairs[0][0].shape[0]
+    ok = 1 <= len(pairs) <= 8 and all(x.dim() == 2 and x.shape[0] == rows and x.stride(1) == 1 and x.shape[1] % 4 == 0 and x.stride(0) % 4 == 0 and
+                                      x.data_ptr() % 16 == 0 and o.is_contiguous() and o.numel() == x.shape[1] for x, o in pairs)
+    if not ok:
+        for x, o in pairs:
+            colsum(x.contiguous(), 1, rows, x.shape[1], 1.0, out=o.view(1, -1), accumulate=True)
+        return
+    n = len(pairs)
+    xs = (ctypes.c_void_p * n)(*[x.data_ptr() for x, _ in pairs])
+    outs = (ctypes.c_void_p * n)(*[o.data_ptr() for _, o in pairs])
+    Cs = (ctypes.c_int * n)(*[x.shape[1] for x, _ in pairs])
+    lds = (ctypes.c_long * n)(*[x.stride(0) for x, _ in pairs])
+    check(L().tf_colsum_multi_f32(n, xs, Cs, lds, outs, rows, stream_of(pairs[0][0])), "tf_colsum_multi_f32")
+
+
 def colsum(x, nseg, rows_per_seg, C, scale=1.0, mask=None, out=None, accumulate=False, pooled=False):
     """pooled=True (internal temporaries only): the result lives in a zero-arena slice and is produced by ONE atomically accumulating
     launch; it is valid until the next LidarCenterNet.forward."""
