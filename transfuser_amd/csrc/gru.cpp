@@ -88,28 +88,40 @@ __global__ void __launch_bounds__(256) gru_wp_bwd_kernel(const float* __restrict
     __shared__ float dgi[GMAXB][3 * GH], dgh[GMAXB][3 * GH];
     __shared__ float dh[GMAXB][GH], dhn[GMAXB][GH];
     __shared__ float dxc[GMAXB][2], dxt[GMAXB][2];
+    __shared__ float hst[2][GMAXB][GH];            // h_t and h_{t-1} of the current step (staged once per step; were re-read from global memory per product term)
     const int tid = threadIdx.x;
     for (int i = tid; i < 3 * GH * GH; i += 256) Whh[i / GH][i % GH] = w_hh[i];
     for (int i = tid; i < 3 * GH * nin; i += 256) Wih[i / nin][i % nin] = w_ih[i];
     for (int i = tid; i < B * GH; i += 256) dh[i / GH][i % GH] = 0.f;
     for (int i = tid; i < B * 2; i += 256) dxc[i / 2][i % 2] = 0.f;
-    __syncthreads();
     const float* hs = cache;
     const float* gates = cache + (long)(P + 1) * B * GH;
     const float* xins = gates + (long)P * B * 4 * GH;
+    for (int i = tid; i < B * GH; i += 256) hst[P & 1][i / GH][i % GH] = hs[(long)P * B * GH + i];
+    __syncthreads();
+    // The parameter gradients are summed over the P steps in REGISTERS (fixed element ownership: thread tid owns elements tid + 256 u) and
+    // added to the global accumulators once at the end - the per-step global read-modify-write of 12 288 + 768 + 512 values made this
+    // single-workgroup kernel 268 us long on the critical path of the step (the summation order over (t, b) is unchanged).
+    constexpr int NHH = 3 * GH * GH / 256, NIH = 3 * GH * GMAXIN / 256;
+    float a_hh[NHH], a_ih[NIH], a_bi = 0.f, a_bh = 0.f, a_wo = 0.f, a_bo = 0.f;
+#pragma unroll
+    for (int u = 0; u < NHH; ++u) a_hh[u] = 0.f;
+#pragma unroll
+    for (int u = 0; u < NIH; ++u) a_ih[u] = 0.f;
     for (int t = P - 1; t >= 0; --t) {
-        const float* ht = hs + (long)(t + 1) * B * GH;   // h_t
-        const float* hp = hs + (long)t * B * GH;         // h_{t-1}
+        float (*ht)[GH] = hst[(t + 1) & 1];          // h_t
+        float (*hp)[GH] = hst[t & 1];                // h_{t-1}
+        for (int i = tid; i < B * GH; i += 256) hp[i / GH][i % GH] = hs[(long)t * B * GH + i];
         for (int i = tid; i < B * 2; i += 256) dxt[i / 2][i % 2] = dxc[i / 2][i % 2] + dwp[((long)(i / 2) * P + t) * 2 + (i % 2)];
         __syncthreads();
         // output layer: x_t = x_{t-1} + (W_out h_t + b_out)[:2]
-        for (int i = tid; i < 2 * GH; i += 256) {
-            const int c = i / GH, k = i % GH;
+        if (tid < 2 * GH) {
+            const int c = tid / GH, k = tid % GH;
             float a = 0.f;
-            for (int b = 0; b < B; ++b) a += dxt[b][c] * ht[b * GH + k];
-            dw_out[c * GH + k] += a;
+            for (int b = 0; b < B; ++b) a += dxt[b][c] * ht[b][k];
+            a_wo += a;
         }
-        if (tid < 2) { float a = 0.f; for (int b = 0; b < B; ++b) a += dxt[b][tid]; db_out[tid] += a; }
+        if (tid >= 254) { const int c = tid - 254; float a = 0.f; for (int b = 0; b < B; ++b) a += dxt[b][c]; a_bo += a; }
         for (int i = tid; i < B * GH; i += 256) {
             const int b = i / GH, k = i % GH;
             dh[b][k] += w_out[k] * dxt[b][0] + w_out[GH + k] * dxt[b][1];
@@ -122,30 +134,33 @@ __global__ void __launch_bounds__(256) gru_wp_bwd_kernel(const float* __restrict
             const float r = gp[0], zz = gp[GH], n = gp[2 * GH], ghn = gp[3 * GH];
             const float g = dh[b][j];
             const float dn = g * (1.f - zz) * (1.f - n * n);
-            const float dzp = g * (hp[b * GH + j] - n) * zz * (1.f - zz);
+            const float dzp = g * (hp[b][j] - n) * zz * (1.f - zz);
             const float drp = dn * ghn * r * (1.f - r);
             dgi[b][j] = drp; dgi[b][GH + j] = dzp; dgi[b][2 * GH + j] = dn;
             dgh[b][j] = drp; dgh[b][GH + j] = dzp; dgh[b][2 * GH + j] = dn * r;
             dhn[b][j] = g * zz;
         }
         __syncthreads();
-        // parameter gradients (single workgroup => plain read-modify-write)
-        for (int i = tid; i < 3 * GH * GH; i += 256) {
-            const int J = i / GH, k = i % GH;
+        // parameter gradients
+#pragma unroll
+        for (int u = 0; u < NHH; ++u) {
+            const int i = tid + 256 * u, J = i / GH, k = i % GH;
             float a = 0.f;
-            for (int b = 0; b < B; ++b) a += dgh[b][J] * hp[b * GH + k];
-            dw_hh[i] += a;
+            for (int b = 0; b < B; ++b) a += dgh[b][J] * hp[b][k];
+            a_hh[u] += a;
         }
-        for (int i = tid; i < 3 * GH * nin; i += 256) {
-            const int J = i / nin, c = i % nin;
+#pragma unroll
+        for (int u = 0; u < NIH; ++u) {
+            const int i = tid + 256 * u, J = i / GMAXIN, c = i % GMAXIN;     // (J, c) over 3 GH x GMAXIN; only c < nin is used
             float a = 0.f;
-            for (int b = 0; b < B; ++b) a += dgi[b][J] * xins[((long)t * B + b) * GMAXIN + c];
-            dw_ih[i] += a;
+            if (c < nin)
+                for (int b = 0; b < B; ++b) a += dgi[b][J] * xins[((long)t * B + b) * GMAXIN + c];
+            a_ih[u] += a;
         }
-        for (int J = tid; J < 3 * GH; J += 256) {
+        if (tid < 3 * GH) {
             float a = 0.f, c = 0.f;
-            for (int b = 0; b < B; ++b) { a += dgi[b][J]; c += dgh[b][J]; }
-            db_ih[J] += a; db_hh[J] += c;
+            for (int b = 0; b < B; ++b) { a += dgi[b][tid]; c += dgh[b][tid]; }
+            a_bi += a; a_bh += c;
         }
         // state gradients
         for (int i = tid; i < B * GH; i += 256) {
@@ -164,6 +179,16 @@ __global__ void __launch_bounds__(256) gru_wp_bwd_kernel(const float* __restrict
         for (int i = tid; i < B * GH; i += 256) dh[i / GH][i % GH] = dhn[i / GH][i % GH];
         __syncthreads();
     }
+#pragma unroll
+    for (int u = 0; u < NHH; ++u) dw_hh[tid + 256 * u] += a_hh[u];
+#pragma unroll
+    for (int u = 0; u < NIH; ++u) {
+        const int i = tid + 256 * u, J = i / GMAXIN, c = i % GMAXIN;
+        if (c < nin) dw_ih[J * nin + c] += a_ih[u];
+    }
+    if (tid < 3 * GH) { db_ih[tid] += a_bi; db_hh[tid] += a_bh; }
+    if (tid < 2 * GH) dw_out[tid] += a_wo;
+    if (tid >= 254) db_out[tid - 254] += a_bo;
     for (int i = tid; i < B * GH; i += 256) dz0[i] = dh[i / GH][i % GH];
 }
 

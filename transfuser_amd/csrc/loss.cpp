@@ -45,10 +45,14 @@ __global__ void __launch_bounds__(256) ce_fwd_kernel(const float* __restrict__ l
     ws = block_sum<4>(ws, red);
     if (threadIdx.x == 0) { partial[blockIdx.x * 2] = ls; partial[blockIdx.x * 2 + 1] = ws; }
 }
+// one wave: the lanes stride over the block partials, then a shuffle tree (fixed order; a single thread walking ~1800 partials was a 61 us
+// chain of dependent loads on the critical path between the forward and the backward pass)
 __global__ void ce_finalize_kernel(const float* __restrict__ partial, int nb, float* __restrict__ loss, float* __restrict__ inv_wsum) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        float a = 0.f, b = 0.f;
-        for (int i = 0; i < nb; ++i) { a += partial[i * 2]; b += partial[i * 2 + 1]; }
+    float a = 0.f, b = 0.f;
+    for (int i = threadIdx.x; i < nb; i += 64) { a += partial[i * 2]; b += partial[i * 2 + 1]; }
+    a = wave_sum(a);
+    b = wave_sum(b);
+    if (threadIdx.x == 0) {
         *loss = a / b;
         *inv_wsum = 1.f / b;
     }
@@ -72,11 +76,10 @@ __global__ void __launch_bounds__(256) l1_fwd_kernel(const float* __restrict__ p
     if (threadIdx.x == 0) partial[blockIdx.x] = ls;
 }
 __global__ void l1_finalize_kernel(const float* __restrict__ partial, int nb, float invn, float* __restrict__ loss) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        float a = 0.f;
-        for (int i = 0; i < nb; ++i) a += partial[i];
-        *loss = a * invn;
-    }
+    float a = 0.f;
+    for (int i = threadIdx.x; i < nb; i += 64) a += partial[i];
+    a = wave_sum(a);
+    if (threadIdx.x == 0) *loss = a * invn;
 }
 
 // x *= (*a) * (*b) * mult   (a, b optional device scalars)
@@ -195,7 +198,12 @@ __global__ void __launch_bounds__(256) centernet_loss_kernel(const float* __rest
     float g[7];
 #pragma unroll
     for (int k = 0; k < 7; ++k) g[k] = (BWD && gup) ? gup[k] : 1.f;
-    for (int cell = blockIdx.x * 256 + threadIdx.x; cell < cells; cell += gridDim.x * 256) {
+    // forward: a thread owns a cell and walks the batch (the partial sums stay in registers).  backward: a thread owns ONE (sample, cell) pair -
+    // B x more threads, each re-deriving the cell's batch weight sum: the 10-sample walk of 21-channel rows per thread was a 76 us latency chain
+    const int nwork = BWD ? cells * B : cells;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < nwork; idx += gridDim.x * 256) {
+        const int cell = BWD ? idx % cells : idx;
+        const int b_lo = BWD ? idx / cells : 0, b_hi = BWD ? b_lo + 1 : B;
         // pass 1: per-cell sums over the batch for the broadcast quirk
         float wsum = 0.f, ce_y = 0.f, ce_b = 0.f;
         for (int b = 0; b < B; ++b) {
@@ -215,7 +223,7 @@ __global__ void __launch_bounds__(256) centernet_loss_kernel(const float* __rest
             }
         }
         if (!BWD) { acc[3] += ce_y * wsum; acc[6] += ce_b * wsum; }
-        for (int b = 0; b < B; ++b) {
+        for (int b = b_lo; b < b_hi; ++b) {
             const long o = (long)b * cells + cell;
             const float* p = pred + o * P;
             const float* t = tgtf + o * 8;
@@ -337,7 +345,7 @@ extern "C" int tf_centernet_loss_fwd_f32(const float* pred, const float* tgtf, c
 extern "C" int tf_centernet_loss_bwd_f32(const float* pred, const float* tgtf, const int32_t* tgti, const int32_t* cnt, const float* gup, int B, int fh,
                                          int fw, int num_dir_bins, float* dpred, void* stream) {
     TF_REQUIRE(pred && tgtf && tgti && cnt && dpred && B > 0 && num_dir_bins <= CN_MAXBINS, "tf_centernet_loss_bwd_f32: bad arguments");
-    const int nb = nblocks((long)fh * fw, 256);
+    const int nb = nblocks((long)fh * fw * B, 1024);
     TF_LAUNCH(centernet_loss_kernel<true>, dim3(nb), dim3(256), stream, pred, tgtf, tgti, cnt, B, fh, fw, num_dir_bins, (float*)nullptr, gup, dpred);
     return launch_status("tf_centernet_loss_bwd_f32");
 }

@@ -76,13 +76,24 @@ __global__ void __launch_bounds__(256) pool_tokens_bwd_kernel(const float* __res
                 if (w < w0 || w >= w1) continue;
                 const float inv = 1.0f / (float)((h1 - h0) * (w1 - w0));
                 const float* g = dtok + ((long)b * T_total + tok_off + i * ow + j) * C + c;
+                if (V == 4) {
+                    const float4 v = *reinterpret_cast<const float4*>(g);
+                    acc[0] += v.x * inv; acc[1 % V] += v.y * inv; acc[2 % V] += v.z * inv; acc[3 % V] += v.w * inv;
+                } else {
 #pragma unroll
-                for (int k = 0; k < V; ++k) acc[k] += g[k] * inv;
+                    for (int k = 0; k < V; ++k) acc[k] += g[k] * inv;
+                }
             }
         }
         float* o = dx + idx * V;
+        if (V == 4) {
+            float4 r = make_float4(acc[0], acc[1 % V], acc[2 % V], acc[3 % V]);
+            if (add) { const float4 a = *reinterpret_cast<const float4*>(add + idx * V); r.x += a.x; r.y += a.y; r.z += a.z; r.w += a.w; }
+            *reinterpret_cast<float4*>(o) = r;
+        } else {
 #pragma unroll
-        for (int k = 0; k < V; ++k) o[k] = add ? add[idx * V + k] + acc[k] : acc[k];
+            for (int k = 0; k < V; ++k) o[k] = add ? add[idx * V + k] + acc[k] : acc[k];
+        }
     }
 }
 
@@ -268,6 +279,81 @@ __global__ void __launch_bounds__(256) bilinear_bwd_kernel(tf_bilinear_desc d, c
     }
 }
 
+// The same gather for SMALL inputs (the GPT stages' 8 x 22 / 8 x 8 token maps up-sampled 8x / 4x: 12 672 input elements that each walk ~20 x 20
+// candidate output pixels - 50 workgroups of 400-step threads took 193 us): R = 8 adjacent lanes share one input element, lane r takes the
+// candidate rows ho_lo + r, + R, ..., the column weights are computed once per thread, and the R partial sums are combined by a fixed shuffle
+// tree (deterministic).  Channel-fastest element order as in bilinear_bwd_kernel: a wave reads 8 consecutive channels of 8 rows per load.
+template <int R>
+__global__ void __launch_bounds__(256) bilinear_bwd_split_kernel(tf_bilinear_desc d, const float* __restrict__ dy, float* __restrict__ dx, float sh,
+                                                                 float sw, int accumulate) {
+    const long total = (long)d.B * d.Hi * d.Wi * d.C;
+    const long nthreads = (total * R + 255) / 256 * 256;               // whole blocks: every lane takes part in the shuffles
+    for (long tidx = (long)blockIdx.x * 256 + threadIdx.x; tidx < nthreads; tidx += (long)gridDim.x * 256) {
+        const long idx = tidx / R;
+        const int r = (int)(tidx % R);
+        const bool live = idx < total;
+        const long e = live ? idx : 0;
+        const int c = (int)(e % d.C);
+        long t = e / d.C;
+        const int wi = (int)(t % d.Wi); t /= d.Wi;
+        const int hi = (int)(t % d.Hi);
+        const int b = (int)(t / d.Hi);
+        int ho_lo, ho_hi, wo_lo, wo_hi;
+        {
+            const float inv = 1.0f / sh;
+            const float lo = d.align_corners ? ((float)hi - 1.f) * inv : ((float)hi - 1.f + 0.5f) * inv - 0.5f;
+            const float hi_ = d.align_corners ? ((float)hi + 1.f) * inv : ((float)hi + 1.f + 0.5f) * inv - 0.5f;
+            ho_lo = (int)floorf(lo) - 1; ho_hi = (int)ceilf(hi_) + 1;
+            if (ho_lo < 0) ho_lo = 0;
+            if (ho_hi > d.Ho - 1) ho_hi = d.Ho - 1;
+        }
+        {
+            const float inv = 1.0f / sw;
+            const float lo = d.align_corners ? ((float)wi - 1.f) * inv : ((float)wi - 1.f + 0.5f) * inv - 0.5f;
+            const float hi_ = d.align_corners ? ((float)wi + 1.f) * inv : ((float)wi + 1.f + 0.5f) * inv - 0.5f;
+            wo_lo = (int)floorf(lo) - 1; wo_hi = (int)ceilf(hi_) + 1;
+            if (wo_lo < 0) wo_lo = 0;
+            if (wo_hi > d.Wo - 1) wo_hi = d.Wo - 1;
+        }
+        float ww[kBlMaxCand];
+#pragma unroll
+        for (int j = 0; j < kBlMaxCand; ++j) {
+            const int wo = wo_lo + j;
+            float w = 0.f;
+            if (wo <= wo_hi) {
+                int w0, w1; float m0, m1;
+                bl_src(wo, sw, d.align_corners, d.Wi, w0, w1, m0, m1);
+                if (w0 == wi) w += m0;
+                if (w1 == wi) w += m1;
+            }
+            ww[j] = w;
+        }
+        const float* g = dy + b * d.sb_o + c * d.sc_o;
+        float acc = 0.f;
+        if (live)
+            for (int ho = ho_lo + r; ho <= ho_hi; ho += R) {
+                int h0, h1; float l0, l1;
+                bl_src(ho, sh, d.align_corners, d.Hi, h0, h1, l0, l1);
+                float wh = 0.f;
+                if (h0 == hi) wh += l0;
+                if (h1 == hi) wh += l1;
+                if (wh == 0.f) continue;
+                const float* grow = g + ho * d.sh_o + wo_lo * d.sw_o;
+                float rowacc = 0.f;
+#pragma unroll
+                for (int j = 0; j < kBlMaxCand; ++j)
+                    if (ww[j] != 0.f) rowacc += ww[j] * grow[j * d.sw_o];
+                acc += wh * rowacc;
+            }
+#pragma unroll
+        for (int m = R / 2; m >= 1; m >>= 1) acc += shfl_xor(acc, m);
+        if (live && r == 0) {
+            const long io = b * d.sb_i + c * d.sc_i + hi * d.sh_i + wi * d.sw_i;
+            dx[io] = accumulate ? dx[io] + acc : acc;
+        }
+    }
+}
+
 inline int ew_blocks(long n) {
     long b = (n + 255) / 256;
     if (b > 8192) b = 8192;
@@ -352,7 +438,12 @@ extern "C" int tf_pool_tokens_bwd_f32(const float* dtok, int B, int H, int W, in
                                       const float* add, void* stream) {
     TF_REQUIRE(dtok && dx && B > 0 && H > 0 && W > 0 && C > 0 && oh > 0 && ow > 0 && tok_off + oh * ow <= T_total, "tf_pool_tokens_bwd_f32: bad arguments");
     const long n = (long)B * H * W * C;
-    TF_LAUNCH(pool_tokens_bwd_kernel<1>, dim3(ew_blocks(n)), dim3(256), stream, dtok, B, H, W, C, oh, ow, T_total, tok_off, dx, add);
+    // one thread per 4 channels where the layout allows (the scalar form spent ~100 integer operations of window arithmetic per ELEMENT: 104 us for
+    // the 64 x 176 x 72 map against a 20 us copy)
+    if (C % 4 == 0 && aligned16(dtok) && aligned16(dx) && (!add || aligned16(add)))
+        TF_LAUNCH(pool_tokens_bwd_kernel<4>, dim3(ew_blocks(n / 4)), dim3(256), stream, dtok, B, H, W, C, oh, ow, T_total, tok_off, dx, add);
+    else
+        TF_LAUNCH(pool_tokens_bwd_kernel<1>, dim3(ew_blocks(n)), dim3(256), stream, dtok, B, H, W, C, oh, ow, T_total, tok_off, dx, add);
     return launch_status("tf_pool_tokens_bwd_f32");
 }
 
@@ -383,8 +474,13 @@ extern "C" int tf_bilinear_bwd_f32(const tf_bilinear_desc* d, const float* dy, f
         TF_LAUNCH(bilinear_bwd_v4_kernel, dim3(ew_blocks(n / 4)), dim3(256), stream, *d, dy, dx, bsh, bsw, accumulate);
         return launch_status("tf_bilinear_bwd_f32");
     }
+    const bool c_fastest = d->sc_i == 1 || d->sc_o == 1;
+    if (fits && c_fastest && n <= (1L << 20) && bsh > 0.f && bsh <= 0.5f) {          // few input elements, each gathering >= 4 x 4 outputs: split the rows
+        TF_LAUNCH(bilinear_bwd_split_kernel<8>, dim3(ew_blocks(n * 8)), dim3(256), stream, *d, dy, dx, bsh, bsw, accumulate);
+        return launch_status("tf_bilinear_bwd_f32");
+    }
     TF_LAUNCH(bilinear_bwd_kernel, dim3(ew_blocks(n)), dim3(256), stream, *d, dy, dx, bl_scale(d->Hi, d->Ho, d->align_corners),
-              bl_scale(d->Wi, d->Wo, d->align_corners), accumulate, (d->sc_i == 1 || d->sc_o == 1) ? 1 : 0);   // channel-fastest threads whenever dY is NHWC:
+              bl_scale(d->Wi, d->Wo, d->align_corners), accumulate, c_fastest ? 1 : 0);   // channel-fastest threads whenever dY is NHWC:
               // an input element gathers ~(scale + 2)^2 dY values but is written once, so the READS must coalesce (the GPT stages' raw-view
               // layout, sc_i = ih * iw, ran pixel-fastest: 4-byte reads at stride C, 256 us for the 64 x 176 x 72 map)
     return launch_status("tf_bilinear_bwd_f32");
