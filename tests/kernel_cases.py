@@ -450,6 +450,20 @@ def check_fused_finalize(dev):
     assert int(ops.workspace(xb.device)[-4096:].view(torch.int32).abs().max()) == 0
 
 
+def check_skinny_wgrad(dev):
+    """Weight gradients with few output features over many rows (the 1x1 head convolutions, model.py:93-99) take the streaming kernel:
+    dW += dY^T X for 1..16 output features, ragged row counts, strided dY; shapes outside its envelope keep the engine path."""
+    for (rows, no, C) in [(40960, 1, 64), (40960, 2, 64), (5000, 3, 64), (4099, 12, 64), (8192, 16, 256), (4500, 5, 72), (4096, 7, 16)]:
+        dyb = R(rows, no + 3, dev=dev)
+        dy = dyb[:, 1:1 + no]                       # row stride > no
+        x = R(rows, C, seed=1, dev=dev)
+        dw0 = R(no, C, seed=2, dev=dev)
+        dw = dw0.clone()
+        ops.gemm(dy, x, dw, no, C, rows, dyb.stride(0), x.stride(0), dw.stride(0), a_trans=True, b_trans=True, accumulate=True)
+        want = dw0.double() + dy.double().t() @ x.double()
+        close(dw, want, tol=3e-5, what="skinny wgrad %s" % ((rows, no, C),))
+
+
 def check_colsum_multi(dev):
     """Several column sums over the same rows in one single-pass launch (the bias gradients of a transformer Block): ragged strips (C % 32 != 0),
     strided views, accumulation into non-zero destinations, bitwise reproducible; the non-vector layout falls back to colsum."""
@@ -507,7 +521,7 @@ BILINEAR_CASES = [(2, 12, 5, 22, 40, 176, False, False), (2, 8, 8, 8, 64, 64, Fa
                   (2, 4, 8, 8, 16, 16, True, False), (1, 3, 16, 16, 40, 40, True, True), (2, 8, 5, 22, 5, 22, False, False),
                   (1, 5, 8, 22, 16, 44, False, False), (2, 6, 5, 22, 1, 2, False, False), (1, 4, 9, 7, 4, 5, True, True),
                   (2, 8, 8, 22, 64, 176, True, False), (1, 32, 16, 44, 64, 176, True, False), (2, 8, 5, 22, 40, 176, True, False),
-                  (1, 12, 16, 16, 40, 40, True, True), (2, 4, 3, 5, 30, 50, True, False)]
+                  (1, 12, 16, 16, 40, 40, True, True), (2, 4, 3, 5, 30, 50, True, False), (1, 6, 8, 22, 32, 88, False, False), (2, 10, 8, 8, 32, 32, False, False)]
 
 
 def check_bilinear(dev, B, C, Hi, Wi, Ho, Wo, in_nhwc, align):

@@ -72,6 +72,10 @@ def test_reduce_with_fused_finalize():
     assert r.returncode == 0 and "fused finalize ok" in r.stdout, r.stdout + r.stderr
 
 
+def test_skinny_wgrad():
+    kc.check_skinny_wgrad("cpu")
+
+
 def test_colsum_multi():
     kc.check_colsum_multi("cpu")
 

@@ -18,6 +18,8 @@ int smallm_fwd(const float* x, long ldx, const float* w, long ldw, const float* 
 int smallm_dgrad(const float* dy, long lddy, const float* w, long ldw, const float* res, long ldres, float* dx, long lddx, int M, int N, int K,
                  int accumulate, void* stream);
 int smallm_wgrad(const float* dy, long lddy, const float* x, long ldx, float* dw, long lddw, int M, int N, int K, int accumulate, void* stream);
+bool skinny_wgrad_ok(int no, int C, int rows, long lddy, long ldx, const float* x, int accumulate);
+int skinny_wgrad(const float* dy, long lddy, const float* x, long ldx, float* dw, long lddw, int rows, int no, int C, void* stream);
 }
 
 static PlainOp make_plain(const float* p, long ld, int rows, int cols, long so, long si, int inner, int batch) {
@@ -59,6 +61,11 @@ extern "C" int tf_gemm_f32(const tf_gemm_desc* d, void* stream) {
             return smallm_dgrad(d->a, d->lda, d->b, d->ldb, d->res, d->ldres, d->c, d->ldc, d->m, d->k, d->n, d->accumulate, stream);
         if (d->a_trans && d->b_trans && d->k <= 16 && !d->bias && !d->res && !d->relu)
             return smallm_wgrad(d->a, d->lda, d->b, d->ldb, d->c, d->ldc, d->k, d->m, d->n, d->accumulate, stream);
+        // few output features over many rows (head convolutions 64 -> 1 / 2 / 3 / 12): streaming reduction instead of a 160-way split 128 x 32 tile
+        static const bool skinny = [] { const char* e = getenv("TF_SKINNY_WGRAD"); return e ? e[0] != '0' : true; }();
+        if (skinny && d->a_trans && d->b_trans && !d->bias && !d->res && !d->relu && (gemm_precision() == 0 || gemm_precision() == 2) &&
+            skinny_wgrad_ok(d->m, d->n, d->k, d->lda, d->ldb, d->b, d->accumulate))
+            return skinny_wgrad(d->a, d->lda, d->b, d->ldb, d->c, d->ldc, d->k, d->m, d->n, stream);
     }
     GemmEpi ep;
     ep.C = d->c; ep.ldc = d->ldc; ep.ldcj = 1; ep.sc_outer = d->sc_outer; ep.sc_inner = d->sc_inner; ep.inner = inner;

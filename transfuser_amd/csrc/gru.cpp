@@ -77,8 +77,9 @@ __global__ void __launch_bounds__(256) gru_wp_fwd_kernel(const float* __restrict
     }
 }
 
+constexpr int GBT = 1024;     // backward workgroup: 16 waves hide the LDS latency of the per-step matrix products (4 waves: 175 us, LDS-latency bound)
 // Gradients of every GRU / output parameter are accumulated (+=) into the given buffers; dz0 is written.
-__global__ void __launch_bounds__(256) gru_wp_bwd_kernel(const float* __restrict__ dwp, const float* __restrict__ cache, const float* __restrict__ w_ih,
+__global__ void __launch_bounds__(GBT) gru_wp_bwd_kernel(const float* __restrict__ dwp, const float* __restrict__ cache, const float* __restrict__ w_ih,
                                                          const float* __restrict__ w_hh, const float* __restrict__ w_out, int B, int P, int nin,
                                                          float* __restrict__ dz0, float* __restrict__ dw_ih, float* __restrict__ dw_hh,
                                                          float* __restrict__ db_ih, float* __restrict__ db_hh, float* __restrict__ dw_out,
@@ -90,19 +91,20 @@ __global__ void __launch_bounds__(256) gru_wp_bwd_kernel(const float* __restrict
     __shared__ float dxc[GMAXB][2], dxt[GMAXB][2];
     __shared__ float hst[2][GMAXB][GH];            // h_t and h_{t-1} of the current step (staged once per step; were re-read from global memory per product term)
     const int tid = threadIdx.x;
-    for (int i = tid; i < 3 * GH * GH; i += 256) Whh[i / GH][i % GH] = w_hh[i];
-    for (int i = tid; i < 3 * GH * nin; i += 256) Wih[i / nin][i % nin] = w_ih[i];
-    for (int i = tid; i < B * GH; i += 256) dh[i / GH][i % GH] = 0.f;
-    for (int i = tid; i < B * 2; i += 256) dxc[i / 2][i % 2] = 0.f;
+    for (int i = tid; i < 3 * GH * GH; i += GBT) Whh[i / GH][i % GH] = w_hh[i];
+    for (int i = tid; i < 3 * GH * nin; i += GBT) Wih[i / nin][i % nin] = w_ih[i];
+    for (int i = tid; i < B * GH; i += GBT) dh[i / GH][i % GH] = 0.f;
+    for (int i = tid; i < B * 2; i += GBT) dxc[i / 2][i % 2] = 0.f;
     const float* hs = cache;
     const float* gates = cache + (long)(P + 1) * B * GH;
     const float* xins = gates + (long)P * B * 4 * GH;
-    for (int i = tid; i < B * GH; i += 256) hst[P & 1][i / GH][i % GH] = hs[(long)P * B * GH + i];
+    for (int i = tid; i < B * GH; i += GBT) hst[P & 1][i / GH][i % GH] = hs[(long)P * B * GH + i];
     __syncthreads();
-    // The parameter gradients are summed over the P steps in REGISTERS (fixed element ownership: thread tid owns elements tid + 256 u) and
+    // The parameter gradients are summed over the P steps in REGISTERS (fixed element ownership: thread tid owns elements tid + GBT u) and
     // added to the global accumulators once at the end - the per-step global read-modify-write of 12 288 + 768 + 512 values made this
     // single-workgroup kernel 268 us long on the critical path of the step (the summation order over (t, b) is unchanged).
-    constexpr int NHH = 3 * GH * GH / 256, NIH = 3 * GH * GMAXIN / 256;
+    constexpr int NHH = 3 * GH * GH / GBT, NIH = (3 * GH * GMAXIN + GBT - 1) / GBT;
+    static_assert(3 * GH * GH % GBT == 0, "dW_hh elements per thread");
     float a_hh[NHH], a_ih[NIH], a_bi = 0.f, a_bh = 0.f, a_wo = 0.f, a_bo = 0.f;
 #pragma unroll
     for (int u = 0; u < NHH; ++u) a_hh[u] = 0.f;
@@ -111,8 +113,8 @@ __global__ void __launch_bounds__(256) gru_wp_bwd_kernel(const float* __restrict
     for (int t = P - 1; t >= 0; --t) {
         float (*ht)[GH] = hst[(t + 1) & 1];          // h_t
         float (*hp)[GH] = hst[t & 1];                // h_{t-1}
-        for (int i = tid; i < B * GH; i += 256) hp[i / GH][i % GH] = hs[(long)t * B * GH + i];
-        for (int i = tid; i < B * 2; i += 256) dxt[i / 2][i % 2] = dxc[i / 2][i % 2] + dwp[((long)(i / 2) * P + t) * 2 + (i % 2)];
+        for (int i = tid; i < B * GH; i += GBT) hp[i / GH][i % GH] = hs[(long)t * B * GH + i];
+        for (int i = tid; i < B * 2; i += GBT) dxt[i / 2][i % 2] = dxc[i / 2][i % 2] + dwp[((long)(i / 2) * P + t) * 2 + (i % 2)];
         __syncthreads();
         // output layer: x_t = x_{t-1} + (W_out h_t + b_out)[:2]
         if (tid < 2 * GH) {
@@ -121,14 +123,14 @@ __global__ void __launch_bounds__(256) gru_wp_bwd_kernel(const float* __restrict
             for (int b = 0; b < B; ++b) a += dxt[b][c] * ht[b][k];
             a_wo += a;
         }
-        if (tid >= 254) { const int c = tid - 254; float a = 0.f; for (int b = 0; b < B; ++b) a += dxt[b][c]; a_bo += a; }
-        for (int i = tid; i < B * GH; i += 256) {
+        if (tid >= GBT - 2) { const int c = tid - (GBT - 2); float a = 0.f; for (int b = 0; b < B; ++b) a += dxt[b][c]; a_bo += a; }
+        for (int i = tid; i < B * GH; i += GBT) {
             const int b = i / GH, k = i % GH;
             dh[b][k] += w_out[k] * dxt[b][0] + w_out[GH + k] * dxt[b][1];
         }
         __syncthreads();
         // gates
-        for (int i = tid; i < B * GH; i += 256) {
+        for (int i = tid; i < B * GH; i += GBT) {
             const int b = i / GH, j = i % GH;
             const float* gp = gates + (((long)t * B + b) * 4) * GH + j;
             const float r = gp[0], zz = gp[GH], n = gp[2 * GH], ghn = gp[3 * GH];
@@ -144,16 +146,16 @@ __global__ void __launch_bounds__(256) gru_wp_bwd_kernel(const float* __restrict
         // parameter gradients
 #pragma unroll
         for (int u = 0; u < NHH; ++u) {
-            const int i = tid + 256 * u, J = i / GH, k = i % GH;
+            const int i = tid + GBT * u, J = i / GH, k = i % GH;
             float a = 0.f;
             for (int b = 0; b < B; ++b) a += dgh[b][J] * hp[b][k];
             a_hh[u] += a;
         }
 #pragma unroll
         for (int u = 0; u < NIH; ++u) {
-            const int i = tid + 256 * u, J = i / GMAXIN, c = i % GMAXIN;     // (J, c) over 3 GH x GMAXIN; only c < nin is used
+            const int i = tid + GBT * u, J = i / GMAXIN, c = i % GMAXIN;     // (J, c) over 3 GH x GMAXIN; only c < nin is used
             float a = 0.f;
-            if (c < nin)
+            if (c < nin && J < 3 * GH)
                 for (int b = 0; b < B; ++b) a += dgi[b][J] * xins[((long)t * B + b) * GMAXIN + c];
             a_ih[u] += a;
         }
@@ -163,33 +165,33 @@ __global__ void __launch_bounds__(256) gru_wp_bwd_kernel(const float* __restrict
             a_bi += a; a_bh += c;
         }
         // state gradients
-        for (int i = tid; i < B * GH; i += 256) {
+        for (int i = tid; i < B * GH; i += GBT) {
             const int b = i / GH, k = i % GH;
             float a = dhn[b][k];
             for (int J = 0; J < 3 * GH; ++J) a += Whh[J][k] * dgh[b][J];
             dhn[b][k] = a;
         }
-        for (int i = tid; i < B * 2; i += 256) {
+        for (int i = tid; i < B * 2; i += GBT) {
             const int b = i / 2, c = i % 2;
             float a = dxt[b][c];
             for (int J = 0; J < 3 * GH; ++J) a += Wih[J][c] * dgi[b][J];
             dxc[b][c] = a;
         }
         __syncthreads();
-        for (int i = tid; i < B * GH; i += 256) dh[i / GH][i % GH] = dhn[i / GH][i % GH];
+        for (int i = tid; i < B * GH; i += GBT) dh[i / GH][i % GH] = dhn[i / GH][i % GH];
         __syncthreads();
     }
 #pragma unroll
-    for (int u = 0; u < NHH; ++u) dw_hh[tid + 256 * u] += a_hh[u];
+    for (int u = 0; u < NHH; ++u) dw_hh[tid + GBT * u] += a_hh[u];
 #pragma unroll
     for (int u = 0; u < NIH; ++u) {
-        const int i = tid + 256 * u, J = i / GMAXIN, c = i % GMAXIN;
-        if (c < nin) dw_ih[J * nin + c] += a_ih[u];
+        const int i = tid + GBT * u, J = i / GMAXIN, c = i % GMAXIN;
+        if (c < nin && J < 3 * GH) dw_ih[J * nin + c] += a_ih[u];
     }
     if (tid < 3 * GH) { db_ih[tid] += a_bi; db_hh[tid] += a_bh; }
     if (tid < 2 * GH) dw_out[tid] += a_wo;
-    if (tid >= 254) db_out[tid - 254] += a_bo;
-    for (int i = tid; i < B * GH; i += 256) dz0[i] = dh[i / GH][i % GH];
+    if (tid >= GBT - 2) db_out[tid - (GBT - 2)] += a_bo;
+    for (int i = tid; i < B * GH; i += GBT) dz0[i] = dh[i / GH][i % GH];
 }
 
 }  // namespace
@@ -211,6 +213,6 @@ extern "C" int tf_gru_waypoints_bwd_f32(const float* dwp, const float* cache, co
                                         float* dw_out, float* db_out, void* stream) {
     TF_REQUIRE(dwp && cache && w_ih && w_hh && w_out && dz0 && dw_ih && dw_hh && db_ih && db_hh && dw_out && db_out, "tf_gru_waypoints_bwd_f32: null argument");
     TF_REQUIRE(hidden == GH && B >= 1 && B <= GMAXB && (nin == 2 || nin == 4), "tf_gru_waypoints_bwd_f32: unsupported shape");
-    TF_LAUNCH(gru_wp_bwd_kernel, dim3(1), dim3(256), stream, dwp, cache, w_ih, w_hh, w_out, B, pred_len, nin, dz0, dw_ih, dw_hh, db_ih, db_hh, dw_out, db_out);
+    TF_LAUNCH(gru_wp_bwd_kernel, dim3(1), dim3(GBT), stream, dwp, cache, w_ih, w_hh, w_out, B, pred_len, nin, dz0, dw_ih, dw_hh, db_ih, db_hh, dw_out, db_out);
     return launch_status("tf_gru_waypoints_bwd_f32");
 }

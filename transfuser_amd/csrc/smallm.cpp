@@ -94,6 +94,82 @@ __global__ void __launch_bounds__(256) smallm_wgrad_kernel(const float* __restri
     }
 }
 
+// ---- "skinny" weight gradient: few output features over MANY rows (the 1x1 head convolutions 64 -> 1 / 2 / 3 / 12 over B * 64 * 64
+// pixels, model.py:93-99: 10 MB of operands).  Through the MFMA engine this is one 128 x 32 tile split 160 ways over K = 47 us per head,
+// six heads per step; here it is a streaming reduction: a block walks a row chunk, thread (tx, ty) holds dW[0..NO)[4 tx .. 4 tx + 3] for the rows
+// ty, ty + RL, ...; the row lanes are combined through LDS and the block adds its partial to dW with fp32 atomics (as the engine's split-K
+// weight gradients do).  dw[o][c] += sum_r dy[r][o] * x[r][c];  C % 4 == 0, C <= 256, NO <= 16.
+template <int NO>
+__global__ void __launch_bounds__(256) skinny_wgrad_kernel(const float* __restrict__ dy, long lddy, const float* __restrict__ x, long ldx, float* __restrict__ dw,
+                                                           long lddw, int rows, int no, int C, int rows_per_block) {
+    __shared__ float4 red[256];
+    const int cv = C >> 2, RL = 256 / cv;
+    const int tx = threadIdx.x % cv, ty = threadIdx.x / cv;
+    const int r0 = blockIdx.x * rows_per_block;
+    int r1 = r0 + rows_per_block;
+    if (r1 > rows) r1 = rows;
+    float4 acc[NO];
+#pragma unroll
+    for (int o = 0; o < NO; ++o) acc[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ty < RL) {
+        int r = r0 + ty;
+        for (; r + 3 * RL < r1; r += 4 * RL) {          // four rows in flight per thread
+            float4 xv[4];
+            float dv[4][NO];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                xv[u] = *reinterpret_cast<const float4*>(x + (long)(r + u * RL) * ldx + 4 * tx);
+                const float* g = dy + (long)(r + u * RL) * lddy;
+#pragma unroll
+                for (int o = 0; o < NO; ++o) dv[u][o] = g[o < no ? o : 0];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int o = 0; o < NO; ++o) {
+                    const float d = dv[u][o];
+                    acc[o].x += d * xv[u].x; acc[o].y += d * xv[u].y; acc[o].z += d * xv[u].z; acc[o].w += d * xv[u].w;
+                }
+        }
+        for (; r < r1; r += RL) {
+            const float4 xv = *reinterpret_cast<const float4*>(x + (long)r * ldx + 4 * tx);
+            const float* g = dy + (long)r * lddy;
+#pragma unroll
+            for (int o = 0; o < NO; ++o) {
+                const float d = g[o < no ? o : 0];
+                acc[o].x += d * xv.x; acc[o].y += d * xv.y; acc[o].z += d * xv.z; acc[o].w += d * xv.w;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < NO; ++o) {
+        __syncthreads();
+        red[threadIdx.x] = acc[o];
+        __syncthreads();
+        if (ty == 0 && o < no) {
+            float4 t = red[tx];
+            for (int j = 1; j < RL; ++j) { const float4 v = red[j * cv + tx]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+            float* d = dw + (long)o * lddw + 4 * tx;
+            atomicAdd(d, t.x); atomicAdd(d + 1, t.y); atomicAdd(d + 2, t.z); atomicAdd(d + 3, t.w);
+        }
+    }
+}
+bool skinny_wgrad_ok(int no, int C, int rows, long lddy, long ldx, const float* x, int accumulate) {
+    return accumulate && no >= 1 && no <= 16 && C % 4 == 0 && C >= 16 && C <= 256 && rows >= 4096 && ldx % 4 == 0 && aligned16(x) && lddy >= no;
+}
+int skinny_wgrad(const float* dy, long lddy, const float* x, long ldx, float* dw, long lddw, int rows, int no, int C, void* stream) {
+    // every block ends with NO x C atomics on the SAME addresses, which the memory side serialises (320 blocks: 36 us, mostly that queue):
+    // few, fat blocks
+    int blocks = cdiv(rows, 512);
+    if (blocks > 96) blocks = 96;
+    const int rpb = cdiv(rows, blocks);
+    blocks = cdiv(rows, rpb);
+#define TF_SK(NO_) TF_LAUNCH(skinny_wgrad_kernel<NO_>, dim3(blocks), dim3(256), stream, dy, lddy, x, ldx, dw, lddw, rows, no, C, rpb)
+    if (no <= 1) TF_SK(1); else if (no <= 2) TF_SK(2); else if (no <= 4) TF_SK(4); else if (no <= 8) TF_SK(8); else TF_SK(16);
+#undef TF_SK
+    return launch_status("tf_gemm_f32[skinny wgrad]");
+}
+
 int smallm_fwd(const float* x, long ldx, const float* w, long ldw, const float* bias, const float* res, long ldres, float* y, long ldy, int M, int N,
                int K, int relu, void* stream) {
     TF_LAUNCH(smallm_fwd_kernel, dim3(cdiv(N, 4)), dim3(256), stream, x, ldx, w, ldw, bias, res, ldres, y, ldy, M, N, K, relu);

@@ -210,13 +210,21 @@ __global__ void __launch_bounds__(256) bilinear_bwd_v4_kernel(tf_bilinear_desc d
             if (h0 == hi) wh += l0;
             if (h1 == hi) wh += l1;
             if (wh == 0.f) continue;
-            const float* grow = g + ho * d.sh_o + wo_lo * d.sw_o;
+            // UNCONDITIONAL loads from clamped addresses, 8 in flight, the weight test applied to the VALUE: a load under `if (w != 0)` makes
+            // hipcc wait for every single one (the 24-candidate walk was a chain of dependent ~1 us loads)
+            const float* grow = g + ho * d.sh_o;
 #pragma unroll
-            for (int j = 0; j < kBlMaxCand; ++j) {
-                const float w = wh * ww[j];
-                if (w != 0.f) {
-                    const float4 v = *reinterpret_cast<const float4*>(grow + j * d.sw_o);
-                    acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
+            for (int j0 = 0; j0 < kBlMaxCand; j0 += 8) {
+                float4 v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int wo = (wo_lo + j0 + j < wo_hi) ? wo_lo + j0 + j : wo_hi;
+                    v[j] = *reinterpret_cast<const float4*>(grow + wo * d.sw_o);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float w = wh * ww[j0 + j];
+                    if (w != 0.f) { acc.x += w * v[j].x; acc.y += w * v[j].y; acc.z += w * v[j].z; acc.w += w * v[j].w; }
                 }
             }
         }
@@ -315,18 +323,29 @@ __global__ void __launch_bounds__(256) bilinear_bwd_split_kernel(tf_bilinear_des
             if (wo_lo < 0) wo_lo = 0;
             if (wo_hi > d.Wo - 1) wo_hi = d.Wo - 1;
         }
+        // column weights of the candidate window, 8 at a time and only as many groups as the window has (the full 24-entry table cost ~500 VALU
+        // operations per thread: the 2x / 4x maps, whose windows are 8 / 12 wide, were bound by it)
+        const int ncand = wo_hi - wo_lo + 1;
         float ww[kBlMaxCand];
 #pragma unroll
-        for (int j = 0; j < kBlMaxCand; ++j) {
-            const int wo = wo_lo + j;
-            float w = 0.f;
-            if (wo <= wo_hi) {
-                int w0, w1; float m0, m1;
-                bl_src(wo, sw, d.align_corners, d.Wi, w0, w1, m0, m1);
-                if (w0 == wi) w += m0;
-                if (w1 == wi) w += m1;
+        for (int j0 = 0; j0 < kBlMaxCand; j0 += 8) {
+            if (j0 < ncand) {
+#pragma unroll
+                for (int j = j0; j < j0 + 8; ++j) {
+                    const int wo = wo_lo + j;
+                    float w = 0.f;
+                    if (wo <= wo_hi) {
+                        int w0, w1; float m0, m1;
+                        bl_src(wo, sw, d.align_corners, d.Wi, w0, w1, m0, m1);
+                        if (w0 == wi) w += m0;
+                        if (w1 == wi) w += m1;
+                    }
+                    ww[j] = w;
+                }
+            } else {
+#pragma unroll
+                for (int j = j0; j < j0 + 8; ++j) ww[j] = 0.f;
             }
-            ww[j] = w;
         }
         const float* g = dy + b * d.sb_o + c * d.sc_o;
         float acc = 0.f;
@@ -338,11 +357,21 @@ __global__ void __launch_bounds__(256) bilinear_bwd_split_kernel(tf_bilinear_des
                 if (h0 == hi) wh += l0;
                 if (h1 == hi) wh += l1;
                 if (wh == 0.f) continue;
-                const float* grow = g + ho * d.sh_o + wo_lo * d.sw_o;
+                const float* grow = g + ho * d.sh_o;
                 float rowacc = 0.f;
 #pragma unroll
-                for (int j = 0; j < kBlMaxCand; ++j)
-                    if (ww[j] != 0.f) rowacc += ww[j] * grow[j * d.sw_o];
+                for (int j0 = 0; j0 < kBlMaxCand; j0 += 8) {      // unconditional clamped loads, 8 in flight (see bilinear_bwd_v4_kernel)
+                    if (j0 >= ncand) break;
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int wo = (wo_lo + j0 + j < wo_hi) ? wo_lo + j0 + j : wo_hi;
+                        v[j] = grow[wo * d.sw_o];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (ww[j0 + j] != 0.f) rowacc += ww[j0 + j] * v[j];
+                }
                 acc += wh * rowacc;
             }
 #pragma unroll
@@ -476,7 +505,10 @@ extern "C" int tf_bilinear_bwd_f32(const tf_bilinear_desc* d, const float* dy, f
     }
     const bool c_fastest = d->sc_i == 1 || d->sc_o == 1;
     if (fits && c_fastest && n <= (1L << 20) && bsh > 0.f && bsh <= 0.5f) {          // few input elements, each gathering >= 4 x 4 outputs: split the rows
-        TF_LAUNCH(bilinear_bwd_split_kernel<8>, dim3(ew_blocks(n * 8)), dim3(256), stream, *d, dy, dx, bsh, bsw, accumulate);
+        // lanes per input element = candidate rows / ~2.5: 8 for the 8x maps (20 rows), 4 for 4x (12 rows), 2 for 2x (8 rows)
+        if (bsh <= 0.1875f) TF_LAUNCH(bilinear_bwd_split_kernel<8>, dim3(ew_blocks(n * 8)), dim3(256), stream, *d, dy, dx, bsh, bsw, accumulate);
+        else if (bsh <= 0.375f) TF_LAUNCH(bilinear_bwd_split_kernel<4>, dim3(ew_blocks(n * 4)), dim3(256), stream, *d, dy, dx, bsh, bsw, accumulate);
+        else TF_LAUNCH(bilinear_bwd_split_kernel<2>, dim3(ew_blocks(n * 2)), dim3(256), stream, *d, dy, dx, bsh, bsw, accumulate);
         return launch_status("tf_bilinear_bwd_f32");
     }
     TF_LAUNCH(bilinear_bwd_kernel, dim3(ew_blocks(n)), dim3(256), stream, *d, dy, dx, bl_scale(d->Hi, d->Ho, d->align_corners),
