@@ -188,6 +188,12 @@ int tf_conv3x3_grouped_wgrad_f32(const float* dy, const float* x, float* dw, int
 int tf_stem_conv_fwd_f32(const tf_conv_geom* g, const float* s0, int C0, const float* s1, int C1, int normalize, const float* w, float* y, void* stream);
 int tf_stem_conv_wgrad_f32(const tf_conv_geom* g, const float* dy, const float* s0, int C0, const float* s1, int C1, int normalize, float* dw,
                            int accumulate, void* stream);
+/* tf_stem_conv_wgrad_f32 with caller scratch: the RegNet stems (ks^2 Cin <= 32, Cout = 32; transfuser.py:136-143) then run on direct kernels
+ * (partial panels in ws + a deterministic reduce) instead of the im2col engine.  tf_stem_conv_wgrad_ws_floats: floats of scratch this geometry
+ * wants (0 = the engine path, no scratch). */
+long tf_stem_conv_wgrad_ws_floats(const tf_conv_geom* g, int C0, int C1);
+int tf_stem_conv_wgrad_ws_f32(const tf_conv_geom* g, const float* dy, const float* s0, int C0, const float* s1, int C1, int normalize, float* dw,
+                              int accumulate, float* ws, long ws_floats, void* stream);
 
 /* ---- row-wise normalisation ------------------------------------------------------------------ */
 

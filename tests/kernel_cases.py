@@ -209,6 +209,19 @@ def check_stem(dev, B, H, W):
     w2 = (R(32, 3, 3, 3, seed=3, dev=dev) * 0.2)
     y2 = F.conv2d(torch.cat((l0, l1), 1), w2, None, 2, 1)
     close(ops.stem_conv_fwd(l0, l1, cl(w2), False).permute(0, 3, 1, 2), y2, what="lidar stem fwd")
+    # its weight gradient (two NCHW sources) accumulated into a non-zero buffer; run twice: the direct kernels' panel reduction is deterministic
+    w2r = w2.clone().requires_grad_(True)
+    y2r = F.conv2d(torch.cat((l0, l1), 1), w2r, None, 2, 1)
+    dy2 = R(*y2r.shape, seed=4, dev=dev)
+    (gw2,) = torch.autograd.grad(y2r, [w2r], dy2)
+    init = cl(R(32, 3, 3, 3, seed=5, dev=dev))
+    outs = []
+    for _ in range(2):
+        dw2 = init.clone()
+        ops.stem_conv_wgrad(dy2.permute(0, 2, 3, 1).contiguous(), l0, l1, dw2, False)
+        outs.append(dw2)
+    close(outs[0], init + gw2, what="lidar stem wgrad (accumulate)")
+    assert torch.equal(outs[0], outs[1]), "stem wgrad: not reproducible"
 
 
 def check_bn_se_consumer_fusion(dev, B=3, H=6, W=10, C=48, Cr=12):

@@ -34,6 +34,7 @@ def test_fused_attention(case):
 
 def test_stem_conv():
     kc.check_stem("cpu", 2, 12, 20)
+    kc.check_stem("cpu", 3, 37, 51)      # odd sizes: ragged last pixel tile / partial panel of the direct kernels
 
 
 @pytest.mark.parametrize("case", [(37, 72), (9, 216), (5, 1512)], ids=str)

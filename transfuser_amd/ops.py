@@ -580,8 +580,11 @@ def stem_conv_wgrad(dy, s0, s1, dw, normalize, accumulate=True, stride=2, pad=No
     C1 = s1.shape[1] if s1 is not None else 0
     ks = dw.shape[2]
     g = conv_geom((B, H, W, C0 + C1), dw.shape[0], ks, stride, ks // 2 if pad is None else pad, 1)
-    check(L().tf_stem_conv_wgrad_f32(byref(g), ptr(_c(dy)), ptr(_c(s0)), C0, ptr(_c(s1)) if s1 is not None else c_p(0), C1, int(normalize),
-                                     wptr(dw), int(accumulate), stream_of(dy)), "tf_stem_conv_wgrad_f32")
+    L().tf_stem_conv_wgrad_ws_floats.restype = ctypes.c_long
+    need = L().tf_stem_conv_wgrad_ws_floats(byref(g), C0, C1)     # > 0: the direct kernels want scratch for their partial panels (RegNet stems)
+    ws = torch.empty(need, dtype=torch.float32, device=dy.device) if need > 0 else None
+    check(L().tf_stem_conv_wgrad_ws_f32(byref(g), ptr(_c(dy)), ptr(_c(s0)), C0, ptr(_c(s1)) if s1 is not None else c_p(0), C1, int(normalize),
+                                        wptr(dw), int(accumulate), ptr(ws), ctypes.c_long(need), stream_of(dy)), "tf_stem_conv_wgrad_ws_f32")
     return dw
 
 
