@@ -27,42 +27,57 @@ struct StemSrc {
     float mean[4], stdv[4];
 };
 
-// value of patch element (pixel p, column k) - 0 outside the image / beyond K; the load itself is unconditional (clamped coordinates)
-__device__ __forceinline__ float stem_gather(const StemSrc& g, long p, int k) {
-    const bool kin = k < g.K && p < g.npix;
-    const long pp = p < g.npix ? p : 0;
-    const int kk = k < g.K ? k : 0;
-    const int ox = (int)(pp % g.Wo);
-    const long t = pp / g.Wo;
-    const int oy = (int)(t % g.Ho), b = (int)(t / g.Ho);
-    const int tap = kk / g.Cin, ci = kk - tap * g.Cin;
-    const int kh = tap / g.ks, kw = tap - kh * g.ks;
-    const int ih = oy * g.stride - g.pad + kh, iw = ox * g.stride - g.pad + kw;
-    const bool ok = kin && (unsigned)ih < (unsigned)g.Hi && (unsigned)iw < (unsigned)g.Wi;
+// Index arithmetic is the cost of these kernels, not the loads: everything that depends on the column k alone (tap, channel, source plane,
+// normalisation constants) is decoded ONCE per block into LDS, pixels are decoded with 32-bit divisions once per tile (forward) or once per
+// 16-pixel batch and then stepped (weight gradient).  (The first version decoded pixel and column with 64-bit divisions inside every gather and
+// was no faster than the engine's im2col loader: 176 / 102 us.)
+struct KCol { int kh, kw, ci; float mean, stdv; };          // kh < 0: column beyond K
+__device__ __forceinline__ void stem_fill_cols(const StemSrc& g, KCol* kc) {
+    if (threadIdx.x < SK) {
+        const int k = threadIdx.x;
+        KCol c;
+        const int tap = k / g.Cin;
+        c.ci = k - tap * g.Cin;
+        c.kh = k < g.K ? tap / g.ks : -1;
+        c.kw = tap - (tap / g.ks) * g.ks;
+        c.mean = g.mean[c.ci & 3]; c.stdv = g.stdv[c.ci & 3];
+        kc[k] = c;
+    }
+    __syncthreads();
+}
+// value of patch element (pixel (b, oy, ox), column c) - 0 outside the image / beyond K / for a dead pixel; the load itself is unconditional
+__device__ __forceinline__ float stem_gather(const StemSrc& g, int b, int oy, int ox, bool plive, const KCol& c) {
+    const int ih = oy * g.stride - g.pad + c.kh, iw = ox * g.stride - g.pad + c.kw;
+    const bool ok = plive && c.kh >= 0 && (unsigned)ih < (unsigned)g.Hi && (unsigned)iw < (unsigned)g.Wi;
     const int ihc = ih < 0 ? 0 : (ih > g.Hi - 1 ? g.Hi - 1 : ih), iwc = iw < 0 ? 0 : (iw > g.Wi - 1 ? g.Wi - 1 : iw);
-    const bool first = ci < g.C0 || !g.s1;
+    const bool first = c.ci < g.C0 || !g.s1;
     const float* src = first ? g.s0 : g.s1;
-    const int cs = first ? ci : ci - g.C0, Cn = first ? g.C0 : g.C1;
+    const int cs = first ? c.ci : c.ci - g.C0, Cn = first ? g.C0 : g.C1;
     float v = src[(((long)b * Cn + cs) * g.Hi + ihc) * g.Wi + iwc];
-    if (g.normalize) v = ((v / 255.0f) - g.mean[ci & 3]) / g.stdv[ci & 3];
+    if (g.normalize) v = ((v / 255.0f) - c.mean) / c.stdv;
     return ok ? v : 0.f;
 }
 
 __global__ void __launch_bounds__(256) stem_direct_fwd_kernel(StemSrc g, const float* __restrict__ w, float* __restrict__ y) {
+    __shared__ KCol kc[SK];
+    stem_fill_cols(g, kc);
     const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
-    const long nwaves = (long)gridDim.x * 4, wave0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nwaves = (int)gridDim.x * 4, wave0 = (int)blockIdx.x * 4 + (threadIdx.x >> 6);
     float wf[SK / 2];                  // B fragment: W[co = l31][k = 2 kk + hi]
 #pragma unroll
     for (int kk = 0; kk < SK / 2; ++kk) {
         const int k = 2 * kk + hi;
         wf[kk] = k < g.K ? w[(long)l31 * g.K + k] : 0.f;
     }
-    const long ntiles = (g.npix + 31) / 32;
-    for (long tile = wave0; tile < ntiles; tile += nwaves) {
-        const long p0 = tile * 32;
+    const int npix = (int)g.npix, ntiles = (npix + 31) / 32;
+    for (int tile = wave0; tile < ntiles; tile += nwaves) {
+        const int p0 = tile * 32, p = p0 + l31;
+        const bool plive = p < npix;
+        const int pp = plive ? p : 0;
+        const int ox = pp % g.Wo, t = pp / g.Wo, oy = t % g.Ho, b = t / g.Ho;
         float a[SK / 2];
 #pragma unroll
-        for (int kk = 0; kk < SK / 2; ++kk) a[kk] = stem_gather(g, p0 + l31, 2 * kk + hi);
+        for (int kk = 0; kk < SK / 2; ++kk) a[kk] = stem_gather(g, b, oy, ox, plive, kc[2 * kk + hi]);
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -70,33 +85,43 @@ __global__ void __launch_bounds__(256) stem_direct_fwd_kernel(StemSrc g, const f
         for (int kk = 0; kk < SK / 2; ++kk) mfma_32x32x2(a[kk], wf[kk], acc);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const long p = p0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            if (p < g.npix) y[p * SK + l31] = acc[r];
+            const int q = p0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (q < npix) y[(long)q * SK + l31] = acc[r];
         }
     }
 }
 
 // partial panel of block-wave w: part[w][co][k] over its kWgPix pixels
 __global__ void __launch_bounds__(256) stem_direct_wgrad_kernel(StemSrc g, const float* __restrict__ dy, float* __restrict__ part) {
+    __shared__ KCol kc[SK];
+    stem_fill_cols(g, kc);
     const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
-    const long wv = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const long p0 = wv * kWgPix;
+    const int wv = (int)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int npix = (int)g.npix;
+    const long p0 = (long)wv * kWgPix;
+    const KCol c = kc[l31];            // this lane's column: fixed
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     for (int q = 0; q < kWgPix; q += 16) {             // 8 MFMA steps (16 pixels) per batch: 16 independent loads per lane in flight
-        float a[8], b[8];
+        const long pb = p0 + q + hi;                   // this lane's first pixel of the batch, then + 2 per step
+        const int pp = pb < npix ? (int)pb : 0;
+        int ox = pp % g.Wo, t = pp / g.Wo, oy = t % g.Ho, b = t / g.Ho;
+        float a[8], bv[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const long p = p0 + q + 2 * u + hi;
-            a[u] = dy[(p < g.npix ? p : 0) * SK + l31];
-            if (p >= g.npix) a[u] = 0.f;
-            b[u] = stem_gather(g, p, l31);
+            const long p = pb + 2 * u;
+            const bool plive = p < npix;
+            a[u] = dy[(plive ? p : 0) * SK + l31];
+            if (!plive) a[u] = 0.f;
+            bv[u] = stem_gather(g, b, oy, ox, plive, c);
+            ox += 2;
+            while (ox >= g.Wo) { ox -= g.Wo; if (++oy >= g.Ho) { oy = 0; ++b; } }
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) mfma_32x32x2(a[u], b[u], acc);
+        for (int u = 0; u < 8; ++u) mfma_32x32x2(a[u], bv[u], acc);
     }
-    float* o = part + wv * (SK * SK);
+    float* o = part + (long)wv * (SK * SK);
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2) + 4 * hi) * SK + l31] = acc[r];
 }
@@ -120,7 +145,8 @@ int gemm_precision();
 bool stem_direct_ok(const tf_conv_geom* g, int C0, int C1) {
     static const bool on = [] { const char* e = getenv("TF_STEM_DIRECT"); return e ? e[0] != '0' : true; }();
     const int prec = gemm_precision();
-    return on && (prec == 0 || prec == 2) && g->Cout == SK && g->groups == 1 && g->ksize * g->ksize * (C0 + C1) <= SK && C0 + C1 <= 4;
+    return on && (prec == 0 || prec == 2) && g->Cout == SK && g->groups == 1 && g->ksize * g->ksize * (C0 + C1) <= SK && C0 + C1 <= 4 &&
+           (long)g->B * g->Ho * g->Wo < (1L << 30) && (long)g->B * 4 * g->Hi * g->Wi < (1L << 31);
 }
 long stem_direct_wgrad_ws_floats(const tf_conv_geom* g) {
     const long npix = (long)g->B * g->Ho * g->Wo;
