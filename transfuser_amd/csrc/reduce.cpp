@@ -359,11 +359,37 @@ inline bool launch_reduce_fin(const RedPlan& p, const F4& f4, const F1& f1, int 
 
 // ---- finalize kernels: one wave per channel, lanes sum the chunk partials (was: one thread per channel
 // walking up to 64 dependent loads = ~19 us per BatchNorm; now a shuffle tree) -------------------------------------------
+// (four loads per trip from clamped indices, the out-of-range ones multiplied by 0: a run-time-bounded loop of single loads is a chain of
+//  ~1 us round trips - up to 8 of them for the 352-512 chunk reductions of the BatchNorm backward)
 __device__ __forceinline__ float chunk_sum(const float* __restrict__ p, long stride, int nch, int lane, bool live) {
     float s = 0.f;
     if (live)
-        for (int j = lane; j < nch; j += 64) s += p[(long)j * stride];
+        for (int j = lane; j < nch; j += 256) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int jj = j + 64 * u; v[u] = p[(long)(jj < nch ? jj : nch - 1) * stride]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s += (j + 64 * u < nch) ? v[u] : 0.f;
+        }
     return wave_sum(s);
+}
+// two sums over the same chunks (the BatchNorm finalizes): the loads of both are in flight together
+__device__ __forceinline__ void chunk_sum2(const float* __restrict__ p, const float* __restrict__ q, long stride, int nch, int lane, bool live, float& sp, float& sq) {
+    float a = 0.f, b = 0.f;
+    if (live)
+        for (int j = lane; j < nch; j += 256) {
+            float v[4], w[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int jj = j + 64 * u;
+                const long o = (long)(jj < nch ? jj : nch - 1) * stride;
+                v[u] = p[o]; w[u] = q[o];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const bool in = j + 64 * u < nch; a += in ? v[u] : 0.f; b += in ? w[u] : 0.f; }
+        }
+    sp = wave_sum(a);
+    sq = wave_sum(b);
 }
 
 // out[seg][c] (+)= scale * sum_chunks ws[seg][chunk][0][c]
@@ -385,7 +411,8 @@ __global__ void __launch_bounds__(256) bn_fwd_finalize_kernel(const float* __res
     const int c0 = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     const bool live = c0 < C;
     const int c = live ? c0 : 0;
-    const float s1 = chunk_sum(ws + c, 2L * C, nch, lane, live), s2 = chunk_sum(ws + C + c, 2L * C, nch, lane, live);
+    float s1, s2;
+    chunk_sum2(ws + c, ws + C + c, 2L * C, nch, lane, live, s1, s2);
     if (!live || lane != 0) return;
     const float dm = s1 / n;
     const float mean = K[c] + dm;
@@ -414,23 +441,44 @@ __global__ void __launch_bounds__(256) bn_fwd_finalize_parts_kernel(const float*
     const bool live = c0 < C;
     const int c = live ? c0 : 0;
     const long ps = 3L * C;
-    float sn = 0.f, sm = 0.f;
-    if (live)
-        for (int p = lane; p < nparts; p += 64) {
-            const float np = parts[p * ps + c];
-            sn += np;
-            sm += np * parts[p * ps + C + c];
+    // a lane keeps its <= 4 parts (256 parts = 8192 rows per wave-tile row... more parts take further trips) in registers: all 12 loads are issued
+    // together and the second pass (Chan's M2 merge needs the global mean) re-uses them instead of re-reading the triples
+    float sn = 0.f, sm = 0.f, m2 = 0.f;
+    if (nparts <= 256) {
+        float np[4], mp[4], qp[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int p = lane + 64 * u;
+            const long o = (long)(p < nparts ? p : nparts - 1) * ps + c;
+            np[u] = parts[o]; mp[u] = parts[o + C]; qp[u] = parts[o + 2L * C];
+            if (!live || p >= nparts) { np[u] = 0.f; qp[u] = 0.f; }
         }
-    sn = wave_sum(sn);
-    sm = wave_sum(sm);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { sn += np[u]; sm += np[u] * mp[u]; }
+        sn = wave_sum(sn);
+        sm = wave_sum(sm);
+        const float mean0 = sn > 0.f ? sm / sn : 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const float d = mp[u] - mean0; m2 += qp[u] + np[u] * d * d; }
+        m2 = wave_sum(m2);
+    } else {
+        if (live)
+            for (int p = lane; p < nparts; p += 64) {
+                const float np = parts[p * ps + c];
+                sn += np;
+                sm += np * parts[p * ps + C + c];
+            }
+        sn = wave_sum(sn);
+        sm = wave_sum(sm);
+        const float mean0 = sn > 0.f ? sm / sn : 0.f;
+        if (live)
+            for (int p = lane; p < nparts; p += 64) {
+                const float np = parts[p * ps + c], d = parts[p * ps + C + c] - mean0;
+                m2 += parts[p * ps + 2L * C + c] + np * d * d;
+            }
+        m2 = wave_sum(m2);
+    }
     const float mean = sn > 0.f ? sm / sn : 0.f;
-    float m2 = 0.f;
-    if (live)
-        for (int p = lane; p < nparts; p += 64) {
-            const float np = parts[p * ps + c], d = parts[p * ps + C + c] - mean;
-            m2 += parts[p * ps + 2L * C + c] + np * d * d;
-        }
-    m2 = wave_sum(m2);
     if (!live || lane != 0) return;
     float var = m2 / n;
     if (var < 0.f) var = 0.f;
@@ -461,7 +509,8 @@ __global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const float* __res
     const int c0 = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     const bool live = c0 < C;
     const int c = live ? c0 : 0;
-    const float sg = chunk_sum(ws + c, 2L * C, nch, lane, live), sgx = chunk_sum(ws + C + c, 2L * C, nch, lane, live);
+    float sg, sgx;
+    chunk_sum2(ws + c, ws + C + c, 2L * C, nch, lane, live, sg, sgx);
     if (!live || lane != 0) return;
     if (dgamma) dgamma[c] += sgx;
     if (dbeta) dbeta[c] += sg;
