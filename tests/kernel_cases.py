@@ -366,6 +366,10 @@ def check_layernorm(dev, rows, C):
     close(dx, gx, what="ln dx")
     close(dg, gg, what="ln dgamma")
     close(db, gb, what="ln dbeta")
+    acc0 = R(rows, C, seed=4, dev=dev)              # dx accumulated in place (the residual stream of a transformer Block)
+    acc = acc0.clone()
+    ops.layernorm_bwd(dy, x.detach(), g.detach(), mean, rstd, torch.zeros(C, device=dev), torch.zeros(C, device=dev), dx=acc, accumulate=True)
+    close(acc, acc0 + gx, what="ln dx accumulate")
 
 
 def check_softmax(dev, rows, n, ld):

@@ -44,7 +44,7 @@ def test_stem_conv():
     kc.check_stem("cuda", 3, 37, 51)      # odd sizes: ragged last pixel tile / partial panel of the direct kernels
 
 
-@pytest.mark.parametrize("case", [(37, 72), (9, 216), (5, 1512)], ids=str)
+@pytest.mark.parametrize("case", [(37, 72), (9, 216), (5, 1512), (6, 576), (3, 2048), (4, 70), (2, 2052), (130, 288)], ids=str)
 def test_layernorm(case):
     kc.check_layernorm("cuda", *case)
 

@@ -246,7 +246,27 @@ __global__ void __launch_bounds__(256) colreduce_kernel(F f, int rows_per_seg, i
         for (int i = 0; i < V; ++i) acc[a].v[i] = 0.f;
     if (rl < rpp) {
         const long base = (long)seg * rows_per_seg;
-        for (int r = r0 + rl; r < r1; r += rpp) {
+        int r = r0 + rl;
+        // four rows per trip, evaluated from clamped row indices before any of them is accumulated (the selection is applied to the VALUES):
+        // the loads of the four rows are in flight together instead of one ~1 us round trip per row of a run-time-bounded loop
+        if (atomic >= 0)
+            for (; r < r1; r += 4 * rpp) {
+                vecf<V> o[4][NACC];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int rr = r + u * rpp;
+                    f.eval(base + (rr < r1 ? rr : r1 - 1), c, o[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bool in = r + u * rpp < r1;
+#pragma unroll
+                    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+                        for (int i = 0; i < V; ++i) acc[a].v[i] += in ? o[u][a].v[i] : 0.f;
+                }
+            }
+        for (; r < r1; r += rpp) {          // atomic < 0: the one-row-per-trip loop (A/B switch TF_COLREDUCE_UNROLL=0)
             vecf<V> o[NACC];
             f.eval(base + r, c, o);
 #pragma unroll
@@ -255,6 +275,7 @@ __global__ void __launch_bounds__(256) colreduce_kernel(F f, int rows_per_seg, i
                 for (int i = 0; i < V; ++i) acc[a].v[i] += o[a].v[i];
         }
     }
+    if (atomic < 0) atomic = 0;
 #pragma unroll
     for (int a = 0; a < NACC; ++a)
 #pragma unroll
@@ -337,6 +358,8 @@ template <int NACC, class F4, class F1>
 inline void launch_reduce(const RedPlan& p, const F4& f4, const F1& f1, int rows_per_seg, int C, int nseg, float* ws, void* stream, int atomic = 0,
                           float scale = 1.f) {
     dim3 grid(p.coltiles, p.nchunks, nseg);
+    static const bool unroll = [] { const char* e = getenv("TF_COLREDUCE_UNROLL"); return e ? e[0] != '0' : true; }();
+    if (!unroll && atomic == 0) atomic = -1;
     if (p.V == 4) TF_LAUNCH((colreduce_kernel<4, NACC, F4, NoFin>), grid, dim3(256), stream, f4, rows_per_seg, C, p.CTV, p.rows_per_chunk, ws, atomic, scale, NoFin(), (int*)nullptr);
     else TF_LAUNCH((colreduce_kernel<1, NACC, F1, NoFin>), grid, dim3(256), stream, f1, rows_per_seg, C, p.CTV, p.rows_per_chunk, ws, atomic, scale, NoFin(), (int*)nullptr);
 }
