@@ -303,7 +303,13 @@ __global__ void __launch_bounds__(256) conv3x3_grouped_wgrad_reduce_kernel(const
     const int ci = i & 31, co = (i >> 5) & 31, tap = i >> 10;
     if (co >= CG || ci >= CG) return;
     float s = 0.f;
-    for (int b = 0; b < nb; ++b) s += part[((long)(grp * nb + b)) * 9216 + i];
+    for (int b0 = 0; b0 < nb; b0 += 8) {                 // 8 partial panels per trip (clamped index, out-of-range ones dropped after the load)
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = part[((long)(grp * nb + (b0 + u < nb ? b0 + u : nb - 1))) * 9216 + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += b0 + u < nb ? v[u] : 0.f;
+    }
     float* d = dw + (((long)grp * CG + co) * 9 + tap) * CG + ci;
     *d = accumulate ? *d + s : s;
 }

@@ -33,10 +33,23 @@ __global__ void __launch_bounds__(256) pool_tokens_fwd_kernel(const float* __res
 #pragma unroll
         for (int k = 0; k < V; ++k) acc[k] = 0.f;
         for (int h = h0; h < h1; ++h)
-            for (int w = w0; w < w1; ++w) {
-                const float* p = x + (((long)b * H + h) * W + w) * C + c;
-                if (V == 4) { float4 v = *reinterpret_cast<const float4*>(p); acc[0] += v.x; acc[1 % V] += v.y; acc[2 % V] += v.z; acc[3 % V] += v.w; }
-                else acc[0] += *p;
+            for (int wb = w0; wb < w1; wb += 8) {        // 8 window columns per trip from clamped indices: the loads are in flight together
+                const float* prow = x + (((long)b * H + h) * W) * C + c;
+                if (V == 4) {
+                    float4 v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(prow + (long)(wb + u < w1 ? wb + u : w1 - 1) * C);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (wb + u < w1) { acc[0] += v[u].x; acc[1 % V] += v[u].y; acc[2 % V] += v[u].z; acc[3 % V] += v[u].w; }
+                } else {
+                    float v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = prow[(long)(wb + u < w1 ? wb + u : w1 - 1) * C];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (wb + u < w1) acc[0] += v[u];
+                }
             }
         const float inv = 1.0f / (float)((h1 - h0) * (w1 - w0));
         const int trow = tok_off + i * ow + j;
