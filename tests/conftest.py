@@ -45,7 +45,9 @@ def emu_backend():
     sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
     import build_emu
     from transfuser_amd import _lib
-    path = build_emu.build()
+    # TF_EMU_ASAN=1: the AddressSanitizer build of the emulated kernels (run pytest under LD_PRELOAD=<clang's libclang_rt.asan-x86_64.so> with
+    # ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0): out-of-bounds reads / writes of the kernels show up on the CPU
+    path = build_emu.build(asan=os.environ.get("TF_EMU_ASAN") == "1")
     _lib._install_test_backend(ctypes.CDLL(path))
     if os.environ.get("PYTEST_XDIST_WORKER"):
         import torch

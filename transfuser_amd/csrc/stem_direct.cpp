@@ -115,8 +115,10 @@ __global__ void __launch_bounds__(256) stem_direct_wgrad_kernel(StemSrc g, const
             a[u] = dy[(plive ? p : 0) * SK + l31];
             if (!plive) a[u] = 0.f;
             bv[u] = stem_gather(g, b, oy, ox, plive, c);
-            ox += 2;
-            while (ox >= g.Wo) { ox -= g.Wo; if (++oy >= g.Ho) { oy = 0; ++b; } }
+            if (p + 2 < npix) {                       // never step past the last pixel: the (unconditional) gather of a dead pixel must stay inside the tensor
+                ox += 2;
+                while (ox >= g.Wo) { ox -= g.Wo; if (++oy >= g.Ho) { oy = 0; ++b; } }
+            }
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) mfma_32x32x2(a[u], bv[u], acc);
