@@ -342,8 +342,14 @@ def main():
             res["cpu_baseline"] = cpu_baseline(make_cfg, backbone, H, W)
         print(json.dumps(res), flush=True)
     if world > 1:
+        # every rank is done (the JSON line is out): leave WITHOUT c10d's teardown - destroy_process_group() of an RCCL group has aborted the
+        # interpreter on the MI355X box at the end of a long process (profiles/r03_gpu_tests_final_219_passed_teardown_abort.log), and a rank that
+        # dies in its shutdown path would turn a finished measurement into a failed torchrun
         torch.distributed.barrier()
-        torch.distributed.destroy_process_group()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":
