@@ -762,18 +762,32 @@ def check_adamw(dev, n):
     assert state[0].item() == 3.0
 
 
-def check_hist(dev, B, N):
+def check_hist(dev, B, N, stride=4, ragged=None):
+    """H1 (data.py:446-470) against the line-by-line oracle, np.array_equal: points on bin edges and on the closed upper borders, > 5 hits
+    per cell (the clip), long runs of one cell (the wave-level run merge), ragged ``num_points`` (incl. an empty and a full sample),
+    ``stride`` 4 (float4 loads) and 5 (scalar loads)."""
     from oracle import hist
     rng = np.random.default_rng(0)
-    pts = np.stack([rng.uniform(-20, 20, (B, N)), rng.uniform(-36, 4, (B, N)), rng.uniform(-4, 1, (B, N)), rng.uniform(0, 1, (B, N))], -1).astype(np.float32)
+    pts = np.stack([rng.uniform(-20, 20, (B, N)), rng.uniform(-36, 4, (B, N)), rng.uniform(-4, 1, (B, N))] +
+                   [rng.uniform(0, 1, (B, N))] * (stride - 3), -1).astype(np.float32)
     pts[0, :40, 0] = 16.0; pts[0, 40:80, 1] = 0.0; pts[0, 80:120, 0] = -16.0; pts[0, 120:160, 1] = -32.0; pts[0, 160:200, 2] = -2.3
     pts[1, :500, :2] = np.round(pts[1, :500, :2] * 8) / 8   # points exactly on bin edges
     pts[1, 500:520] = pts[1, 500]                            # > 5 hits in one bin (clipping)
-    npts = torch.tensor([N, N - 777], dtype=torch.int32)
-    out = ops.lidar_hist(torch.from_numpy(pts).to(dev), npts.to(dev)).cpu().numpy()
+    pts[1, 600:603] = pts[1, 600]; pts[1, 700:704] = pts[1, 700]; pts[1, 800:805] = pts[1, 800]   # runs of 3 / 4 / 5 (below / at the clip)
+    pts[1, 1000:1000 + min(300, N - 1000), :3] = np.float32([3.01, -7.02, 0.5])                    # a run spanning several waves
+    pts[1, 62:67, :3] = np.float32([-3.3, -20.1, -3.0])                                             # a run across a wave boundary
+    if B > 2:
+        pts[2, ::2, :3] = np.float32([1.0, -1.0, 0.0]); pts[2, 1::2, :3] = np.float32([1.0, -1.0, -3.0])   # two cells alternating: no runs, 2 hot counters
+    npts = np.full(B, N, np.int32)
+    npts[1] = N - 777
+    if ragged is not None:
+        npts[:] = np.asarray(ragged, np.int32)
+    out = ops.lidar_hist(torch.from_numpy(pts).to(dev), torch.from_numpy(npts).to(dev)).cpu().numpy()
     for b in range(B):
-        ref = hist.lidar_to_histogram_features(pts[b, :int(npts[b])])
+        ref = hist.lidar_to_histogram_features(pts[b, :int(npts[b]), :4])
         assert np.array_equal(out[b], ref), "H1 histogram must be bit-exact (sample %d: %d bins differ)" % (b, (out[b] != ref).sum())
+    out2 = ops.lidar_hist(torch.from_numpy(pts).to(dev)).cpu().numpy()        # num_points = None: every row counts
+    assert np.array_equal(out2[0], hist.lidar_to_histogram_features(pts[0, :, :4]))
 
 
 # ---------------------------------------------------------------- CenterNet targets + losses vs the oracle

@@ -114,6 +114,8 @@ def test_adamw():
 
 def test_lidar_hist():
     kc.check_hist("cpu", 2, 3000)
+    kc.check_hist("cpu", 3, 3001, stride=5)
+    kc.check_hist("cpu", 4, 2049, ragged=[2049, 0, 1, 1500])
 
 
 @pytest.mark.parametrize("case", [(3, False), (2, True)], ids=str)

@@ -119,6 +119,14 @@ def test_adamw():
 
 def test_lidar_hist():
     kc.check_hist("cuda", 2, 3000)
+    kc.check_hist("cuda", 3, 3001, stride=5)
+
+
+@pytest.mark.parametrize("N", [32768, 40000], ids=["bench_cloud_10x32768", "max_lidar_points_10x40000"])
+def test_lidar_hist_full_size_ragged(N):
+    """H1 at SURVEY 8d's bench cloud (10 x 32768) and at the reference's cap (max_lidar_points = 40000, config.py) with ragged num_points
+    (a full, an empty, a one-point sample): bit-exact against the oracle's np.histogramdd restatement."""
+    kc.check_hist("cuda", 10, N, ragged=[N, N - 777, N, 0, 1, N // 2, 255, 257, N - 1, 12345])
 
 
 @pytest.mark.parametrize("case", [(3, False), (2, True)], ids=str)

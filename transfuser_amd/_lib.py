@@ -10,7 +10,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtransfuser_hip.so")
+# TF_HIP_LIB: A/B runs of two builds of the SAME library inside one GPU lease (tools/gpu_round4.sh); never a different backend
+LIB_PATH = os.environ.get("TF_HIP_LIB") or os.path.join(_HERE, "libtransfuser_hip.so")
 
 _lib = None
 _test_backend = False

@@ -35,12 +35,24 @@ template <int TW> struct Tile {
 
 // group panel -> LDS as wl[tap * CG + k][n] (n < 32 zero padded):  fwd   wl[tap][ci][co] = W[g*CG + co][tap][ci]
 //                                                                   dgrad wl[tap][co][ci] = W[g*CG + co][8 - tap][ci]
-__device__ __forceinline__ void load_group_weights(float (*wl)[WP], const float* __restrict__ w, int dgrad) {
-    for (int i = threadIdx.x; i < 9 * CG * 32; i += 256) {
-        const int n = i & 31, k = (i >> 5) % CG, tap = i / (32 * CG);
-        float v = 0.f;
-        if (n < CG) v = dgrad ? w[((long)k * 9 + (8 - tap)) * CG + n] : w[((long)n * 9 + tap) * CG + k];
-        wl[tap * CG + k][n] = v;
+// The group's panel is 24 x 9 x 24 = 5184 CONTIGUOUS floats: every thread issues its 21 (clamped, unconditional) loads back to back, then the
+// first patch's loads, and only then scatters the panel into LDS - one memory round trip in front of the first tile.  (Round 3 gathered one element per loop trip under a predicate: hipcc put a
+// vmcnt(0) into every one of the 27 trips, ~20 us of dependent latency in front of every forward / input-gradient launch.)
+constexpr int WNE = 9 * CG * CG, WNL = (WNE + 255) / 256;
+struct GroupWeightRegs { float v[WNL]; };
+__device__ __forceinline__ void issue_group_weights(GroupWeightRegs& r, const float* __restrict__ w) {
+#pragma unroll
+    for (int p = 0; p < WNL; ++p) { const int e = threadIdx.x + p * 256; r.v[p] = w[e < WNE ? e : WNE - 1]; }
+}
+__device__ __forceinline__ void scatter_group_weights(float (*wl)[WP], const GroupWeightRegs& r, int dgrad) {
+    for (int i = threadIdx.x; i < 9 * CG * 8; i += 256) wl[i >> 3][CG + (i & 7)] = 0.f;      // the 8 padding columns of the 32-wide MFMA operand
+#pragma unroll
+    for (int p = 0; p < WNL; ++p) {
+        const int e = threadIdx.x + p * 256;
+        const int co = e / (9 * CG), q = e - co * (9 * CG), tap = q / CG, ci = q - tap * CG;
+        if (e < WNE) {
+            if (dgrad) wl[(8 - tap) * CG + co][ci] = r.v[p]; else wl[tap * CG + ci][co] = r.v[p];
+        }
     }
 }
 
@@ -50,10 +62,10 @@ __device__ __forceinline__ float4 load_patch_slot(const float* __restrict__ x, c
     const int pix = s / 6, c = (s - pix * 6) * 4;
     const int ph = pix / T::PW, pw = pix - ph * T::PW;
     const int h = h0 - 1 + ph, w = w0 - 1 + pw;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (pix < T::NPIX && (unsigned)h < (unsigned)g.H && (unsigned)w < (unsigned)g.W)
-        v = *reinterpret_cast<const float4*>(x + (((long)b * g.H + h) * g.W + w) * g.C + coff + c);
-    return v;
+    const bool ok = pix < T::NPIX && (unsigned)h < (unsigned)g.H && (unsigned)w < (unsigned)g.W;
+    const int hc = h < 0 ? 0 : (h >= g.H ? g.H - 1 : h), wc = w < 0 ? 0 : (w >= g.W ? g.W - 1 : w);      // clamped address: the load itself is unconditional
+    const float4 v = *reinterpret_cast<const float4*>(x + (((long)b * g.H + hc) * g.W + wc) * g.C + coff + c);
+    return ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 template <int TW>
 __device__ __forceinline__ void store_patch_slot(float* patch, int s, const float4 v) {
@@ -75,7 +87,8 @@ __global__ void __launch_bounds__(256, 2) conv3x3_grouped_kernel(const float* __
     __shared__ float wl[9 * CG][WP];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int grp = blockIdx.x / g.nb, sub = blockIdx.x - grp * g.nb, coff = grp * CG;
-    load_group_weights(wl, w + (long)grp * CG * 9 * CG, dgrad);
+    GroupWeightRegs wreg;
+    issue_group_weights(wreg, w + (long)grp * CG * 9 * CG);          // 21 loads in flight; the first patch joins them before anything waits
     float4 pre[T::NV];
     auto fetch = [&](int t) {
         const int b = t / (g.tiles_h * g.tiles_w), r = t - b * (g.tiles_h * g.tiles_w);
@@ -85,6 +98,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_grouped_kernel(const float* __
     };
     int tile = sub;
     if (tile < g.ntiles) fetch(tile);
+    scatter_group_weights(wl, wreg, dgrad);
     // this lane's pixel inside the wave's 32: (row, col) of the tile
     const int prow = wave * T::RW + l31 / TW, pcol = l31 % TW;
     float st_n = 0.f, st_mean = 0.f, st_m2 = 0.f;      // STAT: running triple of channel l31 over this wave's pixels (same in both lane halves)
@@ -196,35 +210,50 @@ __global__ void __launch_bounds__(256, 2) conv3x3_grouped_kernel(const float* __
     }
 }
 
-// dW[g*24 + co][tap][ci] (+)= sum_pixels dY[p][g*24 + co] * X[p + tap][g*24 + ci]: per wave 32 pixels as K, 9 accumulators (one per tap);
-// part[(grp * nb + sub)][tap][32][32] partial panels, summed by conv3x3_grouped_wgrad_reduce_kernel.
+// dW[g*24 + co][tap][ci] (+)= sum_pixels dY[p][g*24 + co] * X[p + tap][g*24 + ci].  THREE waves per block, wave kh owns the taps (kh, 0..2): every
+// wave walks ALL 128 pixels of the tile as the K dimension (A[i = co][k = pixel] = the staged dY tile, shared by the three waves; B[k][j = ci] = the
+// patch shifted by the tap), so a wave's three accumulators ARE three finished taps of the block's partial panel - no cross-wave reduction,
+// no barrier after the last tile, the panel rows go straight from the accumulator registers to part[block][tap][co (32)][ci (32)] and
+// conv3x3_grouped_wgrad_reduce_kernel sums a group's panels in a fixed order (deterministic, no atomics).  31-33 KB of LDS and ~100 VGPRs
+// per block: four to five blocks per CU (round 3: four waves splitting the PIXELS, nine accumulators each, an 18-barrier reduction through
+// LDS at the end and one block per CU - 62 us per launch against a 22 us MFMA bound).  Operand rows / columns 24..31 of the 32-wide MFMA
+// carry whatever the neighbouring LDS words hold: they only reach accumulator rows / columns >= 24, which are never read.
 template <int TW, int PREC>
-__global__ void __launch_bounds__(256, 1) conv3x3_grouped_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part, GcGeom g) {
+__global__ void __launch_bounds__(192) conv3x3_grouped_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part, GcGeom g) {
     typedef Tile<TW> T;
-    __shared__ float lds[T::NPIX * PP + 128 * PP];
+    constexpr int NT = 192;
+    constexpr int NVP = (T::NPIX * 6 + NT - 1) / NT, ND = (128 * 6 + NT - 1) / NT;     // float4 slots per thread: patch, dY (6 per pixel)
+    __shared__ float lds[T::NPIX * PP + 128 * PP + 8];
     float* patch = lds;
     float* dyt = lds + T::NPIX * PP;               // [pixel][co]
-    static_assert(T::NPIX * PP + 128 * PP >= 4 * 32 * 33, "the cross-wave reduction reuses the tile memory");
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int grp = blockIdx.x / g.nb, sub = blockIdx.x - grp * g.nb, coff = grp * CG;
-    f32x16 acc[9];
+    f32x16 acc[3];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < 3; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    constexpr int ND = (128 * 6 + 255) / 256;      // dY float4 slots per thread (6 per pixel)
-    float4 pre[T::NV], dpre[ND];
-    auto fetch = [&](int t) {
+    float4 pre[NVP], dpre[ND];
+    auto fetch = [&](int t) {      // unconditional loads from clamped addresses; the zero padding is applied to the VALUE
         const int b = t / (g.tiles_h * g.tiles_w), r = t - b * (g.tiles_h * g.tiles_w);
         const int h0 = (r / g.tiles_w) * T::TH, w0 = (r % g.tiles_w) * TW;
 #pragma unroll
-        for (int p = 0; p < T::NV; ++p) pre[p] = load_patch_slot<TW>(x, g, coff, b, h0, w0, tid + p * 256);
+        for (int p = 0; p < NVP; ++p) {
+            const int s = tid + p * NT, pix = s / 6, c = (s - pix * 6) * 4;
+            const int ph = pix / T::PW, pw = pix - ph * T::PW, h = h0 - 1 + ph, w = w0 - 1 + pw;
+            const bool ok = pix < T::NPIX && (unsigned)h < (unsigned)g.H && (unsigned)w < (unsigned)g.W;
+            const int hc = h < 0 ? 0 : (h >= g.H ? g.H - 1 : h), wc = w < 0 ? 0 : (w >= g.W ? g.W - 1 : w);
+            const float4 v = *reinterpret_cast<const float4*>(x + (((long)b * g.H + hc) * g.W + wc) * g.C + coff + c);
+            pre[p] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
 #pragma unroll
         for (int p = 0; p < ND; ++p) {
-            const int s = tid + p * 256, pix = s / 6, c = (s - pix * 6) * 4;
+            const int s = tid + p * NT, pix = s / 6, c = (s - pix * 6) * 4;
             const int h = h0 + pix / TW, w = w0 + pix % TW;
-            dpre[p] = (pix < 128 && h < g.H && w < g.W) ? *reinterpret_cast<const float4*>(dy + (((long)b * g.H + h) * g.W + w) * g.C + coff + c)
-                                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool ok = pix < 128 && h < g.H && w < g.W;
+            const int hc = h >= g.H ? g.H - 1 : h, wc = w >= g.W ? g.W - 1 : w;
+            const float4 v = *reinterpret_cast<const float4*>(dy + (((long)b * g.H + hc) * g.W + wc) * g.C + coff + c);
+            dpre[p] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     int tile = sub;
@@ -232,68 +261,58 @@ __global__ void __launch_bounds__(256, 1) conv3x3_grouped_wgrad_kernel(const flo
     for (; tile < g.ntiles; tile += g.nb) {
         __syncthreads();
 #pragma unroll
-        for (int p = 0; p < T::NV; ++p) store_patch_slot<TW>(patch, tid + p * 256, pre[p]);
+        for (int p = 0; p < NVP; ++p) {
+            const int s = tid + p * NT, pix = s / 6, c = (s - pix * 6) * 4;
+            if (pix < T::NPIX) { float* q = patch + pix * PP + c; q[0] = pre[p].x; q[1] = pre[p].y; q[2] = pre[p].z; q[3] = pre[p].w; }
+        }
 #pragma unroll
         for (int p = 0; p < ND; ++p) {
-            const int s = tid + p * 256, pix = s / 6, c = (s - pix * 6) * 4;
+            const int s = tid + p * NT, pix = s / 6, c = (s - pix * 6) * 4;
             if (pix < 128) { float* q = dyt + pix * PP + c; q[0] = dpre[p].x; q[1] = dpre[p].y; q[2] = dpre[p].z; q[3] = dpre[p].w; }
         }
         __syncthreads();
         if (tile + g.nb < g.ntiles) fetch(tile + g.nb);
-        // k = pixel 2 kk + hi of this wave's 32: A[i = co][k] = dyt (shared by the 9 taps), B[k][j = ci] = patch shifted by the tap
-        if constexpr (PREC != 0) { // bf16 MFMA (PREC 1: rounded operands, 2: bf16x3 split): the wave's 32 pixels = two 16-deep K groups; lane half hi owns pixels 16 q + 8 hi .. + 7
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                float a[8], b[9][8];
+        if constexpr (PREC != 0) { // bf16 MFMA (PREC 1: rounded operands, 2: bf16x3 split): the tile's 128 pixels = eight 16-deep K groups; lane half hi owns pixels 16 q + 8 hi .. + 7
+#pragma unroll 2
+            for (int q = 0; q < 8; ++q) {
+                float a[8], b[3][8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const int pi = 16 * q + 8 * hi + j, prow = wave * T::RW + pi / TW, pcol = pi % TW;
-                    a[j] = (l31 < CG) ? dyt[(wave * 32 + pi) * PP + l31] : 0.f;
-                    const float* pb = patch + (prow * T::PW + pcol) * PP + (l31 < CG ? l31 : 0);
+                    const int pi = 16 * q + 8 * hi + j, prow = pi / TW, pcol = pi % TW;
+                    a[j] = dyt[pi * PP + l31];
+                    const float* pb = patch + ((prow + wave) * T::PW + pcol) * PP + l31;
 #pragma unroll
-                    for (int tap = 0; tap < 9; ++tap) b[tap][j] = (l31 < CG) ? pb[((tap / 3) * T::PW + (tap % 3)) * PP] : 0.f;
+                    for (int kw = 0; kw < 3; ++kw) b[kw][j] = pb[kw * PP];
                 }
-                if constexpr (PREC == 2) {      // the dY fragment is split once and shared by the 9 taps
+                if constexpr (PREC == 2) {      // the dY fragment is split once and shared by the wave's 3 taps
                     const Bf16x3 fa = split_bf16x3(a);
 #pragma unroll
-                    for (int tap = 0; tap < 9; ++tap) mfma_x3_presplit(fa, split_bf16x3(b[tap]), acc[tap]);
+                    for (int kw = 0; kw < 3; ++kw) mfma_x3_presplit(fa, split_bf16x3(b[kw]), acc[kw]);
                 } else {
 #pragma unroll
-                    for (int tap = 0; tap < 9; ++tap) mfma_32x32x16_lp(a, b[tap], acc[tap], g.f16 ? 3 : 1);
+                    for (int kw = 0; kw < 3; ++kw) mfma_32x32x16_lp(a, b[kw], acc[kw], g.f16 ? 3 : 1);
                 }
             }
         } else {
-#pragma unroll 2
-        for (int kk = 0; kk < 16; ++kk) {
-            const int pi = 2 * kk + hi, prow = wave * T::RW + pi / TW, pcol = pi % TW;
-            const float a = (l31 < CG) ? dyt[(wave * 32 + pi) * PP + l31] : 0.f;
-            const float* pb = patch + (prow * T::PW + pcol) * PP + (l31 < CG ? l31 : 0);
+#pragma unroll 4
+            for (int kk = 0; kk < 64; ++kk) {      // k = pixel 2 kk + hi of the tile
+                const int pi = 2 * kk + hi, prow = pi / TW, pcol = pi % TW;
+                const float a = dyt[pi * PP + l31];
+                const float* pb = patch + ((prow + wave) * T::PW + pcol) * PP + l31;
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int kh = tap / 3, kw = tap - kh * 3;
-                const float bv = (l31 < CG) ? pb[(kh * T::PW + kw) * PP] : 0.f;
-                mfma_32x32x2(a, bv, acc[tap]);
+                for (int kw = 0; kw < 3; ++kw) mfma_32x32x2(a, pb[kw * PP], acc[kw]);
             }
         }
-        }
     }
-    // reduce the 4 waves through LDS (all waves store their accumulator of one tap, then every thread sums 4 copies of 4 elements), then
-    // one partial panel per block: part[block][tap][co (32)][ci (32)]
-    __syncthreads();                               // the MFMAs are done with patch / dyt: their memory is reused as red[4][32][33]
-    float* red = patch;                            // 4 * 32 * 33 floats = 16.5 KB <= the patch + dyt allocation that follows it
-    for (int tap = 0; tap < 9; ++tap) {
+    // the wave's three taps of the block's partial panel: rows co < 24 only (accumulator elements 12..15 are rows 24..31)
+    float* pp = part + ((long)blockIdx.x * 9 + 3 * wave) * 1024 + l31;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
+    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int e = 0; e < 12; ++e) {
             const int i = (e & 3) + 8 * (e >> 2) + 4 * hi;
-            red[(wave * 32 + i) * 33 + l31] = acc[tap][e];
+            pp[kw * 1024 + i * 32] = acc[kw][e];
         }
-        __syncthreads();
-        for (int i = tid; i < 1024; i += 256) {
-            const int o = (i >> 5) * 33 + (i & 31);
-            part[((long)blockIdx.x * 9 + tap) * 1024 + i] = (red[o] + red[32 * 33 + o]) + (red[2 * 32 * 33 + o] + red[3 * 32 * 33 + o]);
-        }
-        __syncthreads();
-    }
 }
 
 __global__ void __launch_bounds__(256) conv3x3_grouped_wgrad_reduce_kernel(const float* __restrict__ part, int nb, float* __restrict__ dw, int accumulate) {
@@ -328,7 +347,8 @@ __global__ void __launch_bounds__(256, 2) conv3x3_grouped_s2_dgrad_kernel(const 
     __shared__ float wl[9 * CG][WP];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int grp = blockIdx.x / g.nb, sub = blockIdx.x - grp * g.nb, coff = grp * CG;
-    load_group_weights(wl, w + (long)grp * CG * 9 * CG, 1);      // wl[tap'][co][ci] = W[co][8 - tap'][ci]: tap (kh, kw) sits at tap' = 8 - (3 kh + kw)
+    GroupWeightRegs wreg;
+    issue_group_weights(wreg, w + (long)grp * CG * 9 * CG);
     float4 pre[NV];
     auto fetch = [&](int t) {      // dY patch rows h0 .. h0 + TH, columns w0 .. w0 + TW (zero outside the dY map); g.H / g.W = the dY extent
         const int b = t / (g.tiles_h * g.tiles_w), r = t - b * (g.tiles_h * g.tiles_w);
@@ -344,6 +364,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_grouped_s2_dgrad_kernel(const 
     };
     int tile = sub;
     if (tile < g.ntiles) fetch(tile);
+    scatter_group_weights(wl, wreg, 1);      // wl[tap'][co][ci] = W[co][8 - tap'][ci]: tap (kh, kw) sits at tap' = 8 - (3 kh + kw)
     const int prow = wave * RW + l31 / TW, pcol = l31 % TW;
     for (; tile < g.ntiles; tile += g.nb) {
         __syncthreads();
@@ -493,17 +514,22 @@ extern "C" int tf_conv3x3_grouped_dgrad_f32(const float* dy, const float* w, flo
     return launch_status("tf_conv3x3_grouped_dgrad_f32");
 }
 
-extern "C" long tf_conv3x3_grouped_wgrad_ws_floats(void) { return (long)(kMaxBlocks + 64) * 9216; }
+constexpr int kWgradMaxBlocks = 1536;   // partial panels in the workspace (36 KB each)
+extern "C" long tf_conv3x3_grouped_wgrad_ws_floats(void) { return (long)kWgradMaxBlocks * 9216; }
 
 extern "C" int tf_conv3x3_grouped_wgrad_f32(const float* dy, const float* x, float* dw, int B, int H, int W, int C, int accumulate, float* ws, void* stream) {
-    TF_REQUIRE(args_ok(dy, x, dw, B, H, W, C) && ws, "tf_conv3x3_grouped_wgrad_f32: needs C %% 24 == 0 and ws of tf_conv3x3_grouped_wgrad_ws_floats() floats");
+    TF_REQUIRE(args_ok(dy, x, dw, B, H, W, C) && ws && aligned16(dy), "tf_conv3x3_grouped_wgrad_f32: needs C %% 24 == 0 and ws of tf_conv3x3_grouped_wgrad_ws_floats() floats");
     const int tw = pick_tw(H, W);
-    // every block ends with a 36 KB partial panel + the cross-wave reduction: give a block ~6+ tiles of work (one block per CU)
-    GcGeom g = make_geom(B, H, W, C, tw, 256);
-    if (g.nb > 1 && g.ntiles / g.nb < 6) { g.nb = g.ntiles / 6; if (g.nb < 1) g.nb = 1; }
-    TF_REQUIRE((long)g.G * g.nb * 9216 <= tf_conv3x3_grouped_wgrad_ws_floats(), "tf_conv3x3_grouped_wgrad_f32: %d groups exceed the workspace", g.G);
+    // three-wave blocks, four to five per CU: ~700 blocks put two waves on every SIMD; a block takes at least two tiles when there are enough
+    // (every block ends with a 27 KB partial panel that the reduce kernel reads back)
+    GcGeom g = make_geom(B, H, W, C, tw, 1024);
+    int tpb = cdiv(g.ntiles, g.nb);                     // tiles per block, balanced: every block takes tpb or tpb - 1 tiles
+    if (tpb < 2 && g.ntiles >= 2) tpb = 2;
+    g.nb = cdiv(g.ntiles, tpb);
+    if ((long)g.G * g.nb > kWgradMaxBlocks) g.nb = kWgradMaxBlocks / g.G;
+    TF_REQUIRE(g.nb >= 1, "tf_conv3x3_grouped_wgrad_f32: %d groups exceed the workspace", g.G);
     const int prec = direct_prec();
-#define TF_GW(TW_, P_) TF_LAUNCH((conv3x3_grouped_wgrad_kernel<TW_, P_>), dim3(g.G * g.nb), dim3(256), stream, x, dy, ws, g)
+#define TF_GW(TW_, P_) TF_LAUNCH((conv3x3_grouped_wgrad_kernel<TW_, P_>), dim3(g.G * g.nb), dim3(192), stream, x, dy, ws, g)
     if (tw == 16) { if (prec == 2) TF_GW(16, 2); else if (prec == 1 || prec == 3) TF_GW(16, 1); else TF_GW(16, 0); }
     else { if (prec == 2) TF_GW(32, 2); else if (prec == 1 || prec == 3) TF_GW(32, 1); else TF_GW(32, 0); }
 #undef TF_GW

@@ -8,50 +8,35 @@
 //   * decode_pil_to_npy + load_crop_bev_npy (data.py:844-856, 586-612): bit-unpack of the encoded top-down map, 7-row shift, rotation by
 //     the augmentation angle (bilinear, skimage.transform.rotate's centre / direction convention), 160 x 160 crop, 3-class argmax.
 #include "tf_common.h"
+#include "tf_hist.h"
 #include "../../include/transfuser_hip.h"
 
 using namespace tf;
 
 namespace {
 
-constexpr int HIST_ROWS = 8;
-
 // pts (B, max_pts, stride >= 4) fp32 as loaded by data.py:166-170 (y already negated at load time); T (B, 16) row-major fp64 =
 // degree_matrix @ Tr_vehicle_to_lidar @ inv(M1) @ M0 @ Tr_lidar_to_vehicle.  align(): p = (x, -y, z, 1); q = T p; (x', y', z') = (q0, -q1, q2).
 __global__ void __launch_bounds__(256) lidar_align_hist_kernel(const float* __restrict__ pts, const int32_t* __restrict__ npts, int max_pts, int stride,
-                                                               const double* __restrict__ T, float* __restrict__ out, float* __restrict__ aligned) {
-    __shared__ int bins[2][HIST_ROWS][256];
-    __shared__ double t[12];
-    const int b = blockIdx.y, slab = blockIdx.x, tid = threadIdx.x;
-    for (int i = tid; i < 2 * HIST_ROWS * 256; i += 256) (&bins[0][0][0])[i] = 0;
-    if (tid < 12) t[tid] = T[(long)b * 16 + tid];
-    __syncthreads();
+                                                               int vec4, const double* __restrict__ T, int* __restrict__ counters, float* __restrict__ aligned) {
+    const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
     const int n = npts ? (npts[b] < max_pts ? npts[b] : max_pts) : max_pts;
-    const float* p = pts + (long)b * max_pts * stride;
-    const int y0 = slab * HIST_ROWS;
-    for (int i = tid; i < n; i += 256) {
-        const double px = p[(long)i * stride], py = -(double)p[(long)i * stride + 1], pz = p[(long)i * stride + 2];
-        // numpy evaluates the row-times-vector dot products left to right in double: ((t0 x + t1 y) + t2 z) + t3
-        const double x = ((t[0] * px + t[1] * py) + t[2] * pz) + t[3];
-        const double y = -(((t[4] * px + t[5] * py) + t[6] * pz) + t[7]);
-        const double z = ((t[8] * px + t[9] * py) + t[10] * pz) + t[11];
-        if (aligned && slab == 0) {     // optional: the aligned cloud itself (PointPillars input, data.py:247-251), fp32 like the collated batch
-            float* q = aligned + ((long)b * max_pts + i) * 4;
-            q[0] = (float)x; q[1] = (float)y; q[2] = (float)z; q[3] = p[(long)i * stride + 3];
-        }
-        if (!(x >= -16.0 && x <= 16.0 && y >= -32.0 && y <= 0.0)) continue;
-        int xb = (int)floor(x * 8.0) + 128; if (xb > 255) xb = 255;
-        int yb = (int)floor(y * 8.0) + 256; if (yb > 255) yb = 255;
-        const int r = yb - y0;
-        if (r < 0 || r >= HIST_ROWS) continue;
-        atomicAdd(&bins[(z <= -2.3) ? 1 : 0][r][255 - xb], 1);
+    const int ic = i < max_pts ? i : max_pts - 1;          // clamped address, unconditional loads (tf_hist.h)
+    const float* p = pts + ((long)b * max_pts + ic) * stride;
+    float fx, fy, fz, fw;
+    if (vec4) { const float4 v = *reinterpret_cast<const float4*>(p); fx = v.x; fy = v.y; fz = v.z; fw = v.w; }
+    else { fx = p[0]; fy = p[1]; fz = p[2]; fw = p[3]; }
+    const double* t = T + (long)b * 16;                    // wave-uniform: scalar loads
+    const double px = fx, py = -(double)fy, pz = fz;
+    // numpy evaluates the row-times-vector dot products left to right in double: ((t0 x + t1 y) + t2 z) + t3
+    const double x = ((t[0] * px + t[1] * py) + t[2] * pz) + t[3];
+    const double y = -(((t[4] * px + t[5] * py) + t[6] * pz) + t[7]);
+    const double z = ((t[8] * px + t[9] * py) + t[10] * pz) + t[11];
+    if (aligned && i < n) {             // optional: the aligned cloud itself (PointPillars input, data.py:247-251), fp32 like the collated batch
+        float* q = aligned + ((long)b * max_pts + i) * 4;
+        q[0] = (float)x; q[1] = (float)y; q[2] = (float)z; q[3] = fw;
     }
-    __syncthreads();
-    for (int i = tid; i < 2 * HIST_ROWS * 256; i += 256) {
-        const int c = i / (HIST_ROWS * 256), r = (i / 256) % HIST_ROWS, col = i % 256;
-        const int cnt = bins[c][r][col];
-        out[(((long)b * 2 + c) * 256 + (y0 + r)) * 256 + col] = (float)(cnt < 5 ? cnt : 5) / 5.0f;
-    }
+    hist_add(counters + (long)b * 2 * 256 * 256, i < n ? hist_cell<double>(x, y, z) : -1);
 }
 
 // mode 0: rgb  -> out f32 (B, C, ch, cw) = src[b, sy + y, sx_b + x, c]
@@ -134,7 +119,15 @@ inline int blocks_for(long total) { long b = (total + 255) / 256; return (int)(b
 extern "C" int tf_lidar_align_hist_f64(const float* points, const int32_t* num_points, int B, int max_points, int point_stride, const double* transforms,
                                        float* out, float* aligned_or_null, void* stream) {
     TF_REQUIRE(points && transforms && out && B > 0 && max_points >= 0 && point_stride >= 4, "tf_lidar_align_hist_f64: bad arguments");
-    TF_LAUNCH(lidar_align_hist_kernel, dim3(256 / HIST_ROWS, B), dim3(256), stream, points, num_points, max_points, point_stride, transforms, out, aligned_or_null);
+    TF_REQUIRE(aligned16(out), "tf_lidar_align_hist_f64: out must be 16-byte aligned");
+    const long n4 = (long)B * 2 * 256 * 256 / 4;
+    TF_LAUNCH(hist_clear_kernel, dim3(cdiv(n4, 256)), dim3(256), stream, reinterpret_cast<float4*>(out), n4);
+    if (max_points > 0) {
+        const int vec4 = (point_stride == 4 && aligned16(points)) ? 1 : 0;
+        TF_LAUNCH(lidar_align_hist_kernel, dim3(cdiv(max_points, 256), B), dim3(256), stream, points, num_points, max_points, point_stride, vec4, transforms,
+                  reinterpret_cast<int*>(out), aligned_or_null);
+    }
+    TF_LAUNCH(hist_finish_kernel, dim3(cdiv(n4, 256)), dim3(256), stream, reinterpret_cast<float4*>(out), n4);
     return launch_status("tf_lidar_align_hist_f64");
 }
 

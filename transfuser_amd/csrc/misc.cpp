@@ -1,5 +1,6 @@
 // Small elementwise kernels, multi-tensor AdamW, LiDAR histogram.
 #include "tf_common.h"
+#include "tf_hist.h"
 #include "../../include/transfuser_hip.h"
 
 using namespace tf;
@@ -94,36 +95,20 @@ __global__ void __launch_bounds__(256) adamw_kernel(float* __restrict__ p, const
 // LiDAR -> 2-bin BEV histogram (data.py:446-470), integer-exact:
 //   valid iff -16 <= x <= 16 and -32 <= y <= 0; xbin = min(floor(8x) + 128, 255), ybin = min(floor(8y) + 256, 255)
 //   channel = (z <= -2.3) ? 1 : 0;  out[c][ybin][255 - xbin] = min(count, 5) / 5
-// One block owns a slab of HIST_ROWS output rows of one sample, scans the sample's points (L2
-// resident) and counts into LDS integer bins, then writes its slab with coalesced stores: no
-// global atomics, no zero-fill pass, bit-reproducible.
-constexpr int HIST_ROWS = 8;
-__global__ void __launch_bounds__(256) lidar_hist_kernel(const float* __restrict__ pts, const int32_t* __restrict__ npts, int max_pts, int stride,
-                                                         float* __restrict__ out) {
-    __shared__ int bins[2][HIST_ROWS][256];
-    const int b = blockIdx.y, slab = blockIdx.x, tid = threadIdx.x;
-    for (int i = tid; i < 2 * HIST_ROWS * 256; i += 256) (&bins[0][0][0])[i] = 0;
-    __syncthreads();
+// Single pass over the cloud: clear + one-thread-per-point counting with int32 atomics on the output's own storage + in-place
+// min(cnt, 5) / 5 (tf_hist.h).  Bit-reproducible (integer counters).
+__global__ void __launch_bounds__(256) lidar_hist_count_kernel(const float* __restrict__ pts, const int32_t* __restrict__ npts, int max_pts, int stride,
+                                                               int vec4, int* __restrict__ counters) {
+    const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
     const int n = npts ? (npts[b] < max_pts ? npts[b] : max_pts) : max_pts;
-    const float* p = pts + (long)b * max_pts * stride;
-    const int y0 = slab * HIST_ROWS;
-    for (int i = tid; i < n; i += 256) {
-        const float x = p[(long)i * stride], y = p[(long)i * stride + 1], z = p[(long)i * stride + 2];
-        if (!(x >= -16.f && x <= 16.f && y >= -32.f && y <= 0.f)) continue;
-        int xb = (int)floorf(x * 8.f) + 128; if (xb > 255) xb = 255;
-        int yb = (int)floorf(y * 8.f) + 256; if (yb > 255) yb = 255;
-        const int r = yb - y0;
-        if (r < 0 || r >= HIST_ROWS) continue;
-        atomicAdd(&bins[(z <= -2.3f) ? 1 : 0][r][255 - xb], 1);
-    }
-    __syncthreads();
-    for (int i = tid; i < 2 * HIST_ROWS * 256; i += 256) {
-        const int c = i / (HIST_ROWS * 256), r = (i / 256) % HIST_ROWS, col = i % 256;
-        const int cnt = bins[c][r][col];
-        out[(((long)b * 2 + c) * 256 + (y0 + r)) * 256 + col] = (float)(cnt < 5 ? cnt : 5) / 5.0f;
-    }
+    const int ic = i < max_pts ? i : max_pts - 1;          // clamped address: the load is unconditional, the predicate applies to the cell
+    const float* p = pts + ((long)b * max_pts + ic) * stride;
+    float x, y, z;
+    if (vec4) { const float4 v = *reinterpret_cast<const float4*>(p); x = v.x; y = v.y; z = v.z; }
+    else { x = p[0]; y = p[1]; z = p[2]; }
+    const int cell = hist_cell<float>(x, y, z);
+    hist_add(counters + (long)b * 2 * 256 * 256, i < n ? cell : -1);
 }
-
 }  // namespace
 
 extern "C" int tf_relu_mask_f32(const float* dy, const float* y, float* out, int64_t n, void* stream) {
@@ -187,6 +172,14 @@ extern "C" int tf_adamw_scaled_f32(float* p, const float* g, float* m, float* v,
 }
 extern "C" int tf_lidar_hist_f32(const float* points, const int32_t* num_points, int B, int max_points, int point_stride, float* out, void* stream) {
     TF_REQUIRE(points && out && B > 0 && max_points >= 0 && point_stride >= 3, "tf_lidar_hist_f32: bad arguments");
-    TF_LAUNCH(lidar_hist_kernel, dim3(256 / HIST_ROWS, B), dim3(256), stream, points, num_points, max_points, point_stride, out);
+    TF_REQUIRE(aligned16(out), "tf_lidar_hist_f32: out must be 16-byte aligned");
+    const long n4 = (long)B * 2 * 256 * 256 / 4;
+    TF_LAUNCH(hist_clear_kernel, dim3(cdiv(n4, 256)), dim3(256), stream, reinterpret_cast<float4*>(out), n4);
+    if (max_points > 0) {
+        const int vec4 = (point_stride == 4 && aligned16(points)) ? 1 : 0;
+        TF_LAUNCH(lidar_hist_count_kernel, dim3(cdiv(max_points, 256), B), dim3(256), stream, points, num_points, max_points, point_stride, vec4,
+                  reinterpret_cast<int*>(out));
+    }
+    TF_LAUNCH(hist_finish_kernel, dim3(cdiv(n4, 256)), dim3(256), stream, reinterpret_cast<float4*>(out), n4);
     return launch_status("tf_lidar_hist_f32");
 }
