@@ -143,13 +143,16 @@ def replica_check(eng, batch, rank, world, dev, log):
     exposed = eng.reducer.exposed_ms()
     eng.reducer.time_waits = False
     p = eng.arena.params[:eng.arena.active_numel]
-    mine = torch.stack([p.double().sum(), p.view(torch.int32).to(torch.int64).sum().double(), torch.tensor(exposed, dtype=torch.float64, device=dev)])
+    # the exact checksum is a 64-bit integer: it travels as two 32-bit halves (a float64 holds only 53 bits of the ~1e17 sum)
+    bits = p.view(torch.int32).to(torch.int64).sum()
+    mine = torch.stack([p.double().sum(), (bits >> 32).double(), (bits & 0xffffffff).double(), torch.tensor(exposed, dtype=torch.float64, device=dev)])
     rows = [torch.zeros_like(mine) for _ in range(world)]
     if world > 1:
         dist.all_gather(rows, mine)
     else:
         rows = [mine]
     rows = [r.cpu().tolist() for r in rows]
+    rows = [[r[0], (int(r[1]) << 32) | int(r[2]), r[3]] for r in rows]
     print("[bench check] rank %d: allreduce_exposed_ms %.3f, param checksum %.9e / bits %d" % (rank, exposed, rows[rank][0], int(rows[rank][1])), file=sys.stderr, flush=True)
     equal = all(r[0] == rows[0][0] and r[1] == rows[0][1] for r in rows)
     assert equal, "replicas diverged: per-rank parameter checksums %s" % [(r[0], int(r[1])) for r in rows]

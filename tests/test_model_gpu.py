@@ -261,6 +261,37 @@ def test_dropout_paths_match_oracle_on_gpu():
     mc.check_dropout_gpt_stage("cuda", C=216, B=2, n_layer=2, p=0.1)
 
 
+def test_late_fusion_backbone_tiny_and_regnety032_on_gpu():
+    """SURVEY 8f-4 on the MI355X (late_fusion.py:5-111; round 3 only had the host emulator): the tiny trunks with and without the velocity
+    embedding (all 11 losses + every parameter gradient vs the oracle), then the real RegNetY-3.2GF trunks at the reference resolution
+    anchored on fp64 (compare_vs_fp64)."""
+    cfg = mc.tiny_config(n_layer=1, lidar_res=128)
+    for use_vel in (False, True):
+        prod, ref = mc.build_pair(cfg, "regnety_tiny", "cuda", backbone="late_fusion", use_velocity=use_vel)
+        batch = mc.small_batch(2, 32, 64, 128, 40)
+        lp, lr = mc.run_pair(prod, ref, cfg, batch, "cuda")
+        mc.compare(prod, ref, lp, lr, grad_tol=1e-2, metric="l2")
+    mc.check_full_size_vs_fp64("late_fusion", 2, 160)
+
+
+def test_use_velocity_transfuser_on_gpu():
+    """--use_velocity 1 through the TransFuser GPT (transfuser.py:309,352-355, train.py:54: the velocity embedding added to every token) on
+    the MI355X: tiny trunks with an odd image size, then the real architecture at 160x704 against fp64."""
+    cfg = mc.tiny_config(n_layer=1)
+    prod, ref = mc.build_pair(cfg, "regnety_tiny", "cuda", use_velocity=True)
+    batch = mc.small_batch(1, 64, 96, 64, 40, seed=3)
+    lp, lr = mc.run_pair(prod, ref, cfg, batch, "cuda")
+    mc.compare(prod, ref, lp, lr)
+    assert prod._model.transformer1.vel_emb.weight.grad is not None and prod._model.transformer1.vel_emb.weight.grad.abs().sum().item() > 0
+    mc.check_full_size_vs_fp64("transFuser", 2, 160, use_velocity=True)
+
+
+def test_f32x3_bench_configuration_parity_B10_H256():
+    """The f32x3 line of the bench (fp32-accurate bf16x3 split contractions) ON the benchmarked configuration - B=10, 256x704, shipped plans -
+    held to exactly the bounds of test_bench_configuration_parity_B10_H256 (losses / outputs 1e-3, gradients vs the fp32 oracle)."""
+    mc.check_full_size_vs_fp32_oracle("transFuser", 10, 256, precision="f32x3")
+
+
 def test_latentTF_full_size_B16_H256_parity():
     """BASELINE configs[4] at its own batch size (latentTF.py:118-217, bs=16/GPU, 3x256x704): real RegNetY-3.2GF trunks, shipped plans."""
     mc.check_full_size_vs_fp64("latentTF", 16, 256)
@@ -339,6 +370,127 @@ def test_single_block_gradients_within_1e3():
         if "attn.key.bias" in n:
             continue                                       # exact gradient is 0 (softmax shift invariance): only round-off on both sides
         assert rel(p.grad, pgo[n].grad) <= 1e-3, (n, rel(p.grad, pgo[n].grad))
+
+
+def test_decoder_and_head_block_gradients_within_1e3():
+    """The 1e-3 gradient bound at block level for the two remaining kinds of block (round-3 verdict): (1) a segmentation decoder
+    (transfuser.py:214-246: 3x3 convs + ReLU + two bilinear up-samplings + the thin-output last layer, i.e. the engine, direct, thin and
+    up-sampling kernels chained) and (2) the CenterNet heads + pred_bev on p2 (model.py:127-147,581-585: 8 x [3x3 conv 64 -> 64, ReLU, 1x1
+    conv], one autograd node) - product kernels vs PyTorch-CPU fp32 autograd on identical weights: outputs, input gradient and every
+    parameter gradient, max-norm relative error <= 1e-3."""
+    from transfuser_amd import transfuser as ptf
+    from oracle import transfuser_cpu as otf
+
+    def rel(a, b):
+        return (a.detach().cpu().float() - b.detach()).abs().max().item() / max(b.detach().abs().max().item(), 1e-6)
+    torch.manual_seed(0)
+    cfg = mc.full_config()
+    # ---- (1) SegDecoder on a (B, 512, 8, 22) grid -> (B, 7, 256, 704) logits (deconv scale factors 8 and 4, config.py:92-93)
+    od = otf.SegDecoder(cfg, cfg.perception_output_features)
+    pd = ptf.SegDecoder(cfg, cfg.perception_output_features).cuda()
+    pd.load_state_dict(od.state_dict(), strict=True)
+    for m in pd.modules():
+        if isinstance(m, torch.nn.Conv2d):
+            m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
+    po = dict(od.named_parameters())
+
+    def run_decoder(B, gh, gw):
+        x = torch.randn(B, cfg.perception_output_features, gh, gw)
+        xo = x.clone().requires_grad_(True)
+        for q in od.parameters():
+            q.grad = None
+        yo = od(xo)
+        dy = torch.randn_like(yo)
+        yo.backward(dy)
+        for q in pd.parameters():
+            q.grad = None
+        xp = x.permute(0, 2, 3, 1).contiguous().cuda().requires_grad_(True)
+        yp = pd.forward_nhwc(xp)
+        yp.backward(dy.permute(0, 2, 3, 1).contiguous().cuda())
+        return yp.permute(0, 3, 1, 2), yo, xp.grad.permute(0, 3, 1, 2), xo.grad
+    # max-norm at 2 x 128 x 352 (the direct / thin kernels engage from 64 K pixels): 2.9 M ReLU units per layer - none within round-off of its kink
+    yp, yo, gp, go = run_decoder(2, 4, 11)
+    assert rel(yp, yo) <= 1e-3
+    assert rel(gp, go) <= 1e-3, rel(gp, go)
+    for n, p in pd.named_parameters():
+        assert rel(p.grad, po[n].grad) <= 1e-3, ("decoder", n, rel(p.grad, po[n].grad))
+    # The full 256 x 704 map has 17 M ReLU units per layer: a handful sit within fp32 round-off of their kink and take the other side in two
+    # summation orders (measured on this chain: hip vs fp64 dx 1.9e-3 in L2 with EVERY operation exact to 3e-7, tools/diag_decoder2.py), so
+    # at full size each backward operation of the chain is checked in ISOLATION against fp64 on the oracle's exact inputs: 1e-5.
+    import torch.nn.functional as Fn
+    from transfuser_amd import ops
+    l2 = lambda a, b: ((a.detach().cpu().double() - b.detach().double()).norm() / b.detach().double().norm()).item()
+    nh = lambda t: t.permute(0, 2, 3, 1).contiguous().float().cuda()
+    for (Cin, Cout, H, W) in [(32, 7, 256, 704), (32, 32, 256, 704), (64, 32, 64, 176), (64, 64, 64, 176), (256, 64, 8, 22)]:
+        x = torch.randn(3, Cin, H, W, dtype=torch.float64).relu()
+        w = torch.randn(Cout, Cin, 3, 3, dtype=torch.float64) * (1.0 / (3 * Cin ** 0.5))
+        xg, wg = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        y = Fn.conv2d(xg, wg, None, 1, 1)
+        dy = torch.randn_like(y)
+        y.backward(dy)
+        xh, wh, dyh = nh(x), w.float().contiguous(memory_format=torch.channels_last).cuda(), nh(dy)
+        dw = torch.zeros_like(wh)
+        ops.conv_wgrad(dyh, xh, dw, 1, 1, 1)
+        errs = (l2(ops.conv_fwd(xh, wh, None, 1, 1, 1, False).permute(0, 3, 1, 2), y), l2(ops.conv_dgrad(dyh, wh, xh.shape, 1, 1, 1).permute(0, 3, 1, 2), xg.grad),
+                l2(ops.conv_dgrad(dyh, wh, xh.shape, 1, 1, 1, mask=xh).permute(0, 3, 1, 2), xg.grad * (x > 0)), l2(dw, wg.grad))
+        assert max(errs) <= 1e-5, ("conv3x3 %d -> %d at %dx%d (fwd, dgrad, dgrad + ReLU mask, wgrad)" % (Cin, Cout, H, W), errs)
+    for (C, H, W, sc) in [(32, 64, 176, 4), (64, 8, 22, 8)]:
+        x = torch.randn(3, C, H, W, dtype=torch.float64, requires_grad=True)
+        y = Fn.interpolate(x, scale_factor=sc, mode="bilinear", align_corners=False)
+        dy = torch.randn_like(y)
+        y.backward(dy)
+        errs = (l2(ops.bilinear_fwd(nh(x.detach()), 3, C, H, W, H * sc, W * sc, align_corners=False).permute(0, 3, 1, 2), y),
+                l2(ops.bilinear_bwd(nh(dy), 3, C, H, W, H * sc, W * sc, align_corners=False).permute(0, 3, 1, 2), x.grad))
+        assert max(errs) <= 1e-5, ("bilinear x%d" % sc, errs)
+    # ---- (2) heads + pred_bev on p2 (B, 64, 64, 64): the product's single HeadsFn node vs the oracle's seven head Sequentials + pred_bev
+    from transfuser_amd.model import HeadsFn
+    tcfg = mc.tiny_config(n_layer=1)
+    prod, ref = mc.build_pair(tcfg, "regnety_tiny", "cuda")
+    C = prod.head.heatmap_head[0].weight.shape[1]
+    p2 = torch.randn(3, C, 64, 64)
+    p2o = p2.clone().requires_grad_(True)
+    outs = [h(p2o) for h in (ref.head.heatmap_head, ref.head.wh_head, ref.head.offset_head, ref.head.yaw_class_head, ref.head.yaw_res_head,
+                             ref.head.velocity_head, ref.head.brake_head)]
+    pred_o = torch.cat(outs, 1)
+    bev_o = ref.pred_bev(p2o)
+    dpred, dbev = torch.randn_like(pred_o), torch.randn_like(bev_o)
+    torch.autograd.backward([pred_o, bev_o], [dpred, dbev])
+    for q in prod.parameters():
+        q.grad = None
+    p2p = p2.permute(0, 2, 3, 1).contiguous().cuda().requires_grad_(True)
+    pred_p, bev_p = HeadsFn.apply(p2p, prod, *prod.head.parameters(), *prod.pred_bev.parameters())
+    torch.autograd.backward([pred_p, bev_p], [dpred.permute(0, 2, 3, 1).contiguous().cuda(), dbev.permute(0, 2, 3, 1).contiguous().cuda()])
+    assert rel(pred_p.permute(0, 3, 1, 2), pred_o) <= 1e-3 and rel(bev_p.permute(0, 3, 1, 2), bev_o) <= 1e-3
+    # 6.3 M hidden ReLU units: the few whose fp64 pre-activation lies within fp32 forward round-off of 0 may take either side of the kink in
+    # ANY fp32 implementation.  They are identified from the fp64 forward and only what such a unit can touch is exempted: the 3x3
+    # neighbourhood of its pixel in dp2, row c of its head's 3x3 weight gradient and entry c of that bias gradient.  Everything else: 1e-3.
+    seqs = [getattr(ref.head, n) for n in ("heatmap_head", "wh_head", "offset_head", "yaw_class_head", "yaw_res_head", "velocity_head", "brake_head")] + [ref.pred_bev]
+    names = ["head.%s" % n for n in ("heatmap_head", "wh_head", "offset_head", "yaw_class_head", "yaw_res_head", "velocity_head", "brake_head")] + ["pred_bev"]
+    touched = torch.zeros(3, 1, 64, 64, dtype=torch.bool)
+    fragile_rows = {}
+    for nm, sq in zip(names, seqs):
+        z = torch.nn.functional.conv2d(p2.double(), sq[0].weight.detach().double(), sq[0].bias.detach().double(), 1, 1)
+        frag = z.abs() < 5e-6 * z.std()          # ~20x the fp32 forward round-off of a K = 576 dot product
+        fragile_rows[nm] = set(torch.nonzero(frag.any(0).any(-1).any(-1)).flatten().tolist())
+        touched |= torch.nn.functional.max_pool2d(frag.any(1, keepdim=True).float(), 3, 1, 1) > 0
+    n_frag = sum(len(v) for v in fragile_rows.values())
+    print("  heads block: %d fragile hidden channels rows, %.4f %% of the dp2 pixels exempt" % (n_frag, 100.0 * touched.float().mean().item()))
+    assert touched.float().mean().item() <= 3e-2 and n_frag <= 64, (touched.float().mean().item(), n_frag)
+    keep = (~touched).expand(-1, C, -1, -1)
+    gp, go = p2p.grad.permute(0, 3, 1, 2).detach().cpu(), p2o.grad
+    assert ((gp - go).abs() * keep).max().item() <= 1e-3 * go.abs().max().item(), ((gp - go).abs() * keep).max().item() / go.abs().max().item()
+    rp = dict(ref.named_parameters())
+    checked = 0
+    for n, p in prod.named_parameters():
+        if n.startswith("head.") or n.startswith("pred_bev."):
+            g, gr = p.grad.detach().cpu().float(), rp[n].grad
+            owner = n.rsplit(".", 2)[0]
+            if n.endswith(".0.weight") or n.endswith(".0.bias"):      # the 3x3 layer in front of the ReLU: fragile channels' rows are exempt
+                rows = [r for r in range(g.shape[0]) if r not in fragile_rows[owner]]
+                g, gr = g[rows], gr[rows]
+            assert (g - gr).abs().max().item() <= 1e-3 * gr.abs().max().item(), ("heads", n, (g - gr).abs().max().item() / gr.abs().max().item())
+            checked += 1
+    assert checked == 32, checked
 
 
 def test_f32x3_split_mode_model_parity():

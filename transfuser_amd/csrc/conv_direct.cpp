@@ -23,14 +23,31 @@ constexpr int NV = (PH * PW * 8 + 255) / 256;  // float4 patch slots per thread
 
 struct DcGeom { int B, H, W, Ci, Co, tiles_h, tiles_w, ntiles, f16; };   // f16: the PREC 1 paths use IEEE-half operands (tf_set_precision(3))
 
-// stage W into LDS as wl[(tap, k)][n]: fwd  wl[tap][ci][co] = Wt[co][tap][ci];  dgrad  wl[tap][co][ci] = Wt[co][8 - tap][ci]
-__device__ __forceinline__ void load_weights(float (*wl)[WP], const float* __restrict__ w, int CoW, int CiW, int dgrad) {
-    for (int i = threadIdx.x; i < 9 * 32 * 32; i += 256) {
+// stage W into LDS as wl[(tap, k)][n]: fwd  wl[tap][ci][co] = Wt[co][tap][ci];  dgrad  wl[tap][co][ci] = Wt[co][8 - tap][ci].
+// Wt is CoW x 9 x CiW <= 9216 CONTIGUOUS floats: a thread issues its (up to 36) loads back to back from clamped addresses, the first patch's
+// loads follow, and only then is the panel scattered into LDS (round 3: one predicated element per loop trip = 36 dependent round trips,
+// ~30 us in front of every launch).
+constexpr int WNL = 9 * 32 * 32 / 256;
+struct WeightRegs { float v[WNL]; };
+__device__ __forceinline__ void issue_weights(WeightRegs& r, const float* __restrict__ w, int CoW, int CiW) {
+    const int ne = CoW * 9 * CiW;
+#pragma unroll
+    for (int p = 0; p < WNL; ++p) { const int e = threadIdx.x + p * 256; r.v[p] = w[e < ne ? e : ne - 1]; }
+}
+__device__ __forceinline__ void scatter_weights(float (*wl)[WP], const WeightRegs& r, int CoW, int CiW, int dgrad) {
+    const int ne = CoW * 9 * CiW, row = 9 * CiW;
+    for (int i = threadIdx.x; i < 9 * 32 * 32; i += 256) {         // the zero padding of a panel narrower than 32 x 32 (slots the scatter never writes)
         const int n = i & 31, k = (i >> 5) & 31, tap = i >> 10;
-        float v = 0.f;
-        if (!dgrad) { if (n < CoW && k < CiW) v = w[((long)n * 9 + tap) * CiW + k]; }
-        else { if (k < CoW && n < CiW) v = w[((long)k * 9 + (8 - tap)) * CiW + n]; }
-        wl[tap * 32 + k][n] = v;
+        const bool used = dgrad ? (k < CoW && n < CiW) : (n < CoW && k < CiW);
+        if (!used) wl[tap * 32 + k][n] = 0.f;
+    }
+#pragma unroll
+    for (int p = 0; p < WNL; ++p) {
+        const int e = threadIdx.x + p * 256;
+        const int co = e / row, q = e - co * row, tap = q / CiW, ci = q - tap * CiW;
+        if (e < ne) {
+            if (dgrad) wl[(8 - tap) * 32 + co][ci] = r.v[p]; else wl[tap * 32 + ci][co] = r.v[p];
+        }
     }
 }
 
@@ -60,7 +77,8 @@ __global__ void __launch_bounds__(256, 2) conv3x3_small_kernel(const float* __re
     __shared__ float patch[PH * PW * PP];
     __shared__ float wl[9 * 32][WP];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
-    load_weights(wl, w, CoW, CiW, dgrad);
+    WeightRegs wreg;
+    issue_weights(wreg, w, CoW, CiW);
     const int kpairs = (g.Ci + 1) >> 1;          // MFMA k-steps per tap (channels padded to even with the zero-filled LDS columns)
     int tile = blockIdx.x;
     float4 pre[NV];
@@ -71,6 +89,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_small_kernel(const float* __re
         for (int p = 0; p < NV; ++p) pre[p] = load_patch_slot<VEC>(x, g, b, h0, w0, tid + p * 256);
     };
     if (tile < g.ntiles) fetch(tile);
+    scatter_weights(wl, wreg, CoW, CiW, dgrad);
     for (; tile < g.ntiles; tile += gridDim.x) {
         __syncthreads();                           // previous tile's MFMAs are done with the patch (and the weights are staged)
 #pragma unroll

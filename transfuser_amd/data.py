@@ -128,7 +128,10 @@ class CARLA_Data(torch.utils.data.Dataset):
             return self._decode(index)
         route_dir, seq = self.frames[index]
         import hashlib
-        path = os.path.join(self.cache_dir, "%s_%04d.pt" % (hashlib.sha1(route_dir.encode()).hexdigest()[:16], seq))
+        # the key covers everything that shapes a decoded item: the route, the decode-affecting config fields and a format version
+        # (a changed max_lidar_points / seq_len / pred_len used to hit stale files)
+        tag = "%s|v2|%d|%d|%d" % (route_dir, getattr(self.config, "max_lidar_points", 0), self.seq_len, self.pred_len)
+        path = os.path.join(self.cache_dir, "%s_%04d.pt" % (hashlib.sha1(tag.encode()).hexdigest()[:16], seq))
         if os.path.exists(path):
             item = torch.load(path)
         else:

@@ -37,6 +37,53 @@ def workspace(device):
     return ws
 
 
+# ---- weight gradients on a side stream (train.Engine, opt-in TF_WGRAD_STREAM=1).  The input-gradient chain is the critical path of the
+# backward; a weight gradient is only needed by AdamW at the end of the step.  Inside ``wgrad_side_stream()`` every weight-gradient launch
+# (the callers accumulate in place into the flat gradient arena) is enqueued on a side stream that waits for the issuing stream's current
+# position (under hipGraph capture: a graph edge), so it runs beside the following input-gradient kernels; ``wgrad_join()`` makes the
+# current stream wait for all of them (before the all-reduce / AdamW).
+_WGRAD_SIDE = bool(int(__import__("os").environ.get("TF_WGRAD_STREAM", "0")))      # round 1 (RegNet blocks only, one stream): 155-158 vs 170 samples/s
+_wg = {"on": False, "streams": {}, "used": []}
+
+
+class wgrad_side_stream:
+    def __enter__(self):
+        self.prev, _wg["on"] = _wg["on"], _WGRAD_SIDE
+
+    def __exit__(self, *a):
+        _wg["on"] = self.prev
+
+
+def wgrad_join():
+    used, _wg["used"] = _wg["used"], []
+    for w in used:
+        torch.cuda.current_stream(w.device).wait_stream(w)
+
+
+def _wgrad_launch(tensors, launch):
+    """Run ``launch`` (which enqueues on torch's current stream) on the side stream of the current stream."""
+    t0 = tensors[0]
+    if not (_wg["on"] and t0.is_cuda) or _wg.get("inside"):
+        return launch()
+    cur = torch.cuda.current_stream(t0.device)
+    w = _wg["streams"].get(cur.cuda_stream)
+    if w is None:
+        w = _wg["streams"][cur.cuda_stream] = torch.cuda.Stream(t0.device)
+    w.wait_stream(cur)
+    _wg["inside"] = True
+    try:
+        with torch.cuda.stream(w):
+            out = launch()
+    finally:
+        _wg["inside"] = False
+    for t in tensors:
+        if t is not None:
+            t.record_stream(w)
+    if w not in _wg["used"]:
+        _wg["used"].append(w)
+    return out
+
+
 def autotune(enable):
     """cudnn.benchmark-style tiling search for the MFMA engine (eager warm-up only: it synchronises)."""
     check(L().tf_autotune(int(bool(enable))), "tf_autotune")
@@ -191,41 +238,10 @@ def wptr(w):
     return ptr(w)
 
 
-# ------------------------------------------------------------------------------------------ weight-gradient stream
-# A layer's weight gradient (dW = f(dy, x)) is off the critical path of the backward pass (only dx feeds the next layer), and many of
-# these launches under-fill the GPU (grouped-conv / small-Cout weight gradients: a few dozen tiles).  wgrad_fork runs them on a second
-# HIP stream - one more parallel branch of the captured hipGraph - so they could overlap the dgrad / BatchNorm chain (experiment).  Inputs are kept alive
-# with record_stream; the join is queued as an autograd-engine callback (end of backward()).
-_WGRAD_FORK = bool(int(__import__("os").environ.get("TF_WGRAD_STREAM", "0")))   # measured SLOWER on the MI355X (155-158 vs 170 samples/s): opt-in
-_wg = {"stream": {}, "pending": False}
-
-
-def _wgrad_join():
-    _wg["pending"] = False
-    for dev, ws in _wg["stream"].items():
-        torch.cuda.current_stream(dev).wait_stream(ws)
-
 
 def wgrad_fork(tensors, fn):
-    t0 = tensors[0]
-    if not (_WGRAD_FORK and t0.is_cuda):
-        return fn()
-    dev = t0.device
-    ws = _wg["stream"].get(dev)
-    if ws is None:
-        ws = _wg["stream"][dev] = torch.cuda.Stream(dev)
-    cur = torch.cuda.current_stream(dev)
-    ws.wait_stream(cur)
-    with torch.cuda.stream(ws):
-        fn()
-    for t in tensors:
-        t.record_stream(ws)
-    if not _wg["pending"]:
-        _wg["pending"] = True
-        try:
-            torch.autograd.Variable._execution_engine.queue_callback(_wgrad_join)
-        except RuntimeError:      # not inside backward(): join right away
-            _wgrad_join()
+    """functions.py: a weight-gradient launch sequence that may run beside the input-gradient chain (see wgrad_side_stream)."""
+    return _wgrad_launch(tensors, fn)
 
 
 # ------------------------------------------------------------------------------------------ GEMM
@@ -378,7 +394,7 @@ def linear_wgrad(dy, x, dw, accumulate=True):
     """dw (+)= dy.T @ x; dy (M, N), x (M, K), dw (N, K)."""
     M, N = dy.shape
     K = x.shape[1]
-    return gemm(dy, x, dw, N, K, M, dy.stride(0), x.stride(0), dw.stride(0), a_trans=True, b_trans=True, accumulate=accumulate)
+    return _wgrad_launch((dy, x), lambda: gemm(dy, x, dw, N, K, M, dy.stride(0), x.stride(0), dw.stride(0), a_trans=True, b_trans=True, accumulate=accumulate))
 
 
 # ------------------------------------------------------------------------------------------ conv
@@ -534,6 +550,13 @@ def _thin_ws(device):
 def conv_wgrad(dy, x, dw, stride=1, pad=None, groups=1, accumulate=True, dbias=None):
     """dbias (optional, (Cout,) accumulator): the bias gradient sum(dy) is added to it by the same launch where the kernel can (thin-output
     layers); returns dw - callers test ``conv_wgrad_takes_bias`` to know whether dbias was consumed."""
+    if _wg["on"]:
+        dy, x = _c(dy), _c(x)
+        return _wgrad_launch((dy, x), lambda: _conv_wgrad(dy, x, dw, stride, pad, groups, accumulate, dbias))
+    return _conv_wgrad(dy, x, dw, stride, pad, groups, accumulate, dbias)
+
+
+def _conv_wgrad(dy, x, dw, stride, pad, groups, accumulate, dbias):
     ks = dw.shape[2]
     pad = ks // 2 if pad is None else pad
     g = conv_geom(x.shape, dw.shape[0], ks, stride, pad, groups)

@@ -428,18 +428,31 @@ class Engine:
         return len(self.cuts) + 1
 
     def _piece0(self, data):
-        with _F.inplace_param_grads(), ops.lowp_managed():
-            return self._piece0_impl(data)
+        with _F.inplace_param_grads(), ops.lowp_managed(), ops.wgrad_side_stream():
+            out = self._piece0_impl(data)
+            ops.wgrad_join()
+            return out
 
     def _piece(self, i):
-        with _F.inplace_param_grads(), ops.lowp_managed():
-            return self._piece_impl(i)
+        with _F.inplace_param_grads(), ops.lowp_managed(), ops.wgrad_side_stream():
+            out = self._piece_impl(i)
+            ops.wgrad_join()
+            return out
 
     def _opt_step(self):
-        """AdamW over the arena, then the 16-bit weight copies of the storage modes are rewritten from the updated master weights."""
+        """AdamW over the arena, then the 16-bit weight copies of the storage modes are rewritten from the updated master weights.  With
+        ZeRO-1 a rank only holds ITS shard's update at this point: the copies are rewritten after the parameter all-gather instead
+        (``_after_opt``), otherwise the cached copies of the other ranks' shards would lag one step and differ from rank to rank."""
         self.optimizer.step()
-        if ops.lowp_storage():
+        if ops.lowp_storage() and not self.zero:
             ops.lowp_refresh_weights()
+
+    def _after_opt(self):
+        """Eager tail of a step behind AdamW (outside the captured graphs: the all-gather is an RCCL call)."""
+        if self.zero:
+            self.reducer.all_gather_params(self.optimizer)
+            if ops.lowp_storage():
+                ops.lowp_refresh_weights()
 
     def _piece0_impl(self, data):
         self.optimizer.zero_grad()
@@ -495,8 +508,7 @@ class Engine:
     def _eager_step(self, data):
         out = self._fwd_bwd(data, reduce=True)
         self._opt_step()
-        if self.zero:
-            self.reducer.all_gather_params(self.optimizer)
+        self._after_opt()
         self._bump_seed()
         return out
 
@@ -516,8 +528,7 @@ class Engine:
         if self._opt_graph is not None:
             self.reducer.finish()
             self._opt_graph.replay()
-            if self.zero:
-                self.reducer.all_gather_params(self.optimizer)
+            self._after_opt()
         return self._out
 
     def _capture(self, data):
@@ -538,6 +549,8 @@ class Engine:
             with torch.no_grad():
                 for t, saved in snap:
                     t.copy_(saved)
+            if ops.lowp_storage():      # the cached 16-bit weight copies were last written from the warm-up's parameters: re-make them from the restored ones
+                ops.lowp_refresh_weights()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         del snap
