@@ -130,6 +130,59 @@ def dominant_kernel_roofline(eng, batch, dev, log, peak=PEAK_F32_MFMA_TF):
     return roof
 
 
+PEAK_HBM_TBS, ACHIEVABLE_HBM_TBS = 8.0, 6.3            # MI355X_MICROARCH.md: HBM3E spec / the sustained copy bandwidth the guide quotes
+
+
+def hbm_rooflines(eng, batch, dev, log):
+    """north_star's HBM clause, from INSIDE the step like the MFMA entry: one more eager training iteration with a HIP-event pair around every
+    call of the bandwidth-bound kernels it names (ops.hbm_census: AdamW over the flat arena, BatchNorm forward / backward, LayerNorm
+    forward; the attention softmax lives inside the fused attention kernel and never touches HBM), plus the H1 LiDAR histogram on the bench
+    cloud (10 x 32768 points; not part of the timed step: batch preparation).  Per family: algorithmic bytes, event time,
+    TB/s, fraction of the 8.0 TB/s spec and of the 6.3 TB/s achievable.  Eager launches carry their host launch gaps for the small layers
+    (the late-stage BatchNorm / LayerNorm calls are launch-latency sized): AdamW and the stem-resolution BatchNorm are the bandwidth figures."""
+    import torch
+    from transfuser_amd import ops
+    from transfuser_amd.data import synthetic_cloud
+    torch.cuda.synchronize()
+    ops.hbm_census = []
+    eng._eager_step(batch)
+    torch.cuda.synchronize()
+    rows, ops.hbm_census = ops.hbm_census, None
+    fam = {}
+    for name, nbytes, a, b in rows:
+        f = fam.setdefault(name, [0, 0, 0.0, 0.0, None])
+        us = a.elapsed_time(b) * 1e3
+        f[0] += 1; f[1] += nbytes; f[2] += us
+        if f[4] is None or nbytes > f[4][0]:
+            f[4] = (nbytes, us)
+    pts = torch.from_numpy(synthetic_cloud(10, 32768, 0)).to(dev)
+    for _ in range(3):
+        ops.lidar_hist(pts)
+    torch.cuda.synchronize()
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):      # a replayed hipGraph of 20 calls, like the step itself (eager launches add ~4 us of host gap to each of the 3 kernels)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            for _ in range(20):
+                ops.lidar_hist(pts)
+        g.replay()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st); g.replay(); e1.record(st); e1.synchronize()
+    h1_bytes = 10 * (32768 * 16 + 2 * 256 * 256 * 4)
+    fam["H1 lidar histogram, 10 x 32768 points (16 B / point read + 512 KB / sample written; clear + count + finish launches; hipGraph replay of 20 calls)"] = \
+        [20, 20 * h1_bytes, e0.elapsed_time(e1) * 1e3, 0.0, (h1_bytes, e0.elapsed_time(e1) * 1e3 / 20)]
+    out = []
+    for name, (calls, nbytes, us, _, big) in fam.items():
+        tbs = nbytes / us / 1e6
+        btbs = big[0] / big[1] / 1e6
+        out.append({"kernel": name, "calls": calls, "bytes": int(nbytes), "us": round(us, 1), "achieved_TBps": round(tbs, 3), "frac_of_8.0": round(tbs / PEAK_HBM_TBS, 4),
+                    "frac_of_6.3": round(tbs / ACHIEVABLE_HBM_TBS, 4),
+                    "largest_call": {"bytes": int(big[0]), "us": round(big[1], 1), "achieved_TBps": round(btbs, 3), "frac_of_8.0": round(btbs / PEAK_HBM_TBS, 4)}})
+    log("in-step HBM census done (%d calls)" % len(rows))
+    return {"bound": "hbm", "peak": PEAK_HBM_TBS, "achievable": ACHIEVABLE_HBM_TBS, "unit": "TB/s", "timing": "HIP events around each call inside one eager training step",
+            "kernels": out}
+
+
 def replica_check(eng, batch, rank, world, dev, log):
     """--check: (1) one more training step with the optimizer's wait for the all-reduce side stream bracketed by timing events - the time the
     main stream stalls there is the part of the gradient all-reduce the backward did NOT hide; (2) a checksum of the parameter arena (fp64
@@ -314,6 +367,10 @@ def main():
     if args.check:      # outside the timed region
         check = replica_check(eng, batch, rank, world, dev, log)
     roof = dominant_kernel_roofline(eng, batch, dev, log, peak)      # every rank runs the census step (it contains the collectives); rank 0 reports
+    try:
+        roof_hbm = hbm_rooflines(eng, batch, dev, log)               # the same for the bandwidth-bound kernels north_star names
+    except Exception as e:   # additional evidence only: never kill the headline line
+        roof_hbm = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = B * world * args.steps / dt
@@ -339,6 +396,7 @@ def main():
             roof["step_achieved_tflops"] = round(step_tf, 2)
             roof["step_frac"] = round(step_tf / peak, 4)
         res["roofline"] = roof
+        res["roofline_hbm"] = roof_hbm
         if world == 1 and args.dtype == "f32" and not args.no_alt:
             res["f32x3"] = alt_precision_line(args, log)
         if world == 1 and not args.no_cpu_baseline:

@@ -21,6 +21,10 @@ extern "C" {
 
 int tf_version(void);
 const char* tf_last_error(void);
+/* Provenance of a shipped library: the first 16 hex digits of the sha256 over the sources it was compiled from (transfuser_amd/csrc/*.cpp,
+ * *.h and this header, sorted by file name; written into the compile line by transfuser_amd/build.py).  The reference has no counterpart
+ * (it ships no native code); the Python binding compares it with the sources beside the library (transfuser_amd/_lib.py:load). */
+const char* tf_build_id(void);
 
 /* GEMM tiling plans.  The reference turns on cudnn.benchmark (train.py:115); the equivalent here: while tf_autotune(1)
  * is on (eager warm-up, NOT during graph capture - it synchronises), the first call of every distinct

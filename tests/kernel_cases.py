@@ -1383,6 +1383,12 @@ def check_bn_fused_stats(dev, plans=((0, 64, 64, 16), (0, 128, 32, 16), (0, 128,
                     y, cs = ops.linear_fwd(x, w, colstat=True)
                     close(y, x @ w.t(), what="linear with colstat")
                     _bn_from_parts(dev, y.view(1, 1, m, n), cs, relu=(n != 24), res=R(1, 1, m, n, seed=8, dev=dev) if n == 72 else None)
+                if (kind, bm) == (0, 64):      # many parts: 288 (one block per channel, one trip) and 1250 (two trips) - the stem / stage-1 / stage-2 layers
+                    for m in (9200, 40000):
+                        x = R(m, 16, dev=dev) + 3.0
+                        w = R(24, 16, seed=5, dev=dev) * 0.2
+                        y, cs = ops.linear_fwd(x, w, colstat=True)
+                        _bn_from_parts(dev, y.view(1, 1, m, 24), cs, relu=True)
                 bias = R(32, seed=6, dev=dev)
                 x = R(150, 9, dev=dev)
                 w = R(32, 9, seed=7, dev=dev)

@@ -27,7 +27,7 @@ pmc_hbm)    timeout 600 bash tools/pmc_hbm.sh $T 2>&1 | tail -24 ;;
 pmc)        timeout 600 bash tools/pmc_roofline.sh fp32 2>&1 | tail -12 ;;
 hbm)        timeout 300 python tools/hbm_bench.py > $O/${T}_hbm_kernels.txt 2>&1; cat $O/${T}_hbm_kernels.txt ;;
 lab)        timeout 300 python tools/launch_lab.py > $O/${T}_launch_lab.txt 2>&1; cat $O/${T}_launch_lab.txt ;;
-grouped)    timeout 300 python tools/grouped_bench.py > $O/${T}_grouped_bench.txt 2>&1; cat $O/${T}_grouped_bench.txt ;;
+grouped)    timeout 300 python tools/grouped_lab.py > $O/${T}_grouped_lab.txt 2>&1; cat $O/${T}_grouped_lab.txt ;;
 tune)       TF_RETUNE=${TF_RETUNE:-0} timeout 900 python tools/tune.py $O/mi355x_$T.txt 10 256,160 ${TUNE_PREC:-fp32} 2>&1 | tail -6 ;;
 census)     timeout 300 python tools/census.py 10 256 ${CENSUS_PREC:-fp32} > $O/${T}_census_${CENSUS_PREC:-fp32}.txt 2>&1; head -${CENSUS_HEAD:-70} $O/${T}_census_${CENSUS_PREC:-fp32}.txt ;;
 cmd)        bash -c "$CMD" ;;

@@ -39,7 +39,28 @@ class ConvGeom(ctypes.Structure):
 def _declare(lib):
     lib.tf_last_error.restype = ctypes.c_char_p
     lib.tf_version.restype = c_i
+    if hasattr(lib, "tf_build_id"):           # absent only from a pre-round-4 build selected through TF_HIP_LIB (A/B runs)
+        lib.tf_build_id.restype = ctypes.c_char_p
     return lib
+
+
+def build_id_check(lib):
+    """Does the loaded library come from the sources beside it?  (The .so is built in the authoring container and shipped; a GPU box never
+    compiles.)  Returns (library id, source id or None when the sources are absent); warns on a mismatch - a stale library is still the
+    product path, but every number it produces belongs to other sources."""
+    if not hasattr(lib, "tf_build_id"):
+        return None, None
+    got = lib.tf_build_id().decode()
+    try:
+        from . import build as _b
+        want = _b.source_hash()
+    except Exception:
+        return got, None
+    if got != want and not os.environ.get("TF_HIP_LIB"):
+        import warnings
+        warnings.warn("transfuser_amd: %s was built from other sources (tf_build_id %s, sources %s): rebuild with `python -m transfuser_amd.build`"
+                      % (LIB_PATH, got, want))
+    return got, want
 
 
 def load():
@@ -49,6 +70,7 @@ def load():
             raise RuntimeError("transfuser_amd: %s not found - build it with `python -m transfuser_amd.build` "
                                "(hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
         _lib = _declare(ctypes.CDLL(LIB_PATH))
+        build_id_check(_lib)
     return _lib
 
 

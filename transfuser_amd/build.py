@@ -20,6 +20,19 @@ def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".cpp"))
 
 
+def source_hash():
+    """sha256[:16] over csrc/*.cpp, csrc/*.h and include/transfuser_hip.h (sorted): what tf_build_id() of a library built from them returns."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".cpp", ".h")))
+    files.append(os.path.join(HERE, "..", "include", "transfuser_hip.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def _newer(target, deps):
     if not os.path.exists(target):
         return True
@@ -32,14 +45,21 @@ def compile_objects(cc, flags, objdir, verbose=True):
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     hdrs.append(os.path.join(HERE, "..", "include", "transfuser_hip.h"))
     jobs = []
+    # api.cpp carries the hash of ALL sources (tf_build_id): it is recompiled whenever the hash changes
+    bid = source_hash()
+    idfile = os.path.join(objdir, "build_id.txt")
+    if not os.path.exists(idfile) or open(idfile).read().strip() != bid:
+        with open(idfile, "w") as f:
+            f.write(bid + "\n")
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
-        if _newer(obj, [src] + hdrs):
+        if _newer(obj, [src] + hdrs + ([idfile] if os.path.basename(src) == "api.cpp" else [])):
             jobs.append((src, obj))
 
     def run(job):
         src, obj = job
-        cmd = [cc] + flags + ["-c", src, "-o", obj]
+        extra = ['-DTF_BUILD_ID="%s"' % bid] if os.path.basename(src) == "api.cpp" else []
+        cmd = [cc] + flags + extra + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("compile failed: %s\n%s\n%s" % (" ".join(cmd), r.stdout, r.stderr))

@@ -2,6 +2,7 @@
 #include "tf_common.h"
 #include "../../include/transfuser_hip.h"
 #include <stdarg.h>
+#include <stdlib.h>
 #include <map>
 #include <mutex>
 #include <string>
@@ -16,9 +17,30 @@ void set_error(const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+// TF_ABLATE=substr[,substr...]: launches of kernels whose (source) name contains one of the substrings become no-ops.  Timing diagnosis only
+// ("what would the step cost if this family were free"): the results of an ablated run are garbage.
+bool ablated(const char* kernel) {
+    static const std::string list = [] { const char* e = getenv("TF_ABLATE"); return std::string(e ? e : ""); }();
+    if (list.empty()) return false;
+    size_t pos = 0;
+    while (pos <= list.size()) {
+        size_t end = list.find(',', pos);
+        if (end == std::string::npos) end = list.size();
+        if (end > pos && strstr(kernel, list.substr(pos, end - pos).c_str())) return true;
+        pos = end + 1;
+    }
+    return false;
+}
 }  // namespace tf
 
-extern "C" int tf_version(void) { return 100; }
+// tf_build_id: sha256 (first 16 hex digits) of the sources this library was compiled from - transfuser_amd/csrc/*.{cpp,h} and
+// include/transfuser_hip.h, in sorted order - written by transfuser_amd/build.py into the compile line of this file.  _lib.load() compares it
+// with the sources next to the library and warns when a shipped .so is stale; tests/test_abi.py asserts equality after build().
+#ifndef TF_BUILD_ID
+#define TF_BUILD_ID "unknown"
+#endif
+extern "C" const char* tf_build_id(void) { return TF_BUILD_ID; }
+extern "C" int tf_version(void) { return 101; }
 extern "C" const char* tf_last_error(void) { return tf::g_err; }
 
 // ---- GEMM plan cache / autotuner switches -----------------------------------------------------------------------

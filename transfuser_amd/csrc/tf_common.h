@@ -7,6 +7,7 @@
 namespace tf {
 
 void set_error(const char* fmt, ...);  // api.cpp
+bool ablated(const char* kernel);      // api.cpp: TF_ABLATE=substr[,substr...] turns the matching kernels' launches into no-ops (timing diagnosis only)
 
 #ifdef TF_EMU
 #define TF_LAUNCH(kern, grid, block, stream, ...)                         \
@@ -16,7 +17,11 @@ void set_error(const char* fmt, ...);  // api.cpp
     } while (0)
 inline int launch_status(const char*) { return 0; }
 #else
-#define TF_LAUNCH(kern, grid, block, stream, ...) hipLaunchKernelGGL(kern, (grid), (block), 0, (hipStream_t)(stream), __VA_ARGS__)
+#define TF_LAUNCH(kern, grid, block, stream, ...)                                                        \
+    do {                                                                                                   \
+        static const bool tf_ablated_ = tf::ablated(#kern);                                              \
+        if (!tf_ablated_) hipLaunchKernelGGL(kern, (grid), (block), 0, (hipStream_t)(stream), __VA_ARGS__); \
+    } while (0)
 inline int launch_status(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

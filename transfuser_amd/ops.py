@@ -245,6 +245,24 @@ def wgrad_fork(tensors, fn):
 
 
 # ------------------------------------------------------------------------------------------ GEMM
+hbm_census = None   # set to a list to record (name, algorithmic bytes, start_event, end_event) of the bandwidth-bound calls north_star names (bench.py roofline_hbm)
+
+
+def _hbm_begin():
+    if hbm_census is None:
+        return None
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
+
+
+def _hbm_end(e0, name, nbytes):
+    if e0 is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        hbm_census.append((name, nbytes, e0, e1))
+
+
 census = None   # set to a list to record (kind, shape, flops, start_event, end_event) of every MFMA-engine call (tools/census.py)
 
 
@@ -682,8 +700,10 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5):
     y = torch.empty_like(x)
     mean = torch.empty(rows, dtype=torch.float32, device=x.device)
     rstd = torch.empty_like(mean)
+    _h = _hbm_begin()
     check(L().tf_layernorm_fwd_f32(ptr(_c(x)), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), rows, C, ctypes.c_float(eps), stream_of(x)),
           "tf_layernorm_fwd_f32")
+    _hbm_end(_h, "layernorm forward (row in registers: x read, y written)", 8 * x.numel())
     return y, mean, rstd
 
 
@@ -805,8 +825,10 @@ def bn_fwd_parts(x, cs, gamma, beta, rmean, rvar, res=None, relu=False, momentum
     y = torch.empty_like(x)
     sm = torch.empty(C, dtype=torch.float32, device=x.device)
     si = torch.empty_like(sm)
+    _h = _hbm_begin()
     check(L().tf_bn_fwd_parts_f32(ptr(_c(x)), rows, C, ptr(cs.buf), cs.nparts.value, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), ctypes.c_float(momentum),
                                   ctypes.c_float(eps), ptr(res), int(relu), ptr(y), ptr(sm), ptr(si), ptr(workspace(x.device)), stream_of(x)), "tf_bn_fwd_parts_f32")
+    _hbm_end(_h, "batchnorm forward (statistics from the producer's epilogue: finalize + apply)", 4 * x.numel() * (2 + (res is not None)))
     return y, sm, si
 
 
@@ -887,8 +909,11 @@ def bn_bwd(dz, z, x, gamma, sm, si, dgamma, dbeta, want_dres=False):
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if want_dres else None
     zacc = zero_scratch(32 * C, x.device) if not _DBG_LEGACY_BNB else None
+    _h = _hbm_begin()
     check(L().tf_bn_bwd_f32(ptr(_c(dz)), ptr(z), ptr(_c(x)), rows, C, ptr(gamma), ptr(sm), ptr(si), ptr(dx), ptr(dres), ptr(dgamma), ptr(dbeta),
                             ptr(workspace(x.device)), ptr(zacc), stream_of(x)), "tf_bn_bwd_f32")
+    # reduce pass reads dz, x (+ z); apply pass reads them again and writes dx (+ dres)
+    _hbm_end(_h, "batchnorm backward (reduce + finalize + apply)", 4 * x.numel() * ((2 + (z is not None)) * 2 + 1 + (dres is not None)))
     return dx, dres
 
 
@@ -1168,12 +1193,14 @@ def gru_waypoints_bwd(dwp, cache, gru, outl, grads, B, H, pred_len):
 
 def adamw_(p, g, m, v, state, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.01, grad_scale=1.0):
     """grad_scale: the gradients are multiplied by it on the way in (1 / loss scale of the fp16 mode)."""
+    _h = _hbm_begin()
     if grad_scale != 1.0:
         check(L().tf_adamw_scaled_f32(ptr(p), ptr(g), ptr(m), ptr(v), ctypes.c_int64(p.numel()), ptr(state), ctypes.c_float(beta1), ctypes.c_float(beta2),
                                       ctypes.c_float(eps), ctypes.c_float(weight_decay), ctypes.c_float(grad_scale), stream_of(p)), "tf_adamw_scaled_f32")
-        return
-    check(L().tf_adamw_f32(ptr(p), ptr(g), ptr(m), ptr(v), ctypes.c_int64(p.numel()), ptr(state), ctypes.c_float(beta1), ctypes.c_float(beta2),
-                           ctypes.c_float(eps), ctypes.c_float(weight_decay), stream_of(p)), "tf_adamw_f32")
+    else:
+        check(L().tf_adamw_f32(ptr(p), ptr(g), ptr(m), ptr(v), ctypes.c_int64(p.numel()), ptr(state), ctypes.c_float(beta1), ctypes.c_float(beta2),
+                               ctypes.c_float(eps), ctypes.c_float(weight_decay), stream_of(p)), "tf_adamw_f32")
+    _hbm_end(_h, "adamw (28 B / parameter: p, g, m, v read; p, m, v written)", 28 * p.numel())
 
 
 def cast_bf16(x, out=None):
