@@ -55,6 +55,10 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra f32x3 measurement that the default f32 line embeds (N=1 only)")
     ap.add_argument("--dropout", type=float, default=0.1)
+    ap.add_argument("--emulate-cpu", action="store_true",
+                    help="DRY RUN of the multi-rank plumbing on a machine without GPUs (tests/test_distributed_cpu.py): tiny trunks, the HIP kernels "
+                         "host-emulated (tests/emu), gloo - exercises the self-spawn, the cut / overlapped reducer path, --check and the no-teardown "
+                         "exit; its numbers mean nothing and the line says so")
     ap.add_argument("--watchdog", type=int, default=900, help="dump all Python stacks to stderr if still running after this many seconds")
     return ap.parse_args()
 
@@ -183,17 +187,18 @@ def hbm_rooflines(eng, batch, dev, log):
             "kernels": out}
 
 
-def replica_check(eng, batch, rank, world, dev, log):
+def replica_check(eng, batch, rank, world, dev, log, cuda=True):
     """--check: (1) one more training step with the optimizer's wait for the all-reduce side stream bracketed by timing events - the time the
     main stream stalls there is the part of the gradient all-reduce the backward did NOT hide; (2) a checksum of the parameter arena (fp64
     sum + exact int64 sum of the raw bits) all-gathered over the ranks: data parallelism (train.py:134) keeps the replicas bit-identical, so
     any difference is a reduction bug and the run FAILS.  Every rank prints its own line to stderr; rank 0 puts the summary into the JSON."""
     import torch
     import torch.distributed as dist
-    eng.reducer.time_waits = True
+    eng.reducer.time_waits = cuda
     eng.train_step(batch)
-    torch.cuda.synchronize()
-    exposed = eng.reducer.exposed_ms()
+    if cuda:
+        torch.cuda.synchronize()
+    exposed = eng.reducer.exposed_ms() if cuda else 0.0
     eng.reducer.time_waits = False
     p = eng.arena.params[:eng.arena.active_numel]
     # the exact checksum is a 64-bit integer: it travels as two 32-bit halves (a float64 holds only 53 bits of the ~1e17 sum)
@@ -293,6 +298,63 @@ def torch_free():
 T0 = time.perf_counter()
 
 
+def leave_without_teardown():
+    """Every rank is done (the JSON line is out): leave WITHOUT c10d's teardown - destroy_process_group() of an RCCL group has aborted the
+    interpreter on the MI355X box at the end of a long process (profiles/r03_gpu_tests_final_219_passed_teardown_abort.log), and a rank that
+    dies in its shutdown path would turn a finished measurement into a failed torchrun."""
+    import torch
+    torch.distributed.barrier()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    sys.stdout.flush(); sys.stderr.flush()
+    os._exit(0)
+
+
+def dry_run_cpu(args, log):
+    """--emulate-cpu: the multi-rank control flow of main() on CPU - same Engine (cuts, segment-wise reduce_async, AdamW), same replica check,
+    same exit path - with the kernels host-emulated and a tiny model.  TEST PLUMBING: nothing here is a measurement."""
+    import ctypes
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import build_emu
+    import model_cases as mc
+    from transfuser_amd import _lib
+    from transfuser_amd.model import LidarCenterNet
+    from transfuser_amd.train import Engine, init_distributed
+    _lib._install_test_backend(ctypes.CDLL(build_emu.build()))
+    rank, local_rank, world = init_distributed()
+    assert world == args.gpus, "WORLD_SIZE %d != --gpus %d" % (world, args.gpus)
+    torch.set_num_threads(2)
+    cfg = mc.tiny_config(n_layer=1, dropout=args.dropout)
+    torch.manual_seed(rank)          # different initial weights per rank: the Engine's broadcast must equalise them
+    model = LidarCenterNet(cfg, "cpu", args.backbone, "regnety_tiny", "regnety_tiny", use_velocity=False)
+    model.train()
+    batch = mc.small_batch(2, 32, 64, 64, 40, seed=rank)
+    eng = Engine(model, cfg, lr=cfg.lr, use_graph=False, grad_dtype=args.grad_dtype)
+    log("dry run: engine ready (%d backward piece(s), world %d)" % (eng.n_pieces(), world))
+    for _ in range(args.warmup):
+        eng.train_step(batch)
+    if world > 1:
+        torch.distributed.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tot, det = eng.train_step(batch)
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    check = None
+    if args.check:
+        check = replica_check(eng, batch, rank, world, torch.device("cpu"), log, cuda=False)
+    if rank == 0:
+        print(json.dumps({"metric": "DRY RUN (host-emulated kernels, tiny model): not a measurement", "value": round(2 * world * args.steps / dt, 3), "unit": "samples/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 1), "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": "dry run of the N-rank plumbing on CPU (gloo)", "final_loss": round(float(tot), 4), "backward_pieces": eng.n_pieces()},
+                          "check": check}), flush=True)
+    if world > 1:
+        leave_without_teardown()
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -309,6 +371,8 @@ def main():
     from transfuser_amd.data import synthetic_batch
     from transfuser_amd.model import LidarCenterNet
     from transfuser_amd.train import Engine, init_distributed
+    if args.emulate_cpu:
+        return dry_run_cpu(args, log)
     _lib.load()   # fails loudly when libtransfuser_hip.so is missing
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     rank, local_rank, world = init_distributed()
@@ -403,14 +467,7 @@ def main():
             res["cpu_baseline"] = cpu_baseline(make_cfg, backbone, H, W)
         print(json.dumps(res), flush=True)
     if world > 1:
-        # every rank is done (the JSON line is out): leave WITHOUT c10d's teardown - destroy_process_group() of an RCCL group has aborted the
-        # interpreter on the MI355X box at the end of a long process (profiles/r03_gpu_tests_final_219_passed_teardown_abort.log), and a rank that
-        # dies in its shutdown path would turn a finished measurement into a failed torchrun
-        torch.distributed.barrier()
-        if torch.cuda.is_available():
-            torch.cuda.synchronize()
-        sys.stdout.flush(); sys.stderr.flush()
-        os._exit(0)
+        leave_without_teardown()
 
 
 if __name__ == "__main__":

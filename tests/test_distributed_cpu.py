@@ -312,3 +312,59 @@ def _ddp_worker(rank, world, port):
 def test_torch_ddp_syncbn_zero_wrappers_world2_gloo():
     port = 33500 + (os.getpid() % 2000)
     mp.spawn(_ddp_worker, args=(2, port), nprocs=2, join=True)
+
+
+def _zero_lowp_worker(rank, world, port):
+    """ZeRO-1 with 16-bit operand STORAGE (--precision bf16 --zero_redundancy_optimizer 1).  A rank only applies ITS shard's AdamW
+    update before the parameter all-gather, so the cached bf16 copies of the GPT linear weights must be re-made AFTER the gather: three
+    steps of the ZeRO engine == the replicated engine (same 16-bit storage), and the replicas stay identical."""
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import ctypes
+    import build_emu
+    from transfuser_amd import _lib, ops
+    _lib._install_test_backend(ctypes.CDLL(build_emu.build()))
+    import model_cases as mc
+    from transfuser_amd.train import Engine
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    cfg = mc.tiny_config(n_layer=1)
+    batch = mc.small_batch(1, 32, 64, 64, 40, seed=20 + rank)
+    finals, losses = {}, {}
+    try:
+        for tag, kw in (("replicated", {}), ("zero", dict(zero_redundancy_optimizer=True))):
+            prod, _ = mc.build_pair(cfg, "regnety_tiny", "cpu", seed=3)
+            prod.train()
+            eng = Engine(prod, cfg, lr=1e-2, precision="bf16", **kw)      # a large step: stale weight copies would show at once
+            assert ops.lowp_storage()
+            losses[tag] = [float(eng.train_step(batch)[0]) for _ in range(3)]
+            finals[tag] = eng.arena.params.clone()
+            both = [torch.zeros_like(eng.arena.params) for _ in range(world)]
+            dist.all_gather(both, eng.arena.params)
+            assert torch.equal(both[0], both[1]), tag
+    finally:
+        ops.set_precision("fp32")
+    assert all(abs(a - b) <= 1e-4 * max(1.0, abs(a)) for a, b in zip(losses["replicated"], losses["zero"])), losses
+    assert torch.allclose(finals["replicated"], finals["zero"], atol=2e-6), (finals["replicated"] - finals["zero"]).abs().max()
+    dist.destroy_process_group()
+
+
+def test_zero1_with_16bit_weight_storage_world2_gloo():
+    port = 29500 + ((os.getpid() + 911) % 2000)
+    mp.spawn(_zero_lowp_worker, args=(2, port), nprocs=2, join=True)
+
+
+def test_bench_self_spawn_two_ranks_check_and_exit_dry_run():
+    """bench.py --gpus 2 from a BARE shell (no torchrun environment): it spawns its two ranks itself, runs the cut / overlapped Engine, --check
+    all-gathers the parameter checksums and asserts replica equality, rank 0's JSON line is relayed and every rank leaves through the
+    no-teardown exit with status 0.  --emulate-cpu: tiny model, host-emulated kernels, gloo (round-3 verdict: this path had never run)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--emulate-cpu", "--check", "--steps", "1", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["check"]["replicas_equal"] is True and line["check"]["n_ranks"] == 2
+    assert line["config"]["backward_pieces"] == 5 and "DRY RUN" in line["metric"]
+    assert r.stderr.count("[bench check] rank") == 2
