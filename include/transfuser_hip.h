@@ -393,6 +393,18 @@ int tf_pillar_canvas_bwd_f32(const float* dout_nhwc, const int32_t* owner, const
  *   (data.py:358-372), 2 -> crop_seg + class LUT (data.py:176-177).  tf_bev_prep_u8: decode_pil_to_npy + load_crop_bev_npy (data.py:844-856,586-612). */
 int tf_lidar_align_hist_f64(const float* points, const int32_t* num_points, int B, int max_points, int point_stride, const double* transforms, float* out,
                             float* aligned_or_null, void* stream);
+
+/* lidar_bev_cam_correspondences + correspondences_at_one_scale (team_code_transfuser/data.py:632-842; per sample at data.py:273 and
+ * submission_agent.py:306) for a batch of raw clouds: points (B, max_points, point_stride >= 3) float32 in the CARLA frame (x left, y forward,
+ * z up; y_negated != 0: the buffer holds the cloud as the loader keeps it, y already negated (data.py:170), and is read with y flipped back),
+ * num_points (B) or NULL.  cam6 (HOST pointer) = {focal_x, focal_y, cos(-60 deg), sin(-60 deg), cos(60 deg), sin(60 deg)} as
+ * data.py:688-712,741-747 evaluates them.  Outputs int32: bev_points (B, 8, 8, 5, 2) = image cells (x in [0, 22), y in [0, 5)) of up to five
+ * points per BEV cell, cam_points (B, 22, 5, 5, 2) = BEV cells of up to five points per image cell, zero padded like the reference.  Cells with
+ * more than five points: the reference draws random.sample(list, 5) from Python's global generator; here a counter-based draw keyed by
+ * (seed, sample, list, cell, entry) with the same distribution.  ws: tf_lidar_cam_correspondences_ws_bytes(B, max_points) bytes, 16-byte aligned. */
+long tf_lidar_cam_correspondences_ws_bytes(int B, int max_points);
+int tf_lidar_cam_correspondences_f32(const float* points, const int32_t* num_points, int B, int max_points, int point_stride, int y_negated,
+                                     const double* cam6, uint32_t seed, void* ws, int32_t* bev_points, int32_t* cam_points, void* stream);
 int tf_image_prep_u8(const uint8_t* src, int B, int Hs, int Ws, int C, int crop_h, int crop_w, int start_y, const int32_t* start_x, int mode, const uint8_t* lut,
                      void* out, void* stream);
 int tf_bev_prep_u8(const uint8_t* encoded, int B, int S, const float* degrees_or_null, int64_t* out, void* stream);

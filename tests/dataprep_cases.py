@@ -38,6 +38,17 @@ def check_dataprep(dev):
     want[tuple(gold["dp_lidar_idx"].astype(np.int64))] = gold["dp_lidar_val"].astype(np.float32) / 5
     assert np.array_equal(out["lidar"].cpu().numpy(), want)                                                                          # align + histogram: integer exact
     assert out["target_point_image"].shape == (B, 1, 256, 256)
+    # geometric fusion (data.py:273,319-320): bev_points / cam_points from the RAW cloud of the loader's buffer (y negated there, data.py:170)
+    from oracle import correspondences as oc
+    prep_geo = D.GpuBatchPrep(cfg, torch.device(dev), correspondences=True, seed=11)
+    og = prep_geo(batch)
+    assert og["bev_points"].shape == (B, 8, 8, 5, 2) and og["cam_points"].shape == (B, 22, 5, 5, 2) and og["bev_points"].dtype == torch.int64
+    for b in range(B):
+        w = raw["lidar_raw"][b, :int(raw["num_points"][b]), :3].copy()
+        w[:, 1] *= -1
+        wb, wc = oc.lidar_bev_cam_correspondences(w, seed=11, sample=b, key_stride=raw["lidar_raw"].shape[1])
+        assert np.array_equal(og["bev_points"][b].cpu().numpy(), wb) and np.array_equal(og["cam_points"][b].cpu().numpy(), wc)
+    assert int(og["bev_points"][..., 0].max()) < 22 and int(og["bev_points"][..., 1].max()) < 5 and int(og["cam_points"].max()) < 8
     # augmentation geometry: the histogram of the cloud rotated by the kernel == the oracle's histogram of the host-rotated cloud; crops shift
     from oracle import hist
     deg = torch.tensor([7.5, -13.0])

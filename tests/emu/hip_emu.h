@@ -61,6 +61,7 @@ static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p 
 static inline int atomicMax(int* p, int v) { int o = *p; if (v > o) *p = v; return o; }
 static inline unsigned atomicMax(unsigned* p, unsigned v) { unsigned o = *p; if (v > o) *p = v; return o; }
 static inline int atomicMin(int* p, int v) { int o = *p; if (v < o) *p = v; return o; }
+static inline unsigned long long atomicMin(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; if (v < o) *p = v; return o; }
 static inline int atomicCAS(int* p, int cmp, int v) { int o = *p; if (o == cmp) *p = v; return o; }
 
 static inline float __fdividef(float a, float b) { return a / b; }

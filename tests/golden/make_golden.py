@@ -277,6 +277,7 @@ def main():
     import model as ref_model            # the reference module, unmodified (cv2 / torchvision / mmcv / mmdet = oracle/mm_shim)
     np.savez_compressed(os.path.join(HERE, "lidar_centernet_tiny.npz"), **model_golden(ref_model))
     np.savez_compressed(os.path.join(HERE, "dataprep.npz"), **dataprep_golden())
+    np.savez_compressed(os.path.join(HERE, "correspondences.npz"), **correspondences_golden())
     # H1: numpy.histogramdd (the reference's algorithm, data.py:446-470) on a seeded cloud with edge cases -> sparse golden
     rng = np.random.default_rng(3)
     pts = np.stack([rng.uniform(-20, 20, 20000), rng.uniform(-36, 4, 20000), rng.uniform(-4, 1, 20000)], 1).astype(np.float32)
@@ -368,6 +369,39 @@ def dataprep_golden():
     res["dp_lidar_idx"] = np.stack(idx).astype(np.int16); res["dp_lidar_val"] = (res.pop("dp_lidar")[idx] * 5).round().astype(np.uint8)
     res["dp_depth"] = res["dp_depth"].astype(np.float64)
     return res
+
+
+# ---------------------------------------------------------------- data.py:632-842 LiDAR <-> camera correspondences (geometric fusion)
+def correspondence_clouds(seed=31):
+    """Raw CARLA-frame clouds (x left, y forward, z up), float32: a sparse one (most cells hold <= 5 points: the deterministic branch of
+    correspondences_at_one_scale), a dense one (random.sample branch) and edge points: on the |x| = 16 / y = 32 / y = 0 borders, on cell
+    borders, straight ahead, at the +-30 degree seams of the three cameras and behind the rotated cameras' image planes."""
+    rng = np.random.default_rng(seed)
+    def cloud(n):
+        return np.stack([rng.uniform(-20, 20, n), rng.uniform(-5, 40, n), rng.uniform(-3, 3, n)], 1).astype(np.float32)
+    edge = np.float32([[16, 5, 0], [-16, 5, 0], [15.999999, 5, 0], [0, 32, 0], [0, 31.999998, 0], [0, 0, 0], [0, 1e-3, 0], [4, 4, 0.5], [-4, 4, 0.5], [8, 8, -1], [0, 10, 0],
+                       [5.7735027, 10, 0], [-5.7735027, 10, 0], [10, 17.320508, 0], [-10, 17.320508, 0], [15, 1, 0], [-15, 1, 0], [15, 0.5, 2], [-15, 0.5, -2], [12, 20.784609, 1],
+                       [2.0, 16.0, 0.1], [-2.0, 16.0, 0.1], [1.9999999, 8.0, 2.0], [12.0, 4.0, 0.25], [-12.0, 4.0, -0.25], [3, 31, 2.9], [3, 31, -2.9]])
+    return {"sparse": np.concatenate([cloud(260), edge]), "dense": np.concatenate([edge, cloud(6000)])}
+
+
+def correspondences_golden():
+    """lidar_bev_cam_correspondences (data.py:675-842, with correspondences_at_one_scale :632-673) executed from the reference's source."""
+    import ast
+    import random
+    from copy import deepcopy
+    ns = {"np": np, "deepcopy": deepcopy, "random": random}
+    src = open("/root/reference/team_code_transfuser/data.py").read()
+    for node in ast.parse(src).body:
+        if isinstance(node, ast.FunctionDef) and node.name in ("correspondences_at_one_scale", "lidar_bev_cam_correspondences"):
+            exec(compile(ast.Module([node], []), "data.py", "exec"), ns)
+    out = {}
+    for name, c in correspondence_clouds().items():
+        random.seed(123)
+        bev, cam = ns["lidar_bev_cam_correspondences"](c.copy())
+        out["corr_%s_bev" % name], out["corr_%s_cam" % name] = bev.astype(np.int16), cam.astype(np.int16)
+        assert np.array_equal(out["corr_%s_bev" % name], bev) and bev.shape == (8, 8, 5, 2) and cam.shape == (22, 5, 5, 2)
+    return out
 
 
 if __name__ == "__main__":

@@ -790,6 +790,39 @@ def check_hist(dev, B, N, stride=4, ragged=None):
     assert np.array_equal(out2[0], hist.lidar_to_histogram_features(pts[0, :, :4]))
 
 
+def check_correspondences(dev):
+    """lidar_bev_cam_correspondences on the GPU (csrc/correspond.cpp) == the oracle (pinned to data.py:632-842 by tests/test_oracle_pinning_data.py),
+    integer outputs compared for equality INCLUDING the crowded cells (the kernel and the oracle share the counter-based draw): the golden
+    clouds with their edge points, ragged num_points over a padded buffer (keys count in units of the buffer length), the loader's
+    y-negated layout, a point stride of 4, several seeds; and an empty sample."""
+    import sys as _sys, os as _os
+    _sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "golden"))
+    import make_golden as mg
+    from oracle import correspondences as oc
+    clouds = mg.correspondence_clouds()
+    N = 6400
+    buf = np.zeros((4, N, 4), np.float32)
+    nums = [len(clouds["sparse"]), len(clouds["dense"]), 3000, 0]
+    buf[0, :nums[0], :3] = clouds["sparse"]; buf[1, :nums[1], :3] = clouds["dense"]; buf[2, :nums[2], :3] = clouds["dense"][500:3500]
+    buf[3, :, :3] = clouds["dense"][:1].repeat(N, 0)          # sample 3 has num_points 0: its padding must be ignored
+    buf[..., 3] = 0.5
+    for seed, yneg in ((0, False), (12345, True)):
+        b2 = buf.copy()
+        if yneg:
+            b2[..., 1] *= -1
+        bev, cam = ops.lidar_cam_correspondences(torch.from_numpy(b2).to(dev), torch.tensor(nums, dtype=torch.int32, device=dev), seed=seed, y_negated=yneg)
+        bev, cam = bev.cpu().numpy(), cam.cpu().numpy()
+        for s in range(4):
+            wb, wc = oc.lidar_bev_cam_correspondences(buf[s, :nums[s], :3], seed=seed, sample=s, key_stride=N)
+            assert np.array_equal(bev[s], wb), ("bev_points", seed, s, int((bev[s] != wb).sum()))
+            assert np.array_equal(cam[s], wc), ("cam_points", seed, s, int((cam[s] != wc).sum()))
+    # stride 3, no num_points: every row counts
+    c3 = np.ascontiguousarray(clouds["dense"][:4096])
+    bev, cam = ops.lidar_cam_correspondences(torch.from_numpy(c3[None]).to(dev), None, seed=7)
+    wb, wc = oc.lidar_bev_cam_correspondences(c3, seed=7, sample=0)
+    assert np.array_equal(bev[0].cpu().numpy(), wb) and np.array_equal(cam[0].cpu().numpy(), wc)
+
+
 # ---------------------------------------------------------------- CenterNet targets + losses vs the oracle
 def synthetic_labels(B, seed=0, crowded=False):
     rng = np.random.default_rng(seed)

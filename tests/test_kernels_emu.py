@@ -118,6 +118,10 @@ def test_lidar_hist():
     kc.check_hist("cpu", 4, 2049, ragged=[2049, 0, 1, 1500])
 
 
+def test_lidar_camera_correspondences():
+    kc.check_correspondences("cpu")
+
+
 @pytest.mark.parametrize("case", [(3, False), (2, True)], ids=str)
 def test_centernet_targets_and_losses(case):
     kc.check_centernet("cpu", *case)

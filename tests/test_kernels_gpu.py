@@ -129,6 +129,10 @@ def test_lidar_hist_full_size_ragged(N):
     kc.check_hist("cuda", 10, N, ragged=[N, N - 777, N, 0, 1, N // 2, 255, 257, N - 1, 12345])
 
 
+def test_lidar_camera_correspondences():
+    kc.check_correspondences("cuda")
+
+
 @pytest.mark.parametrize("case", [(3, False), (2, True)], ids=str)
 def test_centernet_targets_and_losses(case):
     kc.check_centernet("cuda", *case)

@@ -232,9 +232,13 @@ class GpuBatchPrep:
     """Collated raw batch (``CARLA_Data`` items) -> the training batch of train.py:246-271, on the device: one H2D copy of the uint8 images
     and the float32 clouds, then five kernels (csrc/dataprep.cpp) instead of per-sample numpy in the DataLoader workers."""
 
-    def __init__(self, config, device):
+    def __init__(self, config, device, correspondences=False, seed=0):
+        """``correspondences``: also produce ``bev_points`` / ``cam_points`` from the raw cloud (data.py:273,319-320: the geometric-fusion
+        backbone's inputs); ``seed`` keys the draw for cells with more than five points (a new draw per batch, like the reference's
+        ``random.sample`` per sample)."""
         self.config, self.device = config, device
         self.lut = torch.tensor(CONVERTER + [0] * (256 - len(CONVERTER)), dtype=torch.uint8, device=device)
+        self.correspondences, self.seed, self.calls = correspondences, int(seed), 0
 
     def __call__(self, raw):
         from . import ops
@@ -259,6 +263,10 @@ class GpuBatchPrep:
             out["num_points"] = num
         else:
             out["lidar"] = ops.lidar_align_hist(pts, T, num)
+        if self.correspondences:      # data.py:273: on the RAW (un-aligned) cloud; the loader's buffer holds it with y negated (data.py:170)
+            bp, cp = ops.lidar_cam_correspondences(pts, num, seed=self.seed + 0x9E3779B1 * self.calls, y_negated=True)
+            out["bev_points"], out["cam_points"] = bp.long(), cp.long()
+            self.calls += 1
         tp = raw["target_point"]
         out["target_point_image"] = torch.from_numpy(np.stack([draw_target_point_image(*_tp_pixel(tp[b].numpy())) for b in range(B)])).to(dev)
         for k in ("label", "ego_waypoint", "target_point", "ego_vel"):

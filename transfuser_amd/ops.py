@@ -1304,6 +1304,37 @@ def lidar_align_hist(points, transforms, num_points=None, return_aligned=False):
     return (out, al) if return_aligned else out
 
 
+_corr_cam = None
+
+
+def corr_camera_constants():
+    """focal_x, focal_y, cos / sin of the -60 / +60 degree camera yaws, evaluated with NumPy exactly like data.py:688-712,741-747."""
+    global _corr_cam
+    if _corr_cam is None:
+        import numpy as np
+        img_width, img_height, fov_width = 352, 160, 60
+        fov_height = np.rad2deg(2.0 * np.arctan((img_height / img_width) * np.tan(0.5 * np.radians(fov_width))))
+        focal_x = img_width / (2.0 * np.tan(np.deg2rad(fov_width) / 2.0))
+        focal_y = img_height / (2.0 * np.tan(np.deg2rad(fov_height) / 2.0))
+        tl, tr = np.radians(-60.0), np.radians(60.0)
+        _corr_cam = (ctypes.c_double * 6)(float(focal_x), float(focal_y), float(np.cos(tl)), float(np.sin(tl)), float(np.cos(tr)), float(np.sin(tr)))
+    return _corr_cam
+
+
+def lidar_cam_correspondences(points, num_points=None, seed=0, y_negated=False):
+    """lidar_bev_cam_correspondences (data.py:675-842) for a batch of raw clouds (B, N, >= 3) float32 -> (bev_points (B, 8, 8, 5, 2),
+    cam_points (B, 22, 5, 5, 2)) int32: the C4 inputs of the geometric-fusion backbone (train.py:280-288)."""
+    B, N, S = points.shape
+    dev = points.device
+    L().tf_lidar_cam_correspondences_ws_bytes.restype = ctypes.c_long
+    ws = torch.empty(L().tf_lidar_cam_correspondences_ws_bytes(B, N), dtype=torch.uint8, device=dev)
+    bev = torch.empty(B, 8, 8, 5, 2, dtype=torch.int32, device=dev)
+    cam = torch.empty(B, 22, 5, 5, 2, dtype=torch.int32, device=dev)
+    check(L().tf_lidar_cam_correspondences_f32(ptr(_c(points)), ptr(num_points), B, N, S, int(bool(y_negated)), corr_camera_constants(), ctypes.c_uint32(seed & 0xffffffff),
+                                               ptr(ws), ptr(bev), ptr(cam), stream_of(points)), "tf_lidar_cam_correspondences_f32")
+    return bev, cam
+
+
 def image_prep(src, crop_hw, start_y, start_x, mode, lut=None):
     """src (B, Hs, Ws, C) uint8 HWC; mode "rgb" -> (B, C, h, w) float32; "depth" -> (B, h, w) float32 (get_depth); "seg" -> (B, h, w) int64 (LUT)."""
     B, Hs, Ws, C = src.shape

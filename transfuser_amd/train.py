@@ -616,7 +616,8 @@ class Trainer:
         if "rgb_u8" in data:
             if getattr(self, "_prep", None) is None:
                 from .data import GpuBatchPrep
-                self._prep = GpuBatchPrep(self.config, self.device)
+                self._prep = GpuBatchPrep(self.config, self.device, correspondences=getattr(self.args, "backbone", "") == "geometric_fusion",
+                                          seed=1000003 * self.rank)
             data = self._prep(data)                 # with --use_point_pillars data["lidar"] is then the aligned cloud (train.py:258-260) + num_points
         f32 = ("rgb", "lidar", "ego_waypoint", "target_point", "target_point_image", "ego_vel", "label", "depth")
         i64 = ("bev", "semantic", "bev_points", "cam_points")
