@@ -89,6 +89,9 @@ class ConvNeXt(nn.Module):
     def forward_features(self, x):
         return self.stages(self.stem(x))
 
+    def forward(self, x):      # timm 0.5.4 convnext.py ConvNeXt.forward; late_fusion.py:129-132 empties the head
+        return self.head(self.norm_pre(self.forward_features(x)))
+
 
 def convnext_tiny(in_chans=3):
     return ConvNeXt(in_chans, (3, 3, 9, 3), (96, 192, 384, 768))

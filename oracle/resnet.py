@@ -100,6 +100,9 @@ class ResNet(nn.Module):
         x = self.maxpool(self.act1(self.bn1(self.conv1(x))))
         return self.layer4(self.layer3(self.layer2(self.layer1(x))))
 
+    def forward(self, x):      # timm 0.5.4 resnet.py ResNet.forward (drop_rate 0); late_fusion.py:129-132 empties global_pool / fc
+        return self.fc(self.global_pool(self.forward_features(x)))
+
 
 def resnet18(in_chans=3):
     return ResNet(BasicBlock, (2, 2, 2, 2), in_chans)

@@ -241,7 +241,8 @@ class latentTFBackbone(TransfuserBackbone):
 class LateFusionBackbone(nn.Module):
     """team_code_transfuser/late_fusion.py:5-111: the two trunks run WITHOUT any exchange (timm models used as they
     are - no re-labelling, the LiDAR trunk is created with in_chans, late_fusion.py:126-130,155-159), 1x1 reducers to 512, FPN on the
-    LiDAR map, fused = gap(image) + gap(lidar) (+ vel_emb(velocity)).  ConvNeXt / ResNet trunks are not restated (RegNetY only)."""
+    LiDAR map, fused = gap(image) + gap(lidar) (+ vel_emb(velocity)).  ``make_net`` builds either trunk (any of oracle.regnet / resnet / convnext:
+    the reference takes every timm architecture, :126,158); a ConvNeXt trunk's pooled vector goes through LayerNorm(512) (:23-33,92,103)."""
 
     def __init__(self, config, image_architecture='regnety_032', lidar_architecture='regnety_032', use_velocity=0, make_net=None):
         super().__init__()
@@ -260,10 +261,10 @@ class LateFusionBackbone(nn.Module):
         self.image_encoder.features = bare(make_net())
         self.lidar_encoder = nn.Module()
         self.lidar_encoder._model = bare(make_net(in_chans=in_ch))
-        self.norm_after_pool_img = nn.Sequential()
-        self.norm_after_pool_lidar = nn.Sequential()
-        self.use_velocity = use_velocity
         pf = config.perception_output_features
+        self.norm_after_pool_img = nn.LayerNorm((pf,), eps=1e-06) if image_architecture.startswith('convnext') else nn.Sequential()
+        self.norm_after_pool_lidar = nn.LayerNorm((pf,), eps=1e-06) if lidar_architecture.startswith('convnext') else nn.Sequential()
+        self.use_velocity = use_velocity
         if use_velocity:
             self.vel_emb = nn.Linear(1, pf)
         ch = config.bev_features_chanels
@@ -282,7 +283,7 @@ class LateFusionBackbone(nn.Module):
     def forward(self, image, lidar, velocity):
         x = self.reduce_channels_conv_image(self.image_encoder.features(normalize_imagenet(image)))
         y = self.reduce_channels_conv_lidar(self.lidar_encoder._model(lidar))
-        fused = torch.flatten(F.adaptive_avg_pool2d(x, 1), 1) + torch.flatten(F.adaptive_avg_pool2d(y, 1), 1)
+        fused = self.norm_after_pool_img(torch.flatten(F.adaptive_avg_pool2d(x, 1), 1)) + self.norm_after_pool_lidar(torch.flatten(F.adaptive_avg_pool2d(y, 1), 1))
         if self.use_velocity:
             fused = fused + self.vel_emb(velocity)
         return self.top_down(y), x, fused

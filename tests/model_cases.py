@@ -104,7 +104,7 @@ def build_pair(cfg, arch, dev, use_velocity=False, seed=0, backbone='transFuser'
         make_net = oracle_convnext.ARCH[arch]
     else:
         make_net = oracle_regnet.regnety_032
-    ref = model_cpu.LidarCenterNet(cfg, 'cpu', backbone, use_velocity=use_velocity, make_net=make_net)
+    ref = model_cpu.LidarCenterNet(cfg, 'cpu', backbone, arch, arch, use_velocity=use_velocity, make_net=make_net)
     sd = {k: v.detach().cpu().contiguous() for k, v in prod.state_dict().items()}
     missing = ref.load_state_dict(sd, strict=True)
     assert not missing.missing_keys and not missing.unexpected_keys

@@ -271,6 +271,10 @@ def test_late_fusion_backbone_tiny_and_regnety032_on_gpu():
         batch = mc.small_batch(2, 32, 64, 128, 40)
         lp, lr = mc.run_pair(prod, ref, cfg, batch, "cuda")
         mc.compare(prod, ref, lp, lr, grad_tol=1e-2, metric="l2")
+    for arch in ("resnet_tiny", "convnext_mini"):      # the other trunk families of late_fusion.py:23-33,126,158
+        prod, ref = mc.build_pair(cfg, arch, "cuda", backbone="late_fusion", use_velocity=True)
+        lp, lr = mc.run_pair(prod, ref, cfg, mc.small_batch(2, 32, 64, 128, 40), "cuda")
+        mc.compare(prod, ref, lp, lr, grad_tol=1e-2, metric="l2")
     mc.check_full_size_vs_fp64("late_fusion", 2, 160)
 
 

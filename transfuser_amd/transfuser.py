@@ -303,7 +303,9 @@ class _FusionBackbone(nn.Module):
             y = lidar_branch(lambda: self._lid_stem(lidar.contiguous(), lidar_extra.contiguous() if lidar_extra is not None else None))
         x = self._img_stem(image.contiguous())
         self._boundaries = []
-        stage = lambda net, i: getattr(net, "layer%d" % i, None) or getattr(net, "s%d" % i)    # re-labelled (transfuser.py) or plain timm names (late_fusion.py)
+        def stage(net, i):      # re-labelled / ResNet names (layer1..4), plain timm RegNet (s1..s4) or ConvNeXt (stages.0..3) names (late_fusion.py)
+            return getattr(net, "layer%d" % i, None) or getattr(net, "s%d" % i, None) or net.stages[i - 1]
+
         for i in range(1, 5):
             y = lidar_branch(lambda y=y, i=i: stage(li, i)(y))
             x = stage(im, i)(x)
@@ -317,12 +319,16 @@ class _FusionBackbone(nn.Module):
                 y.record_stream(side)
         x = self._conv(getattr(self, self._reducers[0]), x)
         y = self._conv(getattr(self, self._reducers[1]), y)
+        fused = self._pooled(x, y, im, li)
+        return self.top_down_nhwc(y), x, fused
+
+
+    def _pooled(self, x, y, im, li):
+        """fused_features = pooled image vector + pooled LiDAR vector (transfuser.py:203-208)."""
         gp_i, gp_l = getattr(im, "global_pool", None), getattr(li, "global_pool", None)
         if isinstance(getattr(gp_i, "norm", None), nn.LayerNorm):     # ConvNeXt: global_pool = the re-labelled head (pool -> LayerNorm((512, 1, 1)))
-            fused = F_.PoolNormFn.apply(x, gp_i.norm, gp_i.norm.weight, gp_i.norm.bias) + F_.PoolNormFn.apply(y, gp_l.norm, gp_l.norm.weight, gp_l.norm.bias)
-        else:
-            fused = F_.GlobalPoolAddFn.apply(x, y)
-        return self.top_down_nhwc(y), x, fused
+            return F_.PoolNormFn.apply(x, gp_i.norm, gp_i.norm.weight, gp_i.norm.bias) + F_.PoolNormFn.apply(y, gp_l.norm, gp_l.norm.weight, gp_l.norm.bias)
+        return F_.GlobalPoolAddFn.apply(x, y)
 
 
 class TransfuserBackbone(_FusionBackbone):
@@ -358,8 +364,10 @@ class LateFusionBackbone(_FusionBackbone):
     """team_code_transfuser/late_fusion.py:5-111: both RegNetY trunks run without any exchange between the stages (on two
     HIP streams, like the fused backbones), 1x1 reducers 1512 -> 512, FPN on the LiDAR map, fused = gap(image) + gap(lidar) (+ vel_emb).
     Module / parameter names are the reference's (timm models used as they are: ``features.stem.*`` / ``_model.stem.*`` with in_chans
-    input channels, no conv1/layerN aliases; ``reduce_channels_conv_*``), so late-fusion checkpoints load.  This backbone keeps RegNetY trunks only
-    (the ResNet / ConvNeXt branches of late_fusion.py:23-33 are not wired here; TransfuserBackbone / latentTF / geometric fusion take all three families)."""
+    input channels, no conv1/layerN aliases; ``reduce_channels_conv_*``), so late-fusion checkpoints load.  All three trunk families of
+    late_fusion.py:5-33,126-132,155-159: RegNetY, ResNet (timm's own conv1 / bn1 / maxpool / layer1..4; the reducers vanish for a 512-wide image
+    trunk - for BOTH branches, the reference tests the image width twice, :45-52) and ConvNeXt (``stem.0/1``, ``stages.i``; the pooled vector
+    goes through ``norm_after_pool_*`` = LayerNorm(512), :23-33,92,103); the two branches may use different families."""
 
     _reducers = ("reduce_channels_conv_image", "reduce_channels_conv_lidar")
 
@@ -369,15 +377,21 @@ class LateFusionBackbone(_FusionBackbone):
         in_channels = config.num_features[-1] if config.use_point_pillars else 2 * config.lidar_seq_len
         if config.use_target_point_image:
             in_channels += 1
+        def plain(architecture, pretrained, in_chans=3):      # timm.create_model + late_fusion.py:129-132,157-160: classifier / pool / head -> empty
+            mod = convnext if convnext.is_convnext(architecture) else resnet if resnet.is_resnet(architecture) else regnet
+            net = mod.create_model(architecture, pretrained=pretrained, in_chans=in_chans)
+            for name in ("fc", "classifier", "global_pool", "head"):
+                setattr(net, name, nn.Sequential())
+            return net
         self.image_encoder = nn.Module()
         self.image_encoder.normalize = True
-        self.image_encoder.features = regnet.create_model(image_architecture, pretrained=True)
+        self.image_encoder.features = plain(image_architecture, True)
         self.lidar_encoder = nn.Module()
-        self.lidar_encoder._model = regnet.create_model(lidar_architecture, pretrained=False, in_chans=in_channels)
-        self.norm_after_pool_img = nn.Sequential()
-        self.norm_after_pool_lidar = nn.Sequential()
-        self.use_velocity = use_velocity
+        self.lidar_encoder._model = plain(lidar_architecture, False, in_channels)
         pf = config.perception_output_features
+        self.norm_after_pool_img = nn.LayerNorm((pf,), eps=1e-06) if image_architecture.startswith('convnext') else nn.Sequential()
+        self.norm_after_pool_lidar = nn.LayerNorm((pf,), eps=1e-06) if lidar_architecture.startswith('convnext') else nn.Sequential()
+        self.use_velocity = use_velocity
         if use_velocity:
             self.vel_emb = nn.Linear(1, pf)
         channel = config.bev_features_chanels
@@ -390,9 +404,24 @@ class LateFusionBackbone(_FusionBackbone):
         self.up_conv4 = nn.Conv2d(channel, channel, (1, 1))
         self.up_conv3 = nn.Conv2d(channel, channel, (1, 1))
         self.c5_conv = nn.Conv2d(pf, channel, (1, 1))
-        im, li = self.image_encoder.features, self.lidar_encoder._model
-        self._img_stem = _Stem(None, None, True, im.stem, ("conv", "bn"))
-        self._lid_stem = _Stem(None, None, False, li.stem, ("conv", "bn"))
+        def stem_of(net, normalize):
+            if isinstance(net, convnext.ConvNeXt):
+                return _Stem(None, None, normalize, net.stem, ("0", "1"))
+            if isinstance(net, resnet.ResNet):
+                return _Stem(None, None, normalize, net, ("conv1", "bn1"), isinstance(getattr(net, "maxpool", None), nn.MaxPool2d))
+            return _Stem(None, None, normalize, net.stem, ("conv", "bn"))
+        self._img_stem = stem_of(self.image_encoder.features, True)
+        self._lid_stem = stem_of(self.lidar_encoder._model, False)
+
+    def _pooled(self, x, y, im, li):
+        """late_fusion.py:89-106: pool -> flatten -> norm_after_pool (LayerNorm for a ConvNeXt trunk, else nothing) per branch, then the sum."""
+        ni, nl = self.norm_after_pool_img, self.norm_after_pool_lidar
+        if not isinstance(ni, nn.LayerNorm) and not isinstance(nl, nn.LayerNorm):
+            return F_.GlobalPoolAddFn.apply(x, y)
+        zero = lambda t: torch.zeros(t.shape[0], 1, 1, t.shape[3], dtype=t.dtype, device=t.device)      # GlobalPoolAddFn pools two maps: pool one
+        pi = F_.PoolNormFn.apply(x, ni, ni.weight, ni.bias) if isinstance(ni, nn.LayerNorm) else F_.GlobalPoolAddFn.apply(x, zero(x))
+        pl = F_.PoolNormFn.apply(y, nl, nl.weight, nl.bias) if isinstance(nl, nn.LayerNorm) else F_.GlobalPoolAddFn.apply(y, zero(y))
+        return pi + pl
 
     def forward_nhwc(self, image, lidar, velocity, lidar_extra=None, lidar_nhwc=None):
         feats, grid, fused = self._run(image, lidar, lidar_extra, lambda i, x, y: (x, y), lidar_nhwc)
