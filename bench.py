@@ -448,7 +448,7 @@ def main():
                                    "%s, dropout %.2f, %s" % (names[backbone], nparam / 1e6, B, H, W,
                                                              {"f32": "fp32", "f32x3": "fp32 storage/accumulate, contractions as exact bf16x3 splits on the bf16 MFMA (6 partial products, fp32-accurate)",
                                                               "bf16": "bf16 MFMA contractions (fp32 accumulate / master weights / AdamW; GPT linear layers on bf16-STORED operands, other contractions round fp32 operands in registers)",
-                                                              "fp16": "fp16 MFMA contractions, static loss scale 1024 (fp32 accumulate / master weights / AdamW; GPT linear layers on half-STORED operands, other contractions round fp32 operands in registers)"}[args.dtype], args.dropout,
+                                                              "fp16": "fp16 MFMA contractions, dynamic loss scale with overflow skip (fp32 accumulate / master weights / AdamW; GPT linear layers on half-STORED operands, other contractions round fp32 operands in registers)"}[args.dtype], args.dropout,
                                                                "hipGraph replay" if not args.no_graph else "eager"),
                        "global_batch": B * world, "parallelism": "dp%d" % world, "final_loss": round(loss, 4),
                        "grad_allreduce": ("RCCL, %d backward segments, %s bucket all-reduce overlapped on a side stream" % (eng.n_pieces(), args.grad_dtype)) if world > 1 else "none (1 rank)"},

@@ -356,6 +356,14 @@ int tf_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, float*
 /* The same update with the gradients multiplied by grad_scale on the way in (= 1 / loss scale of the fp16 mode; the loss scale seeds the backward). */
 int tf_adamw_scaled_f32(float* p, const float* g, float* m, float* v, int64_t n, float* state_dev, float beta1, float beta2, float eps, float weight_decay,
                         float grad_scale, void* stream);
+/* The same update under a DYNAMIC loss scale (fp16 mode; the reference trains fp32 - config.py:55 - and has no counterpart; semantics of
+ * torch.cuda.amp.GradScaler): ls_state = {scale, clean steps, found_inf, growth interval} floats on the device.  The call (1) sets found_inf
+ * when any of g_check[0 .. n_check) is Inf / NaN (pass the WHOLE reduced gradient arena here, also when p / g / m / v are a ZeRO-1 shard, so
+ * every rank decides alike), (2) skips the step - parameters, moments and the step counter untouched - when it is set, else updates with the
+ * gradients divided by scale, (3) halves the scale after an overflow / doubles it after `growth interval` clean steps and clears found_inf.
+ * The next backward is seeded with ls_state[0].  No host synchronisation: hipGraph-capturable. */
+int tf_adamw_dynscale_f32(float* p, const float* g, float* m, float* v, int64_t n, float* state_dev, float beta1, float beta2, float eps,
+                          float weight_decay, const float* g_check, int64_t n_check, float* ls_state, void* stream);
 /* lidar_to_histogram_features (data.py:446-470): points (B, max_points, stride>=3) f32 -> (B,2,256,256),
  * integer-exact; num_points may be NULL. */
 int tf_lidar_hist_f32(const float* points, const int32_t* num_points, int B, int max_points, int point_stride, float* out, void* stream);

@@ -353,3 +353,40 @@ def test_convnext_trunks_match_oracle():
     batch = mc.small_batch(2, 32, 64, 64, 40)
     lp, lr = mc.run_pair(prod, ref, cfg, batch, "cpu")
     mc.compare(prod, ref, lp, lr)
+
+
+def test_fp16_dynamic_loss_scale_skips_overflowed_steps():
+    """fp16 mode (BASELINE configs[4]) under the device-side dynamic loss scale (tf_adamw_dynscale_f32; GradScaler policy - the reference trains
+    fp32 and has none): a clean step == the static-scale step; a step whose gradients overflow leaves parameters, moments and the step counter
+    untouched and halves the scale; the scale doubles after ``loss_scale_growth_interval`` clean steps.  All on the device (captured-graph safe)."""
+    from transfuser_amd import ops
+    from transfuser_amd.train import Engine
+    cfg = mc.tiny_config(n_layer=1)
+    cfg.loss_scale_growth_interval = 2
+    batch = mc.small_batch(2, 32, 64, 64, 40)
+    try:
+        prod, _ = mc.build_pair(cfg, "regnety_tiny", "cpu", seed=5)
+        prod.train()
+        eng = Engine(prod, cfg, lr=1e-3, precision="fp16")
+        assert eng.ls_state is not None and float(eng.ls_state[0]) == 65536.0
+        eng.ls_state[0] = 1024.0
+        eng.train_step(batch)
+        p1 = eng.arena.params.clone()
+        assert float(eng.optimizer.state[0]) == 1.0 and eng.ls_state.tolist()[:3] == [1024.0, 1.0, 0.0]
+        ref_m, _ = mc.build_pair(cfg, "regnety_tiny", "cpu", seed=5)
+        ref_m.train()
+        ref = Engine(ref_m, cfg, lr=1e-3, precision="fp16", loss_scale=1024.0)
+        ref.train_step(batch)
+        assert torch.equal(ref.arena.params, p1), (ref.arena.params - p1).abs().max()      # same seed, same 1 / 1024: bitwise
+        m1, v1 = eng.optimizer.exp_avg.clone(), eng.optimizer.exp_avg_sq.clone()
+        eng.ls_state[0] = 2.0 ** 120                                                        # every half-precision dy overflows
+        eng.train_step(batch)
+        assert not torch.isfinite(eng.arena.grads).all()
+        assert torch.equal(eng.arena.params, p1) and torch.equal(eng.optimizer.exp_avg, m1) and torch.equal(eng.optimizer.exp_avg_sq, v1)
+        assert float(eng.optimizer.state[0]) == 1.0 and eng.ls_state.tolist()[:3] == [2.0 ** 119, 0.0, 0.0]
+        eng.ls_state[0] = 512.0
+        eng.train_step(batch); eng.train_step(batch)                                        # two clean steps: the scale doubles, the counter restarts
+        assert float(eng.optimizer.state[0]) == 3.0 and eng.ls_state.tolist()[:3] == [1024.0, 0.0, 0.0]
+        assert not torch.equal(eng.arena.params, p1) and torch.isfinite(eng.arena.params).all()
+    finally:
+        ops.set_precision("fp32")

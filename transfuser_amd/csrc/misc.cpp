@@ -59,11 +59,38 @@ __global__ void __launch_bounds__(256) cast_bf16_f32_kernel(const uint16_t* __re
 // torch.optim.AdamW (train.py:142: lr 1e-4, betas (.9,.999), eps 1e-8, weight_decay 0.01, decoupled),
 // ONE launch over the flat parameter arena.  state[0] = step (float), state[1] = lr; the step is
 // advanced by adamw_tick_kernel so a captured graph replays correctly.
-__global__ void adamw_tick_kernel(float* state) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) state[0] += 1.f;
+__global__ void adamw_tick_kernel(float* state, const float* ls = nullptr) {
+    if (threadIdx.x == 0 && blockIdx.x == 0 && !(ls && ls[2] != 0.f)) state[0] += 1.f;      // a skipped (overflowed) step does not count
+}
+// ---- dynamic loss scaling for the fp16 mode (the reference trains fp32 and has none; semantics of torch.cuda.amp.GradScaler: skip the
+// optimizer step when any gradient is non-finite and halve the scale, double it after growth_interval clean steps).  Everything lives on
+// the device - ls = {scale, good steps, found_inf, growth interval} - so the captured step replays it: the backward of step t is seeded
+// with ls[0] (the Engine's seed tensor IS a view of it), this check reads the finished gradients, AdamW divides by ls[0] or returns, and the
+// update kernel prepares ls[0] for step t + 1.
+__global__ void __launch_bounds__(256) grad_nonfinite_kernel(const float* __restrict__ g, long n4, long n, float* __restrict__ ls) {
+    unsigned bad = 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(g)[i];
+        bad |= ((__float_as_uint(v.x) & 0x7f800000u) == 0x7f800000u) | ((__float_as_uint(v.y) & 0x7f800000u) == 0x7f800000u) |
+               ((__float_as_uint(v.z) & 0x7f800000u) == 0x7f800000u) | ((__float_as_uint(v.w) & 0x7f800000u) == 0x7f800000u);
+    }
+    for (long i = n4 * 4 + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) bad |= (__float_as_uint(g[i]) & 0x7f800000u) == 0x7f800000u;
+    if (bad) ls[2] = 1.0f;             // every writer stores the same value: no atomic needed
+}
+__global__ void loss_scale_update_kernel(float* __restrict__ ls) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float scale = ls[0], good = ls[1];
+    if (ls[2] != 0.f) { scale = fmaxf(scale * 0.5f, 1.0f); good = 0.f; }
+    else if (++good >= ls[3]) { scale = fminf(scale * 2.0f, 16777216.0f); good = 0.f; }
+    ls[0] = scale; ls[1] = good; ls[2] = 0.f;
 }
 __global__ void __launch_bounds__(256) adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                                                    long n4, long n, const float* __restrict__ state, float b1, float b2, float eps, float wd, float gs) {
+                                                    long n4, long n, const float* __restrict__ state, float b1, float b2, float eps, float wd, float gs,
+                                                    const float* __restrict__ ls = nullptr) {
+    if (ls) {                          // dynamic loss scale: ls = {scale, good steps, found_inf, growth interval}; an overflowed step is skipped as a whole
+        if (ls[2] != 0.f) return;
+        gs = 1.0f / ls[0];
+    }
     const float step = state[0], lr = state[1];
     const float bc1 = 1.f - powf(b1, step), bc2 = 1.f - powf(b2, step);
     const float step_size = lr / bc1, inv_sq_bc2 = 1.f / sqrtf(bc2), decay = 1.f - lr * wd;
@@ -165,10 +192,21 @@ extern "C" int tf_adamw_scaled_f32(float* p, const float* g, float* m, float* v,
                                    float weight_decay, float grad_scale, void* stream) {
     TF_REQUIRE(p && g && m && v && state_dev && n >= 0, "tf_adamw_f32: bad arguments");
     TF_REQUIRE(aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v), "tf_adamw_f32: arenas must be 16-byte aligned");
-    TF_LAUNCH(adamw_tick_kernel, dim3(1), dim3(64), stream, state_dev);
+    TF_LAUNCH(adamw_tick_kernel, dim3(1), dim3(64), stream, state_dev, (const float*)nullptr);
     if (n > 0) TF_LAUNCH(adamw_kernel, dim3(ew_blocks(n / 4 + 1, 8192)), dim3(256), stream, p, g, m, v, (long)(n / 4), (long)n, (const float*)state_dev,
-                         beta1, beta2, eps, weight_decay, grad_scale);
+                         beta1, beta2, eps, weight_decay, grad_scale, (const float*)nullptr);
     return launch_status("tf_adamw_f32");
+}
+extern "C" int tf_adamw_dynscale_f32(float* p, const float* g, float* m, float* v, int64_t n, float* state_dev, float beta1, float beta2, float eps,
+                                     float weight_decay, const float* g_check, int64_t n_check, float* ls_state, void* stream) {
+    TF_REQUIRE(p && g && m && v && state_dev && ls_state && n >= 0 && n_check >= 0 && (n_check == 0 || g_check), "tf_adamw_dynscale_f32: bad arguments");
+    TF_REQUIRE(aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v) && (!g_check || aligned16(g_check)), "tf_adamw_dynscale_f32: arenas must be 16-byte aligned");
+    if (n_check > 0) TF_LAUNCH(grad_nonfinite_kernel, dim3(ew_blocks(n_check / 4 + 1, 8192)), dim3(256), stream, g_check, (long)(n_check / 4), (long)n_check, ls_state);
+    TF_LAUNCH(adamw_tick_kernel, dim3(1), dim3(64), stream, state_dev, (const float*)ls_state);
+    if (n > 0) TF_LAUNCH(adamw_kernel, dim3(ew_blocks(n / 4 + 1, 8192)), dim3(256), stream, p, g, m, v, (long)(n / 4), (long)n, (const float*)state_dev,
+                         beta1, beta2, eps, weight_decay, 1.0f, (const float*)ls_state);
+    TF_LAUNCH(loss_scale_update_kernel, dim3(1), dim3(64), stream, ls_state);
+    return launch_status("tf_adamw_dynscale_f32");
 }
 extern "C" int tf_lidar_hist_f32(const float* points, const int32_t* num_points, int B, int max_points, int point_stride, float* out, void* stream) {
     TF_REQUIRE(points && out && B > 0 && max_points >= 0 && point_stride >= 3, "tf_lidar_hist_f32: bad arguments");

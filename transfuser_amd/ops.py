@@ -1203,6 +1203,16 @@ def adamw_(p, g, m, v, state, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0
     _hbm_end(_h, "adamw (28 B / parameter: p, g, m, v read; p, m, v written)", 28 * p.numel())
 
 
+def adamw_dynscale_(p, g, m, v, state, ls_state, g_check, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.01):
+    """AdamW under the device-side dynamic loss scale ``ls_state`` = [scale, clean steps, found_inf, growth interval] (tf_adamw_dynscale_f32):
+    non-finite check over ``g_check`` (the whole gradient arena), skip-or-update with gradients / scale, scale halved / doubled."""
+    _h = _hbm_begin()
+    check(L().tf_adamw_dynscale_f32(ptr(p), ptr(g), ptr(m), ptr(v), ctypes.c_int64(p.numel()), ptr(state), ctypes.c_float(beta1), ctypes.c_float(beta2),
+                                    ctypes.c_float(eps), ctypes.c_float(weight_decay), ptr(g_check), ctypes.c_int64(g_check.numel()), ptr(ls_state), stream_of(p)),
+          "tf_adamw_dynscale_f32")
+    _hbm_end(_h, "adamw (28 B / parameter: p, g, m, v read; p, m, v written)", 28 * p.numel() + 4 * g_check.numel())
+
+
 def cast_bf16(x, out=None):
     """fp32 -> bf16 (round to nearest even)."""
     if out is None:

@@ -172,6 +172,11 @@ class FlatAdamW:
 
     def step(self):
         a = self.arena
+        ls = getattr(self, "ls_state", None)
+        if ls is not None:      # fp16 mode with the dynamic loss scale: overflow check over the WHOLE (reduced) gradient arena, skip-or-update, scale update
+            ops.adamw_dynscale_(a.params[self.lo:self.hi], a.grads[self.lo:self.hi], self.exp_avg, self.exp_avg_sq, self.state, ls, a.grads[:a.active_numel],
+                                self.betas[0], self.betas[1], self.eps, self.weight_decay)
+            return
         ops.adamw_(a.params[self.lo:self.hi], a.grads[self.lo:self.hi], self.exp_avg, self.exp_avg_sq, self.state, self.betas[0], self.betas[1],
                    self.eps, self.weight_decay, grad_scale=getattr(self, "grad_scale", 1.0))
 
@@ -363,7 +368,10 @@ class Engine:
         ranges are all-reduced while the next segment runs.  None = DEFAULT_CUTS when there is more than one rank (and the backbone is a
         chain: transFuser / latentTF), no cut on a single GPU; () = never cut.
         ``precision``: compute precision of every MFMA-engine contraction (process-wide, ops.set_precision); None keeps the current one.
-        ``loss_scale``: static loss scale S (the backward is seeded with S instead of 1, AdamW multiplies the gradients by 1 / S); None = 1024
+        ``loss_scale``: a number = STATIC loss scale S (the backward is seeded with S instead of 1, AdamW multiplies the gradients by 1 / S);
+        None = 1 in the fp32 / f32x3 / bf16 modes and a DYNAMIC scale in fp16 mode (initial 2^16, device-side overflow check in front of
+        AdamW: the step is skipped and the scale halved on Inf / NaN gradients, doubled after ``loss_scale_growth_interval`` = 2000 clean
+        steps - torch.cuda.amp.GradScaler's policy; the reference trains fp32 and has no counterpart); formerly None = static 1024
         in "fp16" precision (half operands flush gradients below 6e-8 to zero) and 1 otherwise.  The reported losses are unscaled."""
         self.model = model
         self.config = config
@@ -393,11 +401,15 @@ class Engine:
         self.zero = bool(zero_redundancy_optimizer) and self.reducer.world > 1      # train.py:143-146
         rank = dist.get_rank(group) if self.zero else 0
         self.optimizer = FlatAdamW(self.arena, lr=lr, shard=(rank, self.reducer.world) if self.zero else None)
-        if loss_scale is None:
-            loss_scale = 1024.0 if ops.get_precision() == "fp16" else 1.0
-        self.loss_scale = float(loss_scale)
+        self.ls_state = None
+        if loss_scale is None and ops.get_precision() == "fp16":
+            dev = self.arena.params.device
+            self.ls_state = torch.tensor([65536.0, 0.0, 0.0, float(getattr(config, "loss_scale_growth_interval", 2000))], dtype=torch.float32, device=dev)
+            self.optimizer.ls_state = self.ls_state
+            loss_scale = 65536.0
+        self.loss_scale = float(loss_scale if loss_scale is not None else 1.0)
         self.optimizer.grad_scale = 1.0 / self.loss_scale
-        self._seed_grad = None
+        self._seed_grad = self.ls_state[0] if self.ls_state is not None else None      # a VIEW of the device scale: the update kernel re-seeds the next backward
         self.reducer.broadcast_params()
         w = [1.0] + [0.0] * 10 if wp_only else list(config.detailed_losses_weights)
         self.detailed_weights = dict(zip(config.detailed_losses, w))
@@ -461,7 +473,9 @@ class Engine:
         for key, value in losses.items():   # train.py:307-311
             term = self.detailed_weights[key] * value
             loss = term if loss is None else loss + term
-        if self.loss_scale != 1.0:
+        if self.ls_state is not None:
+            loss.backward(self._seed_grad)
+        elif self.loss_scale != 1.0:
             if self._seed_grad is None or self._seed_grad.device != loss.device:
                 self._seed_grad = torch.full((), self.loss_scale, dtype=torch.float32, device=loss.device)
             loss.backward(self._seed_grad)
@@ -540,7 +554,7 @@ class Engine:
         # the eager loop / the reference's one-update-per-batch loop (train.py:304-316).  Everything a step mutates is snapshotted and put
         # back: parameters, AdamW moments + step counter, BatchNorm running statistics / dropout seed (all module buffers).
         opt = self.optimizer
-        snap = [(t, t.clone()) for t in [self.arena.params, opt.exp_avg, opt.exp_avg_sq, opt.state] + list(self.model.buffers())]
+        snap = [(t, t.clone()) for t in [self.arena.params, opt.exp_avg, opt.exp_avg_sq, opt.state] + ([self.ls_state] if self.ls_state is not None else []) + list(self.model.buffers())]
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):   # warm-up on a side stream (allocator + lazy inits) before capture
