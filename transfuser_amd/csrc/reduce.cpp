@@ -455,63 +455,55 @@ __global__ void __launch_bounds__(256) bn_fwd_finalize_kernel(const float* __res
 }
 // The same from per-part Welford triples written by the PRODUCING convolution's epilogue (tf_gemm_desc.colstat, tf_conv*_colstat_f32):
 // parts[(p * 3 + {0: count, 1: mean, 2: M2}) * C + c].  WPC waves per channel (1: up to 256 parts, four channels per block; 4: a whole block per
-// channel - the stem / stage-1 / stage-2 layers hand over 320 .. 3520 parts): a thread folds its parts into ONE running triple with Chan's
-// pairwise update (single pass: four triples = twelve loads in flight per trip, no second pass for the mean), then the threads' triples are
-// merged by a butterfly of the same update and, for WPC = 4, through LDS in wave order - a fixed order, bitwise reproducible, no
-// cancellation whatever the mean / spread ratio of the activations.  (Round 3 walked more than 256 parts in a two-pass loop of dependent
-// single loads: 20 .. 60 us per launch on exactly those layers.)
-struct Welford { float n, mean, m2; };
-__device__ __forceinline__ Welford wf_merge(const Welford& a, const Welford& b) {
-    const float n = a.n + b.n;
-    if (!(n > 0.f)) return a;
-    const float d = b.mean - a.mean, fb = b.n / n;
-    Welford r;
-    r.n = n;
-    r.mean = a.mean + d * fb;
-    r.m2 = a.m2 + b.m2 + d * d * (a.n * fb);
-    return r;
-}
+// channel, up to 2048 parts - the stem / stage-1 / stage-2 layers hand over 320 .. 1250): a thread keeps ALL its parts in registers (NPT triples:
+// every load of the kernel is issued in one batch), first the count-weighted mean over the whole channel, then
+// M2 = sum_p M2_p + n_p (mean_p - mean)^2 (Chan et al.) against THAT mean - the two-pass form: one rounding in the mean, no cancellation
+// whatever the mean / spread ratio of the activations.  Fixed summation order: bitwise reproducible.  (Round 3 walked more than 256 parts in a
+// loop of dependent single loads: 20 .. 60 us per launch on exactly those layers; a single-pass pairwise Welford merge was tried this round
+// and rejected: its running mean carries 2-3 roundings, which this network amplifies into measurably noisier gradients.)
 template <int WPC>
+__device__ __forceinline__ float chan_sum(float v, float* red) {          // all T = 64 * WPC threads of the channel -> the total, in every thread
+    v = wave_sum(v);
+    if (WPC == 1) return v;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = red[0];
+#pragma unroll
+    for (int i = 1; i < WPC; ++i) t += red[i];
+    return t;
+}
+template <int WPC, int NPT>
 __global__ void __launch_bounds__(256) bn_fwd_finalize_parts_kernel(const float* __restrict__ parts, int nparts, const float* __restrict__ gamma,
                                                                     const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
                                                                     float* __restrict__ save_mean, float* __restrict__ save_invstd,
                                                                     float* __restrict__ coef, int C, float n, float momentum, float eps) {
     constexpr int T = 64 * WPC;                                   // threads per channel
-    __shared__ float red[4][3];
+    __shared__ float red[4];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int c0 = WPC == 1 ? blockIdx.x * 4 + wave : blockIdx.x, t = WPC == 1 ? lane : (int)threadIdx.x;
     const bool live = c0 < C;
     const int c = live ? c0 : 0;
     const long ps = 3L * C;
-    Welford acc{0.f, 0.f, 0.f};
-    for (int p0 = 0; p0 < nparts; p0 += 4 * T) {
-        Welford w[4];
+    float np[NPT], mp[NPT], qp[NPT];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int p = p0 + t + T * u;
-            const long o = (long)(p < nparts ? p : nparts - 1) * ps + c;
-            w[u].n = parts[o]; w[u].mean = parts[o + C]; w[u].m2 = parts[o + 2L * C];
-            if (!live || p >= nparts) { w[u].n = 0.f; w[u].m2 = 0.f; }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) acc = wf_merge(acc, w[u]);
+    for (int u = 0; u < NPT; ++u) {
+        const int p = t + T * u;
+        const long o = (long)(p < nparts ? p : nparts - 1) * ps + c;
+        np[u] = parts[o]; mp[u] = parts[o + C]; qp[u] = parts[o + 2L * C];
+        if (!live || p >= nparts) { np[u] = 0.f; qp[u] = 0.f; }
     }
+    float sn = 0.f, sm = 0.f, m2 = 0.f;
 #pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {                            // lane l ends with the merge of lanes [l & ~(2m - 1), ...) in ascending order
-        Welford o{shfl_xor(acc.n, m), shfl_xor(acc.mean, m), shfl_xor(acc.m2, m)};
-        acc = (lane & m) ? wf_merge(o, acc) : wf_merge(acc, o);
-    }
-    if (WPC > 1) {
-        if (lane == 0) { red[wave][0] = acc.n; red[wave][1] = acc.mean; red[wave][2] = acc.m2; }
-        __syncthreads();
-        if (threadIdx.x != 0) return;
-        acc = Welford{red[0][0], red[0][1], red[0][2]};
+    for (int u = 0; u < NPT; ++u) { sn += np[u]; sm += np[u] * mp[u]; }
+    sn = chan_sum<WPC>(sn, red);
+    sm = chan_sum<WPC>(sm, red);
+    const float mean = sn > 0.f ? sm / sn : 0.f;
 #pragma unroll
-        for (int wv = 1; wv < WPC; ++wv) acc = wf_merge(acc, Welford{red[wv][0], red[wv][1], red[wv][2]});
-    }
-    if (!live || lane != 0) return;
-    const float mean = acc.mean;
-    float var = acc.m2 / n;
+    for (int u = 0; u < NPT; ++u) { const float d = mp[u] - mean; m2 += qp[u] + np[u] * d * d; }
+    m2 = chan_sum<WPC>(m2, red);
+    if (!live || t != 0) return;
+    float var = m2 / n;
     if (var < 0.f) var = 0.f;
     const float invstd = 1.0f / sqrtf(var + eps);
     save_mean[c] = mean;
@@ -781,8 +773,12 @@ inline int ew_blocks(long nvec) {
 // critical path of the GPT stages.
 inline void launch_finalize_parts(const float* parts, int nparts, const float* gamma, const float* beta, float* rmean, float* rvar, float* save_mean,
                                   float* save_invstd, float* coef, int C, float n, float momentum, float eps, void* stream) {
-    if (nparts <= 256) TF_LAUNCH(bn_fwd_finalize_parts_kernel<1>, dim3(cdiv(C, 4)), dim3(256), stream, parts, nparts, gamma, beta, rmean, rvar, save_mean, save_invstd, coef, C, n, momentum, eps);
-    else TF_LAUNCH(bn_fwd_finalize_parts_kernel<4>, dim3(C), dim3(256), stream, parts, nparts, gamma, beta, rmean, rvar, save_mean, save_invstd, coef, C, n, momentum, eps);
+#define TF_FIN(WPC_, NPT_, GRID_) TF_LAUNCH((bn_fwd_finalize_parts_kernel<WPC_, NPT_>), dim3(GRID_), dim3(256), stream, parts, nparts, gamma, beta, rmean, rvar, save_mean, save_invstd, coef, C, n, momentum, eps)
+    if (nparts <= 256) TF_FIN(1, 4, cdiv(C, 4));
+    else if (nparts <= 1024) TF_FIN(4, 4, C);
+    else if (nparts <= 2048) TF_FIN(4, 8, C);
+    else TF_FIN(4, 64, C);               // up to 16384 parts (524288 rows at 32 rows per part): registers / scratch, never reached by the trunks (<= 40000 rows)
+#undef TF_FIN
 }
 constexpr int kMultiMax = 8;
 struct MultiSum { const float* x[kMultiMax]; float* out[kMultiMax]; int C[kMultiMax]; long ld[kMultiMax]; int strip0[kMultiMax + 1]; int n; };
@@ -872,7 +868,7 @@ extern "C" int tf_bn_fwd_f32(const float* x, int rows, int C, const float* gamma
 extern "C" int tf_bn_fwd_parts_f32(const float* x, int rows, int C, const float* parts, int nparts, const float* gamma, const float* beta,
                                    float* running_mean, float* running_var, float momentum, float eps, const float* res, int relu, float* y,
                                    float* save_mean, float* save_invstd, float* ws, void* stream) {
-    TF_REQUIRE(x && parts && nparts > 0 && gamma && beta && y && save_mean && save_invstd && ws && rows > 0 && C > 0, "tf_bn_fwd_parts_f32: bad arguments");
+    TF_REQUIRE(x && parts && nparts > 0 && nparts <= 16384 && gamma && beta && y && save_mean && save_invstd && ws && rows > 0 && C > 0, "tf_bn_fwd_parts_f32: bad arguments");
     float* coef = ws + kWsFloats / 2;
     launch_finalize_parts(parts, nparts, gamma, beta, running_mean, running_var, save_mean, save_invstd, coef, C, (float)rows, momentum, eps, stream);
     const bool v4 = (C % 4 == 0) && aligned16(x) && aligned16(y) && (!res || aligned16(res));
@@ -972,7 +968,7 @@ extern "C" int tf_se_scale_bwd_x_f32(const float* dy, const float* gate, const f
 // consumers of this layer in the forward AND the backward pass)
 extern "C" int tf_bn_finalize_parts_f32(const float* parts, int nparts, int rows, int C, const float* gamma, const float* beta, float* running_mean,
                                         float* running_var, float momentum, float eps, float* save_mean, float* save_invstd, float* coef_out, void* stream) {
-    TF_REQUIRE(parts && nparts > 0 && gamma && beta && save_mean && save_invstd && coef_out && rows > 0 && C > 0, "tf_bn_finalize_parts_f32: bad arguments");
+    TF_REQUIRE(parts && nparts > 0 && nparts <= 16384 && gamma && beta && save_mean && save_invstd && coef_out && rows > 0 && C > 0, "tf_bn_finalize_parts_f32: bad arguments");
     launch_finalize_parts(parts, nparts, gamma, beta, running_mean, running_var, save_mean, save_invstd, coef_out, C, (float)rows, momentum, eps, stream);
     return launch_status("tf_bn_finalize_parts_f32");
 }
