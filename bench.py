@@ -30,8 +30,15 @@ GFLOP_PER_SAMPLE = {("transFuser", 160): 230.3, ("transFuser", 256): 266.6, ("la
                     ("geometric_fusion", 160): 110.2}   # algorithmic training FLOPs (3x forward), SURVEY.md section 8(d)
 PEAK_F32_MFMA_TF = 157.3                                # /opt/skills/guides/MI355X_MICROARCH.md (v_mfma_f32_32x32x2_f32)
 PEAK_BF16_MFMA_TF = 2500.0                              # dense bf16 MFMA peak of the same guide (never the 2:1-sparsity figure)
-PMC_FILE = next((f for f in (os.path.join(ROOT, "profiles", "r03_pmc_gemm_roofline.json"), os.path.join(ROOT, "profiles", "r02_pmc_gemm_roofline.json")) if os.path.exists(f)),
-                os.path.join(ROOT, "profiles", "r03_pmc_gemm_roofline.json"))   # written by tools/pmc_roofline.sh (rocprofv3 --pmc passes); newest committed summary
+def _pmc_file(suffix=""):
+    """Newest committed rocprofv3 PMC summary of the dominant GEMM (tools/pmc_roofline.sh -> profiles/rNN_pmc_gemm_roofline[_<precision>].json)."""
+    for rnd in ("r04", "r03", "r02"):
+        f = os.path.join(ROOT, "profiles", "%s_pmc_gemm_roofline%s.json" % (rnd, suffix))
+        if os.path.exists(f):
+            return f
+    return ""
+
+
 DOMINANT = ("gemm a0b0", (1740, 6048, 1512, 1))         # GPT-4 mlp.0 forward: [1740 x 1512] . [1512 x 6048], bias + ReLU epilogue
 
 
@@ -120,7 +127,7 @@ def dominant_kernel_roofline(eng, batch, dev, log, peak=PEAK_F32_MFMA_TF):
     roof.update(engine_calls=len(rows), engine_ms_per_step=round(tot_s * 1e3, 2), engine_tflops=round(tot_fl / tot_s / 1e12, 2),
                 engine_frac=round(tot_fl / tot_s / 1e12 / PEAK, 4))
     roof["traffic"], roof["traffic_source"] = None, "no PMC summary committed"
-    pmc_file = PMC_FILE if peak == PEAK_F32_MFMA_TF else PMC_FILE.replace(".json", "_f32x3.json") if peak < PEAK_BF16_MFMA_TF else ""
+    pmc_file = _pmc_file("" if peak == PEAK_F32_MFMA_TF else "_f32x3" if peak < PEAK_BF16_MFMA_TF else "_" + ops.get_precision())
     if pmc_file and os.path.exists(pmc_file) and dom:
         try:
             pmc = json.load(open(pmc_file))

@@ -24,7 +24,7 @@ trace)      (cd /tmp && export TMPDIR=/tmp && timeout 500 rocprofv3 --kernel-tra
             cp $O/trace_$T/*kernel_stats.csv $O/${T}_kernel_stats${TRACE_TAG}.csv 2>/dev/null; rm -rf $O/trace_$T ;;
 check)      timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-alt --check 2>&1 | tail -6 ;;
 pmc_hbm)    timeout 600 bash tools/pmc_hbm.sh $T 2>&1 | tail -24 ;;
-pmc)        timeout 600 bash tools/pmc_roofline.sh fp32 2>&1 | tail -12 ;;
+pmc)        for pr in ${PMC_PRECS:-fp32 f32x3 bf16 fp16}; do TAG=$T timeout 600 bash tools/pmc_roofline.sh $pr 2>&1 | tail -9; done ;;
 hbm)        timeout 300 python tools/hbm_bench.py > $O/${T}_hbm_kernels.txt 2>&1; cat $O/${T}_hbm_kernels.txt ;;
 lab)        timeout 300 python tools/launch_lab.py > $O/${T}_launch_lab.txt 2>&1; cat $O/${T}_launch_lab.txt ;;
 grouped)    timeout 300 python tools/grouped_lab.py > $O/${T}_grouped_lab.txt 2>&1; cat $O/${T}_grouped_lab.txt ;;

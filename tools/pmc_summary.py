@@ -6,7 +6,8 @@ import csv, glob, json, os, sys
 d, out = sys.argv[1], sys.argv[2]
 PREC = sys.argv[3] if len(sys.argv) > 3 else "fp32"
 X3 = PREC == "f32x3"
-PEAK = 2500.0 / 6 if X3 else 157.3       # f32x3: six bf16 MFMA products per fp32 product, dense bf16 peak 2.5 PF
+S16 = PREC in ("bf16", "fp16")           # 16-bit STORED operands (tf_gemm16_nt_f32): one v_mfma_f32_32x32x16_{bf16,f16} per 32x32x16 product
+PEAK = 2500.0 / 6 if X3 else 2500.0 if S16 else 157.3       # f32x3: six bf16 MFMA products per fp32 product, dense bf16 / fp16 peak 2.5 PF
 M, N, K = 1740, 6048, 1512
 vals, durs, kname = {}, {}, None
 for cc in sorted(glob.glob(os.path.join(d, "*_counter_collection.csv"))):
@@ -22,7 +23,7 @@ for cc in sorted(glob.glob(os.path.join(d, "*_counter_collection.csv"))):
 avg = lambda v: sum(v[2:]) / max(1, len(v[2:]))          # skip the two warm-up launches
 A = {k: avg(v) for k, v in vals.items()}
 D = {k: avg(v) for k, v in durs.items()}
-algo = (M * K + N * K + M * N + N) * 4
+algo = (M * K + N * K) * (2 if S16 else 4) + (M * N + N) * 4
 lines = ["# rocprofv3 --pmc <one pass per line> --kernel-trace -- python tools/gemm_tuned.py %d %d %d nt 10 %s   (tools/pmc_roofline.sh)" % (M, N, K, PREC),
          "# kernel: %s" % kname, "# per-launch averages over 10 launches (2 warm-ups dropped); algorithmic bytes %.1f MB (A + B + C + bias)" % (algo / 1e6)]
 for k in sorted(A):
@@ -39,11 +40,13 @@ if "SQ_VALU_MFMA_BUSY_CYCLES" in A and "GRBM_GUI_ACTIVE" in A:
     clk = A["GRBM_GUI_ACTIVE"] / 8 / (D["GRBM_GUI_ACTIVE"] * 1e3)
     res.update(effective_clock_ghz=clk, clock_adjusted_peak_tflops=PEAK * clk / 2.4, precision=PREC, peak_tflops=PEAK)
     lines.append("effective clock %.2f GHz (GRBM_GUI_ACTIVE / 8 XCDs / duration) -> clock-adjusted %s peak %.1f TF/s; achieved %.1f TF/s" %
-                 (clk, "bf16-MFMA / 6 (f32x3)" if X3 else "fp32 MFMA", PEAK * clk / 2.4, 2.0 * M * N * K / D["GRBM_GUI_ACTIVE"] / 1e6))
+                 (clk, "bf16-MFMA / 6 (f32x3)" if X3 else "16-bit MFMA" if S16 else "fp32 MFMA", PEAK * clk / 2.4, 2.0 * M * N * K / D["GRBM_GUI_ACTIVE"] / 1e6))
     busy = A["SQ_VALU_MFMA_BUSY_CYCLES"]
     ideal = 2.0 * M * N * K / 4096 * 64 / 1.0        # MFMA 32x32x2 = 4096 FLOP, 64 cycles of one SIMD's pipe
     if X3:
         ideal = 6 * 2.0 * M * N * K / 32768 * 32     # six v_mfma_f32_32x32x16_bf16 (32768 FLOP, 32 cycles) per 32x32x16 product
+    if S16:
+        ideal = 2.0 * M * N * K / 32768 * 32
     res.update(mfma_busy_cycles=busy, mfma_ideal_simd_cycles=ideal)
     for denom_name, denom in (("SQ_BUSY_CYCLES", A.get("SQ_BUSY_CYCLES")),):
         if denom:
