@@ -25,6 +25,9 @@ const char* tf_last_error(void);
  * *.h and this header, sorted by file name; written into the compile line by transfuser_amd/build.py).  The reference has no counterpart
  * (it ships no native code); the Python binding compares it with the sources beside the library (transfuser_amd/_lib.py:load). */
 const char* tf_build_id(void);
+/* Stream-K GEMM launches issued by this process so far (diagnostics / tests: a pinned stream-K plan silently falls back to the data-parallel
+ * launch when the call carries no scratch or the tile count divides evenly). */
+long tf_streamk_launches(void);
 
 /* GEMM tiling plans.  The reference turns on cudnn.benchmark (train.py:115); the equivalent here: while tf_autotune(1)
  * is on (eager warm-up, NOT during graph capture - it synchronises), the first call of every distinct
@@ -71,6 +74,9 @@ typedef struct {
     const float* mask; int64_t ldmask;   /* optional (batch == 1, store mode): c(i,j) is zeroed unless mask[i*ldmask + j] > 0 - the ReLU
                                           * mask of a backward GEMM (dX = (dY W) * [act > 0]) fused into the epilogue */
     float* splitk_ws; int64_t splitk_ws_floats;
+    int* sk_flags;                       /* with splitk_ws: 2048 ints, ZERO on entry and left zero (caller-owned, persistent, one per stream): hand-over flags of the
+                                          * stream-K plans - persistent workgroups split the (tile, k) space evenly when the tile count does not divide over the
+                                          * resident slots (GPT-4: 672 tiles of 128 x 128 on 512 slots); NULL disables them */
     /* optional: train-mode BatchNorm statistics of the OUTPUT fused into the epilogue (timm ConvBnAct = bias-free conv + BatchNormAct2d,
      * transfuser.py:380,442; point_pillar.py:15-25 Linear + BatchNorm1d).  colstat: device buffer of >= 3 * n * ceil(m / 32) floats that
      * receives per-part Welford triples [part][{count, mean, M2}][n]; *colstat_nparts (HOST int, written before the call returns) = number

@@ -2,6 +2,7 @@
 reference / the CPU oracle on the same seeded inputs.  ``dev`` is "cpu" for the emulated build
 (tests/test_kernels_emu.py) and "cuda" for the real MI355X run (tests/test_kernels_gpu.py).
 Tolerances: fp32, 1e-3 per north_star (most ops are far tighter); integer outputs exact."""
+import ctypes
 import math
 
 import numpy as np
@@ -1369,6 +1370,63 @@ def check_two_pass_splitk(dev, kind, sk):
     finally:
         ops.set_precision("fp32")
         ops.force_plan(0)
+
+
+STREAM_K = 2000000     # GemmPlan.splitk == kStreamK
+STREAM_K_KINDS_EMU = [2, 6]
+STREAM_K_KINDS_GPU = [1, 2, 3, 4, 5, 6, 7, 8]
+
+
+def check_stream_k(dev, kind):
+    """Stream-K plans of the LDS-DMA kernels (persistent workgroups over the (tile, k-tile) space, a cut tile's k-tail handed over through
+    scratch + flag): every operand layout and epilogue form (bias + residual + ReLU; ReLU mask; accumulate; alpha), ragged M / N / K, the
+    fused BatchNorm statistics (the owner of a cut tile holds the complete sum), bitwise run-to-run equality (fixed head + tail order), and the
+    flags left clear for the next launch.  Sizes: a tile count that does not divide over the device's resident slots (8 emulated CUs on the
+    host; on the MI355X the shapes are scaled so that tiles are actually cut)."""
+    info = {1: (128, 128), 2: (64, 64), 3: (128, 64), 4: (64, 128), 5: (128, 128), 6: (64, 64), 7: (64, 128), 8: (128, 64)}[kind]
+    bm, bn = info
+    gpu = str(dev).startswith("cuda")
+    # tiles: a little more than one full round of the resident slots (host: 8 CUs x 2..5 workgroups; MI355X: 256 CUs)
+    tm, tn = (6, 7) if not gpu else (33, 19)
+    m, n = tm * bm - 17, tn * bn - 20            # ragged last tile row / column, n % 4 == 0
+    L = ops.L()
+    L.tf_streamk_launches.restype = ctypes.c_long
+    for k in ((260, 264) if not gpu else (1032, 1512)):
+        ops.force_dma(kind, STREAM_K)
+        n0 = L.tf_streamk_launches()
+        try:
+            x, w, b, r = R(m, k, dev=dev), R(n, k, dev=dev) * 0.2, R(n, dev=dev), R(m, n, dev=dev)
+            want = torch.relu(x.double() @ w.double().t() + b.double() + r.double()).float()
+            y = ops.linear_fwd(x, w, b, relu=True, res=r)
+            close(y, want, what="stream-K fwd nt kind %d k %d" % (kind, k))
+            assert torch.equal(y, ops.linear_fwd(x, w, b, relu=True, res=r)), "stream-K must be run-to-run deterministic"
+            flags = ops._sk_flags(x.device)
+            assert not flags.any(), "stream-K flags must be clear between launches"
+            dy, act = R(m, n, seed=1, dev=dev), R(m, k, seed=5, dev=dev)
+            if k % 4 == 0:
+                close(ops.linear_dgrad(dy, w, mask=act), ((dy.double() @ w.double()) * (act > 0)).float(), what="stream-K dgrad nn + mask kind %d" % kind)
+                dw0 = R(n, k, seed=2, dev=dev)
+                close(ops.linear_wgrad(dy, x, dw0.clone(), accumulate=True), (dw0.double() + dy.double().t() @ x.double()).float(), what="stream-K wgrad tn (+=) kind %d" % kind)
+            a, bb = R(m + 17, k, dev=dev), R(n, k, seed=4, dev=dev)
+            mm = m + 17                               # tt needs m % 4 == 0
+            c = torch.empty(mm, n, device=dev)
+            ops.gemm(a.t().contiguous(), bb, c, mm, n, k, mm, k, n, a_trans=True, alpha=0.5)
+            close(c, (0.5 * (a.double() @ bb.double().t())).float(), what="stream-K tt kind %d" % kind)
+            assert not flags.any()
+            # (a layout whose tile count happens to divide over the device's slots runs data-parallel: not every call below is cut on every device)
+            assert L.tf_streamk_launches() - n0 >= (5 if not gpu else 2), "the pinned stream-K plan did not run as stream-K (%d launches)" % (L.tf_streamk_launches() - n0)
+            # BatchNorm statistics from the epilogue of a stream-K launch
+            old = ops.FUSE_BN_STATS
+            ops.FUSE_BN_STATS = True
+            try:
+                if m <= ops._COLSTAT_MAX_ROWS and k % 4 == 0:
+                    yy, cs = ops.linear_fwd(x + 2.0, w, colstat=True)
+                    close(yy, ((x.double() + 2.0) @ w.double().t()).float(), what="stream-K fwd + colstat")
+                    _bn_from_parts(dev, yy.view(1, 1, m, n), cs, relu=True)
+            finally:
+                ops.FUSE_BN_STATS = old
+        finally:
+            ops.force_plan(0)
 
 
 # ---------------------------------------------------------------- BatchNorm statistics fused into the producing convolution

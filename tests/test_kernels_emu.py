@@ -157,6 +157,11 @@ def test_two_pass_splitk(cfg):
     kc.check_two_pass_splitk("cpu", *cfg)
 
 
+@pytest.mark.parametrize("kind", kc.STREAM_K_KINDS_EMU, ids=str)
+def test_stream_k_plans(kind):
+    kc.check_stream_k("cpu", kind)
+
+
 def test_f32x3_split_mode_direct_convs():
     kc.check_f32x3_direct("cpu")
 

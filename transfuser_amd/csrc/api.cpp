@@ -41,6 +41,7 @@ bool ablated(const char* kernel) {
 #endif
 extern "C" const char* tf_build_id(void) { return TF_BUILD_ID; }
 extern "C" int tf_version(void) { return 101; }
+extern "C" long tf_streamk_launches(void) { return tf::streamk_count(0); }
 extern "C" const char* tf_last_error(void) { return tf::g_err; }
 
 // ---- GEMM plan cache / autotuner switches -----------------------------------------------------------------------
@@ -62,6 +63,19 @@ void plan_store(const char* what, int M, int N, int K, int batch, int acc, const
     g_plans[PlanKey(what, M, N, K, batch, acc)] = p;
 }
 bool autotune_enabled() { return g_autotune; }
+long streamk_count(int add) { static long n = 0; n += add; return n; }
+int device_cus() {
+#ifdef TF_EMU
+    return 8;                       // small on purpose: the emulated stream-K launches cut tiles on test-sized problems
+#else
+    static const int n = [] {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        return cus;
+    }();
+    return n;
+#endif
+}
 static GemmPlan g_forced{0, 0, 0, 0, 0};
 bool forced_plan(GemmPlan* out) { if (g_forced.bm == 0) return false; *out = g_forced; return true; }
 }  // namespace tf

@@ -38,14 +38,15 @@ extern "C" long tf_gemm_splitk_ws_floats(const tf_gemm_desc* d) {
     if (!d || d->batch != 1 || d->m <= 0 || d->n <= 0 || d->k <= 0) return 0;
     const long slice = (long)d->m * twopass_ldws(d->n);
     GemmPlan p;
-    if (forced_plan(&p)) return p.splitk >= kTwoPass ? 4 * slice : 0;
+    const long sk_floats = (long)kStreamKMaxBlocks / 4 * 128 * 128;       // stream-K: <= 512 resident workgroups x one 128 x 128 partial tile (larger launches use smaller tiles)
+    if (forced_plan(&p)) return p.splitk == kStreamK ? sk_floats : p.splitk >= kTwoPass ? 4 * slice : 0;
     const char* site = !d->a_trans ? (d->b_trans ? "tf_gemm_f32[nn]" : "tf_gemm_f32[nt]") : (d->b_trans ? "tf_gemm_f32[tn]" : "tf_gemm_f32[tt]");
     int M = d->m, N = d->n;
     if (d->a_trans && d->b_trans && d->m <= 32 && d->n >= 2 * d->m && !d->bias && !d->res && !d->relu) return 0;       // swapped (column-strided) output: no two-pass
     const bool sk_ok = d->accumulate && !d->bias && !d->res && !d->relu;
     const int acc = (d->accumulate ? (sk_ok ? 2 : 1) : 0) + 4 * (gemm_precision() == 3 ? 1 : gemm_precision());
-    if (plan_lookup(site, M, N, d->k, 1, acc, &p)) return p.splitk >= kTwoPass ? (long)(p.splitk - kTwoPass) * slice : 0;
-    return autotune_enabled() ? 4 * slice : 0;
+    if (plan_lookup(site, M, N, d->k, 1, acc, &p)) return p.splitk == kStreamK ? sk_floats : p.splitk >= kTwoPass ? (long)(p.splitk - kTwoPass) * slice : 0;
+    return autotune_enabled() ? (4 * slice > sk_floats ? 4 * slice : sk_floats) : 0;
 }
 
 extern "C" int tf_gemm_f32(const tf_gemm_desc* d, void* stream) {
@@ -73,6 +74,7 @@ extern "C" int tf_gemm_f32(const tf_gemm_desc* d, void* stream) {
     ep.mode = d->accumulate ? 1 : 0;
     ep.mask = d->mask; ep.ldmask = d->ldmask;
     ep.sk_ws = d->splitk_ws; ep.sk_ws_floats = d->splitk_ws ? d->splitk_ws_floats : 0;
+    ep.sk_flags = d->splitk_ws ? d->sk_flags : nullptr;
     if (d->colstat) {
         TF_REQUIRE(d->colstat_nparts && d->batch == 1 && !d->accumulate && !d->res && !d->relu && !d->mask && !d->a_trans,
                    "tf_gemm_f32: colstat needs a plain store (batch 1, no residual / ReLU / mask / accumulate), row-major A and colstat_nparts");

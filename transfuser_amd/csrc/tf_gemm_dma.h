@@ -66,6 +66,34 @@ template <int NW> __device__ __forceinline__ void dma_barrier() {
 __device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 #endif
 
+// ---- stream-K (SK instantiations): cross-workgroup hand-over of a partial accumulator tile.  Only the words that cross workgroups are
+// accessed at agent scope (relaxed atomic store / load = global_store / global_load ... sc1: written through to / read from the memory
+// side, the XCDs' L2s are not coherent with each other); the producer drains its stores (vmcnt(0)) before its flag goes up.  No
+// __threadfence(): on gfx950 that is a write-back + invalidate of the XCD's whole L2 (reduce.cpp, "last block finishes").
+// hipcc turns the 64 hand-over addresses of a 2 x 2 accumulator block into 64 loop-invariant 64-bit registers, hoists them out of the work loop
+// and spills them (a scratch-using kernel: fewer resident waves, the persistent launch degenerates into rounds); an address that passes through
+// an empty asm cannot be hoisted, and the 16 accesses behind it fold their offsets into the instruction's 12-bit immediate
+#ifdef TF_EMU
+__forceinline__ float* sk_launder(float* p) { return p; }
+#else
+__device__ __forceinline__ float* sk_launder(float* p) { asm volatile("" : "+v"(p)); return p; }
+#endif
+#ifdef TF_EMU
+__forceinline__ void sk_store(float* p, float v) { *p = v; }
+__forceinline__ float sk_load(const float* p) { return *p; }
+__forceinline__ void sk_drain() {}
+__forceinline__ void sk_flag_set(int* f, int v) { *f = v; }
+__forceinline__ void sk_flag_wait(int* f) { if (*f == 0) { fprintf(stderr, "stream-K emulation: partial tile not ready (block order)\n"); abort(); } }
+#else
+__device__ __forceinline__ void sk_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float sk_load(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void sk_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void sk_flag_set(int* f, int v) { __hip_atomic_store(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void sk_flag_wait(int* f) {
+    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(4);
+}
+#endif
+
 // swizzle of the 16-byte chunk index inside a row of CH chunks (CH = BK / 4 = 4 or 8): with it the 16 lanes of every ds_read_b128 lane
 // group (MI355X_MICROARCH.md, LDS table) hit 16 distinct 16-byte slots of the 256-byte bank row.  Depends on (row mod 32) only.
 template <int CH> __device__ __forceinline__ int dma_swz(int row) { return CH == 4 ? ((row >> 2) & 3) : ((row >> 1) & 7); }
@@ -84,7 +112,7 @@ struct DmaCfg {
     static_assert(LDS_BYTES <= 64 * 1024, "M0 LDS base is kept within 64 KiB");
 };
 
-template <int TM, int TN, int WAVES_M, int WAVES_N, int BK, int STAGES, bool A_KC, bool B_KC, bool X3>
+template <int TM, int TN, int WAVES_M, int WAVES_N, int BK, int STAGES, bool A_KC, bool B_KC, bool X3, bool SK = false>
 __device__ __forceinline__ void gemm_dma_tile(const PlainOp& la_in, const PlainOp& lb_in, const GemmEpi& ep, int M, int N, int K, int tiles_m,
                                               int tiles_n, int kchunk, float* smem) {
     typedef DmaCfg<TM, TN, WAVES_M, WAVES_N, BK, STAGES, A_KC, B_KC> C;
@@ -97,24 +125,18 @@ __device__ __forceinline__ void gemm_dma_tile(const PlainOp& la_in, const PlainO
     lb.set_batch(z);
     const int wave = wave_uniform(tid >> 6), lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
 
-    // XCD-aware bijective block -> tile map + grouped rasterisation (identical to gemm_kernel)
-    int tile;
-    {
-        const int nt = tiles_m * tiles_n, bid = blockIdx.x;
-        const int q = nt >> 3, r = nt & 7, xcd = bid & 7, loc = bid >> 3;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-    }
-    int tm, tn;
-    if (ep.group_m > 1) {
-        const int per = ep.group_m * tiles_n, sr = tile / per, rem = tile - sr * per;
-        int gsz = tiles_m - sr * ep.group_m;
-        gsz = gsz < ep.group_m ? gsz : ep.group_m;
-        tn = rem / gsz; tm = sr * ep.group_m + (rem - tn * gsz);
-    } else { tm = tile / tiles_n; tn = tile - tm * tiles_n; }
-    const int i0 = tm * BM, j0 = tn * BN;
-    const int kbeg = blockIdx.y * kchunk;
-    const int kend = (kbeg + kchunk < K) ? kbeg + kchunk : K;
-    const int nkt = (kend - kbeg + BK - 1) / BK;
+    // tile index -> (i0, j0): grouped rasterisation (identical to gemm_kernel)
+    auto tile_origin = [&](int tile, int& i0, int& j0) {
+        int tm, tn;
+        if (ep.group_m > 1) {
+            const int per = ep.group_m * tiles_n, sr = tile / per, rem = tile - sr * per;
+            int gsz = tiles_m - sr * ep.group_m;
+            gsz = gsz < ep.group_m ? gsz : ep.group_m;
+            tn = rem / gsz; tm = sr * ep.group_m + (rem - tn * gsz);
+        } else { tm = tile / tiles_n; tn = tile - tm * tiles_n; }
+        i0 = tm * BM; j0 = tn * BN;
+    };
+    int i0 = 0, j0 = 0, kbeg = 0, kend = 0, nkt = 0;      // the current work item: output tile origin and k range
 
     // ---- DMA sources.  Piece j of an operand covers LDS floats [256 j, 256 j + 256) of the stage tile; wave w issues pieces w, w + NW, ...
     //  KC tile [rows][CH chunks]:  slot = 64 j + lane -> row = slot / CH, physical chunk p = slot % CH holds LOGICAL chunk p ^ swz(row).
@@ -123,8 +145,8 @@ __device__ __forceinline__ void gemm_dma_tile(const PlainOp& la_in, const PlainO
     const DmaSrc sb = dma_make_src(lb.p, (unsigned)(((long)(lb.rows - 1) * lb.ld + lb.cols) * 4));
     unsigned voff[DPW];      // byte offset of this lane's 16 bytes in k-tile 0
     int klim[DPW];           // the chunk is inside the matrix while (k-tile index * BK) < klim (INT_MIN: row / column out of range)
-    unsigned astep, bstep;   // byte step per k-tile
-    {
+    const unsigned astep = (unsigned)((A_KC ? (long)BK : (long)BK * la.ld) * 4), bstep = (unsigned)((B_KC ? (long)BK : (long)BK * lb.ld) * 4);   // byte step per k-tile
+    auto seek = [&]() {      // DMA source offsets of the current work item (i0, j0, kbeg, kend)
         auto setup = [&](const PlainOp& op, bool kc, int r0, int extent, int piece, unsigned& vo, int& kl) {
             const int slot = piece * 64 + lane;
             if (kc) {
@@ -143,9 +165,8 @@ __device__ __forceinline__ void gemm_dma_tile(const PlainOp& la_in, const PlainO
         for (int i = 0; i < DA; ++i) setup(la, A_KC, i0, BM, wave + i * NW, voff[i], klim[i]);
 #pragma unroll
         for (int i = 0; i < DB; ++i) setup(lb, B_KC, j0, BN, wave + i * NW, voff[DA + i], klim[DA + i]);
-        astep = (unsigned)((A_KC ? (long)BK : (long)BK * la.ld) * 4);
-        bstep = (unsigned)((B_KC ? (long)BK : (long)BK * lb.ld) * 4);
-    }
+        nkt = (kend - kbeg + BK - 1) / BK;
+    };
     auto issue = [&](int kt, int slot) {     // k-tile kt -> ring slot (all-zero tile when kt >= nkt)
         float* base = smem + slot * C::STAGE_FL + wave * 256;
         const int kpos = kt * BK;
@@ -171,12 +192,6 @@ __device__ __forceinline__ void gemm_dma_tile(const PlainOp& la_in, const PlainO
     b_off = B_KC ? (wn0 + l31) * BK : (4 * hi) * BN + wn0 + l31;
 
     f32x16 acc[TM][TN];
-#pragma unroll
-    for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int b = 0; b < TN; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     auto compute = [&](int slot) {
         const float* As = smem + slot * C::STAGE_FL;
@@ -289,27 +304,121 @@ __device__ __forceinline__ void gemm_dma_tile(const PlainOp& la_in, const PlainO
         }
     };
 
-    // ---- pipeline: STAGES-1 tiles in flight; iteration t: wait for tile t (counted), barrier (also frees slot (t-1) % STAGES for
-    // everyone), request tile t + STAGES - 1 into that slot, multiply tile t.
+    // ---- pipeline over the current item's k-tiles: STAGES-1 tiles in flight; iteration t: wait for tile t (counted), barrier (also frees
+    // slot (t-1) % STAGES for everyone), request tile t + STAGES - 1 into that slot, multiply tile t.
+    auto run = [&]() {
 #pragma unroll
-    for (int s = 0; s < STAGES - 1; ++s) issue(s, s);
-    int cur = 0, nxt = STAGES - 1;
-    for (int kt = 0; kt < nkt; ++kt) {
-        dma_wait<(STAGES - 2) * DPW>();
-        lds_wait();
-        dma_barrier<NW>();
-        issue(kt + STAGES - 1, nxt);
-        if constexpr (X3) compute_bf16(cur);
-        else if constexpr (A_KC && B_KC) { if (ep.packed16) compute16(cur); else if (lowp) compute_bf16(cur); else compute(cur); }
-        else { if (lowp) compute_bf16(cur); else compute(cur); }
-        cur = cur + 1 == STAGES ? 0 : cur + 1;
-        nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
-    }
-    dma_wait<0>();      // drain the (all-zero) tail requests before the epilogue's own loads / the end of the block
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+        seek();
+#pragma unroll
+        for (int s = 0; s < STAGES - 1; ++s) issue(s, s);
+        int cur = 0, nxt = STAGES - 1;
+        for (int kt = 0; kt < nkt; ++kt) {
+            dma_wait<(STAGES - 2) * DPW>();
+            lds_wait();
+            dma_barrier<NW>();
+            issue(kt + STAGES - 1, nxt);
+            if constexpr (X3) compute_bf16(cur);
+            else if constexpr (A_KC && B_KC) { if (ep.packed16) compute16(cur); else if (lowp) compute_bf16(cur); else compute(cur); }
+            else { if (lowp) compute_bf16(cur); else compute(cur); }
+            cur = cur + 1 == STAGES ? 0 : cur + 1;
+            nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
+        }
+        dma_wait<0>();      // drain the (all-zero) tail requests before the epilogue's own loads / the next item / the end of the block
+    };
 
-    GemmEpi epo = ep;
-    epo.C += (long)blockIdx.y * ep.sk_stride;       // two-pass split-K: this k-slice's partial tile (sk_stride = 0 otherwise)
-    gemm_epilogue<TM, TN>(acc, epo, M, N, i0, j0, BM, BN, wm0, wn0, z);
+    if constexpr (!SK) {
+        // XCD-aware bijective block -> tile map: the 8 XCDs (private L2 each) get contiguous tile ranges
+        int tile;
+        {
+            const int nt = tiles_m * tiles_n, bid = blockIdx.x;
+            const int q = nt >> 3, r = nt & 7, xcd = bid & 7, loc = bid >> 3;
+            tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+        }
+        tile_origin(tile, i0, j0);
+        kbeg = blockIdx.y * kchunk;
+        kend = (kbeg + kchunk < K) ? kbeg + kchunk : K;
+        run();
+        GemmEpi epo = ep;
+        epo.C += (long)blockIdx.y * ep.sk_stride;       // two-pass split-K: this k-slice's partial tile (sk_stride = 0 otherwise)
+        gemm_epilogue<TM, TN>(acc, epo, M, N, i0, j0, BM, BN, wm0, wn0, z);
+    } else {
+        // ---- stream-K: the launch has P persistent workgroups (all resident: P <= CUs x blocks per CU).  XCD x (workgroups with bid % 8 == x)
+        // owns the same contiguous tile range as in the data-parallel launch; its tiles x nktT (tile, k-tile) units are laid out tile-major and
+        // its workgroup `loc` takes the contiguous range [loc U / Pb, (loc + 1) U / Pb) - every CU gets the same number of MFMA steps whatever
+        // the tile count mod the slot count is (the data-parallel launch of the GPT-4 shapes runs 672 tiles on 512 slots: a full round plus a
+        // 31 % one).  The host guarantees U / Pb >= nktT, so a tile is cut into at most two parts: its k-HEAD is the LAST item of workgroup loc,
+        // its k-TAIL the FIRST item of workgroup loc + 1 OF THE SAME XCD.  The tail's accumulators go to the scratch slot of that workgroup
+        // right at the start of its life, with plain stores: both workgroups sit behind the same L2, the hand-over never leaves the XCD
+        // (a first version exchanged them at agent scope across XCDs - 67 MB of write-through / L2-bypassing traffic per launch - and
+        // gained nothing).  The head's workgroup, which reaches the tile at the very end of its range, adds them (fixed order: head +
+        // tail, bitwise reproducible) and runs the normal epilogue.  Only the flag is an agent-scope word; it is all but always already up
+        // and is reset by its reader for the next launch.
+        const int P = gridDim.x, bid = blockIdx.x, Pb = P >> 3, xcd = bid & 7;
+#ifdef TF_EMU
+        const int loc = Pb - 1 - (bid >> 3);            // the emulator runs the blocks in ascending order: producers (loc + 1) first
+#else
+        const int loc = bid >> 3;
+#endif
+        const int nktT = (K + BK - 1) / BK;
+        int t_first, t_count;                            // this XCD's tiles (the bijective map of the data-parallel launch)
+        {
+            const int nt = tiles_m * tiles_n, q = nt >> 3, r = nt & 7;
+            t_first = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+            t_count = xcd < r ? q + 1 : q;
+        }
+        const long U = (long)t_count * nktT;
+        long u = (long)loc * U / Pb;
+        const long u1 = (long)(loc + 1) * U / Pb;
+        constexpr int SLOT = NW * TM * TN * 16 * 64;      // floats per partial tile: [wave][t][u][r][lane]
+        const int pos = xcd * Pb + loc;                   // scratch slot / flag of this workgroup; its consumer is (xcd, loc - 1), its producer (xcd, loc + 1)
+        float* part = ep.sk_ws + (long)wave * (TM * TN * 16 * 64) + lane;
+        while (u < u1) {
+            const int trel = (int)(u / nktT), kt0 = (int)(u - (long)trel * nktT), tile = t_first + trel;
+            const long left = u1 - u;
+            const int kt1 = kt0 + left < nktT ? (int)(kt0 + left) : nktT;
+            tile_origin(tile, i0, j0);
+            kbeg = kt0 * BK;
+            kend = kt1 * BK < K ? kt1 * BK : K;
+            lds_wait();
+            dma_barrier<NW>();                          // every wave is done reading the previous item's last tiles before the ring is refilled
+            run();
+            if (kt0 != 0) {                             // k-tail of a tile whose head belongs to workgroup pos - 1: hand the accumulators over
+#pragma unroll
+                for (int t = 0; t < TM; ++t)
+#pragma unroll
+                    for (int v = 0; v < TN; ++v) {
+                        volatile float* dst = sk_launder(part + (long)pos * SLOT + (t * TN + v) * 1024);      // 16 stores = one base + 12-bit immediates
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) dst[r * 64] = acc[t][v][r];
+                    }
+                sk_drain();
+                dma_barrier<NW>();
+                if (tid == 0) sk_flag_set(ep.sk_flags + pos, 1);
+            } else {
+                if (kt1 != nktT) {                      // k-head: the tail was computed by workgroup pos + 1 as its first item
+                    if (tid == 0) sk_flag_wait(ep.sk_flags + pos + 1);
+                    dma_barrier<NW>();
+#pragma unroll
+                    for (int t = 0; t < TM; ++t)
+#pragma unroll
+                        for (int v = 0; v < TN; ++v) {
+                            const volatile float* src = sk_launder(part + (long)(pos + 1) * SLOT + (t * TN + v) * 1024);
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[t][v][r] += src[r * 64];
+                        }
+                    dma_barrier<NW>();
+                    if (tid == 0) sk_flag_set(ep.sk_flags + pos + 1, 0);
+                }
+                gemm_epilogue<TM, TN>(acc, ep, M, N, i0, j0, BM, BN, wm0, wn0, z);
+            }
+            u += kt1 - kt0;
+        }
+    }
 }
 
 // X3 = the bf16x3-split instantiation (tf_set_precision(2)): a separate kernel, so the fp32 / bf16 binary keeps its register allocation
@@ -319,6 +428,15 @@ gemm_dma_kernel(PlainOp la, PlainOp lb, GemmEpi ep, int M, int N, int K, int til
     typedef DmaCfg<TM, TN, WAVES_M, WAVES_N, BK, STAGES, A_KC, B_KC> C;
     __shared__ __attribute__((aligned(1024))) float smem[STAGES * C::STAGE_FL];
     gemm_dma_tile<TM, TN, WAVES_M, WAVES_N, BK, STAGES, A_KC, B_KC, X3>(la, lb, ep, M, N, K, tiles_m, tiles_n, kchunk, smem);
+}
+// the stream-K instantiation of the same configuration (persistent workgroups, see gemm_dma_tile): its own kernel, so the data-parallel one
+// keeps its code size and register allocation
+template <int TM, int TN, int WAVES_M, int WAVES_N, int BK, int STAGES, bool A_KC, bool B_KC, int OCC, bool X3 = false>
+__global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, OCC)
+gemm_dma_sk_kernel(PlainOp la, PlainOp lb, GemmEpi ep, int M, int N, int K, int tiles_m, int tiles_n) {
+    typedef DmaCfg<TM, TN, WAVES_M, WAVES_N, BK, STAGES, A_KC, B_KC> C;
+    __shared__ __attribute__((aligned(1024))) float smem[STAGES * C::STAGE_FL];
+    gemm_dma_tile<TM, TN, WAVES_M, WAVES_N, BK, STAGES, A_KC, B_KC, X3, true>(la, lb, ep, M, N, K, tiles_m, tiles_n, 0, smem);
 }
 
 // can this problem run on the DMA kernels?  (vector-aligned plain operands, 32-bit addressable)
@@ -333,6 +451,25 @@ template <int TM, int TN, int WAVES_M, int WAVES_N, int BK, int STAGES, bool A_K
 inline void launch_dma_cfg(const PlainOp& la, const PlainOp& lb, const GemmEpi& ep, int M, int N, int K, int batch, int splitk, void* stream) {
     typedef DmaCfg<TM, TN, WAVES_M, WAVES_N, BK, STAGES, A_KC, B_KC> C;
     const int tiles_m = cdiv(M, C::BM), tiles_n = cdiv(N, C::BN);
+    if (splitk == kStreamK) {                       // eligibility was checked by launch_gemm (streamk_blocks > 0)
+        const int P = streamk_blocks(ep, M, N, K, batch, C::BM, C::BN, BK, C::NW, OCC, C::LDS_BYTES);
+        streamk_count(1);
+        GemmEpi eps = ep;
+        eps.prec = ep.packed16 ? 0 : gemm_precision();
+        {
+            long panel = (long)C::BM * K * 4;
+            int g = (int)((2L << 20) / (panel > 0 ? panel : 1));
+            if (g > 8) g = 8;
+            if (g > tiles_m) g = tiles_m;
+            eps.group_m = (g >= 2 && tiles_n >= 4) ? g : 1;
+        }
+        if (eps.stat_nparts) *eps.stat_nparts = eps.stat ? cdiv(M, 32 * TM) : 0;
+        if (eps.prec == 2 && !ep.packed16)
+            TF_LAUNCH((gemm_dma_sk_kernel<TM, TN, WAVES_M, WAVES_N, BK, STAGES, A_KC, B_KC, OCC, true>), dim3(P), dim3(C::NT), stream, la, lb, eps, M, N, K, tiles_m, tiles_n);
+        else
+            TF_LAUNCH((gemm_dma_sk_kernel<TM, TN, WAVES_M, WAVES_N, BK, STAGES, A_KC, B_KC, OCC, false>), dim3(P), dim3(C::NT), stream, la, lb, eps, M, N, K, tiles_m, tiles_n);
+        return;
+    }
     const bool twopass = splitk >= kTwoPass;       // eligibility was checked by launch_gemm (twopass_ok)
     if (twopass) splitk -= kTwoPass;
     int kchunk = cdiv(cdiv(K, splitk), BK) * BK;

@@ -244,7 +244,8 @@ struct GemmEpi {
     int group_m = 1;                 // tile rasterisation: rows of tiles walked together (set by launch_cfg)
     const float* mask = nullptr; long ldmask = 0;   // optional ReLU mask of a backward GEMM: element (i, j) is zeroed unless mask(i, j) > 0
     long sk_stride = 0;              // two-pass split-K: k-slice blockIdx.y stores its partial tile at C + blockIdx.y * sk_stride (LDS-DMA kernels)
-    float* sk_ws = nullptr; long sk_ws_floats = 0;   // host side only: caller-owned scratch that makes the two-pass split-K eligible (tf_gemm_desc)
+    float* sk_ws = nullptr; long sk_ws_floats = 0;   // caller-owned scratch that makes the two-pass split-K / stream-K eligible (tf_gemm_desc); read on the device by the stream-K kernels
+    int* sk_flags = nullptr;         // stream-K: kStreamKMaxBlocks hand-over flags, zero between launches (caller-owned, persistent; tf_gemm_desc.sk_flags)
     // BatchNorm statistics of the OUTPUT, fused into the epilogue (train-mode BN behind a bias-free conv, timm BatchNormAct2d via
     // transfuser.py:380,442): every wave writes, for each of its columns, the Welford triple (n, mean, M2) of the rows it owns into
     // stat[(part * 3 + {0,1,2}) * stat_ld + column], part = first row / rows per wave - plain stores, no atomics; a finalize kernel
@@ -690,10 +691,10 @@ struct GemmPlan { int bm, bn, bk, splitk; int kind = 0; };
 
 // LDS-DMA configurations (tf_gemm_dma.h); the launchers live in gemm_dma_{nt,nn,tn,tt}.cpp (one translation unit per operand layout)
 constexpr int kDmaKinds = 8;
-struct DmaKindInfo { int bm, bn, bk; };
+struct DmaKindInfo { int bm, bn, bk, nw, occ, lds; };        // tile, waves per workgroup, __launch_bounds__ waves per SIMD, LDS bytes (mirror of tf_gemm_dma_launch.h)
 inline DmaKindInfo dma_kind_info(int kind) {
-    static const DmaKindInfo t[kDmaKinds + 1] = {{0, 0, 0}, {128, 128, 16}, {64, 64, 16}, {128, 64, 16}, {64, 128, 16}, {128, 128, 32},
-                                                 {64, 64, 16}, {64, 128, 16}, {128, 64, 16}};   // 6-8: one 64x64 accumulator block per wave (1 / 2 / 2 waves)
+    static const DmaKindInfo t[kDmaKinds + 1] = {{0, 0, 0, 0, 0, 0}, {128, 128, 16, 4, 2, 49152}, {64, 64, 16, 4, 4, 32768}, {128, 64, 16, 4, 3, 36864}, {64, 128, 16, 4, 3, 36864},
+                                                 {128, 128, 32, 4, 2, 65536}, {64, 64, 16, 1, 2, 32768}, {64, 128, 16, 2, 2, 36864}, {128, 64, 16, 2, 2, 36864}};   // 6-8: one 64x64 accumulator block per wave (1 / 2 / 2 waves)
     return t[(kind >= 1 && kind <= kDmaKinds) ? kind : 0];
 }
 template <bool A_KC, bool B_KC>
@@ -702,6 +703,27 @@ bool dma_eligible(const PlainOp& a, const PlainOp& b);
 
 // two-pass split-K (gemm_fixup.cpp): C (op)= epilogue(sum_s ws[s]) with the slices summed in order; ws slices are [M][ldws] row-major
 void launch_splitk_fixup(const float* ws, int nsplit, long sk_stride, int ldws, const GemmEpi& ep, int M, int N, void* stream);
+constexpr int kStreamK = 2000000;  // GemmPlan.splitk == kStreamK: stream-K (persistent workgroups over the (tile, k-tile) space; LDS-DMA kinds only, tf_gemm_dma.h)
+constexpr int kStreamKMaxBlocks = 2048;
+int device_cus();                  // api.cpp: compute units of the current device (cached)
+long streamk_count(int add);       // api.cpp: stream-K launches so far (tests assert that a pinned stream-K plan really ran as one)
+// workgroups of a stream-K launch of this configuration, 0 = not eligible: single-batch, non-atomic epilogue, caller scratch + flags, at least one
+// whole tile of work per workgroup (so a tile is cut at most once) and a tile count that does NOT already divide evenly over the resident slots
+inline int streamk_blocks(const GemmEpi& ep, int M, int N, int K, int batch, int bm, int bn, int bk, int nw, int occ, int lds_bytes) {
+    if (!ep.sk_ws || !ep.sk_flags || batch != 1 || ep.mode == 2 || K < 8 * bk) return 0;
+    int per_cu = occ * 4 / nw;                                 // __launch_bounds__(64 nw, occ): occ waves per SIMD
+    const int by_lds = (160 * 1024) / (lds_bytes > 0 ? lds_bytes : 1);
+    if (per_cu > by_lds) per_cu = by_lds;
+    if (per_cu < 1) per_cu = 1;
+    const long nt = (long)cdiv(M, bm) * cdiv(N, bn);
+    long P = (long)device_cus() * per_cu;
+    if (P > kStreamKMaxBlocks) P = kStreamKMaxBlocks;
+    if (P > nt) P = nt;
+    P &= ~7L;                                                  // XCD-contiguous positions
+    if (P < 8 || nt % P == 0) return 0;                        // already balanced: the data-parallel launch is the same thing without the bookkeeping
+    if (P * (long)bm * bn > ep.sk_ws_floats) return 0;
+    return (int)P;
+}
 constexpr int kTwoPass = 1000000;  // GemmPlan.splitk >= kTwoPass: two-pass split-K with S = splitk - kTwoPass slices (LDS-DMA kinds only); atomic split counts stay far below
 inline int twopass_ldws(int N) { return (N + 3) & ~3; }
 // eligibility of the two-pass split for this call: plain row-major single-batch output and enough caller scratch for S slices
@@ -878,10 +900,12 @@ inline GemmPlan autotune_gemm(const LA& la, const LB& lb, const GemmEpi& ep, int
                 if ((long)cdiv(M, ki.bm) * cdiv(N, ki.bn) < 512 && K >= 32 * ki.bk)      // too few tiles for the 256 CUs: deterministic two-pass split
                     for (int S = 2; S <= 4; ++S)
                         if (twopass_ok(ep, M, N, batch, S)) cand[nc++] = kTwoPass + S;
+                if (streamk_blocks(ep, M, N, K, batch, ki.bm, ki.bn, ki.bk, ki.nw, ki.occ, ki.lds) > 0) cand[nc++] = kStreamK;      // tile count does not divide over the resident slots
                 for (int s = 0; s < nc; ++s) {
                     GemmPlan p{ki.bm, ki.bn, ki.bk, cand[s], kind};
                     GemmEpi e = trial;
                     if (p.splitk > 1 && p.splitk < kTwoPass) { if (ep.mode == 0) continue; e.mode = 2; }
+                    if (p.splitk == kStreamK && e.mode == 2) continue;
                     trace_candidate(p, M, N, K, batch, e.mode, stream, true);
                     launch_plan<LA, A_KC, LB, B_KC>(p, la, lb, e, M, N, K, batch, stream);
                     trace_candidate(p, M, N, K, batch, e.mode, stream, false);
@@ -925,7 +949,19 @@ inline int launch_gemm(const LA& la, const LB& lb, GemmEpi ep, int M, int N, int
 #endif
             p = plan_gemm(M, N, K, batch, sk_ok);
     }
-    if (ep.stat) {
+    bool streamk = p.splitk == kStreamK;
+    if (streamk) {      // stream-K plan: needs an LDS-DMA kind, this call's scratch + flags and a tile count that does not divide over the slots
+        bool ok = false;
+        if constexpr (std::is_same<LA, PlainOp>::value && std::is_same<LB, PlainOp>::value) {
+            const DmaKindInfo ki = dma_kind_info(p.kind);
+            ok = p.kind >= 1 && p.kind <= kDmaKinds && dma_eligible(la, lb) && streamk_blocks(ep, M, N, K, batch, ki.bm, ki.bn, ki.bk, ki.nw, ki.occ, ki.lds) > 0;
+        }
+        if (!ok) { p.splitk = 1; streamk = false; }
+    }
+    if (ep.stat && streamk) {
+        if (ep.mode != 0 || ep.res || ep.relu || ep.mask) ep.stat = nullptr;      // the owner of a cut tile holds the complete sum: statistics as usual
+        if (!ep.stat && ep.stat_nparts) *ep.stat_nparts = 0;
+    } else if (ep.stat) {
         // fused output statistics need the whole reduction in one block: no k-split.  A cached two-pass plan keeps its speed and reports
         // "no statistics" (nparts 0): the caller runs its separate reduction for this (rare: <= 256-tile) output
         if (p.splitk >= kTwoPass && p.kind >= 1 && twopass_ok(ep, M, N, batch, p.splitk - kTwoPass)) ep.stat = nullptr;
@@ -933,7 +969,8 @@ inline int launch_gemm(const LA& la, const LB& lb, GemmEpi ep, int M, int N, int
         if (ep.mode != 0 || ep.res || ep.relu || ep.mask) ep.stat = nullptr;
         if (!ep.stat && ep.stat_nparts) *ep.stat_nparts = 0;
     }
-    if (p.splitk >= kTwoPass) {
+    if (streamk) {
+    } else if (p.splitk >= kTwoPass) {
         if (p.kind < 1 || !twopass_ok(ep, M, N, batch, p.splitk - kTwoPass)) p.splitk = 1;     // no scratch on this call / not a plain output
     } else {
         if (!sk_ok) p.splitk = 1;

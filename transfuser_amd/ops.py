@@ -305,6 +305,19 @@ _TRACE_GEMM = os.environ.get("TF_TRACE_GEMM", "0") == "1"
 _TWO_PASS_MAX_ELEMS = 4300000      # <= ~256 tiles of 128 x 128
 
 
+STREAM_K = os.environ.get("TF_STREAM_K", "1") != "0"      # stream-K plans for tile counts that do not divide over the resident workgroup slots (A/B switch)
+_skf_cache = {}
+
+
+def _sk_flags(device):
+    """Hand-over flags of the stream-K GEMM plans: zero between launches (the kernels reset what they set), one buffer per (device, stream)."""
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream if getattr(device, "type", str(device)[:4]) == "cuda" else 0)
+    f = _skf_cache.get(key)
+    if f is None:
+        f = _skf_cache[key] = torch.zeros(2048, dtype=torch.int32, device=device)
+    return f
+
+
 _wsq = None
 
 
@@ -332,11 +345,13 @@ def gemm(a, b, c, m, n, k, lda, ldb, ldc, a_trans=False, b_trans=False, bias=Non
     if colstat is not None:
         d.colstat, d.colstat_nparts = ptr(colstat.buf), ctypes.pointer(colstat.nparts)
     skws = None
-    if TWO_PASS_SPLITK and batch == 1 and k >= 512 and 128 * 128 <= m * n <= _TWO_PASS_MAX_ELEMS:
-        need = _ws_query()(byref(d))          # > 0 only when the plan of THIS shape is a two-pass plan (or the autotuner wants to try one)
+    if TWO_PASS_SPLITK and batch == 1 and k >= 256 and 128 * 128 <= m * n and (m * n <= _TWO_PASS_MAX_ELEMS or STREAM_K):
+        need = _ws_query()(byref(d))          # > 0 only when the plan of THIS shape is a two-pass / stream-K plan (or the autotuner wants to try one)
         if need > 0:
             skws = torch.empty(need, dtype=torch.float32, device=c.device)
             d.splitk_ws, d.splitk_ws_floats = ptr(skws), need
+            if STREAM_K:
+                d.sk_flags = ptr(_sk_flags(c.device))
     _e = _census_begin()
     if _TRACE_GEMM:      # debugging aid: name every call before it runs and wait for it (TF_TRACE_GEMM=1)
         print("[gemm] m=%d n=%d k=%d a_trans=%d b_trans=%d lda=%d ldb=%d ldc=%d batch=%d acc=%d relu=%d bias=%d res=%d mask=%d ws=%s" % (
