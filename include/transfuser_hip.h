@@ -389,6 +389,12 @@ int tf_lidar_hist_f32(const float* points, const int32_t* num_points, int B, int
  *   tf_pillar_canvas_bwd_f32 -> dz (N,C): the canvas gradient routed to each pillar's arg-max point. */
 int tf_pillar_keys_f32(const float* points, const int32_t* num_points, int B, int max_points, int point_stride, float min_x, float max_x,
                        float min_y, float max_y, float pixels_per_meter, int GX, int GY, int32_t* keys, int32_t* keep, int32_t* occ, void* stream);
+/* Both scans of the pillar index in two launches (point_pillar.py:85-91: what torch.unique(return_inverse) yields, without the sort): pos = exclusive
+ * scan of [keys >= 0] (row of every kept point in the compacted cloud), rank = exclusive scan of the occupancy grid (sorted-unique pillar id of
+ * every occupied cell), cellkey[rank] = cell, totals = {kept points, pillars}.  ws: (n_points + ncells) / 1024 + 2 ints.  tf_pillar_gather_f32 may
+ * then be called with occ = NULL (the cell keys exist already). */
+int tf_pillar_index_scan_i32(const int32_t* keys, int64_t n_points, const int32_t* occ, int64_t ncells, int32_t* pos, int32_t* rank, int32_t* cellkey,
+                             int32_t* totals, int32_t* ws, void* stream);
 int tf_exclusive_scan_i32(const int32_t* in, int64_t n, int32_t* out, int32_t* total, int32_t* ws /* n/1024+1 ints */, void* stream);
 int tf_pillar_gather_f32(const float* points, int point_stride, const int32_t* keys, const int32_t* pos, const int32_t* occ, const int32_t* rank,
                          int64_t n_all, int64_t ncells, int P, float* pts4, int32_t* inv, float* sums, int32_t* cellkey, void* stream);

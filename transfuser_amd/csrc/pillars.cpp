@@ -105,6 +105,76 @@ __global__ void __launch_bounds__(256) scan_final_kernel(const int32_t* __restri
     }
 }
 
+// ---- both exclusive scans of the pillar index (kept-point positions over the keys, sorted-unique ranks over the occupancy grid) in TWO launches:
+// one pass of 1024-element block sums over the concatenation [keys >= 0 | occ], then every block adds up the sums in front of it inside its
+// own array (<= ~700 values: one strided pass of the block), scans its elements and writes; the occupancy blocks also emit
+// cellkey[rank] = cell (round 3: 2 x 3 scan launches + a cell-key launch).  totals[0] = kept points, totals[1] = pillars.
+__global__ void __launch_bounds__(256) scan2_block_sums_kernel(const int32_t* __restrict__ keys, long nA, const int32_t* __restrict__ occ, long nB, int nbA,
+                                                               int32_t* __restrict__ bsum) {
+    __shared__ int sm[4];
+    const bool isA = (int)blockIdx.x < nbA;
+    const long n = isA ? nA : nB, base = (long)(isA ? blockIdx.x : blockIdx.x - nbA) * 1024 + threadIdx.x * 4;
+    const int32_t* in = isA ? keys : occ;
+    int v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = in[base + k < n ? base + k : n - 1];
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s += (base + k < n) ? (isA ? (v[k] >= 0) : v[k]) : 0;
+    s = (int)wave_sum((float)s);                   // <= 256 per wave: exact in fp32
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) bsum[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+__global__ void __launch_bounds__(256) scan2_final_kernel(const int32_t* __restrict__ keys, long nA, const int32_t* __restrict__ occ, long nB, int nbA, int nbB,
+                                                          const int32_t* __restrict__ bsum, int32_t* __restrict__ pos, int32_t* __restrict__ rank,
+                                                          int32_t* __restrict__ cellkey, int32_t* __restrict__ totals) {
+    __shared__ int sm[256];
+    __shared__ int red[4];
+    const bool isA = (int)blockIdx.x < nbA;
+    const int b = isA ? blockIdx.x : blockIdx.x - nbA, first = isA ? 0 : nbA, nb = isA ? nbA : nbB;
+    // offset of this block = sum of the block sums in front of it (same array): eight loads in flight per trip
+    int pre = 0;
+    for (int j0 = 0; j0 < b; j0 += 8 * 256) {
+        int t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int j = j0 + threadIdx.x + 256 * u; t[u] = bsum[first + (j < b ? j : 0)]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) pre += (j0 + (int)threadIdx.x + 256 * u < b) ? t[u] : 0;
+    }
+    // (block totals stay far below 2^24: fp32 wave sums are exact)
+    pre = (int)wave_sum((float)(pre & 0xffff)) + ((int)wave_sum((float)(pre >> 16)) << 16);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = pre;
+    __syncthreads();
+    const int boff = (red[0] + red[1]) + (red[2] + red[3]);
+    const long n = isA ? nA : nB, base = (long)b * 1024 + threadIdx.x * 4;
+    const int32_t* in = isA ? keys : occ;
+    int raw[4], v[4], s = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) raw[k] = in[base + k < n ? base + k : n - 1];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v[k] = (base + k < n) ? (isA ? (raw[k] >= 0) : raw[k]) : 0; s += v[k]; }
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {       // inclusive Hillis-Steele over the 256 thread sums
+        const int t = (int)threadIdx.x >= off ? sm[threadIdx.x - off] : 0;
+        __syncthreads();
+        sm[threadIdx.x] += t;
+        __syncthreads();
+    }
+    int run = boff + sm[threadIdx.x] - s;
+    int32_t* out = isA ? pos : rank;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (base + k < n) {
+            out[base + k] = run;
+            if (!isA && v[k]) cellkey[run] = (int32_t)(base + k);
+        }
+        run += v[k];
+    }
+    if (b == nb - 1 && threadIdx.x == 255) totals[isA ? 0 : 1] = boff + sm[255];
+}
+
 // rank -> cell key of every occupied cell (= torch.unique's sorted unique_coords, point_pillar.py:88)
 __global__ void __launch_bounds__(256) pillar_cells_kernel(const int32_t* __restrict__ occ, const int32_t* __restrict__ rank, long ncells,
                                                            int32_t* __restrict__ cellkey) {
@@ -237,6 +307,15 @@ extern "C" int tf_pillar_keys_f32(const float* points, const int32_t* num_points
     return launch_status("tf_pillar_keys_f32");
 }
 
+extern "C" int tf_pillar_index_scan_i32(const int32_t* keys, int64_t n_points, const int32_t* occ, int64_t ncells, int32_t* pos, int32_t* rank, int32_t* cellkey,
+                                        int32_t* totals, int32_t* ws, void* stream) {
+    TF_REQUIRE(keys && occ && pos && rank && cellkey && totals && ws && n_points > 0 && ncells > 0, "tf_pillar_index_scan_i32: bad arguments (ws needs (n_points + ncells) / 1024 + 2 ints)");
+    const int nbA = cdiv(n_points, 1024), nbB = cdiv(ncells, 1024);
+    TF_LAUNCH(scan2_block_sums_kernel, dim3(nbA + nbB), dim3(256), stream, keys, (long)n_points, occ, (long)ncells, nbA, ws);
+    TF_LAUNCH(scan2_final_kernel, dim3(nbA + nbB), dim3(256), stream, keys, (long)n_points, occ, (long)ncells, nbA, nbB, (const int32_t*)ws, pos, rank, cellkey, totals);
+    return launch_status("tf_pillar_index_scan_i32");
+}
+
 extern "C" int tf_exclusive_scan_i32(const int32_t* in, int64_t n, int32_t* out, int32_t* total, int32_t* ws, void* stream) {
     TF_REQUIRE(in && out && total && ws && n > 0, "tf_exclusive_scan_i32: bad arguments (ws needs n/1024 + 1 ints)");
     const int nb = cdiv(n, 1024);
@@ -249,11 +328,11 @@ extern "C" int tf_exclusive_scan_i32(const int32_t* in, int64_t n, int32_t* out,
 extern "C" int tf_pillar_gather_f32(const float* points, int point_stride, const int32_t* keys, const int32_t* pos, const int32_t* occ,
                                     const int32_t* rank, int64_t n_all, int64_t ncells, int P, float* pts4, int32_t* inv, float* sums,
                                     int32_t* cellkey, void* stream) {
-    TF_REQUIRE(points && keys && pos && occ && rank && pts4 && inv && sums && cellkey && n_all > 0 && ncells > 0 && P >= 0,
+    TF_REQUIRE(points && keys && pos && rank && pts4 && inv && sums && cellkey && n_all > 0 && ncells > 0 && P >= 0,
                "tf_pillar_gather_f32: bad arguments");
     if (P == 0) return 0;
     TF_LAUNCH(fill_i32_kernel, dim3(pl_blocks((long)P * 4)), dim3(256), stream, reinterpret_cast<int32_t*>(sums), (long)P * 4, 0);
-    TF_LAUNCH(pillar_cells_kernel, dim3(pl_blocks(ncells)), dim3(256), stream, occ, rank, (long)ncells, cellkey);
+    if (occ) TF_LAUNCH(pillar_cells_kernel, dim3(pl_blocks(ncells)), dim3(256), stream, occ, rank, (long)ncells, cellkey);      // NULL: tf_pillar_index_scan_i32 already wrote the cell keys
     TF_LAUNCH(pillar_gather_kernel, dim3(pl_blocks(n_all)), dim3(256), stream, points, point_stride, keys, pos, rank, (long)n_all, pts4, inv, sums);
     return launch_status("tf_pillar_gather_f32");
 }

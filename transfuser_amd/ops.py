@@ -1273,15 +1273,20 @@ def pillar_index(points, num_points, min_x, max_x, min_y, max_y, ppm):
     f = ctypes.c_float
     check(L().tf_pillar_keys_f32(ptr(_c(points)), ptr(num_points), B, Nmax, Fp, f(min_x), f(max_x), f(min_y), f(max_y), f(ppm), GX, GY,
                                  ptr(keys), ptr(keep), ptr(occ), stream_of(points)), "tf_pillar_keys_f32")
-    pos, n_tot = _scan(keep)
-    rank, p_tot = _scan(occ)
-    N, P = int(n_tot.item()), int(p_tot.item())
+    # both scans + the cell keys in two launches, ONE host read of (N, P)
+    ncells = B * GX * GY
+    pos, rank, totals = i32(B * Nmax), i32(ncells), i32(2)
+    cellkey_full = i32(min(B * Nmax, ncells))
+    ws = i32((B * Nmax + ncells) // 1024 + 4)
+    check(L().tf_pillar_index_scan_i32(ptr(keys), ctypes.c_int64(B * Nmax), ptr(occ), ctypes.c_int64(ncells), ptr(pos), ptr(rank), ptr(cellkey_full), ptr(totals),
+                                       ptr(ws), stream_of(points)), "tf_pillar_index_scan_i32")
+    N, P = (int(v) for v in totals.tolist())
     pts4 = torch.empty(N, 4, dtype=torch.float32, device=dev)
     feat = torch.empty(N, 9, dtype=torch.float32, device=dev)
-    inv, cellkey = i32(N), i32(P)
+    inv, cellkey = i32(N), cellkey_full[:P]
     sums = torch.empty(P, 4, dtype=torch.float32, device=dev)
     if N:
-        check(L().tf_pillar_gather_f32(ptr(points), Fp, ptr(keys), ptr(pos), ptr(occ), ptr(rank), ctypes.c_int64(B * Nmax), ctypes.c_int64(B * GX * GY), P,
+        check(L().tf_pillar_gather_f32(ptr(points), Fp, ptr(keys), ptr(pos), c_p(0), ptr(rank), ctypes.c_int64(B * Nmax), ctypes.c_int64(ncells), P,
                                        ptr(pts4), ptr(inv), ptr(sums), ptr(cellkey), stream_of(points)), "tf_pillar_gather_f32")
         check(L().tf_pillar_decorate_f32(ptr(pts4), ptr(inv), ptr(sums), ptr(cellkey), ctypes.c_int64(N), GX, GY, f(ppm), f(min_x), f(min_y), ptr(feat),
                                          stream_of(points)), "tf_pillar_decorate_f32")
