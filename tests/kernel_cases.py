@@ -642,7 +642,7 @@ def check_pillars(dev, B, N, npts):
             close(p, q, what=n_, tol=1e-4)
 
 
-SE_EXCITE_CASES = [(10, 576, 144), (2, 72, 8), (16, 1512, 378), (3, 218, 54), (1, 24, 6)]
+SE_EXCITE_CASES = [(10, 576, 144), (2, 72, 8), (16, 1512, 378), (3, 218, 54), (1, 24, 6), (2, 2048, 512), (2, 3072, 64), (12, 216, 54)]
 
 
 def check_se_excite(dev, B, C, Cr):

@@ -13,13 +13,67 @@ namespace {
 
 constexpr int SE_MAXB = 16;
 constexpr int SE_SPLIT = 8;        // forward: blocks per sample (each recomputes fc1 - cheap - and owns 1/8 of the fc2 outputs)
-constexpr int SE_U = 4;            // independent dot products in flight per wave (8 measured slower: 18.8 vs 17.5 us per forward launch)
-constexpr int SE_MAXC = 4096, SE_MAXR = 1024;
+constexpr int SE_U = 4;            // scalar path: independent dot products in flight per wave
+constexpr int SE_MAXC = 3072, SE_MAXR = 1024;
 
 __device__ __forceinline__ float dot4(const float4 a, const float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 
+// U rows of a row-major (rows x 4 n4) matrix against a vector in LDS, for one wave: every weight load of the call is issued before the first
+// multiply (U * NK 16-byte loads in flight per lane; the run-time-bounded k loop this replaces waited for each trip's loads - a chain of
+// ~1 us round trips, 9 per block at C = 576).  NK = float4 per lane and row; lanes past n4 load a clamped address and multiply by 0.
+template <int U, int NK>
+__device__ __forceinline__ void se_dots(const float* const* w, const float* __restrict__ vec, int n4, int lane, float* acc) {
+    float4 wv[U][NK];
+#pragma unroll
+    for (int i = 0; i < NK; ++i) {
+        const int k4 = lane + 64 * i, kc = k4 < n4 ? k4 : n4 - 1;
+#pragma unroll
+        for (int u = 0; u < U; ++u) wv[u][i] = reinterpret_cast<const float4*>(w[u])[kc];
+    }
+#pragma unroll
+    for (int i = 0; i < NK; ++i) {
+        const int k4 = lane + 64 * i;
+        float4 sv = reinterpret_cast<const float4*>(vec)[k4 < n4 ? k4 : n4 - 1];
+        if (k4 >= n4) sv = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u] += dot4(wv[u][i], sv);
+    }
+}
+
+// out[r] = f(bias[r] + W[r][:] . vec) for rows r0 .. r1 of W (row length 4 n4), the block's waves striding over groups of U rows
+template <int U, int NK, class Store>
+__device__ __forceinline__ void se_rows(const float* __restrict__ W, const float* __restrict__ vec, int n4, int r0, int r1, int wave, int nw, int lane, Store store) {
+    for (int rb = r0 + wave * U; rb < r1; rb += nw * U) {
+        float acc[U];
+        const float* w[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            acc[u] = 0.f;
+            w[u] = W + (long)((rb + u < r1) ? rb + u : r1 - 1) * (4 * n4);
+        }
+        se_dots<U, NK>(w, vec, n4, lane, acc);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float a = wave_sum(acc[u]);
+            if (lane == 0 && rb + u < r1) store(rb + u, a);
+        }
+    }
+}
+// float4 per lane and row -> (rows in flight, NK) with <= 16 loads per lane outstanding
+template <class Store>
+__device__ __forceinline__ void se_rows_v4(const float* __restrict__ W, const float* __restrict__ vec, int n4, int r0, int r1, int wave, int nw, int lane, Store store) {
+    const int nk = (n4 + 63) >> 6;
+    if (nk <= 1) se_rows<8, 1>(W, vec, n4, r0, r1, wave, nw, lane, store);
+    else if (nk <= 2) se_rows<8, 2>(W, vec, n4, r0, r1, wave, nw, lane, store);
+    else if (nk <= 3) se_rows<4, 3>(W, vec, n4, r0, r1, wave, nw, lane, store);
+    else if (nk <= 4) se_rows<4, 4>(W, vec, n4, r0, r1, wave, nw, lane, store);
+    else if (nk <= 6) se_rows<2, 6>(W, vec, n4, r0, r1, wave, nw, lane, store);
+    else if (nk <= 8) se_rows<2, 8>(W, vec, n4, r0, r1, wave, nw, lane, store);
+    else se_rows<1, 12>(W, vec, n4, r0, r1, wave, nw, lane, store);          // up to 768 float4 (the host requires C <= 3072)
+}
+
 // g1[b][j] = relu(b1[j] + sum_k W1[j][k] s[b][k]);   gate[b][n] = b2[n] + sum_j W2[n][j] g1[b][j]
-// nch > 0: ``s`` holds the squeeze as nch partial column sums per sample, [b][chunk][C] (tf_colsum_bnrelu_parts_f32): they are added up here
+// nch > 0: ``s`` holds the squeeze as nch <= 8 partial column sums per sample, [b][chunk][C] (tf_colsum_bnrelu_parts_f32): they are added up here
 // (x scale = 1 / HW) instead of by a finalize launch, and block (b, 0) writes the squeezed vector to s_out for the backward.
 template <bool V4>
 __global__ void __launch_bounds__(1024) se_excite_fwd_kernel(const float* __restrict__ s, const float* __restrict__ W1, const float* __restrict__ b1,
@@ -29,85 +83,77 @@ __global__ void __launch_bounds__(1024) se_excite_fwd_kernel(const float* __rest
     __shared__ __attribute__((aligned(16))) float ss[SE_MAXC];
     __shared__ __attribute__((aligned(16))) float hh[SE_MAXR];
     const int b = blockIdx.x, part = blockIdx.y;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
+    const int tid = threadIdx.x, wave = wave_uniform(tid >> 6), lane = tid & 63, nw = blockDim.x >> 6;      // wave in an SGPR: the row pointers stay scalar
     if (nch > 0) {
         for (int k = tid; k < C; k += blockDim.x) {
             const float* p = s + (long)b * nch * C + k;
-            float v = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;      // four independent chains: the chunk loads are in flight together
-            int j = 0;
-            for (; j + 3 < nch; j += 4) { v += p[(long)j * C]; v1 += p[(long)(j + 1) * C]; v2 += p[(long)(j + 2) * C]; v3 += p[(long)(j + 3) * C]; }
-            for (; j < nch; ++j) v += p[(long)j * C];
-            v = ((v + v1) + (v2 + v3)) * scale;
-            ss[k] = v;
-            if (part == 0) s_out[(long)b * C + k] = v;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = p[(long)(j < nch ? j : nch - 1) * C];          // all chunk loads in flight together
+            float t = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t += j < nch ? v[j] : 0.f;
+            for (int j = 8; j < nch; ++j) t += p[(long)j * C];                                 // (the producer caps nch at 8)
+            t *= scale;
+            ss[k] = t;
+            if (part == 0) s_out[(long)b * C + k] = t;
         }
     } else {
         for (int k = tid; k < C; k += blockDim.x) ss[k] = s[(long)b * C + k];
     }
     __syncthreads();
-    // SE_U independent dot products per wave iteration: SE_U x more loads in flight (the weights come from HBM, ~1 us away)
-    for (int j0 = wave * SE_U; j0 < Cr; j0 += nw * SE_U) {
-        float acc[SE_U];
-        const float* w[SE_U];
-#pragma unroll
-        for (int u = 0; u < SE_U; ++u) {
-            acc[u] = 0.f;
-            w[u] = W1 + (long)((j0 + u < Cr) ? j0 + u : Cr - 1) * C;
+    auto store1 = [&](int j, float a) {
+        const float v = fmaxf(a + (b1 ? b1[j] : 0.f), 0.f);
+        hh[j] = v;
+        if (part == 0) {
+            g1[(long)b * Cr + j] = v;
+            if (zs) zs[(long)b * Cr + j] = 0.f;      // the backward's (B, Cr) atomic accumulator, cleared here instead of by its own launch
         }
-        if (V4) {
-            for (int k4 = lane; k4 < (C >> 2); k4 += 64) {
-                const float4 sv = *reinterpret_cast<const float4*>(ss + 4 * k4);
+    };
+    const int per = (C + SE_SPLIT - 1) / SE_SPLIT;
+    const int n0 = part * per, n1 = (n0 + per < C) ? n0 + per : C;
+    auto store2 = [&](int n, float a) { gate[(long)b * C + n] = a + (b2 ? b2[n] : 0.f); };
+    if (V4) {
+        se_rows_v4(W1, ss, C >> 2, 0, Cr, wave, nw, lane, store1);
+        __syncthreads();
+        if (n0 < n1) se_rows_v4(W2, hh, Cr >> 2, n0, n1, wave, nw, lane, store2);
+    } else {
+        for (int j0 = wave * SE_U; j0 < Cr; j0 += nw * SE_U) {
+            float acc[SE_U];
+            const float* w[SE_U];
 #pragma unroll
-                for (int u = 0; u < SE_U; ++u) acc[u] += dot4(*reinterpret_cast<const float4*>(w[u] + 4 * k4), sv);
+            for (int u = 0; u < SE_U; ++u) {
+                acc[u] = 0.f;
+                w[u] = W1 + (long)((j0 + u < Cr) ? j0 + u : Cr - 1) * C;
             }
-        } else {
             for (int k = lane; k < C; k += 64) {
 #pragma unroll
                 for (int u = 0; u < SE_U; ++u) acc[u] += w[u][k] * ss[k];
             }
-        }
 #pragma unroll
-        for (int u = 0; u < SE_U; ++u) {
-            const float a = wave_sum(acc[u]);
-            const int j = j0 + u;
-            if (lane == 0 && j < Cr) {
-                const float v = fmaxf(a + (b1 ? b1[j] : 0.f), 0.f);
-                hh[j] = v;
-                if (part == 0) {
-                    g1[(long)b * Cr + j] = v;
-                    if (zs) zs[(long)b * Cr + j] = 0.f;      // the backward's (B, Cr) atomic accumulator, cleared here instead of by its own launch
-                }
+            for (int u = 0; u < SE_U; ++u) {
+                const float a = wave_sum(acc[u]);
+                if (lane == 0 && j0 + u < Cr) store1(j0 + u, a);
             }
         }
-    }
-    __syncthreads();
-    const int per = (C + SE_SPLIT - 1) / SE_SPLIT;
-    const int n0 = part * per, n1 = (n0 + per < C) ? n0 + per : C;
-    for (int nb = n0 + wave * SE_U; nb < n1; nb += nw * SE_U) {
-        float acc[SE_U];
-        const float* w[SE_U];
+        __syncthreads();
+        for (int nb = n0 + wave * SE_U; nb < n1; nb += nw * SE_U) {
+            float acc[SE_U];
+            const float* w[SE_U];
 #pragma unroll
-        for (int u = 0; u < SE_U; ++u) {
-            acc[u] = 0.f;
-            w[u] = W2 + (long)((nb + u < n1) ? nb + u : n1 - 1) * Cr;
-        }
-        if (V4) {
-            for (int j4 = lane; j4 < (Cr >> 2); j4 += 64) {
-                const float4 hv = *reinterpret_cast<const float4*>(hh + 4 * j4);
-#pragma unroll
-                for (int u = 0; u < SE_U; ++u) acc[u] += dot4(*reinterpret_cast<const float4*>(w[u] + 4 * j4), hv);
+            for (int u = 0; u < SE_U; ++u) {
+                acc[u] = 0.f;
+                w[u] = W2 + (long)((nb + u < n1) ? nb + u : n1 - 1) * Cr;
             }
-        } else {
             for (int j = lane; j < Cr; j += 64) {
 #pragma unroll
                 for (int u = 0; u < SE_U; ++u) acc[u] += w[u][j] * hh[j];
             }
-        }
 #pragma unroll
-        for (int u = 0; u < SE_U; ++u) {
-            const float a = wave_sum(acc[u]);
-            const int n = nb + u;
-            if (lane == 0 && n < n1) gate[(long)b * C + n] = a + (b2 ? b2[n] : 0.f);
+            for (int u = 0; u < SE_U; ++u) {
+                const float a = wave_sum(acc[u]);
+                if (lane == 0 && nb + u < n1) store2(nb + u, a);
+            }
         }
     }
 }
@@ -254,7 +300,7 @@ __global__ void __launch_bounds__(256) se_excite_bwd1_kernel(const float* __rest
 extern "C" int tf_se_excite_fwd_f32(const float* s, const float* W1, const float* b1, const float* W2, const float* b2, int B, int C, int Cr, float* g1,
                                     float* gate, float* bwd_scratch, void* stream) {
     TF_REQUIRE(s && W1 && W2 && g1 && gate && B > 0 && C > 0 && Cr > 0 && C <= SE_MAXC && Cr <= SE_MAXR,
-               "tf_se_excite_fwd_f32: bad arguments (C <= 4096, Cr <= 1024)");
+               "tf_se_excite_fwd_f32: bad arguments (C <= 3072, Cr <= 1024)");
     const bool v4 = C % 4 == 0 && Cr % 4 == 0 && aligned16(W1) && aligned16(W2);
     if (v4) TF_LAUNCH(se_excite_fwd_kernel<true>, dim3(B, SE_SPLIT), dim3(1024), stream, s, W1, b1, W2, b2, C, Cr, g1, gate, bwd_scratch);
     else TF_LAUNCH(se_excite_fwd_kernel<false>, dim3(B, SE_SPLIT), dim3(1024), stream, s, W1, b1, W2, b2, C, Cr, g1, gate, bwd_scratch);
@@ -276,7 +322,7 @@ extern "C" int tf_se_excite_bwd_f32(const float* dgate, const float* s, const fl
 extern "C" int tf_se_excite_fwd_parts_f32(const float* parts, int nchunks, float scale, const float* W1, const float* b1, const float* W2, const float* b2, int B,
                                           int C, int Cr, float* s_out, float* g1, float* gate, float* bwd_scratch, void* stream) {
     TF_REQUIRE(parts && nchunks > 0 && W1 && W2 && s_out && g1 && gate && B > 0 && C > 0 && Cr > 0 && C <= SE_MAXC && Cr <= SE_MAXR,
-               "tf_se_excite_fwd_parts_f32: bad arguments (C <= 4096, Cr <= 1024)");
+               "tf_se_excite_fwd_parts_f32: bad arguments (C <= 3072, Cr <= 1024)");
     const bool v4 = C % 4 == 0 && Cr % 4 == 0 && aligned16(W1) && aligned16(W2);
     if (v4) TF_LAUNCH(se_excite_fwd_kernel<true>, dim3(B, SE_SPLIT), dim3(1024), stream, parts, W1, b1, W2, b2, C, Cr, g1, gate, bwd_scratch, nchunks, scale, s_out);
     else TF_LAUNCH(se_excite_fwd_kernel<false>, dim3(B, SE_SPLIT), dim3(1024), stream, parts, W1, b1, W2, b2, C, Cr, g1, gate, bwd_scratch, nchunks, scale, s_out);

@@ -40,7 +40,6 @@ __forceinline__ void dma_b128(float* lds_wave_dst, const DmaSrc& s, unsigned vof
 template <int N> __forceinline__ void dma_wait() {}
 __forceinline__ void lds_wait() {}
 template <int NW> __forceinline__ void dma_barrier() { if (NW > 1) __syncthreads(); else emu::wave_barrier(); }
-__forceinline__ int wave_uniform(int v) { return v; }
 #else
 typedef i32x4 DmaSrc;
 __device__ __forceinline__ DmaSrc dma_make_src(const float* p, unsigned bytes) {
@@ -63,7 +62,6 @@ __device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)"
 template <int NW> __device__ __forceinline__ void dma_barrier() {
     if (NW > 1) asm volatile("s_barrier" ::: "memory");
 }
-__device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 #endif
 
 // ---- stream-K (SK instantiations): cross-workgroup hand-over of a partial accumulator tile.  Only the words that cross workgroups are

@@ -25,6 +25,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define TF_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
 
+// a value every lane of the wave agrees on (wave index, a row pointer's row): keeps it - and the addresses derived from it - in SGPRs
+#ifdef TF_EMU
+__forceinline__ int wave_uniform(int v) { return v; }
+#else
+__device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+#endif
+
 #ifdef TF_EMU
 __forceinline__ int lane_id() { return emu::cur_lane(); }
 
