@@ -373,6 +373,10 @@ int tf_adamw_dynscale_f32(float* p, const float* g, float* m, float* v, int64_t 
 /* lidar_to_histogram_features (data.py:446-470): points (B, max_points, stride>=3) f32 -> (B,2,256,256),
  * integer-exact; num_points may be NULL. */
 int tf_lidar_hist_f32(const float* points, const int32_t* num_points, int B, int max_points, int point_stride, float* out, void* stream);
+/* The same in two launches instead of three: `zero_ws` = tf_lidar_hist_ws_bytes(B) bytes (16-byte aligned) owned by the caller, ALL ZERO before the
+ * first call; every call leaves it all zero again (the int32 cell counters live there instead of in `out`, the finishing pass clears them). */
+long tf_lidar_hist_ws_bytes(int B);
+int tf_lidar_hist_ws_f32(const float* points, const int32_t* num_points, int B, int max_points, int point_stride, void* zero_ws, float* out, void* stream);
 
 /* ---- H2: PointPillars front-end (point_pillar.py:37-122, model.py:736-738) - integer-exact pillar ids without a sort ---------
  * The reference's torch.unique(dim=0, return_inverse=True) over (batch, x_idx, y_idx) rows == rank of the occupied cell in an
@@ -413,6 +417,8 @@ int tf_pillar_canvas_bwd_f32(const float* dout_nhwc, const int32_t* owner, const
  *   (data.py:358-372), 2 -> crop_seg + class LUT (data.py:176-177).  tf_bev_prep_u8: decode_pil_to_npy + load_crop_bev_npy (data.py:844-856,586-612). */
 int tf_lidar_align_hist_f64(const float* points, const int32_t* num_points, int B, int max_points, int point_stride, const double* transforms, float* out,
                             float* aligned_or_null, void* stream);
+int tf_lidar_align_hist_ws_f64(const float* points, const int32_t* num_points, int B, int max_points, int point_stride, const double* transforms,
+                               void* zero_ws, float* out, float* aligned_or_null, void* stream);      /* two launches, workspace as tf_lidar_hist_ws_f32 */
 
 /* lidar_bev_cam_correspondences + correspondences_at_one_scale (team_code_transfuser/data.py:632-842; per sample at data.py:273 and
  * submission_agent.py:306) for a batch of raw clouds: points (B, max_points, point_stride >= 3) float32 in the CARLA frame (x left, y forward,

@@ -787,8 +787,15 @@ def check_hist(dev, B, N, stride=4, ragged=None):
     for b in range(B):
         ref = hist.lidar_to_histogram_features(pts[b, :int(npts[b]), :4])
         assert np.array_equal(out[b], ref), "H1 histogram must be bit-exact (sample %d: %d bins differ)" % (b, (out[b] != ref).sum())
-    out2 = ops.lidar_hist(torch.from_numpy(pts).to(dev)).cpu().numpy()        # num_points = None: every row counts
+    out2 = ops.lidar_hist(torch.from_numpy(pts).to(dev)).cpu().numpy()        # num_points = None: every row counts (and: the previous call left its counter workspace zeroed)
     assert np.array_equal(out2[0], hist.lidar_to_histogram_features(pts[0, :, :4]))
+    assert int(ops._hist_ws(B, torch.device(dev)).abs().sum()) == 0, "the counter workspace must be all zero between calls"
+    # the three-launch entry point without a workspace (counters in the output buffer)
+    from transfuser_amd._lib import ptr, stream_of, check
+    pt, nt = torch.from_numpy(pts).to(dev), torch.from_numpy(npts).to(dev)
+    out3 = torch.empty(B, 2, 256, 256, dtype=torch.float32, device=dev)
+    check(ops.L().tf_lidar_hist_f32(ptr(pt), ptr(nt), B, N, stride, ptr(out3), stream_of(pt)), "tf_lidar_hist_f32")
+    assert np.array_equal(out3.cpu().numpy(), out)
 
 
 def check_correspondences(dev):

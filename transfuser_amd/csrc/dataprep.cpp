@@ -130,6 +130,20 @@ extern "C" int tf_lidar_align_hist_f64(const float* points, const int32_t* num_p
     TF_LAUNCH(hist_finish_kernel, dim3(cdiv(n4, 256)), dim3(256), stream, reinterpret_cast<float4*>(out), n4);
     return launch_status("tf_lidar_align_hist_f64");
 }
+// two launches with the zeroed counter workspace of tf_lidar_hist_ws_f32 (tf_lidar_hist_ws_bytes(B))
+extern "C" int tf_lidar_align_hist_ws_f64(const float* points, const int32_t* num_points, int B, int max_points, int point_stride, const double* transforms,
+                                          void* zero_ws, float* out, float* aligned_or_null, void* stream) {
+    TF_REQUIRE(points && transforms && out && zero_ws && B > 0 && max_points >= 0 && point_stride >= 4, "tf_lidar_align_hist_ws_f64: bad arguments");
+    TF_REQUIRE(aligned16(out) && aligned16(zero_ws), "tf_lidar_align_hist_ws_f64: out / workspace must be 16-byte aligned");
+    const long n4 = (long)B * 2 * 256 * 256 / 4;
+    if (max_points > 0) {
+        const int vec4 = (point_stride == 4 && aligned16(points)) ? 1 : 0;
+        TF_LAUNCH(lidar_align_hist_kernel, dim3(cdiv(max_points, 256), B), dim3(256), stream, points, num_points, max_points, point_stride, vec4, transforms,
+                  reinterpret_cast<int*>(zero_ws), aligned_or_null);
+    }
+    TF_LAUNCH(hist_finish_ws_kernel, dim3(cdiv(n4, 256)), dim3(256), stream, reinterpret_cast<int4*>(zero_ws), reinterpret_cast<float4*>(out), n4);
+    return launch_status("tf_lidar_align_hist_ws_f64");
+}
 
 extern "C" int tf_image_prep_u8(const uint8_t* src, int B, int Hs, int Ws, int C, int crop_h, int crop_w, int start_y, const int32_t* start_x, int mode,
                                 const uint8_t* lut, void* out, void* stream) {

@@ -221,3 +221,17 @@ extern "C" int tf_lidar_hist_f32(const float* points, const int32_t* num_points,
     TF_LAUNCH(hist_finish_kernel, dim3(cdiv(n4, 256)), dim3(256), stream, reinterpret_cast<float4*>(out), n4);
     return launch_status("tf_lidar_hist_f32");
 }
+// the same in TWO launches: the counters live in a caller-owned workspace that is all zero on entry and left all zero (tf_hist.h)
+extern "C" long tf_lidar_hist_ws_bytes(int B) { return (long)B * 2 * 256 * 256 * 4; }
+extern "C" int tf_lidar_hist_ws_f32(const float* points, const int32_t* num_points, int B, int max_points, int point_stride, void* zero_ws, float* out, void* stream) {
+    TF_REQUIRE(points && out && zero_ws && B > 0 && max_points >= 0 && point_stride >= 3, "tf_lidar_hist_ws_f32: bad arguments");
+    TF_REQUIRE(aligned16(out) && aligned16(zero_ws), "tf_lidar_hist_ws_f32: out / workspace must be 16-byte aligned");
+    const long n4 = (long)B * 2 * 256 * 256 / 4;
+    if (max_points > 0) {
+        const int vec4 = (point_stride == 4 && aligned16(points)) ? 1 : 0;
+        TF_LAUNCH(lidar_hist_count_kernel, dim3(cdiv(max_points, 256), B), dim3(256), stream, points, num_points, max_points, point_stride, vec4,
+                  reinterpret_cast<int*>(zero_ws));
+    }
+    TF_LAUNCH(hist_finish_ws_kernel, dim3(cdiv(n4, 256)), dim3(256), stream, reinterpret_cast<int4*>(zero_ws), reinterpret_cast<float4*>(out), n4);
+    return launch_status("tf_lidar_hist_ws_f32");
+}

@@ -1,6 +1,7 @@
 // H1: the 2-bin LiDAR height histogram (team_code_transfuser/data.py:446-470), single pass over the cloud.
 //
-// Three launches on the caller's stream, no workspace: (1) clear the (B, 2, 256, 256) output, viewed as int32 counters; (2) one thread
+// Three launches on the caller's stream without a workspace (two with one: the *_ws entry points keep the counters in a caller-owned buffer that
+// every call leaves zeroed, hist_finish_ws_kernel): (1) clear the (B, 2, 256, 256) output, viewed as int32 counters; (2) one thread
 // per point: one 16-byte load, bin, one return-less int32 atomic on the counter of its cell (the counters of a step's clouds are 5 MB:
 // they live in L2 / the Infinity Cache); (3) counters -> min(cnt, 5) / 5 in place.  The cloud is read ONCE (the round-3 kernel had every
 // one of 32 slab blocks per sample re-scan it).  Same-address atomics queue (~0.1 us each), so a wave first merges RUNS of equal cells
@@ -46,6 +47,17 @@ static __global__ void __launch_bounds__(256) hist_finish_kernel(float4* __restr
     const float4 v = out[i];
     const int a = __float_as_int(v.x), b = __float_as_int(v.y), c = __float_as_int(v.z), d = __float_as_int(v.w);
     out[i] = make_float4((float)(a < 5 ? a : 5) / 5.0f, (float)(b < 5 ? b : 5) / 5.0f, (float)(c < 5 ? c : 5) / 5.0f, (float)(d < 5 ? d : 5) / 5.0f);
+}
+
+// two-launch form: the counters live in a caller-owned int32 workspace that is ALL ZERO between calls - this kernel turns them into the output
+// and re-zeroes them, so no clear launch is needed in front of the next call
+static __global__ void __launch_bounds__(256) hist_finish_ws_kernel(int4* __restrict__ counters, float4* __restrict__ out, long n4) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const int4 v = counters[i];
+    int4 zero; zero.x = zero.y = zero.z = zero.w = 0;
+    counters[i] = zero;
+    out[i] = make_float4((float)(v.x < 5 ? v.x : 5) / 5.0f, (float)(v.y < 5 ? v.y : 5) / 5.0f, (float)(v.z < 5 ? v.z : 5) / 5.0f, (float)(v.w < 5 ? v.w : 5) / 5.0f);
 }
 
 }  // namespace tf

@@ -1246,8 +1246,22 @@ def lidar_hist(points, num_points=None):
     """points (B, N, >=3) float32 -> (B, 2, 256, 256) float32 BEV histogram (data.py:446-470)."""
     B, N, S = points.shape
     out = torch.empty(B, 2, 256, 256, dtype=torch.float32, device=points.device)
-    check(L().tf_lidar_hist_f32(ptr(_c(points)), ptr(num_points), B, N, S, ptr(out), stream_of(points)), "tf_lidar_hist_f32")
+    check(L().tf_lidar_hist_ws_f32(ptr(_c(points)), ptr(num_points), B, N, S, ctypes.c_void_p(_hist_ws(B, points.device).data_ptr()), ptr(out),
+                                   stream_of(points)), "tf_lidar_hist_ws_f32")
     return out
+
+
+_HIST_WS = {}
+
+
+def _hist_ws(B, device):
+    """The histogram kernels' int32 cell counters: zeroed once here, left zeroed by every call (two launches instead of three).  One buffer per
+    (device, stream): calls on different streams must not share counters."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
+    ws = _HIST_WS.get(key)
+    if ws is None or ws.numel() < B * 2 * 256 * 256:
+        ws = _HIST_WS[key] = torch.zeros(B * 2 * 256 * 256, dtype=torch.int32, device=device)
+    return ws
 
 
 # ------------------------------------------------------------------------------------------ H2 PointPillars front-end
@@ -1329,8 +1343,8 @@ def lidar_align_hist(points, transforms, num_points=None, return_aligned=False):
     out = torch.empty(B, 2, 256, 256, dtype=torch.float32, device=points.device)
     al = torch.empty(B, N, 4, dtype=torch.float32, device=points.device) if return_aligned else None
     t = transforms.to(device=points.device, dtype=torch.float64).contiguous()
-    check(L().tf_lidar_align_hist_f64(ptr(_c(points)), ptr(num_points), B, N, S, ctypes.c_void_p(t.data_ptr()), ptr(out), ptr(al), stream_of(points)),
-          "tf_lidar_align_hist_f64")
+    check(L().tf_lidar_align_hist_ws_f64(ptr(_c(points)), ptr(num_points), B, N, S, ctypes.c_void_p(t.data_ptr()),
+                                         ctypes.c_void_p(_hist_ws(B, points.device).data_ptr()), ptr(out), ptr(al), stream_of(points)), "tf_lidar_align_hist_ws_f64")
     return (out, al) if return_aligned else out
 
 
