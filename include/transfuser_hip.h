@@ -190,6 +190,15 @@ int tf_conv3x3_grouped_dgrad_f32(const float* dy, const float* w, float* dx, int
 int tf_conv3x3_grouped_s2_dgrad_f32(const float* dy, const float* w, float* dx, int B, int Hi, int Wi, int C, int accumulate, void* stream);
 long tf_conv3x3_grouped_wgrad_ws_floats(void);
 int tf_conv3x3_grouped_wgrad_f32(const float* dy, const float* x, float* dw, int B, int H, int W, int C, int accumulate, float* ws, void* stream);
+/* conv1 -> BatchNormAct2d -> grouped conv2 of a timm RegNetY Bottleneck (transfuser.py:380,442) with the BatchNorm apply folded into the CONSUMER:
+ * x is the RAW output of conv1, in_coef = [scale | shift] (2 C floats, tf_bn_finalize_parts_f32) of its BatchNorm; the kernels stage
+ * max(x scale + shift, 0) themselves (zero padding stays zero), so the normalised activation is never written to memory.  Forward = the
+ * colstat forward above, weight gradient = tf_conv3x3_grouped_wgrad_f32 against that recomputed activation; the BatchNorm's own backward
+ * recomputes its ReLU mask the same way (tf_bn_bwd_remask_f32). */
+int tf_conv3x3_grouped_bnrelu_fwd_colstat_f32(const float* x, const float* in_coef, const float* w, float* y, int B, int H, int W, int C, float* colstat,
+                                              int* colstat_nparts, void* stream);
+int tf_conv3x3_grouped_bnrelu_wgrad_f32(const float* dy, const float* x, const float* in_coef, float* dw, int B, int H, int W, int C, int accumulate, float* ws,
+                                        void* stream);
 
 /* Stem convolutions reading the NCHW model inputs directly (Cin <= 4, no bias, NHWC output):
  * channels [0,C0) from s0, [C0,C0+C1) from s1 - the torch.cat of model.py:741-742 is never

@@ -1281,6 +1281,27 @@ def check_conv_grouped(dev, B, H, W, C):
         ops.conv_wgrad(dyh, xh, dw2, 1, None, groups)
         close(dw2, gw, what="ops.conv_wgrad -> grouped")
         close(ops.conv_dgrad(dyh, wh, xh.shape, 1, None, groups).permute(0, 3, 1, 2), gx, what="ops.conv_dgrad -> grouped")
+    # BatchNorm apply folded into the consumer: conv(relu(x sc + sh)) and its weight gradient from the RAW x; the zero padding must stay zero
+    # (shift > 0 on some channels would otherwise leak relu(shift) in from the border), forward output statistics as the plain colstat forward
+    sc, sh = R(C, seed=7, dev="cpu") * 0.5 + 1.0, R(C, seed=8, dev="cpu") * 0.7 + 0.3
+    z = torch.relu(x.detach() * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)).requires_grad_(True)
+    yz = F.conv2d(z, w, None, 1, 1, 1, groups)
+    (gwz,) = torch.autograd.grad(yz, [w], dy)
+    coef = torch.cat([sc, sh]).to(dev)
+    y2 = torch.empty(B, H, W, C, device=dev)
+    cs = ops.ColStat(B * H * W, C, xh.device, max_parts=L.tf_conv3x3_grouped_colstat_parts())
+    from ctypes import byref
+    check(L.tf_conv3x3_grouped_bnrelu_fwd_colstat_f32(ptr(xh), ptr(coef), wptr(wh), ptr(y2), B, H, W, C, ptr(cs.buf), byref(cs.nparts), stream_of(xh)), "grouped bnrelu fwd")
+    close(y2.permute(0, 3, 1, 2), yz, what="grouped fwd with the BatchNorm apply of its input folded in")
+    g_, b_ = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    _, sm, si = ops.bn_finalize_parts(cs, g_, b_, rm, rv)
+    y64 = yz.detach().double().permute(0, 2, 3, 1).reshape(-1, C)
+    close(sm.cpu(), y64.mean(0).float(), what="grouped bnrelu fwd: output mean", tol=1e-4)
+    close(si.cpu(), (1.0 / torch.sqrt(y64.var(0, unbiased=False) + 1e-5)).float(), what="grouped bnrelu fwd: output invstd", tol=1e-4)
+    dwz = torch.full_like(wh, 0.25)
+    check(L.tf_conv3x3_grouped_bnrelu_wgrad_f32(ptr(dyh), ptr(xh), ptr(coef), wptr(dwz), B, H, W, C, 1, ptr(ws), stream_of(xh)), "grouped bnrelu wgrad")
+    close(dwz, cl(gwz) + 0.25, what="grouped wgrad against the recomputed activation (accumulate)")
 
 
 def check_bf16_direct(dev):

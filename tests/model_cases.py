@@ -448,3 +448,48 @@ def check_full_size_vs_fp32_oracle(backbone, B, H, dev="cuda", loss_tol=1e-3, pe
     assert med <= median and len(bad) <= 3, (med, bad[:6])
     if plans:
         ops.L().tf_plans_clear()
+
+
+def check_bn_conv_fold(dev, batch_dims, lidar_res=None):
+    """conv1 -> BatchNorm -> ReLU -> grouped conv2 with the BatchNorm apply folded into conv2 / its weight gradient (TF_FUSE_BN_CONV, YBlockFn): the
+    same model run with the switch on and off - losses and every parameter gradient agree to fp32 round-off, the running statistics are
+    updated identically, and the folded path really ran."""
+    from transfuser_amd import ops
+    calls = {"fwd": 0, "wgrad": 0}
+    of, ow = ops.grouped_bnrelu_fwd, ops.grouped_bnrelu_wgrad
+
+    def cf(*a, **k):
+        calls["fwd"] += 1
+        return of(*a, **k)
+
+    def cw(*a, **k):
+        calls["wgrad"] += 1
+        return ow(*a, **k)
+    cfg = tiny_config(n_layer=1, **({"lidar_res": lidar_res} if lidar_res else {}))
+    prod, ref = build_pair(cfg, "regnety_tiny", dev)
+    batch = small_batch(*batch_dims)
+    state = {k: v.clone() for k, v in prod.state_dict().items()}
+    res = {}
+    prev = ops.FUSE_BN_CONV
+    ops.grouped_bnrelu_fwd, ops.grouped_bnrelu_wgrad = cf, cw
+    try:
+        for on in (True, False):
+            ops.FUSE_BN_CONV = on
+            prod.load_state_dict(state)
+            lp, _ = run_pair(prod, ref, cfg, batch, dev)
+            res[on] = ({k: float(v) for k, v in lp.items()}, {n: p.grad.clone() for n, p in prod.named_parameters() if p.grad is not None},
+                       {n: b.clone() for n, b in prod.named_buffers() if "running" in n})
+            if on:
+                assert calls["fwd"] > 0 and calls["fwd"] == calls["wgrad"], calls
+                seen = dict(calls)
+        assert calls == seen, "the unfused run must not touch the folded kernels"
+    finally:
+        ops.FUSE_BN_CONV = prev
+        ops.grouped_bnrelu_fwd, ops.grouped_bnrelu_wgrad = of, ow
+    for k, v in res[True][0].items():
+        assert abs(v - res[False][0][k]) <= 1e-5 * max(1.0, abs(v)), (k, v, res[False][0][k])
+    for n, g in res[True][1].items():
+        g0 = res[False][1][n]
+        assert (g - g0).abs().max().item() <= 2e-4 * max(g0.abs().max().item(), 1e-3), n
+    for n, b in res[True][2].items():
+        assert torch.allclose(b, res[False][2][n], rtol=1e-6, atol=1e-7), n

@@ -390,3 +390,7 @@ def test_fp16_dynamic_loss_scale_skips_overflowed_steps():
         assert not torch.equal(eng.arena.params, p1) and torch.isfinite(eng.arena.params).all()
     finally:
         ops.set_precision("fp32")
+
+
+def test_bottleneck_bn_apply_folded_into_conv2_matches_the_unfused_block():
+    mc.check_bn_conv_fold("cpu", (2, 64, 128, 64, 40))

@@ -27,6 +27,10 @@ def test_tiny_model_losses_and_grads():
     mc.compare(prod, ref, lp, lr, grad_tol=5e-3, verbose=True, metric="l2")
 
 
+def test_bottleneck_bn_apply_folded_into_conv2_matches_the_unfused_block():
+    mc.check_bn_conv_fold("cuda", (2, 160, 352, 128, 40), lidar_res=128)
+
+
 def test_tiny_latentTF_losses_and_grads():
     """BASELINE config 5 backbone (latentTF.py:118-217): positional grid replaces the LiDAR histogram."""
     cfg = mc.tiny_config(n_layer=2, lidar_res=128)

@@ -57,7 +57,7 @@ __device__ __forceinline__ void scatter_group_weights(float (*wl)[WP], const Gro
 }
 
 template <int TW>
-__device__ __forceinline__ float4 load_patch_slot(const float* __restrict__ x, const GcGeom& g, int coff, int b, int h0, int w0, int s) {
+__device__ __forceinline__ float4 load_patch_slot(const float* __restrict__ x, const GcGeom& g, int coff, int b, int h0, int w0, int s, bool* valid = nullptr) {
     typedef Tile<TW> T;
     const int pix = s / 6, c = (s - pix * 6) * 4;
     const int ph = pix / T::PW, pw = pix - ph * T::PW;
@@ -65,12 +65,24 @@ __device__ __forceinline__ float4 load_patch_slot(const float* __restrict__ x, c
     const bool ok = pix < T::NPIX && (unsigned)h < (unsigned)g.H && (unsigned)w < (unsigned)g.W;
     const int hc = h < 0 ? 0 : (h >= g.H ? g.H - 1 : h), wc = w < 0 ? 0 : (w >= g.W ? g.W - 1 : w);      // clamped address: the load itself is unconditional
     const float4 v = *reinterpret_cast<const float4*>(x + (((long)b * g.H + hc) * g.W + wc) * g.C + coff + c);
+    if (valid) *valid = ok;
     return ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 template <int TW>
 __device__ __forceinline__ void store_patch_slot(float* patch, int s, const float4 v) {
     const int pix = s / 6, c = (s - pix * 6) * 4;
     if (pix < Tile<TW>::NPIX) { float* q = patch + pix * PP + c; q[0] = v.x; q[1] = v.y; q[2] = v.z; q[3] = v.w; }
+}
+// BatchNorm apply of the PRODUCER folded into this consumer (timm ConvBnAct conv1 -> conv2 of a RegNetY bottleneck): the kernel reads the raw
+// convolution output and stages max(x sc + sh, 0) - the normalised activation is never written to memory.  cf = [scale (24) | shift (24)] of the
+// block's group in LDS; zero padding stays zero (the transform is applied to pixels inside the map only).
+__device__ __forceinline__ float4 bnrelu4(const float4 v, const float* cf, int c, bool ok) {
+    if (!ok) return make_float4(0.f, 0.f, 0.f, 0.f);
+    return make_float4(fmaxf(v.x * cf[c] + cf[CG + c], 0.f), fmaxf(v.y * cf[c + 1] + cf[CG + c + 1], 0.f), fmaxf(v.z * cf[c + 2] + cf[CG + c + 2], 0.f),
+                       fmaxf(v.w * cf[c + 3] + cf[CG + c + 3], 0.f));
+}
+__device__ __forceinline__ void stage_group_coef(float* cf, const float* __restrict__ in_coef, int coff, int C) {
+    if (in_coef && threadIdx.x < 2 * CG) cf[threadIdx.x] = in_coef[threadIdx.x < CG ? coff + threadIdx.x : C + coff + threadIdx.x - CG];
 }
 
 // y[.., g*24 + co] = sum_{tap, ci} x[.. + tap, g*24 + ci] * W  (+ bias) (relu) (+= when accumulate); dgrad != 0: x is dY, y is dX
@@ -81,31 +93,44 @@ __device__ __forceinline__ void store_patch_slot(float* patch, int s, const floa
 template <int TW, bool X3 = false, bool STAT = false>
 __global__ void __launch_bounds__(256, 2) conv3x3_grouped_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                                  float* __restrict__ y, GcGeom g, int dgrad, int relu, int accumulate, int prec,
-                                                                 float* __restrict__ stat = nullptr) {
+                                                                 float* __restrict__ stat = nullptr, const float* __restrict__ in_coef = nullptr) {
     typedef Tile<TW> T;
     __shared__ float patch[T::NPIX * PP];
     __shared__ float wl[9 * CG][WP];
+    __shared__ float cf[2 * CG];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int grp = blockIdx.x / g.nb, sub = blockIdx.x - grp * g.nb, coff = grp * CG;
     GroupWeightRegs wreg;
     issue_group_weights(wreg, w + (long)grp * CG * 9 * CG);          // 21 loads in flight; the first patch joins them before anything waits
     float4 pre[T::NV];
+    unsigned okm = 0;                                                 // validity of the pre[] slots (in_coef: the transform must leave the zero padding zero)
     auto fetch = [&](int t) {
         const int b = t / (g.tiles_h * g.tiles_w), r = t - b * (g.tiles_h * g.tiles_w);
         const int h0 = (r / g.tiles_w) * T::TH, w0 = (r % g.tiles_w) * TW;
+        okm = 0;
 #pragma unroll
-        for (int p = 0; p < T::NV; ++p) pre[p] = load_patch_slot<TW>(x, g, coff, b, h0, w0, tid + p * 256);
+        for (int p = 0; p < T::NV; ++p) {
+            bool ok;
+            pre[p] = load_patch_slot<TW>(x, g, coff, b, h0, w0, tid + p * 256, &ok);
+            okm |= ok ? 1u << p : 0u;
+        }
     };
     int tile = sub;
     if (tile < g.ntiles) fetch(tile);
+    stage_group_coef(cf, in_coef, coff, g.C);
     scatter_group_weights(wl, wreg, dgrad);
     // this lane's pixel inside the wave's 32: (row, col) of the tile
     const int prow = wave * T::RW + l31 / TW, pcol = l31 % TW;
     float st_n = 0.f, st_mean = 0.f, st_m2 = 0.f;      // STAT: running triple of channel l31 over this wave's pixels (same in both lane halves)
     for (; tile < g.ntiles; tile += g.nb) {
-        __syncthreads();                           // previous tile's MFMAs are done with the patch (and the weights are staged)
+        __syncthreads();                           // previous tile's MFMAs are done with the patch (and the weights / coefficients are staged)
+        if (in_coef) {
 #pragma unroll
-        for (int p = 0; p < T::NV; ++p) store_patch_slot<TW>(patch, tid + p * 256, pre[p]);
+            for (int p = 0; p < T::NV; ++p) store_patch_slot<TW>(patch, tid + p * 256, bnrelu4(pre[p], cf, ((tid + p * 256) % 6) * 4, (okm >> p) & 1u));
+        } else {
+#pragma unroll
+            for (int p = 0; p < T::NV; ++p) store_patch_slot<TW>(patch, tid + p * 256, pre[p]);
+        }
         __syncthreads();
         const int nxt = tile + g.nb;
         if (nxt < g.ntiles) fetch(nxt);            // next patch travels while this one is multiplied
@@ -219,11 +244,13 @@ __global__ void __launch_bounds__(256, 2) conv3x3_grouped_kernel(const float* __
 // LDS at the end and one block per CU - 62 us per launch against a 22 us MFMA bound).  Operand rows / columns 24..31 of the 32-wide MFMA
 // carry whatever the neighbouring LDS words hold: they only reach accumulator rows / columns >= 24, which are never read.
 template <int TW, int PREC>
-__global__ void __launch_bounds__(192) conv3x3_grouped_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part, GcGeom g) {
+__global__ void __launch_bounds__(192) conv3x3_grouped_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part, GcGeom g,
+                                                                    const float* __restrict__ in_coef = nullptr) {
     typedef Tile<TW> T;
     constexpr int NT = 192;
     constexpr int NVP = (T::NPIX * 6 + NT - 1) / NT, ND = (128 * 6 + NT - 1) / NT;     // float4 slots per thread: patch, dY (6 per pixel)
     __shared__ float lds[T::NPIX * PP + 128 * PP + 8];
+    __shared__ float cf[2 * CG];
     float* patch = lds;
     float* dyt = lds + T::NPIX * PP;               // [pixel][co]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
@@ -234,9 +261,11 @@ __global__ void __launch_bounds__(192) conv3x3_grouped_wgrad_kernel(const float*
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     float4 pre[NVP], dpre[ND];
+    unsigned okm = 0;              // validity of the pre[] slots (in_coef, see bnrelu4)
     auto fetch = [&](int t) {      // unconditional loads from clamped addresses; the zero padding is applied to the VALUE
         const int b = t / (g.tiles_h * g.tiles_w), r = t - b * (g.tiles_h * g.tiles_w);
         const int h0 = (r / g.tiles_w) * T::TH, w0 = (r % g.tiles_w) * TW;
+        okm = 0;
 #pragma unroll
         for (int p = 0; p < NVP; ++p) {
             const int s = tid + p * NT, pix = s / 6, c = (s - pix * 6) * 4;
@@ -245,6 +274,7 @@ __global__ void __launch_bounds__(192) conv3x3_grouped_wgrad_kernel(const float*
             const int hc = h < 0 ? 0 : (h >= g.H ? g.H - 1 : h), wc = w < 0 ? 0 : (w >= g.W ? g.W - 1 : w);
             const float4 v = *reinterpret_cast<const float4*>(x + (((long)b * g.H + hc) * g.W + wc) * g.C + coff + c);
             pre[p] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            okm |= ok ? 1u << p : 0u;
         }
 #pragma unroll
         for (int p = 0; p < ND; ++p) {
@@ -258,12 +288,14 @@ __global__ void __launch_bounds__(192) conv3x3_grouped_wgrad_kernel(const float*
     };
     int tile = sub;
     if (tile < g.ntiles) fetch(tile);
+    stage_group_coef(cf, in_coef, coff, g.C);
     for (; tile < g.ntiles; tile += g.nb) {
         __syncthreads();
 #pragma unroll
         for (int p = 0; p < NVP; ++p) {
             const int s = tid + p * NT, pix = s / 6, c = (s - pix * 6) * 4;
-            if (pix < T::NPIX) { float* q = patch + pix * PP + c; q[0] = pre[p].x; q[1] = pre[p].y; q[2] = pre[p].z; q[3] = pre[p].w; }
+            const float4 v = in_coef ? bnrelu4(pre[p], cf, c, (okm >> p) & 1u) : pre[p];
+            if (pix < T::NPIX) { float* q = patch + pix * PP + c; q[0] = v.x; q[1] = v.y; q[2] = v.z; q[3] = v.w; }
         }
 #pragma unroll
         for (int p = 0; p < ND; ++p) {
@@ -484,20 +516,30 @@ extern "C" int tf_conv3x3_grouped_fwd_f32(const float* x, const float* w, const 
 
 extern "C" int tf_conv3x3_grouped_colstat_parts(void) { return kMaxBlocks; }
 
-extern "C" int tf_conv3x3_grouped_fwd_colstat_f32(const float* x, const float* w, float* y, int B, int H, int W, int C, float* colstat, int* colstat_nparts,
-                                                  void* stream) {
-    TF_REQUIRE(args_ok(x, w, y, B, H, W, C) && colstat && colstat_nparts, "tf_conv3x3_grouped_fwd_colstat_f32: needs NHWC tensors with C %% 24 == 0, colstat and colstat_nparts");
+static int grouped_fwd_colstat(const char* what, const float* x, const float* in_coef, const float* w, float* y, int B, int H, int W, int C, float* colstat,
+                               int* colstat_nparts, void* stream) {
     const int tw = pick_tw(H, W);
     GcGeom g = make_geom(B, H, W, C, tw);
     const int prec = fwd_prec();
     const float* nob = nullptr;
     *colstat_nparts = g.nb;
     if (prec == 2) {
-        if (tw == 16) TF_LAUNCH((conv3x3_grouped_kernel<16, true, true>), dim3(g.G * g.nb), dim3(256), stream, x, w, nob, y, g, 0, 0, 0, 2, colstat);
-        else TF_LAUNCH((conv3x3_grouped_kernel<32, true, true>), dim3(g.G * g.nb), dim3(256), stream, x, w, nob, y, g, 0, 0, 0, 2, colstat);
-    } else if (tw == 16) TF_LAUNCH((conv3x3_grouped_kernel<16, false, true>), dim3(g.G * g.nb), dim3(256), stream, x, w, nob, y, g, 0, 0, 0, prec, colstat);
-    else TF_LAUNCH((conv3x3_grouped_kernel<32, false, true>), dim3(g.G * g.nb), dim3(256), stream, x, w, nob, y, g, 0, 0, 0, prec, colstat);
-    return launch_status("tf_conv3x3_grouped_fwd_colstat_f32");
+        if (tw == 16) TF_LAUNCH((conv3x3_grouped_kernel<16, true, true>), dim3(g.G * g.nb), dim3(256), stream, x, w, nob, y, g, 0, 0, 0, 2, colstat, in_coef);
+        else TF_LAUNCH((conv3x3_grouped_kernel<32, true, true>), dim3(g.G * g.nb), dim3(256), stream, x, w, nob, y, g, 0, 0, 0, 2, colstat, in_coef);
+    } else if (tw == 16) TF_LAUNCH((conv3x3_grouped_kernel<16, false, true>), dim3(g.G * g.nb), dim3(256), stream, x, w, nob, y, g, 0, 0, 0, prec, colstat, in_coef);
+    else TF_LAUNCH((conv3x3_grouped_kernel<32, false, true>), dim3(g.G * g.nb), dim3(256), stream, x, w, nob, y, g, 0, 0, 0, prec, colstat, in_coef);
+    return launch_status(what);
+}
+extern "C" int tf_conv3x3_grouped_fwd_colstat_f32(const float* x, const float* w, float* y, int B, int H, int W, int C, float* colstat, int* colstat_nparts,
+                                                  void* stream) {
+    TF_REQUIRE(args_ok(x, w, y, B, H, W, C) && colstat && colstat_nparts, "tf_conv3x3_grouped_fwd_colstat_f32: needs NHWC tensors with C %% 24 == 0, colstat and colstat_nparts");
+    return grouped_fwd_colstat("tf_conv3x3_grouped_fwd_colstat_f32", x, nullptr, w, y, B, H, W, C, colstat, colstat_nparts, stream);
+}
+extern "C" int tf_conv3x3_grouped_bnrelu_fwd_colstat_f32(const float* x, const float* in_coef, const float* w, float* y, int B, int H, int W, int C, float* colstat,
+                                                         int* colstat_nparts, void* stream) {
+    TF_REQUIRE(args_ok(x, w, y, B, H, W, C) && in_coef && colstat && colstat_nparts,
+               "tf_conv3x3_grouped_bnrelu_fwd_colstat_f32: needs NHWC tensors with C %% 24 == 0, in_coef = [scale | shift] (2 C), colstat and colstat_nparts");
+    return grouped_fwd_colstat("tf_conv3x3_grouped_bnrelu_fwd_colstat_f32", x, in_coef, w, y, B, H, W, C, colstat, colstat_nparts, stream);
 }
 
 extern "C" int tf_conv3x3_grouped_dgrad_f32(const float* dy, const float* w, float* dx, int B, int H, int W, int C, int accumulate, void* stream) {
@@ -517,8 +559,8 @@ extern "C" int tf_conv3x3_grouped_dgrad_f32(const float* dy, const float* w, flo
 constexpr int kWgradMaxBlocks = 1536;   // partial panels in the workspace (36 KB each)
 extern "C" long tf_conv3x3_grouped_wgrad_ws_floats(void) { return (long)kWgradMaxBlocks * 9216; }
 
-extern "C" int tf_conv3x3_grouped_wgrad_f32(const float* dy, const float* x, float* dw, int B, int H, int W, int C, int accumulate, float* ws, void* stream) {
-    TF_REQUIRE(args_ok(dy, x, dw, B, H, W, C) && ws && aligned16(dy), "tf_conv3x3_grouped_wgrad_f32: needs C %% 24 == 0 and ws of tf_conv3x3_grouped_wgrad_ws_floats() floats");
+static int grouped_wgrad(const char* what, const float* dy, const float* x, const float* in_coef, float* dw, int B, int H, int W, int C, int accumulate, float* ws,
+                         void* stream) {
     const int tw = pick_tw(H, W);
     // three-wave blocks, four to five per CU: ~700 blocks put two waves on every SIMD; a block takes at least two tiles when there are enough
     // (every block ends with a 27 KB partial panel that the reduce kernel reads back)
@@ -527,14 +569,25 @@ extern "C" int tf_conv3x3_grouped_wgrad_f32(const float* dy, const float* x, flo
     if (tpb < 2 && g.ntiles >= 2) tpb = 2;
     g.nb = cdiv(g.ntiles, tpb);
     if ((long)g.G * g.nb > kWgradMaxBlocks) g.nb = kWgradMaxBlocks / g.G;
-    TF_REQUIRE(g.nb >= 1, "tf_conv3x3_grouped_wgrad_f32: %d groups exceed the workspace", g.G);
+    TF_REQUIRE(g.nb >= 1, "%s: %d groups exceed the workspace", what, g.G);
     const int prec = direct_prec();
-#define TF_GW(TW_, P_) TF_LAUNCH((conv3x3_grouped_wgrad_kernel<TW_, P_>), dim3(g.G * g.nb), dim3(192), stream, x, dy, ws, g)
+#define TF_GW(TW_, P_) TF_LAUNCH((conv3x3_grouped_wgrad_kernel<TW_, P_>), dim3(g.G * g.nb), dim3(192), stream, x, dy, ws, g, in_coef)
     if (tw == 16) { if (prec == 2) TF_GW(16, 2); else if (prec == 1 || prec == 3) TF_GW(16, 1); else TF_GW(16, 0); }
     else { if (prec == 2) TF_GW(32, 2); else if (prec == 1 || prec == 3) TF_GW(32, 1); else TF_GW(32, 0); }
 #undef TF_GW
     TF_LAUNCH(conv3x3_grouped_wgrad_reduce_kernel, dim3(36, g.G), dim3(256), stream, (const float*)ws, g.nb, dw, accumulate);
-    return launch_status("tf_conv3x3_grouped_wgrad_f32");
+    return launch_status(what);
+}
+extern "C" int tf_conv3x3_grouped_wgrad_f32(const float* dy, const float* x, float* dw, int B, int H, int W, int C, int accumulate, float* ws, void* stream) {
+    TF_REQUIRE(args_ok(dy, x, dw, B, H, W, C) && ws && aligned16(dy), "tf_conv3x3_grouped_wgrad_f32: needs C %% 24 == 0 and ws of tf_conv3x3_grouped_wgrad_ws_floats() floats");
+    return grouped_wgrad("tf_conv3x3_grouped_wgrad_f32", dy, x, nullptr, dw, B, H, W, C, accumulate, ws, stream);
+}
+// the weight gradient against max(x sc + sh, 0) of a raw producer output x (BatchNorm apply folded into the consumer, see bnrelu4)
+extern "C" int tf_conv3x3_grouped_bnrelu_wgrad_f32(const float* dy, const float* x, const float* in_coef, float* dw, int B, int H, int W, int C, int accumulate,
+                                                   float* ws, void* stream) {
+    TF_REQUIRE(args_ok(dy, x, dw, B, H, W, C) && in_coef && ws && aligned16(dy),
+               "tf_conv3x3_grouped_bnrelu_wgrad_f32: needs C %% 24 == 0, in_coef = [scale | shift] (2 C) and ws of tf_conv3x3_grouped_wgrad_ws_floats() floats");
+    return grouped_wgrad("tf_conv3x3_grouped_bnrelu_wgrad_f32", dy, x, in_coef, dw, B, H, W, C, accumulate, ws, stream);
 }
 
 extern "C" int tf_conv3x3_grouped_s2_dgrad_f32(const float* dy, const float* w, float* dx, int B, int Hi, int Wi, int C, int accumulate, void* stream) {

@@ -399,8 +399,18 @@ class YBlockFn(torch.autograd.Function):
         x2 = x.view(-1, Cin)
         y1, cs1, x2s = _c1x1_fwd(x2, w2d(blk.conv1.conv.weight))      # BN statistics gathered by the GEMM epilogue
         y1 = y1.view(B, H, W, C)
-        z1, st1 = _bn(y1, blk.conv1.bn, relu=True, stat=cs1)
-        y2, cs2 = ops.conv_fwd(z1, blk.conv2.conv.weight, None, blk.stride, 1, blk.groups, colstat=True)
+        bn1 = blk.conv1.bn
+        fuse1 = (cs1 is not None and bn1.training and getattr(bn1, "_sync_group", None) is None and not isinstance(bn1, torch.nn.SyncBatchNorm) and
+                 ops.grouped_bnrelu_ok(y1.shape, C, blk.groups, blk.stride))
+        if fuse1:
+            # BatchNorm apply folded into the consumer: the grouped conv2 (and, backward, its weight gradient and the BatchNorm backward's mask)
+            # recompute z1 = relu(bn1(y1)) from the raw conv1 output - z1 is never written (st1 = (mean, invstd, [scale | shift]))
+            coef1, sm1, si1 = ops.bn_finalize_parts(cs1, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var, bn1.momentum, bn1.eps)
+            st1, z1 = (sm1, si1, coef1), None
+            y2, cs2 = ops.grouped_bnrelu_fwd(y1, coef1, blk.conv2.conv.weight)
+        else:
+            z1, st1 = _bn(y1, bn1, relu=True, stat=cs1)
+            y2, cs2 = ops.conv_fwd(z1, blk.conv2.conv.weight, None, blk.stride, 1, blk.groups, colstat=True)
         _, Ho, Wo, _ = y2.shape
         bn2 = blk.conv2.bn
         fuse2 = (ops.FUSE_BN_SE and cs2 is not None and bn2.training and B <= 16 and B * blk.se.fc1.weight.shape[0] <= 8192 and
@@ -477,9 +487,15 @@ class YBlockFn(torch.autograd.Function):
             dy2, _ = _bn_bwd(dz2, z2, y2, blk.conv2.bn, st2)
         # grouped 3x3
         w2 = blk.conv2.conv.weight
-        ops.wgrad_fork((dy2, z1), lambda: ops.conv_wgrad(dy2, z1, gbuf(w2), blk.stride, 1, blk.groups))
-        dz1 = ops.conv_dgrad(dy2, w2, z1.shape, blk.stride, 1, blk.groups)
-        dy1, _ = _bn_bwd(dz1, z1, y1, blk.conv1.bn, st1)
+        if z1 is None:      # forward ran with bn1's apply folded into conv2
+            bn1 = blk.conv1.bn
+            ops.grouped_bnrelu_wgrad(dy2, y1, st1[2], gbuf(w2))
+            dz1 = ops.conv_dgrad(dy2, w2, y1.shape, blk.stride, 1, blk.groups)
+            dy1 = ops.bn_bwd_remask(dz1, y1, st1[2], bn1.weight, st1[0], st1[1], gbuf(bn1.weight), gbuf(bn1.bias))
+        else:
+            ops.wgrad_fork((dy2, z1), lambda: ops.conv_wgrad(dy2, z1, gbuf(w2), blk.stride, 1, blk.groups))
+            dz1 = ops.conv_dgrad(dy2, w2, z1.shape, blk.stride, 1, blk.groups)
+            dy1, _ = _bn_bwd(dz1, z1, y1, blk.conv1.bn, st1)
         dy1_2 = dy1.view(-1, C)
         w1 = blk.conv1.conv.weight
         if blk.downsample is None:

@@ -862,6 +862,41 @@ def bn_finalize_parts(cs, gamma, beta, rmean, rvar, momentum=0.1, eps=1e-5):
     return coef, sm, si
 
 
+FUSE_BN_CONV = os.environ.get("TF_FUSE_BN_CONV", "1") != "0"
+
+
+def grouped_bnrelu_ok(x_shape, C, groups, stride):
+    """conv1 -> BatchNorm -> ReLU -> grouped conv2 of a RegNetY bottleneck with the BatchNorm apply folded into conv2 (csrc/conv_grouped.cpp): the
+    per-group direct kernels (3x3 / stride 1, group width 24) with output statistics."""
+    rows = x_shape[0] * x_shape[1] * x_shape[2]
+    return FUSE_BN_CONV and _grouped_ok(x_shape, C, C, 3, stride, 1, groups) and want_colstat(rows) and not _direct_ok(x_shape, C, C, 3, stride, 1, groups)
+
+
+def grouped_bnrelu_fwd(x, coef, w):
+    """y = grouped_conv3x3(max(x * scale + shift, 0)) + BatchNorm statistics of y, x = the RAW output of the preceding convolution, coef = [scale | shift]
+    of its BatchNorm (bn_finalize_parts): the normalised activation is never written.  Returns (y, ColStat)."""
+    B, H, W, C = x.shape
+    y = torch.empty_like(x)
+    _e = _census_begin()
+    cs = ColStat(B * H * W, C, x.device, max_parts=L().tf_conv3x3_grouped_colstat_parts())
+    check(L().tf_conv3x3_grouped_bnrelu_fwd_colstat_f32(ptr(_c(x)), ptr(coef), wptr(w), ptr(y), B, H, W, C, ptr(cs.buf), byref(cs.nparts), stream_of(x)),
+          "tf_conv3x3_grouped_bnrelu_fwd_colstat_f32")
+    _census_end(_e, "conv fwd g", (B, H, W, C, C, 3, 1, C // 24), 2.0 * B * H * W * C * 24 * 9)
+    return y, cs
+
+
+def grouped_bnrelu_wgrad(dy, x, coef, dw, accumulate=True):
+    """dW (+)= grouped weight gradient against max(x * scale + shift, 0) (the activation grouped_bnrelu_fwd never stored)."""
+    def run():
+        B, H, W, C = x.shape
+        _e = _census_begin()
+        check(L().tf_conv3x3_grouped_bnrelu_wgrad_f32(ptr(_c(dy)), ptr(_c(x)), ptr(coef), wptr(dw), B, H, W, C, int(accumulate), ptr(_grouped_ws(x.device)),
+                                                      stream_of(dy)), "tf_conv3x3_grouped_bnrelu_wgrad_f32")
+        _census_end(_e, "conv wgrad g", (B, H, W, C, C, 3, 1, C // 24), 2.0 * B * H * W * C * 24 * 9)
+    _wgrad_launch((dy, x, coef), run)
+    return dw
+
+
 def se_squeeze_excite_bn_fwd(y, coef, w1, b1, w2, b2):
     """SE squeeze + excitation on z = relu(y * scale + shift) WITHOUT materialising z: chunk sums of z per sample (one launch), finished inside
     the excitation kernel.  y (B, H, W, C) -> (s (B, C) squeezed means, g1 (B, Cr), gate (B, C) pre-sigmoid)."""
