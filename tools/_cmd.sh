@@ -1,3 +1,9 @@
 cd $GRAFT_REPO_ROOT; O=gpurun_out; mkdir -p $O
-timeout 600 python -m pytest tests/test_kernels_gpu.py tests/test_dataprep.py -q -x -k "hist or prep or corr" 2>&1 | tail -2
-timeout 300 python tools/hbm_bench.py 2>&1 | grep -i "H1\|H2\|pillar" | head
+bl() { python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', d['ms_per_step'], 'ms/step; loss', d['config']['final_loss'])"; }
+B="python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-alt"
+timeout 300 python -m pytest tests/test_kernels_gpu.py -m gpu -q -x -k "grouped" 2>&1 | tail -2
+timeout 600 python -m pytest tests/test_model_gpu.py -m gpu -q -x -k "folded or single_block or decoder_and_head" 2>&1 | tail -2
+for rep in 1 2; do
+ TF_FUSE_BN_CONV=0 timeout 200 $B 2>/dev/null | bl "unfused"
+ timeout 200 $B 2>/dev/null | bl "folded "
+done
