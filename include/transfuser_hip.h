@@ -129,6 +129,10 @@ int tf_se_excite_bwd_parts_f32(const float* parts, int nchunks, const float* gat
                                int C, int Cr, float* dW1, float* db1, float* dW2, float* db2, float* ds, float* scratch, int scratch_is_zero, void* stream);
 int tf_bn_bwd_remask_f32(const float* dz, const float* x, const float* fwd_coef, int rows, int C, const float* gamma, const float* save_mean,
                          const float* save_invstd, float* dx, float* dgamma, float* dbeta, float* ws, void* stream);
+/* tf_se_scale_bwd_x_f32 folded into tf_bn_bwd_remask_f32 (the BatchNorm in front of a timm SEModule, backward): the incoming gradient
+ * dz = dy * sigmoid(gate[b][c]) + dmean[b][c] / HW is recomputed by the reduction and the apply pass instead of being written; x (B, HW, C). */
+int tf_bn_bwd_remask_se_f32(const float* dy, const float* gate, const float* dmean, int B, int HW, int C, const float* x, const float* fcoef, const float* gamma,
+                            const float* save_mean, const float* save_invstd, float* dx, float* dgamma, float* dbeta, float* ws, void* stream);
 
 /* ---- ConvNeXt trunk pieces (timm 0.5.4 convnext_*: the re-labelling branch of ImageCNN / LidarEncoder, transfuser.py:395-416,457-471).
  * tf_dwconv7_fwd_f32: depthwise 7x7 / pad 3 (+ bias) on NHWC, weights (C, 7, 7) = the (C, 1, 7, 7) parameter; flip != 0 mirrors the taps = the

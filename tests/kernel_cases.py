@@ -266,6 +266,11 @@ def check_bn_se_consumer_fusion(dev, B=3, H=6, W=10, C=48, Cr=12):
     dy = ops.bn_bwd_remask(dz, y, coef, gamma, sm, si, dgm, dbt)
     close(dy, grads[0], tol=1e-4, what="fused bn bwd (recomputed mask)")
     close(dgm, grads[1], tol=1e-4, what="fused bn dgamma"); close(dbt, grads[2], tol=1e-4, what="fused bn dbeta")
+    # the SE scale's backward folded into the BatchNorm backward (dz never written)
+    dgm2, dbt2 = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    dy2 = ops.bn_bwd_remask_se(dzs, gate, ds, y, coef, gamma, sm, si, dgm2, dbt2)
+    close(dy2, grads[0], tol=1e-4, what="bn bwd with the SE scale backward folded in")
+    close(dgm2, grads[1], tol=1e-4, what="folded bn dgamma"); close(dbt2, grads[2], tol=1e-4, what="folded bn dbeta")
 
 
 def check_convnext_pieces(dev):

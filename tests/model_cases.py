@@ -451,12 +451,12 @@ def check_full_size_vs_fp32_oracle(backbone, B, H, dev="cuda", loss_tol=1e-3, pe
 
 
 def check_bn_conv_fold(dev, batch_dims, lidar_res=None):
-    """conv1 -> BatchNorm -> ReLU -> grouped conv2 with the BatchNorm apply folded into conv2 / its weight gradient (TF_FUSE_BN_CONV, YBlockFn): the
-    same model run with the switch on and off - losses and every parameter gradient agree to fp32 round-off, the running statistics are
+    """conv1 -> BatchNorm -> ReLU -> grouped conv2 with the BatchNorm apply folded into conv2 / its weight gradient (TF_FUSE_BN_CONV, YBlockFn) and the
+    SE scale's backward folded into the BatchNorm backward in front of it (TF_FUSE_SE_BN_BWD): the same model run with the switches on and off - losses and every parameter gradient agree to fp32 round-off, the running statistics are
     updated identically, and the folded path really ran."""
     from transfuser_amd import ops
-    calls = {"fwd": 0, "wgrad": 0}
-    of, ow = ops.grouped_bnrelu_fwd, ops.grouped_bnrelu_wgrad
+    calls = {"fwd": 0, "wgrad": 0, "se_bn_bwd": 0}
+    of, ow, os_ = ops.grouped_bnrelu_fwd, ops.grouped_bnrelu_wgrad, ops.bn_bwd_remask_se
 
     def cf(*a, **k):
         calls["fwd"] += 1
@@ -465,27 +465,30 @@ def check_bn_conv_fold(dev, batch_dims, lidar_res=None):
     def cw(*a, **k):
         calls["wgrad"] += 1
         return ow(*a, **k)
+    def cs(*a, **k):
+        calls["se_bn_bwd"] += 1
+        return os_(*a, **k)
     cfg = tiny_config(n_layer=1, **({"lidar_res": lidar_res} if lidar_res else {}))
     prod, ref = build_pair(cfg, "regnety_tiny", dev)
     batch = small_batch(*batch_dims)
     state = {k: v.clone() for k, v in prod.state_dict().items()}
     res = {}
-    prev = ops.FUSE_BN_CONV
-    ops.grouped_bnrelu_fwd, ops.grouped_bnrelu_wgrad = cf, cw
+    prev = ops.FUSE_BN_CONV, ops.FUSE_SE_BN_BWD
+    ops.grouped_bnrelu_fwd, ops.grouped_bnrelu_wgrad, ops.bn_bwd_remask_se = cf, cw, cs
     try:
         for on in (True, False):
-            ops.FUSE_BN_CONV = on
+            ops.FUSE_BN_CONV = ops.FUSE_SE_BN_BWD = on
             prod.load_state_dict(state)
             lp, _ = run_pair(prod, ref, cfg, batch, dev)
             res[on] = ({k: float(v) for k, v in lp.items()}, {n: p.grad.clone() for n, p in prod.named_parameters() if p.grad is not None},
                        {n: b.clone() for n, b in prod.named_buffers() if "running" in n})
             if on:
-                assert calls["fwd"] > 0 and calls["fwd"] == calls["wgrad"], calls
+                assert calls["fwd"] > 0 and calls["fwd"] == calls["wgrad"] and calls["se_bn_bwd"] > 0, calls
                 seen = dict(calls)
         assert calls == seen, "the unfused run must not touch the folded kernels"
     finally:
-        ops.FUSE_BN_CONV = prev
-        ops.grouped_bnrelu_fwd, ops.grouped_bnrelu_wgrad = of, ow
+        ops.FUSE_BN_CONV, ops.FUSE_SE_BN_BWD = prev
+        ops.grouped_bnrelu_fwd, ops.grouped_bnrelu_wgrad, ops.bn_bwd_remask_se = of, ow, os_
     for k, v in res[True][0].items():
         assert abs(v - res[False][0][k]) <= 1e-5 * max(1.0, abs(v)), (k, v, res[False][0][k])
     for n, g in res[True][1].items():

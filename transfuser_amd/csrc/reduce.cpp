@@ -135,6 +135,24 @@ template <int V> struct BnBwdRemaskF {  // BnBwdF with the ReLU mask recomputed 
     }
 };
 
+// BnBwdRemaskF with the SE scale's backward folded in: the incoming gradient is dz = dy * sigmoid(gate[b][c]) + dmean[b][c] * inv_hw (tf_se_scale_bwd_x_f32),
+// recomputed here instead of being written by its own pass; rows are sample-major (b = row / HW)
+template <int V> struct SeBnBwdRemaskF {
+    const float* dy; const float* gate; const float* dmean; const float* x; const float* coef; const float* mean; const float* invstd; int C; int HW; float inv_hw;
+    __device__ __forceinline__ void eval(long row, int c, vecf<V>* o) const {
+        const long bc = (row / HW) * C + c;
+        vecf<V> g = ldv<V>(dy + row * C + c), a = ldv<V>(x + row * C + c), m = ldv<V>(mean + c), s = ldv<V>(invstd + c), sc = ldv<V>(coef + c), sh = ldv<V>(coef + C + c);
+        vecf<V> gt = ldv<V>(gate + bc), dm = ldv<V>(dmean + bc);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            float gi = g.v[i] * (1.f / (1.f + expf(-gt.v[i]))) + dm.v[i] * inv_hw;
+            if (!(a.v[i] * sc.v[i] + sh.v[i] > 0.f)) gi = 0.f;
+            o[0].v[i] = gi;
+            o[1].v[i] = gi * ((a.v[i] - m.v[i]) * s.v[i]);
+        }
+    }
+};
+
 // ---- finalize fused into the reduction ("last block finishes"): every block stores its partial (agent scope), drains the stores and takes a ticket of its
 // (segment, column tile); the block that draws the last ticket re-reads ALL the chunk partials of that tile (agent-scope loads: other XCDs wrote
 // them) in a FIXED order - chunk lanes, then the LDS row-lane order - so the result does not depend on which block came last (bitwise run-to-run
@@ -731,6 +749,26 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_remask_kernel(const float* _
         stv<V>(dx + i * V, a);
     }
 }
+// bn_bwd_apply_remask_kernel on dz = dy * sigmoid(gate) + dmean * inv_hw (SeBnBwdRemaskF): dz itself is never written
+template <int V>
+__global__ void __launch_bounds__(256) bn_bwd_apply_remask_se_kernel(const float* __restrict__ dy, const float* __restrict__ gate, const float* __restrict__ dmean,
+                                                                     const float* __restrict__ x, const float* __restrict__ fcoef, const float* __restrict__ coef,
+                                                                     float* __restrict__ dx, long nvec, int C, long vec_per_b, float inv_hw) {
+    const int cv = C / V;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % cv) * V;
+        const long bc = (i / vec_per_b) * C + c;
+        vecf<V> g = ldv<V>(dy + i * V), a = ldv<V>(x + i * V), A = ldv<V>(coef + c), Bc = ldv<V>(coef + C + c), Cc = ldv<V>(coef + 2 * C + c);
+        vecf<V> sc = ldv<V>(fcoef + c), sh = ldv<V>(fcoef + C + c), gt = ldv<V>(gate + bc), dm = ldv<V>(dmean + bc);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            float gi = g.v[k] * (1.f / (1.f + expf(-gt.v[k]))) + dm.v[k] * inv_hw;
+            if (!(a.v[k] * sc.v[k] + sh.v[k] > 0.f)) gi = 0.f;
+            a.v[k] = A.v[k] * gi + Bc.v[k] * a.v[k] + Cc.v[k];
+        }
+        stv<V>(dx + i * V, a);
+    }
+}
 // dx (+)= dy * sigmoid(gate[b][c]) + dmean[b][c] * inv_hw      (either term optional)
 template <int V>
 __global__ void __launch_bounds__(256) se_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ gate, const float* __restrict__ dmean,
@@ -1022,6 +1060,30 @@ extern "C" int tf_bn_bwd_remask_f32(const float* dz, const float* x, const float
     if (v4) TF_LAUNCH(bn_bwd_apply_remask_kernel<4>, dim3(ew_blocks(n / 4)), dim3(256), stream, dz, x, fcoef, (const float*)coef, dx, n / 4, C);
     else TF_LAUNCH(bn_bwd_apply_remask_kernel<1>, dim3(ew_blocks(n)), dim3(256), stream, dz, x, fcoef, (const float*)coef, dx, n, C);
     return launch_status("tf_bn_bwd_remask_f32");
+}
+
+// the same with the SE scale's backward folded in (tf_se_scale_bwd_x_f32 + tf_bn_bwd_remask_f32 in one reduction + one apply pass):
+// dz = dy * sigmoid(gate[b][c]) + dmean[b][c] / HW is recomputed by both passes, never written
+extern "C" int tf_bn_bwd_remask_se_f32(const float* dy, const float* gate, const float* dmean, int B, int HW, int C, const float* x, const float* fcoef,
+                                       const float* gamma, const float* save_mean, const float* save_invstd, float* dx, float* dgamma, float* dbeta, float* ws,
+                                       void* stream) {
+    TF_REQUIRE(dy && gate && dmean && x && fcoef && gamma && save_mean && save_invstd && dx && ws && B > 0 && HW > 0 && C > 0, "tf_bn_bwd_remask_se_f32: bad arguments");
+    const int rows = B * HW;
+    float* coef = ws + kWsFloats / 2;
+    const bool v4 = (C % 4 == 0) && aligned16(dy) && aligned16(x) && aligned16(dx) && aligned16(fcoef) && aligned16(gate) && aligned16(dmean);
+    RedPlan p = plan_reduce(rows, C, 1, 2, v4);
+    const float inv_hw = 1.f / (float)HW;
+    SeBnBwdRemaskF<4> f4{dy, gate, dmean, x, fcoef, save_mean, save_invstd, C, HW, inv_hw};
+    SeBnBwdRemaskF<1> f1{dy, gate, dmean, x, fcoef, save_mean, save_invstd, C, HW, inv_hw};
+    if (!launch_reduce_fin<2>(p, f4, f1, rows, C, 1, ws, stream, BnBwdFin{gamma, save_mean, save_invstd, dgamma, dbeta, coef, C, (float)rows})) {
+        launch_reduce<2>(p, f4, f1, rows, C, 1, ws, stream);
+        TF_LAUNCH(bn_bwd_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), stream, (const float*)ws, gamma, save_mean, save_invstd, dgamma, dbeta, coef, C, p.nchunks,
+                  (float)rows);
+    }
+    const long n = (long)rows * C;
+    if (v4) TF_LAUNCH(bn_bwd_apply_remask_se_kernel<4>, dim3(ew_blocks(n / 4)), dim3(256), stream, dy, gate, dmean, x, fcoef, (const float*)coef, dx, n / 4, C, (long)HW * C / 4, inv_hw);
+    else TF_LAUNCH(bn_bwd_apply_remask_se_kernel<1>, dim3(ew_blocks(n)), dim3(256), stream, dy, gate, dmean, x, fcoef, (const float*)coef, dx, n, C, (long)HW * C, inv_hw);
+    return launch_status("tf_bn_bwd_remask_se_f32");
 }
 
 // out[c] (+)= sum over rows of a[r][c] * b[r][c]  (ConvNeXt layer-scale gradient d gamma = sum dy * branch output, transfuser.py:395 via timm)

@@ -467,9 +467,12 @@ class YBlockFn(torch.autograd.Function):
         if z2 is None:      # forward ran with the BatchNorm apply folded into the consumers (st2 = (mean, invstd, [scale | shift]))
             ds = ops.se_gate_excite_bn_bwd(dz2s, y2, st2[2], gate, s, g1, se.fc1.weight, se.fc2.weight, gbuf(se.fc1.weight), gbuf(se.fc1.bias),
                                            gbuf(se.fc2.weight), gbuf(se.fc2.bias))
-            dz2 = ops.se_scale_bwd_x(dz2s, gate, ds, y2.shape)
             bn2 = blk.conv2.bn
-            dy2 = ops.bn_bwd_remask(dz2, y2, st2[2], bn2.weight, st2[0], st2[1], gbuf(bn2.weight), gbuf(bn2.bias))
+            if ops.FUSE_SE_BN_BWD:      # the SE scale's backward (dz2 = dz2s * sigmoid(gate) + ds / HW) recomputed inside the BatchNorm backward's two passes
+                dy2 = ops.bn_bwd_remask_se(dz2s, gate, ds, y2, st2[2], bn2.weight, st2[0], st2[1], gbuf(bn2.weight), gbuf(bn2.bias))
+            else:
+                dz2 = ops.se_scale_bwd_x(dz2s, gate, ds, y2.shape)
+                dy2 = ops.bn_bwd_remask(dz2, y2, st2[2], bn2.weight, st2[0], st2[1], gbuf(bn2.weight), gbuf(bn2.bias))
         else:
             dgate = ops.se_scale_bwd_gate(dz2s, z2, gate)
             if B <= 16 and B * g1.shape[1] <= 8192:

@@ -953,6 +953,21 @@ def bn_bwd_remask(dz, x, coef, gamma, sm, si, dgamma, dbeta):
     return dx
 
 
+FUSE_SE_BN_BWD = os.environ.get("TF_FUSE_SE_BN_BWD", "1") != "0"
+
+
+def bn_bwd_remask_se(dy, gate, dmean, x, coef, gamma, sm, si, dgamma, dbeta):
+    """se_scale_bwd_x + bn_bwd_remask in one reduction and one apply pass: the BatchNorm's incoming gradient dy * sigmoid(gate) + dmean / HW is
+    recomputed by both passes instead of being written.  x (B, H, W, C) raw convolution output, gate / dmean (B, C)."""
+    B, H, W, C = x.shape
+    dx = torch.empty_like(x)
+    _h = _hbm_begin()
+    check(L().tf_bn_bwd_remask_se_f32(ptr(_c(dy)), ptr(gate), ptr(_c(dmean)), B, H * W, C, ptr(_c(x)), ptr(coef), ptr(gamma), ptr(sm), ptr(si), ptr(dx), ptr(dgamma),
+                                      ptr(dbeta), ptr(workspace(x.device)), stream_of(x)), "tf_bn_bwd_remask_se_f32")
+    _hbm_end(_h, "batchnorm backward (reduce + finalize + apply)", 4 * x.numel() * 5)
+    return dx
+
+
 def bn_bwd(dz, z, x, gamma, sm, si, dgamma, dbeta, want_dres=False):
     C = x.shape[-1]
     rows = x.numel() // C
