@@ -483,6 +483,10 @@ def main():
                        "global_batch": B * world, "parallelism": "dp%d" % world, "final_loss": round(loss, 4),
                        "grad_allreduce": ("RCCL, %d backward segments, %s bucket all-reduce overlapped on a side stream" % (eng.n_pieces(), args.grad_dtype)) if world > 1 else "none (1 rank)"},
         }
+        try:      # which sources the measured library was compiled from (sha256 prefix over csrc/ + include/, csrc/api.cpp:tf_build_id)
+            res["config"]["build_id"] = ops.L().tf_build_id().decode()
+        except Exception:
+            res["config"]["build_id"] = None
         if check is not None:
             res["check"] = check
         if gf:
