@@ -394,3 +394,15 @@ def test_fp16_dynamic_loss_scale_skips_overflowed_steps():
 
 def test_bottleneck_bn_apply_folded_into_conv2_matches_the_unfused_block():
     mc.check_bn_conv_fold("cpu", (2, 64, 128, 64, 40))
+
+
+def test_se_blocks_wider_than_the_fused_excitation_kernels_take_the_generic_path(monkeypatch):
+    """csrc/se.cpp keeps a sample's squeezed vector in LDS (C <= ops.SE_FUSED_MAX_C); wider bottlenecks (regnety_320: 3712 channels) must fall back to the
+    generic colsum + linear path instead of failing - forced here by lowering the limit under the tiny trunk's widths."""
+    from transfuser_amd import ops
+    monkeypatch.setattr(ops, "SE_FUSED_MAX_C", 8)
+    cfg = mc.tiny_config(n_layer=1)
+    prod, ref = mc.build_pair(cfg, "regnety_tiny", "cpu")
+    batch = mc.small_batch(2, 32, 64, 64, 40)
+    lp, lr = mc.run_pair(prod, ref, cfg, batch, "cpu")
+    mc.compare(prod, ref, lp, lr)

@@ -413,7 +413,7 @@ class YBlockFn(torch.autograd.Function):
             y2, cs2 = ops.conv_fwd(z1, blk.conv2.conv.weight, None, blk.stride, 1, blk.groups, colstat=True)
         _, Ho, Wo, _ = y2.shape
         bn2 = blk.conv2.bn
-        fuse2 = (ops.FUSE_BN_SE and cs2 is not None and bn2.training and B <= 16 and B * blk.se.fc1.weight.shape[0] <= 8192 and
+        fuse2 = (ops.FUSE_BN_SE and cs2 is not None and bn2.training and B <= 16 and C <= ops.SE_FUSED_MAX_C and B * blk.se.fc1.weight.shape[0] <= 8192 and
                  getattr(bn2, "_sync_group", None) is None and not isinstance(bn2, torch.nn.SyncBatchNorm))
         if fuse2:
             # BatchNorm apply folded into its consumers: z2 = relu(bn2(y2)) is recomputed by the SE squeeze, the SE scale and (backward) the gate
@@ -425,7 +425,7 @@ class YBlockFn(torch.autograd.Function):
         else:
             z2, st2 = _bn(y2, bn2, relu=True, stat=cs2)
             s = ops.colsum(z2, B, Ho * Wo, C, 1.0 / (Ho * Wo))
-            if B <= 16:
+            if B <= 16 and C <= ops.SE_FUSED_MAX_C:
                 g1, gate = ops.se_excite_fwd(s, blk.se.fc1.weight, blk.se.fc1.bias, blk.se.fc2.weight, blk.se.fc2.bias)
             else:
                 g1 = ops.linear_fwd(s, w2d(blk.se.fc1.weight), blk.se.fc1.bias, relu=True)
@@ -475,7 +475,7 @@ class YBlockFn(torch.autograd.Function):
                 dy2 = ops.bn_bwd_remask(dz2, y2, st2[2], bn2.weight, st2[0], st2[1], gbuf(bn2.weight), gbuf(bn2.bias))
         else:
             dgate = ops.se_scale_bwd_gate(dz2s, z2, gate)
-            if B <= 16 and B * g1.shape[1] <= 8192:
+            if B <= 16 and C <= ops.SE_FUSED_MAX_C and B * g1.shape[1] <= 8192:
                 ds = ops.se_excite_bwd(dgate, s, g1, se.fc1.weight, se.fc2.weight, gbuf(se.fc1.weight), gbuf(se.fc1.bias), gbuf(se.fc2.weight),
                                        gbuf(se.fc2.bias))
             else:

@@ -849,6 +849,7 @@ def bn_fwd_parts(x, cs, gamma, beta, rmean, rvar, res=None, relu=False, momentum
 
 # ---- BatchNorm apply folded into the consumers (YBlockFn's conv2 -> BN -> ReLU -> SE segment; csrc/reduce.cpp, csrc/se.cpp)
 FUSE_BN_SE = os.environ.get("TF_FUSE_BN_SE", "1") != "0"
+SE_FUSED_MAX_C = 3072      # csrc/se.cpp: the fused excitation kernels hold a sample's squeezed vector in LDS (wider blocks take the generic linear path)
 
 
 def bn_finalize_parts(cs, gamma, beta, rmean, rvar, momentum=0.1, eps=1e-5):
