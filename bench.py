@@ -493,6 +493,7 @@ def main():
             step_tf = value / world * gf / 1e3
             roof["step_achieved_tflops"] = round(step_tf, 2)
             roof["step_frac"] = round(step_tf / peak, 4)
+            roof["step_frac_of_fp16_mfma_peak"] = round(step_tf / PEAK_BF16_MFMA_TF, 4)      # north_star quotes the 16-bit MFMA roofline (2.5 PFLOP/s dense) for every line
         res["roofline"] = roof
         res["roofline_hbm"] = roof_hbm
         if world == 1 and args.dtype == "f32" and not args.no_alt:
