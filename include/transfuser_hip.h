@@ -203,6 +203,14 @@ int tf_conv3x3_grouped_bnrelu_fwd_colstat_f32(const float* x, const float* in_co
                                               int* colstat_nparts, void* stream);
 int tf_conv3x3_grouped_bnrelu_wgrad_f32(const float* dy, const float* x, const float* in_coef, float* dw, int B, int H, int W, int C, int accumulate, float* ws,
                                         void* stream);
+/* The STRIDE-2 grouped 3x3 convolution of the first block of every RegNetY stage (timm Bottleneck conv2 with stride 2) as direct kernels: forward
+ * (Hi x Wi input -> ((Hi - 1) / 2 + 1) x ((Wi - 1) / 2 + 1) output; colstat / colstat_nparts optional: BatchNorm statistics of y as above; in_coef
+ * optional: the producer's BatchNorm apply folded in) and weight gradient (ws as tf_conv3x3_grouped_wgrad_f32).  The input gradient is
+ * tf_conv3x3_grouped_s2_dgrad_f32. */
+int tf_conv3x3_grouped_s2_fwd_f32(const float* x, const float* in_coef, const float* w, float* y, int B, int Hi, int Wi, int C, float* colstat, int* colstat_nparts,
+                                  void* stream);
+int tf_conv3x3_grouped_s2_wgrad_f32(const float* dy, const float* x, const float* in_coef, float* dw, int B, int Hi, int Wi, int C, int accumulate, float* ws,
+                                    void* stream);
 
 /* Stem convolutions reading the NCHW model inputs directly (Cin <= 4, no bias, NHWC output):
  * channels [0,C0) from s0, [C0,C0+C1) from s1 - the torch.cat of model.py:741-742 is never

@@ -1309,6 +1309,68 @@ def check_conv_grouped(dev, B, H, W, C):
     close(dwz, cl(gwz) + 0.25, what="grouped wgrad against the recomputed activation (accumulate)")
 
 
+GROUPED_S2_CASES = [(2, 16, 44, 72), (1, 9, 17, 48), (2, 8, 16, 24), (1, 33, 31, 48), (1, 12, 70, 72)]
+
+
+def check_conv_grouped_s2(dev, B, H, W, C):
+    """The direct STRIDE-2 grouped 3x3 kernels (first block of a RegNetY stage; opt-in TF_GROUPED_S2): forward with output statistics, forward with
+    the producer's BatchNorm apply folded in, weight gradient (plain / folded, accumulate) vs F.conv2d(stride 2); even and odd input extents, both
+    tile shapes, 1..3 groups; and the ops dispatch with the switch on."""
+    groups = C // 24
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    x = R(B, C, H, W, dev="cpu").requires_grad_(True)
+    w = (R(C, 24, 3, 3, dev="cpu") * 0.1).requires_grad_(True)
+    y = F.conv2d(x, w, None, 2, 1, 1, groups)
+    assert y.shape[2:] == (Ho, Wo)
+    dy = R(*y.shape, seed=1, dev="cpu")
+    (gw,) = torch.autograd.grad(y, [w], dy)
+    xh, wh = x.detach().permute(0, 2, 3, 1).contiguous().to(dev), cl(w.detach()).to(dev)
+    dyh = dy.permute(0, 2, 3, 1).contiguous().to(dev)
+    L = ops.L()
+    from ctypes import byref
+    from transfuser_amd.ops import ptr, wptr, stream_of, check, c_p
+    yh = torch.empty(B, Ho, Wo, C, device=dev)
+    cs = ops.ColStat(B * Ho * Wo, C, xh.device, max_parts=L.tf_conv3x3_grouped_colstat_parts())
+    check(L.tf_conv3x3_grouped_s2_fwd_f32(ptr(xh), c_p(0), wptr(wh), ptr(yh), B, H, W, C, ptr(cs.buf), byref(cs.nparts), stream_of(xh)), "grouped s2 fwd")
+    close(yh.permute(0, 3, 1, 2), y, what="grouped s2 fwd")
+    one, zero = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+    _, sm, si = ops.bn_finalize_parts(cs, one, zero, zero.clone(), one.clone())
+    y64 = y.detach().double().permute(0, 2, 3, 1).reshape(-1, C)
+    close(sm.cpu(), y64.mean(0).float(), what="grouped s2 fwd: output mean", tol=1e-4)
+    close(si.cpu(), (1.0 / torch.sqrt(y64.var(0, unbiased=False) + 1e-5)).float(), what="grouped s2 fwd: output invstd", tol=1e-4)
+    yh2 = torch.empty_like(yh)
+    check(L.tf_conv3x3_grouped_s2_fwd_f32(ptr(xh), c_p(0), wptr(wh), ptr(yh2), B, H, W, C, c_p(0), c_p(0), stream_of(xh)), "grouped s2 fwd (no statistics)")
+    assert torch.equal(yh2, yh)
+    ws = ops._grouped_ws(xh.device)
+    dw = torch.full_like(wh, 0.25)
+    check(L.tf_conv3x3_grouped_s2_wgrad_f32(ptr(dyh), ptr(xh), c_p(0), wptr(dw), B, H, W, C, 1, ptr(ws), stream_of(xh)), "grouped s2 wgrad")
+    close(dw, cl(gw) + 0.25, what="grouped s2 wgrad (accumulate)")
+    # the producer's BatchNorm apply folded in: conv(relu(x sc + sh)) from the raw x, zero padding stays zero
+    sc, sh = R(C, seed=7, dev="cpu") * 0.5 + 1.0, R(C, seed=8, dev="cpu") * 0.7 + 0.3
+    z = torch.relu(x.detach() * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)).requires_grad_(True)
+    yz = F.conv2d(z, w, None, 2, 1, 1, groups)
+    (gwz,) = torch.autograd.grad(yz, [w], dy)
+    coef = torch.cat([sc, sh]).to(dev)
+    check(L.tf_conv3x3_grouped_s2_fwd_f32(ptr(xh), ptr(coef), wptr(wh), ptr(yh2), B, H, W, C, c_p(0), c_p(0), stream_of(xh)), "grouped s2 bnrelu fwd")
+    close(yh2.permute(0, 3, 1, 2), yz, what="grouped s2 fwd with the BatchNorm apply of its input folded in")
+    dwz = torch.zeros_like(wh)
+    check(L.tf_conv3x3_grouped_s2_wgrad_f32(ptr(dyh), ptr(xh), ptr(coef), wptr(dwz), B, H, W, C, 0, ptr(ws), stream_of(xh)), "grouped s2 bnrelu wgrad")
+    close(dwz, cl(gwz), what="grouped s2 wgrad against the recomputed activation")
+    # dispatch through the public ops with the switch on
+    if groups > 1 and Ho >= 4 and Wo >= 8:
+        prev = ops._GROUPED_S2
+        ops._GROUPED_S2 = True
+        try:
+            yo, cso = ops.conv_fwd(xh, wh, None, 2, 1, groups, colstat=True)
+            close(yo.permute(0, 3, 1, 2), y, what="ops.conv_fwd -> grouped s2")
+            assert cso is not None and cso.nparts.value > 0
+            dw2 = torch.zeros_like(wh)
+            ops.conv_wgrad(dyh, xh, dw2, 2, 1, groups)
+            close(dw2, cl(gw), what="ops.conv_wgrad -> grouped s2")
+        finally:
+            ops._GROUPED_S2 = prev
+
+
 def check_bf16_direct(dev):
     """The LDS-tiled direct convolutions (decoder tails, RegNetY grouped 3x3) in bf16-MFMA mode: == fp32 convolution of bf16-rounded operands."""
     old = ops._DIRECT_MIN_PIXELS

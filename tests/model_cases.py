@@ -496,3 +496,40 @@ def check_bn_conv_fold(dev, batch_dims, lidar_res=None):
         assert (g - g0).abs().max().item() <= 2e-4 * max(g0.abs().max().item(), 1e-3), n
     for n, b in res[True][2].items():
         assert torch.allclose(b, res[False][2][n], rtol=1e-6, atol=1e-7), n
+
+
+def check_grouped_s2_switch(dev, batch_dims, lidar_res=None):
+    """The opt-in direct stride-2 grouped kernels (TF_GROUPED_S2; forward with statistics + folded BatchNorm apply, weight gradient) inside the model:
+    the same model with the switch on and off - the stride-2 bottlenecks then run on the direct kernels resp. the im2col engine."""
+    from transfuser_amd import ops
+    n = {"s2": 0}
+    of = ops.grouped_bnrelu_fwd
+
+    def cf(x, coef, w, stride=1):
+        n["s2"] += int(stride == 2)
+        return of(x, coef, w, stride)
+    cfg = tiny_config(n_layer=1, **({"lidar_res": lidar_res} if lidar_res else {}))
+    prod, ref = build_pair(cfg, "regnety_tiny", dev)
+    batch = small_batch(*batch_dims)
+    state = {k: v.clone() for k, v in prod.state_dict().items()}
+    res = {}
+    prev = ops._GROUPED_S2
+    ops.grouped_bnrelu_fwd = cf
+    try:
+        for on in (True, False):
+            ops._GROUPED_S2 = on
+            prod.load_state_dict(state)
+            lp, _ = run_pair(prod, ref, cfg, batch, dev)
+            res[on] = ({k: float(v) for k, v in lp.items()}, {nm: p.grad.clone() for nm, p in prod.named_parameters() if p.grad is not None})
+            if on:
+                assert n["s2"] > 0, "no stride-2 bottleneck took the direct kernels (maps too small?)"
+                seen = n["s2"]
+        assert n["s2"] == seen
+    finally:
+        ops._GROUPED_S2 = prev
+        ops.grouped_bnrelu_fwd = of
+    for k, v in res[True][0].items():
+        assert abs(v - res[False][0][k]) <= 1e-4 * max(1.0, abs(v)), (k, v, res[False][0][k])
+    for nm, g in res[True][1].items():
+        g0 = res[False][1][nm]
+        assert (g - g0).abs().max().item() <= 1e-3 * max(g0.abs().max().item(), 1e-3), nm

@@ -152,6 +152,11 @@ def test_grouped_conv_direct(case):
     kc.check_conv_grouped("cpu", *case)
 
 
+@pytest.mark.parametrize("case", kc.GROUPED_S2_CASES, ids=str)
+def test_conv_grouped_stride2_direct_kernels(case):
+    kc.check_conv_grouped_s2("cpu", *case)
+
+
 @pytest.mark.parametrize("cfg", kc.TWO_PASS_CASES, ids=str)
 def test_two_pass_splitk(cfg):
     kc.check_two_pass_splitk("cpu", *cfg)

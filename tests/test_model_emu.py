@@ -406,3 +406,7 @@ def test_se_blocks_wider_than_the_fused_excitation_kernels_take_the_generic_path
     batch = mc.small_batch(2, 32, 64, 64, 40)
     lp, lr = mc.run_pair(prod, ref, cfg, batch, "cpu")
     mc.compare(prod, ref, lp, lr)
+
+
+def test_direct_stride2_grouped_kernels_match_the_engine_path_inside_the_model():
+    mc.check_grouped_s2_switch("cpu", (2, 64, 128, 64, 40))

@@ -31,6 +31,10 @@ def test_bottleneck_bn_apply_folded_into_conv2_matches_the_unfused_block():
     mc.check_bn_conv_fold("cuda", (2, 160, 352, 128, 40), lidar_res=128)
 
 
+def test_direct_stride2_grouped_kernels_match_the_engine_path_inside_the_model():
+    mc.check_grouped_s2_switch("cuda", (2, 160, 352, 128, 40), lidar_res=128)
+
+
 def test_tiny_latentTF_losses_and_grads():
     """BASELINE config 5 backbone (latentTF.py:118-217): positional grid replaces the LiDAR histogram."""
     cfg = mc.tiny_config(n_layer=2, lidar_res=128)

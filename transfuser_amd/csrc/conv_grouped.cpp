@@ -462,6 +462,259 @@ __global__ void __launch_bounds__(256, 2) conv3x3_grouped_s2_dgrad_kernel(const 
     }
 }
 
+// ---- the STRIDE-2 grouped 3x3 convolution (first block of every RegNetY stage) as direct kernels: forward (+ output statistics, + the producer's
+// BatchNorm apply folded in like bnrelu4) and weight gradient.  Tiles run over the OUTPUT grid (128 output pixels), the staged input patch is
+// (2 TH + 1) x (2 TW + 1) pixels (56 KB; with the weight panel 87 KB of LDS: one block per CU, the next patch travels in registers meanwhile);
+// output pixel (i, j), tap (kh, kw) reads patch pixel (2 i + kh, 2 j + kw).  Through the implicit-GEMM engine these 16 launches per step ran at
+// 6-34 TFLOP/s (profiles/r04_census_fp32_final.txt).  OPT-IN (ops: TF_GROUPED_S2=1) until measured on the MI355X.
+template <int TW> struct Tile2 {
+    static constexpr int RW = 32 / TW, TH = 4 * RW;
+    static constexpr int PH = 2 * TH + 1, PW = 2 * TW + 1, NPIX = PH * PW;
+};
+
+template <int TW, bool STAT>
+__global__ void __launch_bounds__(256, 1) conv3x3_grouped_s2_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, GcGeom g, int Ho,
+                                                                        int Wo, int prec, float* __restrict__ stat, const float* __restrict__ in_coef) {
+    typedef Tile2<TW> T;
+    constexpr int NV = (T::NPIX * 6 + 255) / 256;
+    __shared__ float patch[T::NPIX * PP];
+    __shared__ float wl[9 * CG][WP];
+    __shared__ float cf[2 * CG];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int grp = blockIdx.x / g.nb, sub = blockIdx.x - grp * g.nb, coff = grp * CG;
+    GroupWeightRegs wreg;
+    issue_group_weights(wreg, w + (long)grp * CG * 9 * CG);
+    float4 pre[NV];
+    unsigned okm = 0;
+    auto fetch = [&](int t) {      // g.H / g.W = the INPUT extent, tiles over the output grid
+        const int b = t / (g.tiles_h * g.tiles_w), r = t - b * (g.tiles_h * g.tiles_w);
+        const int h0 = (r / g.tiles_w) * T::TH, w0 = (r % g.tiles_w) * TW;
+        okm = 0;
+#pragma unroll
+        for (int p = 0; p < NV; ++p) {
+            const int s = tid + p * 256, pix = s / 6, c = (s - pix * 6) * 4;
+            const int ph = pix / T::PW, pw = pix - ph * T::PW, h = 2 * h0 - 1 + ph, ww = 2 * w0 - 1 + pw;
+            const bool ok = pix < T::NPIX && (unsigned)h < (unsigned)g.H && (unsigned)ww < (unsigned)g.W;
+            const int hc = h < 0 ? 0 : (h >= g.H ? g.H - 1 : h), wc = ww < 0 ? 0 : (ww >= g.W ? g.W - 1 : ww);
+            const float4 v = *reinterpret_cast<const float4*>(x + (((long)b * g.H + hc) * g.W + wc) * g.C + coff + c);
+            pre[p] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            okm |= ok ? 1u << p : 0u;
+        }
+    };
+    int tile = sub;
+    if (tile < g.ntiles) fetch(tile);
+    stage_group_coef(cf, in_coef, coff, g.C);
+    scatter_group_weights(wl, wreg, 0);
+    const int prow = wave * T::RW + l31 / TW, pcol = l31 % TW;
+    float st_n = 0.f, st_mean = 0.f, st_m2 = 0.f;
+    for (; tile < g.ntiles; tile += g.nb) {
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < NV; ++p) {
+            const int s = tid + p * 256, pix = s / 6, c = (s - pix * 6) * 4;
+            const float4 v = in_coef ? bnrelu4(pre[p], cf, c, (okm >> p) & 1u) : pre[p];
+            if (pix < T::NPIX) { float* q = patch + pix * PP + c; q[0] = v.x; q[1] = v.y; q[2] = v.z; q[3] = v.w; }
+        }
+        __syncthreads();
+        if (tile + g.nb < g.ntiles) fetch(tile + g.nb);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        if (prec == 1 || prec == 3) {
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int kh = tap / 3, kw = tap - kh * 3;
+                const float* pa = patch + ((2 * prow + kh) * T::PW + 2 * pcol + kw) * PP;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    float a[8], b[8];
+                    const bool live = (q == 0) || (hi == 0);
+                    const int k0 = 16 * q + 8 * hi;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        a[j] = live ? pa[k0 + j] : 0.f;
+                        b[j] = live ? wl[tap * CG + k0 + j][l31] : 0.f;
+                    }
+                    mfma_32x32x16_lp(a, b, acc, prec);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int kh = tap / 3, kw = tap - kh * 3;
+                const float* pa = patch + ((2 * prow + kh) * T::PW + 2 * pcol + kw) * PP + hi;
+                const float* pb = &wl[tap * CG + hi][l31];
+#pragma unroll
+                for (int kk = 0; kk < CG / 2; ++kk) mfma_32x32x2(pa[2 * kk], pb[2 * kk * WP], acc);
+            }
+        }
+        const int b = tile / (g.tiles_h * g.tiles_w), r = tile - b * (g.tiles_h * g.tiles_w);
+        const int h0 = (r / g.tiles_w) * T::TH, w0 = (r % g.tiles_w) * TW;
+        if (l31 < CG) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int i = (e & 3) + 8 * (e >> 2) + 4 * hi;
+                const int hh = h0 + wave * T::RW + i / TW, ww = w0 + i % TW;
+                if (hh < Ho && ww < Wo) y[(((long)b * Ho + hh) * Wo + ww) * g.C + coff + l31] = acc[e];
+            }
+        }
+        if constexpr (STAT) {       // as conv3x3_grouped_kernel: a running Welford triple per (wave, channel), merged per block at the end
+            float s = 0.f, cnt = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int i = (e & 3) + 8 * (e >> 2) + 4 * hi;
+                const bool ok = (h0 + wave * T::RW + i / TW) < Ho && (w0 + i % TW) < Wo;
+                s += ok ? acc[e] : 0.f;
+                cnt += ok ? 1.f : 0.f;
+            }
+            s += shfl_xor(s, 32);
+            cnt += shfl_xor(cnt, 32);
+            if (cnt > 0.f) {
+                const float m_t = s / cnt;
+                float q = 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int i = (e & 3) + 8 * (e >> 2) + 4 * hi;
+                    const bool ok = (h0 + wave * T::RW + i / TW) < Ho && (w0 + i % TW) < Wo;
+                    const float d = acc[e] - m_t;
+                    q += ok ? d * d : 0.f;
+                }
+                q += shfl_xor(q, 32);
+                const float n_new = st_n + cnt, delta = m_t - st_mean;
+                st_mean += delta * (cnt / n_new);
+                st_m2 += q + delta * delta * (st_n * cnt / n_new);
+                st_n = n_new;
+            }
+        }
+    }
+    if constexpr (STAT) {
+        __syncthreads();
+        float* red = patch;                                              // [wave][3][32]
+        if (hi == 0) { red[(wave * 3 + 0) * 32 + l31] = st_n; red[(wave * 3 + 1) * 32 + l31] = st_mean; red[(wave * 3 + 2) * 32 + l31] = st_m2; }
+        __syncthreads();
+        if (tid < CG) {
+            float n = 0.f, mean = 0.f, m2 = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < 4; ++wv) {
+                const float nb_ = red[(wv * 3 + 0) * 32 + tid], mb = red[(wv * 3 + 1) * 32 + tid], qb = red[(wv * 3 + 2) * 32 + tid];
+                if (nb_ > 0.f) {
+                    const float n_new = n + nb_, delta = mb - mean;
+                    mean += delta * (nb_ / n_new);
+                    m2 += qb + delta * delta * (n * nb_ / n_new);
+                    n = n_new;
+                }
+            }
+            float* o = stat + (long)sub * 3 * g.C + coff + tid;
+            o[0] = n; o[g.C] = mean; o[2 * (long)g.C] = m2;
+        }
+    }
+}
+
+// weight gradient of the stride-2 convolution: conv3x3_grouped_wgrad_kernel with the input patch of Tile2 (wave kh owns the taps (kh, 0..2), K = the
+// tile's 128 OUTPUT pixels, B operand = patch pixel (2 i + kh, 2 j + kw)); partial panels reduced by conv3x3_grouped_wgrad_reduce_kernel
+template <int TW, int PREC>
+__global__ void __launch_bounds__(192) conv3x3_grouped_s2_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part, GcGeom g,
+                                                                       int Ho, int Wo, const float* __restrict__ in_coef) {
+    typedef Tile2<TW> T;
+    constexpr int NT = 192;
+    constexpr int NVP = (T::NPIX * 6 + NT - 1) / NT, ND = (128 * 6 + NT - 1) / NT;
+    __shared__ float lds[T::NPIX * PP + 128 * PP + 8];
+    __shared__ float cf[2 * CG];
+    float* patch = lds;
+    float* dyt = lds + T::NPIX * PP;               // [output pixel][co]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int grp = blockIdx.x / g.nb, sub = blockIdx.x - grp * g.nb, coff = grp * CG;
+    f32x16 acc[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float4 pre[NVP], dpre[ND];
+    unsigned okm = 0;
+    auto fetch = [&](int t) {
+        const int b = t / (g.tiles_h * g.tiles_w), r = t - b * (g.tiles_h * g.tiles_w);
+        const int h0 = (r / g.tiles_w) * T::TH, w0 = (r % g.tiles_w) * TW;
+        okm = 0;
+#pragma unroll
+        for (int p = 0; p < NVP; ++p) {
+            const int s = tid + p * NT, pix = s / 6, c = (s - pix * 6) * 4;
+            const int ph = pix / T::PW, pw = pix - ph * T::PW, h = 2 * h0 - 1 + ph, w = 2 * w0 - 1 + pw;
+            const bool ok = pix < T::NPIX && (unsigned)h < (unsigned)g.H && (unsigned)w < (unsigned)g.W;
+            const int hc = h < 0 ? 0 : (h >= g.H ? g.H - 1 : h), wc = w < 0 ? 0 : (w >= g.W ? g.W - 1 : w);
+            const float4 v = *reinterpret_cast<const float4*>(x + (((long)b * g.H + hc) * g.W + wc) * g.C + coff + c);
+            pre[p] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            okm |= ok ? 1u << p : 0u;
+        }
+#pragma unroll
+        for (int p = 0; p < ND; ++p) {
+            const int s = tid + p * NT, pix = s / 6, c = (s - pix * 6) * 4;
+            const int h = h0 + pix / TW, w = w0 + pix % TW;
+            const bool ok = pix < 128 && h < Ho && w < Wo;
+            const int hc = h >= Ho ? Ho - 1 : h, wc = w >= Wo ? Wo - 1 : w;
+            const float4 v = *reinterpret_cast<const float4*>(dy + (((long)b * Ho + hc) * Wo + wc) * g.C + coff + c);
+            dpre[p] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    int tile = sub;
+    if (tile < g.ntiles) fetch(tile);
+    stage_group_coef(cf, in_coef, coff, g.C);
+    for (; tile < g.ntiles; tile += g.nb) {
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < NVP; ++p) {
+            const int s = tid + p * NT, pix = s / 6, c = (s - pix * 6) * 4;
+            const float4 v = in_coef ? bnrelu4(pre[p], cf, c, (okm >> p) & 1u) : pre[p];
+            if (pix < T::NPIX) { float* q = patch + pix * PP + c; q[0] = v.x; q[1] = v.y; q[2] = v.z; q[3] = v.w; }
+        }
+#pragma unroll
+        for (int p = 0; p < ND; ++p) {
+            const int s = tid + p * NT, pix = s / 6, c = (s - pix * 6) * 4;
+            if (pix < 128) { float* q = dyt + pix * PP + c; q[0] = dpre[p].x; q[1] = dpre[p].y; q[2] = dpre[p].z; q[3] = dpre[p].w; }
+        }
+        __syncthreads();
+        if (tile + g.nb < g.ntiles) fetch(tile + g.nb);
+        if constexpr (PREC != 0) {
+#pragma unroll 2
+            for (int q = 0; q < 8; ++q) {
+                float a[8], b[3][8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int pi = 16 * q + 8 * hi + j, prow = pi / TW, pcol = pi % TW;
+                    a[j] = dyt[pi * PP + l31];
+                    const float* pb = patch + ((2 * prow + wave) * T::PW + 2 * pcol) * PP + l31;
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) b[kw][j] = pb[kw * PP];
+                }
+                if constexpr (PREC == 2) {
+                    const Bf16x3 fa = split_bf16x3(a);
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) mfma_x3_presplit(fa, split_bf16x3(b[kw]), acc[kw]);
+                } else {
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) mfma_32x32x16_lp(a, b[kw], acc[kw], g.f16 ? 3 : 1);
+                }
+            }
+        } else {
+#pragma unroll 4
+            for (int kk = 0; kk < 64; ++kk) {
+                const int pi = 2 * kk + hi, prow = pi / TW, pcol = pi % TW;
+                const float a = dyt[pi * PP + l31];
+                const float* pb = patch + ((2 * prow + wave) * T::PW + 2 * pcol) * PP + l31;
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) mfma_32x32x2(a, pb[kw * PP], acc[kw]);
+            }
+        }
+    }
+    float* pp = part + ((long)blockIdx.x * 9 + 3 * wave) * 1024 + l31;
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int e = 0; e < 12; ++e) {
+            const int i = (e & 3) + 8 * (e >> 2) + 4 * hi;
+            pp[kw * 1024 + i * 32] = acc[kw][e];
+        }
+}
+
 constexpr int kMaxBlocks = 768;     // persistent grid: up to 3 blocks per CU
 
 // compute precision of these kernels; TF_X3_DIRECT=0 keeps them on the exact fp32 MFMA in f32x3 mode (A/B switch)
@@ -588,6 +841,44 @@ extern "C" int tf_conv3x3_grouped_bnrelu_wgrad_f32(const float* dy, const float*
     TF_REQUIRE(args_ok(dy, x, dw, B, H, W, C) && in_coef && ws && aligned16(dy),
                "tf_conv3x3_grouped_bnrelu_wgrad_f32: needs C %% 24 == 0, in_coef = [scale | shift] (2 C) and ws of tf_conv3x3_grouped_wgrad_ws_floats() floats");
     return grouped_wgrad("tf_conv3x3_grouped_bnrelu_wgrad_f32", dy, x, in_coef, dw, B, H, W, C, accumulate, ws, stream);
+}
+
+// stride-2 forward (+ output statistics when colstat != NULL, + the producer's BatchNorm apply when in_coef != NULL) and weight gradient; Hi x Wi = input extent
+extern "C" int tf_conv3x3_grouped_s2_fwd_f32(const float* x, const float* in_coef, const float* w, float* y, int B, int Hi, int Wi, int C, float* colstat,
+                                             int* colstat_nparts, void* stream) {
+    TF_REQUIRE(args_ok(x, w, y, B, Hi, Wi, C) && (!colstat || colstat_nparts), "tf_conv3x3_grouped_s2_fwd_f32: needs NHWC tensors with C %% 24 == 0 (group width 24), 16-byte aligned");
+    const int Ho = (Hi - 1) / 2 + 1, Wo = (Wi - 1) / 2 + 1;
+    const int tw = pick_tw(Ho, Wo);
+    GcGeom g = make_geom(B, Ho, Wo, C, tw, 256);            // one 87 KB block per CU
+    g.H = Hi; g.W = Wi;
+    int prec = tf::gemm_precision();
+    if (prec == 2) prec = 0;                                 // f32x3: the exact fp32 MFMA (at least as accurate)
+    if (colstat_nparts) *colstat_nparts = colstat ? g.nb : 0;
+#define TF_S2F(TW_, ST_) TF_LAUNCH((conv3x3_grouped_s2_fwd_kernel<TW_, ST_>), dim3(g.G * g.nb), dim3(256), stream, x, w, y, g, Ho, Wo, prec, colstat, in_coef)
+    if (tw == 16) { if (colstat) TF_S2F(16, true); else TF_S2F(16, false); }
+    else { if (colstat) TF_S2F(32, true); else TF_S2F(32, false); }
+#undef TF_S2F
+    return launch_status("tf_conv3x3_grouped_s2_fwd_f32");
+}
+extern "C" int tf_conv3x3_grouped_s2_wgrad_f32(const float* dy, const float* x, const float* in_coef, float* dw, int B, int Hi, int Wi, int C, int accumulate, float* ws,
+                                               void* stream) {
+    TF_REQUIRE(args_ok(dy, x, dw, B, Hi, Wi, C) && ws && aligned16(dy), "tf_conv3x3_grouped_s2_wgrad_f32: needs C %% 24 == 0 and ws of tf_conv3x3_grouped_wgrad_ws_floats() floats");
+    const int Ho = (Hi - 1) / 2 + 1, Wo = (Wi - 1) / 2 + 1;
+    const int tw = pick_tw(Ho, Wo);
+    GcGeom g = make_geom(B, Ho, Wo, C, tw, 512);            // 69 KB of LDS: two blocks per CU
+    int tpb = cdiv(g.ntiles, g.nb);
+    if (tpb < 2 && g.ntiles >= 2) tpb = 2;
+    g.nb = cdiv(g.ntiles, tpb);
+    if ((long)g.G * g.nb > kWgradMaxBlocks) g.nb = kWgradMaxBlocks / g.G;
+    TF_REQUIRE(g.nb >= 1, "tf_conv3x3_grouped_s2_wgrad_f32: %d groups exceed the workspace", g.G);
+    g.H = Hi; g.W = Wi;
+    const int prec = direct_prec();
+#define TF_GW2(TW_, P_) TF_LAUNCH((conv3x3_grouped_s2_wgrad_kernel<TW_, P_>), dim3(g.G * g.nb), dim3(192), stream, x, dy, ws, g, Ho, Wo, in_coef)
+    if (tw == 16) { if (prec == 2) TF_GW2(16, 2); else if (prec == 1 || prec == 3) TF_GW2(16, 1); else TF_GW2(16, 0); }
+    else { if (prec == 2) TF_GW2(32, 2); else if (prec == 1 || prec == 3) TF_GW2(32, 1); else TF_GW2(32, 0); }
+#undef TF_GW2
+    TF_LAUNCH(conv3x3_grouped_wgrad_reduce_kernel, dim3(36, g.G), dim3(256), stream, (const float*)ws, g.nb, dw, accumulate);
+    return launch_status("tf_conv3x3_grouped_s2_wgrad_f32");
 }
 
 extern "C" int tf_conv3x3_grouped_s2_dgrad_f32(const float* dy, const float* w, float* dx, int B, int Hi, int Wi, int C, int accumulate, void* stream) {

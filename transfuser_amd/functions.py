@@ -407,7 +407,7 @@ class YBlockFn(torch.autograd.Function):
             # recompute z1 = relu(bn1(y1)) from the raw conv1 output - z1 is never written (st1 = (mean, invstd, [scale | shift]))
             coef1, sm1, si1 = ops.bn_finalize_parts(cs1, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var, bn1.momentum, bn1.eps)
             st1, z1 = (sm1, si1, coef1), None
-            y2, cs2 = ops.grouped_bnrelu_fwd(y1, coef1, blk.conv2.conv.weight)
+            y2, cs2 = ops.grouped_bnrelu_fwd(y1, coef1, blk.conv2.conv.weight, blk.stride)
         else:
             z1, st1 = _bn(y1, bn1, relu=True, stat=cs1)
             y2, cs2 = ops.conv_fwd(z1, blk.conv2.conv.weight, None, blk.stride, 1, blk.groups, colstat=True)
@@ -492,7 +492,7 @@ class YBlockFn(torch.autograd.Function):
         w2 = blk.conv2.conv.weight
         if z1 is None:      # forward ran with bn1's apply folded into conv2
             bn1 = blk.conv1.bn
-            ops.grouped_bnrelu_wgrad(dy2, y1, st1[2], gbuf(w2))
+            ops.grouped_bnrelu_wgrad(dy2, y1, st1[2], gbuf(w2), stride=blk.stride)
             dz1 = ops.conv_dgrad(dy2, w2, y1.shape, blk.stride, 1, blk.groups)
             dy1 = ops.bn_bwd_remask(dz1, y1, st1[2], bn1.weight, st1[0], st1[1], gbuf(bn1.weight), gbuf(bn1.bias))
         else:

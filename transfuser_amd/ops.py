@@ -474,6 +474,15 @@ def _grouped_ok(shape, cout, cin, ks, stride, pad, groups):
     return _GROUPED and ks == 3 and stride == 1 and pad == 1 and groups > 1 and cin == cout == groups * 24 and shape[1] >= 4 and shape[2] >= 8
 
 
+_GROUPED_S2 = bool(int(__import__("os").environ.get("TF_GROUPED_S2", "0")))      # opt-in: the direct stride-2 forward / weight-gradient kernels are not yet measured on the MI355X
+
+
+def _grouped_s2_ok(shape, cout, cin, ks, stride, pad, groups):
+    """The stride-2 grouped 3x3 convolution of the first block of a RegNetY stage -> csrc/conv_grouped.cpp:conv3x3_grouped_s2_{fwd,wgrad}_kernel."""
+    return (_GROUPED_S2 and ks == 3 and stride == 2 and pad == 1 and groups > 1 and cin == cout == groups * 24 and (shape[1] - 1) // 2 + 1 >= 4 and
+            (shape[2] - 1) // 2 + 1 >= 8)
+
+
 def _grouped_ws(device):
     key = (str(device), torch.cuda.current_stream(device).cuda_stream if getattr(device, "type", str(device)[:4]) == "cuda" else 0)
     ws = _gws_cache.get(key)
@@ -496,7 +505,12 @@ def conv_fwd(x, w, bias=None, stride=1, pad=None, groups=1, relu=False, colstat=
         rows = g.B * g.Ho * g.Wo
         cs = None
         if want_colstat(rows) and bias is None and not relu and not _direct_ok(x.shape, g.Cout, g.Cin, ks, stride, pad, groups):
-            if _grouped_ok(x.shape, g.Cout, g.Cin, ks, stride, pad, groups):
+            if _grouped_s2_ok(x.shape, g.Cout, g.Cin, ks, stride, pad, groups):
+                cs = ColStat(rows, g.Cout, x.device, max_parts=L().tf_conv3x3_grouped_colstat_parts())
+                check(L().tf_conv3x3_grouped_s2_fwd_f32(ptr(_c(x)), c_p(0), wptr(w), ptr(y), g.B, g.Hi, g.Wi, g.Cin, ptr(cs.buf), byref(cs.nparts), stream_of(x)),
+                      "tf_conv3x3_grouped_s2_fwd_f32")
+                _census_end(_e, "conv fwd g2", _gshape(g), _gflops(g))
+            elif _grouped_ok(x.shape, g.Cout, g.Cin, ks, stride, pad, groups):
                 cs = ColStat(rows, g.Cout, x.device, max_parts=L().tf_conv3x3_grouped_colstat_parts())
                 check(L().tf_conv3x3_grouped_fwd_colstat_f32(ptr(_c(x)), wptr(w), ptr(y), g.B, g.Hi, g.Wi, g.Cin, ptr(cs.buf), byref(cs.nparts), stream_of(x)),
                       "tf_conv3x3_grouped_fwd_colstat_f32")
@@ -520,6 +534,10 @@ def conv_fwd(x, w, bias=None, stride=1, pad=None, groups=1, relu=False, colstat=
     if _grouped_ok(x.shape, g.Cout, g.Cin, ks, stride, pad, groups):
         check(L().tf_conv3x3_grouped_fwd_f32(ptr(_c(x)), wptr(w), ptr(bias), ptr(y), g.B, g.Hi, g.Wi, g.Cin, int(relu), stream_of(x)), "tf_conv3x3_grouped_fwd_f32")
         _census_end(_e, "conv fwd g", _gshape(g), _gflops(g))
+        return y
+    if bias is None and not relu and _grouped_s2_ok(x.shape, g.Cout, g.Cin, ks, stride, pad, groups):
+        check(L().tf_conv3x3_grouped_s2_fwd_f32(ptr(_c(x)), c_p(0), wptr(w), ptr(y), g.B, g.Hi, g.Wi, g.Cin, c_p(0), c_p(0), stream_of(x)), "tf_conv3x3_grouped_s2_fwd_f32")
+        _census_end(_e, "conv fwd g2", _gshape(g), _gflops(g))
         return y
     check(L().tf_conv2d_fwd_f32(byref(g), ptr(_c(x)), wptr(w), ptr(bias), ptr(y), int(relu), stream_of(x)), "tf_conv2d_fwd_f32")
     _census_end(_e, "conv fwd", _gshape(g), _gflops(g))
@@ -609,6 +627,11 @@ def _conv_wgrad(dy, x, dw, stride, pad, groups, accumulate, dbias):
         check(L().tf_conv3x3_grouped_wgrad_f32(ptr(_c(dy)), ptr(_c(x)), wptr(dw), g.B, g.Hi, g.Wi, g.Cin, int(accumulate), ptr(_grouped_ws(x.device)),
                                                stream_of(dy)), "tf_conv3x3_grouped_wgrad_f32")
         _census_end(_e, "conv wgrad g", _gshape(g), _gflops(g))
+        return dw
+    if _grouped_s2_ok(x.shape, g.Cout, g.Cin, ks, stride, pad, groups):
+        check(L().tf_conv3x3_grouped_s2_wgrad_f32(ptr(_c(dy)), ptr(_c(x)), c_p(0), wptr(dw), g.B, g.Hi, g.Wi, g.Cin, int(accumulate), ptr(_grouped_ws(x.device)),
+                                                  stream_of(dy)), "tf_conv3x3_grouped_s2_wgrad_f32")
+        _census_end(_e, "conv wgrad g2", _gshape(g), _gflops(g))
         return dw
     check(L().tf_conv2d_wgrad_f32(byref(g), ptr(_c(dy)), ptr(_c(x)), wptr(dw), int(accumulate), stream_of(dy)), "tf_conv2d_wgrad_f32")
     _census_end(_e, "conv wgrad", _gshape(g), _gflops(g))
@@ -869,14 +892,25 @@ FUSE_BN_CONV = os.environ.get("TF_FUSE_BN_CONV", "1") != "0"
 def grouped_bnrelu_ok(x_shape, C, groups, stride):
     """conv1 -> BatchNorm -> ReLU -> grouped conv2 of a RegNetY bottleneck with the BatchNorm apply folded into conv2 (csrc/conv_grouped.cpp): the
     per-group direct kernels (3x3 / stride 1, group width 24) with output statistics."""
+    if stride == 2:      # the direct stride-2 kernels (opt-in) take the same folded coefficients
+        rows = x_shape[0] * ((x_shape[1] - 1) // 2 + 1) * ((x_shape[2] - 1) // 2 + 1)
+        return FUSE_BN_CONV and _grouped_s2_ok(x_shape, C, C, 3, 2, 1, groups) and want_colstat(rows)
     rows = x_shape[0] * x_shape[1] * x_shape[2]
     return FUSE_BN_CONV and _grouped_ok(x_shape, C, C, 3, stride, 1, groups) and want_colstat(rows) and not _direct_ok(x_shape, C, C, 3, stride, 1, groups)
 
 
-def grouped_bnrelu_fwd(x, coef, w):
+def grouped_bnrelu_fwd(x, coef, w, stride=1):
     """y = grouped_conv3x3(max(x * scale + shift, 0)) + BatchNorm statistics of y, x = the RAW output of the preceding convolution, coef = [scale | shift]
     of its BatchNorm (bn_finalize_parts): the normalised activation is never written.  Returns (y, ColStat)."""
     B, H, W, C = x.shape
+    if stride == 2:
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        y = torch.empty(B, Ho, Wo, C, dtype=torch.float32, device=x.device)
+        _e = _census_begin()
+        cs = ColStat(B * Ho * Wo, C, x.device, max_parts=L().tf_conv3x3_grouped_colstat_parts())
+        check(L().tf_conv3x3_grouped_s2_fwd_f32(ptr(_c(x)), ptr(coef), wptr(w), ptr(y), B, H, W, C, ptr(cs.buf), byref(cs.nparts), stream_of(x)), "tf_conv3x3_grouped_s2_fwd_f32")
+        _census_end(_e, "conv fwd g2", (B, H, W, C, C, 3, 2, C // 24), 2.0 * B * Ho * Wo * C * 24 * 9)
+        return y, cs
     y = torch.empty_like(x)
     _e = _census_begin()
     cs = ColStat(B * H * W, C, x.device, max_parts=L().tf_conv3x3_grouped_colstat_parts())
@@ -886,11 +920,16 @@ def grouped_bnrelu_fwd(x, coef, w):
     return y, cs
 
 
-def grouped_bnrelu_wgrad(dy, x, coef, dw, accumulate=True):
+def grouped_bnrelu_wgrad(dy, x, coef, dw, accumulate=True, stride=1):
     """dW (+)= grouped weight gradient against max(x * scale + shift, 0) (the activation grouped_bnrelu_fwd never stored)."""
     def run():
         B, H, W, C = x.shape
         _e = _census_begin()
+        if stride == 2:
+            check(L().tf_conv3x3_grouped_s2_wgrad_f32(ptr(_c(dy)), ptr(_c(x)), ptr(coef), wptr(dw), B, H, W, C, int(accumulate), ptr(_grouped_ws(x.device)), stream_of(dy)),
+                  "tf_conv3x3_grouped_s2_wgrad_f32")
+            _census_end(_e, "conv wgrad g2", (B, H, W, C, C, 3, 2, C // 24), 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * C * 24 * 9)
+            return
         check(L().tf_conv3x3_grouped_bnrelu_wgrad_f32(ptr(_c(dy)), ptr(_c(x)), ptr(coef), wptr(dw), B, H, W, C, int(accumulate), ptr(_grouped_ws(x.device)),
                                                       stream_of(dy)), "tf_conv3x3_grouped_bnrelu_wgrad_f32")
         _census_end(_e, "conv wgrad g", (B, H, W, C, C, 3, 1, C // 24), 2.0 * B * H * W * C * 24 * 9)
