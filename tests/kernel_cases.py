@@ -1399,6 +1399,42 @@ def check_bf16_direct(dev):
         ops._DIRECT_MIN_PIXELS = old
 
 
+def check_grouped_s2_modes(dev):
+    """The opt-in direct stride-2 grouped kernels in the other compute modes: bf16 / fp16 == fp32 convolution of the operands rounded to that type
+    (forward and weight gradient), f32x3 within the fp32 bound of a float64 reference."""
+    prev = ops._GROUPED_S2
+    ops._GROUPED_S2 = True
+    try:
+        for (B, H, W, C) in ((2, 16, 44, 72), (1, 9, 17, 48)):
+            groups = C // 24
+            x = R(B, C, H, W, dev="cpu")
+            w = R(C, 24, 3, 3, dev="cpu") * 0.1
+            y0 = F.conv2d(x, w, None, 2, 1, 1, groups)
+            dy = R(*y0.shape, seed=1, dev="cpu")
+            xh, wh = x.permute(0, 2, 3, 1).contiguous().to(dev), cl(w).to(dev)
+            dyh = dy.permute(0, 2, 3, 1).contiguous().to(dev)
+            for mode, rd in (("bf16", _bf), ("fp16", lambda t: t.half().float())):
+                ops.set_precision(mode)
+                wr = rd(w).requires_grad_(True)
+                yr = F.conv2d(rd(x), wr, None, 2, 1, 1, groups)
+                (gw,) = torch.autograd.grad(yr, [wr], rd(dy))
+                close(ops.conv_fwd(xh, wh, None, 2, 1, groups).permute(0, 3, 1, 2), yr, tol=1e-4, what=mode + " grouped s2 fwd")
+                dw = torch.zeros_like(wh)
+                ops.conv_wgrad(dyh, xh, dw, 2, 1, groups)
+                close(dw, cl(gw), tol=1e-4, what=mode + " grouped s2 wgrad")
+            ops.set_precision("f32x3")
+            wd = w.double().requires_grad_(True)
+            yd = F.conv2d(x.double(), wd, None, 2, 1, 1, groups)
+            (gwd,) = torch.autograd.grad(yd, [wd], dy.double())
+            assert _err64(ops.conv_fwd(xh, wh, None, 2, 1, groups).permute(0, 3, 1, 2), yd.detach()) <= 4e-6
+            dw = torch.zeros_like(wh)
+            ops.conv_wgrad(dyh, xh, dw, 2, 1, groups)
+            assert _err64(dw, gwd.detach()) <= 4e-6
+    finally:
+        ops.set_precision("fp32")
+        ops._GROUPED_S2 = prev
+
+
 def check_f32x3_direct(dev):
     """The LDS-tiled direct convolutions (decoder tails, RegNetY grouped 3x3) in f32x3 mode: float64 reference, the fp32-accuracy bound of
     check_f32x3_mode (<= 2e-6 relative, <= 3x the exact-fp32-MFMA kernels' own error + 2e-7)."""

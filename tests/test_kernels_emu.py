@@ -235,3 +235,8 @@ def test_centernet_decode(case):
 @pytest.mark.parametrize("case", [(130, 72, 96), (10, 64, 32), (200, 50, 150)], ids=str)
 def test_gemm_relu_mask_epilogue(case):
     kc.check_gemm_mask("cpu", *case)
+
+
+def test_conv_grouped_stride2_direct_kernels_compute_modes():
+    kc.check_grouped_s2_modes("cpu")
+
