@@ -165,6 +165,10 @@ int tf_gemm16_nt_colstat_f32(const void* a16, const void* b16, float* c, int m, 
 /* dst[b][2 i][2 j][:] += src[b][i][j][:] (NHWC, C % 4 == 0): the scatter half of a 1x1 / stride-2 convolution's input gradient (the RegNet
  * downsample branches, timm Bottleneck via transfuser.py:380,442); the other half is a plain GEMM over the B Ho Wo output pixels. */
 int tf_add_strided2_f32(const float* src, float* dst, int B, int Ho, int Wo, int C, int Hi, int Wi, void* stream);
+/* im2col matrix of a dense 3x3 / stride 1 / pad 1 convolution on NHWC: cols (B H W, 9 C), K ordered like the (Cout, kh, kw, Cin) weight, zero padding.
+ * For the few-row, deep-K convolutions at the head of the Seg / Depth decoders (transfuser.py:221-225, 256-260: 512 -> 128 at 8 x 22): the product then
+ * runs as tf_gemm_f32 with its deterministic split-K (opt-in, ops: TF_IM2COL_GEMM=1). */
+int tf_im2col3x3_f32(const float* x, float* cols, int B, int H, int W, int C, void* stream);
 
 /* The same layer shape with a THIN output: Cin == 32, 1 <= Cout <= 7 (the decoders' last convolution, transfuser.py:237,272: 32 -> 7 / 32 -> 1
  * at 256 x 704).  The 9 taps are folded into the GEMM's N (forward) / K (dgrad) / M (wgrad) dimension, so the launches are bandwidth-bound like

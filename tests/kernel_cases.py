@@ -1309,6 +1309,31 @@ def check_conv_grouped(dev, B, H, W, C):
     close(dwz, cl(gwz) + 0.25, what="grouped wgrad against the recomputed activation (accumulate)")
 
 
+def check_im2col_gemm_conv(dev):
+    """The opt-in im2col + plain-GEMM form of the few-row / deep-K dense 3x3 convolutions (decoder heads; TF_IM2COL_GEMM): the matrix itself (zero
+    padding, (kh, kw, c) column order) and the convolution with bias + ReLU through ops.conv_fwd vs F.conv2d."""
+    from transfuser_amd.ops import ptr, stream_of, check
+    for (B, H, W, Cin, Cout) in ((2, 8, 22, 128, 32), (1, 5, 7, 116, 24)):
+        x = R(B, Cin, H, W, dev="cpu")
+        w = R(Cout, Cin, 3, 3, seed=1, dev="cpu") * 0.05
+        b = R(Cout, seed=2, dev="cpu")
+        xh = x.permute(0, 2, 3, 1).contiguous().to(dev)
+        cols = torch.empty(B * H * W, 9 * Cin, device=dev)
+        check(ops.L().tf_im2col3x3_f32(ptr(xh), ptr(cols), B, H, W, Cin, stream_of(xh)), "tf_im2col3x3_f32")
+        ref = F.unfold(x, 3, padding=1).view(B, Cin, 9, H * W).permute(0, 3, 2, 1).reshape(B * H * W, 9 * Cin)      # unfold orders (c, tap): -> (tap, c)
+        assert torch.equal(cols.cpu(), ref), "im2col matrix"
+        prev = ops._IM2COL_GEMM
+        ops._IM2COL_GEMM = True
+        try:
+            g = ops.conv_geom(xh.shape, Cout, 3, 1, 1, 1)
+            assert ops._im2col_gemm_ok(g, 3, 1, 1, 1)
+            y = ops.conv_fwd(xh, cl(w).to(dev), b.to(dev), 1, 1, 1, relu=True)
+        finally:
+            ops._IM2COL_GEMM = prev
+        close(y.permute(0, 3, 1, 2), torch.relu(F.conv2d(x, w, b, 1, 1)), what="im2col + GEMM convolution (bias, ReLU)")
+        close(y, ops.conv_fwd(xh, cl(w).to(dev), b.to(dev), 1, 1, 1, relu=True), what="== the implicit-GEMM path", tol=1e-5)
+
+
 GROUPED_S2_CASES = [(2, 16, 44, 72), (1, 9, 17, 48), (2, 8, 16, 24), (1, 33, 31, 48), (1, 12, 70, 72)]
 
 

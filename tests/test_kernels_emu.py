@@ -240,3 +240,7 @@ def test_gemm_relu_mask_epilogue(case):
 def test_conv_grouped_stride2_direct_kernels_compute_modes():
     kc.check_grouped_s2_modes("cpu")
 
+
+def test_im2col_gemm_form_of_few_row_deep_k_convolutions():
+    kc.check_im2col_gemm_conv("cpu")
+

@@ -74,6 +74,28 @@ __global__ void __launch_bounds__(256) add_strided2_kernel(const float* __restri
     }
 }
 
+// cols[(b, h, w)][(kh * 3 + kw) * C + c] = x[b][h + kh - 1][w + kw - 1][c] (zero outside): the im2col matrix of a dense 3x3 / stride 1 / pad 1 convolution,
+// K ordered like the (Cout, kh, kw, Cin) weight.  For the FEW-ROW, DEEP-K convolutions at the head of the decoders (SegDecoder / DepthDecoder
+// deconv1, transfuser.py:221-225: 512 -> 128 at 8 x 22, 1760 output rows = 56 tiles with K = 4608: 178 us at 11.6 TFLOP/s through the implicit
+// GEMM, one k-chain per tile) the product then runs as a PLAIN GEMM whose deterministic two-pass split-K fills the chip.
+__global__ void __launch_bounds__(256) im2col3x3_kernel(const float* __restrict__ x, float* __restrict__ cols, int B, int H, int W, int C) {
+    const int c4n = C >> 2;
+    const long total = (long)B * H * W * 9 * c4n;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c4 = (int)(i % c4n);
+        long r = i / c4n;
+        const int tap = (int)(r % 9); r /= 9;
+        const int w = (int)(r % W); r /= W;
+        const int h = (int)(r % H);
+        const int b = (int)(r / H);
+        const int hh = h + tap / 3 - 1, ww = w + tap % 3 - 1;
+        const bool ok = (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W;
+        const int hc = hh < 0 ? 0 : (hh >= H ? H - 1 : hh), wc = ww < 0 ? 0 : (ww >= W ? W - 1 : ww);
+        const float4 v = *reinterpret_cast<const float4*>(x + (((long)b * H + hc) * W + wc) * C + 4 * c4);
+        *reinterpret_cast<float4*>(cols + i * 4) = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
 }  // namespace
 
 extern "C" int tf_cast16_f32(const float* x, int rows, int cols, int ldx, void* y16, int ldy, void* y16t, int ldyt, int dtype, void* stream) {
@@ -84,6 +106,15 @@ extern "C" int tf_cast16_f32(const float* x, int rows, int cols, int ldx, void* 
     TF_LAUNCH(cast16_kernel, dim3(cdiv(cols, TS), cdiv(rows, TS)), dim3(256), stream, x, rows, cols, (long)ldx, (uint16_t*)y16, (long)ldy, (uint16_t*)y16t, (long)ldyt,
               dtype == 2 ? 1 : 0, vec);
     return launch_status("tf_cast16_f32");
+}
+
+extern "C" int tf_im2col3x3_f32(const float* x, float* cols, int B, int H, int W, int C, void* stream) {
+    TF_REQUIRE(x && cols && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && aligned16(x) && aligned16(cols), "tf_im2col3x3_f32: needs C %% 4 == 0 and 16-byte aligned tensors");
+    const long total = (long)B * H * W * 9 * (C / 4);
+    long nb = (total + 255) / 256;
+    if (nb > 8192) nb = 8192;
+    TF_LAUNCH(im2col3x3_kernel, dim3((int)nb), dim3(256), stream, x, cols, B, H, W, C);
+    return launch_status("tf_im2col3x3_f32");
 }
 
 extern "C" int tf_add_strided2_f32(const float* src, float* dst, int B, int Ho, int Wo, int C, int Hi, int Wi, void* stream) {

@@ -483,6 +483,17 @@ def _grouped_s2_ok(shape, cout, cin, ks, stride, pad, groups):
             (shape[2] - 1) // 2 + 1 >= 8)
 
 
+_IM2COL_GEMM = bool(int(__import__("os").environ.get("TF_IM2COL_GEMM", "0")))    # opt-in (written at the end of round 4, not yet measured on the MI355X)
+
+
+def _im2col_gemm_ok(g, ks, stride, pad, groups):
+    """Dense 3x3 / s1 / p1 convolution with FEW output rows and a DEEP contraction (the first layer of the Seg / Depth decoders, 512 -> 128 at 8 x 22:
+    56 output tiles, K = 4608): materialise the im2col matrix (tf_im2col3x3_f32) and run a plain GEMM, whose split-K plans fill the chip - through
+    the implicit GEMM each tile is one 144-step k-chain (178 us at 11.6 TFLOP/s, profiles/r04_census_fp32_final.txt)."""
+    return (_IM2COL_GEMM and ks == 3 and stride == 1 and pad == 1 and groups == 1 and g.Cin % 4 == 0 and 9 * g.Cin >= 1024 and g.B * g.Ho * g.Wo <= 4096 and
+            g.Cout <= 256)
+
+
 def _grouped_ws(device):
     key = (str(device), torch.cuda.current_stream(device).cuda_stream if getattr(device, "type", str(device)[:4]) == "cuda" else 0)
     ws = _gws_cache.get(key)
@@ -534,6 +545,13 @@ def conv_fwd(x, w, bias=None, stride=1, pad=None, groups=1, relu=False, colstat=
     if _grouped_ok(x.shape, g.Cout, g.Cin, ks, stride, pad, groups):
         check(L().tf_conv3x3_grouped_fwd_f32(ptr(_c(x)), wptr(w), ptr(bias), ptr(y), g.B, g.Hi, g.Wi, g.Cin, int(relu), stream_of(x)), "tf_conv3x3_grouped_fwd_f32")
         _census_end(_e, "conv fwd g", _gshape(g), _gflops(g))
+        return y
+    if _im2col_gemm_ok(g, ks, stride, pad, groups):
+        M = g.B * g.Ho * g.Wo
+        cols = torch.empty(M, 9 * g.Cin, dtype=torch.float32, device=x.device)
+        check(L().tf_im2col3x3_f32(ptr(_c(x)), ptr(cols), g.B, g.Hi, g.Wi, g.Cin, stream_of(x)), "tf_im2col3x3_f32")
+        assert w.permute(0, 2, 3, 1).is_contiguous(), "conv weights must be channels_last"
+        linear_fwd(cols, w.permute(0, 2, 3, 1).reshape(g.Cout, 9 * g.Cin), bias, relu=relu, out=y.view(M, g.Cout))      # its split-K plans fill the chip
         return y
     if bias is None and not relu and _grouped_s2_ok(x.shape, g.Cout, g.Cin, ks, stride, pad, groups):
         check(L().tf_conv3x3_grouped_s2_fwd_f32(ptr(_c(x)), c_p(0), wptr(w), ptr(y), g.B, g.Hi, g.Wi, g.Cin, c_p(0), c_p(0), stream_of(x)), "tf_conv3x3_grouped_s2_fwd_f32")
