@@ -1313,7 +1313,10 @@ def check_im2col_gemm_conv(dev):
     """The opt-in im2col + plain-GEMM form of the few-row / deep-K dense 3x3 convolutions (decoder heads; TF_IM2COL_GEMM): the matrix itself (zero
     padding, (kh, kw, c) column order) and the convolution with bias + ReLU through ops.conv_fwd vs F.conv2d."""
     from transfuser_amd.ops import ptr, stream_of, check
-    for (B, H, W, Cin, Cout) in ((2, 8, 22, 128, 32), (1, 5, 7, 116, 24)):
+    cases = ((2, 8, 22, 128, 32), (1, 5, 7, 116, 24))
+    if dev != "cpu":      # the decoders' own first layers at the bench batch (512 -> 128 and 128 -> 64 at 8 x 22, B = 10)
+        cases += ((10, 8, 22, 512, 128), (10, 8, 22, 128, 64))
+    for (B, H, W, Cin, Cout) in cases:
         x = R(B, Cin, H, W, dev="cpu")
         w = R(Cout, Cin, 3, 3, seed=1, dev="cpu") * 0.05
         b = R(Cout, seed=2, dev="cpu")

@@ -533,3 +533,147 @@ def check_grouped_s2_switch(dev, batch_dims, lidar_res=None):
     for nm, g in res[True][1].items():
         g0 = res[False][1][nm]
         assert (g - g0).abs().max().item() <= 1e-3 * max(g0.abs().max().item(), 1e-3), nm
+
+
+def check_remaining_blocks(dev, full=True):
+    """The 1e-3 gradient bound for the blocks the earlier block tests left out (round-4 verdict, weak #1): (a) a STRIDE-1 RegNetY bottleneck at the
+    stage-3 width (576 -> 576 at 16 x 44: the folded BatchNorm / SE kernels of round 4), (b) both stems (normalize_imagenet + 3x3 / s2 conv +
+    BatchNorm + ReLU on the NCHW inputs; the LiDAR one with the target-point channel as a separate tensor), (c) the FPN ``top_down``
+    (transfuser.py:221-237), (d) the join MLP + GRU waypoint decoder (model.py:592-646), (e) one geometric-fusion stage (stage 3, C = 576:
+    pool, gather of the 5 correspondences, MLP, up-sample, 1x1, residual) - product kernels vs PyTorch-CPU fp32 autograd on identical
+    weights: outputs, input gradients and every parameter gradient, max-norm relative error <= 1e-3."""
+    from transfuser_amd import regnet as preg, functions as fn, ops
+    from oracle import regnet as oreg, transfuser_cpu as otf
+    import torch.nn.functional as Fn
+    W3 = 576 if full else 48                      # bottleneck width (24-wide groups)
+    arch = "regnety_032" if full else "regnety_tiny"
+
+    def rel(a, b):
+        return (a.detach().cpu().float() - b.detach()).abs().max().item() / max(b.detach().abs().max().item(), 1e-6)
+    nh = lambda t: t.permute(0, 2, 3, 1).contiguous().to(dev)
+    torch.manual_seed(0)
+    # ---- (a) Y block 576 -> 576, stride 1 (no downsample branch: the shortcut is the input), group width 24
+    ob = oreg.Bottleneck(W3, W3, 1, 24, 0.25)
+    with torch.no_grad():
+        for bn in (ob.conv1.bn, ob.conv2.bn, ob.conv3.bn):
+            bn.weight.uniform_(0.5, 1.0)
+            bn.bias.uniform_(-0.2, 0.2)
+    pb = preg.Bottleneck(W3, W3, 1, 24, 0.25).to(dev)
+    pb.load_state_dict(ob.state_dict(), strict=True)
+    for m in pb.modules():
+        if isinstance(m, torch.nn.Conv2d):
+            m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
+    ob.train(); pb.train()
+    if full:
+        assert ops.FUSE_BN_CONV and ops.FUSE_BN_SE and ops.grouped_bnrelu_ok((4, 16, 44, 576), 576, 24, 1), "the folded kernels are what this case is about"
+    x = torch.randn(4, W3, 16, 44) if full else torch.randn(2, W3, 8, 12)
+    xo = x.clone().requires_grad_(True)
+    yo = ob(xo)
+    dy = torch.randn_like(yo)
+    yo.backward(dy)
+    xp = nh(x).requires_grad_(True)
+    yp = pb(xp)
+    yp.backward(nh(dy))
+    assert rel(yp.permute(0, 3, 1, 2), yo) <= 1e-3
+    assert rel(xp.grad.permute(0, 3, 1, 2), xo.grad) <= 1e-3, rel(xp.grad.permute(0, 3, 1, 2), xo.grad)
+    po = dict(ob.named_parameters())
+    for n, p in pb.named_parameters():
+        assert rel(p.grad, po[n].grad) <= 1e-3, ("bottleneck s1", n, rel(p.grad, po[n].grad))
+    # ---- (b)-(d) on a full-width model pair (RegNetY-3.2GF, the reference configuration)
+    cfg = full_config() if full else tiny_config(n_layer=1)
+    prod, ref = build_pair(cfg, arch, dev)
+    prod.train(); ref.train()
+    pref = dict(ref.named_parameters())
+
+    def check_params(prefixes, what):
+        n_checked = 0
+        for n, p in prod.named_parameters():
+            if any(n.startswith(q) for q in prefixes):
+                assert p.grad is not None and pref[n].grad is not None, (what, n)
+                assert rel(p.grad, pref[n].grad) <= 1e-3, (what, n, rel(p.grad, pref[n].grad))
+                n_checked += 1
+        assert n_checked > 0, what
+        for q in list(prod.parameters()) + list(ref.parameters()):
+            q.grad = None
+    # (b) stems
+    g = torch.Generator().manual_seed(3)
+    image = torch.randint(0, 256, (2, 3, 96, 160) if full else (2, 3, 32, 48), generator=g).float()
+    lidar = torch.rand(2, 2, 64, 64, generator=g) * (torch.rand(2, 2, 64, 64, generator=g) < 0.3)
+    extra = (torch.rand(2, 1, 64, 64, generator=g) < 0.05).float()
+    im, li = ref._model.image_encoder.features, ref._model.lidar_encoder._model
+    so = im.act1(im.bn1(im.conv1(otf.normalize_imagenet(image))))
+    lo = li.act1(li.bn1(li.conv1(torch.cat((lidar, extra), 1))))
+    ds, dl = torch.randn_like(so), torch.randn_like(lo)
+    torch.autograd.backward([so, lo], [ds, dl])
+    sp = prod._model._img_stem(image.to(dev))
+    lp = prod._model._lid_stem(lidar.to(dev).contiguous(), extra.to(dev).contiguous())
+    torch.autograd.backward([sp, lp], [nh(ds), nh(dl)])
+    assert rel(sp.permute(0, 3, 1, 2), so) <= 1e-3 and rel(lp.permute(0, 3, 1, 2), lo) <= 1e-3
+    check_params(("_model.image_encoder.features.conv1.", "_model.image_encoder.features.bn1.", "_model.lidar_encoder._model.conv1.",
+                  "_model.lidar_encoder._model.bn1."), "stems")
+    # (c) FPN top_down on the (B, 512, 8, 8) LiDAR map
+    y = torch.randn(3, cfg.perception_output_features, 8, 8)
+    yo_ = y.clone().requires_grad_(True)
+    outs_o = ref._model.top_down(yo_)
+    douts = [torch.randn_like(t) for t in outs_o]
+    torch.autograd.backward(list(outs_o), douts)
+    yp_ = nh(y).requires_grad_(True)
+    outs_p = prod._model.top_down_nhwc(yp_)
+    torch.autograd.backward(list(outs_p), [nh(t) for t in douts])
+    for a, b in zip(outs_p, outs_o):
+        assert rel(a.permute(0, 3, 1, 2), b) <= 1e-3
+    assert rel(yp_.grad.permute(0, 3, 1, 2), yo_.grad) <= 1e-3, rel(yp_.grad.permute(0, 3, 1, 2), yo_.grad)
+    check_params(("_model.c5_conv.", "_model.up_conv5.", "_model.up_conv4.", "_model.up_conv3."), "top_down")
+    # (d) join MLP + GRU decoder
+    z = torch.randn(10 if full else 3, 512)
+    tp = torch.rand(10 if full else 3, 2) * 40 - 10
+    zo = z.clone().requires_grad_(True)
+    wo = ref.forward_gru(zo, tp)
+    dw = torch.randn_like(wo)
+    wo.backward(dw)
+    zp = z.to(dev).requires_grad_(True)
+    wp = prod.forward_gru(zp, tp.to(dev))[0]
+    wp.backward(dw.to(dev))
+    assert rel(wp, wo) <= 1e-3
+    assert rel(zp.grad, zo.grad) <= 1e-3, rel(zp.grad, zo.grad)
+    check_params(("join.", "decoder.", "output."), "join MLP + GRU")
+    del prod, ref
+    # ---- (e) geometric-fusion stage 3 (C = 576, anchors x 2) in isolation, both directions
+    gcfg = full_config() if full else tiny_config(n_layer=1)
+    gprod, gref = build_pair(gcfg, arch, dev, backbone="geometric_fusion")
+    gprod.train(); gref.train()
+    pb_, rb_ = gprod._model, gref._model
+    st = pb_._stages[2]
+    B, C = 3, st.image_conv.weight.shape[1]
+    ih, iw, lh, lw = gcfg.img_vert_anchors, gcfg.img_horz_anchors, gcfg.lidar_vert_anchors, gcfg.lidar_horz_anchors
+    pts = geo_points(B, gcfg, seed=1)
+    x = torch.randn(B, C, ih * 2, iw * 2)
+    y = torch.randn(B, C, lh * 2, lw * 2)
+    xo, yo_ = x.clone().requires_grad_(True), y.clone().requires_grad_(True)
+    img_e = rb_.avgpool_img(rb_.image_conv3(xo))
+    lid_e = rb_.avgpool_lidar(rb_.lidar_conv3(yo_))
+    up = lambda t: Fn.interpolate(t, scale_factor=2, mode='bilinear', align_corners=False)
+    bev = rb_.image_projection3(rb_._gather_sum(img_e, pts['bev_points'], lh, lw)).permute(0, 3, 1, 2).contiguous()
+    y_out = yo_ + rb_.lidar_deconv3(up(bev))
+    img = rb_.lidar_projection3(rb_._gather_sum(lid_e, pts['cam_points'], ih, iw)).permute(0, 3, 1, 2).contiguous()
+    x_out = xo + rb_.image_deconv3(up(img))
+    dxo, dyo = torch.randn_like(x_out), torch.randn_like(y_out)
+    torch.autograd.backward([x_out, y_out], [dxo, dyo])
+    params = [p for m in (st.image_conv, st.lidar_conv, st.image_deconv, st.lidar_deconv, st.image_projection, st.lidar_projection) for p in m.parameters()]
+    xp_, yp_ = nh(x).requires_grad_(True), nh(y).requires_grad_(True)
+    bev_idx = pb_._flat_idx(pts['bev_points'].to(dev), B, lh * lw)
+    img_idx = pb_._flat_idx(pts['cam_points'].to(dev), B, ih * iw)
+    ox, oy, _ = fn.GeoStageFn.apply(xp_, yp_, None, st, None, bev_idx, img_idx, *params)
+    torch.autograd.backward([ox, oy], [nh(dxo), nh(dyo)])
+    assert rel(ox.permute(0, 3, 1, 2), x_out) <= 1e-3 and rel(oy.permute(0, 3, 1, 2), y_out) <= 1e-3
+    assert rel(xp_.grad.permute(0, 3, 1, 2), xo.grad) <= 1e-3, rel(xp_.grad.permute(0, 3, 1, 2), xo.grad)
+    assert rel(yp_.grad.permute(0, 3, 1, 2), yo_.grad) <= 1e-3, rel(yp_.grad.permute(0, 3, 1, 2), yo_.grad)
+    gpref = dict(gref.named_parameters())
+    n_checked = 0
+    for n, p in gprod.named_parameters():
+        if any(n.startswith("_model.%s3." % q) for q in ("image_conv", "lidar_conv", "image_deconv", "lidar_deconv", "image_projection", "lidar_projection")):
+            assert rel(p.grad, gpref[n].grad) <= 1e-3, ("geometric stage 3", n, rel(p.grad, gpref[n].grad))
+            n_checked += 1
+    assert n_checked == 20, n_checked
+
+

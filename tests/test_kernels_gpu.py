@@ -168,6 +168,14 @@ def test_conv_grouped_stride2_direct_kernels(case):
     kc.check_conv_grouped_s2("cuda", *case)
 
 
+def test_conv_grouped_stride2_direct_kernels_compute_modes():
+    kc.check_grouped_s2_modes("cuda")
+
+
+def test_im2col_gemm_form_of_few_row_deep_k_convolutions():
+    kc.check_im2col_gemm_conv("cuda")
+
+
 @pytest.mark.parametrize("cfg", kc.TWO_PASS_CASES, ids=str)
 def test_two_pass_splitk(cfg):
     kc.check_two_pass_splitk("cuda", *cfg)

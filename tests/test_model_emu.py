@@ -410,3 +410,9 @@ def test_se_blocks_wider_than_the_fused_excitation_kernels_take_the_generic_path
 
 def test_direct_stride2_grouped_kernels_match_the_engine_path_inside_the_model():
     mc.check_grouped_s2_switch("cpu", (2, 64, 128, 64, 40))
+
+
+def test_remaining_block_gradients_within_1e3_tiny():
+    """The logic of the -m gpu test of the same name at tiny widths: stride-1 bottleneck, both stems, FPN top_down, join MLP + GRU, one
+    geometric-fusion stage - outputs, input gradients and every parameter gradient within 1e-3 (max norm) of PyTorch-CPU autograd."""
+    mc.check_remaining_blocks("cpu", full=False)

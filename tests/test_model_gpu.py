@@ -384,6 +384,12 @@ def test_single_block_gradients_within_1e3():
         assert rel(p.grad, pgo[n].grad) <= 1e-3, (n, rel(p.grad, pgo[n].grad))
 
 
+def test_remaining_block_gradients_within_1e3():
+    """model_cases.check_remaining_blocks at the reference widths: stride-1 bottleneck 576 -> 576 (folded BatchNorm / SE kernels), both stems,
+    the FPN top_down, the join MLP + GRU decoder, geometric-fusion stage 3 - outputs, input gradients, every parameter gradient <= 1e-3."""
+    mc.check_remaining_blocks("cuda", full=True)
+
+
 def test_decoder_and_head_block_gradients_within_1e3():
     """The 1e-3 gradient bound at block level for the two remaining kinds of block (round-3 verdict): (1) a segmentation decoder
     (transfuser.py:214-246: 3x3 convs + ReLU + two bilinear up-samplings + the thin-output last layer, i.e. the engine, direct, thin and
