@@ -89,6 +89,16 @@ int tf_gemm_f32(const tf_gemm_desc* d, void* stream);
  * the caller only allocates scratch for the few GEMMs that want it (the reference's addmm never needs caller scratch: torch's cuBLAS
  * workspace plays this role, transfuser.py:500-507,539-541). */
 long tf_gemm_splitk_ws_floats(const tf_gemm_desc* d);
+/* Pair launch: between tf_gemm_pair_begin() and tf_gemm_pair_end(stream) (same thread) up to TWO tf_gemm_f32 calls whose plan is a 64 x 64
+ * register-staged tiling (batch 1, 16-byte aligned operands, no output statistics) are held back and issued by tf_gemm_pair_end: a weight
+ * gradient ([tn]: a_trans && b_trans) + an input gradient ([nn]: b_trans) pair as ONE grid whose second problem's workgroups start as the first
+ * one's retire; any other held call as its ordinary launch, in call order.  Calls that are not eligible launch immediately, as without the
+ * bracket.  The two calls must be independent (neither reads what the other writes): the weight / input gradient of one layer, which torch
+ * autograd issues back to back behind every Conv2d / Linear of the reference (transfuser.py:380,442,545-549).  tf_gemm_pair_count(0 | 1):
+ * joint / single launches issued by tf_gemm_pair_end so far on this thread. */
+int tf_gemm_pair_begin(void);
+int tf_gemm_pair_end(void* stream);
+long tf_gemm_pair_count(int singles);
 
 /* 2-D convolution as implicit GEMM (im2col gather -> LDS -> MFMA): kernel 1x1 or 3x3, stride 1/2,
  * pad, groups.  Replaces cuDNN conv fwd/bwd of the RegNetY trunks (timm regnety_032 via

@@ -1718,3 +1718,67 @@ def check_fused_attention(dev, B, nh, T, hs, p):
     close(dq[:, C:2 * C], g[:, C:2 * C], what="fused attention dQ")
     close(dq[:, :C], g[:, :C], what="fused attention dK")
     close(dq[:, 2 * C:], g[:, 2 * C:], what="fused attention dV")
+
+
+# ---------------------------------------------------------------- pair launch (csrc/gemm_pair.cpp)
+GEMM_PAIR_CASES = [(300, 72, 100, 3), (132, 216, 40, 1), (70, 64, 64, 2), (260, 132, 72, 4), (64, 24, 36, 1)]      # dims % 4 == 0: the joint kernel needs 16-byte operand loads
+
+
+def check_gemm_pair(dev, M, N, K, splitk, bks=((32, 32), (32, 16), (16, 32), (16, 16))):
+    """Weight gradient + input gradient of one layer in ONE grid (ops.gemm_pair): dW (N, K) += dy^T x with an atomic k-split, dx (M, K) = dy W
+    (+ residual, ReLU mask) - against fp64, and against the same two calls issued one by one; every BK combination of the joint kernel; the
+    library must report a joint launch.  A lone held call and a pair without a joint kernel (two forward products) fall back to plain launches."""
+    dy, x, w = R(M, N, dev=dev), R(M, K, seed=1, dev=dev), R(N, K, seed=2, dev=dev) * 0.1
+    res, act = R(M, K, seed=3, dev=dev), R(M, K, seed=4, dev=dev)
+    dw0 = R(N, K, seed=5, dev=dev) * 0.1
+    want_dw = (dw0.double() + dy.double().t() @ x.double()).float()
+    want_dx = ((dy.double() @ w.double() + res.double()) * (act > 0)).float()
+    for (bkw, bkd) in bks:
+        # the plan pin applies to both calls; the weight gradient's BK is pinned first, then re-pinned for the input gradient (plans are resolved per call)
+        n0 = ops.gemm_pair_count()
+        dw = dw0.clone()
+        with ops.gemm_pair(dy) as gp:
+            assert gp.on
+            ops.force_plan(64, 64, bkw, splitk)
+            ops.linear_wgrad(dy, x, dw)
+            ops.force_plan(64, 64, bkd, 1)
+            dx = ops.linear_dgrad(dy, w, res=res, mask=act)
+            ops.force_plan(0)
+        assert ops.gemm_pair_count() == n0 + 1, "the joint kernel did not run"
+        close(dw, want_dw, tol=2e-5 * max(1, M // 64), what="pair wgrad %s" % ((M, N, K, splitk, bkw, bkd),))
+        close(dx, want_dx, tol=2e-5 * max(1, N // 64), what="pair dgrad %s" % ((M, N, K, splitk, bkw, bkd),))
+        # the same two calls one by one
+        dw1 = dw0.clone()
+        ops.force_plan(64, 64, bkw, splitk)
+        ops.linear_wgrad(dy, x, dw1)
+        ops.force_plan(64, 64, bkd, 1)
+        dx1 = ops.linear_dgrad(dy, w, res=res, mask=act)
+        ops.force_plan(0)
+        assert torch.equal(dx1, dx), "pair dgrad == single dgrad (bitwise)"
+        close(dw, dw1, tol=1e-6, what="pair wgrad vs single wgrad")
+    # one eligible call inside the bracket: an ordinary launch at the end of the block
+    s0 = ops.gemm_pair_count(singles=True)
+    ops.force_plan(64, 64, 32, 1)
+    with ops.gemm_pair(dy):
+        dx = ops.linear_dgrad(dy, w)
+    assert ops.gemm_pair_count(singles=True) == s0 + 1
+    close(dx, (dy.double() @ w.double()).float(), tol=2e-5 * max(1, N // 64), what="lone held call")
+    # two forward products: no joint kernel for that layout pair -> two plain launches in call order (the second reads the first's output)
+    with ops.gemm_pair(dy):
+        y1 = ops.linear_fwd(x, w)            # (M, N)
+        y2 = ops.linear_fwd(x, w, res=dy)
+    ops.force_plan(0)
+    close(y1, (x.double() @ w.double().t()).float(), tol=2e-5 * max(1, K // 64), what="forward inside the bracket")
+    close(y2, (x.double() @ w.double().t() + dy.double()).float(), tol=2e-5 * max(1, K // 64), what="second forward inside the bracket")
+    # an ineligible plan (128-row tiles) launches immediately, the eligible partner at the end
+    p0, s0 = ops.gemm_pair_count(), ops.gemm_pair_count(singles=True)
+    dw = dw0.clone()
+    with ops.gemm_pair(dy):
+        ops.force_plan(128, 64, 16, 1)
+        ops.linear_wgrad(dy, x, dw)
+        ops.force_plan(64, 64, 16, 1)
+        dx = ops.linear_dgrad(dy, w, res=res, mask=act)
+        ops.force_plan(0)
+    assert ops.gemm_pair_count() == p0 and ops.gemm_pair_count(singles=True) == s0 + 1
+    close(dw, want_dw, tol=2e-5 * max(1, M // 64), what="ineligible wgrad")
+    close(dx, want_dx, tol=2e-5 * max(1, N // 64), what="eligible dgrad beside an ineligible wgrad")

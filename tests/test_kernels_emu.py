@@ -244,3 +244,8 @@ def test_conv_grouped_stride2_direct_kernels_compute_modes():
 def test_im2col_gemm_form_of_few_row_deep_k_convolutions():
     kc.check_im2col_gemm_conv("cpu")
 
+
+
+@pytest.mark.parametrize("case", kc.GEMM_PAIR_CASES, ids=str)
+def test_gemm_pair_launch(case):
+    kc.check_gemm_pair("cpu", *case)

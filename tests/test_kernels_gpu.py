@@ -290,3 +290,8 @@ def test_dataprep_matches_reference_functions():
     """GPU-side batch preparation vs the reference's own data.py functions (tests/golden/dataprep.npz)."""
     import dataprep_cases as dc
     dc.check_dataprep("cuda")
+
+
+@pytest.mark.parametrize("case", kc.GEMM_PAIR_CASES + [(7040, 576, 576, 6), (2560, 576, 576, 6), (28160, 216, 216, 64)], ids=str)
+def test_gemm_pair_launch(case):
+    kc.check_gemm_pair("cuda", *case, **({} if case[0] < 2000 else dict(bks=((32, 32), (32, 16)))))

@@ -253,6 +253,7 @@ struct GemmEpi {
     // set at launch time to the number of parts this launch writes (0: the chosen plan cannot produce them - caller falls back).
     float* stat = nullptr; long stat_ld = 0; int* stat_nparts = nullptr;
     int prec = 0;                    // 0: exact fp32 MFMA; 1: operands rounded to bf16 on the LDS->register path, bf16 MFMA, fp32 accumulate; 2: bf16x3 split (fp32-accurate, 6 bf16 MFMAs); 3: as 1 with IEEE-half operands (set by launch_cfg)
+    int stagger = 0;                 // experiment (TF_GEMM_STAGGER=1): co-resident workgroups take distinct static issue priorities (s_setprio by dispatch round) so their load / LDS-write / barrier phases stop coinciding
     int packed16 = 0;                // LDS-DMA kernels, both operands K-contiguous: the operands ARE 16-bit matrices (1: bf16, 2: IEEE half) described in units of
                                      // 4 bytes (ld, cols, K = halves / 2): tiles are moved as bytes, one ds_read_b128 = one 8-deep MFMA operand (tf_gemm16_nt_f32)
 };
@@ -351,7 +352,7 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[TM][TN], const
 // ---------------------------------------------------------------- kernel
 template <int BM, int BN, int WAVES_M, int BK, class LA, bool A_KC, class LB, bool B_KC, bool ALLVEC, int NT = 256, int PF = 1>
 __device__ __forceinline__ void gemm_tile(LA& la, LB& lb, const GemmEpi& ep, int M, int N, int K, int tiles_m, int tiles_n, int kchunk,
-                                          float (*As)[BK][BM + GEMM_PAD], float (*Bs)[BK][BN + GEMM_PAD]) {
+                                          float (*As)[BK][BM + GEMM_PAD], float (*Bs)[BK][BN + GEMM_PAD], int blk_x, int blk_y, int blk_z) {
     constexpr int WAVES_N = (NT / 64) / WAVES_M;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -360,7 +361,15 @@ __device__ __forceinline__ void gemm_tile(LA& la, LB& lb, const GemmEpi& ep, int
     constexpr int NLA = (BM * KQ + NT - 1) / NT, NLB = (BN * KQ + NT - 1) / NT;   // float4 slots per thread
 
     const int tid = threadIdx.x;
-    const int z = blockIdx.z;
+    if (ep.stagger) {         // waves of the (up to four) workgroups resident on a CU belong to different dispatch rounds of 256 CUs: one priority level each
+        switch ((blockIdx.x >> 8) & 3) {
+            case 1: TF_SETPRIO(1); break;
+            case 2: TF_SETPRIO(2); break;
+            case 3: TF_SETPRIO(3); break;
+            default: break;
+        }
+    }
+    const int z = blk_z;      // (blk_x, blk_y, blk_z): the block's coordinates in ITS problem's grid (= blockIdx in gemm_kernel; decoded from a shared grid in gemm_pair_kernel)
     la.set_batch(z);
     lb.set_batch(z);
 
@@ -368,7 +377,7 @@ __device__ __forceinline__ void gemm_tile(LA& la, LB& lb, const GemmEpi& ep, int
     // ranges; inside a range tn is fastest so neighbouring tiles share the A row panel.
     int tile;
     {
-        const int nt = tiles_m * tiles_n, bid = blockIdx.x;
+        const int nt = tiles_m * tiles_n, bid = blk_x;
         const int q = nt >> 3, r = nt & 7, xcd = bid & 7, loc = bid >> 3;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
@@ -383,7 +392,7 @@ __device__ __forceinline__ void gemm_tile(LA& la, LB& lb, const GemmEpi& ep, int
         tn = rem / gsz; tm = sr * ep.group_m + (rem - tn * gsz);
     } else { tm = tile / tiles_n; tn = tile - tm * tiles_n; }
     const int i0 = tm * BM, j0 = tn * BN;
-    const int kbeg = blockIdx.y * kchunk;
+    const int kbeg = blk_y * kchunk;
     const int kend = (kbeg + kchunk < K) ? kbeg + kchunk : K;
     const int nkt = (kend - kbeg + BK - 1) / BK;
 
@@ -681,7 +690,35 @@ template <int BM, int BN, int WAVES_M, int BK, class LA, bool A_KC, class LB, bo
 __global__ void __launch_bounds__(NT, NT == 512 ? 2 : ((BM * BN >= 128 * 96) ? 3 : 4)) gemm_kernel(LA la, LB lb, GemmEpi ep, int M, int N, int K, int tiles_m, int tiles_n, int kchunk) {
     __shared__ __attribute__((aligned(16))) float As[2][BK][BM + GEMM_PAD];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN + GEMM_PAD];
-    gemm_tile<BM, BN, WAVES_M, BK, LA, A_KC, LB, B_KC, ALLVEC, NT, PF>(la, lb, ep, M, N, K, tiles_m, tiles_n, kchunk, As, Bs);
+    gemm_tile<BM, BN, WAVES_M, BK, LA, A_KC, LB, B_KC, ALLVEC, NT, PF>(la, lb, ep, M, N, K, tiles_m, tiles_n, kchunk, As, Bs, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// ---------------------------------------------------------------- pair launch
+// TWO independent plain GEMMs in ONE grid (the weight gradient and the input gradient of a layer both read dy and write disjoint outputs):
+// blocks [0, n1) run problem 1's tiles, blocks [n1pad, n1pad + n2) problem 2's (n1pad = n1 rounded up to the 8 XCDs; the blocks between exit).
+// The second problem's workgroups start as the first one's retire, so the drain of one launch, the dispatch gap and the ramp of the next -
+// 4-9 us per 64 x 64-tile launch on this part (profiles/r04_launch_lab.txt) - are filled with MFMA work, without the cross-queue edge a side
+// stream costs (~10 us each, DESIGN section 3 "round 4").  64 x 64 tiles, 4 waves, both problems with 16-byte operand loads.
+struct PairSide { PlainOp la, lb; GemmEpi ep; int M, N, K, tiles_m, tiles_n, kchunk, gx, gy; };
+
+template <int BK1, bool A1_KC, bool B1_KC, int BK2, bool A2_KC, bool B2_KC>
+__global__ void __launch_bounds__(256, 4) gemm_pair_kernel(PairSide s1, PairSide s2, int n1, int n1pad) {
+    constexpr int BKM = BK1 > BK2 ? BK1 : BK2;
+    __shared__ __attribute__((aligned(16))) float As[2 * BKM * (64 + GEMM_PAD)];
+    __shared__ __attribute__((aligned(16))) float Bs[2 * BKM * (64 + GEMM_PAD)];
+    int bid = blockIdx.x;
+    if (bid < n1) {
+        const int by = bid / s1.gx, bx = bid - by * s1.gx;
+        gemm_tile<64, 64, 2, BK1, PlainOp, A1_KC, PlainOp, B1_KC, true>(s1.la, s1.lb, s1.ep, s1.M, s1.N, s1.K, s1.tiles_m, s1.tiles_n, s1.kchunk,
+                                                                            reinterpret_cast<float (*)[BK1][64 + GEMM_PAD]>(As),
+                                                                            reinterpret_cast<float (*)[BK1][64 + GEMM_PAD]>(Bs), bx, by, 0);
+    } else if (bid >= n1pad) {
+        bid -= n1pad;
+        const int by = bid / s2.gx, bx = bid - by * s2.gx;
+        gemm_tile<64, 64, 2, BK2, PlainOp, A2_KC, PlainOp, B2_KC, true>(s2.la, s2.lb, s2.ep, s2.M, s2.N, s2.K, s2.tiles_m, s2.tiles_n, s2.kchunk,
+                                                                            reinterpret_cast<float (*)[BK2][64 + GEMM_PAD]>(As),
+                                                                            reinterpret_cast<float (*)[BK2][64 + GEMM_PAD]>(Bs), bx, by, 0);
+    }
 }
 
 // ---------------------------------------------------------------- host dispatch
@@ -731,6 +768,10 @@ inline bool twopass_ok(const GemmEpi& ep, int M, int N, int batch, int S) {
     return ep.sk_ws && batch == 1 && ep.ldcj == 1 && (ep.mode == 0 || ep.mode == 1) && S >= 2 && S <= 4 && (long)S * M * twopass_ldws(N) <= ep.sk_ws_floats;
 }
 
+// pair launch (gemm_pair.cpp): between tf_gemm_pair_begin() and tf_gemm_pair_end() up to two eligible GEMMs are held back and launched as ONE grid
+bool pair_capturing();
+bool pair_hold(const PlainOp& la, const PlainOp& lb, const GemmEpi& ep, int M, int N, int K, bool a_kc, bool b_kc, const GemmPlan& p, const char* what);
+
 // plan cache + autotuner state (api.cpp)
 bool plan_lookup(const char* what, int M, int N, int K, int batch, int acc, GemmPlan* out);
 void plan_store(const char* what, int M, int N, int K, int batch, int acc, const GemmPlan& p);
@@ -766,25 +807,41 @@ inline GemmPlan plan_gemm(int M, int N, int K, int batch, bool allow_splitk) {
     return p;
 }
 
-template <int BM, int BN, int WAVES_M, int BK, class LA, bool A_KC, class LB, bool B_KC, int NT = 256, int PF = 1>
-inline void launch_cfg(const LA& la, const LB& lb, const GemmEpi& ep, int M, int N, int K, int batch, int splitk, void* stream) {
-    const int tiles_m = cdiv(M, BM), tiles_n = cdiv(N, BN);
+// grid geometry + launch-time epilogue fields (compute precision, tile rasterisation, number of statistic parts) of one register-staged launch
+struct CfgGeom { int tiles_m, tiles_n, kchunk, nsplit; GemmEpi epg; };
+inline CfgGeom cfg_geom(const GemmEpi& ep, int M, int N, int K, int splitk, int BM, int BN, int BK, int WAVES_M) {
+    CfgGeom c;
+    c.tiles_m = cdiv(M, BM); c.tiles_n = cdiv(N, BN);
     int kchunk = cdiv(cdiv(K, splitk), BK) * BK;
     if (kchunk < BK) kchunk = BK;
+    c.kchunk = kchunk;
     const int nsplit = cdiv(K, kchunk);
-    dim3 grid(tiles_m * tiles_n, nsplit > 0 ? nsplit : 1, batch);
-    GemmEpi epg = ep;
-    epg.prec = gemm_precision();
+    c.nsplit = nsplit > 0 ? nsplit : 1;
+    c.epg = ep;
+    c.epg.prec = gemm_precision();
+    {
+        static const int stg = [] { const char* e = getenv("TF_GEMM_STAGGER"); return e ? atoi(e) : 0; }();
+        c.epg.stagger = stg;
+    }
     {
         static const int forced = [] { const char* e = getenv("TF_GROUP_M"); return e ? atoi(e) : 0; }();
         long panel = (long)BM * (kchunk < K ? kchunk : K) * 4;          // bytes of one A panel of this launch
         int g = (int)((2L << 20) / (panel > 0 ? panel : 1));            // as many tile-rows as keep their A panels in ~half the L2
         if (g > 8) g = 8;
         if (forced > 0) g = forced;
-        if (g > tiles_m) g = tiles_m;
-        epg.group_m = (g >= 2 && tiles_n >= 4) ? g : 1;
+        if (g > c.tiles_m) g = c.tiles_m;
+        c.epg.group_m = (g >= 2 && c.tiles_n >= 4) ? g : 1;
     }
-    if (epg.stat_nparts) *epg.stat_nparts = epg.stat ? cdiv(M, BM / WAVES_M) : 0;
+    if (c.epg.stat_nparts) *c.epg.stat_nparts = c.epg.stat ? cdiv(M, BM / WAVES_M) : 0;
+    return c;
+}
+
+template <int BM, int BN, int WAVES_M, int BK, class LA, bool A_KC, class LB, bool B_KC, int NT = 256, int PF = 1>
+inline void launch_cfg(const LA& la, const LB& lb, const GemmEpi& ep, int M, int N, int K, int batch, int splitk, void* stream) {
+    const CfgGeom cg = cfg_geom(ep, M, N, K, splitk, BM, BN, BK, WAVES_M);
+    const int tiles_m = cg.tiles_m, tiles_n = cg.tiles_n, kchunk = cg.kchunk;
+    dim3 grid(tiles_m * tiles_n, cg.nsplit, batch);
+    const GemmEpi& epg = cg.epg;
     if (la.vec && lb.vec)
         TF_LAUNCH((gemm_kernel<BM, BN, WAVES_M, BK, LA, A_KC, LB, B_KC, true, NT, PF>), grid, dim3(NT), stream, la, lb, epg, M, N, K, tiles_m, tiles_n, kchunk);
     else
@@ -805,6 +862,15 @@ inline void launch_plan(const GemmPlan& p, const LA& la, const LB& lb, const Gem
         if (p.bk == 32) launch_cfg<BM_, BN_, WM_, 32, LA, A_KC, LB, B_KC>(la, lb, ep, M, N, K, batch, sk, stream); \
         else launch_cfg<BM_, BN_, WM_, 16, LA, A_KC, LB, B_KC>(la, lb, ep, M, N, K, batch, sk, stream);       \
     } while (0)
+    if constexpr (std::is_same<LA, PlainOp>::value && std::is_same<LB, PlainOp>::value) {
+        // experiment (TF_GEMM_PF2=1): the 64 x 64 plain-operand tiles with prefetch distance 2 (tile kt + 2 requested while tile kt is multiplied)
+        static const bool pf2 = [] { const char* e = getenv("TF_GEMM_PF2"); return e && atoi(e) != 0; }();
+        if (pf2 && p.bm == 64 && p.bn == 64 && la.vec && lb.vec) {
+            if (p.bk == 32) launch_cfg<64, 64, 2, 32, LA, A_KC, LB, B_KC, 256, 2>(la, lb, ep, M, N, K, batch, sk, stream);
+            else launch_cfg<64, 64, 2, 16, LA, A_KC, LB, B_KC, 256, 2>(la, lb, ep, M, N, K, batch, sk, stream);
+            return;
+        }
+    }
     if (p.bm == 128) {
         if (p.bn == 32) TF_CFG(128, 32, 4);
         else if (p.bn == 64) TF_CFG(128, 64, 2);
@@ -975,6 +1041,13 @@ inline int launch_gemm(const LA& la, const LB& lb, GemmEpi ep, int M, int N, int
     } else {
         if (!sk_ok) p.splitk = 1;
         if (p.splitk > 1) ep.mode = 2;
+    }
+    if constexpr (std::is_same<LA, PlainOp>::value && std::is_same<LB, PlainOp>::value) {
+        // tf_gemm_pair_begin(): a 64 x 64-tile register-staged launch with vector operands is held back so that tf_gemm_pair_end() can put
+        // it into one grid with its partner (gemm_pair.cpp); anything else launches right here, as always
+        if (pair_capturing() && p.kind == 0 && p.bm == 64 && p.bn == 64 && (p.bk == 16 || p.bk == 32) && p.splitk < kTwoPass && batch == 1 && la.vec && lb.vec &&
+            !ep.stat && pair_hold(la, lb, ep, M, N, K, A_KC, B_KC, p, what))
+            return 0;
     }
     launch_plan<LA, A_KC, LB, B_KC>(p, la, lb, ep, M, N, K, batch, stream);
     return launch_status(what);

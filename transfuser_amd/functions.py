@@ -382,8 +382,10 @@ def _c1x1_bwd(dy2, saved, w, dw, res=None):
         _, w16t = ops.lowp_weight(w)
         dx = torch.empty(dy2.shape[0], w.shape[1], dtype=torch.float32, device=dy2.device)
         return ops.gemm16_nt(d16, w16t, dx, res=res, k=w.shape[0])
-    ops.wgrad_fork((dy2, saved), lambda: ops.linear_wgrad(dy2, saved, dw))
-    return ops.linear_dgrad(dy2, w, res=res)
+    with ops.gemm_pair(dy2):      # weight + input gradient in one grid where both plans are 64 x 64 tilings (csrc/gemm_pair.cpp)
+        ops.linear_wgrad(dy2, saved, dw)
+        dx = ops.linear_dgrad(dy2, w, res=res)
+    return dx
 
 
 # ============================================================================================ RegNetY block
@@ -496,7 +498,7 @@ class YBlockFn(torch.autograd.Function):
             dz1 = ops.conv_dgrad(dy2, w2, y1.shape, blk.stride, 1, blk.groups)
             dy1 = ops.bn_bwd_remask(dz1, y1, st1[2], bn1.weight, st1[0], st1[1], gbuf(bn1.weight), gbuf(bn1.bias))
         else:
-            ops.wgrad_fork((dy2, z1), lambda: ops.conv_wgrad(dy2, z1, gbuf(w2), blk.stride, 1, blk.groups))
+            ops.conv_wgrad(dy2, z1, gbuf(w2), blk.stride, 1, blk.groups)
             dz1 = ops.conv_dgrad(dy2, w2, z1.shape, blk.stride, 1, blk.groups)
             dy1, _ = _bn_bwd(dz1, z1, y1, blk.conv1.bn, st1)
         dy1_2 = dy1.view(-1, C)
@@ -508,10 +510,10 @@ class YBlockFn(torch.autograd.Function):
             dyd, _ = _bn_bwd(dsc, None, yd, blk.downsample.bn, std)
             wd = blk.downsample.conv.weight
             if blk.stride == 1:
-                ops.wgrad_fork((dyd, x), lambda: ops.linear_wgrad(dyd.view(-1, C), x2, w2d(gbuf(wd))))
+                ops.linear_wgrad(dyd.view(-1, C), x2, w2d(gbuf(wd)))
                 ops.linear_dgrad(dyd.view(-1, C), w2d(wd), out=dx, accumulate=True)
             else:
-                ops.wgrad_fork((dyd, x), lambda: ops.conv_wgrad(dyd, x, gbuf(wd), blk.stride, 0, 1))
+                ops.conv_wgrad(dyd, x, gbuf(wd), blk.stride, 0, 1)
                 ops.conv_dgrad(dyd, wd, x.shape, blk.stride, 0, 1, out=dx.view(B, H, W, Cin), accumulate=True)
         ctx.saved = None
         return (dx.view(B, H, W, Cin), None) + (None,) * (len(ctx.needs_input_grad) - 2)
@@ -706,12 +708,15 @@ def _gpt_block_bwd(gpt, li, saved, dx, B, T, drop):
         bias_later(da1, fc1.bias)
         dh2 = _lin16_bwd(da1, h2, fc1.weight, gbuf(fc1.weight))
     else:
-        ops.linear_wgrad(dres, a1, gbuf(fc2.weight))
+        # (weight gradient, input gradient) of a layer: one grid where both plans are 64 x 64 tilings (the narrow stages; ops.gemm_pair)
+        with ops.gemm_pair(dres):
+            ops.linear_wgrad(dres, a1, gbuf(fc2.weight))
+            da1 = ops.linear_dgrad(dres, fc2.weight, mask=a1)     # ReLU backward fused into the dgrad epilogue
         bias_later(dres, fc2.bias, dres is not dx)
-        da1 = ops.linear_dgrad(dres, fc2.weight, mask=a1)     # ReLU backward fused into the dgrad epilogue
-        ops.linear_wgrad(da1, h2, gbuf(fc1.weight))
+        with ops.gemm_pair(da1):
+            ops.linear_wgrad(da1, h2, gbuf(fc1.weight))
+            dh2 = ops.linear_dgrad(da1, fc1.weight)
         bias_later(da1, fc1.bias)
-        dh2 = ops.linear_dgrad(da1, fc1.weight)
     # dx_mid = dx + ln2_bwd(dh2): accumulate in place into dx
     ops.layernorm_bwd(dh2, x_mid, blk.ln2.weight, m2, r2, gbuf(blk.ln2.weight), gbuf(blk.ln2.bias), dx=dx, accumulate=True)
     # ---- attention: x_mid = x + drop(proj(att @ v))
@@ -722,8 +727,9 @@ def _gpt_block_bwd(gpt, li, saved, dx, B, T, drop):
     if lowp:
         dy = _lin16_bwd(dres, y_att, proj.weight, gbuf(proj.weight))
     else:
-        ops.linear_wgrad(dres, y_att, gbuf(proj.weight))
-        dy = ops.linear_dgrad(dres, proj.weight)
+        with ops.gemm_pair(dres):
+            ops.linear_wgrad(dres, y_att, gbuf(proj.weight))
+            dy = ops.linear_dgrad(dres, proj.weight)
     if att_d is None:       # fused attention: att is the log-sum-exp; probabilities are recomputed inside the two backward kernels
         adrop = (gpt.seed, gpt.site(4 * li + 1), gpt.attn_pdrop) if (drop and gpt.attn_pdrop > 0) else None
         dqkv = ops.attention_bwd(qkv, dy, att, B, T, C, nh, adrop)
@@ -758,12 +764,13 @@ def _gpt_block_bwd(gpt, li, saved, dx, B, T, drop):
         for j, l3 in enumerate((blk.attn.key, blk.attn.query, blk.attn.value)):
             ops.axpby(gbuf(l3.bias), b3[0, j * C:(j + 1) * C], 1.0, 1.0, out=gbuf(l3.bias))
     elif fw is not None:
-        ops.linear_wgrad(dqkv, h1, fw[2])
+        with ops.gemm_pair(dqkv):
+            ops.linear_wgrad(dqkv, h1, fw[2])
+            dh1 = ops.linear_dgrad(dqkv, fw[0])
         if ops.COLSUM_MULTI:
             pending.append((dqkv, fw[3].view(-1)))
         else:
             ops.colsum(dqkv, 1, B * T, 3 * C, 1.0, out=fw[3].view(1, -1), accumulate=True)
-        dh1 = ops.linear_dgrad(dqkv, fw[0])
     else:
         dh1 = None
         for j, lin in enumerate((blk.attn.key, blk.attn.query, blk.attn.value)):

@@ -37,51 +37,41 @@ def workspace(device):
     return ws
 
 
-# ---- weight gradients on a side stream (train.Engine, opt-in TF_WGRAD_STREAM=1).  The input-gradient chain is the critical path of the
-# backward; a weight gradient is only needed by AdamW at the end of the step.  Inside ``wgrad_side_stream()`` every weight-gradient launch
-# (the callers accumulate in place into the flat gradient arena) is enqueued on a side stream that waits for the issuing stream's current
-# position (under hipGraph capture: a graph edge), so it runs beside the following input-gradient kernels; ``wgrad_join()`` makes the
-# current stream wait for all of them (before the all-reduce / AdamW).
-_WGRAD_SIDE = bool(int(__import__("os").environ.get("TF_WGRAD_STREAM", "0")))      # round 1 (RegNet blocks only, one stream): 155-158 vs 170 samples/s
-_wg = {"on": False, "streams": {}, "used": []}
+# ---- pair launch (csrc/gemm_pair.cpp): the weight gradient and the input gradient of a layer both read dy and write disjoint outputs; inside
+# ``gemm_pair()`` the (up to two) eligible GEMMs are held back by the library and issued as ONE grid when the block closes, so the second
+# problem's workgroups start as the first one's retire (no drain / dispatch gap / ramp between the two launches, no cross-queue edge).
+# Weight gradients on a side stream - the other way to overlap them - were measured at +3.7 ms/step in rounds 1 and 4 (~10 us per cross-queue
+# dependency) and are gone.
+GEMM_PAIR = os.environ.get("TF_GEMM_PAIR", "1") != "0"      # A/B switch of the round-5 pair launch
+_pair_open = [False]
 
 
-class wgrad_side_stream:
+class gemm_pair:
+    """with gemm_pair(t): linear_wgrad(...); dx = linear_dgrad(...)   (t: any tensor on the device / stream the calls use)"""
+
+    def __init__(self, t):
+        self.t = t
+        self.on = False
+
     def __enter__(self):
-        self.prev, _wg["on"] = _wg["on"], _WGRAD_SIDE
+        self.on = GEMM_PAIR and census is None and not _CHECK and not _pair_open[0] and (self.t.is_cuda or _lib.is_test_backend())
+        if self.on:
+            check(L().tf_gemm_pair_begin(), "tf_gemm_pair_begin")
+            _pair_open[0] = True
+        return self
 
-    def __exit__(self, *a):
-        _wg["on"] = self.prev
+    def __exit__(self, et, ev, tb):
+        if self.on:
+            _pair_open[0] = False
+            rc = L().tf_gemm_pair_end(stream_of(self.t))
+            if et is None:
+                check(rc, "tf_gemm_pair_end")
+        return False
 
 
-def wgrad_join():
-    used, _wg["used"] = _wg["used"], []
-    for w in used:
-        torch.cuda.current_stream(w.device).wait_stream(w)
-
-
-def _wgrad_launch(tensors, launch):
-    """Run ``launch`` (which enqueues on torch's current stream) on the side stream of the current stream."""
-    t0 = tensors[0]
-    if not (_wg["on"] and t0.is_cuda) or _wg.get("inside"):
-        return launch()
-    cur = torch.cuda.current_stream(t0.device)
-    w = _wg["streams"].get(cur.cuda_stream)
-    if w is None:
-        w = _wg["streams"][cur.cuda_stream] = torch.cuda.Stream(t0.device)
-    w.wait_stream(cur)
-    _wg["inside"] = True
-    try:
-        with torch.cuda.stream(w):
-            out = launch()
-    finally:
-        _wg["inside"] = False
-    for t in tensors:
-        if t is not None:
-            t.record_stream(w)
-    if w not in _wg["used"]:
-        _wg["used"].append(w)
-    return out
+def gemm_pair_count(singles=False):
+    L().tf_gemm_pair_count.restype = ctypes.c_long
+    return L().tf_gemm_pair_count(int(singles))
 
 
 def autotune(enable):
@@ -239,11 +229,6 @@ def wptr(w):
 
 
 
-def wgrad_fork(tensors, fn):
-    """functions.py: a weight-gradient launch sequence that may run beside the input-gradient chain (see wgrad_side_stream)."""
-    return _wgrad_launch(tensors, fn)
-
-
 # ------------------------------------------------------------------------------------------ GEMM
 hbm_census = None   # set to a list to record (name, algorithmic bytes, start_event, end_event) of the bandwidth-bound calls north_star names (bench.py roofline_hbm)
 
@@ -305,7 +290,8 @@ _TRACE_GEMM = os.environ.get("TF_TRACE_GEMM", "0") == "1"
 _TWO_PASS_MAX_ELEMS = 4300000      # <= ~256 tiles of 128 x 128
 
 
-STREAM_K = os.environ.get("TF_STREAM_K", "1") != "0"      # stream-K plans for tile counts that do not divide over the resident workgroup slots (A/B switch)
+STREAM_K = os.environ.get("TF_STREAM_K", "0") != "0"      # opt-in: stream-K plans (measured no faster than the data-parallel launches, profiles/r04_sk_lab_*; no shipped plan uses one).
+# Off, no call hands the library hand-over flags, so the tuner cannot pick a stream-K plan on timing noise and the two-pass scratch query keeps its output-size cap
 _skf_cache = {}
 
 
@@ -427,7 +413,7 @@ def linear_wgrad(dy, x, dw, accumulate=True):
     """dw (+)= dy.T @ x; dy (M, N), x (M, K), dw (N, K)."""
     M, N = dy.shape
     K = x.shape[1]
-    return _wgrad_launch((dy, x), lambda: gemm(dy, x, dw, N, K, M, dy.stride(0), x.stride(0), dw.stride(0), a_trans=True, b_trans=True, accumulate=accumulate))
+    return gemm(dy, x, dw, N, K, M, dy.stride(0), x.stride(0), dw.stride(0), a_trans=True, b_trans=True, accumulate=accumulate)
 
 
 # ------------------------------------------------------------------------------------------ conv
@@ -474,7 +460,7 @@ def _grouped_ok(shape, cout, cin, ks, stride, pad, groups):
     return _GROUPED and ks == 3 and stride == 1 and pad == 1 and groups > 1 and cin == cout == groups * 24 and shape[1] >= 4 and shape[2] >= 8
 
 
-_GROUPED_S2 = bool(int(__import__("os").environ.get("TF_GROUPED_S2", "0")))      # opt-in: the direct stride-2 forward / weight-gradient kernels are not yet measured on the MI355X
+_GROUPED_S2 = bool(int(__import__("os").environ.get("TF_GROUPED_S2", "1")))      # round 5: default on (GPU suite green with it; same-lease A/B 49.42-49.62 vs 49.62-49.74 ms/step together with the im2col form, gpurun_out/r05_call1.log)
 
 
 def _grouped_s2_ok(shape, cout, cin, ks, stride, pad, groups):
@@ -483,7 +469,7 @@ def _grouped_s2_ok(shape, cout, cin, ks, stride, pad, groups):
             (shape[2] - 1) // 2 + 1 >= 8)
 
 
-_IM2COL_GEMM = bool(int(__import__("os").environ.get("TF_IM2COL_GEMM", "0")))    # opt-in (written at the end of round 4, not yet measured on the MI355X)
+_IM2COL_GEMM = bool(int(__import__("os").environ.get("TF_IM2COL_GEMM", "1")))    # round 5: default on (parity at the decoders' own shapes on the MI355X: test_im2col_gemm_form_of_few_row_deep_k_convolutions)
 
 
 def _im2col_gemm_ok(g, ks, stride, pad, groups):
@@ -619,9 +605,6 @@ def _thin_ws(device):
 def conv_wgrad(dy, x, dw, stride=1, pad=None, groups=1, accumulate=True, dbias=None):
     """dbias (optional, (Cout,) accumulator): the bias gradient sum(dy) is added to it by the same launch where the kernel can (thin-output
     layers); returns dw - callers test ``conv_wgrad_takes_bias`` to know whether dbias was consumed."""
-    if _wg["on"]:
-        dy, x = _c(dy), _c(x)
-        return _wgrad_launch((dy, x), lambda: _conv_wgrad(dy, x, dw, stride, pad, groups, accumulate, dbias))
     return _conv_wgrad(dy, x, dw, stride, pad, groups, accumulate, dbias)
 
 
@@ -951,7 +934,7 @@ def grouped_bnrelu_wgrad(dy, x, coef, dw, accumulate=True, stride=1):
         check(L().tf_conv3x3_grouped_bnrelu_wgrad_f32(ptr(_c(dy)), ptr(_c(x)), ptr(coef), wptr(dw), B, H, W, C, int(accumulate), ptr(_grouped_ws(x.device)),
                                                       stream_of(dy)), "tf_conv3x3_grouped_bnrelu_wgrad_f32")
         _census_end(_e, "conv wgrad g", (B, H, W, C, C, 3, 1, C // 24), 2.0 * B * H * W * C * 24 * 9)
-    _wgrad_launch((dy, x, coef), run)
+    run()
     return dw
 
 

@@ -440,16 +440,12 @@ class Engine:
         return len(self.cuts) + 1
 
     def _piece0(self, data):
-        with _F.inplace_param_grads(), ops.lowp_managed(), ops.wgrad_side_stream():
-            out = self._piece0_impl(data)
-            ops.wgrad_join()
-            return out
+        with _F.inplace_param_grads(), ops.lowp_managed():
+            return self._piece0_impl(data)
 
     def _piece(self, i):
-        with _F.inplace_param_grads(), ops.lowp_managed(), ops.wgrad_side_stream():
-            out = self._piece_impl(i)
-            ops.wgrad_join()
-            return out
+        with _F.inplace_param_grads(), ops.lowp_managed():
+            return self._piece_impl(i)
 
     def _opt_step(self):
         """AdamW over the arena, then the 16-bit weight copies of the storage modes are rewritten from the updated master weights.  With
