@@ -677,3 +677,37 @@ def check_remaining_blocks(dev, full=True):
     assert n_checked == 20, n_checked
 
 
+
+
+MERGED_HEAD_WEIGHTS = [(0.2, 0.2, 0.2, 0.2, 0.2, 0.0, 0.0), (0.2, 0.2, 0.2, 0.2, 0.2, 0.3, 0.4), (0.2, 0.0, 0.2, 0.2, 0.2, 0.0, 0.4)]
+
+
+def check_merged_heads(dev, weights):
+    """Inside the Engine the eight 3x3 convolutions on p2 (seven CenterNet heads + pred_bev) run as ONE 64 -> 512 convolution over the
+    arena-adjacent weights; the backward differentiates the live heads' channels only - a prefix when the zero-weight heads are the reference's
+    (velocity, brake), every channel (dead slices zero-filled) otherwise.  Gradients of every head parameter and of p2's producers vs the oracle."""
+    from oracle import model_cpu
+    from transfuser_amd.train import Engine
+    from transfuser_amd.model import merged_head_convs
+    cfg = tiny_config(n_layer=1)
+    cfg.detailed_losses_weights = [1.0, 1.0, 1.0, 1.0] + list(weights)
+    prod, ref = build_pair(cfg, "regnety_tiny", dev)
+    eng = Engine(prod, cfg, lr=0.0)
+    assert merged_head_convs(prod) is not None
+    batch = small_batch(2, 32, 64, 64, 40)
+    prod.train(); ref.train()
+    eng.train_step({k: v.to(dev) for k, v in batch.items()})
+    losses = ref(batch['rgb'], batch['lidar'], ego_waypoint=batch['ego_waypoint'], target_point=batch['target_point'],
+                 target_point_image=batch['target_point_image'], ego_vel=batch['ego_vel'].reshape(-1, 1), bev=batch['bev'], label=batch['label'],
+                 depth=batch['depth'], semantic=batch['semantic'])
+    model_cpu.total_loss(losses, cfg).backward()
+    rp = dict(ref.named_parameters())
+    n = 0
+    for name, p in prod.named_parameters():
+        if name.startswith("head.") or name.startswith("pred_bev.") or name.startswith("_model.up_conv3."):
+            g = rp[name].grad if rp[name].grad is not None else torch.zeros_like(rp[name])
+            scale = max(1e-6, g.abs().max().item())
+            err = (p.grad.detach().cpu() - g).abs().max().item()
+            assert err <= 2e-3 * scale + 1e-7, (name, err, scale)
+            n += 1
+    assert n == 34, n

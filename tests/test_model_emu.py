@@ -36,6 +36,8 @@ def test_engine_two_steps_match_oracle_adamw():
     prod, ref = mc.build_pair(cfg, "regnety_tiny", "cpu")
     eng = Engine(prod, cfg, lr=1e-3)
     assert prod._model.transformer1.blocks[0].attn.fused() is not None, "arena must make k/q/v adjacent"
+    from transfuser_amd.model import merged_head_convs
+    assert merged_head_convs(prod) is not None, "arena must make the eight 3x3 head convolutions adjacent (one 64 -> 512 convolution)"
     opt = torch.optim.AdamW(ref.parameters(), lr=1e-3)
     batch = mc.small_batch(2, 32, 64, 64, 40)
     prod.train(); ref.train()
@@ -416,3 +418,8 @@ def test_remaining_block_gradients_within_1e3_tiny():
     """The logic of the -m gpu test of the same name at tiny widths: stride-1 bottleneck, both stems, FPN top_down, join MLP + GRU, one
     geometric-fusion stage - outputs, input gradients and every parameter gradient within 1e-3 (max norm) of PyTorch-CPU autograd."""
     mc.check_remaining_blocks("cpu", full=False)
+
+
+@pytest.mark.parametrize("weights", mc.MERGED_HEAD_WEIGHTS, ids=str)
+def test_engine_merged_head_convolution_gradients(weights):
+    mc.check_merged_heads("cpu", weights)

@@ -750,3 +750,10 @@ def _rccl_single_rank_body():
         torch.cuda.synchronize()
     finally:
         pass        # no destroy_process_group(): the caller leaves the process right after the success marker (see the test's docstring)
+
+
+@pytest.mark.parametrize("weights", mc.MERGED_HEAD_WEIGHTS, ids=str)
+def test_engine_merged_head_convolution_gradients(weights):
+    """One 64 -> 512 convolution for the seven CenterNet heads + pred_bev inside the Engine (model.merged_head_convs): head / pred_bev / up_conv3
+    gradients vs the oracle for the reference's zero-weight heads (live prefix), no zero weights, and a zero weight in the middle."""
+    mc.check_merged_heads("cuda", weights)

@@ -253,7 +253,6 @@ struct GemmEpi {
     // set at launch time to the number of parts this launch writes (0: the chosen plan cannot produce them - caller falls back).
     float* stat = nullptr; long stat_ld = 0; int* stat_nparts = nullptr;
     int prec = 0;                    // 0: exact fp32 MFMA; 1: operands rounded to bf16 on the LDS->register path, bf16 MFMA, fp32 accumulate; 2: bf16x3 split (fp32-accurate, 6 bf16 MFMAs); 3: as 1 with IEEE-half operands (set by launch_cfg)
-    int stagger = 0;                 // experiment (TF_GEMM_STAGGER=1): co-resident workgroups take distinct static issue priorities (s_setprio by dispatch round) so their load / LDS-write / barrier phases stop coinciding
     int packed16 = 0;                // LDS-DMA kernels, both operands K-contiguous: the operands ARE 16-bit matrices (1: bf16, 2: IEEE half) described in units of
                                      // 4 bytes (ld, cols, K = halves / 2): tiles are moved as bytes, one ds_read_b128 = one 8-deep MFMA operand (tf_gemm16_nt_f32)
 };
@@ -361,14 +360,6 @@ __device__ __forceinline__ void gemm_tile(LA& la, LB& lb, const GemmEpi& ep, int
     constexpr int NLA = (BM * KQ + NT - 1) / NT, NLB = (BN * KQ + NT - 1) / NT;   // float4 slots per thread
 
     const int tid = threadIdx.x;
-    if (ep.stagger) {         // waves of the (up to four) workgroups resident on a CU belong to different dispatch rounds of 256 CUs: one priority level each
-        switch ((blockIdx.x >> 8) & 3) {
-            case 1: TF_SETPRIO(1); break;
-            case 2: TF_SETPRIO(2); break;
-            case 3: TF_SETPRIO(3); break;
-            default: break;
-        }
-    }
     const int z = blk_z;      // (blk_x, blk_y, blk_z): the block's coordinates in ITS problem's grid (= blockIdx in gemm_kernel; decoded from a shared grid in gemm_pair_kernel)
     la.set_batch(z);
     lb.set_batch(z);
@@ -820,10 +811,6 @@ inline CfgGeom cfg_geom(const GemmEpi& ep, int M, int N, int K, int splitk, int 
     c.epg = ep;
     c.epg.prec = gemm_precision();
     {
-        static const int stg = [] { const char* e = getenv("TF_GEMM_STAGGER"); return e ? atoi(e) : 0; }();
-        c.epg.stagger = stg;
-    }
-    {
         static const int forced = [] { const char* e = getenv("TF_GROUP_M"); return e ? atoi(e) : 0; }();
         long panel = (long)BM * (kchunk < K ? kchunk : K) * 4;          // bytes of one A panel of this launch
         int g = (int)((2L << 20) / (panel > 0 ? panel : 1));            // as many tile-rows as keep their A panels in ~half the L2
@@ -862,15 +849,6 @@ inline void launch_plan(const GemmPlan& p, const LA& la, const LB& lb, const Gem
         if (p.bk == 32) launch_cfg<BM_, BN_, WM_, 32, LA, A_KC, LB, B_KC>(la, lb, ep, M, N, K, batch, sk, stream); \
         else launch_cfg<BM_, BN_, WM_, 16, LA, A_KC, LB, B_KC>(la, lb, ep, M, N, K, batch, sk, stream);       \
     } while (0)
-    if constexpr (std::is_same<LA, PlainOp>::value && std::is_same<LB, PlainOp>::value) {
-        // experiment (TF_GEMM_PF2=1): the 64 x 64 plain-operand tiles with prefetch distance 2 (tile kt + 2 requested while tile kt is multiplied)
-        static const bool pf2 = [] { const char* e = getenv("TF_GEMM_PF2"); return e && atoi(e) != 0; }();
-        if (pf2 && p.bm == 64 && p.bn == 64 && la.vec && lb.vec) {
-            if (p.bk == 32) launch_cfg<64, 64, 2, 32, LA, A_KC, LB, B_KC, 256, 2>(la, lb, ep, M, N, K, batch, sk, stream);
-            else launch_cfg<64, 64, 2, 16, LA, A_KC, LB, B_KC, 256, 2>(la, lb, ep, M, N, K, batch, sk, stream);
-            return;
-        }
-    }
     if (p.bm == 128) {
         if (p.bn == 32) TF_CFG(128, 32, 4);
         else if (p.bn == 64) TF_CFG(128, 64, 2);

@@ -21,10 +21,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // instruction-scheduling fence for hipcc (nothing may be moved across it); no-op in the host emulation
 #ifdef TF_EMU
 #define TF_SCHED_FENCE() ((void)0)
-#define TF_SETPRIO(n) ((void)0)
 #else
 #define TF_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-#define TF_SETPRIO(n) __builtin_amdgcn_s_setprio(n)      // wave issue priority 0..3 (immediate)
 #endif
 
 // a value every lane of the wave agrees on (wave index, a row pointer's row): keeps it - and the addresses derived from it - in SGPRs

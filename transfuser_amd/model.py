@@ -74,35 +74,81 @@ class LidarCenterNetHead(nn.Module):
         return [getattr(self, n) for n in HEAD_ORDER]
 
 
+# order of the eight 3x3 convolutions on p2 inside the parameter arena (train.ParamArena groups them): the heads that can carry a zero loss
+# weight (velocity, brake - quirk Q6) last, so that the live ones are a PREFIX of the merged 64 -> 512 convolution
+MERGED_ORDER = ("heatmap_head", "wh_head", "offset_head", "yaw_class_head", "yaw_res_head", "pred_bev", "velocity_head", "brake_head")
+
+
+def merged_head_convs(model):
+    """(W (8 Ch, C, 3, 3) channels_last, b (8 Ch,), dW, db) - views over the eight first convolutions of the CenterNet heads + pred_bev - when
+    the parameter arena made them adjacent in MERGED_ORDER (one 64 -> 512 convolution instead of eight 64 -> 64 ones); None
+    otherwise (plain torch parameters: the per-head path)."""
+    seqs = [getattr(model.head, n) if n != "pred_bev" else model.pred_bev for n in MERGED_ORDER]
+    ws, bs = [sq[0].weight for sq in seqs], [sq[0].bias for sq in seqs]
+    w0 = ws[0]
+    key = (w0.data_ptr(), w0.grad.data_ptr() if w0.grad is not None else 0, bs[0].data_ptr())
+    cached = getattr(model, "_merged_heads", None)
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    out = None
+    if all(p.grad is not None for p in ws + bs) and all(w.shape == w0.shape and w.permute(0, 2, 3, 1).is_contiguous() for w in ws):
+        def adjacent(ts):
+            return all(ts[i + 1].data_ptr() == t.data_ptr() + t.numel() * 4 for i, t in enumerate(ts[:-1])) and \
+                ts[0].untyped_storage().data_ptr() == ts[-1].untyped_storage().data_ptr()
+        if adjacent(ws) and adjacent(bs) and adjacent([p.grad for p in ws]) and adjacent([p.grad for p in bs]):
+            Ch, C = w0.shape[0], w0.shape[1]
+            n = len(ws)
+            wview = lambda t: torch.as_strided(t, (n * Ch, C, 3, 3), (9 * C, 1, 3 * C, C), t.storage_offset())
+            bview = lambda t: torch.as_strided(t, (n * Ch,), (1,), t.storage_offset())
+            out = (wview(w0.data), bview(bs[0].data), wview(w0.grad), bview(bs[0].grad))
+    model._merged_heads = (key, out)
+    return out
+
+
 @F_.routes_param_grads
 class HeadsFn(torch.autograd.Function):
     """The 7 CenterNet heads + pred_bev on p2 in one autograd node (model.py:127-147,581-585,759):
     8 x [conv3x3 64->64 + ReLU + conv1x1]; head outputs are packed as (B,h,w,9+bins) logits
-    [hm, wh(2), off(2), yaw_cls(bins), yaw_res, vel, brake(2)] for the fused loss kernel."""
+    [hm, wh(2), off(2), yaw_cls(bins), yaw_res, vel, brake(2)] for the fused loss kernel.
+    Inside train.Engine the eight 3x3 convolutions are ONE 64 -> 512 convolution over the arena-adjacent weights (merged_head_convs), its
+    backward one weight-gradient and one input-gradient launch over the live heads' channels (a prefix of the 512)."""
 
     @staticmethod
     def forward(ctx, p2, model, *params):
         B, H, W, C = p2.shape
         seqs = model.head.heads() + [model.pred_bev]
+        names = list(HEAD_ORDER) + ["pred_bev"]
         P = model.head.pred_channels
         pred = torch.empty(B, H, W, P, dtype=torch.float32, device=p2.device)
         bev = torch.empty(B, H, W, seqs[-1][2].weight.shape[0], dtype=torch.float32, device=p2.device)
+        merged = merged_head_convs(model) if F_._INPLACE else None
+        hid_all = None
+        if merged is not None:
+            hid_all = ops.conv_fwd(p2, merged[0], merged[1], 1, 1, 1, relu=True)          # (B, H, W, 8 Ch)
+            Ch = seqs[0][0].weight.shape[0]
+            hid2 = hid_all.view(-1, hid_all.shape[-1])
         hids, off = [], 0
         for i, sq in enumerate(seqs):
-            hid = ops.conv_fwd(p2, sq[0].weight, sq[0].bias, 1, 1, 1, relu=True)
+            if merged is not None:
+                j = MERGED_ORDER.index(names[i])
+                h2 = hid2[:, j * Ch:(j + 1) * Ch]                                          # row stride 8 Ch
+            else:
+                hid = ops.conv_fwd(p2, sq[0].weight, sq[0].bias, 1, 1, 1, relu=True)
+                h2 = hid.view(-1, hid.shape[-1])
             k = sq[2].weight.shape[0]
             dst = bev.view(-1, k) if i == len(seqs) - 1 else pred.view(-1, P)[:, off:off + k]
-            ops.linear_fwd(hid.view(-1, hid.shape[-1]), F_.w2d(sq[2].weight), sq[2].bias, out=dst)
+            ops.linear_fwd(h2, F_.w2d(sq[2].weight), sq[2].bias, out=dst)
             if i < len(seqs) - 1:
                 off += k
-            hids.append(hid)
-        ctx.saved = (p2, model, hids)
+            hids.append(h2)
+        ctx.saved = (p2, model, hids, merged)
         return pred, bev
 
     @staticmethod
     def backward(ctx, dpred, dbev):
-        p2, model, hids = ctx.saved
+        p2, model, hids, merged = ctx.saved
         seqs = model.head.heads() + [model.pred_bev]
+        names = list(HEAD_ORDER) + ["pred_bev"]
         B, H, W, C = p2.shape
         P = model.head.pred_channels
         dpred, dbev = dpred.contiguous(), dbev.contiguous()
@@ -111,6 +157,15 @@ class HeadsFn(torch.autograd.Function):
         off = 0
         dead = getattr(model, "_dead_heads", ())   # heads whose loss weight is 0 (config.detailed_losses_weights: velocity, brake - quirk Q6):
         first = True                               # their incoming gradient is exactly 0, so is everything their backward would add
+        Ch = hids[0].shape[-1]
+        dh_all = None
+        if merged is not None:
+            # live heads = a prefix of MERGED_ORDER unless a head in front of the tail is dead too (then every channel is differentiated)
+            live = [n for n in MERGED_ORDER if n not in dead]
+            nlive = len(live) if list(MERGED_ORDER[:len(live)]) == live else len(MERGED_ORDER)
+            dh_all = torch.empty(B * H * W, nlive * Ch, dtype=torch.float32, device=p2.device)
+            if nlive == len(MERGED_ORDER) and dead:
+                dh_all.zero_()
         for i, sq in enumerate(seqs):
             k = sq[2].weight.shape[0]
             last = i == len(seqs) - 1
@@ -118,19 +173,29 @@ class HeadsFn(torch.autograd.Function):
                 off += k
                 continue
             g2 = dbev.view(-1, k) if last else dpred.view(-1, P)[:, off:off + k]
-            hid = hids[i]
-            Ch = hid.shape[-1]
-            ops.linear_wgrad(g2, hid.view(-1, Ch), F_.w2d(F_.gbuf(sq[2].weight)))
+            h2 = hids[i]
+            ops.linear_wgrad(g2, h2, F_.w2d(F_.gbuf(sq[2].weight)))
             if last:
                 F_.bias_grad(g2, sq[2].bias)
             else:
                 ops.axpby(F_.gbuf(sq[2].bias), db_pred[0, off:off + k], 1.0, 1.0, out=F_.gbuf(sq[2].bias))
                 off += k
-            dh = ops.linear_dgrad(g2, F_.w2d(sq[2].weight), mask=hid.view(-1, Ch)).view(B, H, W, Ch)     # ReLU backward in the epilogue
+            if merged is not None:
+                j = MERGED_ORDER.index(names[i])
+                ops.linear_dgrad(g2, F_.w2d(sq[2].weight), out=dh_all[:, j * Ch:(j + 1) * Ch], mask=h2)      # ReLU backward in the epilogue
+                continue
+            dh = ops.linear_dgrad(g2, F_.w2d(sq[2].weight), mask=h2).view(B, H, W, Ch)     # ReLU backward in the epilogue
             F_.bias_grad(dh.view(-1, Ch), sq[0].bias)
             ops.conv_wgrad(dh, p2, F_.gbuf(sq[0].weight), 1, 1, 1)
             ops.conv_dgrad(dh, sq[0].weight, p2.shape, 1, 1, 1, out=dp2, accumulate=not first)
             first = False
+        if merged is not None:
+            n = dh_all.shape[1]
+            W_all, _, dW_all, db_all = merged
+            ops.colsum(dh_all, 1, B * H * W, n, 1.0, out=db_all[:n].view(1, -1), accumulate=True)
+            dh4 = dh_all.view(B, H, W, n)
+            ops.conv_wgrad(dh4, p2, dW_all[:n], 1, 1, 1)
+            ops.conv_dgrad(dh4, W_all[:n], p2.shape, 1, 1, 1, out=dp2)
         ctx.saved = None
         return (dp2, None) + (None,) * (len(ctx.needs_input_grad) - 2)
 

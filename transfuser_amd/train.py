@@ -31,11 +31,21 @@ _ALIGN = 64  # floats (256 B): keeps every parameter 16-byte aligned for float4 
 _KQV = __import__("re").compile(r"(^|\.)attn\.(key|query|value)\.")
 
 
+_HEAD3 = __import__("re").compile(r"(?:^|\.)(?:head\.(\w+_head)|(pred_bev))\.0\.(weight|bias)$")
+
+
 def _group_key(name):
-    """Parameters that must be adjacent: attention key/query/value weights (and biases) per layer."""
+    """Parameters that must be adjacent: attention key/query/value weights (and biases) per layer; the first (3x3) convolutions of the seven
+    CenterNet heads and pred_bev in model.MERGED_ORDER (one 64 -> 512 convolution, model.merged_head_convs)."""
     m = _KQV.search(name)
     if m:
         return name[:m.start(2)] + "KQV" + name[m.end(2):], ("key", "query", "value").index(m.group(2))
+    m = _HEAD3.search(name)
+    if m:
+        from .model import MERGED_ORDER
+        which = m.group(1) or m.group(2)
+        if which in MERGED_ORDER:
+            return name[:m.start()] + "HEADS3x3." + m.group(3), MERGED_ORDER.index(which)
     return name, 0
 
 
