@@ -371,11 +371,6 @@ int tf_centernet_decode_f32(const float* pred, int B, int fh, int fw, int num_di
 int tf_relu_mask_f32(const float* dy, const float* y, float* out, int64_t n, void* stream);
 int tf_sigmoid_f32(const float* x, float* y, int64_t n, void* stream);
 int tf_axpby_f32(const float* a, const float* b, float* out, float alpha, float beta, int64_t n, void* stream);
-/* total = sum_i weights[i] * terms[i][0] over 1..16 device scalars in separate allocations, added in index order, and its backward
- * dterms[i] = weights[i] * dtotal[0] (dtotal NULL = 1): the weighted sum of the 11 detailed losses of train.py:307-311 in one launch per direction.
- * terms / weights are HOST arrays read at call time (graph-capturable: they travel as kernel arguments). */
-int tf_weighted_sum_f32(const float* const* terms, const float* weights, int n, float* out, void* stream);
-int tf_weighted_sum_bwd_f32(const float* dtotal, const float* weights, int n, float* dterms, void* stream);
 /* nn.Dropout with a counter-based RNG keyed by (*seed_dev, site, index); calling it on dy with the
  * same key is the backward (transfuser.py:311,504-505,542). */
 int tf_dropout_f32(const float* x, float* y, int64_t n, const uint32_t* seed_dev, uint32_t site, float p, void* stream);
@@ -402,11 +397,6 @@ int tf_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, float*
 /* The same update with the gradients multiplied by grad_scale on the way in (= 1 / loss scale of the fp16 mode; the loss scale seeds the backward). */
 int tf_adamw_scaled_f32(float* p, const float* g, float* m, float* v, int64_t n, float* state_dev, float beta1, float beta2, float eps, float weight_decay,
                         float grad_scale, void* stream);
-/* One RANGE of the arena; the step counter advances only with tick != 0 (the first range of an optimizer step).  Lets a range whose gradients
- * are final early in the backward be updated beside the rest of the backward (the reference's optimizer.step() runs after loss.backward(),
- * train.py:313-316: same update, same step number, other schedule). */
-int tf_adamw_part_f32(float* p, const float* g, float* m, float* v, int64_t n, float* state_dev, float beta1, float beta2, float eps, float weight_decay,
-                      float grad_scale, int tick, void* stream);
 /* The same update under a DYNAMIC loss scale (fp16 mode; the reference trains fp32 - config.py:55 - and has no counterpart; semantics of
  * torch.cuda.amp.GradScaler): ls_state = {scale, clean steps, found_inf, growth interval} floats on the device.  The call (1) sets found_inf
  * when any of g_check[0 .. n_check) is Inf / NaN (pass the WHOLE reduced gradient arena here, also when p / g / m / v are a ZeRO-1 shard, so

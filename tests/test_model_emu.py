@@ -202,9 +202,7 @@ def test_segmented_backward_equals_single_autograd_graph():
         keys = sorted((cut_key(c) for c in cuts), reverse=True)
         keys = [k for k in keys if not (k[1] == 1 and k[2] >= cfg.n_layer)]       # DEFAULT_CUTS names Blocks 1..3 of GPT-4: this model has 2
         assert list(eng.cuts) == keys
-        akeys = list(eng.arena_cuts)       # what orders the arena: the cuts - or, uncut on one rank, the early-AdamW mark (GPT-4 and everything behind it first)
-        assert akeys == keys or (not keys and akeys == [Engine.EARLY_OPT_MARK] and eng.early_opt)
-        assert eng.n_pieces() == len(keys) + 1 and len(eng.arena.segment_ranges) == len(akeys) + 1
+        assert eng.n_pieces() == len(keys) + 1 and len(eng.arena.segment_ranges) == len(keys) + 1
         out = eng._fwd_bwd(batch)
         grads = {n: p.grad.detach().clone() for n, p in prod.named_parameters()}
         eng.optimizer.step()
@@ -214,7 +212,7 @@ def test_segmented_backward_equals_single_autograd_graph():
         rr = eng.arena.segment_ranges
         assert rr[0][0] == 0 and rr[-1][1] == eng.arena.active_numel and all(a[1] == b[0] for a, b in zip(rr, rr[1:]))
         for n, p, o in eng.arena.layout:
-            k = sum(1 for c in akeys if param_key(n) <= c)
+            k = sum(1 for c in keys if param_key(n) <= c)
             assert rr[k][0] <= o and o + p.numel() <= rr[k][1], (n, k, o, rr)
         if len(keys) >= 3:
             assert all(b - a > 0 for a, b in rr), rr

@@ -150,39 +150,6 @@ extern "C" int tf_axpby_f32(const float* a, const float* b, float* out, float al
     TF_LAUNCH(axpby_kernel, dim3(ew_blocks(n)), dim3(256), stream, a, b, out, alpha, beta, (long)n);
     return launch_status("tf_axpby_f32");
 }
-// total = sum_i w_i * loss_i over <= 16 scalars that live in separate allocations (train.py:307-311: the 11 weighted detailed losses), and its
-// backward d loss_i = w_i * d total: one launch each instead of the ~20 0-dim ATen mul / add launches per direction
-namespace {
-struct WSumArgs { const float* p[16]; float w[16]; int n; };
-__global__ void weighted_sum_kernel(WSumArgs a, float* out) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        float s = 0.f;
-        for (int i = 0; i < a.n; ++i) s += a.w[i] * a.p[i][0];      // in index order: the reference's left-to-right Python sum
-        out[0] = s;
-    }
-}
-__global__ void weighted_sum_bwd_kernel(WSumArgs a, const float* g, float* out) {
-    const int i = threadIdx.x;
-    if (blockIdx.x == 0 && i < a.n) out[i] = a.w[i] * (g ? g[0] : 1.f);
-}
-}  // namespace
-extern "C" int tf_weighted_sum_f32(const float* const* terms, const float* weights, int n, float* out, void* stream) {
-    TF_REQUIRE(terms && weights && out && n >= 1 && n <= 16, "tf_weighted_sum_f32: 1..16 terms (got %d)", n);
-    WSumArgs a;
-    for (int i = 0; i < 16; ++i) { a.p[i] = i < n ? terms[i] : nullptr; a.w[i] = i < n ? weights[i] : 0.f; }
-    a.n = n;
-    for (int i = 0; i < n; ++i) TF_REQUIRE(a.p[i], "tf_weighted_sum_f32: null term %d", i);
-    TF_LAUNCH(weighted_sum_kernel, dim3(1), dim3(64), stream, a, out);
-    return launch_status("tf_weighted_sum_f32");
-}
-extern "C" int tf_weighted_sum_bwd_f32(const float* dtotal, const float* weights, int n, float* dterms, void* stream) {
-    TF_REQUIRE(weights && dterms && n >= 1 && n <= 16, "tf_weighted_sum_bwd_f32: 1..16 terms (got %d)", n);
-    WSumArgs a;
-    for (int i = 0; i < 16; ++i) { a.p[i] = nullptr; a.w[i] = i < n ? weights[i] : 0.f; }
-    a.n = n;
-    TF_LAUNCH(weighted_sum_bwd_kernel, dim3(1), dim3(64), stream, a, dtotal, dterms);
-    return launch_status("tf_weighted_sum_bwd_f32");
-}
 extern "C" int tf_sigmoid_f32(const float* x, float* y, int64_t n, void* stream) {
     TF_REQUIRE(x && y && n >= 0, "tf_sigmoid_f32: bad arguments");
     if (n == 0) return 0;
@@ -221,20 +188,11 @@ extern "C" int tf_adamw_f32(float* p, const float* g, float* m, float* v, int64_
                             float weight_decay, void* stream) {
     return tf_adamw_scaled_f32(p, g, m, v, n, state_dev, beta1, beta2, eps, weight_decay, 1.0f, stream);
 }
-extern "C" int tf_adamw_part_f32(float* p, const float* g, float* m, float* v, int64_t n, float* state_dev, float beta1, float beta2, float eps,
-                                 float weight_decay, float grad_scale, int tick, void* stream);
 extern "C" int tf_adamw_scaled_f32(float* p, const float* g, float* m, float* v, int64_t n, float* state_dev, float beta1, float beta2, float eps,
                                    float weight_decay, float grad_scale, void* stream) {
-    return tf_adamw_part_f32(p, g, m, v, n, state_dev, beta1, beta2, eps, weight_decay, grad_scale, 1, stream);
-}
-// one RANGE of the arena: the step counter is advanced only when ``tick`` is set, i.e. by the first range of an optimizer step - a range
-// whose gradients are final early in the backward (the GPT-4 blocks: 65 % of the parameters) can then be updated on a side stream beside
-// the remaining backward (train.Engine), the rest after it, both with the same step number
-extern "C" int tf_adamw_part_f32(float* p, const float* g, float* m, float* v, int64_t n, float* state_dev, float beta1, float beta2, float eps,
-                                 float weight_decay, float grad_scale, int tick, void* stream) {
     TF_REQUIRE(p && g && m && v && state_dev && n >= 0, "tf_adamw_f32: bad arguments");
     TF_REQUIRE(aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v), "tf_adamw_f32: arenas must be 16-byte aligned");
-    if (tick) TF_LAUNCH(adamw_tick_kernel, dim3(1), dim3(64), stream, state_dev, (const float*)nullptr);
+    TF_LAUNCH(adamw_tick_kernel, dim3(1), dim3(64), stream, state_dev, (const float*)nullptr);
     if (n > 0) TF_LAUNCH(adamw_kernel, dim3(ew_blocks(n / 4 + 1, 8192)), dim3(256), stream, p, g, m, v, (long)(n / 4), (long)n, (const float*)state_dev,
                          beta1, beta2, eps, weight_decay, grad_scale, (const float*)nullptr);
     return launch_status("tf_adamw_f32");

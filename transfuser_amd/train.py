@@ -31,7 +31,6 @@ _ALIGN = 64  # floats (256 B): keeps every parameter 16-byte aligned for float4 
 _KQV = __import__("re").compile(r"(^|\.)attn\.(key|query|value)\.")
 
 
-EARLY_OPT = os.environ.get("TF_EARLY_OPT", "1") != "0"      # A/B switch: AdamW of the first-finished arena segment beside the backward (Engine.early_opt)
 _HEAD3 = __import__("re").compile(r"(?:^|\.)(?:head\.(\w+_head)|(pred_bev))\.0\.(weight|bias)$")
 
 
@@ -181,29 +180,8 @@ class FlatAdamW:
     def zero_grad(self, set_to_none=False):
         self.arena.zero_grad()
 
-    def step_early(self, rng, stream):
-        """Update arena range ``rng`` NOW, on ``stream`` (ordered after the current stream's work; None: the current stream): its gradients
-        are final although the backward is still running.  The next ``step()`` joins the stream and updates only the rest."""
-        assert getattr(self, "_early", None) is None, "step_early twice without step()"
-        if stream is None:        # host emulation of the kernels (tests): same launches, no streams
-            self.step_range(rng[0], rng[1], tick=True)
-        else:
-            stream.wait_stream(torch.cuda.current_stream(self.arena.params.device))
-            with torch.cuda.stream(stream):
-                self.step_range(rng[0], rng[1], tick=True)
-        self._early = (rng, stream)
-
     def step(self):
         a = self.arena
-        early = getattr(self, "_early", None)
-        if early is not None:       # [lo, hi) was updated beside the backward (step_early): join, then the rest with the same step number
-            self._early = None
-            (lo, hi), stream = early
-            if stream is not None:
-                torch.cuda.current_stream(a.params.device).wait_stream(stream)
-            self.step_range(self.lo, lo, tick=False)
-            self.step_range(hi, self.hi, tick=False)
-            return
         ls = getattr(self, "ls_state", None)
         if ls is not None:      # fp16 mode with the dynamic loss scale: overflow check over the WHOLE (reduced) gradient arena, skip-or-update, scale update
             ops.adamw_dynscale_(a.params[self.lo:self.hi], a.grads[self.lo:self.hi], self.exp_avg, self.exp_avg_sq, self.state, ls, a.grads[:a.active_numel],
@@ -211,14 +189,6 @@ class FlatAdamW:
             return
         ops.adamw_(a.params[self.lo:self.hi], a.grads[self.lo:self.hi], self.exp_avg, self.exp_avg_sq, self.state, self.betas[0], self.betas[1],
                    self.eps, self.weight_decay, grad_scale=getattr(self, "grad_scale", 1.0))
-
-    def step_range(self, lo, hi, tick):
-        """The update of arena range [lo, hi) only (unsharded optimizer, no dynamic loss scale); ``tick``: this is the first range of the step."""
-        assert self.lo == 0 and getattr(self, "ls_state", None) is None
-        a = self.arena
-        if hi > lo:
-            ops.adamw_(a.params[lo:hi], a.grads[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], self.state, self.betas[0], self.betas[1],
-                       self.eps, self.weight_decay, grad_scale=getattr(self, "grad_scale", 1.0), tick=tick)
 
     def _layout(self):
         """[(parameter name, arena offset, numel)] of the parameters the optimizer updates: what makes a saved state independent of the
@@ -436,19 +406,7 @@ class Engine:
         self.cuts = tuple(k for k in keys if not (k[1] == 1 and k[2] >= nblk))       # a cut in front of a Block the model does not have is dropped
         if can_cut:
             backbone._cuts = frozenset(self.cuts)
-        # Single GPU, uncut backward: the parameters downstream of the stage-4 trunks (the four GPT-4 Blocks = 65 % of all parameters, the neck,
-        # decoders, heads, GRU) have their final gradients as soon as the backward has passed GPT-4's input, a third of the way into it.
-        # Their AdamW update (HBM-bound, 28 B / parameter) then runs on a side stream beside the MFMA-bound backward of stages 4..1 instead
-        # of after it; the arena is ordered for that split (the same grouping the multi-GPU cuts use), the update itself is unchanged.
-        early_layout = (EARLY_OPT and world == 1 and not self.cuts and can_cut and getattr(model, "backbone", "") == "transFuser" and
-                        (next(model.parameters()).is_cuda or ops._lib.is_test_backend()))
-        self.early_opt = early_layout and not (loss_scale is None and ops.get_precision() == "fp16")      # the dynamic loss scale checks the WHOLE gradient arena first
-        self.arena_cuts = self.cuts if not early_layout else (self.EARLY_OPT_MARK,)      # what orders the arena (= the backward cuts, or the early-AdamW mark)
-        self.arena = ParamArena(model, self.arena_cuts)
-        if self.early_opt:
-            backbone._marks = {self.EARLY_OPT_MARK: self._early_opt_cb}
-            self._opt_stream = torch.cuda.Stream(self.arena.params.device) if self.arena.params.is_cuda else None
-        self._early_armed = False
+        self.arena = ParamArena(model, self.cuts)
         self.reducer = GradReducer(self.arena, group, bucket_mb, grad_dtype)
         self.zero = bool(zero_redundancy_optimizer) and self.reducer.world > 1      # train.py:143-146
         rank = dist.get_rank(group) if self.zero else 0
@@ -499,20 +457,11 @@ class Engine:
         with _F.inplace_param_grads(), ops.lowp_managed():
             return self._piece_impl(i)
 
-    EARLY_OPT_MARK = (4, 0, 0)      # cut key "between the stage-4 trunks and GPT 4" (transfuser._FusionBackbone._cut)
-
-    def _early_opt_cb(self):
-        """Backward hook at EARLY_OPT_MARK (functions.MarkFn): AdamW over the first-finished arena segment on the optimizer side stream."""
-        if not self._early_armed:
-            return
-        self._early_armed = False
-        self.optimizer.step_early(self.arena.segment_ranges[0], self._opt_stream)
-
     def _opt_step(self):
         """AdamW over the arena, then the 16-bit weight copies of the storage modes are rewritten from the updated master weights.  With
         ZeRO-1 a rank only holds ITS shard's update at this point: the copies are rewritten after the parameter all-gather instead
         (``_after_opt``), otherwise the cached copies of the other ranks' shards would lag one step and differ from rank to rank."""
-        self.optimizer.step()       # (a segment updated early by _early_opt_cb is joined and skipped there)
+        self.optimizer.step()
         if ops.lowp_storage() and not self.zero:
             ops.lowp_refresh_weights()
 
@@ -524,17 +473,12 @@ class Engine:
                 ops.lowp_refresh_weights()
 
     def _piece0_impl(self, data):
-        self._early_armed = self.early_opt and torch.is_grad_enabled()
         self.optimizer.zero_grad()
         losses = self.load_data_compute_loss(data)
-        keys = list(losses)                  # train.py:307-311: loss = sum of weight * detailed loss, in dictionary order - one launch per direction
-        if ops._AB_WSUM and 1 <= len(keys) <= 16 and all(v.dim() == 0 and v.dtype == torch.float32 and v.is_contiguous() for v in losses.values()):
-            loss = _F.WeightedSumFn.apply(tuple(self.detailed_weights[k] for k in keys), *[losses[k] for k in keys])
-        else:
-            loss = None
-            for key, value in losses.items():
-                term = self.detailed_weights[key] * value
-                loss = term if loss is None else loss + term
+        loss = None
+        for key, value in losses.items():   # train.py:307-311
+            term = self.detailed_weights[key] * value
+            loss = term if loss is None else loss + term
         if self.ls_state is not None:
             loss.backward(self._seed_grad)
         elif self.loss_scale != 1.0:

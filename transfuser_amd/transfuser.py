@@ -201,7 +201,6 @@ class _FusionBackbone(nn.Module):
     #   (i, 1, j)  inside GPT i in front of Block j (the token matrix; j = 0: between the embedding and Block 0).
     # Forward order of the keys = their tuple order; an int c is shorthand for (c, 2, 0).
     _cuts = frozenset()
-    _marks = {}         # cut key -> callable: train.Engine is told (in the backward) that the gradients have passed this point (functions.MarkFn)
 
     @staticmethod
     def cut_key(c):
@@ -215,9 +214,6 @@ class _FusionBackbone(nn.Module):
         hit = key in self._cuts
         if tensors is None:
             return hit
-        cb = self._marks.get(key)
-        if cb is not None and torch.is_grad_enabled() and tensors[0].requires_grad:
-            tensors = F_.MarkFn.apply(cb, *tensors)
         if not (hit and torch.is_grad_enabled() and tensors[0].requires_grad):
             return tensors
         leaves = tuple(l if l is not None else t.detach().requires_grad_(True) for t, l in zip(tensors, leaves or (None,) * len(tensors)))
