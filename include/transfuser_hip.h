@@ -371,6 +371,11 @@ int tf_centernet_decode_f32(const float* pred, int B, int fh, int fw, int num_di
 int tf_relu_mask_f32(const float* dy, const float* y, float* out, int64_t n, void* stream);
 int tf_sigmoid_f32(const float* x, float* y, int64_t n, void* stream);
 int tf_axpby_f32(const float* a, const float* b, float* out, float alpha, float beta, int64_t n, void* stream);
+/* total = sum_i weights[i] * terms[i][0] over 1..16 device scalars in separate allocations, added in index order, and its backward
+ * dterms[i] = weights[i] * dtotal[0] (dtotal NULL = 1): the weighted sum of the 11 detailed losses of train.py:307-311 in one launch per direction.
+ * terms / weights are HOST arrays read at call time (graph-capturable: they travel as kernel arguments). */
+int tf_weighted_sum_f32(const float* const* terms, const float* weights, int n, float* out, void* stream);
+int tf_weighted_sum_bwd_f32(const float* dtotal, const float* weights, int n, float* dterms, void* stream);
 /* nn.Dropout with a counter-based RNG keyed by (*seed_dev, site, index); calling it on dy with the
  * same key is the backward (transfuser.py:311,504-505,542). */
 int tf_dropout_f32(const float* x, float* y, int64_t n, const uint32_t* seed_dev, uint32_t site, float p, void* stream);

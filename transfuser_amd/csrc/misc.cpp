@@ -150,6 +150,39 @@ extern "C" int tf_axpby_f32(const float* a, const float* b, float* out, float al
     TF_LAUNCH(axpby_kernel, dim3(ew_blocks(n)), dim3(256), stream, a, b, out, alpha, beta, (long)n);
     return launch_status("tf_axpby_f32");
 }
+// total = sum_i w_i * loss_i over <= 16 scalars that live in separate allocations (train.py:307-311: the 11 weighted detailed losses), and its
+// backward d loss_i = w_i * d total: one launch each instead of the ~20 0-dim ATen mul / add launches per direction
+namespace {
+struct WSumArgs { const float* p[16]; float w[16]; int n; };
+__global__ void weighted_sum_kernel(WSumArgs a, float* out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float s = 0.f;
+        for (int i = 0; i < a.n; ++i) s += a.w[i] * a.p[i][0];      // in index order: the reference's left-to-right Python sum
+        out[0] = s;
+    }
+}
+__global__ void weighted_sum_bwd_kernel(WSumArgs a, const float* g, float* out) {
+    const int i = threadIdx.x;
+    if (blockIdx.x == 0 && i < a.n) out[i] = a.w[i] * (g ? g[0] : 1.f);
+}
+}  // namespace
+extern "C" int tf_weighted_sum_f32(const float* const* terms, const float* weights, int n, float* out, void* stream) {
+    TF_REQUIRE(terms && weights && out && n >= 1 && n <= 16, "tf_weighted_sum_f32: 1..16 terms (got %d)", n);
+    WSumArgs a;
+    for (int i = 0; i < 16; ++i) { a.p[i] = i < n ? terms[i] : nullptr; a.w[i] = i < n ? weights[i] : 0.f; }
+    a.n = n;
+    for (int i = 0; i < n; ++i) TF_REQUIRE(a.p[i], "tf_weighted_sum_f32: null term %d", i);
+    TF_LAUNCH(weighted_sum_kernel, dim3(1), dim3(64), stream, a, out);
+    return launch_status("tf_weighted_sum_f32");
+}
+extern "C" int tf_weighted_sum_bwd_f32(const float* dtotal, const float* weights, int n, float* dterms, void* stream) {
+    TF_REQUIRE(weights && dterms && n >= 1 && n <= 16, "tf_weighted_sum_bwd_f32: 1..16 terms (got %d)", n);
+    WSumArgs a;
+    for (int i = 0; i < 16; ++i) { a.p[i] = nullptr; a.w[i] = i < n ? weights[i] : 0.f; }
+    a.n = n;
+    TF_LAUNCH(weighted_sum_bwd_kernel, dim3(1), dim3(64), stream, a, dtotal, dterms);
+    return launch_status("tf_weighted_sum_bwd_f32");
+}
 extern "C" int tf_sigmoid_f32(const float* x, float* y, int64_t n, void* stream) {
     TF_REQUIRE(x && y && n >= 0, "tf_sigmoid_f32: bad arguments");
     if (n == 0) return 0;

@@ -1134,19 +1134,27 @@ class L1Fn(torch.autograd.Function):
 
 
 class CenterNetLossFn(torch.autograd.Function):
-    """get_targets + the 7 CenterNet losses (model.py:150-248,285-374) -> (7,) tensor."""
+    """get_targets + the 7 CenterNet losses (model.py:150-248,285-374) -> 7 scalars (views of one (7,) tensor: indexing a (7,) output
+    instead cost a select_backward - zeros + copy - and an accumulation launch per loss in the backward)."""
 
     @staticmethod
     def forward(ctx, pred, label, nbins, ratio_w, ratio_h):
         B, fh, fw, _ = pred.shape
         tgtf, tgti, cnt = ops.centernet_targets(label, fh, fw, ratio_w, ratio_h, nbins)
         ctx.saved = (pred, tgtf, tgti, cnt, nbins)
-        return ops.centernet_loss_fwd(pred, tgtf, tgti, cnt, nbins)
+        out = ops.centernet_loss_fwd(pred, tgtf, tgti, cnt, nbins)
+        return tuple(out[i] for i in range(out.shape[0]))
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, *gs):
         pred, tgtf, tgti, cnt, nbins = ctx.saved
         ctx.saved = None
+        g0 = gs[0]
+        if all(t.is_contiguous() and t.untyped_storage().data_ptr() == g0.untyped_storage().data_ptr() and t.storage_offset() == g0.storage_offset() + i
+               for i, t in enumerate(gs)):       # WeightedSumFn hands back adjacent elements of one tensor: no gather
+            g = torch.as_strided(g0, (len(gs),), (1,), g0.storage_offset())
+        else:
+            g = torch.stack([t.reshape(()) for t in gs])
         return ops.centernet_loss_bwd(pred, tgtf, tgti, cnt, g.contiguous(), nbins), None, None, None, None
 
 
@@ -1187,4 +1195,21 @@ class WaypointFn(torch.autograd.Function):
         dfused = ops.linear_dgrad(da0, j0.weight)
         ctx.saved = None
         return (dfused, None, None) + (None,) * (len(ctx.needs_input_grad) - 3)
+
+
+
+class WeightedSumFn(torch.autograd.Function):
+    """total = sum_i w_i * loss_i (train.py:307-311) over the detailed losses' 0-dim tensors: one launch forward, one backward, instead of the
+    0-dim ATen multiplies / adds of the Python loop and their autograd nodes.  ``weights`` is a tuple of Python floats."""
+
+    @staticmethod
+    def forward(ctx, weights, *terms):
+        ctx.weights = tuple(float(w) for w in weights)
+        ctx.dev = terms[0].device
+        return ops.weighted_sum([t.detach() for t in terms], ctx.weights)
+
+    @staticmethod
+    def backward(ctx, dtotal):
+        g = ops.weighted_sum_bwd(dtotal.contiguous() if dtotal is not None else None, ctx.weights, ctx.dev)
+        return (None,) + tuple(g[i] for i in range(len(ctx.weights)))
 

@@ -121,7 +121,7 @@ class HeadsFn(torch.autograd.Function):
         P = model.head.pred_channels
         pred = torch.empty(B, H, W, P, dtype=torch.float32, device=p2.device)
         bev = torch.empty(B, H, W, seqs[-1][2].weight.shape[0], dtype=torch.float32, device=p2.device)
-        merged = merged_head_convs(model) if F_._INPLACE else None
+        merged = merged_head_convs(model) if (F_._INPLACE and ops._AB_MERGE_HEADS) else None
         hid_all = None
         if merged is not None:
             hid_all = ops.conv_fwd(p2, merged[0], merged[1], 1, 1, 1, relu=True)          # (B, H, W, 8 Ch)

@@ -44,6 +44,8 @@ def workspace(device):
 # dependency) and are gone.
 GEMM_PAIR = os.environ.get("TF_GEMM_PAIR", "1") != "0"      # A/B switch of the round-5 pair launch
 _pair_open = [False]
+_AB_MERGE_HEADS = os.environ.get("TF_AB_MERGE_HEADS", "1") != "0"      # TEMPORARY same-lease A/B switches of round 5 (removed once measured)
+_AB_WSUM = os.environ.get("TF_AB_WSUM", "1") != "0"
 
 
 class gemm_pair:
@@ -1260,6 +1262,26 @@ def axpby(a, b=None, alpha=1.0, beta=1.0, out=None):
     return out
 
 
+def weighted_sum(terms, weights, out=None):
+    """sum_i weights[i] * terms[i] over <= 16 device scalars (separate allocations), added in index order: one launch."""
+    n = len(terms)
+    if out is None:
+        out = torch.empty((), dtype=torch.float32, device=terms[0].device)
+    arr = (c_p * n)(*[ptr(t) for t in terms])
+    w = (ctypes.c_float * n)(*[float(v) for v in weights])
+    check(L().tf_weighted_sum_f32(arr, w, n, ptr(out), stream_of(terms[0])), "tf_weighted_sum_f32")
+    return out
+
+
+def weighted_sum_bwd(dtotal, weights, device):
+    """(n,) tensor of weights[i] * dtotal (dtotal None = 1): the gradients of weighted_sum's terms."""
+    n = len(weights)
+    out = torch.empty(n, dtype=torch.float32, device=device)
+    w = (ctypes.c_float * n)(*[float(v) for v in weights])
+    check(L().tf_weighted_sum_bwd_f32(ptr(dtotal), w, n, ptr(out), stream_of(out)), "tf_weighted_sum_bwd_f32")
+    return out
+
+
 def dropout(x, seed, site, p, out=None):
     if out is None:
         out = torch.empty_like(x)
@@ -1298,7 +1320,7 @@ def gru_waypoints_bwd(dwp, cache, gru, outl, grads, B, H, pred_len):
 
 
 def adamw_(p, g, m, v, state, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.01, grad_scale=1.0):
-    """grad_scale: the gradients are multiplied by it on the way in (1 / loss scale of the fp16 mode)."""
+    """grad_scale: the gradients are multiplied by it on the way in (1 / loss scale of the fp16 mode; 1 / world of a summed all-reduce)."""
     _h = _hbm_begin()
     if grad_scale != 1.0:
         check(L().tf_adamw_scaled_f32(ptr(p), ptr(g), ptr(m), ptr(v), ctypes.c_int64(p.numel()), ptr(state), ctypes.c_float(beta1), ctypes.c_float(beta2),

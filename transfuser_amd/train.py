@@ -475,10 +475,14 @@ class Engine:
     def _piece0_impl(self, data):
         self.optimizer.zero_grad()
         losses = self.load_data_compute_loss(data)
-        loss = None
-        for key, value in losses.items():   # train.py:307-311
-            term = self.detailed_weights[key] * value
-            loss = term if loss is None else loss + term
+        keys = list(losses)                  # train.py:307-311: loss = sum of weight * detailed loss, in dictionary order - one launch per direction
+        if ops._AB_WSUM and 1 <= len(keys) <= 16 and all(v.dim() == 0 and v.dtype == torch.float32 and v.is_contiguous() for v in losses.values()):
+            loss = _F.WeightedSumFn.apply(tuple(self.detailed_weights[k] for k in keys), *[losses[k] for k in keys])
+        else:
+            loss = None
+            for key, value in losses.items():
+                term = self.detailed_weights[key] * value
+                loss = term if loss is None else loss + term
         if self.ls_state is not None:
             loss.backward(self._seed_grad)
         elif self.loss_scale != 1.0:
