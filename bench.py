@@ -32,19 +32,26 @@ PEAK_F32_MFMA_TF = 157.3                                # /opt/skills/guides/MI3
 PEAK_BF16_MFMA_TF = 2500.0                              # dense bf16 MFMA peak of the same guide (never the 2:1-sparsity figure)
 def _pmc_file(suffix=""):
     """Newest committed rocprofv3 PMC summary of the dominant GEMM (tools/pmc_roofline.sh -> profiles/rNN_pmc_gemm_roofline[_<precision>].json)."""
-    for rnd in ("r04", "r03", "r02"):
+    for rnd in ("r05", "r04", "r03", "r02"):
         f = os.path.join(ROOT, "profiles", "%s_pmc_gemm_roofline%s.json" % (rnd, suffix))
         if os.path.exists(f):
             return f
     return ""
 
 
-def _trace_file(suffix=""):
-    """Newest committed per-kernel summary of a rocprofv3 kernel trace of the graph-replayed bench step (tools/trace_csv_stats.py)."""
-    for name in ("r04_kernel_trace_graph%s.txt", "r04a_kernel_trace_graph%s_mid_round.txt"):
+def _trace_file(suffix="", build_id=None):
+    """Newest committed per-kernel summary of a rocprofv3 kernel trace of the graph-replayed bench step (tools/trace_csv_stats.py) that was
+    measured ON THIS BUILD: the summary's first line names the library it traced ("# build_id <tf_build_id>", written by tools/gpu_round4.sh
+    trace); a summary of another build - or one without that line - is not used (the figure would be stale against this run's FLOPs)."""
+    for name in ("r05_kernel_trace_graph%s.txt", "r04_kernel_trace_graph%s.txt"):
         f = os.path.join(ROOT, "profiles", name % suffix)
         if os.path.exists(f):
-            return f
+            try:
+                first = open(f).readline().split()
+            except OSError:
+                continue
+            if build_id and len(first) == 3 and first[:2] == ["#", "build_id"] and first[2] == build_id:
+                return f
     return ""
 
 
@@ -67,9 +74,13 @@ def parse_args():
                     help="after the timed region: one more step with the optimizer's wait for the all-reduce stream event-timed (per-rank allreduce_exposed_ms), "
                          "then all-gather a checksum of the parameter arena and ASSERT that every replica holds the same parameters (self-diagnosing --gpus N run)")
     ap.add_argument("--grad-dtype", default="fp32", choices=["fp32", "bf16"], help="payload of the gradient all-reduce buckets (bf16 halves the xGMI bytes; the arena stays fp32)")
+    ap.add_argument("--force-pieces", type=int, default=0,
+                    help="N = 1 only: run the MULTI-GPU code path on this one GPU - a world-size-1 RCCL group, the backward cut into this many hipGraph pieces "
+                         "(<= 8 = Engine.DEFAULT_CUTS + 1), every segment's gradient range all-reduced bucket by bucket on the side stream between the replays, the "
+                         "reducer told it has 2 ranks (so the 1 / world scale runs), AdamW waiting for the side stream: what the per-GPU step costs when it is not ONE graph")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-alt", action="store_true", help="skip the extra f32x3 measurement that the default f32 line embeds (N=1 only)")
+    ap.add_argument("--no-alt", action="store_true", help="skip the extra measurements the default f32 line embeds (N=1 only): f32x3, BASELINE configs[2..4], the multi-GPU path on one GPU")
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--emulate-cpu", action="store_true",
                     help="DRY RUN of the multi-rank plumbing on a machine without GPUs (tests/test_distributed_cpu.py): tiny trunks, the HIP kernels "
@@ -122,43 +133,77 @@ def dominant_kernel_roofline(eng, batch, dev, log, peak=PEAK_F32_MFMA_TF, headli
     tot_fl = sum(fl for _, _, fl, _, _ in rows)
     PEAK = peak
     roof = dict(bound="mfma", peak=PEAK, unit="TFLOP/s")
+    # every (call kind, shape) of the step, ranked by the time it takes: the DOMINANT entry is the one with the most step time (round-4 verdict:
+    # not the best-running shape), the five largest are listed; "gemm pair" = a layer's weight + input gradient in one grid (csrc/gemm_pair.cpp)
+    groups = {}
+    for kind, shape, fl, a, b in rows:
+        g = groups.setdefault((kind, tuple(shape)), [0, 0.0, 0.0])
+        g[0] += 1; g[1] += a.elapsed_time(b) * 1e-3; g[2] += fl
+    ranked = sorted(groups.items(), key=lambda kv: -kv[1][1])
+    fmt = lambda k, v: {"call": "%s %s" % (k[0], list(k[1])), "launches_per_step": v[0], "ms_per_step": round(v[1] * 1e3, 3), "gflop_per_launch": round(v[2] / v[0] / 1e9, 3),
+                        "avg_launch_us": round(v[1] / v[0] * 1e6, 2), "tflops": round(v[2] / v[1] / 1e12, 2), "frac": round(v[2] / v[1] / 1e12 / PEAK, 4)}
+    roof["top5"] = [fmt(k, v) for k, v in ranked[:5]]
+    gpt = None
     if dom:
         sec = sum(t for t, _ in dom) / len(dom)
         ach = dom[0][1] / sec / 1e12
-        roof.update(kernel=("tf::gemm_dma_kernel on 16-bit STORED operands (tf_gemm16_nt_f32) on GPT4 [1740x1512].[1512x6048] (mlp.0 forward, mlp.2 input gradient); "
+        gpt = dict(kernel=("tf::gemm_dma_kernel on 16-bit STORED operands (tf_gemm16_nt_f32) on GPT4 [1740x1512].[1512x6048] (mlp.0 forward, mlp.2 input gradient); "
                             if dom16 else "tf::gemm_kernel / tf::gemm_dma_kernel (autotuned plan) on GPT4 mlp.0 forward: [1740x1512].[1512x6048], bias+ReLU epilogue; ") +
                            "average of its %d launches inside one eager training step" % len(dom),
                     achieved=round(ach, 2), frac=round(ach / PEAK, 4), flops_per_launch=dom[0][1], avg_launch_us=round(sec * 1e6, 2))
-    else:   # other backbones / shapes: the engine aggregate is the roofline entry
-        ach = tot_fl / tot_s / 1e12
-        roof.update(kernel="all MFMA-engine launches of one eager training step (plain GEMMs + implicit-GEMM convolutions)",
-                    achieved=round(ach, 2), frac=round(ach / PEAK, 4), flops_per_launch=None, avg_launch_us=None)
+        roof["gpt4_mlp0"] = gpt      # the best-running large GEMM of the step (the row earlier rounds quoted as THE roofline kernel): kept as one row
+    if ranked:
+        k, v = ranked[0]
+        roof.update(kernel="%s %s (m, n, k, batch | B, Hi, Wi, Cin, Cout, ks, stride, groups): the MFMA-engine call with the most time in the step - %d launches, "
+                           "%.2f ms of the %.2f ms the engine takes in one eager training step; HIP events around each launch on its stream" %
+                           (k[0], list(k[1]), v[0], v[1] * 1e3, tot_s * 1e3),
+                    achieved=round(v[2] / v[1] / 1e12, 2), frac=round(v[2] / v[1] / 1e12 / PEAK, 4), flops_per_launch=v[2] / v[0], avg_launch_us=round(v[1] / v[0] * 1e6, 2))
     roof.update(engine_calls=len(rows), engine_ms_per_step=round(tot_s * 1e3, 2), engine_tflops=round(tot_fl / tot_s / 1e12, 2),
                 engine_frac=round(tot_fl / tot_s / 1e12 / PEAK, 4))
     # The event-timed figure above is an EAGER step: every one of ~700 engine launches carries its host launch gap.  The timed region replays
     # hipGraphs; the engine kernels' durations there come from the committed rocprofv3 kernel trace of this command (tools/gpu_round4.sh trace).
-    tr = _trace_file("" if peak == PEAK_F32_MFMA_TF else "_" + ops.get_precision())
+    try:
+        bid = ops.L().tf_build_id().decode()
+    except Exception:
+        bid = None
+    tr = _trace_file("" if peak == PEAK_F32_MFMA_TF else "_" + ops.get_precision(), bid)
+    if not tr and headline_workload:
+        roof["engine_graph"] = None      # no kernel-trace summary of THIS build is committed (profiles/r05_kernel_trace_graph*.txt names the build it traced)
     if tr and dom and headline_workload:      # the committed trace is of configs[1] (transFuser, B = 10, 256 x 704)
         try:
             import re
             m = re.search(r"gemm engine[^,]*? ([0-9.]+)", open(tr).read())
             ms = float(m.group(1))
             roof["engine_graph"] = {"ms_per_step": ms, "tflops": round(tot_fl / ms / 1e9, 2), "frac": round(tot_fl / ms / 1e9 / PEAK, 4),
-                                    "source": "profiles/%s: sum of the engine kernels' durations per step in the rocprofv3 --kernel-trace of the hipGraph replay "
-                                              "(B = 10, 256 x 704); FLOPs = this run's census" % os.path.basename(tr)}
+                                    "source": "profiles/%s (traced on this build, %s): sum of the engine kernels' durations per step in the rocprofv3 --kernel-trace of the "
+                                              "hipGraph replay (B = 10, 256 x 704); FLOPs = this run's census" % (os.path.basename(tr), bid)}
         except Exception as e:
             roof["engine_graph"] = {"error": "unreadable %s: %s" % (tr, e)}
     roof["traffic"], roof["traffic_source"] = None, "no PMC summary committed"
     pmc_file = _pmc_file("" if peak == PEAK_F32_MFMA_TF else "_f32x3" if peak < PEAK_BF16_MFMA_TF else "_" + ops.get_precision())
-    if pmc_file and os.path.exists(pmc_file) and dom:
+    if pmc_file and os.path.exists(pmc_file) and gpt is not None:
         try:
             pmc = json.load(open(pmc_file))
-            roof["traffic"] = int(pmc["traffic_bytes_per_launch"])
-            roof["traffic_source"] = "profiles/%s: %s" % (os.path.basename(pmc_file), pmc.get("note", ""))
+            gpt["traffic"] = int(pmc["traffic_bytes_per_launch"])
+            gpt["traffic_source"] = "profiles/%s: %s" % (os.path.basename(pmc_file), pmc.get("note", ""))
             if pmc.get("mfma_busy_frac") is not None:
-                roof["mfma_busy_frac_pmc"] = pmc["mfma_busy_frac"]
+                gpt["mfma_busy_frac_pmc"] = pmc["mfma_busy_frac"]
         except Exception as e:   # a malformed summary must not kill the bench line
-            roof["traffic_source"] = "unreadable %s: %s" % (pmc_file, e)
+            gpt["traffic_source"] = "unreadable %s: %s" % (pmc_file, e)
+    # counter traffic of the DOMINANT call: the trunk table (tools/pmc_trunk.sh -> profiles/r05_pmc_trunk.json) when it holds that shape
+    trunk = os.path.join(ROOT, "profiles", "r05_pmc_trunk.json")
+    if ranked and os.path.exists(trunk) and peak == PEAK_F32_MFMA_TF:
+        try:
+            k = ranked[0][0]
+            want = {"gemm a0b0": "nt", "gemm a0b1": "nn", "gemm a1b1": "tn"}.get(k[0])
+            m, n, kk = (k[1][0], k[1][1], k[1][2]) if want != "tn" else (k[1][2], k[1][0], k[1][1])
+            for row in json.load(open(trunk)):
+                if want and row["case"] == "gemm %s (%d,%d,%d)" % (want, m, n, kk) and row.get("traffic_bytes"):
+                    roof["traffic"] = int(row["traffic_bytes"])
+                    roof["traffic_source"] = ("profiles/r05_pmc_trunk.json: 2 x FETCH_SIZE + WRITE_SIZE per call (rocprofv3 --pmc, separate passes, gfx950 correction); "
+                                              "algorithmic %.1f MB; MFMA busy %.2f" % (row["algorithmic_bytes"] / 1e6, row.get("mfma_busy_frac") or -1))
+        except Exception as e:
+            roof["traffic_source"] = "unreadable %s: %s" % (trunk, e)
     log("in-step roofline census done (%d engine launches)" % len(rows))
     return roof
 
@@ -319,6 +364,47 @@ def alt_precision_line(args, log):
         return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
+def child_line(extra, log, what, timeout=600):
+    """One more bench line from a CHILD process on the same box (own process: own RCCL group / precision / plans; never kills the headline)."""
+    torch_free()
+    cmd = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--no-alt"] + extra
+    try:
+        out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=timeout).stdout.decode().strip().splitlines()
+        d = json.loads(out[-1])
+        log("%s: %.2f ms/step" % (what, d["ms_per_step"]))
+        return d
+    except Exception as e:
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+
+
+def baseline_config_lines(args, log):
+    """BASELINE.json configs[2..4] on this GPU (one rank each; their 8-GPU form is the driver's scaling run): driver-observed numbers instead of
+    builder-kept ones.  configs[2] TransFuser bf16 B=10; configs[3] geometric fusion B=12 at 160 x 704 fp32; configs[4] latentTF B=16 fp16."""
+    common = ["--steps", str(args.steps), "--warmup", str(args.warmup), "--dropout", str(args.dropout)]
+    out = {}
+    for key, extra in (("configs[2] TransFuser bf16 B=10", ["--dtype", "bf16"]),
+                       ("configs[3] geometric_fusion B=12 H=160 fp32", ["--backbone", "geometric_fusion", "--batch", "12", "--height", "160"]),
+                       ("configs[4] latentTF B=16 fp16", ["--backbone", "latentTF", "--batch", "16", "--dtype", "fp16"])):
+        d = child_line(common + extra, log, key)
+        out[key] = d if "error" in d else {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "dtype": d["dtype"], "workload": d["config"]["workload"],
+                                           "final_loss": d["config"]["final_loss"], "step_frac_of_fp16_mfma_peak": d["roofline"].get("step_frac_of_fp16_mfma_peak"),
+                                           "roofline_kernel": d["roofline"].get("kernel"), "roofline_frac": d["roofline"].get("frac")}
+    return out
+
+
+def multi_gpu_path_line(args, single_ms, log):
+    """The N > 1 code path priced on ONE GPU (bench.py --force-pieces 8 --check in a child process): 8 hipGraph pieces, eager RCCL all-reduce of
+    every segment on the side stream, AdamW behind it - against this run's single-graph step."""
+    d = child_line(["--steps", str(args.steps), "--warmup", str(args.warmup), "--dropout", str(args.dropout), "--force-pieces", "8", "--check",
+                    "--grad-dtype", args.grad_dtype], log, "multi-GPU path on one GPU (8 pieces)")
+    if "error" in d:
+        return d
+    return {"segmented_ms_per_step": d["ms_per_step"], "single_graph_ms_per_step": round(single_ms, 3), "segmented_minus_single_ms": round(d["ms_per_step"] - single_ms, 3),
+            "backward_pieces": d["check"]["backward_pieces"], "allreduce_exposed_ms": d["check"]["allreduce_exposed_ms"][0], "grad_dtype": d["check"]["grad_dtype"],
+            "note": "world-size-1 RCCL group, the reducer told it has 2 ranks: every segment's arena range is all-reduced in 64 MB buckets on the side stream between the graph "
+                    "replays (identity on one rank, but every launch, event and wait of the 8-GPU step is there); 1 / world rides on AdamW's gradient scale"}
+
+
 def torch_free():
     import torch
     torch.cuda.synchronize()
@@ -409,6 +495,14 @@ def main():
     assert world == args.gpus, "WORLD_SIZE %d != --gpus %d" % (world, args.gpus)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    if args.force_pieces:
+        assert world == 1 and 2 <= args.force_pieces <= len(Engine.DEFAULT_CUTS) + 1, "--force-pieces needs --gpus 1 and 2..%d pieces" % (len(Engine.DEFAULT_CUTS) + 1)
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", str(port))
+        torch.distributed.init_process_group("nccl", rank=0, world_size=1)
     backbone = args.backbone
     B = args.batch or {"transFuser": 10, "geometric_fusion": 12, "latentTF": 16}[backbone]
     H = args.height or (160 if backbone == "geometric_fusion" else 256)
@@ -429,7 +523,13 @@ def main():
     hist_fn = lambda pts: ops.lidar_hist(torch.from_numpy(pts).to(dev)[None])[0].cpu().numpy()
     batch = {k: v.to(dev) for k, v in synthetic_batch(B, H, W, seed=rank, hist_fn=hist_fn).items()}
     log("model + batch on device")
-    eng = Engine(model, cfg, lr=cfg.lr, use_graph=not args.no_graph, precision={"f32": "fp32", "f32x3": "f32x3", "bf16": "bf16", "fp16": "fp16"}[args.dtype], grad_dtype=args.grad_dtype)
+    eng = Engine(model, cfg, lr=cfg.lr, use_graph=not args.no_graph, precision={"f32": "fp32", "f32x3": "f32x3", "bf16": "bf16", "fp16": "fp16"}[args.dtype], grad_dtype=args.grad_dtype,
+                 cuts=Engine.DEFAULT_CUTS[:args.force_pieces - 1] if args.force_pieces else None)
+    if args.force_pieces:      # the reducer behaves as on 2 ranks: all-reduce (identity here) + the mean's scale, on the side stream, between the graph replays
+        eng.reducer.world = 2
+        if eng.reducer.bf16 and eng.reducer._half is None:
+            per = eng.reducer.buckets[0][1] - eng.reducer.buckets[0][0]
+            eng.reducer._half = torch.empty(min(per, eng.arena.numel), dtype=torch.bfloat16, device=dev)
     peak = {"f32": PEAK_F32_MFMA_TF, "f32x3": round(PEAK_BF16_MFMA_TF / 6, 1), "bf16": PEAK_BF16_MFMA_TF, "fp16": PEAK_BF16_MFMA_TF}[args.dtype]
     log("engine ready (arena %.1f M floats, %d backward piece(s))" % (eng.arena.numel / 1e6, eng.n_pieces()))
 
@@ -461,10 +561,12 @@ def main():
     if args.check:      # outside the timed region
         check = replica_check(eng, batch, rank, world, dev, log)
     roof = dominant_kernel_roofline(eng, batch, dev, log, peak, headline_workload=(backbone == "transFuser" and B == 10 and H == 256))      # every rank runs the census step (it contains the collectives); rank 0 reports
-    try:
-        roof_hbm = hbm_rooflines(eng, batch, dev, log)               # the same for the bandwidth-bound kernels north_star names
-    except Exception as e:   # additional evidence only: never kill the headline line
-        roof_hbm = {"error": "%s: %s" % (type(e).__name__, e)}
+    roof_hbm = {"skipped": "single-rank runs only: the census is one more training step with collectives inside a try / except - a rank that failed in it would leave the others in all_reduce"}
+    if world == 1 and not args.force_pieces:
+        try:
+            roof_hbm = hbm_rooflines(eng, batch, dev, log)               # the same for the bandwidth-bound kernels north_star names
+        except Exception as e:   # additional evidence only: never kill the headline line
+            roof_hbm = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = B * world * args.steps / dt
@@ -481,7 +583,7 @@ def main():
                                                               "fp16": "fp16 MFMA contractions, dynamic loss scale with overflow skip (fp32 accumulate / master weights / AdamW; GPT linear layers on half-STORED operands, other contractions round fp32 operands in registers)"}[args.dtype], args.dropout,
                                                                "hipGraph replay" if not args.no_graph else "eager"),
                        "global_batch": B * world, "parallelism": "dp%d" % world, "final_loss": round(loss, 4),
-                       "grad_allreduce": ("RCCL, %d backward segments, %s bucket all-reduce overlapped on a side stream" % (eng.n_pieces(), args.grad_dtype)) if world > 1 else "none (1 rank)"},
+                       "grad_allreduce": ("RCCL, %d backward segments, %s bucket all-reduce overlapped on a side stream" % (eng.n_pieces(), args.grad_dtype)) if (world > 1 or args.force_pieces) else "none (1 rank)"},
         }
         try:      # which sources the measured library was compiled from (sha256 prefix over csrc/ + include/, csrc/api.cpp:tf_build_id)
             res["config"]["build_id"] = ops.L().tf_build_id().decode()
@@ -498,11 +600,17 @@ def main():
         res["roofline_hbm"] = roof_hbm
         if world == 1 and args.dtype == "f32" and not args.no_alt:
             res["f32x3"] = alt_precision_line(args, log)
+            if backbone == "transFuser" and not args.batch and not args.height and not args.no_graph:      # the headline invocation: the other BASELINE configs + the N > 1 path
+                res["configs"] = baseline_config_lines(args, log)
+                res["multi_gpu_path_on_one_gpu"] = multi_gpu_path_line(args, ms, log)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(make_cfg, backbone, H, W)
         print(json.dumps(res), flush=True)
     if world > 1:
         leave_without_teardown()
+    if args.force_pieces:      # a real RCCL group exists: leave without c10d's teardown (see leave_without_teardown)
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":

@@ -390,6 +390,13 @@ def test_fp16_dynamic_loss_scale_skips_overflowed_steps():
         eng.train_step(batch); eng.train_step(batch)                                        # two clean steps: the scale doubles, the counter restarts
         assert float(eng.optimizer.state[0]) == 3.0 and eng.ls_state.tolist()[:3] == [1024.0, 0.0, 0.0]
         assert not torch.equal(eng.arena.params, p1) and torch.isfinite(eng.arena.params).all()
+        # the scale schedule is part of the optimizer state: a resumed run continues it (in place - the backward's seed is a view of the tensor)
+        sd = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in eng.optimizer.state_dict().items()}
+        assert sd["ls_state"].tolist()[:3] == [1024.0, 0.0, 0.0]
+        seed_ptr = eng._seed_grad.data_ptr()
+        eng.ls_state[0] = 4.0; eng.ls_state[1] = 7.0
+        eng.optimizer.load_state_dict(sd)
+        assert eng.ls_state.tolist()[:3] == [1024.0, 0.0, 0.0] and eng._seed_grad.data_ptr() == seed_ptr and float(eng._seed_grad) == 1024.0
     finally:
         ops.set_precision("fp32")
 

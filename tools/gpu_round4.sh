@@ -20,7 +20,7 @@ ab_lib)     # A/B of two builds of the library inside this lease: the build of t
             done ;;
 ab)         for v in $AB_VALUES; do env $AB_VAR=$v timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-alt $BENCH_ARGS 2>/dev/null | bench_line "$AB_VAR=$v"; done ;;
 trace)      (cd /tmp && export TMPDIR=/tmp && timeout 500 rocprofv3 --kernel-trace --stats -d $O/trace_$T -o step --output-format csv -- python $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-alt $BENCH_ARGS > $O/${T}_trace_bench.log 2>&1)
-            python tools/trace_csv_stats.py $O/trace_$T > $O/${T}_kernel_trace_graph${TRACE_TAG}.txt 2>&1; python tools/trace_timeline.py $O/trace_$T > $O/${T}_timeline${TRACE_TAG}.txt 2>&1; head -${TRACE_HEAD:-60} $O/${T}_timeline${TRACE_TAG}.txt
+            python tools/trace_csv_stats.py $O/trace_$T $O/${T}_trace_bench.log > $O/${T}_kernel_trace_graph${TRACE_TAG}.txt 2>&1; python tools/trace_timeline.py $O/trace_$T > $O/${T}_timeline${TRACE_TAG}.txt 2>&1; head -${TRACE_HEAD:-60} $O/${T}_timeline${TRACE_TAG}.txt
             cp $O/trace_$T/*kernel_stats.csv $O/${T}_kernel_stats${TRACE_TAG}.csv 2>/dev/null; rm -rf $O/trace_$T ;;
 check)      timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-alt --check 2>&1 | tail -6 ;;
 pmc_hbm)    timeout 600 bash tools/pmc_hbm.sh $T 2>&1 | tail -24 ;;

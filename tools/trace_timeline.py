@@ -42,7 +42,7 @@ print("last %d steps: wall %.2f ms/step; idle %.2f ms; time with 1 / 2 / 3 / >=4
 qb = collections.defaultdict(float)
 for name, s, e, q in seg: qb[q] += e - s
 print("per queue busy ms/step:", ", ".join("%s: %.2f" % (q, v / n / 1e6) for q, v in sorted(qb.items(), key=lambda kv: -kv[1])))
-fam = lambda name: ("gemm engine" if "gemm_kernel" in name or "gemm_dma" in name else "grouped conv" if "conv3x3_grouped" in name else "direct conv" if ("conv3x3_small" in name or "conv3x3_thin" in name or "stem_direct" in name) else
+fam = lambda name: ("gemm engine" if "gemm_kernel" in name or "gemm_dma" in name or "gemm_pair" in name else "grouped conv" if "conv3x3_grouped" in name else "direct conv" if ("conv3x3_small" in name or "conv3x3_thin" in name or "stem_direct" in name) else
                     "batchnorm" if ("bn_" in name or "BnStat" in name or "BnBwd" in name or "BnRelu" in name) else "attention" if "attention" in name else "se" if "se_" in name or "SeGate" in name else "adamw" if "adamw" in name else "other")
 fc = collections.defaultdict(float); fs = collections.defaultdict(float)
 for name in charged: fc[fam(name)] += charged[name]; fs[fam(name)] += solo[name]

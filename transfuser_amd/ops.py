@@ -44,6 +44,7 @@ def workspace(device):
 # dependency) and are gone.
 GEMM_PAIR = os.environ.get("TF_GEMM_PAIR", "1") != "0"      # A/B switch of the round-5 pair launch
 _pair_open = [False]
+_pair_shapes = []      # (m, n, k, batch, flops) of the calls inside the open bracket (census only)
 _AB_MERGE_HEADS = os.environ.get("TF_AB_MERGE_HEADS", "1") != "0"      # TEMPORARY same-lease A/B switches of round 5 (removed once measured)
 _AB_WSUM = os.environ.get("TF_AB_WSUM", "1") != "0"
 
@@ -56,8 +57,10 @@ class gemm_pair:
         self.on = False
 
     def __enter__(self):
-        self.on = GEMM_PAIR and census is None and not _CHECK and not _pair_open[0] and (self.t.is_cuda or _lib.is_test_backend())
+        self.on = GEMM_PAIR and not _CHECK and not _pair_open[0] and (self.t.is_cuda or _lib.is_test_backend())
         if self.on:
+            self._e = _census_begin()          # the census times the bracket as ONE entry (the held calls launch when it closes)
+            _pair_shapes.clear()
             check(L().tf_gemm_pair_begin(), "tf_gemm_pair_begin")
             _pair_open[0] = True
         return self
@@ -68,6 +71,8 @@ class gemm_pair:
             rc = L().tf_gemm_pair_end(stream_of(self.t))
             if et is None:
                 check(rc, "tf_gemm_pair_end")
+                if self._e is not None and _pair_shapes:
+                    _census_end(self._e, "gemm pair wgrad+dgrad", _pair_shapes[-1][:4], sum(v[4] for v in _pair_shapes))
         return False
 
 
@@ -254,7 +259,7 @@ census = None   # set to a list to record (kind, shape, flops, start_event, end_
 
 
 def _census_begin():
-    if census is None:
+    if census is None or _pair_open[0]:
         return None
     e = torch.cuda.Event(enable_timing=True)
     e.record()
@@ -341,6 +346,8 @@ def gemm(a, b, c, m, n, k, lda, ldb, ldc, a_trans=False, b_trans=False, bias=Non
             if STREAM_K:
                 d.sk_flags = ptr(_sk_flags(c.device))
     _e = _census_begin()
+    if _pair_open[0] and census is not None:
+        _pair_shapes.append((m, n, k, batch, 2.0 * m * n * k * batch))
     if _TRACE_GEMM:      # debugging aid: name every call before it runs and wait for it (TF_TRACE_GEMM=1)
         print("[gemm] m=%d n=%d k=%d a_trans=%d b_trans=%d lda=%d ldb=%d ldc=%d batch=%d acc=%d relu=%d bias=%d res=%d mask=%d ws=%s" % (
             m, n, k, a_trans, b_trans, lda, ldb, ldc, batch, accumulate, relu, bias is not None, res is not None, mask is not None,

@@ -187,8 +187,12 @@ class FlatAdamW:
             ops.adamw_dynscale_(a.params[self.lo:self.hi], a.grads[self.lo:self.hi], self.exp_avg, self.exp_avg_sq, self.state, ls, a.grads[:a.active_numel],
                                 self.betas[0], self.betas[1], self.eps, self.weight_decay)
             return
+        gs = getattr(self, "grad_scale", 1.0)
+        red = getattr(self, "reducer", None)
+        if red is not None and red.defer_scale and red.world > 1:      # the arena holds the all-reduced SUM: the mean's 1 / world rides on the gradient scale
+            gs = gs / red.world
         ops.adamw_(a.params[self.lo:self.hi], a.grads[self.lo:self.hi], self.exp_avg, self.exp_avg_sq, self.state, self.betas[0], self.betas[1],
-                   self.eps, self.weight_decay, grad_scale=getattr(self, "grad_scale", 1.0))
+                   self.eps, self.weight_decay, grad_scale=gs)
 
     def _layout(self):
         """[(parameter name, arena offset, numel)] of the parameters the optimizer updates: what makes a saved state independent of the
@@ -212,7 +216,10 @@ class FlatAdamW:
                 dist.all_gather(parts, mine, group=group)
                 full.append(torch.cat(parts)[:n].clone())
             ea, es = full
-        return dict(exp_avg=ea, exp_avg_sq=es, state=self.state, active_numel=self.arena.active_numel, layout=self._layout())
+        sd = dict(exp_avg=ea, exp_avg_sq=es, state=self.state, active_numel=self.arena.active_numel, layout=self._layout())
+        if getattr(self, "ls_state", None) is not None:      # fp16 mode: {scale, clean steps, found_inf, growth interval} - a resumed run continues the scale schedule
+            sd["ls_state"] = self.ls_state
+        return sd
 
     def load_state_dict(self, sd):
         """Accepts the full state written by ``state_dict`` on any world size / with any backward cuts: the moments are copied parameter
@@ -249,6 +256,8 @@ class FlatAdamW:
                 raise ValueError("optimizer state %s has %d elements, expected %d" % (name, full.numel(), n))
             dst.copy_(full[self.lo:self.hi] if dst.numel() != n else full)
         self.state.copy_(sd["state"])
+        if sd.get("ls_state") is not None and getattr(self, "ls_state", None) is not None:
+            self.ls_state.copy_(sd["ls_state"].to(self.ls_state.device))      # in place: the Engine's backward seed is a view of this tensor
 
 
 class GradReducer:
@@ -271,6 +280,7 @@ class GradReducer:
         assert grad_dtype in ("fp32", "bf16"), grad_dtype
         self.bf16 = grad_dtype == "bf16"
         self._half = torch.empty(min(per, n), dtype=torch.bfloat16, device=arena.grads.device) if self.bf16 and self.world > 1 else None
+        self.defer_scale = False       # fp32 buckets: leave the SUM in the arena, the optimizer multiplies by 1 / world (train.Engine sets it when its AdamW can)
         self._wait_events = None       # (before, after) timing events around the optimizer's wait for the side stream: the EXPOSED all-reduce time
         self.time_waits = False        # bench.py --check turns the event pair on
 
@@ -302,7 +312,8 @@ class GradReducer:
                 ops.cast_f32(h, g[s:e], 1.0 / self.world)
             else:
                 dist.all_reduce(g[s:e], op=dist.ReduceOp.SUM, group=self.group)
-                ops.scale_dev_(g[s:e], None, None, 1.0 / self.world)
+                if not self.defer_scale:      # otherwise AdamW applies 1 / world on its way in (its gradient scale): no launch per bucket
+                    ops.scale_dev_(g[s:e], None, None, 1.0 / self.world)
 
     def reduce_async(self, lo, hi):
         """All-reduce (mean) the gradient range [lo, hi) on the side stream, ordered after everything enqueued so far on the current
@@ -419,6 +430,10 @@ class Engine:
             loss_scale = 65536.0
         self.loss_scale = float(loss_scale if loss_scale is not None else 1.0)
         self.optimizer.grad_scale = 1.0 / self.loss_scale
+        # fp32 gradient buckets: no 1 / world launch per bucket behind the all-reduce, AdamW's gradient scale carries it (the dynamic loss scale
+        # computes its own scale on the device and keeps the per-bucket launch; bf16 buckets scale for free while they are widened)
+        self.optimizer.reducer = self.reducer
+        self.reducer.defer_scale = self.ls_state is None and not self.reducer.bf16
         self._seed_grad = self.ls_state[0] if self.ls_state is not None else None      # a VIEW of the device scale: the update kernel re-seeds the next backward
         self.reducer.broadcast_params()
         w = [1.0] + [0.0] * 10 if wp_only else list(config.detailed_losses_weights)
