@@ -595,20 +595,24 @@ class Engine:
         del snap
         fused_opt = self.reducer.world == 1 and self.n_pieces() == 1
         self._graphs = [torch.cuda.CUDAGraph() for _ in range(self.n_pieces())]
-        with torch.cuda.graph(self._graphs[0]):
+        # With a process group alive, c10d's watchdog THREAD polls the events of the (already finished) warm-up collectives; in the default
+        # "global" capture mode such a query from another thread is an error that kills the process ("operation not permitted when stream is
+        # capturing", seen on the MI355X with a world-size-1 RCCL group).  Thread-local mode restricts the check to the capturing thread.
+        mode = dict(capture_error_mode="thread_local") if (dist.is_available() and dist.is_initialized()) else {}
+        with torch.cuda.graph(self._graphs[0], **mode):
             self._out = self._piece0(self._static)
             if fused_opt:
                 self._opt_step()
                 self._bump_seed()
         pool = self._graphs[0].pool()
         for i in range(1, self.n_pieces()):
-            with torch.cuda.graph(self._graphs[i], pool=pool):
+            with torch.cuda.graph(self._graphs[i], pool=pool, **mode):
                 self._piece(i)
         if fused_opt:
             self._opt_graph = None
         else:
             self._opt_graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._opt_graph, pool=pool):
+            with torch.cuda.graph(self._opt_graph, pool=pool, **mode):
                 self._opt_step()
                 self._bump_seed()
 
