@@ -424,7 +424,8 @@ int tf_lidar_hist_ws_f32(const float* points, const int32_t* num_points, int B, 
  * up; the reference clamps it in scatter_points).  Call order (host reads the two scan totals N, P in between):
  *   tf_pillar_keys_f32  -> keys (B*Nmax; -1 = dropped), keep flags, occupancy grid (B*GX*GY)         [:70-83, first num_points]
  *   tf_exclusive_scan_i32 x2 -> pos = scan(keep) (+N), rank = scan(occ) (+P)                          [torch.unique, :88]
- *   tf_pillar_gather_f32 -> stable compaction pts4 (N,4), inv (N), per-pillar xyz sums + count (P,4), cellkey (P)
+ *   tf_pillar_gather_f32 -> stable compaction pts4 (N,4), inv (N), per-pillar xyz sums + count (P,4) as int64 (coordinates in units of 2^-24 m:
+ *                           integer atomics, so the sums do not depend on the order they land in - run-to-run reproducible), cellkey (P)
  *   tf_pillar_decorate_f32 -> 9 features per point (:54-67, quirk Q15 kept)
  *   [DynamicPointNet: Linear+BN1d+ReLU x2 through tf_gemm_f32 / tf_bn_*]
  *   tf_pillar_scatter_max_f32 -> pillar_feat (P,C) = scatter_max (:32), arg (P,C) = lowest row attaining it
@@ -441,8 +442,8 @@ int tf_pillar_index_scan_i32(const int32_t* keys, int64_t n_points, const int32_
                              int32_t* totals, int32_t* ws, void* stream);
 int tf_exclusive_scan_i32(const int32_t* in, int64_t n, int32_t* out, int32_t* total, int32_t* ws /* n/1024+1 ints */, void* stream);
 int tf_pillar_gather_f32(const float* points, int point_stride, const int32_t* keys, const int32_t* pos, const int32_t* occ, const int32_t* rank,
-                         int64_t n_all, int64_t ncells, int P, float* pts4, int32_t* inv, float* sums, int32_t* cellkey, void* stream);
-int tf_pillar_decorate_f32(const float* pts4, const int32_t* inv, const float* sums, const int32_t* cellkey, int64_t N, int GX, int GY,
+                         int64_t n_all, int64_t ncells, int P, float* pts4, int32_t* inv, int64_t* sums, int32_t* cellkey, void* stream);
+int tf_pillar_decorate_f32(const float* pts4, const int32_t* inv, const int64_t* sums, const int32_t* cellkey, int64_t N, int GX, int GY,
                            float pixels_per_meter, float min_x, float min_y, float* feat, void* stream);
 int tf_pillar_scatter_max_f32(const float* z, const int32_t* inv, int64_t N, int C, int P, float* pillar_feat, int32_t* arg, void* stream);
 int tf_pillar_canvas_f32(const float* pillar_feat, const int32_t* cellkey, int P, int C, int B, int H, int W, int GX, int GY,

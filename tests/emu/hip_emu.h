@@ -58,6 +58,7 @@ static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; ret
 static inline double atomicAdd(double* p, double v) { double o = *p; *p = o + v; return o; }
 static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
+static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }
 static inline int atomicMax(int* p, int v) { int o = *p; if (v > o) *p = v; return o; }
 static inline unsigned atomicMax(unsigned* p, unsigned v) { unsigned o = *p; if (v > o) *p = v; return o; }
 static inline int atomicMin(int* p, int v) { int o = *p; if (v < o) *p = v; return o; }

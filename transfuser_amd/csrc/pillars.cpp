@@ -182,33 +182,62 @@ __global__ void __launch_bounds__(256) pillar_cells_kernel(const int32_t* __rest
         if (occ[i]) cellkey[rank[i]] = (int32_t)i;
 }
 
-// stable compaction of the kept points + inverse indices + per-pillar xyz sums / counts (scatter_mean numerator, :61)
+// stable compaction of the kept points + inverse indices + per-pillar xyz sums / counts (scatter_mean numerator, :61).
+// The sums are FIXED-POINT (2^-24 m) 64-bit integers: integer atomics commute, so the result does not depend on the order the atomics land
+// in (run-to-run reproducible; torch_scatter's fp32 atomics - and this file's until round 4 - are not), and x 2^24 is exact for every
+// |coordinate| >= 0.5 m (fp32 has <= 23 fraction bits there), within 6e-8 m below.  A thread owns FOUR consecutive points: a spinning
+// LiDAR emits a pillar's points back to back, so runs of equal pillars inside the quad are merged in registers and cost one set of atomics.
+constexpr float kPillarFix = 16777216.0f;      // 2^24
 __global__ void __launch_bounds__(256) pillar_gather_kernel(const float* __restrict__ pts, int F, const int32_t* __restrict__ keys,
                                                             const int32_t* __restrict__ pos, const int32_t* __restrict__ rank, long n_all,
-                                                            float* __restrict__ pts4, int32_t* __restrict__ inv, float* __restrict__ sums) {
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n_all; i += (long)gridDim.x * 256) {
-        const int key = keys[i];
-        if (key < 0) continue;
-        const int row = pos[i], r = rank[key];
-        const float x = pts[i * F], y = pts[i * F + 1], z = pts[i * F + 2], w = pts[i * F + 3];
-        *reinterpret_cast<float4*>(pts4 + (long)row * 4) = make_float4(x, y, z, w);
-        inv[row] = r;
-        atomicAdd(sums + (long)r * 4, x);
-        atomicAdd(sums + (long)r * 4 + 1, y);
-        atomicAdd(sums + (long)r * 4 + 2, z);
-        atomicAdd(sums + (long)r * 4 + 3, 1.0f);
+                                                            float* __restrict__ pts4, int32_t* __restrict__ inv, long long* __restrict__ sums) {
+    const long nq = (n_all + 3) / 4;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < nq; q += (long)gridDim.x * 256) {
+        int cur = -1;
+        long long sx = 0, sy = 0, sz = 0, sn = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long i = q * 4 + j;
+            const int key = i < n_all ? keys[i] : -1;
+            int r = -1;
+            if (key >= 0) {
+                r = rank[key];
+                const int row = pos[i];
+                const float x = pts[i * F], y = pts[i * F + 1], z = pts[i * F + 2], w = pts[i * F + 3];
+                *reinterpret_cast<float4*>(pts4 + (long)row * 4) = make_float4(x, y, z, w);
+                inv[row] = r;
+                if (r != cur && cur >= 0) {
+                    atomicAdd(reinterpret_cast<unsigned long long*>(sums + (long)cur * 4), (unsigned long long)sx);
+                    atomicAdd(reinterpret_cast<unsigned long long*>(sums + (long)cur * 4 + 1), (unsigned long long)sy);
+                    atomicAdd(reinterpret_cast<unsigned long long*>(sums + (long)cur * 4 + 2), (unsigned long long)sz);
+                    atomicAdd(reinterpret_cast<unsigned long long*>(sums + (long)cur * 4 + 3), (unsigned long long)sn);
+                    sx = sy = sz = sn = 0;
+                }
+                cur = r;
+                sx += (long long)llrintf(x * kPillarFix); sy += (long long)llrintf(y * kPillarFix); sz += (long long)llrintf(z * kPillarFix); sn += 1;
+            }
+        }
+        if (cur >= 0) {
+            atomicAdd(reinterpret_cast<unsigned long long*>(sums + (long)cur * 4), (unsigned long long)sx);
+            atomicAdd(reinterpret_cast<unsigned long long*>(sums + (long)cur * 4 + 1), (unsigned long long)sy);
+            atomicAdd(reinterpret_cast<unsigned long long*>(sums + (long)cur * 4 + 2), (unsigned long long)sz);
+            atomicAdd(reinterpret_cast<unsigned long long*>(sums + (long)cur * 4 + 3), (unsigned long long)sn);
+        }
     }
 }
 
 // decorate (:54-67): [x, y, z, i, xyz - pillar mean, x - x_center, y - y_center]; quirk Q15: x_center comes from the y index
 // (column 2 of the (b, x_idx, y_idx) rows) + min_x and y_center from the x index + min_y - reproduced literally.
 __global__ void __launch_bounds__(256) pillar_decorate_kernel(const float* __restrict__ pts4, const int32_t* __restrict__ inv,
-                                                              const float* __restrict__ sums, const int32_t* __restrict__ cellkey, long N, int GX,
+                                                              const long long* __restrict__ sums, const int32_t* __restrict__ cellkey, long N, int GX,
                                                               int GY, float ppm, float min_x, float min_y, float* __restrict__ feat) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < N; i += (long)gridDim.x * 256) {
         const float4 p = *reinterpret_cast<const float4*>(pts4 + i * 4);
         const int r = inv[i];
-        const float4 s = *reinterpret_cast<const float4*>(sums + (long)r * 4);
+        const long long* sr = sums + (long)r * 4;
+        const double inv_fix = 1.0 / (double)kPillarFix;
+        float4 s;       // the pillar's coordinate SUMS rounded to fp32 once (the reference accumulates them in fp32, in an unspecified order)
+        s.x = (float)((double)sr[0] * inv_fix); s.y = (float)((double)sr[1] * inv_fix); s.z = (float)((double)sr[2] * inv_fix); s.w = (float)sr[3];
         const float cnt = s.w < 1.f ? 1.f : s.w;
         const int key = cellkey[r];
         const int cy = key % GY, cx = (key / GY) % GX;
@@ -326,23 +355,24 @@ extern "C" int tf_exclusive_scan_i32(const int32_t* in, int64_t n, int32_t* out,
 }
 
 extern "C" int tf_pillar_gather_f32(const float* points, int point_stride, const int32_t* keys, const int32_t* pos, const int32_t* occ,
-                                    const int32_t* rank, int64_t n_all, int64_t ncells, int P, float* pts4, int32_t* inv, float* sums,
+                                    const int32_t* rank, int64_t n_all, int64_t ncells, int P, float* pts4, int32_t* inv, int64_t* sums,
                                     int32_t* cellkey, void* stream) {
     TF_REQUIRE(points && keys && pos && rank && pts4 && inv && sums && cellkey && n_all > 0 && ncells > 0 && P >= 0,
                "tf_pillar_gather_f32: bad arguments");
     if (P == 0) return 0;
-    TF_LAUNCH(fill_i32_kernel, dim3(pl_blocks((long)P * 4)), dim3(256), stream, reinterpret_cast<int32_t*>(sums), (long)P * 4, 0);
+    TF_LAUNCH(fill_i32_kernel, dim3(pl_blocks((long)P * 8)), dim3(256), stream, reinterpret_cast<int32_t*>(sums), (long)P * 8, 0);
     if (occ) TF_LAUNCH(pillar_cells_kernel, dim3(pl_blocks(ncells)), dim3(256), stream, occ, rank, (long)ncells, cellkey);      // NULL: tf_pillar_index_scan_i32 already wrote the cell keys
-    TF_LAUNCH(pillar_gather_kernel, dim3(pl_blocks(n_all)), dim3(256), stream, points, point_stride, keys, pos, rank, (long)n_all, pts4, inv, sums);
+    TF_LAUNCH(pillar_gather_kernel, dim3(pl_blocks((n_all + 3) / 4)), dim3(256), stream, points, point_stride, keys, pos, rank, (long)n_all, pts4, inv,
+              reinterpret_cast<long long*>(sums));
     return launch_status("tf_pillar_gather_f32");
 }
 
-extern "C" int tf_pillar_decorate_f32(const float* pts4, const int32_t* inv, const float* sums, const int32_t* cellkey, int64_t N, int GX, int GY,
+extern "C" int tf_pillar_decorate_f32(const float* pts4, const int32_t* inv, const int64_t* sums, const int32_t* cellkey, int64_t N, int GX, int GY,
                                       float pixels_per_meter, float min_x, float min_y, float* feat, void* stream) {
     TF_REQUIRE(pts4 && inv && sums && cellkey && feat && N >= 0, "tf_pillar_decorate_f32: bad arguments");
     if (N == 0) return 0;
-    TF_LAUNCH(pillar_decorate_kernel, dim3(pl_blocks(N)), dim3(256), stream, pts4, inv, sums, cellkey, (long)N, GX, GY, pixels_per_meter, min_x, min_y,
-              feat);
+    TF_LAUNCH(pillar_decorate_kernel, dim3(pl_blocks(N)), dim3(256), stream, pts4, inv, reinterpret_cast<const long long*>(sums), cellkey, (long)N, GX, GY,
+              pixels_per_meter, min_x, min_y, feat);
     return launch_status("tf_pillar_decorate_f32");
 }
 

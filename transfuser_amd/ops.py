@@ -1418,7 +1418,7 @@ def pillar_index(points, num_points, min_x, max_x, min_y, max_y, ppm):
     pts4 = torch.empty(N, 4, dtype=torch.float32, device=dev)
     feat = torch.empty(N, 9, dtype=torch.float32, device=dev)
     inv, cellkey = i32(N), cellkey_full[:P]
-    sums = torch.empty(P, 4, dtype=torch.float32, device=dev)
+    sums = torch.empty(P, 4, dtype=torch.int64, device=dev)      # fixed-point (2^-24 m) xyz sums + count: order-independent integer atomics
     if N:
         check(L().tf_pillar_gather_f32(ptr(points), Fp, ptr(keys), ptr(pos), c_p(0), ptr(rank), ctypes.c_int64(B * Nmax), ctypes.c_int64(ncells), P,
                                        ptr(pts4), ptr(inv), ptr(sums), ptr(cellkey), stream_of(points)), "tf_pillar_gather_f32")
