@@ -1537,6 +1537,14 @@ STREAM_K_KINDS_GPU = [1, 2, 3, 4, 5, 6, 7, 8]
 
 
 def check_stream_k(dev, kind):
+    prev, ops.STREAM_K = ops.STREAM_K, True      # opt-in since round 5 (TF_STREAM_K, default off): the kernels stay tested
+    try:
+        _check_stream_k(dev, kind)
+    finally:
+        ops.STREAM_K = prev
+
+
+def _check_stream_k(dev, kind):
     """Stream-K plans of the LDS-DMA kernels (persistent workgroups over the (tile, k-tile) space, a cut tile's k-tail handed over through
     scratch + flag): every operand layout and epilogue form (bias + residual + ReLU; ReLU mask; accumulate; alpha), ragged M / N / K, the
     fused BatchNorm statistics (the owner of a cut tile holds the complete sum), bitwise run-to-run equality (fixed head + tail order), and the

@@ -29,8 +29,7 @@ template <int V> __device__ __forceinline__ void stv(float* p, const vecf<V>& a)
 constexpr int kBnSlots = 16;    // accumulator copies of the atomically accumulated BatchNorm statistics
 constexpr int kMaxChunks = 512;   // finalize is wave-parallel over chunks, so many small partials are cheap
 constexpr long kWsFloats = 4L << 20;  // 16 MiB workspace (floats), see tf_workspace_bytes()
-constexpr int kTickets = 4096;        // arrival counters of the fused finalize (one per (segment, column tile)), stored BEHIND the kWsFloats floats:
-                                      // the workspace is zero-initialised ONCE by its owner and every counter is reset by the block that finishes it
+constexpr int kTickets = 4096;        // spare ints behind the kWsFloats floats (tf_workspace_bytes() keeps its value)
 
 struct RedPlan { int V, CTV, coltiles, rpp, nchunks, rows_per_chunk; };
 
@@ -153,101 +152,11 @@ template <int V> struct SeBnBwdRemaskF {
     }
 };
 
-// ---- finalize fused into the reduction ("last block finishes"): every block stores its partial (agent scope), drains the stores and takes a ticket of its
-// (segment, column tile); the block that draws the last ticket re-reads ALL the chunk partials of that tile (agent-scope loads: other XCDs wrote
-// them) in a FIXED order - chunk lanes, then the LDS row-lane order - so the result does not depend on which block came last (bitwise run-to-run
-// reproducible, no floating-point atomics), applies the finalizer and resets the counter.  Replaces one tiny launch per reduction
-// (bn_bwd_finalize / colsum_finalize / se_bwd_finalize: ~320 launches of 5-8 us per training step on the critical path of their stream).
-// Cross-XCD visibility WITHOUT fences: __threadfence() is `buffer_wbl2 sc1` + `buffer_inv sc1` on gfx950 - a write-back and an invalidate of the
-// XCD's whole L2 per wave, measured at +15 ms per training step.  Instead only the few words that cross blocks are accessed at agent scope
-// (relaxed atomic store / load = `global_store / global_load ... sc1`: written through to / read from the memory side), the stores are drained
-// with `s_waitcnt vmcnt(0)` before the block's ticket is taken, and the data the kernel streams stays cached as usual.
-__device__ __forceinline__ float ld_agent(const float* p) {
-#ifdef TF_EMU
-    return *p;
-#else
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
-}
-__device__ __forceinline__ void st_agent(float* p, float v) {
-#ifdef TF_EMU
-    *p = v;
-#else
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
-}
-__device__ __forceinline__ void drain_stores() {
-#ifndef TF_EMU
-    __builtin_amdgcn_s_waitcnt(0);       // vmcnt(0): the sc1 stores above are acknowledged by the memory side
-#endif
-}
-__device__ __forceinline__ int ticket_take(int* t) {
-#ifdef TF_EMU
-    return atomicAdd(t, 1);
-#else
-    return __hip_atomic_fetch_add(t, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
-}
-__device__ __forceinline__ void ticket_reset(int* t) {
-#ifdef TF_EMU
-    *t = 0;
-#else
-    __hip_atomic_store(t, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
-}
-struct NoFin {
-    static constexpr bool kOn = false;
-    template <int V> __device__ __forceinline__ void apply(int, int, const vecf<V>*) const {}
-};
-// out[seg][c] (+)= scale * sum
-struct ColsumFin {
-    static constexpr bool kOn = true;
-    float* out; int C; float scale; int accumulate;
-    template <int V> __device__ __forceinline__ void apply(int seg, int c, const vecf<V>* t) const {
-#pragma unroll
-        for (int i = 0; i < V; ++i) {
-            float* o = out + (long)seg * C + c + i;
-            const float s = t[0].v[i] * scale;
-            if (accumulate) *o += s; else *o = s;
-        }
-    }
-};
-// dgamma += sum g*xhat, dbeta += sum g; dx = A*g + Bc*x + Cc  (coef = [A | Bc | Cc]) - bn_bwd_finalize_kernel's arithmetic
-struct BnBwdFin {
-    static constexpr bool kOn = true;
-    const float* gamma; const float* mean; const float* invstd; float* dgamma; float* dbeta; float* coef; int C; float n;
-    template <int V> __device__ __forceinline__ void apply(int, int c0, const vecf<V>* t) const {
-#pragma unroll
-        for (int i = 0; i < V; ++i) {
-            const int c = c0 + i;
-            const float sg = t[0].v[i], sgx = t[1].v[i];
-            if (dgamma) dgamma[c] += sgx;
-            if (dbeta) dbeta[c] += sg;
-            const float A = gamma[c] * invstd[c];
-            const float Bc = -A * invstd[c] * (sgx / n);
-            coef[c] = A;
-            coef[C + c] = Bc;
-            coef[2 * C + c] = -A * (sg / n) - Bc * mean[c];
-        }
-    }
-};
-// dgate_pre[b][c] = (sum_hw dy*x) * s * (1 - s), s = sigmoid(gate) - se_bwd_finalize_kernel's arithmetic
-struct SeGateFin {
-    static constexpr bool kOn = true;
-    const float* gate; float* dgate; int C;
-    template <int V> __device__ __forceinline__ void apply(int seg, int c, const vecf<V>* t) const {
-#pragma unroll
-        for (int i = 0; i < V; ++i) {
-            const long k = (long)seg * C + c + i;
-            const float sg = 1.f / (1.f + expf(-gate[k]));
-            dgate[k] = t[0].v[i] * sg * (1.f - sg);
-        }
-    }
-};
-
-template <int V, int NACC, class F, class FIN = NoFin>
+// (A "last block finishes" form of this kernel - partials at agent scope, a ticket per column tile, the last block finalizes - removed ~270 finalize
+// launches per step and was measured SLOWER: 55.6 vs 51.6 ms/step, 66.7 with __threadfence(); DESIGN section 3.  It is gone since round 5.)
+template <int V, int NACC, class F>
 __global__ void __launch_bounds__(256) colreduce_kernel(F f, int rows_per_seg, int C, int CTV, int rows_per_chunk, float* __restrict__ ws, int atomic,
-                                                        float scale, FIN fin = FIN(), int* __restrict__ tickets = nullptr) {
+                                                        float scale) {
     __shared__ __attribute__((aligned(16))) float red[NACC][256][V];
     const int tid = threadIdx.x;
     const int rpp = 256 / CTV;
@@ -318,56 +227,9 @@ __global__ void __launch_bounds__(256) colreduce_kernel(F f, int rows_per_seg, i
             } else if (atomic) {   // ws = accumulators [seg][NACC][C] (zeroed, or a gradient being accumulated): no partials, no finalize pass
 #pragma unroll
                 for (int i = 0; i < V; ++i) atomicAdd(ws + ((long)seg * NACC + a) * C + c + i, t.v[i] * scale);
-            } else if constexpr (FIN::kOn) {
-                float* pw = ws + (((long)seg * nch + chunk) * NACC + a) * C + c;
-#pragma unroll
-                for (int i = 0; i < V; ++i) st_agent(pw + i, t.v[i]);
             } else {
                 stv<V>(ws + (((long)seg * nch + chunk) * NACC + a) * C + c, t);
             }
-        }
-    }
-    if constexpr (FIN::kOn) {
-        __shared__ int s_last;
-        const int nch = gridDim.y;
-        drain_stores();                      // this block's partials have reached the memory side before its ticket is taken
-        __syncthreads();
-        if (tid == 0) {
-            int* t = tickets + seg * gridDim.x + blockIdx.x;
-            const int prev = ticket_take(t);
-            s_last = (prev == nch - 1);
-            if (s_last) ticket_reset(t);     // nobody else touches this counter any more: the next launch on the stream finds zero
-        }
-        __syncthreads();
-        if (!s_last) return;
-#pragma unroll
-        for (int a = 0; a < NACC; ++a)
-#pragma unroll
-            for (int i = 0; i < V; ++i) acc[a].v[i] = 0.f;
-        if (rl < rpp)
-            for (int ch = rl; ch < nch; ch += rpp) {
-                const float* pw = ws + ((long)seg * nch + ch) * NACC * C + c;
-#pragma unroll
-                for (int a = 0; a < NACC; ++a)
-#pragma unroll
-                    for (int i = 0; i < V; ++i) acc[a].v[i] += ld_agent(pw + (long)a * C + i);
-            }
-#pragma unroll
-        for (int a = 0; a < NACC; ++a)
-#pragma unroll
-            for (int i = 0; i < V; ++i) red[a][tid][i] = acc[a].v[i];
-        __syncthreads();
-        if (rl == 0) {
-            vecf<V> t[NACC];
-#pragma unroll
-            for (int a = 0; a < NACC; ++a) {
-#pragma unroll
-                for (int i = 0; i < V; ++i) t[a].v[i] = 0.f;
-                for (int j = 0; j < rpp; ++j)
-#pragma unroll
-                    for (int i = 0; i < V; ++i) t[a].v[i] += red[a][j * CTV + cq][i];
-            }
-            fin.template apply<V>(seg, c, t);
         }
     }
 }
@@ -378,25 +240,10 @@ inline void launch_reduce(const RedPlan& p, const F4& f4, const F1& f1, int rows
     dim3 grid(p.coltiles, p.nchunks, nseg);
     static const bool unroll = [] { const char* e = getenv("TF_COLREDUCE_UNROLL"); return e ? e[0] != '0' : true; }();
     if (!unroll && atomic == 0) atomic = -1;
-    if (p.V == 4) TF_LAUNCH((colreduce_kernel<4, NACC, F4, NoFin>), grid, dim3(256), stream, f4, rows_per_seg, C, p.CTV, p.rows_per_chunk, ws, atomic, scale, NoFin(), (int*)nullptr);
-    else TF_LAUNCH((colreduce_kernel<1, NACC, F1, NoFin>), grid, dim3(256), stream, f1, rows_per_seg, C, p.CTV, p.rows_per_chunk, ws, atomic, scale, NoFin(), (int*)nullptr);
+    if (p.V == 4) TF_LAUNCH((colreduce_kernel<4, NACC, F4>), grid, dim3(256), stream, f4, rows_per_seg, C, p.CTV, p.rows_per_chunk, ws, atomic, scale);
+    else TF_LAUNCH((colreduce_kernel<1, NACC, F1>), grid, dim3(256), stream, f1, rows_per_seg, C, p.CTV, p.rows_per_chunk, ws, atomic, scale);
 }
 
-// reduction + fused finalize (see colreduce_kernel); false = too many (segment, column tile) pairs for the ticket array: the caller falls
-// back to its separate finalize launch
-// OPT-IN (TF_FUSE_FINALIZE=1): measured SLOWER on the MI355X - 55.6 vs 51.6 ms/step with the agent-scope accesses below (66.7 ms with
-// __threadfence()): a block of these reductions lives ~1-2 us, and the fused form adds two cross-XCD round trips to every block (store
-// acknowledgement, ticket) plus the last block's re-read of the partials - more than the 5-8 us finalize launch it removes.
-static const bool g_fuse_fin = [] { const char* e = getenv("TF_FUSE_FINALIZE"); return e ? e[0] != '0' : false; }();
-template <int NACC, class F4, class F1, class FIN>
-inline bool launch_reduce_fin(const RedPlan& p, const F4& f4, const F1& f1, int rows_per_seg, int C, int nseg, float* ws, void* stream, const FIN& fin) {
-    if (!g_fuse_fin || (long)p.coltiles * nseg > kTickets) return false;
-    int* tickets = reinterpret_cast<int*>(ws + kWsFloats);
-    dim3 grid(p.coltiles, p.nchunks, nseg);
-    if (p.V == 4) TF_LAUNCH((colreduce_kernel<4, NACC, F4, FIN>), grid, dim3(256), stream, f4, rows_per_seg, C, p.CTV, p.rows_per_chunk, ws, 0, 1.f, fin, tickets);
-    else TF_LAUNCH((colreduce_kernel<1, NACC, F1, FIN>), grid, dim3(256), stream, f1, rows_per_seg, C, p.CTV, p.rows_per_chunk, ws, 0, 1.f, fin, tickets);
-    return true;
-}
 
 // ---- finalize kernels: one wave per channel, lanes sum the chunk partials (was: one thread per channel
 // walking up to 64 dependent loads = ~19 us per BatchNorm; now a shuffle tree) -------------------------------------------
@@ -935,11 +782,9 @@ extern "C" int tf_bn_bwd_f32(const float* dz, const float* z, const float* x, in
                        dres, rows, C, p.CTV, p.rows_per_chunk, (float)rows);
         return launch_status("tf_bn_bwd_f32");
     }
-    if (!launch_reduce_fin<2>(p, f4, f1, rows, C, 1, ws, stream, BnBwdFin{gamma, save_mean, save_invstd, dgamma, dbeta, coef, C, (float)rows})) {
-        launch_reduce<2>(p, f4, f1, rows, C, 1, ws, stream);
-        TF_LAUNCH(bn_bwd_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), stream, (const float*)ws, gamma, save_mean, save_invstd, dgamma, dbeta, coef,
-                  C, p.nchunks, (float)rows);
-    }
+    launch_reduce<2>(p, f4, f1, rows, C, 1, ws, stream);
+    TF_LAUNCH(bn_bwd_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), stream, (const float*)ws, gamma, save_mean, save_invstd, dgamma, dbeta, coef,
+              C, p.nchunks, (float)rows);
     const bool v4 = (C % 4 == 0) && aligned16(dz) && aligned16(x) && aligned16(dx) && (!z || aligned16(z)) && (!dres || aligned16(dres));
     const long n = (long)rows * C;
     if (v4) TF_LAUNCH(bn_bwd_apply_kernel<4>, dim3(ew_blocks(n / 4)), dim3(256), stream, dz, z, x, (const float*)coef, dx, dres, n / 4, C);
@@ -960,10 +805,8 @@ extern "C" int tf_colsum_f32(const float* x, const float* mask, int nseg, int ro
         launch_reduce<1>(p, f4, f1, rows_per_seg, C, nseg, out, stream, 1, scale);
         return launch_status("tf_colsum_f32");
     }
-    if (!launch_reduce_fin<1>(p, f4, f1, rows_per_seg, C, nseg, ws, stream, ColsumFin{out, C, scale, accumulate})) {
-        launch_reduce<1>(p, f4, f1, rows_per_seg, C, nseg, ws, stream);
-        TF_LAUNCH(colsum_finalize_kernel, dim3(cdiv((long)nseg * C, 4)), dim3(256), stream, (const float*)ws, out, C, p.nchunks, nseg, scale, accumulate);
-    }
+    launch_reduce<1>(p, f4, f1, rows_per_seg, C, nseg, ws, stream);
+    TF_LAUNCH(colsum_finalize_kernel, dim3(cdiv((long)nseg * C, 4)), dim3(256), stream, (const float*)ws, out, C, p.nchunks, nseg, scale, accumulate);
     return launch_status("tf_colsum_f32");
 }
 
@@ -983,10 +826,8 @@ extern "C" int tf_se_scale_bwd_gate_f32(const float* dy, const float* x, const f
     RedPlan p = plan_reduce(HW, C, B, 1);
     MulF<4> f4{dy, x, C};
     MulF<1> f1{dy, x, C};
-    if (!launch_reduce_fin<1>(p, f4, f1, HW, C, B, ws, stream, SeGateFin{gate, dgate, C})) {
-        launch_reduce<1>(p, f4, f1, HW, C, B, ws, stream);
-        TF_LAUNCH(se_bwd_finalize_kernel, dim3(cdiv((long)B * C, 4)), dim3(256), stream, (const float*)ws, gate, dgate, C, p.nchunks, B);
-    }
+    launch_reduce<1>(p, f4, f1, HW, C, B, ws, stream);
+    TF_LAUNCH(se_bwd_finalize_kernel, dim3(cdiv((long)B * C, 4)), dim3(256), stream, (const float*)ws, gate, dgate, C, p.nchunks, B);
     return launch_status("tf_se_scale_bwd_gate_f32");
 }
 // dx (+)= dy * sigmoid(gate) + dmean / HW   (dy/gate pair optional, dmean optional): the input
@@ -1051,11 +892,9 @@ extern "C" int tf_bn_bwd_remask_f32(const float* dz, const float* x, const float
     RedPlan p = plan_reduce(rows, C, 1, 2, v4);
     BnBwdRemaskF<4> f4{dz, x, fcoef, save_mean, save_invstd, C};
     BnBwdRemaskF<1> f1{dz, x, fcoef, save_mean, save_invstd, C};
-    if (!launch_reduce_fin<2>(p, f4, f1, rows, C, 1, ws, stream, BnBwdFin{gamma, save_mean, save_invstd, dgamma, dbeta, coef, C, (float)rows})) {
-        launch_reduce<2>(p, f4, f1, rows, C, 1, ws, stream);
-        TF_LAUNCH(bn_bwd_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), stream, (const float*)ws, gamma, save_mean, save_invstd, dgamma, dbeta, coef, C, p.nchunks,
-                  (float)rows);
-    }
+    launch_reduce<2>(p, f4, f1, rows, C, 1, ws, stream);
+    TF_LAUNCH(bn_bwd_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), stream, (const float*)ws, gamma, save_mean, save_invstd, dgamma, dbeta, coef, C, p.nchunks,
+              (float)rows);
     const long n = (long)rows * C;
     if (v4) TF_LAUNCH(bn_bwd_apply_remask_kernel<4>, dim3(ew_blocks(n / 4)), dim3(256), stream, dz, x, fcoef, (const float*)coef, dx, n / 4, C);
     else TF_LAUNCH(bn_bwd_apply_remask_kernel<1>, dim3(ew_blocks(n)), dim3(256), stream, dz, x, fcoef, (const float*)coef, dx, n, C);
@@ -1075,11 +914,9 @@ extern "C" int tf_bn_bwd_remask_se_f32(const float* dy, const float* gate, const
     const float inv_hw = 1.f / (float)HW;
     SeBnBwdRemaskF<4> f4{dy, gate, dmean, x, fcoef, save_mean, save_invstd, C, HW, inv_hw};
     SeBnBwdRemaskF<1> f1{dy, gate, dmean, x, fcoef, save_mean, save_invstd, C, HW, inv_hw};
-    if (!launch_reduce_fin<2>(p, f4, f1, rows, C, 1, ws, stream, BnBwdFin{gamma, save_mean, save_invstd, dgamma, dbeta, coef, C, (float)rows})) {
-        launch_reduce<2>(p, f4, f1, rows, C, 1, ws, stream);
-        TF_LAUNCH(bn_bwd_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), stream, (const float*)ws, gamma, save_mean, save_invstd, dgamma, dbeta, coef, C, p.nchunks,
-                  (float)rows);
-    }
+    launch_reduce<2>(p, f4, f1, rows, C, 1, ws, stream);
+    TF_LAUNCH(bn_bwd_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), stream, (const float*)ws, gamma, save_mean, save_invstd, dgamma, dbeta, coef, C, p.nchunks,
+              (float)rows);
     const long n = (long)rows * C;
     if (v4) TF_LAUNCH(bn_bwd_apply_remask_se_kernel<4>, dim3(ew_blocks(n / 4)), dim3(256), stream, dy, gate, dmean, x, fcoef, (const float*)coef, dx, n / 4, C, (long)HW * C / 4, inv_hw);
     else TF_LAUNCH(bn_bwd_apply_remask_se_kernel<1>, dim3(ew_blocks(n)), dim3(256), stream, dy, gate, dmean, x, fcoef, (const float*)coef, dx, n, C, (long)HW * C, inv_hw);
@@ -1092,10 +929,8 @@ extern "C" int tf_colsum_mul_f32(const float* a, const float* b, int rows, int C
     RedPlan p = plan_reduce(rows, C, 1, 1, aligned16(a) && aligned16(b));
     MulF<4> f4{a, b, C};
     MulF<1> f1{a, b, C};
-    if (!launch_reduce_fin<1>(p, f4, f1, rows, C, 1, ws, stream, ColsumFin{out, C, 1.f, accumulate})) {
-        launch_reduce<1>(p, f4, f1, rows, C, 1, ws, stream);
-        TF_LAUNCH(colsum_finalize_kernel, dim3(cdiv((long)C, 4)), dim3(256), stream, (const float*)ws, out, C, p.nchunks, 1, 1.f, accumulate);
-    }
+    launch_reduce<1>(p, f4, f1, rows, C, 1, ws, stream);
+    TF_LAUNCH(colsum_finalize_kernel, dim3(cdiv((long)C, 4)), dim3(256), stream, (const float*)ws, out, C, p.nchunks, 1, 1.f, accumulate);
     return launch_status("tf_colsum_mul_f32");
 }
 

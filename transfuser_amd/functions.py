@@ -356,18 +356,10 @@ class PoolNormFn(torch.autograd.Function):
         return ops.se_scale_bwd_x(None, None, dp, shape), None, None, None
 
 
-# ---- 1x1 convolutions of the trunks on 16-bit STORED operands (precision "bf16" / "fp16", ops.lowp_conv1x1_ok): same scheme as _lin16_* -
-# the forward casts the input once (row-major copy for this product, transposed copy kept for the weight gradient), the backward casts dy once.
+# ---- 1x1 convolutions of the trunks.  (A 16-bit STORED-operand form of these - cast16 + gemm16_nt like the GPT linears - was measured at
+# 39.1 vs 38.3 ms/step in bf16: two cast passes per convolution cost more than the packed GEMMs gain.  Removed in round 5.)
 def _c1x1_fwd(x2, w, colstat=True):
-    """y (M, N) = x2 (M, K) @ w (N, K)^T  (+ BatchNorm statistics of y); returns (y, ColStat or None, saved) with saved = A16 or the fp32 x2."""
-    M, K = x2.shape
-    N = w.shape[0]
-    if ops.lowp_conv1x1_ok(M, K, N):
-        x16, x16t = ops.cast16(x2)
-        w16, _ = ops.lowp_weight(w)
-        y = torch.empty(M, N, dtype=torch.float32, device=x2.device)
-        y, cs = ops.gemm16_nt_colstat(x16, w16, y, want_stat=colstat)
-        return y, cs, A16(x16t)
+    """y (M, N) = x2 (M, K) @ w (N, K)^T  (+ BatchNorm statistics of y); returns (y, ColStat or None, saved input)."""
     if colstat:
         y, cs = ops.linear_fwd(x2, w, colstat=True)
         return y, cs, x2
@@ -376,12 +368,6 @@ def _c1x1_fwd(x2, w, colstat=True):
 
 def _c1x1_bwd(dy2, saved, w, dw, res=None):
     """dW += dy^T x, returns dx = dy W (+ res)."""
-    if isinstance(saved, A16):
-        d16, d16t = ops.cast16(dy2)
-        ops.gemm16_nt(d16t, saved.t, dw, accumulate=True, k=d16t.shape[1])
-        _, w16t = ops.lowp_weight(w)
-        dx = torch.empty(dy2.shape[0], w.shape[1], dtype=torch.float32, device=dy2.device)
-        return ops.gemm16_nt(d16, w16t, dx, res=res, k=w.shape[0])
     with ops.gemm_pair(dy2):      # weight + input gradient in one grid where both plans are 64 x 64 tilings (csrc/gemm_pair.cpp)
         ops.linear_wgrad(dy2, saved, dw)
         dx = ops.linear_dgrad(dy2, w, res=res)
@@ -434,8 +420,6 @@ class YBlockFn(torch.autograd.Function):
                 gate = ops.linear_fwd(g1, w2d(blk.se.fc2.weight), blk.se.fc2.bias)
             z2s = ops.se_scale_fwd(z2, gate)
         y3, cs3, z2ss = _c1x1_fwd(z2s.view(-1, C), w2d(blk.conv3.conv.weight))
-        if isinstance(z2ss, A16):
-            z2s = None          # only its transposed 16-bit copy is needed again (weight gradient of conv3)
         y3 = y3.view(B, Ho, Wo, C)
         yd = std = None
         if blk.downsample is not None:

@@ -162,15 +162,6 @@ def gemm16_nt_colstat(a16, b16, out, want_stat=True):
     return out, (cs if cs else None)
 
 
-LOWP_CONV1X1 = os.environ.get("TF_STORE16_CONV", "0") != "0"      # default off: measured 39.1 vs 38.3 ms/step in bf16 (two cast passes per convolution)
-LOWP_CONV1X1_MIN = {"k": 64, "m": 512}        # (tests lower these to reach the path on the tiny models)
-
-
-def lowp_conv1x1_ok(M, K, N):
-    """1x1 convolutions of the trunks on 16-bit stored operands: worth the cast passes from a few hundred rows / 64 channels on."""
-    return bool(_lowp["dtype"]) and LOWP_CONV1X1 and K % 8 == 0 and N % 8 == 0 and K >= LOWP_CONV1X1_MIN["k"] and M >= LOWP_CONV1X1_MIN["m"]
-
-
 def lowp_weight(w):
     """(w16 (N, K), w16t (K, N8)) of a linear weight (N, K).  Inside train.Engine the copies are cached and rewritten once per step right after
     AdamW (``lowp_refresh_weights``); anywhere else they are re-made at every use (the parameter may have changed)."""
