@@ -321,8 +321,6 @@ def test_lowp_storage_modes_tiny_model(mode):
         assert abs(a[0][k] - b[0][k]) <= 1e-5 * max(1.0, abs(b[0][k])), (k, a[0][k], b[0][k])
     rel = float((a[1] - b[1]).norm() / b[1].norm())
     assert rel <= 1e-5, rel
-    for k in a[0]:
-        assert abs(res[(True, True)][0][k] - b[0][k]) <= 1e-4 * max(1.0, abs(b[0][k])), (k, res[(True, True)][0][k], b[0][k])
 
 
 @pytest.mark.parametrize("arch", ["resnet_tiny", "resnet_tiny50"])
