@@ -44,8 +44,9 @@ for (M, N, K) in [(7040, 576, 576), (2560, 576, 576), (28160, 216, 216), (10240,
     p0 = ops.gemm_pair_count()
     pair()
     joint = ops.gemm_pair_count() > p0
+    cs = ops.ColStat(M, N, dev)
     t = [graph_time(lambda: ops.linear_fwd(x, w, out=out)), graph_time(lambda: ops.linear_dgrad(dy, w, out=dx)), graph_time(lambda: ops.linear_wgrad(dy, x, dw)),
-         graph_time(seq), graph_time(pair)]
+         graph_time(seq), graph_time(pair), graph_time(lambda: ops.gemm(x, w, out, M, N, K, K, K, N, colstat=cs))]
     fl = 2.0 * M * N * K
-    print("%-20s fwd %6.1f (%5.1f TF/s) | dgrad %6.1f | wgrad %6.1f | two launches %6.1f | one grid %6.1f%s" % (
-        (M, N, K), t[0], fl / t[0] / 1e6, t[1], t[2], t[3], t[4], "" if joint else "  (no joint kernel for these plans)"), flush=True)
+    print("%-20s fwd %6.1f (%5.1f TF/s) | fwd + BN statistics %6.1f | dgrad %6.1f | wgrad %6.1f | two launches %6.1f | one grid %6.1f%s" % (
+        (M, N, K), t[0], fl / t[0] / 1e6, t[5], t[1], t[2], t[3], t[4], "" if joint else "  (no joint kernel for these plans)"), flush=True)
