@@ -60,6 +60,7 @@ class gemm_pair:
         self.on = GEMM_PAIR and not _CHECK and not _pair_open[0] and (self.t.is_cuda or _lib.is_test_backend())
         if self.on:
             self._e = _census_begin()          # the census times the bracket as ONE entry (the held calls launch when it closes)
+            self._n0 = gemm_pair_count() if self._e is not None else 0
             _pair_shapes.clear()
             check(L().tf_gemm_pair_begin(), "tf_gemm_pair_begin")
             _pair_open[0] = True
@@ -72,7 +73,8 @@ class gemm_pair:
             if et is None:
                 check(rc, "tf_gemm_pair_end")
                 if self._e is not None and _pair_shapes:
-                    _census_end(self._e, "gemm pair wgrad+dgrad", _pair_shapes[-1][:4], sum(v[4] for v in _pair_shapes))
+                    joint = gemm_pair_count() > self._n0
+                    _census_end(self._e, "gemm pair wgrad+dgrad (one grid)" if joint else "gemm wgrad+dgrad (two launches)", _pair_shapes[-1][:4], sum(v[4] for v in _pair_shapes))
         return False
 
 
