@@ -83,12 +83,6 @@ typedef struct {
      * of parts written, 0 when the plan chosen for this call cannot produce them (the caller then reduces separately).  Needs batch == 1,
      * a_trans == 0, store mode, no residual / ReLU / mask.  Consumed by tf_bn_fwd_parts_f32. */
     float* colstat; int* colstat_nparts;
-    /* BatchNorm-BACKWARD statistics of the output (round 5; all NULL / 0 = off): c is the incoming gradient g of a train-mode BatchNorm with input
-     * bn_x (m x n, row stride ldbn_x) and saved statistics bn_mean / bn_invstd (n): the epilogue also writes (sum g, sum g * xhat) per column over
-     * every 32- or 64-row part to bn_bstat[(part * 2 + {0, 1}) * n + j] - what tf_bn_bwd_parts_f32 finishes without a reduction pass over g and x
-     * (torch's batch_norm_backward behind every BatchNormAct2d of transfuser.py:380,442 reduces in its own pass).  *bn_bstat_nparts (HOST pointer) is set
-     * at launch time to the number of parts written, 0 = this call's plan cannot produce them.  Needs batch 1, a plain store, a_trans == 0. */
-    const float* bn_x; int64_t ldbn_x; const float* bn_mean; const float* bn_invstd; float* bn_bstat; int* bn_bstat_nparts;
 } tf_gemm_desc;
 int tf_gemm_f32(const tf_gemm_desc* d, void* stream);
 /* Floats of splitk_ws this call can use: 0 unless the cached (or about-to-be-tuned) plan of the call's shape is a two-pass split-K plan, so
@@ -296,10 +290,6 @@ int tf_bn_fwd_f32(const float* x, int rows, int C, const float* gamma, const flo
 int tf_bn_zacc_floats(int C);
 int tf_bn_bwd_f32(const float* dz, const float* z, const float* x, int rows, int C, const float* gamma, const float* save_mean, const float* save_invstd,
                   float* dx, float* dres, float* dgamma, float* dbeta, float* ws, float* zacc, void* stream);
-/* The same backward when the epilogue of the GEMM that produced dz already gathered the two column sums (tf_gemm_desc.bn_bstat: nparts partial
- * pairs): finalize + apply, no reduction pass.  dz carries its ReLU mask already (the producing launch applied it). */
-int tf_bn_bwd_parts_f32(const float* parts, int nparts, const float* dz, const float* x, int rows, int C, const float* gamma, const float* save_mean,
-                        const float* save_invstd, float* dx, float* dgamma, float* dbeta, float* ws, void* stream);
 /* out[seg][c] (+)= scale * sum_rows x (* [mask > 0]): SE squeeze / global average pool
  * (transfuser.py:203-205), bias gradients, pos_emb gradient. */
 int tf_colsum_f32(const float* x, const float* mask, int nseg, int rows_per_seg, int C, float scale, float* out, int accumulate, float* ws, void* stream);

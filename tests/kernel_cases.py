@@ -1790,63 +1790,3 @@ def check_gemm_pair(dev, M, N, K, splitk, bks=((32, 32), (32, 16), (16, 32), (16
     assert ops.gemm_pair_count() == p0 and ops.gemm_pair_count(singles=True) == s0 + 1
     close(dw, want_dw, tol=2e-5 * max(1, M // 64), what="ineligible wgrad")
     close(dx, want_dx, tol=2e-5 * max(1, N // 64), what="eligible dgrad beside an ineligible wgrad")
-
-
-# ---------------------------------------------------------------- BatchNorm-backward sums in the producing GEMM's epilogue (round 5)
-BN_BWD_STAT_CASES = [(300, 72, 48), (130, 96, 200), (70, 24, 36), (1000, 216, 216)]
-
-
-def check_bn_bwd_stats_epilogue(dev, M, N, K, plans=((64, 64, 32), (64, 64, 16), (128, 32, 16), (128, 64, 32))):
-    """dx = (dy W + res) [x > 0] with the BatchNorm-backward column sums (sum g, sum g * xhat) of dx gathered by the same launch's epilogue
-    (tf_gemm_desc.bn_bstat), then ops.bn_bwd_parts (finalize + apply) - against torch autograd through relu(bn(y) + shortcut) with the same
-    incoming gradient, against the separate reduce + finalize + apply path (ops.bn_bwd), inside the pair bracket, and for every tile shape
-    that can produce the parts."""
-    import torch.nn.functional as F
-    dy, w = R(M, N, dev=dev), R(N, K, seed=1, dev=dev) * 0.2
-    res = R(M, K, seed=2, dev=dev)
-    y3 = R(M, K, seed=3, dev=dev)                       # the BatchNorm's input (raw conv3 output of the previous block)
-    sc = R(M, K, seed=4, dev=dev)                       # the previous block's shortcut
-    gamma, beta = (R(K, seed=5, dev=dev) * 0.3 + 1.0), R(K, seed=6, dev=dev) * 0.1
-    # reference: out = relu(bn(y3) + sc); the gradient arriving at out is d = dy W + res
-    y3r = y3.double().cpu().requires_grad_(True)
-    g_r, b_r = gamma.double().cpu().requires_grad_(True), beta.double().cpu().requires_grad_(True)
-    out_r = torch.relu(F.batch_norm(y3r, None, None, g_r, b_r, True, 0.1, 1e-5) + sc.double().cpu())
-    d = dy.double().cpu() @ w.double().cpu() + res.double().cpu()
-    out_r.backward(d)
-    mean = y3.double().mean(0)
-    var = y3.double().var(0, unbiased=False)
-    sm, si = mean.float(), (1.0 / torch.sqrt(var + 1e-5)).float()
-    out = torch.relu(((y3.double() - mean) * (1.0 / torch.sqrt(var + 1e-5)) * gamma.double() + beta.double() + sc.double())).float()      # = the next block's input x
-    for plan in plans:
-        ops.force_plan(*plan, 1)
-        try:
-            bst = ops.BnBwdStat(y3, sm, si)
-            dx = ops.linear_dgrad(dy, w, res=res, mask=out, bstat=bst)
-        finally:
-            ops.force_plan(0)
-        assert bst, "plan %s produced no parts" % (plan,)
-        close(dx, (d * (out.double().cpu() > 0)).float(), tol=2e-5 * max(1, N // 64), what="masked dgrad %s" % (plan,))
-        dg, db = torch.zeros(K, device=dev), torch.zeros(K, device=dev)
-        dy3 = ops.bn_bwd_parts(bst, dx, y3, gamma, sm, si, dg, db)
-        tol = 3e-4
-        close(dy3, y3r.grad.float(), tol=tol, what="bn backward from epilogue sums %s" % (plan,))
-        close(dg, g_r.grad.float(), tol=tol * max(1.0, M / 256), what="dgamma")
-        close(db, b_r.grad.float(), tol=tol * max(1.0, M / 256), what="dbeta")
-        # the reduce + finalize + apply path on the same (pre-masked) gradient
-        dg2, db2 = torch.zeros(K, device=dev), torch.zeros(K, device=dev)
-        dy3b, _ = ops.bn_bwd(dx, None, y3, gamma, sm, si, dg2, db2, False)
-        close(dy3, dy3b, tol=2e-5, what="== reduce + finalize + apply")
-        close(dg, dg2, tol=2e-5 * max(1.0, M / 256), what="dgamma ==")
-    # inside the pair bracket (the weight gradient of the same layer beside it)
-    x, dw = R(M, N, seed=7, dev=dev), torch.zeros(N, N, device=dev)
-    ops.force_plan(64, 64, 32, 1)
-    try:
-        bst = ops.BnBwdStat(y3, sm, si)
-        with ops.gemm_pair(dy):
-            ops.linear_wgrad(dy, x, dw)
-            dxp = ops.linear_dgrad(dy, w, res=res, mask=out, bstat=bst)
-    finally:
-        ops.force_plan(0)
-    assert bst
-    dg3, db3 = torch.zeros(K, device=dev), torch.zeros(K, device=dev)
-    close(ops.bn_bwd_parts(bst, dxp, y3, gamma, sm, si, dg3, db3), y3r.grad.float(), tol=3e-4, what="bn backward from the pair launch's sums")

@@ -711,41 +711,3 @@ def check_merged_heads(dev, weights):
             assert err <= 2e-3 * scale + 1e-7, (name, err, scale)
             n += 1
     assert n == 34, n
-
-
-def check_bn_bwd_link(dev, batch_dims, lidar_res=None):
-    """Between two consecutive bottlenecks of a RegNetY stage the second one's last input-gradient GEMM applies the first one's output ReLU and
-    gathers the backward sums of its conv3 BatchNorm in the epilogue (functions.BnLink, TF_FUSE_BN_BWD_STATS): the same model with the switch on and
-    off - losses identical (the forward does not change), every parameter gradient equal to fp32 round-off, and the linked path really ran."""
-    from transfuser_amd import ops
-    calls = {"parts": 0}
-    orig = ops.bn_bwd_parts
-
-    def counted(*a, **k):
-        calls["parts"] += 1
-        return orig(*a, **k)
-    cfg = tiny_config(n_layer=1, **({"lidar_res": lidar_res} if lidar_res else {}))
-    prod, ref = build_pair(cfg, "regnety_tiny", dev)
-    batch = small_batch(*batch_dims)
-    state = {k: v.clone() for k, v in prod.state_dict().items()}
-    res = {}
-    prev = ops.FUSE_BN_BWD_STATS
-    ops.bn_bwd_parts = counted
-    try:
-        for on in (True, False):
-            ops.FUSE_BN_BWD_STATS = on
-            prod.load_state_dict(state)
-            lp, _ = run_pair(prod, ref, cfg, batch, dev)
-            res[on] = ({k: float(v) for k, v in lp.items()}, {n: p.grad.clone() for n, p in prod.named_parameters() if p.grad is not None})
-            if on:
-                assert calls["parts"] >= 2, calls          # one inner block per trunk in the tiny stage 2
-                seen = dict(calls)
-        assert calls == seen, "the unlinked run must not touch the parts path"
-    finally:
-        ops.FUSE_BN_BWD_STATS = prev
-        ops.bn_bwd_parts = orig
-    for k, v in res[True][0].items():
-        assert v == res[False][0][k], (k, v, res[False][0][k])
-    for n, g in res[True][1].items():
-        g0 = res[False][1][n]
-        assert (g - g0).abs().max().item() <= 2e-4 * max(g0.abs().max().item(), 1e-3), n

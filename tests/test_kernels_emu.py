@@ -241,8 +241,3 @@ def test_im2col_gemm_form_of_few_row_deep_k_convolutions():
 @pytest.mark.parametrize("case", kc.GEMM_PAIR_CASES, ids=str)
 def test_gemm_pair_launch(case):
     kc.check_gemm_pair("cpu", *case)
-
-
-@pytest.mark.parametrize("case", kc.BN_BWD_STAT_CASES, ids=str)
-def test_bn_backward_sums_in_the_producing_gemm_epilogue(case):
-    kc.check_bn_bwd_stats_epilogue("cpu", *case)

@@ -289,8 +289,3 @@ def test_dataprep_matches_reference_functions():
 @pytest.mark.parametrize("case", kc.GEMM_PAIR_CASES + [(7040, 576, 576, 6), (2560, 576, 576, 6), (28160, 216, 216, 64)], ids=str)
 def test_gemm_pair_launch(case):
     kc.check_gemm_pair("cuda", *case, **({} if case[0] < 2000 else dict(bks=((32, 32), (32, 16)))))
-
-
-@pytest.mark.parametrize("case", kc.BN_BWD_STAT_CASES + [(7040, 576, 576), (2560, 576, 576), (28160, 216, 216)], ids=str)
-def test_bn_backward_sums_in_the_producing_gemm_epilogue(case):
-    kc.check_bn_bwd_stats_epilogue("cuda", *case, **({} if case[0] < 2000 else dict(plans=((64, 64, 32), (64, 64, 16)))))

@@ -421,7 +421,3 @@ def test_remaining_block_gradients_within_1e3_tiny():
 @pytest.mark.parametrize("weights", mc.MERGED_HEAD_WEIGHTS, ids=str)
 def test_engine_merged_head_convolution_gradients(weights):
     mc.check_merged_heads("cpu", weights)
-
-
-def test_bn_backward_sums_and_relu_mask_ride_on_the_next_blocks_input_gradient():
-    mc.check_bn_bwd_link("cpu", (2, 64, 128, 64, 40))

@@ -759,8 +759,3 @@ def test_engine_merged_head_convolution_gradients(weights):
     """One 64 -> 512 convolution for the seven CenterNet heads + pred_bev inside the Engine (model.merged_head_convs): head / pred_bev / up_conv3
     gradients vs the oracle for the reference's zero-weight heads (live prefix), no zero weights, and a zero weight in the middle."""
     mc.check_merged_heads("cuda", weights)
-
-
-def test_bn_backward_sums_and_relu_mask_ride_on_the_next_blocks_input_gradient():
-    """functions.BnLink on / off on the MI355X (tiny trunks at 160 x 352): same losses, gradients equal to fp32 round-off, the linked path ran."""
-    mc.check_bn_bwd_link("cuda", (2, 160, 352, 128, 40), lidar_res=128)

@@ -29,8 +29,7 @@ class GemmDesc(ctypes.Structure):
                 ("batch", c_i), ("inner", c_i),
                 ("sa_outer", c_l), ("sa_inner", c_l), ("sb_outer", c_l), ("sb_inner", c_l), ("sc_outer", c_l), ("sc_inner", c_l),
                 ("alpha", c_f), ("relu", c_i), ("accumulate", c_i), ("mask", c_p), ("ldmask", c_l),
-                ("splitk_ws", c_p), ("splitk_ws_floats", c_l), ("sk_flags", c_p), ("colstat", c_p), ("colstat_nparts", ctypes.POINTER(ctypes.c_int)),
-                ("bn_x", c_p), ("ldbn_x", c_l), ("bn_mean", c_p), ("bn_invstd", c_p), ("bn_bstat", c_p), ("bn_bstat_nparts", ctypes.POINTER(ctypes.c_int))]
+                ("splitk_ws", c_p), ("splitk_ws_floats", c_l), ("sk_flags", c_p), ("colstat", c_p), ("colstat_nparts", ctypes.POINTER(ctypes.c_int))]
 
 
 class ConvGeom(ctypes.Structure):

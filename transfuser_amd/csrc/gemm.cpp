@@ -55,7 +55,7 @@ extern "C" int tf_gemm_f32(const tf_gemm_desc* d, void* stream) {
                d->k, d->batch);
     const int inner = d->inner > 0 ? d->inner : 1;
     // per-sample matmuls (SE excitation, join MLP): rows = batch <= 16 -> streaming kernels instead of a 128-row MFMA tile
-    if (d->batch == 1 && d->alpha == 1.0f && d->m > 0 && d->n > 0 && d->k > 0 && !d->mask && !d->colstat && !d->bn_bstat) {
+    if (d->batch == 1 && d->alpha == 1.0f && d->m > 0 && d->n > 0 && d->k > 0 && !d->mask && !d->colstat) {
         if (!d->a_trans && !d->b_trans && d->m <= 16 && !d->accumulate)
             return smallm_fwd(d->a, d->lda, d->b, d->ldb, d->bias, d->res, d->ldres, d->c, d->ldc, d->m, d->n, d->k, d->relu, stream);
         if (!d->a_trans && d->b_trans && d->m <= 16 && !d->bias && !d->relu && !(d->accumulate && d->res))
@@ -82,13 +82,6 @@ extern "C" int tf_gemm_f32(const tf_gemm_desc* d, void* stream) {
         *d->colstat_nparts = 0;
     }
     TF_REQUIRE(!d->mask || (d->batch == 1 && !d->accumulate), "tf_gemm_f32: mask needs batch == 1 and a plain store");
-    if (d->bn_bstat) {
-        TF_REQUIRE(d->bn_x && d->bn_mean && d->bn_invstd && d->bn_bstat_nparts && d->batch == 1 && !d->accumulate && !d->a_trans,
-                   "tf_gemm_f32: bn_bstat needs bn_x / bn_mean / bn_invstd / bn_bstat_nparts, batch 1, a plain store and row-major A");
-        ep.bx = d->bn_x; ep.ldbx = d->ldbn_x; ep.bmean = d->bn_mean; ep.binv = d->bn_invstd;
-        ep.bstat = d->bn_bstat; ep.bstat_ld = d->n; ep.bstat_nparts = d->bn_bstat_nparts;
-        *d->bn_bstat_nparts = 0;
-    }
     // A: KC when stored [m][k] (rows = i), IC when stored [k][m] (rows = k)
     PlainOp A = d->a_trans ? make_plain(d->a, d->lda, d->k, d->m, d->sa_outer, d->sa_inner, inner, d->batch)
                            : make_plain(d->a, d->lda, d->m, d->k, d->sa_outer, d->sa_inner, inner, d->batch);

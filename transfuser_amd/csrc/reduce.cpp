@@ -792,23 +792,6 @@ extern "C" int tf_bn_bwd_f32(const float* dz, const float* z, const float* x, in
     return launch_status("tf_bn_bwd_f32");
 }
 
-// BatchNorm2d backward whose two column sums were already gathered by the epilogue of the GEMM that produced dz (tf_gemm_desc.bn_bstat: nparts
-// partial pairs [part][{sum g, sum g * xhat}][C]): finalize + apply only - no reduction pass over dz and x.  dz is the gradient as stored by that
-// launch (its ReLU mask already applied); dgamma / dbeta are ACCUMULATED.
-extern "C" int tf_bn_bwd_parts_f32(const float* parts, int nparts, const float* dz, const float* x, int rows, int C, const float* gamma, const float* save_mean,
-                                   const float* save_invstd, float* dx, float* dgamma, float* dbeta, float* ws, void* stream) {
-    TF_REQUIRE(parts && nparts > 0 && dz && x && gamma && save_mean && save_invstd && dx && ws && rows > 0 && C > 0, "tf_bn_bwd_parts_f32: bad arguments");
-    float* coef = ws + kWsFloats / 2;
-    TF_LAUNCH(bn_bwd_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), stream, parts, gamma, save_mean, save_invstd, dgamma, dbeta, coef, C, nparts, (float)rows);
-    const bool v4 = (C % 4 == 0) && aligned16(dz) && aligned16(x) && aligned16(dx);
-    const long n = (long)rows * C;
-    const float* noz = nullptr;
-    float* nores = nullptr;
-    if (v4) TF_LAUNCH(bn_bwd_apply_kernel<4>, dim3(ew_blocks(n / 4)), dim3(256), stream, dz, noz, x, (const float*)coef, dx, nores, n / 4, C);
-    else TF_LAUNCH(bn_bwd_apply_kernel<1>, dim3(ew_blocks(n)), dim3(256), stream, dz, noz, x, (const float*)coef, dx, nores, n, C);
-    return launch_status("tf_bn_bwd_parts_f32");
-}
-
 // out[seg][c] (+)= scale * sum over the segment's rows of x (* [mask > 0]).  Uses: SE squeeze /
 // global average pool (scale = 1/HW, nseg = B), bias gradients (nseg = 1, mask = ReLU output).
 extern "C" int tf_colsum_f32(const float* x, const float* mask, int nseg, int rows_per_seg, int C, float scale, float* out, int accumulate,

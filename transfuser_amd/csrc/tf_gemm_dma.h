@@ -462,8 +462,6 @@ inline void launch_dma_cfg(const PlainOp& la, const PlainOp& lb, const GemmEpi& 
             eps.group_m = (g >= 2 && tiles_n >= 4) ? g : 1;
         }
         if (eps.stat_nparts) *eps.stat_nparts = eps.stat ? cdiv(M, 32 * TM) : 0;
-        eps.bstat = nullptr;                                    // (launch_gemm never sends a backward-statistics request down a stream-K plan)
-        if (eps.bstat_nparts) *eps.bstat_nparts = 0;
         if (eps.prec == 2 && !ep.packed16)
             TF_LAUNCH((gemm_dma_sk_kernel<TM, TN, WAVES_M, WAVES_N, BK, STAGES, A_KC, B_KC, OCC, true>), dim3(P), dim3(C::NT), stream, la, lb, eps, M, N, K, tiles_m, tiles_n);
         else
@@ -492,8 +490,6 @@ inline void launch_dma_cfg(const PlainOp& la, const PlainOp& lb, const GemmEpi& 
     }
     if (twopass || nsplit > 1) epg.stat = nullptr;          // (launch_gemm never sends a statistics request down a k-split plan)
     if (epg.stat_nparts) *epg.stat_nparts = epg.stat ? cdiv(M, 32 * TM) : 0;
-    if (twopass || nsplit > 1) epg.bstat = nullptr;
-    if (epg.bstat_nparts) *epg.bstat_nparts = epg.bstat ? cdiv(M, 32 * TM) : 0;
     if (epg.prec == 2 && !ep.packed16)
         TF_LAUNCH((gemm_dma_kernel<TM, TN, WAVES_M, WAVES_N, BK, STAGES, A_KC, B_KC, OCC, true>), grid, dim3(C::NT), stream, la, lb, epg, M, N, K,
                   tiles_m, tiles_n, kchunk);

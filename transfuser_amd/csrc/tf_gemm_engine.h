@@ -252,13 +252,6 @@ struct GemmEpi {
     // merges the parts (Chan's formula).  Only for plain stores (mode 0, no residual / ReLU / mask / split-K).  stat_nparts: HOST pointer,
     // set at launch time to the number of parts this launch writes (0: the chosen plan cannot produce them - caller falls back).
     float* stat = nullptr; long stat_ld = 0; int* stat_nparts = nullptr;
-    // BatchNorm-BACKWARD statistics of the OUTPUT (round 5): the gradient this launch writes - an input gradient (+ residual) (+ ReLU mask) - is the
-    // incoming gradient g of a train-mode BatchNorm whose input bx and saved (mean, invstd) are known: every wave also writes, for each of its
-    // columns, (sum g, sum g * xhat), xhat = (bx(i, j) - bmean[j]) * binv[j], over the rows it owns into bstat[(part * 2 + {0, 1}) * bstat_ld + j]
-    // (part as for ``stat``; plain stores) - the layout bn_bwd_finalize_kernel reads, so the BatchNorm backward needs no reduction pass
-    // (tf_bn_bwd_parts_f32).  Plain stores only (mode 0, no k-split).  bstat_nparts: HOST pointer, as stat_nparts.
-    const float* bx = nullptr; long ldbx = 0; const float* bmean = nullptr; const float* binv = nullptr;
-    float* bstat = nullptr; long bstat_ld = 0; int* bstat_nparts = nullptr;
     int prec = 0;                    // 0: exact fp32 MFMA; 1: operands rounded to bf16 on the LDS->register path, bf16 MFMA, fp32 accumulate; 2: bf16x3 split (fp32-accurate, 6 bf16 MFMAs); 3: as 1 with IEEE-half operands (set by launch_cfg)
     int packed16 = 0;                // LDS-DMA kernels, both operands K-contiguous: the operands ARE 16-bit matrices (1: bf16, 2: IEEE half) described in units of
                                      // 4 bytes (ld, cols, K = halves / 2): tiles are moved as bytes, one ds_read_b128 = one 8-deep MFMA operand (tf_gemm16_nt_f32)
@@ -349,42 +342,6 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[TM][TN], const
                 if (hi == 0 && jok) {
                     float* st = ep.stat + (long)part * 3 * ep.stat_ld + cz + j;
                     st[0] = (float)nrow; st[ep.stat_ld] = mean; st[2 * ep.stat_ld] = q;
-                }
-            }
-        }
-    }
-    if (ep.bstat) {     // wave-uniform: (sum g, sum g * xhat) of the STORED values over this wave's 32 * TM rows (see GemmEpi.bstat); batch 1 only
-        constexpr int WMR = 32 * TM;
-        const int r0 = i0 + wm0;
-        if (r0 < M) {
-            const int part = r0 / WMR;
-#pragma unroll
-            for (int u = 0; u < TN; ++u) {
-                const int j = j0 + wn0 + u * 32 + l31;
-                const bool jok = j < N;
-                const int jc = jok ? j : 0;
-                const float bj = bias ? bias[jc] : 0.f, mu = ep.bmean[jc], is = ep.binv[jc];
-                float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-                for (int t = 0; t < TM; ++t)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int i = r0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                        const bool ok = jok && i < M;
-                        const long ic = ok ? i : r0;
-                        float v = ep.alpha * acc[t][u][r] + bj;                      // the value emit() stored: same expression, same order
-                        if (res) v += res[ic * ep.ldres + jc];
-                        v = ep.relu ? fmaxf(v, 0.f) : v;
-                        if (ep.mask) v = (ep.mask[ic * ep.ldmask + jc] > 0.f) ? v : 0.f;
-                        const float xh = (ep.bx[ic * ep.ldbx + jc] - mu) * is;
-                        s0 += ok ? v : 0.f;
-                        s1 += ok ? v * xh : 0.f;
-                    }
-                s0 += shfl_xor(s0, 32);
-                s1 += shfl_xor(s1, 32);
-                if (hi == 0 && jok) {
-                    float* st = ep.bstat + (long)part * 2 * ep.bstat_ld + j;
-                    st[0] = s0; st[ep.bstat_ld] = s1;
                 }
             }
         }
@@ -863,7 +820,6 @@ inline CfgGeom cfg_geom(const GemmEpi& ep, int M, int N, int K, int splitk, int 
         c.epg.group_m = (g >= 2 && c.tiles_n >= 4) ? g : 1;
     }
     if (c.epg.stat_nparts) *c.epg.stat_nparts = c.epg.stat ? cdiv(M, BM / WAVES_M) : 0;
-    if (c.epg.bstat_nparts) *c.epg.bstat_nparts = c.epg.bstat ? cdiv(M, BM / WAVES_M) : 0;
     return c;
 }
 
@@ -1056,11 +1012,6 @@ inline int launch_gemm(const LA& la, const LB& lb, GemmEpi ep, int M, int N, int
         else if (p.splitk > 1) p.splitk = 1;
         if (ep.mode != 0 || ep.res || ep.relu || ep.mask) ep.stat = nullptr;
         if (!ep.stat && ep.stat_nparts) *ep.stat_nparts = 0;
-    }
-    if (ep.bstat) {     // backward statistics of the output: a plain store by the block that holds the whole reduction, or none (nparts 0: the caller reduces)
-        if (streamk || p.splitk >= kTwoPass || ep.mode != 0 || batch != 1) ep.bstat = nullptr;
-        else p.splitk = 1;
-        if (!ep.bstat && ep.bstat_nparts) *ep.bstat_nparts = 0;
     }
     if (streamk) {
     } else if (p.splitk >= kTwoPass) {

@@ -366,24 +366,12 @@ def _c1x1_fwd(x2, w, colstat=True):
     return ops.linear_fwd(x2, w), None, x2
 
 
-def _c1x1_bwd(dy2, saved, w, dw, res=None, mask=None, bstat=None):
-    """dW += dy^T x, returns dx = dy W (+ res) (zeroed where mask <= 0) (+ the BatchNorm-backward sums of dx: ops.BnBwdStat)."""
+def _c1x1_bwd(dy2, saved, w, dw, res=None):
+    """dW += dy^T x, returns dx = dy W (+ res)."""
     with ops.gemm_pair(dy2):      # weight + input gradient in one grid where both plans are 64 x 64 tilings (csrc/gemm_pair.cpp)
         ops.linear_wgrad(dy2, saved, dw)
-        dx = ops.linear_dgrad(dy2, w, res=res, mask=mask, bstat=bstat)
+        dx = ops.linear_dgrad(dy2, w, res=res)
     return dx
-
-
-class BnLink:
-    """What block k of a RegNetY stage tells block k + 1 about the BatchNorm + ReLU that produced its output (conv3.bn, + shortcut, ReLU): the raw
-    conv3 output and the saved statistics.  Block k + 1's backward ends with the input-gradient GEMM of its conv1; that launch's epilogue applies
-    the ReLU mask of block k's output ([x > 0]: x IS that output) and gathers the two column sums of conv3.bn's backward, so block k's backward starts
-    with a finalize + apply instead of reduce (3 reads) + finalize + apply (3 reads, 2 writes).  ``premasked`` / ``bstat`` are set by block k + 1's backward."""
-    __slots__ = ("y3", "mean", "invstd", "premasked", "bstat")
-
-    def __init__(self):
-        self.y3 = self.mean = self.invstd = self.bstat = None
-        self.premasked = False
 
 
 # ============================================================================================ RegNetY block
@@ -393,7 +381,7 @@ class YBlockFn(torch.autograd.Function):
     1x1 -> BN (+ shortcut / 1x1-s2 downsample BN) -> ReLU."""
 
     @staticmethod
-    def forward(ctx, x, blk, prev_link, my_link, *params):
+    def forward(ctx, x, blk, *params):
         B, H, W, Cin = x.shape
         C = blk.out_chs
         x2 = x.view(-1, Cin)
@@ -444,11 +432,7 @@ class YBlockFn(torch.autograd.Function):
         else:
             sc = x
         out, st3 = _bn(y3, blk.conv3.bn, res=sc, relu=True, stat=cs3)
-        if my_link is not None and len(st3) == 2 and blk.conv3.bn.training:      # local train-mode BatchNorm: the next block of the stage may take over its mask + sums
-            my_link.y3, my_link.mean, my_link.invstd = y3.view(-1, C), st3[0], st3[1]
-        if prev_link is not None and (prev_link.y3 is None or blk.downsample is not None or not ops.FUSE_BN_BWD_STATS):
-            prev_link = None
-        ctx.saved = (x, blk, y1, z1, st1, y2, z2, st2, s, g1, gate, z2ss, y3, st3, yd, std, out, x2s, prev_link, my_link)
+        ctx.saved = (x, blk, y1, z1, st1, y2, z2, st2, s, g1, gate, z2ss, y3, st3, yd, std, out, x2s)
         return out
 
     @staticmethod
@@ -456,22 +440,11 @@ class YBlockFn(torch.autograd.Function):
         if ctx.saved is None:
             raise RuntimeError("YBlockFn: trying to backward through the graph a second time: the saved activations are freed by the first backward "
                                "(retain_graph is not supported by the block Functions)")
-        x, blk, y1, z1, st1, y2, z2, st2, s, g1, gate, z2ss, y3, st3, yd, std, out, x2s, prev_link, my_link = ctx.saved
+        x, blk, y1, z1, st1, y2, z2, st2, s, g1, gate, z2ss, y3, st3, yd, std, out, x2s = ctx.saved
         B, H, W, Cin = x.shape
         _, Ho, Wo, C = out.shape
         x2 = x.view(-1, Cin)
-        dout = dout.contiguous()
-        if my_link is not None and my_link.premasked:
-            # the next block's last GEMM already applied this block's output ReLU to dout (and, where its plan could, gathered bn3's backward sums)
-            bn3 = blk.conv3.bn
-            if my_link.bstat is not None:
-                dy3 = ops.bn_bwd_parts(my_link.bstat, dout, y3, bn3.weight, st3[0], st3[1], gbuf(bn3.weight), gbuf(bn3.bias))
-            else:
-                dy3, _ = _bn_bwd(dout, None, y3, bn3, st3, want_dres=False)
-            dsc = dout                                     # the shortcut's gradient IS the masked incoming gradient: no copy
-            my_link.bstat = None
-        else:
-            dy3, dsc = _bn_bwd(dout, out, y3, blk.conv3.bn, st3, want_dres=True)
+        dy3, dsc = _bn_bwd(dout.contiguous(), out, y3, blk.conv3.bn, st3, want_dres=True)
         dy3_2 = dy3.view(-1, C)
         w3 = blk.conv3.conv.weight
         dz2s = _c1x1_bwd(dy3_2, z2ss, w2d(w3), w2d(gbuf(w3))).view(B, Ho, Wo, C)
@@ -514,12 +487,7 @@ class YBlockFn(torch.autograd.Function):
             dy1, _ = _bn_bwd(dz1, z1, y1, blk.conv1.bn, st1)
         dy1_2 = dy1.view(-1, C)
         w1 = blk.conv1.conv.weight
-        if blk.downsample is None and prev_link is not None:
-            # x is the ReLU output of the previous block of the stage: its mask and its BatchNorm's backward sums ride on this launch's epilogue
-            bst = ops.BnBwdStat(prev_link.y3, prev_link.mean, prev_link.invstd) if ops.want_colstat(x2.shape[0]) else None
-            dx = _c1x1_bwd(dy1_2, x2s, w2d(w1), w2d(gbuf(w1)), res=dsc.view(-1, Cin), mask=x2, bstat=bst)
-            prev_link.premasked, prev_link.bstat = True, (bst if bst else None)
-        elif blk.downsample is None:
+        if blk.downsample is None:
             dx = _c1x1_bwd(dy1_2, x2s, w2d(w1), w2d(gbuf(w1)), res=dsc.view(-1, Cin))
         else:
             dx = _c1x1_bwd(dy1_2, x2s, w2d(w1), w2d(gbuf(w1)))
@@ -532,7 +500,7 @@ class YBlockFn(torch.autograd.Function):
                 ops.conv_wgrad(dyd, x, gbuf(wd), blk.stride, 0, 1)
                 ops.conv_dgrad(dyd, wd, x.shape, blk.stride, 0, 1, out=dx.view(B, H, W, Cin), accumulate=True)
         ctx.saved = None
-        return (dx.view(B, H, W, Cin), None, None, None) + (None,) * (len(ctx.needs_input_grad) - 4)
+        return (dx.view(B, H, W, Cin), None) + (None,) * (len(ctx.needs_input_grad) - 2)
 
 
 # ============================================================================================ GPT fusion stage

@@ -316,9 +316,8 @@ def _ws_query():
 
 
 def gemm(a, b, c, m, n, k, lda, ldb, ldc, a_trans=False, b_trans=False, bias=None, res=None, ldres=0, alpha=1.0, relu=False,
-         accumulate=False, batch=1, inner=1, sa=(0, 0), sb=(0, 0), sc=(0, 0), mask=None, colstat=None, bstat=None):
-    """colstat: a ColStat request (see linear_fwd(..., colstat=True)): the epilogue also writes the BatchNorm statistics of the output.
-    bstat: a BnBwdStat request: the output is the incoming gradient of a BatchNorm backward, the epilogue also writes its two column sums."""
+         accumulate=False, batch=1, inner=1, sa=(0, 0), sb=(0, 0), sc=(0, 0), mask=None, colstat=None):
+    """colstat: a ColStat request (see linear_fwd(..., colstat=True)): the epilogue also writes the BatchNorm statistics of the output."""
     if _CHECK and c.is_cuda:
         cview = lambda: torch.as_strided(c, (batch // inner, inner, m, n), (sc[0], sc[1], ldc, 1))
         old = cview().double().clone() if accumulate else None
@@ -331,9 +330,6 @@ def gemm(a, b, c, m, n, k, lda, ldb, ldc, a_trans=False, b_trans=False, bias=Non
                  ldmask=mask.stride(0) if mask is not None else 0, splitk_ws=c_p(0), splitk_ws_floats=0)
     if colstat is not None:
         d.colstat, d.colstat_nparts = ptr(colstat.buf), ctypes.pointer(colstat.nparts)
-    if bstat is not None:
-        d.bn_x, d.ldbn_x, d.bn_mean, d.bn_invstd = ptr(bstat.x), bstat.x.stride(0), ptr(bstat.mean), ptr(bstat.invstd)
-        d.bn_bstat, d.bn_bstat_nparts = ptr(bstat.buf), ctypes.pointer(bstat.nparts)
     skws = None
     if TWO_PASS_SPLITK and batch == 1 and k >= 256 and 128 * 128 <= m * n and (m * n <= _TWO_PASS_MAX_ELEMS or STREAM_K):
         need = _ws_query()(byref(d))          # > 0 only when the plan of THIS shape is a two-pass / stream-K plan (or the autotuner wants to try one)
@@ -388,21 +384,6 @@ class ColStat:
         return self.nparts.value > 0
 
 
-class BnBwdStat:
-    """Request + result of the BatchNorm-backward statistics gathered by the epilogue of the GEMM that produces the BatchNorm's incoming
-    gradient (tf_gemm_desc.bn_bstat): x (rows, C) = the BatchNorm's input, mean / invstd its saved statistics.  ``nparts`` is filled in on
-    the host at launch time (0: the launch could not produce them - the consumer runs its reduction pass)."""
-
-    def __init__(self, x2d, mean, invstd):
-        self.x, self.mean, self.invstd = x2d, mean, invstd
-        rows, C = x2d.shape
-        self.nparts = ctypes.c_int(0)
-        self.buf = torch.empty(2 * C * ((rows + 31) // 32), dtype=torch.float32, device=x2d.device)
-
-    def __bool__(self):
-        return self.nparts.value > 0
-
-
 def want_colstat(rows):
     return FUSE_BN_STATS and rows <= _COLSTAT_MAX_ROWS
 
@@ -420,14 +401,14 @@ def linear_fwd(x, w, bias=None, relu=False, res=None, out=None, colstat=False):
     return (y, cs if cs else None) if colstat else y
 
 
-def linear_dgrad(dy, w, out=None, accumulate=False, res=None, mask=None, bstat=None):
-    """dx = dy @ w (+res); dy (M, N), w (N, K).  mask (M, K): dx is zeroed where mask <= 0 (fused ReLU backward).  bstat: BnBwdStat request."""
+def linear_dgrad(dy, w, out=None, accumulate=False, res=None, mask=None):
+    """dx = dy @ w (+res); dy (M, N), w (N, K).  mask (M, K): dx is zeroed where mask <= 0 (fused ReLU backward)."""
     M, N = dy.shape
     K = w.shape[1]
     if out is None:
         out = torch.empty(M, K, dtype=torch.float32, device=dy.device)
     return gemm(dy, w, out, M, K, N, dy.stride(0), w.stride(0), out.stride(0), b_trans=True, accumulate=accumulate, res=res,
-                ldres=res.stride(0) if res is not None else 0, mask=mask, bstat=bstat)
+                ldres=res.stride(0) if res is not None else 0, mask=mask)
 
 
 def linear_wgrad(dy, x, dw, accumulate=True):
@@ -1042,22 +1023,6 @@ def bn_bwd(dz, z, x, gamma, sm, si, dgamma, dbeta, want_dres=False):
     # reduce pass reads dz, x (+ z); apply pass reads them again and writes dx (+ dres)
     _hbm_end(_h, "batchnorm backward (reduce + finalize + apply)", 4 * x.numel() * ((2 + (z is not None)) * 2 + 1 + (dres is not None)))
     return dx, dres
-
-
-def bn_bwd_parts(bstat, dz, x, gamma, sm, si, dgamma, dbeta):
-    """BatchNorm backward from the column sums the producing GEMM's epilogue gathered (BnBwdStat): finalize + apply, no reduction pass; dz is
-    already masked by the producer."""
-    C = x.shape[-1]
-    rows = x.numel() // C
-    dx = torch.empty_like(x)
-    _h = _hbm_begin()
-    check(L().tf_bn_bwd_parts_f32(ptr(bstat.buf), bstat.nparts.value, ptr(_c(dz)), ptr(_c(x)), rows, C, ptr(gamma), ptr(sm), ptr(si), ptr(dx), ptr(dgamma), ptr(dbeta),
-                                  ptr(workspace(x.device)), stream_of(x)), "tf_bn_bwd_parts_f32")
-    _hbm_end(_h, "batchnorm backward (reduce + finalize + apply)", 4 * x.numel() * 3)      # apply only: reads dz, x, writes dx
-    return dx
-
-
-FUSE_BN_BWD_STATS = os.environ.get("TF_FUSE_BN_BWD_STATS", "1") != "0"      # A/B switch of round 5: ReLU mask + BatchNorm-backward sums in the producing dgrad's epilogue
 
 
 COLSUM_MULTI = os.environ.get("TF_COLSUM_MULTI", "1") != "0"      # the Block's bias gradients in one launch (A/B switch)

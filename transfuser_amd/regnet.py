@@ -51,13 +51,7 @@ class Bottleneck(nn.Module):
         self.downsample = ConvBnAct(cin, cout, 1, stride, apply_act=False) if (cin != cout or stride != 1) else None
 
     def forward(self, x):
-        return F_.YBlockFn.apply(x, self, None, None, *self.parameters())
-
-    def forward_linked(self, x, prev_link):
-        """Inside a RegStage: ``prev_link`` describes the BatchNorm (conv3.bn of the previous block) whose ReLU output x is - this block's last input-gradient
-        GEMM then applies that ReLU's mask and gathers that BatchNorm's backward sums in its epilogue (functions.BnLink).  Returns (out, link of this block)."""
-        link = F_.BnLink()
-        return F_.YBlockFn.apply(x, self, prev_link, link, *self.parameters()), link
+        return F_.YBlockFn.apply(x, self, *self.parameters())
 
 
 class RegStage(nn.Module):
@@ -67,9 +61,8 @@ class RegStage(nn.Module):
             self.add_module("b%d" % (i + 1), Bottleneck(cin if i == 0 else cout, cout, 2 if i == 0 else 1, group_w, se_ratio))
 
     def forward(self, x):
-        link = None          # the stage's blocks are a chain: block k's output has exactly one consumer, block k + 1
         for blk in self.children():
-            x, link = blk.forward_linked(x, link)
+            x = blk(x)
         return x
 
 
