@@ -195,8 +195,9 @@ def dominant_kernel_roofline(eng, batch, dev, log, peak=PEAK_F32_MFMA_TF, headli
     if ranked and os.path.exists(trunk) and peak == PEAK_F32_MFMA_TF:
         try:
             k = ranked[0][0]
-            want = {"gemm a0b0": "nt", "gemm a0b1": "nn", "gemm a1b1": "tn"}.get(k[0])
-            m, n, kk = (k[1][0], k[1][1], k[1][2]) if want != "tn" else (k[1][2], k[1][0], k[1][1])
+            want = {"gemm a0b0": "nt", "gemm a0b1": "nn", "gemm a1b1": "tn", "gemm pair wgrad+dgrad (one grid)": "pair"}.get(k[0])
+            # census shapes are (m, n, k) of the call: forward (M, N, K); input gradient (M, K_in, N_out); weight gradient (N_out, K_in, M); pair = its input gradient's
+            m, n, kk = (k[1][2], k[1][0], k[1][1]) if want == "tn" else (k[1][0], k[1][2], k[1][1]) if want in ("nn", "pair") else (k[1][0], k[1][1], k[1][2])
             for row in json.load(open(trunk)):
                 if want and row["case"] == "gemm %s (%d,%d,%d)" % (want, m, n, kk) and row.get("traffic_bytes"):
                     roof["traffic"] = int(row["traffic_bytes"])

@@ -18,6 +18,8 @@ def cases():
         for form in ("nt", "nn", "tn"):
             byt = (M * K + N * K + M * N) * 4
             out.append(dict(name="gemm %s (%d,%d,%d)" % (form, M, N, K), flops=2.0 * M * N * K, bytes=byt, match="gemm"))
+        # the layer's weight + input gradient as ONE grid (csrc/gemm_pair.cpp): dy read by both, x and W read once, dx and dW written
+        out.append(dict(name="gemm pair (%d,%d,%d)" % (M, N, K), flops=4.0 * M * N * K, bytes=(2 * M * N + 2 * M * K + 2 * N * K) * 4, match="gemm"))
     for (B, H, W, C) in GROUPED:
         E = B * H * W * C
         for p in ("fwd", "dgrad", "wgrad"):
@@ -40,6 +42,12 @@ if __name__ == "__main__":
         fns.append(lambda x=x, w=w, y=y: ops.linear_fwd(x, w, out=y))
         fns.append(lambda dy=dy, w=w, dx=dx: ops.linear_dgrad(dy, w, out=dx))
         fns.append(lambda dy=dy, x=x, dw=dw: ops.linear_wgrad(dy, x, dw, accumulate=True))
+
+        def pair(dy=dy, x=x, dw=dw, w=w, dx=dx):
+            with ops.gemm_pair(dy):
+                ops.linear_wgrad(dy, x, dw, accumulate=True)
+                ops.linear_dgrad(dy, w, out=dx)
+        fns.append(pair)
     for (B, H, W, C) in GROUPED:
         g = C // 24
         x = torch.randn(B, H, W, C, device=dev); dy = torch.randn(B, H, W, C, device=dev)
