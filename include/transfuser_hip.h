@@ -450,6 +450,16 @@ int tf_pillar_canvas_f32(const float* pillar_feat, const int32_t* cellkey, int P
                          const float* extra_nchw, int Ce, int32_t* owner, float* out_nhwc, void* stream);
 int tf_pillar_canvas_bwd_f32(const float* dout_nhwc, const int32_t* owner, const int32_t* cellkey, const int32_t* inv, const int32_t* arg,
                              int64_t N, int C, int Cs, int GX, int GY, int H, int W, float* dz, void* stream);
+/* Static-shape mode of the front-end (round 5: --use_point_pillars under a captured hipGraph).  The kept-point / pillar counts stay on the DEVICE
+ * (totals of tf_pillar_index_scan_i32): every buffer has its capacity (B * max_points rows, min(B * max_points, cells) pillars), the compacted cloud and
+ * inv are zero-filled, unused cell-key slots hold -1 (tf_pillar_canvas_f32 skips them), and the point net's nn.BatchNorm1d (point_pillar.py:17-27), whose
+ * row count is data dependent, runs as tf_bn_rows_dev_*: statistics over the first *nrows_dev rows only, rows beyond written as zero by both apply passes -
+ * so Linear, scatter-max and the weight gradients can run over the whole capacity.  C <= 256 dividing 256; ws: tf_bn_rows_dev_ws_floats(C) floats. */
+long tf_bn_rows_dev_ws_floats(int C);
+int tf_bn_rows_dev_fwd_f32(const float* x, const int32_t* nrows_dev, int rows_cap, int C, const float* gamma, const float* beta, float* running_mean,
+                           float* running_var, float momentum, float eps, int relu, float* y, float* save_mean, float* save_invstd, float* ws, void* stream);
+int tf_bn_rows_dev_bwd_f32(const float* dz, const float* z, const float* x, const int32_t* nrows_dev, int rows_cap, int C, const float* gamma,
+                           const float* save_mean, const float* save_invstd, float* dx, float* dgamma, float* dbeta, float* ws, void* stream);
 
 /* GPU-side batch preparation: the per-sample numpy work of team_code_transfuser/data.py after file decoding, batched.
  * tf_lidar_align_hist_f64: align (data.py:411-444: q = T (x, -y, z, 1), y' = -q1; T (B,16) row-major fp64) fused with the 2-bin height histogram

@@ -131,6 +131,50 @@ def test_point_pillars_model_matches_oracle():
     mc.compare_vs_fp64(prod, ref, lp, lr, batch, cfg)
 
 
+def test_point_pillars_static_shapes_match_the_host_read_path():
+    """The static-shape mode of the PointPillars front-end (what train.Engine uses under a captured hipGraph: capacity-sized buffers, the kept-point /
+    pillar counts never leave the device, BatchNorm1d with a device-side row count): same losses, the same gradients for every parameter and the same
+    running statistics as the mode that reads the two counts on the host - with ragged clouds (a sample with dropped points, one with none kept in
+    range being impossible here: the second sample keeps fewer)."""
+    from transfuser_amd import ops
+    cfg = mc.tiny_config(n_layer=1, lidar_res=64)
+    cfg.use_point_pillars = True
+    cfg.min_x, cfg.max_x, cfg.min_y, cfg.max_y = -4, 4, -8, 0
+    prod, ref = mc.build_pair(cfg, "regnety_tiny", "cpu")
+    batch = mc.small_batch(2, 32, 64, 64, 40)
+    g = torch.Generator().manual_seed(5)
+    batch["lidar"] = torch.stack([torch.rand(2, 3000, generator=g) * 10 - 5, torch.rand(2, 3000, generator=g) * 10 - 9,
+                                  torch.rand(2, 3000, generator=g) * 5 - 4, torch.rand(2, 3000, generator=g)], -1)
+    batch["num_points"] = torch.tensor([3000, 1700], dtype=torch.int32)
+    state = {k: v.clone() for k, v in prod.state_dict().items()}
+    res = {}
+    calls = {"n": 0}
+    orig = ops.bn_rows_dev_fwd
+
+    def counted(*a, **k):
+        calls["n"] += 1
+        return orig(*a, **k)
+    ops.bn_rows_dev_fwd = counted
+    try:
+        for static in (False, True):
+            prod.load_state_dict(state)
+            prod.point_pillar_net.static_shapes = static
+            lp, _ = mc.run_pair(prod, ref, cfg, batch, "cpu")
+            res[static] = ({k: float(v) for k, v in lp.items()}, {n: p.grad.clone() for n, p in prod.named_parameters() if p.grad is not None},
+                           {n: b.clone() for n, b in prod.named_buffers() if "running" in n})
+            assert calls["n"] == (2 if static else 0), calls
+    finally:
+        ops.bn_rows_dev_fwd = orig
+        prod.point_pillar_net.static_shapes = False
+    for k, v in res[True][0].items():
+        assert abs(v - res[False][0][k]) <= 2e-5 * max(1.0, abs(v)), (k, v, res[False][0][k])
+    for n, gr in res[True][1].items():
+        g0 = res[False][1][n]
+        assert (gr - g0).abs().max().item() <= 5e-4 * max(g0.abs().max().item(), 1e-3), (n, (gr - g0).abs().max().item(), g0.abs().max().item())
+    for n, b in res[True][2].items():
+        assert torch.allclose(b, res[False][2][n], rtol=1e-5, atol=1e-6), n
+
+
 def test_forward_ego_and_reference_checkpoint():
     """(a) a reference-style checkpoint (DDP 'module.' prefix, NCHW-contiguous conv weights) loads with strict key
     matching; (b) forward_ego / control_pid reproduce the oracle's inference outputs."""

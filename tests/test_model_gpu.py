@@ -759,3 +759,48 @@ def test_engine_merged_head_convolution_gradients(weights):
     """One 64 -> 512 convolution for the seven CenterNet heads + pred_bev inside the Engine (model.merged_head_convs): head / pred_bev / up_conv3
     gradients vs the oracle for the reference's zero-weight heads (live prefix), no zero weights, and a zero weight in the middle."""
     mc.check_merged_heads("cuda", weights)
+
+
+def test_point_pillars_train_under_the_captured_graph():
+    """--use_point_pillars 1 under train.Engine(use_graph=True) (round 5: the front-end's static-shape mode - capacity-sized buffers, the kept-point /
+    pillar counts never read on the host, BatchNorm1d with a device-side row count): the replayed graph follows the eager engine (which reads the
+    counts like the reference's unique()) step for step on ragged clouds, and a replay with a DIFFERENT cloud in the same static buffers equals the
+    eager engine's step on that cloud (the counts are really re-read on the device)."""
+    from transfuser_amd import ops, transfuser as ptf
+    from transfuser_amd.train import Engine
+    cfg = mc.tiny_config(n_layer=1, lidar_res=64)
+    cfg.use_point_pillars = True
+    cfg.min_x, cfg.max_x, cfg.min_y, cfg.max_y = -4, 4, -8, 0
+    g = torch.Generator().manual_seed(5)
+
+    def cloud(n0, n1):
+        b = mc.small_batch(2, 32, 64, 64, 40)
+        b["lidar"] = torch.stack([torch.rand(2, 3000, generator=g) * 10 - 5, torch.rand(2, 3000, generator=g) * 10 - 9,
+                                  torch.rand(2, 3000, generator=g) * 5 - 4, torch.rand(2, 3000, generator=g)], -1)
+        b["num_points"] = torch.tensor([n0, n1], dtype=torch.int32)
+        return {k: v.cuda() for k, v in b.items()}
+    batches = [cloud(3000, 1700), cloud(2200, 2900), cloud(3000, 1700)]
+    outs, params = [], []
+    ops.force_plan(64, 64, 16, 1)
+    try:
+        for use_graph in (False, True):
+            ptf.GPT._site_base = 0
+            prod, _ = mc.build_pair(cfg, "regnety_tiny", "cuda")
+            prod.train()
+            eng = Engine(prod, cfg, lr=1e-3, use_graph=use_graph, autotune=False)
+            assert bool(getattr(prod.point_pillar_net, "static_shapes", False)) == use_graph
+            losses = []
+            for b in batches:
+                tot, det = eng.train_step(b)
+                losses.append([float(tot)] + [float(det[k]) for k in cfg.detailed_losses])
+            torch.cuda.synchronize()
+            assert not use_graph or eng._graphs is not None, "the pillar path must run as a captured graph"
+            outs.append(torch.tensor(losses, dtype=torch.float64))
+            params.append(eng.arena.params.detach().clone())
+    finally:
+        ops.force_plan(0)
+    rel = ((outs[0] - outs[1]).abs() / outs[0].abs().clamp_min(1e-3)).max(dim=1).values
+    print("  pillars graph vs eager: max relative loss difference per step %s" % ["%.1e" % v for v in rel.tolist()])
+    assert rel[0].item() <= 2e-5 and rel.max().item() <= 5e-4, rel
+    assert (params[0] - params[1]).abs().mean().item() <= 5e-6
+    assert (outs[1][0] - outs[1][1]).abs().max().item() > 1e-3, "the second cloud must change the losses"

@@ -283,8 +283,10 @@ __device__ __forceinline__ long pillar_cell(int key, int GX, int GY, int H, int 
 
 __global__ void __launch_bounds__(256) pillar_owner_kernel(const int32_t* __restrict__ cellkey, int P, int GX, int GY, int H, int W,
                                                            int32_t* __restrict__ owner) {
-    for (int r = blockIdx.x * 256 + threadIdx.x; r < P; r += gridDim.x * 256)
-        atomicMax(owner + pillar_cell(cellkey[r], GX, GY, H, W), r);      // index_put: the last (highest-rank) duplicate wins
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < P; r += gridDim.x * 256) {
+        const int key = cellkey[r];                                       // < 0: an unused slot of a fixed-capacity key list (static-shape mode)
+        if (key >= 0) atomicMax(owner + pillar_cell(key, GX, GY, H, W), r);      // index_put: the last (highest-rank) duplicate wins
+    }
 }
 
 __global__ void __launch_bounds__(256) pillar_canvas_kernel(const float* __restrict__ pf, const int32_t* __restrict__ owner, long ncell, int C,
@@ -320,6 +322,105 @@ __global__ void __launch_bounds__(256) pillar_canvas_bwd_kernel(const float* __r
             if (owner[cell] == r) g = dout[cell * Cs + c];
         }
         dz[i] = g;
+    }
+}
+
+// ---- BatchNorm1d (+ ReLU) over the FIRST n rows of a fixed-capacity (rows_cap, C) matrix, n read on the DEVICE (the kept-point count of the pillar
+// index, totals[0]): what lets --use_point_pillars run under a captured hipGraph (the point net's nn.BatchNorm1d, point_pillar.py:17-27, sees a
+// data-dependent number of rows).  Rows >= n are IGNORED by the statistics and written as ZERO by the apply passes, so everything downstream
+// (Linear, scatter-max, weight gradients) can run over the whole capacity.  C <= 256, 256 % C == 0.  Two statistics passes (sum, then centred
+// squares: every block re-reduces the first pass's <= kBnrBlocks partials in its prologue) + apply = 3 launches; backward 2.  Deterministic.
+constexpr int kBnrBlocks = 256;
+template <int PASS>      // 1: sum x   2: sum (x - mean)^2   3 (backward): sum g, sum g * xhat with g = dz * [z > 0]
+__global__ void __launch_bounds__(256) bnr_stats_kernel(const float* __restrict__ x, const float* __restrict__ dz, const float* __restrict__ z,
+                                                        const int32_t* __restrict__ nrows, int rows_cap, int C, const float* __restrict__ part1,
+                                                        const float* __restrict__ mean_in, const float* __restrict__ invstd_in, float* __restrict__ part) {
+    __shared__ float red[2][256];
+    __shared__ float mu[256];
+    const int tid = threadIdx.x, c = tid % C, rl = tid / C, rpb = 256 / C;
+    int n = nrows[0];
+    n = n < 0 ? 0 : (n > rows_cap ? rows_cap : n);
+    if (PASS == 2) {
+        if (tid < C) {
+            float s = 0.f;
+            for (int b = 0; b < (int)gridDim.x; ++b) s += part1[(long)b * C + tid];
+            mu[tid] = s / (float)(n > 0 ? n : 1);
+        }
+        __syncthreads();
+    }
+    const float m = PASS == 2 ? mu[c] : (PASS == 3 ? mean_in[c] : 0.f), is = PASS == 3 ? invstd_in[c] : 0.f;
+    float a0 = 0.f, a1 = 0.f;
+    for (long r = (long)blockIdx.x * rpb + rl; r < n; r += (long)gridDim.x * rpb) {
+        const float v = x[r * C + c];
+        if (PASS == 1) a0 += v;
+        else if (PASS == 2) { const float d = v - m; a0 += d * d; }
+        else { float g = dz[r * C + c]; if (!(z[r * C + c] > 0.f)) g = 0.f; a0 += g; a1 += g * ((v - m) * is); }
+    }
+    red[0][tid] = a0; red[1][tid] = a1;
+    __syncthreads();
+    if (rl == 0) {
+        float t0 = 0.f, t1 = 0.f;
+        for (int j = 0; j < rpb; ++j) { t0 += red[0][j * C + c]; t1 += red[1][j * C + c]; }
+        if (PASS == 3) { part[((long)blockIdx.x * 2 + 0) * C + c] = t0; part[((long)blockIdx.x * 2 + 1) * C + c] = t1; }
+        else part[(long)blockIdx.x * C + c] = t0;
+    }
+}
+// y = relu(x * sc + sh) for rows < n, 0 beyond; block 0 also publishes mean / invstd and updates the running statistics (unbiased variance)
+__global__ void __launch_bounds__(256) bnr_apply_kernel(const float* __restrict__ x, const int32_t* __restrict__ nrows, int rows_cap, int C, int nblk,
+                                                        const float* __restrict__ part1, const float* __restrict__ part2, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar, float momentum,
+                                                        float eps, int relu, float* __restrict__ y, float* __restrict__ save_mean,
+                                                        float* __restrict__ save_invstd) {
+    __shared__ float sc[256], sh[256];
+    int n = nrows[0];
+    n = n < 0 ? 0 : (n > rows_cap ? rows_cap : n);
+    if ((int)threadIdx.x < C) {
+        const int c = threadIdx.x;
+        float s = 0.f, q = 0.f;
+        for (int b = 0; b < nblk; ++b) { s += part1[(long)b * C + c]; q += part2[(long)b * C + c]; }
+        const float fn = (float)(n > 0 ? n : 1), mean = s / fn, var = q / fn, inv = 1.0f / sqrtf(var + eps);
+        sc[c] = gamma[c] * inv; sh[c] = beta[c] - mean * (gamma[c] * inv);
+        if (blockIdx.x == 0) {
+            save_mean[c] = mean; save_invstd[c] = inv;
+            if (rmean && n > 0) {
+                rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+                rvar[c] = (1.f - momentum) * rvar[c] + momentum * (n > 1 ? var * (fn / (fn - 1.f)) : var);
+            }
+        }
+    }
+    __syncthreads();
+    const long total = (long)rows_cap * C, live = (long)n * C;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        float v = x[i < live ? i : 0] * sc[c] + sh[c];
+        if (relu) v = fmaxf(v, 0.f);
+        y[i] = i < live ? v : 0.f;
+    }
+}
+// dx = A g + Bc x + Cc (coefficients as bn_bwd_finalize_kernel's) for rows < n, 0 beyond; block 0 accumulates dgamma / dbeta
+__global__ void __launch_bounds__(256) bnr_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ z, const float* __restrict__ x,
+                                                            const int32_t* __restrict__ nrows, int rows_cap, int C, int nblk, const float* __restrict__ part,
+                                                            const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                            float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ float cA[256], cB[256], cC[256];
+    int n = nrows[0];
+    n = n < 0 ? 0 : (n > rows_cap ? rows_cap : n);
+    if ((int)threadIdx.x < C) {
+        const int c = threadIdx.x;
+        float sg = 0.f, sgx = 0.f;
+        for (int b = 0; b < nblk; ++b) { sg += part[((long)b * 2 + 0) * C + c]; sgx += part[((long)b * 2 + 1) * C + c]; }
+        const float fn = (float)(n > 0 ? n : 1), A = gamma[c] * invstd[c], Bc = -A * invstd[c] * (sgx / fn);
+        cA[c] = A; cB[c] = Bc; cC[c] = -A * (sg / fn) - Bc * mean[c];
+        if (blockIdx.x == 0) { if (dgamma) dgamma[c] += sgx; if (dbeta) dbeta[c] += sg; }
+    }
+    __syncthreads();
+    const long total = (long)rows_cap * C, live = (long)n * C;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const long j = i < live ? i : 0;
+        float g = dz[j];
+        if (!(z[j] > 0.f)) g = 0.f;
+        dx[i] = i < live ? cA[c] * g + cB[c] * x[j] + cC[c] : 0.f;
     }
 }
 
@@ -406,4 +507,35 @@ extern "C" int tf_pillar_canvas_bwd_f32(const float* dout_nhwc, const int32_t* o
     if (N == 0) return 0;
     TF_LAUNCH(pillar_canvas_bwd_kernel, dim3(pl_blocks(N * C)), dim3(256), stream, dout_nhwc, owner, cellkey, inv, arg, (long)N, C, Cs, GX, GY, H, W, dz);
     return launch_status("tf_pillar_canvas_bwd_f32");
+}
+
+// BatchNorm1d + ReLU over the first *nrows_dev rows of x (rows_cap, C) - see bnr_stats_kernel.  ws: 2 * 256 * C floats (the two passes' block partials).
+extern "C" long tf_bn_rows_dev_ws_floats(int C) { return 2L * kBnrBlocks * C; }
+extern "C" int tf_bn_rows_dev_fwd_f32(const float* x, const int32_t* nrows_dev, int rows_cap, int C, const float* gamma, const float* beta, float* running_mean,
+                                      float* running_var, float momentum, float eps, int relu, float* y, float* save_mean, float* save_invstd, float* ws,
+                                      void* stream) {
+    TF_REQUIRE(x && nrows_dev && gamma && beta && y && save_mean && save_invstd && ws && rows_cap > 0 && C > 0 && C <= 256 && 256 % C == 0,
+               "tf_bn_rows_dev_fwd_f32: needs C <= 256 dividing 256 (got %d)", C);
+    int nblk = cdiv(rows_cap, (256 / C) * 16);
+    nblk = nblk < 1 ? 1 : (nblk > kBnrBlocks ? kBnrBlocks : nblk);
+    float* p1 = ws; float* p2 = ws + (long)kBnrBlocks * C;
+    const float* nof = nullptr;
+    TF_LAUNCH(bnr_stats_kernel<1>, dim3(nblk), dim3(256), stream, x, nof, nof, nrows_dev, rows_cap, C, nof, nof, nof, p1);
+    TF_LAUNCH(bnr_stats_kernel<2>, dim3(nblk), dim3(256), stream, x, nof, nof, nrows_dev, rows_cap, C, (const float*)p1, nof, nof, p2);
+    TF_LAUNCH(bnr_apply_kernel, dim3(pl_blocks((long)rows_cap * C)), dim3(256), stream, x, nrows_dev, rows_cap, C, nblk, (const float*)p1, (const float*)p2, gamma, beta,
+              running_mean, running_var, momentum, eps, relu, y, save_mean, save_invstd);
+    return launch_status("tf_bn_rows_dev_fwd_f32");
+}
+// its backward: dz = gradient of the (post-ReLU) output z; dgamma / dbeta are ACCUMULATED; dx rows >= *nrows_dev are written as zero
+extern "C" int tf_bn_rows_dev_bwd_f32(const float* dz, const float* z, const float* x, const int32_t* nrows_dev, int rows_cap, int C, const float* gamma,
+                                      const float* save_mean, const float* save_invstd, float* dx, float* dgamma, float* dbeta, float* ws, void* stream) {
+    TF_REQUIRE(dz && z && x && nrows_dev && gamma && save_mean && save_invstd && dx && ws && rows_cap > 0 && C > 0 && C <= 256 && 256 % C == 0,
+               "tf_bn_rows_dev_bwd_f32: needs C <= 256 dividing 256 (got %d)", C);
+    int nblk = cdiv(rows_cap, (256 / C) * 16);
+    nblk = nblk < 1 ? 1 : (nblk > kBnrBlocks ? kBnrBlocks : nblk);
+    const float* nof = nullptr;
+    TF_LAUNCH(bnr_stats_kernel<3>, dim3(nblk), dim3(256), stream, x, dz, z, nrows_dev, rows_cap, C, nof, save_mean, save_invstd, ws);
+    TF_LAUNCH(bnr_bwd_apply_kernel, dim3(pl_blocks((long)rows_cap * C)), dim3(256), stream, dz, z, x, nrows_dev, rows_cap, C, nblk, (const float*)ws, gamma, save_mean,
+              save_invstd, dx, dgamma, dbeta);
+    return launch_status("tf_bn_rows_dev_bwd_f32");
 }

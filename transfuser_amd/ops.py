@@ -1387,10 +1387,13 @@ def _scan(flags):
     return out, total
 
 
-def pillar_index(points, num_points, min_x, max_x, min_y, max_y, ppm):
+def pillar_index(points, num_points, min_x, max_x, min_y, max_y, ppm, static=False):
     """point_pillar.py:98-117 without the sort: returns a dict with the compacted points (N,4), 9 decorated features (N,9),
     inverse indices (N) int32, cellkey (P) int32 [= ((b*GX + x_idx)*GY + y_idx), sorted like torch.unique] and the grid dims.
-    One host read (N, P) - the reference's unique() synchronises at the same place."""
+    One host read (N, P) - the reference's unique() synchronises at the same place.
+    static=True (hipGraph capture): NO host read - every tensor has its capacity (N -> B * Nmax rows, P -> min(B * Nmax, cells)), ``totals`` =
+    (kept points, pillars) stays on the device, rows / slots beyond the counts are zero (points, inv, features of the zero point) or -1 (cell keys);
+    the consumers run over the capacity and the point net's BatchNorm reads its row count from ``totals`` (bn_rows_dev_*)."""
     B, Nmax, Fp = points.shape
     nx, ny = int((max_x - min_x) * ppm), int((max_y - min_y) * ppm)
     GX, GY = nx + 1, ny + 1
@@ -1403,21 +1406,57 @@ def pillar_index(points, num_points, min_x, max_x, min_y, max_y, ppm):
     # both scans + the cell keys in two launches, ONE host read of (N, P)
     ncells = B * GX * GY
     pos, rank, totals = i32(B * Nmax), i32(ncells), i32(2)
-    cellkey_full = i32(min(B * Nmax, ncells))
+    cellkey_full = torch.full((min(B * Nmax, ncells),), -1, dtype=torch.int32, device=dev) if static else i32(min(B * Nmax, ncells))
     ws = i32((B * Nmax + ncells) // 1024 + 4)
     check(L().tf_pillar_index_scan_i32(ptr(keys), ctypes.c_int64(B * Nmax), ptr(occ), ctypes.c_int64(ncells), ptr(pos), ptr(rank), ptr(cellkey_full), ptr(totals),
                                        ptr(ws), stream_of(points)), "tf_pillar_index_scan_i32")
-    N, P = (int(v) for v in totals.tolist())
-    pts4 = torch.empty(N, 4, dtype=torch.float32, device=dev)
+    if static:
+        N, P = B * Nmax, cellkey_full.numel()
+        pts4 = torch.zeros(N, 4, dtype=torch.float32, device=dev)
+        inv = torch.zeros(N, dtype=torch.int32, device=dev)
+    else:
+        N, P = (int(v) for v in totals.tolist())
+        pts4 = torch.empty(N, 4, dtype=torch.float32, device=dev)
+        inv = i32(N)
     feat = torch.empty(N, 9, dtype=torch.float32, device=dev)
-    inv, cellkey = i32(N), cellkey_full[:P]
+    cellkey = cellkey_full[:P]
     sums = torch.empty(P, 4, dtype=torch.int64, device=dev)      # fixed-point (2^-24 m) xyz sums + count: order-independent integer atomics
     if N:
         check(L().tf_pillar_gather_f32(ptr(points), Fp, ptr(keys), ptr(pos), c_p(0), ptr(rank), ctypes.c_int64(B * Nmax), ctypes.c_int64(ncells), P,
                                        ptr(pts4), ptr(inv), ptr(sums), ptr(cellkey), stream_of(points)), "tf_pillar_gather_f32")
         check(L().tf_pillar_decorate_f32(ptr(pts4), ptr(inv), ptr(sums), ptr(cellkey), ctypes.c_int64(N), GX, GY, f(ppm), f(min_x), f(min_y), ptr(feat),
                                          stream_of(points)), "tf_pillar_decorate_f32")
-    return dict(points=pts4, feat=feat, inv=inv, cellkey=cellkey, N=N, P=P, GX=GX, GY=GY, nx=nx, ny=ny)
+    return dict(points=pts4, feat=feat, inv=inv, cellkey=cellkey, N=N, P=P, GX=GX, GY=GY, nx=nx, ny=ny, totals=totals, static=bool(static))
+
+
+_bnr_ws = {}
+
+
+def _bn_rows_ws(C, device):
+    key = (str(device), C, torch.cuda.current_stream(device).cuda_stream if getattr(device, "type", str(device)[:4]) == "cuda" else 0)
+    ws = _bnr_ws.get(key)
+    if ws is None:
+        L().tf_bn_rows_dev_ws_floats.restype = ctypes.c_long
+        ws = _bnr_ws[key] = torch.empty(L().tf_bn_rows_dev_ws_floats(C), dtype=torch.float32, device=device)
+    return ws
+
+
+def bn_rows_dev_fwd(x, nrows_dev, gamma, beta, running_mean, running_var, momentum, eps, relu=True):
+    """BatchNorm1d (+ ReLU) over the first ``nrows_dev[0]`` rows of x (rows_cap, C), the count read on the device; rows beyond are written as zero."""
+    rows, C = x.shape
+    y = torch.empty_like(x)
+    sm, si = torch.empty(C, dtype=torch.float32, device=x.device), torch.empty(C, dtype=torch.float32, device=x.device)
+    check(L().tf_bn_rows_dev_fwd_f32(ptr(_c(x)), ptr(nrows_dev), rows, C, ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), ctypes.c_float(momentum),
+                                     ctypes.c_float(eps), int(relu), ptr(y), ptr(sm), ptr(si), ptr(_bn_rows_ws(C, x.device)), stream_of(x)), "tf_bn_rows_dev_fwd_f32")
+    return y, sm, si
+
+
+def bn_rows_dev_bwd(dz, z, x, nrows_dev, gamma, sm, si, dgamma, dbeta):
+    rows, C = x.shape
+    dx = torch.empty_like(x)
+    check(L().tf_bn_rows_dev_bwd_f32(ptr(_c(dz)), ptr(z), ptr(_c(x)), ptr(nrows_dev), rows, C, ptr(gamma), ptr(sm), ptr(si), ptr(dx), ptr(dgamma), ptr(dbeta),
+                                     ptr(_bn_rows_ws(C, x.device)), stream_of(x)), "tf_bn_rows_dev_bwd_f32")
+    return dx
 
 
 def pillar_scatter_max(z, inv, P):

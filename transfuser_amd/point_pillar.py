@@ -29,13 +29,22 @@ class PillarFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, points, num_points, extra, net, *params):
-        ix = ops.pillar_index(points, num_points, net.min_x, net.max_x, net.min_y, net.max_y, net.pixels_per_meter)
         seq = net.point_net.net
+        # static shapes (train.Engine under a hipGraph): no host read of the two counts - capacity-sized buffers, the BatchNorm1d layers take their row
+        # count from the device (ops.bn_rows_dev_*).  Needs plain local train-mode BatchNorm layers whose width divides 256.
+        static = bool(getattr(net, "static_shapes", False)) and all(
+            type(seq[li + 1]) is nn.BatchNorm1d and seq[li + 1].training and getattr(seq[li + 1], "_sync_group", None) is None and 256 % seq[li + 1].num_features == 0
+            for li in range(0, len(seq), 3))
+        ix = ops.pillar_index(points, num_points, net.min_x, net.max_x, net.min_y, net.max_y, net.pixels_per_meter, static=static)
         acts, x = [], ix["feat"]
         for li in range(0, len(seq), 3):
             lin, bn = seq[li], seq[li + 1]
             h = ops.linear_fwd(x, lin.weight, lin.bias)
-            z, st = F_._bn(h, bn, relu=True)
+            if static:
+                z, sm, si = ops.bn_rows_dev_fwd(h, ix["totals"], bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, relu=True)
+                st = (sm, si, "rows_dev")
+            else:
+                z, st = F_._bn(h, bn, relu=True)
             acts.append((x, h, z, st))
             x = z
         pf, arg = ops.pillar_scatter_max(x, ix["inv"], ix["P"])
@@ -51,7 +60,10 @@ class PillarFn(torch.autograd.Function):
         for k in range(len(acts) - 1, -1, -1):
             lin, bn = seq[3 * k], seq[3 * k + 1]
             x, h, z, st = acts[k]
-            dh, _ = F_._bn_bwd(dz, z, h, bn, st)
+            if len(st) == 3 and st[2] == "rows_dev":
+                dh = ops.bn_rows_dev_bwd(dz, z, h, ix["totals"], bn.weight, st[0], st[1], F_.gbuf(bn.weight), F_.gbuf(bn.bias))
+            else:
+                dh, _ = F_._bn_bwd(dz, z, h, bn, st)
             ops.linear_wgrad(dh, x, F_.gbuf(lin.weight))
             F_.bias_grad(dh, lin.bias)
             if k:

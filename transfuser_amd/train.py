@@ -444,6 +444,9 @@ class Engine:
                                 ("heatmap_head", "wh_head", "offset_head", "yaw_class_head", "yaw_res_head", "velocity_head", "brake_head")))
         model._dead_heads = frozenset(h for k, h in loss_to_head.items() if self.detailed_weights.get(k, 1.0) == 0.0)
         self.use_graph = use_graph
+        ppn = getattr(model, "point_pillar_net", None) if getattr(model, "use_point_pillars", False) else None
+        if ppn is not None:      # under a captured graph the PointPillars front-end runs with static shapes (no host read of the kept-point / pillar counts)
+            ppn.static_shapes = bool(use_graph)
         self._graphs = None
         self._static = None
         self._out = None
@@ -553,7 +556,7 @@ class Engine:
 
     def train_step(self, data):
         """Returns (total loss, dict of the 11 detailed losses) as device tensors (no host sync)."""
-        if not self.use_graph or getattr(self.model, "use_point_pillars", False):   # pillar counts are read on the host: eager only
+        if not self.use_graph:
             return self._eager_step(data)
         if self._graphs is None:
             self._capture(data)
