@@ -45,7 +45,7 @@ def workspace(device):
 GEMM_PAIR = os.environ.get("TF_GEMM_PAIR", "1") != "0"      # A/B switch of the round-5 pair launch
 _pair_open = [False]
 _pair_shapes = []      # (m, n, k, batch, flops) of the calls inside the open bracket (census only)
-_AB_MERGE_HEADS = os.environ.get("TF_AB_MERGE_HEADS", "1") != "0"      # TEMPORARY same-lease A/B switches of round 5 (removed once measured)
+_AB_MERGE_HEADS = os.environ.get("TF_AB_MERGE_HEADS", "1") != "0"      # same-lease A/B switches of round 5 (tools/final_evidence_r05.sh: "round-4 behaviour of the same library")
 _AB_WSUM = os.environ.get("TF_AB_WSUM", "1") != "0"
 
 
