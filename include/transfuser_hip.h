@@ -83,6 +83,11 @@ typedef struct {
      * of parts written, 0 when the plan chosen for this call cannot produce them (the caller then reduces separately).  Needs batch == 1,
      * a_trans == 0, store mode, no residual / ReLU / mask.  Consumed by tf_bn_fwd_parts_f32. */
     float* colstat; int* colstat_nparts;
+    /* nn.Dropout on the product before the residual is added (round 5; drop_seed NULL = off): c = res + dropout(alpha a b + bias), the
+     * x + resid_drop(proj(...)) / x + mlp(...)[-1] of a transformer Block (transfuser.py:543-549) in the GEMM's own epilogue.  The mask is the one
+     * tf_dropout_f32 / tf_dropout_add_f32 generate for (seed, site) over the contiguous (m, n) output, so the backward regenerates it with
+     * tf_dropout_f32.  Needs batch 1, a plain store, ldc == n, a_trans == 0. */
+    const uint32_t* drop_seed; uint32_t drop_site; float drop_p;
 } tf_gemm_desc;
 int tf_gemm_f32(const tf_gemm_desc* d, void* stream);
 /* Floats of splitk_ws this call can use: 0 unless the cached (or about-to-be-tuned) plan of the call's shape is a two-pass split-K plan, so

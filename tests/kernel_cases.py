@@ -990,6 +990,35 @@ def check_gemm_mask(dev, M, N, K):
     close(got, want, what="masked dgrad")
 
 
+def check_gemm_dropout(dev, M, N, K):
+    """y = res + dropout(x W^T + b) in the GEMM's own epilogue (tf_gemm_desc.drop_seed: the Block's x + resid_drop(proj(.)) / x + mlp(.),
+    transfuser.py:543-549) == the separate tf_dropout_add_f32 launch on the same product, BITWISE (same mask, same order of operations), under
+    the planner's choice, pinned engine tilings, every LDS-DMA configuration and a two-pass split-K plan (the fix-up pass applies the mask)."""
+    x, w, b, r = R(M, K, dev=dev), R(N, K, seed=1, dev=dev) * 0.1, R(N, seed=2, dev=dev), R(M, N, seed=3, dev=dev)
+    seed = torch.tensor([4321], dtype=torch.int32, device=dev)
+    site, p = 5, 0.1
+
+    def one(what):
+        want = ops.dropout_add(ops.linear_fwd(x, w, b), r, seed, site, p)
+        got = ops.linear_fwd(x, w, b, res=r, drop=(seed, site, p))
+        assert torch.equal(got, want), "dropout epilogue (%s): max diff %.3e" % (what, (got - want).abs().max().item())
+        kept = (got != r).float().mean().item()
+        assert abs(kept - (1 - p)) < 0.05, kept
+    try:
+        one("planned")
+        for bm, bn, bk in ((64, 64, 16), (128, 32, 32), (64, 128, 16)):
+            ops.force_plan(bm, bn, bk, 1)
+            one("engine %dx%dx%d" % (bm, bn, bk))
+        for kind in (1, 2, 3, 4, 5):
+            for sk in (1, 2):
+                ops.force_dma(kind, sk)
+                one("dma %d split %d" % (kind, sk))
+    finally:
+        ops.force_plan(0)
+    y0 = ops.linear_fwd(x, w, b, res=r, drop=(seed, site, 0.0))
+    assert torch.equal(y0, ops.linear_fwd(x, w, b, res=r)), "p = 0 keeps everything"
+
+
 # ---------------------------------------------------------------- the benchmarked shapes under the shipped (tuned) plans, CPU fp32 reference
 BENCH_GEMMS = [(1740, 6048, 1512), (1740, 1512, 6048), (1740, 4536, 1512), (1740, 1512, 1512), (7040, 576, 576), (2560, 576, 576), (28160, 216, 216)]
 

@@ -229,6 +229,11 @@ def test_gemm_relu_mask_epilogue(case):
     kc.check_gemm_mask("cpu", *case)
 
 
+@pytest.mark.parametrize("case", [(174, 72, 72), (348, 216, 864), (130, 100, 52)], ids=str)
+def test_gemm_dropout_residual_epilogue(case):
+    kc.check_gemm_dropout("cpu", *case)
+
+
 def test_conv_grouped_stride2_direct_kernels_compute_modes():
     kc.check_grouped_s2_modes("cpu")
 

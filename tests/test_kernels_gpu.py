@@ -259,6 +259,11 @@ def test_gemm_relu_mask_epilogue(case):
     kc.check_gemm_mask("cuda", *case)
 
 
+@pytest.mark.parametrize("case", [(174, 72, 72), (348, 216, 864), (130, 100, 52)], ids=str)
+def test_gemm_dropout_residual_epilogue(case):
+    kc.check_gemm_dropout("cuda", *case)
+
+
 @pytest.fixture
 def tuned_plans():
     """The plan cache bench.py runs with (transfuser_amd/plans/mi355x.txt, loaded by train.Engine)."""

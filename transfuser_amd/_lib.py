@@ -29,7 +29,8 @@ class GemmDesc(ctypes.Structure):
                 ("batch", c_i), ("inner", c_i),
                 ("sa_outer", c_l), ("sa_inner", c_l), ("sb_outer", c_l), ("sb_inner", c_l), ("sc_outer", c_l), ("sc_inner", c_l),
                 ("alpha", c_f), ("relu", c_i), ("accumulate", c_i), ("mask", c_p), ("ldmask", c_l),
-                ("splitk_ws", c_p), ("splitk_ws_floats", c_l), ("sk_flags", c_p), ("colstat", c_p), ("colstat_nparts", ctypes.POINTER(ctypes.c_int))]
+                ("splitk_ws", c_p), ("splitk_ws_floats", c_l), ("sk_flags", c_p), ("colstat", c_p), ("colstat_nparts", ctypes.POINTER(ctypes.c_int)),
+                ("drop_seed", c_p), ("drop_site", ctypes.c_uint32), ("drop_p", c_f)]
 
 
 class ConvGeom(ctypes.Structure):

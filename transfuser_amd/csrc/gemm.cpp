@@ -55,7 +55,7 @@ extern "C" int tf_gemm_f32(const tf_gemm_desc* d, void* stream) {
                d->k, d->batch);
     const int inner = d->inner > 0 ? d->inner : 1;
     // per-sample matmuls (SE excitation, join MLP): rows = batch <= 16 -> streaming kernels instead of a 128-row MFMA tile
-    if (d->batch == 1 && d->alpha == 1.0f && d->m > 0 && d->n > 0 && d->k > 0 && !d->mask && !d->colstat) {
+    if (d->batch == 1 && d->alpha == 1.0f && d->m > 0 && d->n > 0 && d->k > 0 && !d->mask && !d->colstat && !d->drop_seed) {
         if (!d->a_trans && !d->b_trans && d->m <= 16 && !d->accumulate)
             return smallm_fwd(d->a, d->lda, d->b, d->ldb, d->bias, d->res, d->ldres, d->c, d->ldc, d->m, d->n, d->k, d->relu, stream);
         if (!d->a_trans && d->b_trans && d->m <= 16 && !d->bias && !d->relu && !(d->accumulate && d->res))
@@ -82,6 +82,11 @@ extern "C" int tf_gemm_f32(const tf_gemm_desc* d, void* stream) {
         *d->colstat_nparts = 0;
     }
     TF_REQUIRE(!d->mask || (d->batch == 1 && !d->accumulate), "tf_gemm_f32: mask needs batch == 1 and a plain store");
+    if (d->drop_seed) {
+        TF_REQUIRE(d->batch == 1 && !d->accumulate && !d->a_trans && d->ldc == d->n && d->drop_p >= 0.f && d->drop_p < 1.f && !d->colstat && (long)d->m * d->n < 4294967296L,
+                   "tf_gemm_f32: drop_seed needs batch 1, a plain store into a contiguous (m, n) output, row-major A and 0 <= drop_p < 1");
+        ep.drop_seed = d->drop_seed; ep.drop_site = d->drop_site; ep.drop_thresh = (uint32_t)((double)d->drop_p * 4294967296.0); ep.drop_scale = 1.f / (1.f - d->drop_p);
+    }
     // A: KC when stored [m][k] (rows = i), IC when stored [k][m] (rows = k)
     PlainOp A = d->a_trans ? make_plain(d->a, d->lda, d->k, d->m, d->sa_outer, d->sa_inner, inner, d->batch)
                            : make_plain(d->a, d->lda, d->m, d->k, d->sa_outer, d->sa_inner, inner, d->batch);

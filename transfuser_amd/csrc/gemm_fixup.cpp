@@ -25,9 +25,11 @@ __global__ void __launch_bounds__(256) splitk_fixup_kernel(const float* __restri
         } else v[0] += p[(long)s * sk_stride];
     }
     float* dst = ep.C + (long)i * ep.ldc + j;
+    const uint32_t dseed = ep.drop_seed ? *ep.drop_seed : 0u;
 #pragma unroll
     for (int e = 0; e < V; ++e) {
         float x = ep.alpha * v[e] + (ep.bias ? ep.bias[j + e] : 0.f);
+        if (ep.drop_seed) x = dropout_keep(dseed, ep.drop_site, (uint32_t)((long)i * N + j + e), ep.drop_thresh) ? x * ep.drop_scale : 0.f;      // see GemmEpi.drop_seed
         if (ep.res) x += ep.res[(long)i * ep.ldres + j + e];
         x = ep.relu ? fmaxf(x, 0.f) : x;
         if (ep.mask) x = (ep.mask[(long)i * ep.ldmask + j + e] > 0.f) ? x : 0.f;

@@ -480,6 +480,7 @@ inline void launch_dma_cfg(const PlainOp& la, const PlainOp& lb, const GemmEpi& 
     if (twopass) {      // slices store raw partial sums [M][ldws] into the caller's scratch; the epilogue proper runs in the fix-up pass
         epg.C = ep.sk_ws; epg.ldc = ldws; epg.ldcj = 1; epg.sc_outer = epg.sc_inner = 0; epg.inner = 1; epg.bias = nullptr; epg.res = nullptr;
         epg.mask = nullptr; epg.alpha = 1.f; epg.relu = 0; epg.mode = 0; epg.sk_stride = (long)M * ldws;
+        epg.drop_seed = nullptr;
     }
     {
         long panel = (long)C::BM * (kchunk < K ? kchunk : K) * 4;

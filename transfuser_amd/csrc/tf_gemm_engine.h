@@ -252,6 +252,10 @@ struct GemmEpi {
     // merges the parts (Chan's formula).  Only for plain stores (mode 0, no residual / ReLU / mask / split-K).  stat_nparts: HOST pointer,
     // set at launch time to the number of parts this launch writes (0: the chosen plan cannot produce them - caller falls back).
     float* stat = nullptr; long stat_ld = 0; int* stat_nparts = nullptr;
+    // nn.Dropout on the product BEFORE the residual is added (x + resid_drop(proj(...)), transfuser.py:543-544): element (i, j) survives iff
+    // dropout_keep(*drop_seed, drop_site, i * N + j, drop_thresh) - the mask tf_dropout_add_f32 / tf_dropout_f32 generate for the same (seed, site) over
+    // the contiguous (M, N) output, so the backward's tf_dropout_f32 regenerates it.  Batch 1, ldc == N.  (round 5: one launch less per residual branch)
+    const uint32_t* drop_seed = nullptr; uint32_t drop_site = 0, drop_thresh = 0; float drop_scale = 1.f;
     int prec = 0;                    // 0: exact fp32 MFMA; 1: operands rounded to bf16 on the LDS->register path, bf16 MFMA, fp32 accumulate; 2: bf16x3 split (fp32-accurate, 6 bf16 MFMAs); 3: as 1 with IEEE-half operands (set by launch_cfg)
     int packed16 = 0;                // LDS-DMA kernels, both operands K-contiguous: the operands ARE 16-bit matrices (1: bf16, 2: IEEE half) described in units of
                                      // 4 bytes (ld, cols, K = halves / 2): tiles are moved as bytes, one ds_read_b128 = one 8-deep MFMA operand (tf_gemm16_nt_f32)
@@ -271,6 +275,7 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[TM][TN], const
     const float* res = ep.res ? ep.res + cz : nullptr;
     const float* bias = ep.bias ? ep.bias + (long)z * ep.sbias : nullptr;
     const bool full = (i0 + BM <= M) && (j0 + BN <= N);
+    const uint32_t dseed = ep.drop_seed ? *ep.drop_seed : 0u;
     auto emit = [&](auto mode_c, auto res_c, auto full_c) {
         constexpr int MODE = decltype(mode_c)::value;
         constexpr bool RES = decltype(res_c)::value, FULL = decltype(full_c)::value;
@@ -286,6 +291,7 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[TM][TN], const
                     const int i = i0 + wm0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                     if (FULL || (jok && i < M)) {
                         float v = ep.alpha * acc[t][u][r] + bj;
+                        if (ep.drop_seed) v = dropout_keep(dseed, ep.drop_site, (uint32_t)((long)i * N + j), ep.drop_thresh) ? v * ep.drop_scale : 0.f;
                         if (RES) v += res[(long)i * ep.ldres + j];
                         v = ep.relu ? fmaxf(v, 0.f) : v;
                         if (ep.mask) v = (ep.mask[(long)i * ep.ldmask + j] > 0.f) ? v : 0.f;

@@ -640,7 +640,10 @@ def _gpt_block_fwd(gpt, li, x, B, T, drop):
     else:
         ya_16 = y_att
         lin = lambda a, layer, **kw: ops.linear_fwd(a, layer.weight, layer.bias, **kw)
-    if rdrop:
+    fdrop = rdrop and not lowp and ops.FUSE_DROPOUT      # fp32-stored operands: resid_drop + the residual add ride in the GEMM's epilogue (same mask)
+    if fdrop:
+        x_mid = lin(ya_16, blk.attn.proj, res=x, drop=(gpt.seed, gpt.site(4 * li + 2), gpt.resid_pdrop))
+    elif rdrop:
         pr = lin(ya_16, blk.attn.proj)
         x_mid = ops.dropout_add(pr, x, gpt.seed, gpt.site(4 * li + 2), gpt.resid_pdrop, out=pr)
     else:
@@ -654,7 +657,9 @@ def _gpt_block_fwd(gpt, li, x, B, T, drop):
         a1s = A16(a1_t, a1)
     else:
         a1 = a1_16 = a1s = lin(h2, blk.mlp[0], relu=True)
-    if rdrop:
+    if fdrop:
+        x_out = lin(a1_16, blk.mlp[2], res=x_mid, drop=(gpt.seed, gpt.site(4 * li + 3), gpt.resid_pdrop))
+    elif rdrop:
         f2 = lin(a1_16, blk.mlp[2])
         x_out = ops.dropout_add(f2, x_mid, gpt.seed, gpt.site(4 * li + 3), gpt.resid_pdrop, out=f2)
     else:

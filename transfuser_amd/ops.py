@@ -316,8 +316,9 @@ def _ws_query():
 
 
 def gemm(a, b, c, m, n, k, lda, ldb, ldc, a_trans=False, b_trans=False, bias=None, res=None, ldres=0, alpha=1.0, relu=False,
-         accumulate=False, batch=1, inner=1, sa=(0, 0), sb=(0, 0), sc=(0, 0), mask=None, colstat=None):
-    """colstat: a ColStat request (see linear_fwd(..., colstat=True)): the epilogue also writes the BatchNorm statistics of the output."""
+         accumulate=False, batch=1, inner=1, sa=(0, 0), sb=(0, 0), sc=(0, 0), mask=None, colstat=None, drop=None):
+    """colstat: a ColStat request (see linear_fwd(..., colstat=True)): the epilogue also writes the BatchNorm statistics of the output.
+    drop = (seed tensor, site, p): nn.Dropout on the product before ``res`` is added (tf_gemm_desc.drop_seed; the mask of ops.dropout(seed, site, p))."""
     if _CHECK and c.is_cuda:
         cview = lambda: torch.as_strided(c, (batch // inner, inner, m, n), (sc[0], sc[1], ldc, 1))
         old = cview().double().clone() if accumulate else None
@@ -330,6 +331,9 @@ def gemm(a, b, c, m, n, k, lda, ldb, ldc, a_trans=False, b_trans=False, bias=Non
                  ldmask=mask.stride(0) if mask is not None else 0, splitk_ws=c_p(0), splitk_ws_floats=0)
     if colstat is not None:
         d.colstat, d.colstat_nparts = ptr(colstat.buf), ctypes.pointer(colstat.nparts)
+    if drop is not None:
+        assert ldc == n and batch == 1 and not accumulate, "gemm: dropout epilogue needs a contiguous (m, n) plain store"
+        d.drop_seed, d.drop_site, d.drop_p = ptr(drop[0]), int(drop[1]), float(drop[2])
     skws = None
     if TWO_PASS_SPLITK and batch == 1 and k >= 256 and 128 * 128 <= m * n and (m * n <= _TWO_PASS_MAX_ELEMS or STREAM_K):
         need = _ws_query()(byref(d))          # > 0 only when the plan of THIS shape is a two-pass / stream-K plan (or the autotuner wants to try one)
@@ -388,16 +392,17 @@ def want_colstat(rows):
     return FUSE_BN_STATS and rows <= _COLSTAT_MAX_ROWS
 
 
-def linear_fwd(x, w, bias=None, relu=False, res=None, out=None, colstat=False):
+def linear_fwd(x, w, bias=None, relu=False, res=None, out=None, colstat=False, drop=None):
     """y = x @ w.T + bias (+res) (relu); x (M, K) row-major (row stride may exceed K), w (N, K).
-    colstat=True: returns (y, ColStat) - the epilogue also gathers the BatchNorm statistics of y (None when not worthwhile / not possible)."""
+    colstat=True: returns (y, ColStat) - the epilogue also gathers the BatchNorm statistics of y (None when not worthwhile / not possible).
+    drop = (seed, site, p): y = res + dropout(x @ w.T + bias) in the same launch (the Block's residual branches, transfuser.py:543-549)."""
     M, K = x.shape
     N = w.shape[0]
     if out is None:
         out = torch.empty(M, N, dtype=torch.float32, device=x.device)
     cs = ColStat(M, N, x.device) if (colstat and want_colstat(M) and res is None and not relu) else None
     y = gemm(x, w, out, M, N, K, x.stride(0), w.stride(0), out.stride(0), bias=bias, res=res,
-             ldres=res.stride(0) if res is not None else 0, relu=relu, colstat=cs)
+             ldres=res.stride(0) if res is not None else 0, relu=relu, colstat=cs, drop=drop)
     return (y, cs if cs else None) if colstat else y
 
 
@@ -1023,6 +1028,9 @@ def bn_bwd(dz, z, x, gamma, sm, si, dgamma, dbeta, want_dres=False):
     # reduce pass reads dz, x (+ z); apply pass reads them again and writes dx (+ dres)
     _hbm_end(_h, "batchnorm backward (reduce + finalize + apply)", 4 * x.numel() * ((2 + (z is not None)) * 2 + 1 + (dres is not None)))
     return dx, dres
+
+
+FUSE_DROPOUT = os.environ.get("TF_FUSE_DROPOUT", "1") != "0"      # A/B switch of round 5: resid_drop + residual add in the producing GEMM's epilogue
 
 
 COLSUM_MULTI = os.environ.get("TF_COLSUM_MULTI", "1") != "0"      # the Block's bias gradients in one launch (A/B switch)
