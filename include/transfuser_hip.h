@@ -172,6 +172,16 @@ int tf_colsum_multi_f32(int n, const float* const* xs, const int* Cs, const long
  * accumulate); k, lda, ldb % 8 == 0; dtype as above (+ 16 x kind pins LDS-DMA tile configuration kind = 1..8: tests / tuning).  With the transposed copies every contraction of a linear layer (transfuser.py:500-527,540-547:
  * y = x W^T, dx = dy W, dW = dy^T x) is such an NT product. */
 int tf_cast16_f32(const float* x, int rows, int cols, int ldx, void* y16, int ldy, void* y16t, int ldyt, int dtype, void* stream);
+/* The same copies of MANY matrices in one launch (round 5: every cached 16-bit linear weight after AdamW, train.py:316 optimizer.step()): a
+ * DEVICE-resident table sorted by tile0 = the index of the item's first 64 x 64 tile in the launch (prefix sums of ceil(rows / 64) * ceil(cols / 64));
+ * total_tiles = the sum.  Per item the rules of tf_cast16_f32 hold (the caller checks them: the table is device memory). */
+typedef struct { const float* x; void* y16; void* y16t; int rows, cols, ldx, ldy, ldyt, tile0; } tf_cast16_item;
+int tf_cast16_multi_f32(const tf_cast16_item* items_dev, int n_items, int total_tiles, int dtype, void* stream);
+/* nn.LayerNorm whose outputs are ONLY those 16-bit copies (round 5): ln1 / ln2 of a Block in the 16-bit storage modes (transfuser.py:535-536,546-547),
+ * == tf_cast16_f32(tf_layernorm_fwd_f32(x)) bitwise, without the fp32 tensor in between.  C % 4 == 0, C <= 2048, 16-byte aligned x / gamma / beta;
+ * y16 (may be NULL): ldy % 4 == 0, 8-byte aligned; y16t (may be NULL): as tf_cast16_f32.  mean / rstd as tf_layernorm_fwd_f32 (kept for the backward). */
+int tf_layernorm_fwd16_f32(const float* x, const float* gamma, const float* beta, void* y16, int ldy, void* y16t, int ldyt, float* mean, float* rstd,
+                           int rows, int C, float eps, int dtype, void* stream);
 int tf_gemm16_nt_f32(const void* a16, const void* b16, float* c, int m, int n, int k, int lda, int ldb, int ldc, const float* bias, const float* res, int ldres,
                      float alpha, int relu, int accumulate, const float* mask, int ldmask, int dtype, void* stream);
 /* plain store + the BatchNorm statistics of the output (tf_gemm_desc.colstat semantics): the RegNetY 1x1 convolutions in the 16-bit storage modes */
@@ -251,6 +261,11 @@ int tf_stem_conv_wgrad_ws_f32(const tf_conv_geom* g, const float* dy, const floa
 int tf_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, int rows, int C, float eps, void* stream);
 int tf_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx, int dx_accumulate,
                          float* dgamma, float* dbeta, int rows, int C, void* stream);
+/* tf_layernorm_bwd_f32 + a second output dropped = nn.Dropout(p)(dx) (dx = the finished, accumulated gradient) with the mask of
+ * tf_dropout_f32(seed, site) over the contiguous (rows, C) tensor: the gradient entering the attention branch of a Block behind ln2's backward
+ * (x_mid = x + resid_drop(proj(.)), transfuser.py:543-547) without a separate dropout launch (round 5).  dropped != dx. */
+int tf_layernorm_bwd_drop_f32(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx, int dx_accumulate,
+                              float* dgamma, float* dbeta, int rows, int C, float* dropped, const uint32_t* seed_dev, uint32_t site, float p, void* stream);
 /* F.softmax over attention rows (transfuser.py:520), in place; bwd turns dP into dS in place. */
 int tf_softmax_fwd_f32(float* s, int rows, int n, int ld, void* stream);
 int tf_softmax_bwd_f32(const float* p, float* dp, int rows, int n, int ld, void* stream);

@@ -1180,6 +1180,63 @@ def check_lowp16_storage(dev, mode):
         ops.set_precision("fp32")
 
 
+def check_lowp16_fused_producers(dev, mode):
+    """Round 5: the 16-bit operand copies written by their PRODUCERS instead of cast launches - bitwise equal to the separate launches.
+    (1) tf_layernorm_fwd16_f32 == tf_cast16_f32(tf_layernorm_fwd_f32(x)): both copies, the zero pad rows of the transposed one, mean / rstd; row counts
+        around the 8-row blocks, every register-row width (C up to 2048).  (2) tf_cast16_multi_f32 == one tf_cast16_f32 per matrix (ragged shapes)."""
+    ops.set_precision(mode)
+    try:
+        for rows, C in ((61, 72), (64, 216), (8, 576), (1, 24), (349, 1512), (13, 2048), (20, 1024), (9, 260)):
+            x = R(rows, C, dev=dev, scale=2.0) + 0.5
+            g, b = R(C, seed=1, dev=dev), R(C, seed=2, dev=dev)
+            assert ops.layernorm_fwd16_ok(x, g, b)
+            h, m, r = ops.layernorm_fwd(x, g, b, 1e-5)
+            y, yt = ops.cast16(h)
+            y2, yt2, m2, r2 = ops.layernorm_fwd16(x, g, b, 1e-5)
+            assert torch.equal(m, m2) and torch.equal(r, r2), "fwd16 statistics"
+            assert torch.equal(y.view(torch.int16), y2.view(torch.int16)), "fwd16 row-major copy (%d, %d)" % (rows, C)
+            assert yt2.shape == yt.shape and torch.equal(yt.view(torch.int16), yt2.view(torch.int16)), "fwd16 transposed copy (%d, %d)" % (rows, C)
+            assert bool((yt2[:, rows:].float() == 0).all()), "fwd16: the pad rows of the transposed copy must be zero"
+        assert not ops.layernorm_fwd16_ok(R(4, 2052, dev=dev), R(2052, dev=dev), R(2052, dev=dev))
+        # many matrices, one launch: the Engine's weight refresh
+        ws = [R(n, k, seed=i, dev=dev) for i, (n, k) in enumerate(((216, 72), (72, 216), (70, 40), (1, 8), (130, 264), (64, 64)))]
+        for w in ws:
+            ops.lowp_weight(w)                                 # registers (w, w16, w16t) in the cache
+        for w in ws:
+            w.mul_(1.5).add_(0.25)                             # "AdamW"
+        old = ops.CAST16_MULTI
+        try:
+            ops.CAST16_MULTI = True
+            with ops.lowp_managed():
+                ops.lowp_refresh_weights()
+                got = [tuple(t.clone() for t in ops.lowp_weight(w)) for w in ws]
+        finally:
+            ops.CAST16_MULTI = old
+        for w, (g16, g16t) in zip(ws, got):
+            y, yt = ops.cast16(w)
+            assert torch.equal(y.view(torch.int16), g16.view(torch.int16)) and torch.equal(yt.view(torch.int16), g16t.view(torch.int16)), "cast16_multi %s" % (tuple(w.shape),)
+    finally:
+        ops.set_precision("fp32")
+
+
+def check_layernorm_bwd_drop(dev):
+    """tf_layernorm_bwd_drop_f32: dx as tf_layernorm_bwd_f32 (bitwise, with and without accumulation), dropped == tf_dropout_f32(dx) (same mask)."""
+    seed = torch.tensor([99], dtype=torch.int32, device=dev)
+    for rows, C in ((61, 72), (174, 216), (9, 1512), (5, 30), (33, 2048)):
+        x, dy = R(rows, C, dev=dev), R(rows, C, seed=1, dev=dev)
+        g, b = R(C, seed=2, dev=dev), R(C, seed=3, dev=dev)
+        _, m, r = ops.layernorm_fwd(x, g, b, 1e-5)
+        for acc in (False, True):
+            base = R(rows, C, seed=4, dev=dev)
+            dg0, db0 = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+            dg1, db1 = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+            want = ops.layernorm_bwd(dy, x, g, m, r, dg0, db0, dx=base.clone(), accumulate=acc)
+            got, dropped = ops.layernorm_bwd(dy, x, g, m, r, dg1, db1, dx=base.clone(), accumulate=acc, drop=(seed, 6, 0.1))
+            assert torch.equal(got, want), "ln bwd drop: dx"
+            assert torch.equal(dropped, ops.dropout(want, seed, 6, 0.1)), "ln bwd drop: dropped (%d, %d)" % (rows, C)
+            close(dg1, dg0, what="ln bwd drop dgamma"); close(db1, db0, what="ln bwd drop dbeta")
+
+
 def check_conv1x1_s2_dgrad(dev):
     """Input gradient of a 1x1 / stride-2 convolution in accumulate mode (the RegNet downsample branch): plain GEMM + scatter-add path."""
     for (B, Hi, Wi, Cin, Cout) in ((2, 8, 8, 32, 72), (1, 9, 7, 24, 40), (2, 16, 44, 72, 216)):

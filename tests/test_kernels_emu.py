@@ -187,6 +187,15 @@ def test_lowp16_storage_cast_and_gemm(mode):
     kc.check_lowp16_storage("cpu", mode)
 
 
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+def test_lowp16_copies_written_by_their_producers(mode):
+    kc.check_lowp16_fused_producers("cpu", mode)
+
+
+def test_layernorm_backward_with_dropped_second_output():
+    kc.check_layernorm_bwd_drop("cpu")
+
+
 def test_fp16_mfma_mode():
     kc.check_bf16_mode("cpu", "plan", (64, 64, 16, 1), mode="fp16")
     kc.check_bf16_mode("cpu", "dma", (1, 1), mode="fp16")

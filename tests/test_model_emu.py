@@ -330,6 +330,11 @@ def test_dropout_paths_match_oracle_with_the_same_masks():
     mc.check_dropout_model("cpu")
 
 
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_round5_launch_fusions_are_bitwise_neutral(mode):
+    mc.check_round5_fusions_bitwise("cpu", mode)
+
+
 @pytest.mark.parametrize("mode", ["bf16", "fp16"])
 def test_lowp_storage_modes_tiny_model(mode):
     """16-bit operand STORAGE (ops.lowp_storage(): the GPT linear layers run on cast16 / gemm16_nt) end to end on the tiny model: the 11 losses

@@ -259,6 +259,12 @@ def test_bench_configuration_parity_B10_H256():
     mc.check_full_size_vs_fp32_oracle("transFuser", 10, 256)
 
 
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_round5_launch_fusions_are_neutral_on_gpu(mode):
+    """resid_drop in the GEMM epilogue / from ln2's backward launch, LayerNorm writing the 16-bit copies, one-launch weight copies: on vs off."""
+    mc.check_round5_fusions_bitwise("cuda", mode)
+
+
 def test_dropout_paths_match_oracle_on_gpu():
     """p = 0.1 - the bench's setting - on the MI355X against the ORACLE (not against the unfused product kernels): the whole tiny model
     (28 dropout sites: embd_drop, attn_drop inside the softmax kernels, the two fused dropout + residual adds per Block, masks regenerated in

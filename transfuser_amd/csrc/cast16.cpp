@@ -17,10 +17,9 @@ constexpr int TS = 64;            // tile side
 constexpr int TP = TS + 8;        // LDS row pitch in halves (16-byte aligned rows, bank spread)
 
 // y16[r][c] (ld ldy) and / or y16t[c][r] (ld ldyt) from x[r][c] (ld ldx); pad columns of y16 (cols .. ldy) and pad rows of y16t (rows .. rows8) are zeroed
-__global__ void __launch_bounds__(256) cast16_kernel(const float* __restrict__ x, int rows, int cols, long ldx, uint16_t* __restrict__ y, long ldy,
-                                                     uint16_t* __restrict__ yt, long ldyt, int f16, int vec) {
-    __shared__ __attribute__((aligned(16))) uint16_t T[TS * TP];
-    const int tid = threadIdx.x, r0 = blockIdx.y * TS, c0 = blockIdx.x * TS;
+__device__ __forceinline__ void cast16_tile(const float* __restrict__ x, int rows, int cols, long ldx, uint16_t* __restrict__ y, long ldy,
+                                            uint16_t* __restrict__ yt, long ldyt, int f16, int vec, int bx, int by, uint16_t* T) {
+    const int tid = threadIdx.x, r0 = by * TS, c0 = bx * TS;
     const int c4 = (tid & 15) * 4;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
@@ -56,6 +55,27 @@ __global__ void __launch_bounds__(256) cast16_kernel(const float* __restrict__ x
             *reinterpret_cast<float4*>(yt + (long)(c0 + col) * ldyt + r0 + rc) = q;
         }
     }
+}
+__global__ void __launch_bounds__(256) cast16_kernel(const float* __restrict__ x, int rows, int cols, long ldx, uint16_t* __restrict__ y, long ldy,
+                                                     uint16_t* __restrict__ yt, long ldyt, int f16, int vec) {
+    __shared__ __attribute__((aligned(16))) uint16_t T[TS * TP];
+    cast16_tile(x, rows, cols, ldx, y, ldy, yt, ldyt, f16, vec, blockIdx.x, blockIdx.y, T);
+}
+// Many matrices in ONE launch (round 5): the 16-bit copies of every cached linear weight after AdamW were one launch per weight (64 per step in the
+// TransFuser configuration).  Block b works on tile b - items[i].tile0 of the item whose tile range holds b (the table is sorted by tile0).
+__global__ void __launch_bounds__(256) cast16_multi_kernel(const tf_cast16_item* __restrict__ items, int n_items, int f16) {
+    __shared__ __attribute__((aligned(16))) uint16_t T[TS * TP];
+    const int b = blockIdx.x;
+    int lo = 0, hi = n_items - 1;
+    while (lo < hi) {                          // last item with tile0 <= b (block-uniform)
+        const int mid = (lo + hi + 1) >> 1;
+        if (items[mid].tile0 <= b) lo = mid; else hi = mid - 1;
+    }
+    const tf_cast16_item it = items[lo];
+    const int tx = (it.cols + TS - 1) / TS, t = b - it.tile0;
+    if (t >= tx * ((it.rows + TS - 1) / TS)) return;
+    const int vec = ((((uintptr_t)it.x) & 15) == 0 && it.ldx % 4 == 0) ? 1 : 0;
+    cast16_tile(it.x, it.rows, it.cols, (long)it.ldx, (uint16_t*)it.y16, (long)it.ldy, (uint16_t*)it.y16t, (long)it.ldyt, f16, vec, t % tx, t / tx, T);
 }
 
 // dst[b][2 i][2 j][:] += src[b][i][j][:]  (input gradient of a 1x1 / stride-2 convolution = a plain GEMM + this scatter)
@@ -106,6 +126,12 @@ extern "C" int tf_cast16_f32(const float* x, int rows, int cols, int ldx, void* 
     TF_LAUNCH(cast16_kernel, dim3(cdiv(cols, TS), cdiv(rows, TS)), dim3(256), stream, x, rows, cols, (long)ldx, (uint16_t*)y16, (long)ldy, (uint16_t*)y16t, (long)ldyt,
               dtype == 2 ? 1 : 0, vec);
     return launch_status("tf_cast16_f32");
+}
+
+extern "C" int tf_cast16_multi_f32(const tf_cast16_item* items_dev, int n_items, int total_tiles, int dtype, void* stream) {
+    TF_REQUIRE(items_dev && n_items > 0 && total_tiles > 0 && (dtype == 1 || dtype == 2), "tf_cast16_multi_f32: bad arguments (dtype 1 = bf16, 2 = fp16)");
+    TF_LAUNCH(cast16_multi_kernel, dim3(total_tiles), dim3(256), stream, items_dev, n_items, dtype == 2 ? 1 : 0);
+    return launch_status("tf_cast16_multi_f32");
 }
 
 extern "C" int tf_im2col3x3_f32(const float* x, float* cols, int B, int H, int W, int C, void* stream) {

@@ -33,11 +33,16 @@ __global__ void __launch_bounds__(256) layernorm_fwd_kernel(const float* __restr
     if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
 }
 
+// Optional second output of the backward (round 5): out = nn.Dropout(dx) with the mask tf_dropout_f32 generates for (seed, site) over the contiguous
+// (rows, C) tensor - the gradient that enters the NEXT residual branch of a transformer Block (x_mid = x + resid_drop(proj(.)), transfuser.py:543),
+// written by the launch that finishes dx instead of a separate dropout launch.
+struct LnDrop { float* out; const uint32_t* seed; uint32_t site, thresh; float keep_scale; };
+
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma
 __global__ void __launch_bounds__(256) layernorm_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                const float* __restrict__ gamma, const float* __restrict__ mean,
                                                                const float* __restrict__ rstd, float* __restrict__ dx, int rows, int C,
-                                                               int accumulate) {
+                                                               int accumulate, LnDrop dr) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const bool live = row < rows;
@@ -57,7 +62,9 @@ __global__ void __launch_bounds__(256) layernorm_bwd_dx_kernel(const float* __re
         float g = dy[o + c] * gamma[c];
         float xh = (x[o + c] - m) * rs;
         float v = rs * (g - s1 - xh * s2);
-        if (accumulate) dx[o + c] += v; else dx[o + c] = v;
+        if (accumulate) v += dx[o + c];
+        dx[o + c] = v;
+        if (dr.out) dr.out[o + c] = dropout_keep(*dr.seed, dr.site, (uint32_t)(o + c), dr.thresh) ? v * dr.keep_scale : 0.f;
     }
 }
 
@@ -111,7 +118,7 @@ __global__ void __launch_bounds__(256) layernorm_fwd_v4_kernel(const float* __re
 template <int NV>
 __global__ void __launch_bounds__(256) layernorm_bwd_dx_v4_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
                                                                   const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ dx, int rows,
-                                                                  int C, int accumulate) {
+                                                                  int C, int accumulate, LnDrop dr) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     const bool live = row < rows;
     const int cv = C >> 2;
@@ -149,7 +156,75 @@ __global__ void __launch_bounds__(256) layernorm_bwd_dx_v4_kernel(const float* _
                                    rs * (g[u].w - s1 - xh[u].w * s2));
             if (accumulate) { v.x += old[u].x; v.y += old[u].y; v.z += old[u].z; v.w += old[u].w; }
             o4[lane + 64 * u] = v;
+            if (dr.out) {
+                const uint32_t sd = *dr.seed, e0 = (uint32_t)(o + 4 * (lane + 64 * u));
+                reinterpret_cast<float4*>(dr.out + o)[lane + 64 * u] =
+                    make_float4(dropout_keep(sd, dr.site, e0, dr.thresh) ? v.x * dr.keep_scale : 0.f, dropout_keep(sd, dr.site, e0 + 1, dr.thresh) ? v.y * dr.keep_scale : 0.f,
+                                dropout_keep(sd, dr.site, e0 + 2, dr.thresh) ? v.z * dr.keep_scale : 0.f, dropout_keep(sd, dr.site, e0 + 3, dr.thresh) ? v.w * dr.keep_scale : 0.f);
+            }
         }
+}
+// ---- LayerNorm forward whose ONLY outputs are the 16-bit operand copies of the packed-16 GEMM path (round 5; bf16 / fp16 storage modes): y16 [rows][C]
+// and its transpose y16t [C][rows8] (rows zero-padded to a multiple of 8), exactly what tf_cast16_f32 writes from the fp32 result of
+// tf_layernorm_fwd_f32 - which nothing reads in those modes (the Block's backward needs x, mean, rstd and the TRANSPOSED 16-bit copy).  8 rows per
+// block (one wave each, the row in registers); the transposed copy goes through LDS as an [8][C] tile so that every column's 8 rows leave as one
+// 16-byte store.  12 B / element (4 read + 4 written + 4 re-read by the cast + 2 x 2 written) become 8.
+template <int NV>
+__global__ void __launch_bounds__(512) layernorm_fwd16_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              uint16_t* __restrict__ y, long ldy, uint16_t* __restrict__ yt, long ldyt,
+                                                              float* __restrict__ mean_out, float* __restrict__ rstd_out, int rows, int C, float eps, int f16) {
+    __shared__ __attribute__((aligned(16))) uint16_t ln_tile[8 * 256 * NV];      // [8][C], C <= 256 NV
+    const int w = threadIdx.x >> 6, row = blockIdx.x * 8 + w, lane = threadIdx.x & 63;
+    const bool live = row < rows;
+    const int cv = C >> 2;
+    const float4* xr = reinterpret_cast<const float4*>(x + (long)(live ? row : 0) * C);
+    float4 v[NV];
+    bool in[NV];
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        const int i = lane + 64 * u;
+        in[u] = live && i < cv;
+        v[u] = xr[i < cv ? i : cv - 1];
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int u = 0; u < NV; ++u) s += in[u] ? (v[u].x + v[u].y) + (v[u].z + v[u].w) : 0.f;
+    s = wave_sum(s);
+    const float mean = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        const float a = v[u].x - mean, b = v[u].y - mean, c = v[u].z - mean, d = v[u].w - mean;
+        q += in[u] ? (a * a + b * b) + (c * c + d * d) : 0.f;
+    }
+    q = wave_sum(q);
+    const float rstd = 1.0f / sqrtf(q / (float)C + eps);
+    const float4* g4 = reinterpret_cast<const float4*>(gamma);
+    const float4* b4 = reinterpret_cast<const float4*>(beta);
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        const int i = lane + 64 * u;
+        if (i < cv) {
+            uint16_t h[4] = {0, 0, 0, 0};
+            if (live) {
+                const float4 g = g4[i], b = b4[i];
+                h[0] = cvt16_bits((v[u].x - mean) * rstd * g.x + b.x, f16 != 0); h[1] = cvt16_bits((v[u].y - mean) * rstd * g.y + b.y, f16 != 0);
+                h[2] = cvt16_bits((v[u].z - mean) * rstd * g.z + b.z, f16 != 0); h[3] = cvt16_bits((v[u].w - mean) * rstd * g.w + b.w, f16 != 0);
+            }
+            const float2 pk = make_float2(__uint_as_float((uint32_t)h[0] | ((uint32_t)h[1] << 16)), __uint_as_float((uint32_t)h[2] | ((uint32_t)h[3] << 16)));      // bit containers
+            if (live && y) *reinterpret_cast<float2*>(y + (long)row * ldy + 4 * i) = pk;
+            *reinterpret_cast<float2*>(ln_tile + (long)w * C + 4 * i) = pk;          // dead rows (the zero padding of the transposed copy) store zeros
+        }
+    }
+    if (live && lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+    if (!yt) return;
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 512) {
+        uint32_t d[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) d[r] = (uint32_t)ln_tile[(2 * r) * C + c] | ((uint32_t)ln_tile[(2 * r + 1) * C + c] << 16);
+        *reinterpret_cast<float4*>(yt + (long)c * ldyt + blockIdx.x * 8) = make_float4(__uint_as_float(d[0]), __uint_as_float(d[1]), __uint_as_float(d[2]), __uint_as_float(d[3]));
+    }
 }
 static const bool g_ln_v4 = [] { const char* e = getenv("TF_LN_V4"); return e ? e[0] != '0' : true; }();
 static inline int ln_nv(int C, const void* a, const void* b, const void* c) {
@@ -209,22 +284,52 @@ extern "C" int tf_layernorm_fwd_f32(const float* x, const float* gamma, const fl
     return launch_status("tf_layernorm_fwd_f32");
 }
 
-extern "C" int tf_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx,
-                                    int dx_accumulate, float* dgamma, float* dbeta, int rows, int C, void* stream) {
-    TF_REQUIRE(dy && x && gamma && mean && rstd && dx && rows >= 0 && C > 0, "tf_layernorm_bwd_f32: bad arguments");
+extern "C" int tf_layernorm_fwd16_f32(const float* x, const float* gamma, const float* beta, void* y16, int ldy, void* y16t, int ldyt, float* mean, float* rstd,
+                                      int rows, int C, float eps, int dtype, void* stream) {
+    TF_REQUIRE(x && gamma && beta && mean && rstd && (y16 || y16t) && rows >= 0 && C > 0 && (dtype == 1 || dtype == 2), "tf_layernorm_fwd16_f32: bad arguments (dtype 1 = bf16, 2 = fp16)");
+    TF_REQUIRE(C % 4 == 0 && C <= 2048 && aligned16(x) && aligned16(gamma) && aligned16(beta), "tf_layernorm_fwd16_f32: needs C %% 4 == 0, C <= 2048, 16-byte aligned x / gamma / beta");
+    TF_REQUIRE(!y16 || (ldy >= C && ldy % 4 == 0 && ((uintptr_t)y16 & 7) == 0), "tf_layernorm_fwd16_f32: y16 needs ldy >= C, ldy %% 4 == 0, 8-byte alignment");
+    TF_REQUIRE(!y16t || (ldyt >= ((rows + 7) & ~7) && ldyt % 8 == 0 && aligned16(y16t)), "tf_layernorm_fwd16_f32: the transposed copy needs ldyt %% 8 == 0, ldyt >= rows rounded up to 8, 16-byte aligned");
     if (rows == 0) return 0;
-    switch (ln_nv(C, dy, x, gamma) && aligned16(dx) ? ln_nv(C, dy, x, gamma) : 0) {
-#define TF_LNB(NV_) case NV_: TF_LAUNCH(layernorm_bwd_dx_v4_kernel<NV_>, dim3(cdiv(rows, 4)), dim3(256), stream, dy, x, gamma, mean, rstd, dx, rows, C, dx_accumulate); break
+    const int need = (C / 4 + 63) / 64, nv = need <= 1 ? 1 : need <= 2 ? 2 : need <= 3 ? 3 : need <= 4 ? 4 : need <= 6 ? 6 : 8;
+    switch (nv) {
+#define TF_LNF16(NV_) case NV_: TF_LAUNCH(layernorm_fwd16_kernel<NV_>, dim3(cdiv(rows, 8)), dim3(512), stream, x, gamma, beta, (uint16_t*)y16, (long)ldy, (uint16_t*)y16t, (long)ldyt, mean, rstd, rows, C, eps, dtype == 2 ? 1 : 0); break
+        TF_LNF16(1); TF_LNF16(2); TF_LNF16(3); TF_LNF16(4); TF_LNF16(6); TF_LNF16(8);
+#undef TF_LNF16
+    }
+    return launch_status("tf_layernorm_fwd16_f32");
+}
+
+static int layernorm_bwd_impl(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx,
+                              int dx_accumulate, float* dgamma, float* dbeta, int rows, int C, LnDrop dr, void* stream, const char* what) {
+    if (rows == 0) return 0;
+    switch (ln_nv(C, dy, x, gamma) && aligned16(dx) && (!dr.out || aligned16(dr.out)) ? ln_nv(C, dy, x, gamma) : 0) {
+#define TF_LNB(NV_) case NV_: TF_LAUNCH(layernorm_bwd_dx_v4_kernel<NV_>, dim3(cdiv(rows, 4)), dim3(256), stream, dy, x, gamma, mean, rstd, dx, rows, C, dx_accumulate, dr); break
         TF_LNB(1); TF_LNB(2); TF_LNB(3); TF_LNB(4); TF_LNB(6); TF_LNB(8);
 #undef TF_LNB
-        default: TF_LAUNCH(layernorm_bwd_dx_kernel, dim3(cdiv(rows, 4)), dim3(256), stream, dy, x, gamma, mean, rstd, dx, rows, C, dx_accumulate);
+        default: TF_LAUNCH(layernorm_bwd_dx_kernel, dim3(cdiv(rows, 4)), dim3(256), stream, dy, x, gamma, mean, rstd, dx, rows, C, dx_accumulate, dr);
     }
     if (dgamma && dbeta) {
         const int rpb = 64;
         TF_LAUNCH(layernorm_bwd_dw_kernel, dim3(cdiv(C, 64), cdiv(rows, rpb)), dim3(256), stream, dy, x, mean, rstd, dgamma, dbeta, rows,
                   C, rpb);
     }
-    return launch_status("tf_layernorm_bwd_f32");
+    return launch_status(what);
+}
+
+extern "C" int tf_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx,
+                                    int dx_accumulate, float* dgamma, float* dbeta, int rows, int C, void* stream) {
+    TF_REQUIRE(dy && x && gamma && mean && rstd && dx && rows >= 0 && C > 0, "tf_layernorm_bwd_f32: bad arguments");
+    return layernorm_bwd_impl(dy, x, gamma, mean, rstd, dx, dx_accumulate, dgamma, dbeta, rows, C, LnDrop{nullptr, nullptr, 0u, 0u, 1.f}, stream, "tf_layernorm_bwd_f32");
+}
+
+extern "C" int tf_layernorm_bwd_drop_f32(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx,
+                                         int dx_accumulate, float* dgamma, float* dbeta, int rows, int C, float* dropped, const uint32_t* seed_dev,
+                                         uint32_t site, float p, void* stream) {
+    TF_REQUIRE(dy && x && gamma && mean && rstd && dx && rows >= 0 && C > 0 && dropped && dropped != dx && seed_dev && p >= 0.f && p < 1.f && (long)rows * C < 4294967296L,
+               "tf_layernorm_bwd_drop_f32: bad arguments (dropped must be a second buffer, 0 <= p < 1)");
+    const LnDrop dr{dropped, seed_dev, site, (uint32_t)((double)p * 4294967296.0), 1.f / (1.f - p)};
+    return layernorm_bwd_impl(dy, x, gamma, mean, rstd, dx, dx_accumulate, dgamma, dbeta, rows, C, dr, stream, "tf_layernorm_bwd_drop_f32");
 }
 
 // ------------------------------------------------------------------ softmax (attention rows)

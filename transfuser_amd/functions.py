@@ -604,11 +604,16 @@ def _gpt_block_fwd(gpt, li, x, B, T, drop):
     blk = gpt.blocks[li]
     C, nh, dev = x.shape[1], gpt.n_head, x.device
     lowp = _lowp_block(gpt, blk, C)
-    h1, m1, r1 = ops.layernorm_fwd(x, blk.ln1.weight, blk.ln1.bias, blk.ln1.eps)
+    ln16 = lowp and ops.LN_FWD16 and ops.layernorm_fwd16_ok(x, blk.ln1.weight, blk.ln1.bias) and ops.layernorm_fwd16_ok(x, blk.ln2.weight, blk.ln2.bias)      # 16-bit storage: LayerNorm writes the operand copies itself (no fp32 h, no cast launch)
+    if ln16:
+        h1_16, h1_t, m1, r1 = ops.layernorm_fwd16(x, blk.ln1.weight, blk.ln1.bias, blk.ln1.eps)
+    else:
+        h1, m1, r1 = ops.layernorm_fwd(x, blk.ln1.weight, blk.ln1.bias, blk.ln1.eps)
     qkv = torch.empty(B * T, 3 * C, dtype=torch.float32, device=dev)
     fw = blk.attn.fused()
     if lowp:
-        h1_16, h1_t = ops.cast16(h1)
+        if not ln16:
+            h1_16, h1_t = ops.cast16(h1)
         if fw is not None:
             _lin16_fwd(h1_16, fw[0], fw[1], out=qkv)
         else:
@@ -648,9 +653,13 @@ def _gpt_block_fwd(gpt, li, x, B, T, drop):
         x_mid = ops.dropout_add(pr, x, gpt.seed, gpt.site(4 * li + 2), gpt.resid_pdrop, out=pr)
     else:
         x_mid = lin(ya_16, blk.attn.proj, res=x)
-    h2, m2, r2 = ops.layernorm_fwd(x_mid, blk.ln2.weight, blk.ln2.bias, blk.ln2.eps)
+    if ln16:
+        h2_16, h2_t, m2, r2 = ops.layernorm_fwd16(x_mid, blk.ln2.weight, blk.ln2.bias, blk.ln2.eps)
+    else:
+        h2, m2, r2 = ops.layernorm_fwd(x_mid, blk.ln2.weight, blk.ln2.bias, blk.ln2.eps)
     if lowp:
-        h2_16, h2_t = ops.cast16(h2)
+        if not ln16:
+            h2_16, h2_t = ops.cast16(h2)
         a1 = lin(h2_16, blk.mlp[0], relu=True)
         h2 = A16(h2_t)
         a1_16, a1_t = ops.cast16(a1)
@@ -707,11 +716,15 @@ def _gpt_block_bwd(gpt, li, saved, dx, B, T, drop):
             dh2 = ops.linear_dgrad(da1, fc1.weight)
         bias_later(da1, fc1.bias)
     # dx_mid = dx + ln2_bwd(dh2): accumulate in place into dx
-    ops.layernorm_bwd(dh2, x_mid, blk.ln2.weight, m2, r2, gbuf(blk.ln2.weight), gbuf(blk.ln2.bias), dx=dx, accumulate=True)
-    # ---- attention: x_mid = x + drop(proj(att @ v))
-    dres = dx
-    if drop and gpt.resid_pdrop > 0:
-        dres = ops.dropout(dx, gpt.seed, gpt.site(4 * li + 2), gpt.resid_pdrop)
+    # ---- attention: x_mid = x + drop(proj(att @ v)); the launch that finishes dx_mid also writes resid_drop's gradient of it (same mask as the forward)
+    if drop and gpt.resid_pdrop > 0 and ops.FUSE_DROPOUT:
+        _, dres = ops.layernorm_bwd(dh2, x_mid, blk.ln2.weight, m2, r2, gbuf(blk.ln2.weight), gbuf(blk.ln2.bias), dx=dx, accumulate=True,
+                                    drop=(gpt.seed, gpt.site(4 * li + 2), gpt.resid_pdrop))
+    else:
+        ops.layernorm_bwd(dh2, x_mid, blk.ln2.weight, m2, r2, gbuf(blk.ln2.weight), gbuf(blk.ln2.bias), dx=dx, accumulate=True)
+        dres = dx
+        if drop and gpt.resid_pdrop > 0:
+            dres = ops.dropout(dx, gpt.seed, gpt.site(4 * li + 2), gpt.resid_pdrop)
     bias_later(dres, proj.bias, dres is not dx)
     if lowp:
         dy = _lin16_bwd(dres, y_att, proj.weight, gbuf(proj.weight))

@@ -101,6 +101,7 @@ def set_precision(mode):
     check(L().tf_set_precision(m), "tf_set_precision")
     _lowp["dtype"] = {1: 1, 3: 2}.get(m, 0) if _STORE16 else 0
     _lowp["w"].clear()
+    _lowp.pop("table", None)
 
 
 def get_precision():
@@ -178,9 +179,49 @@ def lowp_weight(w):
     return ent[1], ent[2]
 
 
+class _Cast16Item(ctypes.Structure):      # include/transfuser_hip.h: tf_cast16_item
+    _fields_ = [("x", ctypes.c_void_p), ("y16", ctypes.c_void_p), ("y16t", ctypes.c_void_p), ("rows", ctypes.c_int), ("cols", ctypes.c_int),
+                ("ldx", ctypes.c_int), ("ldy", ctypes.c_int), ("ldyt", ctypes.c_int), ("tile0", ctypes.c_int)]
+
+
+CAST16_MULTI = os.environ.get("TF_CAST16_MULTI", "1") != "0"      # A/B switch of round 5: the weight copies in one launch
+
+
+def _cast16_table():
+    """Device-resident tf_cast16_item table over the cached weights (rebuilt only when the set of cached weights changes; built OUTSIDE graph
+    capture - the Engine's warm-up steps run lowp_refresh_weights eagerly before anything is captured)."""
+    ents = list(_lowp["w"].values())
+    key = tuple((src.data_ptr(), y.data_ptr(), yt.data_ptr()) for src, y, yt in ents)
+    tab = _lowp.get("table")
+    if tab is not None and tab[0] == key:
+        return tab
+    assert not (ents[0][0].is_cuda and torch.cuda.is_current_stream_capturing()), "the 16-bit weight table must exist before graph capture (run a warm-up step)"
+    items = (_Cast16Item * len(ents))()
+    tile = 0
+    for it, (src, y, yt) in zip(items, ents):
+        rows, cols = src.shape
+        assert src.stride(1) == 1 and y.stride(0) >= cols and yt.stride(0) % 8 == 0 and yt.stride(0) >= (rows + 7) // 8 * 8 and yt.data_ptr() % 16 == 0
+        it.x, it.y16, it.y16t = src.data_ptr(), y.data_ptr(), yt.data_ptr()
+        it.rows, it.cols, it.ldx, it.ldy, it.ldyt, it.tile0 = rows, cols, src.stride(0), y.stride(0), yt.stride(0), tile
+        tile += ((rows + 63) // 64) * ((cols + 63) // 64)
+    host = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8)
+    dev = host.to(ents[0][0].device)
+    tab = (key, dev, len(ents), tile)
+    _lowp["table"] = tab
+    return tab
+
+
 def lowp_refresh_weights():
-    for src, y, yt in _lowp["w"].values():
-        cast16(src, out=y, out_t=yt)
+    ents = _lowp["w"]
+    if not ents:
+        return
+    if not CAST16_MULTI or len(ents) == 1:
+        for src, y, yt in ents.values():
+            cast16(src, out=y, out_t=yt)
+        return
+    _, dev, n, tiles = _cast16_table()
+    src0 = next(iter(ents.values()))[0]
+    check(L().tf_cast16_multi_f32(ctypes.c_void_p(dev.data_ptr()), n, tiles, _lowp["dtype"], stream_of(src0)), "tf_cast16_multi_f32")
 
 
 class lowp_managed:
@@ -753,10 +794,37 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma=None, dbeta=None, dx=None, accumulate=False):
+def layernorm_fwd16(x, gamma, beta, eps=1e-5):
+    """LayerNorm whose outputs are the 16-bit operand copies only (lowp_storage() modes): (y16 (rows, C), y16t (C, rows8), mean, rstd) ==
+    cast16(layernorm_fwd(x)[0]) bitwise, without the fp32 tensor in between (tf_layernorm_fwd16_f32)."""
+    rows, C = x.shape
+    rows8 = (rows + 7) // 8 * 8
+    y = torch.empty(rows, C, dtype=_t16(), device=x.device)
+    yt = torch.empty(C, rows8, dtype=_t16(), device=x.device)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    check(L().tf_layernorm_fwd16_f32(ptr(_c(x)), ptr(gamma), ptr(beta), ctypes.c_void_p(y.data_ptr()), C, ctypes.c_void_p(yt.data_ptr()), rows8, ptr(mean), ptr(rstd),
+                                     rows, C, ctypes.c_float(eps), _lowp["dtype"], stream_of(x)), "tf_layernorm_fwd16_f32")
+    return y, yt, mean, rstd
+
+
+def layernorm_fwd16_ok(x, gamma, beta):
+    C = x.shape[1]
+    return C % 4 == 0 and C <= 2048 and x.is_contiguous() and all(t.data_ptr() % 16 == 0 for t in (x, gamma, beta))
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma=None, dbeta=None, dx=None, accumulate=False, drop=None):
+    """drop = (seed, site, p): also returns nn.Dropout(p)(dx) of the finished gradient (mask of ops.dropout(seed, site)) -> (dx, dropped)."""
     rows, C = x.shape
     if dx is None:
         dx = torch.empty_like(x)
+    if drop is not None:
+        dropped = torch.empty_like(dx)
+        assert dx.is_contiguous()
+        check(L().tf_layernorm_bwd_drop_f32(ptr(_c(dy)), ptr(_c(x)), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), int(accumulate), ptr(dgamma), ptr(dbeta),
+                                            rows, C, ptr(dropped), ptr(drop[0]), ctypes.c_uint32(int(drop[1])), ctypes.c_float(drop[2]), stream_of(x)),
+              "tf_layernorm_bwd_drop_f32")
+        return dx, dropped
     check(L().tf_layernorm_bwd_f32(ptr(_c(dy)), ptr(_c(x)), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), int(accumulate), ptr(dgamma), ptr(dbeta),
                                    rows, C, stream_of(x)), "tf_layernorm_bwd_f32")
     return dx
@@ -1031,6 +1099,7 @@ def bn_bwd(dz, z, x, gamma, sm, si, dgamma, dbeta, want_dres=False):
 
 
 FUSE_DROPOUT = os.environ.get("TF_FUSE_DROPOUT", "1") != "0"      # A/B switch of round 5: resid_drop + residual add in the producing GEMM's epilogue
+LN_FWD16 = os.environ.get("TF_LN_FWD16", "1") != "0"      # A/B switch of round 5: ln1 / ln2 of a 16-bit-storage Block write the operand copies themselves
 
 
 COLSUM_MULTI = os.environ.get("TF_COLSUM_MULTI", "1") != "0"      # the Block's bias gradients in one launch (A/B switch)
