@@ -177,6 +177,20 @@ int tf_cast16_f32(const float* x, int rows, int cols, int ldx, void* y16, int ld
  * total_tiles = the sum.  Per item the rules of tf_cast16_f32 hold (the caller checks them: the table is device memory). */
 typedef struct { const float* x; void* y16; void* y16t; int rows, cols, ldx, ldy, ldyt, tile0; } tf_cast16_item;
 int tf_cast16_multi_f32(const tf_cast16_item* items_dev, int n_items, int total_tiles, int dtype, void* stream);
+/* The four element-wise producers of a RegNetY Bottleneck's 1x1-convolution operands (timm Bottleneck behind transfuser.py:380,442) writing the 16-bit copies
+ * themselves (round 5; 16-bit storage modes: conv1 / conv3 then run as tf_gemm16_nt_f32 products like the GPT linear layers).  y16 (rows x C, contiguous, may
+ * be NULL) and y16t (C x rows8, row stride ldyt % 8 == 0, rows zero-padded to a multiple of 8, may be NULL) are bitwise tf_cast16_f32 of the fp32 kernel named
+ * below; the fp32 output (y32 / dx32) may be NULL where only the 16-bit GEMMs read the result.  C % 4 == 0, every tensor 16-byte aligned, dtype 1 = bf16, 2 = half.
+ *   tf_bn_apply16_f32      : y = x sc + sh (+ res) (ReLU), coef = [sc | sh] of tf_bn_finalize_parts_f32 - the apply pass of tf_bn_fwd_parts_f32 (block output)
+ *   tf_se_scale_bn16_f32   : tf_se_scale_bn_fwd_f32 (conv3's input; x is (B, HW, C), gate (B, C))
+ *   tf_bn_bwd16_f32        : tf_bn_bwd_f32 (the gradient entering conv3; + dres, dgamma / dbeta ACCUMULATED; ws of tf_workspace_bytes())
+ *   tf_bn_bwd_remask16_f32 : tf_bn_bwd_remask_f32 (the gradient entering conv1) */
+int tf_bn_apply16_f32(const float* x, const float* coef, const float* res, int relu, float* y32, int rows, int C, void* y16, void* y16t, int ldyt, int dtype, void* stream);
+int tf_se_scale_bn16_f32(const float* x, const float* coef, const float* gate, int B, int HW, int C, void* y16, void* y16t, int ldyt, int dtype, void* stream);
+int tf_bn_bwd16_f32(const float* dz, const float* z, const float* x, int rows, int C, const float* gamma, const float* save_mean, const float* save_invstd, float* dx32,
+                    float* dres, float* dgamma, float* dbeta, float* ws, void* dx16, void* dx16t, int ldyt, int dtype, void* stream);
+int tf_bn_bwd_remask16_f32(const float* dz, const float* x, const float* fcoef, int rows, int C, const float* gamma, const float* save_mean, const float* save_invstd,
+                           float* dx32, float* dgamma, float* dbeta, float* ws, void* dx16, void* dx16t, int ldyt, int dtype, void* stream);
 /* nn.LayerNorm whose outputs are ONLY those 16-bit copies (round 5): ln1 / ln2 of a Block in the 16-bit storage modes (transfuser.py:535-536,546-547),
  * == tf_cast16_f32(tf_layernorm_fwd_f32(x)) bitwise, without the fp32 tensor in between.  C % 4 == 0, C <= 2048, 16-byte aligned x / gamma / beta;
  * y16 (may be NULL): ldy % 4 == 0, 8-byte aligned; y16t (may be NULL): as tf_cast16_f32.  mean / rstd as tf_layernorm_fwd_f32 (kept for the backward). */

@@ -1219,6 +1219,113 @@ def check_lowp16_fused_producers(dev, mode):
         ops.set_precision("fp32")
 
 
+def check_lowp16_conv_producers(dev, mode):
+    """Round 5: the element-wise producers of the bottleneck 1x1-convolution operands write the 16-bit copies themselves (tile16_kernel) - every copy is
+    bitwise tf_cast16_f32 of the fp32 kernel it stands in for (ragged row counts around the 64-row tiles, C around the 64-column tiles, zero pad rows), the
+    fp32 side outputs (block output, shortcut gradient, dgamma / dbeta) are those of the fp32 kernels."""
+    ops.set_precision(mode)
+    old_dbg = ops._DBG_LEGACY_BNB
+    ops._DBG_LEGACY_BNB = True          # fp32 comparison kernels on the chunk-partials + finalize path (no atomics): the path the 16-bit entry points use
+    same = lambda a, b, what: (_ for _ in ()).throw(AssertionError(what)) if not torch.equal(a.view(torch.int16), b.view(torch.int16)) else None
+    try:
+        for (B, H, W, C) in ((2, 5, 7, 72), (1, 8, 8, 216), (3, 4, 11, 24), (1, 1, 1, 8), (2, 16, 5, 136)):
+            rows = B * H * W
+            x = R(B, H, W, C, dev=dev, scale=1.5)
+            g, b = R(C, seed=1, dev=dev).abs() + 0.5, R(C, seed=2, dev=dev)
+            rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+            # forward statistics as a producing GEMM would gather them
+            xin, w = R(rows, 40, seed=3, dev=dev), R(C, 40, seed=4, dev=dev) * 0.3
+            y, cs = ops.linear_fwd(xin, w, colstat=True)
+            if cs is None:
+                continue
+            y = y.view(B, H, W, C)
+            res = R(B, H, W, C, seed=5, dev=dev)
+            want, sm, si = ops.bn_fwd_parts(y, cs, g, b, rm.clone(), rv.clone(), res, True)
+            coef, sm2, si2 = ops.bn_finalize_parts(cs, g, b, rm.clone(), rv.clone())
+            assert torch.equal(sm, sm2) and torch.equal(si, si2)
+            y32, y16, y16t = ops.bn_apply16(y, coef, res, True)
+            assert torch.equal(y32, want), "bn_apply16 fp32 output"
+            w16, w16t = ops.cast16(want.view(rows, C))
+            same(y16, w16, "bn_apply16 row-major"); same(y16t, w16t, "bn_apply16 transposed")
+            _, n16, n16t = ops.bn_apply16(y, coef, None, False, want_f32=False)
+            p16, p16t = ops.cast16(ops.bn_fwd_parts(y, cs, g, b, rm.clone(), rv.clone(), None, False)[0].view(rows, C))
+            same(n16, p16, "bn_apply16 (no res / relu)"); same(n16t, p16t, "bn_apply16 (no res / relu) transposed")
+            # BatchNorm apply + ReLU + SE scale
+            gate = R(B, C, seed=6, dev=dev)
+            z16, z16t = ops.se_scale_bn16(y, coef, gate)
+            q16, q16t = ops.cast16(ops.se_scale_bn_fwd(y, coef, gate).view(rows, C))
+            same(z16, q16, "se_scale_bn16 row-major"); same(z16t, q16t, "se_scale_bn16 transposed")
+            # BatchNorm backward (ReLU mask from the stored output) + shortcut gradient
+            dz = R(B, H, W, C, seed=7, dev=dev)
+            dg0, db0, dg1, db1 = (torch.zeros(C, device=dev) for _ in range(4))
+            dx, dres = ops.bn_bwd(dz, want, y, g, sm, si, dg0, db0, want_dres=True)
+            dx32, d16, d16t, dres2 = ops.bn_bwd16(dz, want, y, g, sm, si, dg1, db1, want_dres=True, want_f32=True)
+            assert torch.equal(dx32, dx) and torch.equal(dres2, dres) and torch.equal(dg0, dg1) and torch.equal(db0, db1), "bn_bwd16 fp32 outputs"
+            e16, e16t = ops.cast16(dx.view(rows, C))
+            same(d16, e16, "bn_bwd16 row-major"); same(d16t, e16t, "bn_bwd16 transposed")
+            # BatchNorm backward with the mask recomputed from the raw input
+            dg0.zero_(); db0.zero_(); dg1.zero_(); db1.zero_()
+            dxr = ops.bn_bwd_remask(dz, y, coef, g, sm, si, dg0, db0)
+            _, r16, r16t = ops.bn_bwd_remask16(dz, y, coef, g, sm, si, dg1, db1)
+            assert torch.equal(dg0, dg1) and torch.equal(db0, db1), "bn_bwd_remask16 parameter gradients"
+            f16_, f16t = ops.cast16(dxr.view(rows, C))
+            same(r16, f16_, "bn_bwd_remask16 row-major"); same(r16t, f16t, "bn_bwd_remask16 transposed")
+            assert bool((r16t[:, rows:].float() == 0).all()), "pad rows of the transposed copy must be zero"
+    finally:
+        ops._DBG_LEGACY_BNB = old_dbg
+        ops.set_precision("fp32")
+
+
+def check_lowp16_conv_stage(dev, mode):
+    """A RegNetY stage (stride-2 bottleneck + two stride-1 bottlenecks, 48 -> 72 channels, group width 24) in a 16-bit storage mode: the 1x1
+    convolutions on STORED operands whose copies their producers write (ops.STORE16_CONV, functions.YBlockFn "lp") against the in-register rounding
+    path of the same mode - the same operands rounded to the same 16-bit values, so output and input gradient agree to fp32 summation order (bitwise on
+    the emulator) and every parameter gradient to 1e-5; and the copies really are handed from block to block: ONE activation cast launch (the stage input)."""
+    from transfuser_amd import regnet
+    torch.manual_seed(0)
+    st = regnet.RegStage(48, 72, 3, 24, 0.25)
+    for m in st.modules():
+        if isinstance(m, regnet.Bottleneck):
+            torch.nn.init.normal_(m.conv3.bn.weight, 1.0, 0.1)
+        if isinstance(m, torch.nn.Conv2d):
+            m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
+    st = st.to(dev).train()
+    x0, dy = R(2, 16, 20, 48, dev=dev), R(2, 8, 10, 72, seed=1, dev=dev)
+    old, orig = ops.STORE16_CONV, ops.cast16
+    res, casts = {}, {}
+    try:
+        for on in (True, False):
+            ops.STORE16_CONV = on
+            ops.set_precision(mode)
+            n = [0]
+
+            def counting(*a, **k):
+                n[0] += 1
+                return orig(*a, **k)
+            for q in st.parameters():
+                q.grad = None
+            x = x0.clone().requires_grad_(True)
+            with ops.lowp_managed():        # as inside train.Engine: the 16-bit weight copies are made once, not at every use
+                for blk in st.children():
+                    for w in (blk.conv1.conv.weight, blk.conv3.conv.weight):
+                        ops.lowp_weight(w.detach().view(w.shape[0], w.shape[1]))
+                ops.cast16 = counting
+                y = st(x)
+                y.backward(dy)
+                ops.cast16 = orig
+            res[on], casts[on] = (y.detach().clone(), x.grad.clone(), {k: q.grad.clone() for k, q in st.named_parameters()}), n[0]
+    finally:
+        ops.cast16, ops.STORE16_CONV = orig, old
+        ops.set_precision("fp32")
+    assert casts[True] == 1 and casts[False] == 0, casts
+    a, b = res[True], res[False]
+    rel = lambda u, v: float((u - v).norm() / v.norm().clamp_min(1e-12))
+    ty, tg = (1e-6, 1e-5) if dev == "cpu" else (1e-5, 1e-4)      # MI355X: different tile plans / k-split atomics between the two paths
+    assert rel(a[0], b[0]) <= ty and rel(a[1], b[1]) <= tg, (rel(a[0], b[0]), rel(a[1], b[1]))
+    for k in a[2]:
+        assert rel(a[2][k], b[2][k]) <= tg, (k, rel(a[2][k], b[2][k]))
+
+
 def check_layernorm_bwd_drop(dev):
     """tf_layernorm_bwd_drop_f32: dx as tf_layernorm_bwd_f32 (bitwise, with and without accumulation), dropped == tf_dropout_f32(dx) (same mask)."""
     seed = torch.tensor([99], dtype=torch.int32, device=dev)

@@ -192,6 +192,16 @@ def test_lowp16_copies_written_by_their_producers(mode):
     kc.check_lowp16_fused_producers("cpu", mode)
 
 
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+def test_lowp16_bottleneck_conv_operand_producers(mode):
+    kc.check_lowp16_conv_producers("cpu", mode)
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+def test_lowp16_bottleneck_convs_on_stored_operands_stage(mode):
+    kc.check_lowp16_conv_stage("cpu", mode)
+
+
 def test_layernorm_backward_with_dropped_second_output():
     kc.check_layernorm_bwd_drop("cpu")
 

@@ -345,16 +345,16 @@ def test_lowp_storage_modes_tiny_model(mode):
     cfg = mc.tiny_config(n_layer=2)
     batch = mc.small_batch(2, 32, 64, 64, 40)
     res = {}
-    for store, conv in ((True, False), (False, False)):
+    for store, conv in ((True, False), (False, False), (True, True)):
         prod, ref = mc.build_pair(cfg, "regnety_tiny", "cpu")
-        old = ops._STORE16
-        ops._STORE16 = store
+        old, oldc = ops._STORE16, ops.STORE16_CONV
+        ops._STORE16, ops.STORE16_CONV = store, conv
         ops.set_precision(mode)
         try:
-            assert bool(ops.lowp_storage()) == store
+            assert bool(ops.lowp_storage()) == store and bool(ops.lowp_conv()) == (store and conv)
             lp, lr = mc.run_pair(prod, ref, cfg, batch, "cpu")
         finally:
-            ops._STORE16 = old
+            ops._STORE16, ops.STORE16_CONV = old, oldc
             ops.set_precision("fp32")
         rp = dict(ref.named_parameters())
         names = [n for n, p in prod.named_parameters() if rp[n].grad is not None]
@@ -370,6 +370,14 @@ def test_lowp_storage_modes_tiny_model(mode):
         assert abs(a[0][k] - b[0][k]) <= 1e-5 * max(1.0, abs(b[0][k])), (k, a[0][k], b[0][k])
     rel = float((a[1] - b[1]).norm() / b[1].norm())
     assert rel <= 1e-5, rel
+    # (True, True): additionally the RegNetY bottlenecks' 1x1 convolutions on stored operands (round 5).  The packed-16 kernels add the same rounded
+    # products in another order than the in-register kernels (1e-7 on a layer output, check_lowp16_conv_stage pins that at the block level); this
+    # network amplifies such round-off ~1e4x into its gradients, so at the model level: losses within 1e-4, gradient within 2e-2 of the other storage path
+    c = res[(True, True)]
+    for k in c[0]:
+        assert abs(c[0][k] - a[0][k]) <= 1e-4 * max(1.0, abs(a[0][k])), (k, c[0][k], a[0][k])
+    relc = float((c[1] - a[1]).norm() / a[1].norm())
+    assert relc <= 2e-2, relc
 
 
 @pytest.mark.parametrize("arch", ["resnet_tiny", "resnet_tiny50"])

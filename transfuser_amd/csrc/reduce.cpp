@@ -702,6 +702,109 @@ __global__ void __launch_bounds__(256) colsum_multi_kernel(MultiSum d, int rows)
     }
 }
 
+// ---- 16-bit operand copies written by the element-wise PRODUCERS of a bottleneck's 1x1 convolutions (round 5; bf16 / fp16 storage modes).
+// In those modes conv1 / conv3 of a RegNetY Bottleneck (timm, transfuser.py:380,442) run as packed-16 NT GEMMs (tf_gemm16_nt_f32) like the GPT
+// linear layers: y = x W^T needs x as a row-major 16-bit matrix, dW = dy^T x needs dy AND x transposed, dx = dy W needs dy row-major.  A cast
+// launch per operand costs more than the packed GEMMs gain (measured in round 4), so the four element-wise passes that produce those operands
+// write the copies themselves: BatchNorm apply (+ shortcut + ReLU: the block output = the next block's conv1 input), BatchNorm apply + ReLU + SE scale
+// (conv3's input), and the two BatchNorm backward applies (the gradients entering conv3 / conv1).  One 64 x 64 tile per block: the value of an element
+// is computed ONCE by the functor (the expression of the fp32 kernel it replaces, so the copy is bitwise cast16 of that kernel's output), stored as
+// fp32 where something still reads it, packed row-major, and transposed through LDS (rows zero-padded to a multiple of 8) - cast16.cpp's tile.
+constexpr int T16S = 64, T16P = T16S + 8;
+template <class F>
+__global__ void __launch_bounds__(256) tile16_kernel(F f, int rows, int C, uint16_t* __restrict__ y, uint16_t* __restrict__ yt, long ldyt, int f16) {
+    __shared__ __attribute__((aligned(16))) uint16_t T[T16S * T16P];
+    const int tid = threadIdx.x, r0 = blockIdx.y * T16S, c0 = blockIdx.x * T16S, c4 = (tid & 15) * 4;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int row = it * 16 + (tid >> 4), r = r0 + row, c = c0 + c4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        const bool in = r < rows && c < C;          // C % 4 == 0: a float4 never straddles the edge
+        if (in) f(r, c, v);
+        uint16_t h[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h[e] = cvt16_bits(v[e], f16 != 0);
+        if (y && in) *reinterpret_cast<float2*>(y + (long)r * C + c) = make_float2(__uint_as_float((uint32_t)h[0] | ((uint32_t)h[1] << 16)), __uint_as_float((uint32_t)h[2] | ((uint32_t)h[3] << 16)));
+        if (yt) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) T[(c4 + e) * T16P + row] = h[e];
+        }
+    }
+    if (!yt) return;
+    __syncthreads();
+    const int rows8 = (rows + 7) & ~7;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int id = p * 256 + tid, col = id >> 3, rc = (id & 7) * 8;
+        if (c0 + col < C && r0 + rc < rows8) *reinterpret_cast<float4*>(yt + (long)(c0 + col) * ldyt + r0 + rc) = *reinterpret_cast<const float4*>(T + col * T16P + rc);
+    }
+}
+struct BnApply16F {          // bn_apply_kernel: y = x sc + sh (+ res) (relu); y32 (may be NULL) keeps the fp32 result
+    const float* x; const float* coef; const float* res; float* y32; int C; int relu;
+    __device__ __forceinline__ void operator()(int r, int c, float (&v)[4]) const {
+        const long o = (long)r * C + c;
+        const vecf<4> a = ldv<4>(x + o), s = ldv<4>(coef + c), t = ldv<4>(coef + C + c);
+        vecf<4> rr;
+        if (res) rr = ldv<4>(res + o);
+        vecf<4> out;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float w = a.v[k] * s.v[k] + t.v[k];
+            if (res) w += rr.v[k];
+            if (relu) w = fmaxf(w, 0.f);
+            out.v[k] = v[k] = w;
+        }
+        if (y32) stv<4>(y32 + o, out);
+    }
+};
+struct SeScaleBn16F {        // se_scale_bn_kernel: y = max(x sc + sh, 0) * sigmoid(gate[b][c]), b = row / HW
+    const float* x; const float* coef; const float* gate; int C; int HW;
+    __device__ __forceinline__ void operator()(int r, int c, float (&v)[4]) const {
+        const long o = (long)r * C + c;
+        const vecf<4> a = ldv<4>(x + o), g = ldv<4>(gate + (long)(r / HW) * C + c), sc = ldv<4>(coef + c), sh = ldv<4>(coef + C + c);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = fmaxf(a.v[k] * sc.v[k] + sh.v[k], 0.f) * (1.f / (1.f + expf(-g.v[k])));
+    }
+};
+struct BnBwdApply16F {       // bn_bwd_apply_kernel: g = dz [z > 0] (-> dres), dx = A g + Bc x + Cc; dx32 (may be NULL) keeps the fp32 result
+    const float* dz; const float* z; const float* x; const float* coef; float* dx32; float* dres; int C;
+    __device__ __forceinline__ void operator()(int r, int c, float (&v)[4]) const {
+        const long o = (long)r * C + c;
+        vecf<4> g = ldv<4>(dz + o);
+        const vecf<4> a = ldv<4>(x + o), A = ldv<4>(coef + c), Bc = ldv<4>(coef + C + c), Cc = ldv<4>(coef + 2 * C + c);
+        if (z) { const vecf<4> zz = ldv<4>(z + o);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (!(zz.v[k] > 0.f)) g.v[k] = 0.f; }
+        if (dres) stv<4>(dres + o, g);
+        vecf<4> out;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) out.v[k] = v[k] = A.v[k] * g.v[k] + Bc.v[k] * a.v[k] + Cc.v[k];
+        if (dx32) stv<4>(dx32 + o, out);
+    }
+};
+struct BnBwdRemask16F {      // bn_bwd_apply_remask_kernel: the ReLU mask recomputed from x and the forward (scale | shift)
+    const float* dz; const float* x; const float* fcoef; const float* coef; float* dx32; int C;
+    __device__ __forceinline__ void operator()(int r, int c, float (&v)[4]) const {
+        const long o = (long)r * C + c;
+        vecf<4> g = ldv<4>(dz + o);
+        const vecf<4> a = ldv<4>(x + o), A = ldv<4>(coef + c), Bc = ldv<4>(coef + C + c), Cc = ldv<4>(coef + 2 * C + c), sc = ldv<4>(fcoef + c), sh = ldv<4>(fcoef + C + c);
+        vecf<4> out;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (!(a.v[k] * sc.v[k] + sh.v[k] > 0.f)) g.v[k] = 0.f;
+            out.v[k] = v[k] = A.v[k] * g.v[k] + Bc.v[k] * a.v[k] + Cc.v[k];
+        }
+        if (dx32) stv<4>(dx32 + o, out);
+    }
+};
+template <class F>
+inline void launch_tile16(const F& f, int rows, int C, void* y16, void* y16t, int ldyt, int dtype, void* stream) {
+    TF_LAUNCH(tile16_kernel<F>, dim3(cdiv(C, T16S), cdiv(rows, T16S)), dim3(256), stream, f, rows, C, (uint16_t*)y16, (uint16_t*)y16t, (long)ldyt, dtype == 2 ? 1 : 0);
+}
+inline bool tile16_ok(int rows, int C, const void* y16, const void* y16t, int ldyt, int dtype) {
+    return rows > 0 && C > 0 && C % 4 == 0 && (dtype == 1 || dtype == 2) && (y16 || y16t) && (!y16 || (((uintptr_t)y16) & 7) == 0) &&
+           (!y16t || (aligned16(y16t) && ldyt % 8 == 0 && ldyt >= ((rows + 7) & ~7)));
+}
 }  // namespace
 
 extern "C" long tf_workspace_bytes(void) { return (kWsFloats + kTickets) * 4; }
@@ -954,4 +1057,55 @@ extern "C" int tf_colsum_multi_f32(int n, const float* const* xs, const int* Cs,
     d.strip0[kMultiMax] = strips;
     TF_LAUNCH(colsum_multi_kernel, dim3(strips), dim3(256), stream, d, rows);
     return launch_status("tf_colsum_multi_f32");
+}
+
+// ---- the four producers of a bottleneck's 1x1-convolution operands with their 16-bit copies (tile16_kernel above).  y16 (rows x C, contiguous) and / or
+// y16t (C x rows8, row stride ldyt % 8 == 0, rows zero-padded to a multiple of 8) as tf_cast16_f32 writes them; dtype 1 = bf16, 2 = IEEE half.
+// Every tensor 16-byte aligned, C % 4 == 0.  The fp32 output is optional (NULL) wherever only the 16-bit GEMMs read the result.
+extern "C" int tf_bn_apply16_f32(const float* x, const float* coef, const float* res, int relu, float* y32, int rows, int C, void* y16, void* y16t, int ldyt,
+                                 int dtype, void* stream) {
+    TF_REQUIRE(x && coef && tile16_ok(rows, C, y16, y16t, ldyt, dtype) && aligned16(x) && aligned16(coef) && (!res || aligned16(res)) && (!y32 || aligned16(y32)),
+               "tf_bn_apply16_f32: needs C %% 4 == 0, 16-byte aligned tensors, dtype 1 / 2, ldyt %% 8 == 0 and >= rows rounded up to 8");
+    launch_tile16(BnApply16F{x, coef, res, y32, C, relu}, rows, C, y16, y16t, ldyt, dtype, stream);
+    return launch_status("tf_bn_apply16_f32");
+}
+extern "C" int tf_se_scale_bn16_f32(const float* x, const float* coef, const float* gate, int B, int HW, int C, void* y16, void* y16t, int ldyt, int dtype,
+                                    void* stream) {
+    TF_REQUIRE(x && coef && gate && B > 0 && HW > 0 && tile16_ok(B * HW, C, y16, y16t, ldyt, dtype) && aligned16(x) && aligned16(coef) && aligned16(gate),
+               "tf_se_scale_bn16_f32: needs C %% 4 == 0, 16-byte aligned tensors, dtype 1 / 2, ldyt %% 8 == 0 and >= rows rounded up to 8");
+    launch_tile16(SeScaleBn16F{x, coef, gate, C, HW}, B * HW, C, y16, y16t, ldyt, dtype, stream);
+    return launch_status("tf_se_scale_bn16_f32");
+}
+// tf_bn_bwd_f32 (chunk partials + finalize, no atomics) whose apply pass writes dx as 16-bit copies (+ fp32 dx32 when not NULL, + dres)
+extern "C" int tf_bn_bwd16_f32(const float* dz, const float* z, const float* x, int rows, int C, const float* gamma, const float* save_mean,
+                               const float* save_invstd, float* dx32, float* dres, float* dgamma, float* dbeta, float* ws, void* dx16, void* dx16t, int ldyt,
+                               int dtype, void* stream) {
+    TF_REQUIRE(dz && x && gamma && save_mean && save_invstd && ws && tile16_ok(rows, C, dx16, dx16t, ldyt, dtype) && aligned16(dz) && aligned16(x) &&
+               (!z || aligned16(z)) && (!dres || aligned16(dres)) && (!dx32 || aligned16(dx32)),
+               "tf_bn_bwd16_f32: needs C %% 4 == 0, 16-byte aligned tensors, dtype 1 / 2, ldyt %% 8 == 0 and >= rows rounded up to 8");
+    float* coef = ws + kWsFloats / 2;
+    RedPlan p = plan_reduce(rows, C, 1, 2, true);
+    BnBwdF<4> f4{dz, z, x, save_mean, save_invstd, C};
+    BnBwdF<1> f1{dz, z, x, save_mean, save_invstd, C};
+    launch_reduce<2>(p, f4, f1, rows, C, 1, ws, stream);
+    TF_LAUNCH(bn_bwd_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), stream, (const float*)ws, gamma, save_mean, save_invstd, dgamma, dbeta, coef, C, p.nchunks,
+              (float)rows);
+    launch_tile16(BnBwdApply16F{dz, z, x, (const float*)coef, dx32, dres, C}, rows, C, dx16, dx16t, ldyt, dtype, stream);
+    return launch_status("tf_bn_bwd16_f32");
+}
+extern "C" int tf_bn_bwd_remask16_f32(const float* dz, const float* x, const float* fcoef, int rows, int C, const float* gamma, const float* save_mean,
+                                      const float* save_invstd, float* dx32, float* dgamma, float* dbeta, float* ws, void* dx16, void* dx16t, int ldyt, int dtype,
+                                      void* stream) {
+    TF_REQUIRE(dz && x && fcoef && gamma && save_mean && save_invstd && ws && tile16_ok(rows, C, dx16, dx16t, ldyt, dtype) && aligned16(dz) && aligned16(x) &&
+               aligned16(fcoef) && (!dx32 || aligned16(dx32)),
+               "tf_bn_bwd_remask16_f32: needs C %% 4 == 0, 16-byte aligned tensors, dtype 1 / 2, ldyt %% 8 == 0 and >= rows rounded up to 8");
+    float* coef = ws + kWsFloats / 2;
+    RedPlan p = plan_reduce(rows, C, 1, 2, true);
+    BnBwdRemaskF<4> f4{dz, x, fcoef, save_mean, save_invstd, C};
+    BnBwdRemaskF<1> f1{dz, x, fcoef, save_mean, save_invstd, C};
+    launch_reduce<2>(p, f4, f1, rows, C, 1, ws, stream);
+    TF_LAUNCH(bn_bwd_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), stream, (const float*)ws, gamma, save_mean, save_invstd, dgamma, dbeta, coef, C, p.nchunks,
+              (float)rows);
+    launch_tile16(BnBwdRemask16F{dz, x, fcoef, (const float*)coef, dx32, C}, rows, C, dx16, dx16t, ldyt, dtype, stream);
+    return launch_status("tf_bn_bwd_remask16_f32");
 }

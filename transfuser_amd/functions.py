@@ -356,8 +356,9 @@ class PoolNormFn(torch.autograd.Function):
         return ops.se_scale_bwd_x(None, None, dp, shape), None, None, None
 
 
-# ---- 1x1 convolutions of the trunks.  (A 16-bit STORED-operand form of these - cast16 + gemm16_nt like the GPT linears - was measured at
-# 39.1 vs 38.3 ms/step in bf16: two cast passes per convolution cost more than the packed GEMMs gain.  Removed in round 5.)
+# ---- 1x1 convolutions of the trunks.  (A 16-bit STORED-operand form of these with a cast16 launch per operand was measured at 39.1 vs 38.3 ms/step
+# in bf16 - two cast passes per convolution cost more than the packed GEMMs gain - and removed; YBlockFn's "lp" path below is its successor: the
+# copies come out of the element-wise passes that produce the operands anyway.)
 def _c1x1_fwd(x2, w, colstat=True):
     """y (M, N) = x2 (M, K) @ w (N, K)^T  (+ BatchNorm statistics of y); returns (y, ColStat or None, saved input)."""
     if colstat:
@@ -374,6 +375,15 @@ def _c1x1_bwd(dy2, saved, w, dw, res=None):
     return dx
 
 
+def _c1x1_bwd16(d16, d16t, xt16, w, dw, res=None):
+    """16-bit storage form of _c1x1_bwd: dW += dy16^T . x16 (both through their transposed copies, contraction over the rows padded to 8),
+    returns dx = dy16 . W16 (+ res) in fp32."""
+    ops.gemm16_nt(d16t, xt16, dw, accumulate=True, k=d16t.shape[1])
+    _, w16t = ops.lowp_weight(w)
+    out = torch.empty(d16.shape[0], w.shape[1], dtype=torch.float32, device=d16.device)
+    return ops.gemm16_nt(d16, w16t, out, res=res, k=w.shape[0])
+
+
 # ============================================================================================ RegNetY block
 @routes_param_grads
 class YBlockFn(torch.autograd.Function):
@@ -385,9 +395,21 @@ class YBlockFn(torch.autograd.Function):
         B, H, W, Cin = x.shape
         C = blk.out_chs
         x2 = x.view(-1, Cin)
-        y1, cs1, x2s = _c1x1_fwd(x2, w2d(blk.conv1.conv.weight))      # BN statistics gathered by the GEMM epilogue
-        y1 = y1.view(B, H, W, C)
         bn1 = blk.conv1.bn
+        # 16-bit storage modes (round 5): conv1 / conv3 as packed-16 NT GEMMs on STORED operands whose copies are written by their producers
+        # (the previous block's output pass, the SE-scale pass, the two BatchNorm backward applies: ops.bn_apply16 / se_scale_bn16 / bn_bwd16 /
+        # bn_bwd_remask16); where a producer variant has no such form, a cast16 launch makes the copies
+        lp = (bool(ops.lowp_conv()) and Cin % 8 == 0 and C % 8 == 0 and bn1.training and blk.conv2.bn.training and blk.conv3.bn.training and x.is_contiguous() and
+              B * ((H - 1) // blk.stride + 1) * ((W - 1) // blk.stride + 1) >= 32)      # <= 16 rows: the fp32 small-M kernels (exact, latency-sized) keep the layer
+        x16t = z16t = None
+        if lp:
+            pre = getattr(x, "_lp16", None)
+            x16, x16t = pre if pre is not None else ops.cast16(x2)
+            y1, cs1 = ops.gemm16_nt_colstat(x16, ops.lowp_weight(w2d(blk.conv1.conv.weight))[0], torch.empty(B * H * W, C, dtype=torch.float32, device=x.device))
+            x2s = None
+        else:
+            y1, cs1, x2s = _c1x1_fwd(x2, w2d(blk.conv1.conv.weight))      # BN statistics gathered by the GEMM epilogue
+        y1 = y1.view(B, H, W, C)
         fuse1 = (cs1 is not None and bn1.training and getattr(bn1, "_sync_group", None) is None and not isinstance(bn1, torch.nn.SyncBatchNorm) and
                  ops.grouped_bnrelu_ok(y1.shape, C, blk.groups, blk.stride))
         if fuse1:
@@ -409,7 +431,11 @@ class YBlockFn(torch.autograd.Function):
             coef2, sm2, si2 = ops.bn_finalize_parts(cs2, bn2.weight, bn2.bias, bn2.running_mean, bn2.running_var, bn2.momentum, bn2.eps)
             st2, z2 = (sm2, si2, coef2), None
             s, g1, gate = ops.se_squeeze_excite_bn_fwd(y2, coef2, blk.se.fc1.weight, blk.se.fc1.bias, blk.se.fc2.weight, blk.se.fc2.bias)
-            z2s = ops.se_scale_bn_fwd(y2, coef2, gate)
+            if lp:
+                z16, z16t = ops.se_scale_bn16(y2, coef2, gate)      # conv3's operand copies straight from the SE-scale pass: no fp32 z2s
+                z2s = None
+            else:
+                z2s = ops.se_scale_bn_fwd(y2, coef2, gate)
         else:
             z2, st2 = _bn(y2, bn2, relu=True, stat=cs2)
             s = ops.colsum(z2, B, Ho * Wo, C, 1.0 / (Ho * Wo))
@@ -419,7 +445,13 @@ class YBlockFn(torch.autograd.Function):
                 g1 = ops.linear_fwd(s, w2d(blk.se.fc1.weight), blk.se.fc1.bias, relu=True)
                 gate = ops.linear_fwd(g1, w2d(blk.se.fc2.weight), blk.se.fc2.bias)
             z2s = ops.se_scale_fwd(z2, gate)
-        y3, cs3, z2ss = _c1x1_fwd(z2s.view(-1, C), w2d(blk.conv3.conv.weight))
+        if lp:
+            if z2s is not None:
+                z16, z16t = ops.cast16(z2s.view(-1, C))
+            y3, cs3 = ops.gemm16_nt_colstat(z16, ops.lowp_weight(w2d(blk.conv3.conv.weight))[0], torch.empty(B * Ho * Wo, C, dtype=torch.float32, device=x.device))
+            z2ss = None
+        else:
+            y3, cs3, z2ss = _c1x1_fwd(z2s.view(-1, C), w2d(blk.conv3.conv.weight))
         y3 = y3.view(B, Ho, Wo, C)
         yd = std = None
         if blk.downsample is not None:
@@ -431,8 +463,16 @@ class YBlockFn(torch.autograd.Function):
             sc, std = _bn(yd, blk.downsample.bn, relu=False, stat=csd)
         else:
             sc = x
-        out, st3 = _bn(y3, blk.conv3.bn, res=sc, relu=True, stat=cs3)
-        ctx.saved = (x, blk, y1, z1, st1, y2, z2, st2, s, g1, gate, z2ss, y3, st3, yd, std, out, x2s)
+        bn3 = blk.conv3.bn
+        if lp and cs3 is not None and getattr(bn3, "_sync_group", None) is None and not isinstance(bn3, torch.nn.SyncBatchNorm):
+            # the block output pass also writes the 16-bit copies the NEXT bottleneck's conv1 multiplies (handed over as an attribute of the tensor)
+            coef3, sm3, si3 = ops.bn_finalize_parts(cs3, bn3.weight, bn3.bias, bn3.running_mean, bn3.running_var, bn3.momentum, bn3.eps)
+            out, o16, o16t = ops.bn_apply16(y3, coef3, sc, True)
+            st3 = (sm3, si3)
+            out._lp16 = (o16, o16t)
+        else:
+            out, st3 = _bn(y3, bn3, res=sc, relu=True, stat=cs3)
+        ctx.saved = (x, blk, y1, z1, st1, y2, z2, st2, s, g1, gate, z2ss, y3, st3, yd, std, out, x2s, (lp, x16t, z16t))
         return out
 
     @staticmethod
@@ -440,14 +480,23 @@ class YBlockFn(torch.autograd.Function):
         if ctx.saved is None:
             raise RuntimeError("YBlockFn: trying to backward through the graph a second time: the saved activations are freed by the first backward "
                                "(retain_graph is not supported by the block Functions)")
-        x, blk, y1, z1, st1, y2, z2, st2, s, g1, gate, z2ss, y3, st3, yd, std, out, x2s = ctx.saved
+        x, blk, y1, z1, st1, y2, z2, st2, s, g1, gate, z2ss, y3, st3, yd, std, out, x2s, (lp, x16t, z16t) = ctx.saved
         B, H, W, Cin = x.shape
         _, Ho, Wo, C = out.shape
         x2 = x.view(-1, Cin)
-        dy3, dsc = _bn_bwd(dout.contiguous(), out, y3, blk.conv3.bn, st3, want_dres=True)
-        dy3_2 = dy3.view(-1, C)
         w3 = blk.conv3.conv.weight
-        dz2s = _c1x1_bwd(dy3_2, z2ss, w2d(w3), w2d(gbuf(w3))).view(B, Ho, Wo, C)
+        if lp:
+            bn3 = blk.conv3.bn
+            if len(st3) == 2:       # the gradient entering conv3 leaves the BatchNorm backward as 16-bit copies (no fp32 dy3)
+                _, d16, d16t, dsc = ops.bn_bwd16(dout.contiguous(), out, y3, bn3.weight, st3[0], st3[1], gbuf(bn3.weight), gbuf(bn3.bias), want_dres=True)
+            else:
+                dy3, dsc = _bn_bwd(dout.contiguous(), out, y3, bn3, st3, want_dres=True)
+                d16, d16t = ops.cast16(dy3.view(-1, C))
+            dz2s = _c1x1_bwd16(d16, d16t, z16t, w2d(w3), w2d(gbuf(w3))).view(B, Ho, Wo, C)
+        else:
+            dy3, dsc = _bn_bwd(dout.contiguous(), out, y3, blk.conv3.bn, st3, want_dres=True)
+            dy3_2 = dy3.view(-1, C)
+            dz2s = _c1x1_bwd(dy3_2, z2ss, w2d(w3), w2d(gbuf(w3))).view(B, Ho, Wo, C)
         # squeeze-excite
         se = blk.se
         if z2 is None:      # forward ran with the BatchNorm apply folded into the consumers (st2 = (mean, invstd, [scale | shift]))
@@ -480,17 +529,26 @@ class YBlockFn(torch.autograd.Function):
             bn1 = blk.conv1.bn
             ops.grouped_bnrelu_wgrad(dy2, y1, st1[2], gbuf(w2), stride=blk.stride)
             dz1 = ops.conv_dgrad(dy2, w2, y1.shape, blk.stride, 1, blk.groups)
-            dy1 = ops.bn_bwd_remask(dz1, y1, st1[2], bn1.weight, st1[0], st1[1], gbuf(bn1.weight), gbuf(bn1.bias))
+            if lp:
+                _, e16, e16t = ops.bn_bwd_remask16(dz1, y1, st1[2], bn1.weight, st1[0], st1[1], gbuf(bn1.weight), gbuf(bn1.bias))
+            else:
+                dy1 = ops.bn_bwd_remask(dz1, y1, st1[2], bn1.weight, st1[0], st1[1], gbuf(bn1.weight), gbuf(bn1.bias))
         else:
             ops.conv_wgrad(dy2, z1, gbuf(w2), blk.stride, 1, blk.groups)
             dz1 = ops.conv_dgrad(dy2, w2, z1.shape, blk.stride, 1, blk.groups)
             dy1, _ = _bn_bwd(dz1, z1, y1, blk.conv1.bn, st1)
-        dy1_2 = dy1.view(-1, C)
+            if lp:
+                e16, e16t = ops.cast16(dy1.view(-1, C))
         w1 = blk.conv1.conv.weight
-        if blk.downsample is None:
-            dx = _c1x1_bwd(dy1_2, x2s, w2d(w1), w2d(gbuf(w1)), res=dsc.view(-1, Cin))
+        if lp:
+            c1b = lambda res=None: _c1x1_bwd16(e16, e16t, x16t, w2d(w1), w2d(gbuf(w1)), res=res)
         else:
-            dx = _c1x1_bwd(dy1_2, x2s, w2d(w1), w2d(gbuf(w1)))
+            dy1_2 = dy1.view(-1, C)
+            c1b = lambda res=None: _c1x1_bwd(dy1_2, x2s, w2d(w1), w2d(gbuf(w1)), res=res)
+        if blk.downsample is None:
+            dx = c1b(dsc.view(-1, Cin))
+        else:
+            dx = c1b()
             dyd, _ = _bn_bwd(dsc, None, yd, blk.downsample.bn, std)
             wd = blk.downsample.conv.weight
             if blk.stride == 1:

@@ -165,6 +165,63 @@ def gemm16_nt_colstat(a16, b16, out, want_stat=True):
     return out, (cs if cs else None)
 
 
+STORE16_CONV = os.environ.get("TF_STORE16_CONV", "1") != "0"      # round 5 (second session): the bottlenecks' 1x1 convolutions on 16-bit STORED operands whose copies their producers write
+
+
+def lowp_conv():
+    """16-bit storage mode of the RegNetY bottlenecks' 1x1 convolutions (functions.YBlockFn): 0 off, else the storage dtype code."""
+    return _lowp["dtype"] if STORE16_CONV else 0
+
+
+def _pair16(rows, C, dev, want=True):
+    rows8 = (rows + 7) // 8 * 8
+    return (torch.empty(rows, C, dtype=_t16(), device=dev) if want else None), torch.empty(C, rows8, dtype=_t16(), device=dev), rows8
+
+
+_vp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def bn_apply16(x, coef, res=None, relu=False, want_f32=True):
+    """y = x * scale + shift (+ res) (relu) from coef = [scale | shift] (bn_finalize_parts) -> (y fp32 or None, y16 (rows, C), y16t (C, rows8))."""
+    C = x.shape[-1]
+    rows = x.numel() // C
+    y = torch.empty_like(x) if want_f32 else None
+    y16, y16t, rows8 = _pair16(rows, C, x.device)
+    check(L().tf_bn_apply16_f32(ptr(_c(x)), ptr(coef), ptr(res), int(relu), ptr(y), rows, C, _vp(y16), _vp(y16t), rows8, _lowp["dtype"], stream_of(x)), "tf_bn_apply16_f32")
+    return y, y16, y16t
+
+
+def se_scale_bn16(y, coef, gate):
+    """relu(y * scale + shift) * sigmoid(gate[b, c]) as 16-bit copies only -> (z16 (rows, C), z16t (C, rows8))."""
+    B, H, W, C = y.shape
+    z16, z16t, rows8 = _pair16(B * H * W, C, y.device)
+    check(L().tf_se_scale_bn16_f32(ptr(_c(y)), ptr(coef), ptr(_c(gate)), B, H * W, C, _vp(z16), _vp(z16t), rows8, _lowp["dtype"], stream_of(y)), "tf_se_scale_bn16_f32")
+    return z16, z16t
+
+
+def bn_bwd16(dz, z, x, gamma, sm, si, dgamma, dbeta, want_dres=False, want_f32=False):
+    """bn_bwd whose dx leaves as 16-bit copies -> (dx fp32 or None, dx16, dx16t, dres or None)."""
+    C = x.shape[-1]
+    rows = x.numel() // C
+    dx = torch.empty_like(x) if want_f32 else None
+    dres = torch.empty_like(x) if want_dres else None
+    d16, d16t, rows8 = _pair16(rows, C, x.device)
+    check(L().tf_bn_bwd16_f32(ptr(_c(dz)), ptr(z), ptr(_c(x)), rows, C, ptr(gamma), ptr(sm), ptr(si), ptr(dx), ptr(dres), ptr(dgamma), ptr(dbeta),
+                              ptr(workspace(x.device)), _vp(d16), _vp(d16t), rows8, _lowp["dtype"], stream_of(x)), "tf_bn_bwd16_f32")
+    return dx, d16, d16t, dres
+
+
+def bn_bwd_remask16(dz, x, coef, gamma, sm, si, dgamma, dbeta, want_f32=False):
+    """bn_bwd_remask whose dx leaves as 16-bit copies -> (dx fp32 or None, dx16, dx16t)."""
+    C = x.shape[-1]
+    rows = x.numel() // C
+    dx = torch.empty_like(x) if want_f32 else None
+    d16, d16t, rows8 = _pair16(rows, C, x.device)
+    check(L().tf_bn_bwd_remask16_f32(ptr(_c(dz)), ptr(_c(x)), ptr(coef), rows, C, ptr(gamma), ptr(sm), ptr(si), ptr(dx), ptr(dgamma), ptr(dbeta),
+                                     ptr(workspace(x.device)), _vp(d16), _vp(d16t), rows8, _lowp["dtype"], stream_of(x)), "tf_bn_bwd_remask16_f32")
+    return dx, d16, d16t
+
+
 def lowp_weight(w):
     """(w16 (N, K), w16t (K, N8)) of a linear weight (N, K).  Inside train.Engine the copies are cached and rewritten once per step right after
     AdamW (``lowp_refresh_weights``); anywhere else they are re-made at every use (the parameter may have changed)."""
