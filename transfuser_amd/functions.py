@@ -400,7 +400,8 @@ class YBlockFn(torch.autograd.Function):
         # (the previous block's output pass, the SE-scale pass, the two BatchNorm backward applies: ops.bn_apply16 / se_scale_bn16 / bn_bwd16 /
         # bn_bwd_remask16); where a producer variant has no such form, a cast16 launch makes the copies
         lp = (bool(ops.lowp_conv()) and Cin % 8 == 0 and C % 8 == 0 and bn1.training and blk.conv2.bn.training and blk.conv3.bn.training and x.is_contiguous() and
-              B * ((H - 1) // blk.stride + 1) * ((W - 1) // blk.stride + 1) >= 32)      # <= 16 rows: the fp32 small-M kernels (exact, latency-sized) keep the layer
+              B * ((H - 1) // blk.stride + 1) * ((W - 1) // blk.stride + 1) >= 32 and      # <= 16 rows: the fp32 small-M kernels (exact, latency-sized) keep the layer
+              ops.want_colstat(B * H * W))      # stage 1 (> 40 000 rows: no statistics epilogue, so no folded producers) would need a cast launch per operand
         x16t = z16t = None
         if lp:
             pre = getattr(x, "_lp16", None)
