@@ -13,7 +13,7 @@ TRACE_TAG=_bf16 BENCH_ARGS="--dtype bf16" bash tools/gpu_round4.sh trace > /dev/
 cp $O/${TAG}_kernel_trace_graph_bf16.txt profiles/${TAG}_kernel_trace_graph_bf16.txt 2>/dev/null
 ( time timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/${TAG}_bench_n1.json 2> $O/${TAG}_bench_n1.err ) 2>&1 | tail -3
 tail -12 $O/${TAG}_bench_n1.err
-S1="TF_FUSE_DROPOUT=0 TF_LN_FWD16=0 TF_CAST16_MULTI=0"
+S1="TF_FUSE_DROPOUT=0 TF_LN_FWD16=0 TF_CAST16_MULTI=0 TF_STORE16_CONV=0"
 for rep in 1 2 3; do
   env $S1 TF_GEMM_PAIR=0 TF_AB_MERGE_HEADS=0 TF_AB_WSUM=0 TF_GROUPED_S2=0 TF_IM2COL_GEMM=0 timeout 200 $B 2>/dev/null | bl "fp32 round-4 behaviour of this library                     "
   env $S1 timeout 200 $B 2>/dev/null | bl "fp32 first session of round 5 (launch fusions off)         "
@@ -21,7 +21,11 @@ for rep in 1 2 3; do
 done
 for rep in 1 2 3; do
   env $S1 timeout 200 $B --dtype bf16 2>/dev/null | bl "bf16 first session of round 5 (cast launches)              "
-  timeout 200 $B --dtype bf16 2>/dev/null | bl "bf16 round-5 head (LayerNorm -> 16-bit copies, 1 weight cast)"
+  timeout 200 $B --dtype bf16 2>/dev/null | bl "bf16 round-5 head (LayerNorm -> 16-bit copies, 1 weight cast, stored trunk 1x1 convolutions)"
+done
+for rep in 1 2; do
+  env $S1 timeout 200 $B --dtype fp16 --backbone latentTF 2>/dev/null | bl "latentTF fp16 B=16 first session of round 5"
+  timeout 200 $B --dtype fp16 --backbone latentTF 2>/dev/null | bl "latentTF fp16 B=16 round-5 head            "
 done
 bash tools/gpu_round4.sh hbm 2>&1 | tail -16
 bash tools/gpu_round4.sh tests_all
