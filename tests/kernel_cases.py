@@ -1322,7 +1322,7 @@ def check_lowp16_conv_stage(dev, mode):
     rel = lambda u, v: float((u - v).norm() / v.norm().clamp_min(1e-12))
     # MI355X: the two paths run different tile plans and k-split atomics (run-to-run summation order), and a ReLU / 16-bit rounding decision that flips on a
     # 1e-7 difference moves a gradient element by its whole size - the emulator pins exactness, the GPU run checks agreement well below any real defect (O(0.1))
-    ty, tg = (1e-6, 1e-5) if dev == "cpu" else (1e-4, 5e-3)
+    ty, tg = (1e-6, 1e-5) if dev == "cpu" else (1e-4, 2e-2)      # one flipped ReLU decision among 3e4 elements is ~6e-3 of a gradient's norm
     assert rel(a[0], b[0]) <= ty and rel(a[1], b[1]) <= tg, (rel(a[0], b[0]), rel(a[1], b[1]))
     for k in a[2]:
         assert rel(a[2][k], b[2][k]) <= tg, (k, rel(a[2][k], b[2][k]))
