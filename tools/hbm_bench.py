@@ -112,6 +112,19 @@ ops.set_precision("bf16")
 for (M, C) in ((1740, 6048), (1740, 1512)):
     xc = torch.randn(M, C, device=dev)
     row("cast16 (row-major + transposed bf16 copies) [%d x %d]  (4 B read + 2 x 2 B written)" % (M, C), M * C * 8, lambda: ops.cast16(xc))
+# round 5 (second session): the producers that write the 16-bit operand copies themselves (norm.cpp layernorm_fwd16, reduce.cpp tile16_kernel)
+for (M, C) in ((1740, 1512), (1740, 576)):
+    xl, gl, bl_ = torch.randn(M, C, device=dev), torch.ones(C, device=dev), torch.zeros(C, device=dev)
+    row("layernorm -> bf16 copies (row-major + transposed) [%d x %d]  (4 B read + 2 x 2 B written)" % (M, C), M * C * 8, lambda: ops.layernorm_fwd16(xl, gl, bl_))
+Bq, Hq, Wq, Cq = 10, 16, 44, 576
+yq, rq = torch.randn(Bq, Hq, Wq, Cq, device=dev), torch.randn(Bq, Hq, Wq, Cq, device=dev)
+coefq, gateq = torch.cat([torch.ones(Cq, device=dev), torch.zeros(Cq, device=dev)]), torch.randn(Bq, Cq, device=dev)
+Eq = yq.numel()
+row("bottleneck output: BatchNorm apply + shortcut + ReLU -> fp32 + bf16 copies (10, 16, 44, 576)  (8 B read + 8 B written)", Eq * 16, lambda: ops.bn_apply16(yq, coefq, rq, True))
+row("conv3 input: BatchNorm + ReLU + SE scale -> bf16 copies only (10, 16, 44, 576)  (4 B read + 4 B written)", Eq * 8, lambda: ops.se_scale_bn16(yq, coefq, gateq))
+gq, smq, siq, dgq, dbq = torch.ones(Cq, device=dev), torch.zeros(Cq, device=dev), torch.ones(Cq, device=dev), torch.zeros(Cq, device=dev), torch.zeros(Cq, device=dev)
+row("BatchNorm backward (reduce + finalize + apply) -> bf16 copies + shortcut gradient (10, 16, 44, 576)  (2 x 12 B read + 8 B written)", Eq * 32,
+    lambda: ops.bn_bwd16(rq, yq, yq, gq, smq, siq, dgq, dbq, want_dres=True))
 ops.set_precision("fp32")
 xm = torch.randn(10, 128, 352, 64, device=dev)
 row("maxpool 3x3/s2 fwd (10, 128, 352, 64)  (read x, write y + 1 B index)", xm.numel() * 4 + xm.numel() // 4 * 5, lambda: ops.maxpool3x3s2_fwd(xm))
