@@ -437,11 +437,104 @@ def check_full_size_vs_fp64(backbone, B, H, dev="cuda", use_velocity=False, prec
         ops.L().tf_plans_clear()
 
 
+def check_lowp_full_size(backbone, B, H, precision, dev="cuda", loss_tol=3e-2, out_tol=6e-2, cos_min=0.9, med_max=0.5, loss_scale=1.0, tiny=None):
+    """Model-level parity of a 16-bit compute mode ("bf16" = BASELINE configs[2], "fp16" = configs[4]) AT a BASELINE configuration's own batch size
+    and resolution, real RegNetY-3.2GF trunks, the shipped plans, and every 16-bit STORAGE path of the mode switched on (GPT linear layers on
+    stored operands, LayerNorm writing the 16-bit copies, the bottlenecks' 1x1 convolutions on the copies their producers write - the wrappers
+    below prove that these kernels really ran) against the fp32 CPU oracle.  Stated tolerances of a 16-bit-operand mode (8 / 11-bit mantissas,
+    fp32 accumulation, ~60 layers): the 11 losses within ``loss_tol`` relative, the forward outputs (waypoints, fused features, feature grid, p2,
+    BEV logits) within ``out_tol`` in relative L2 (and every single element within 4 ``out_tol`` of the output's range), the whole gradient's cosine with the fp32 oracle's gradient >= ``cos_min`` and the
+    median per-tensor relative L2 <= ``med_max`` (per-tensor agreement below that is not attainable: this network amplifies fp32 round-off itself
+    to 1e-2 per tensor, see compare_vs_fp64).  ``loss_scale``: the backward is seeded with it (fp16: what train.Engine does) and divided out."""
+    import os
+    from oracle import hist
+    from transfuser_amd import ops
+    from transfuser_amd.data import synthetic_batch
+    if tiny is None:
+        ops.plans_load(os.path.join(os.path.dirname(os.path.abspath(ops.__file__)), "plans", "mi355x.txt"))
+        cfg = full_config()
+        prod, ref = build_pair(cfg, "regnety_032", dev, backbone=backbone)
+        batch = synthetic_batch(B, H, 704, seed=0, hist_fn=hist.lidar_to_histogram_features, n_points=8192)
+        keys = ("rgb", "lidar", "ego_waypoint", "target_point", "target_point_image", "ego_vel", "bev", "label", "depth", "semantic") + \
+            (("bev_points", "cam_points") if backbone == "geometric_fusion" else ())
+        batch = {k: batch[k] for k in keys}
+    else:                                         # (cfg, batch) of the tiny twin: the emulator runs this very function (tests/test_model_emu.py)
+        cfg, batch = tiny
+        prod, ref = build_pair(cfg, "regnety_tiny", dev, backbone=backbone)
+    torch.set_num_threads(min(64, os.cpu_count()))
+    calls = {"gemm16_nt": 0, "gemm16_nt_colstat": 0, "layernorm_fwd16": 0}
+    saved = {k: getattr(ops, k) for k in calls}
+
+    def counted(name):
+        def f(*a, **k):
+            calls[name] += 1
+            return saved[name](*a, **k)
+        return f
+    for k in calls:
+        setattr(ops, k, counted(k))
+    ops.set_precision(precision)
+    try:
+        assert ops.lowp_storage() and ops.lowp_conv(), "the 16-bit storage paths are switched off (TF_STORE16 / TF_STORE16_CONV)"
+        prod.train(); ref.train()
+        call = lambda m, b: m(b['rgb'], b['lidar'], ego_waypoint=b['ego_waypoint'], target_point=b['target_point'],
+                              target_point_image=b['target_point_image'], ego_vel=b['ego_vel'].reshape(-1, 1), bev=b['bev'], label=b['label'],
+                              depth=b['depth'], semantic=b['semantic'], **{k: b[k] for k in ('bev_points', 'cam_points') if k in b})
+        lp = call(prod, {k: v.to(dev) for k, v in batch.items()})
+        lr = call(ref, batch)
+        w = dict(zip(cfg.detailed_losses, [1.0, 1.0, 1.0, 1.0, 0.2, 0.2, 0.2, 0.2, 0.2, 0.3, 0.4]))
+        for p in prod.parameters():
+            p.grad = None
+        (sum(w[k] * v for k, v in lp.items()) * loss_scale).backward()
+        sum(w[k] * v for k, v in lr.items()).backward()
+        if dev != "cpu":
+            torch.cuda.synchronize()
+    finally:
+        ops.set_precision("fp32")
+        for k in calls:
+            setattr(ops, k, saved[k])
+        ops.L().tf_plans_clear()
+    print("  %s %s B=%d H=%d: stored-operand launches %s" % (backbone, precision, B, H, calls))
+    assert calls["gemm16_nt"] > 0 and calls["layernorm_fwd16"] > 0, calls
+    assert calls["gemm16_nt_colstat"] > 0 or tiny is not None, calls     # the trunks' 1x1 convolutions ran on the copies their producers wrote
+    # every figure first (one printed line per run: the tolerances below are read against it), then the assertions
+    dev_l = max(abs(float(lp[k].detach()) - float(lr[k].detach())) / max(1.0, abs(float(lr[k].detach()))) for k in lr)
+    o, r = prod._last, ref._last
+    outs = {}
+    for name, a, b in [("pred_wp", o["pred_wp"], r["pred_wp"]), ("fused_features", o["fused"], r["fused"]),
+                       ("image_features_grid", o["grid"].permute(0, 3, 1, 2), r["grid"]), ("p2", o["features"][0].permute(0, 3, 1, 2), r["features"][0]),
+                       ("pred_bev", o["bev_up"].permute(0, 3, 1, 2), r["pred_bev"])]:
+        a, b = a.detach().cpu().double(), b.detach().double()
+        outs[name] = ((a - b).norm().item() / max(b.norm().item(), 1e-30), (a - b).abs().max().item() / max(1.0, b.abs().max().item()))
+    worst_out = max(v[0] for v in outs.values())
+    rp = dict(ref.named_parameters())
+    names = [n for n, p in prod.named_parameters() if rp[n].grad is not None]
+    pp = dict(prod.named_parameters())
+    gp = torch.cat([pp[n].grad.detach().cpu().double().flatten() for n in names]) / loss_scale
+    gr = torch.cat([rp[n].grad.double().flatten() for n in names])
+    cos = float(torch.dot(gp, gr) / (gp.norm() * gr.norm()))
+    errs = sorted((pp[n].grad.detach().cpu().double() / loss_scale - rp[n].grad.double()).norm().item() / rp[n].grad.double().norm().item()
+                  for n in names if rp[n].grad.norm().item() > 1e-10)
+    live = [e for e in errs if e < 0.99]           # (a tensor whose true gradient is zero up to round-off compares noise with noise: ~1.4)
+    med = live[len(live) // 2]
+    print("  %s %s B=%d H=%d vs fp32 oracle: max loss deviation %.2e; outputs rel-L2 / max-of-range %s; gradient cosine %.4f, norm ratio %.4f, "
+          "per-tensor rel-L2 median %.2e / 90th pct %.2e over %d tensors" % (backbone, precision, B, H, dev_l, {k: "%.1e / %.1e" % v for k, v in outs.items()}, cos,
+                                                                            float(gp.norm() / gr.norm()), med, live[int(len(live) * 0.9)], len(live)))
+    for k in lr:
+        a, b = float(lp[k].detach()), float(lr[k].detach())
+        assert math.isfinite(a) and abs(a - b) <= loss_tol * max(1.0, abs(b)), "loss %s: %s %g vs fp32 oracle %g" % (k, precision, a, b)
+    for name, (l2, mx) in outs.items():           # relative L2 over the whole output; its single worst element may sit 4x further out
+        assert l2 <= out_tol and mx <= 4 * out_tol, "output %s: rel-L2 %.3e, max %.3e of its range" % (name, l2, mx)
+    assert bool(torch.isfinite(gp).all())
+    assert cos >= cos_min and med <= med_max, (cos, med)
+    return dev_l, worst_out, cos, med
+
+
 def check_full_size_vs_fp32_oracle(backbone, B, H, dev="cuda", loss_tol=1e-3, per_tensor=5e-2, median=1.5e-2, plans=True, precision="fp32"):
     """Parity at a BASELINE configuration's own batch size and resolution with the real RegNetY-3.2GF trunks: the 11 losses and the forward
     outputs within ``loss_tol`` of the fp32 CPU oracle (north_star: 1e-3), every parameter gradient against the oracle's fp32 gradient in
-    relative L2 (fp32 gradients of this network carry ~1e-2 of round-off noise per tensor on ANY implementation, see compare_vs_fp64:
-    per-tensor bound 5e-2, median 1.5e-2 - a wrong kernel / tile plan at these exact shapes gives O(1))."""
+    relative L2 (fp32 gradients of this network carry ~1e-2 of round-off noise per tensor on ANY implementation: median bound 1.5e-2), and - the
+    gate proper, with no allowance for "any few tensors" and no name-based skips - EVERY parameter gradient as close to the fp64 oracle's as the fp32
+    oracle's own gradient is (compare_vs_fp64 on the same B / H / plans; tensors beyond ``per_tensor`` of the fp32 oracle are printed)."""
     import os
     from oracle import hist
     from transfuser_amd import ops
@@ -482,11 +575,19 @@ def check_full_size_vs_fp32_oracle(backbone, B, H, dev="cuda", loss_tol=1e-3, pe
     errs.sort(reverse=True)
     med = errs[len(errs) // 2][0]
     print("  %s B=%d H=%d gradient rel-L2 vs fp32 oracle: median %.2e, worst %s" % (backbone, B, H, med, [("%.2e" % e, n) for e, n in errs[:4]]))
-    noise_only = ("attn.key.bias",)                        # true gradient is zero up to round-off (softmax shift invariance)
-    bad = [(e, n) for e, n in errs if e > per_tensor and not any(t in n for t in noise_only)]
-    assert med <= median and len(bad) <= 3, (med, bad[:6])
-    if plans:
-        ops.L().tf_plans_clear()
+    assert med <= median, (med, errs[:6])
+    # No free passes (round-5 review, weak #1): a tensor beyond ``per_tensor`` of the fp32 oracle is accepted ONLY if the fp64 oracle says the fp32
+    # oracle itself is that far from the true gradient there - compare_vs_fp64 holds EVERY tensor to e_hip <= 4 max(e_cpu32, median e_cpu32) + 2e-3
+    # and identifies the noise-only tensors (true gradient zero up to round-off, e.g. attn.key.bias under softmax's shift invariance) by
+    # MEASUREMENT (e_cpu32 >= 0.5), not by name.  A wrong kernel / tile plan at these shapes gives O(1) on the tensors it feeds and fails both.
+    over = [(e, n) for e, n in errs if e > per_tensor]
+    if over:
+        print("  beyond %.0e of the fp32 oracle (must be explained by the fp64 anchor below): %s" % (per_tensor, [("%.2e" % e, n) for e, n in over]))
+    try:
+        compare_vs_fp64(prod, ref, lp, lr, batch, cfg, out_tol=loss_tol)
+    finally:
+        if plans:
+            ops.L().tf_plans_clear()
 
 
 def check_bn_conv_fold(dev, batch_dims, lidar_res=None):

@@ -380,6 +380,15 @@ def test_lowp_storage_modes_tiny_model(mode):
     assert relc <= 2e-2, relc
 
 
+@pytest.mark.parametrize("backbone,mode", [("transFuser", "bf16"), ("latentTF", "fp16")])
+def test_lowp_model_level_gate_on_the_tiny_twin(backbone, mode):
+    """The model-level 16-bit gate of the MI355X suite (mc.check_lowp_full_size: test_lowp_bench_configuration_parity_B10_H256,
+    test_fp16_full_size_forward_parity) run on the tiny twin through the emulator: same code, same assertions, same loss-scaled backward."""
+    cfg = mc.tiny_config(n_layer=2)
+    batch = mc.small_batch(2, 32, 64, 64, 40)
+    mc.check_lowp_full_size(backbone, 2, 32, mode, dev="cpu", loss_scale=1024.0 if mode == "fp16" else 1.0, tiny=(cfg, batch), cos_min=0.97, out_tol=8e-2)
+
+
 @pytest.mark.parametrize("arch", ["resnet_tiny", "resnet_tiny50"])
 def test_resnet_trunks_match_oracle(arch):
     """the ResNet trunks the reference's constructors default to (transfuser.py:15; timm names, no re-labelling: 7x7 / s2 stem +

@@ -32,7 +32,7 @@ for name, s, e in seg:
     a[0] += 1; a[1] += e - s; a[2] = min(a[2], e - s); a[3] = max(a[3], e - s)
 fam = collections.defaultdict(float)
 for name, (c, t, _, _) in agg.items():
-    key = "gemm engine (gemm_kernel / gemm_pair_kernel / gemm_dma_kernel)" if "gemm_kernel" in name or "gemm_dma" in name or "gemm_pair" in name else "direct conv" if ("conv3x3_small" in name or "conv3x3_grouped" in name) else \
+    key = "gemm engine (gemm_kernel / gemm_pair_kernel / gemm_dma_kernel)" if "gemm_kernel" in name or "gemm_dma" in name or "gemm_pair" in name else "direct conv (conv3x3_grouped / conv3x3_small / conv3x3_thin)" if ("conv3x3_small" in name or "conv3x3_grouped" in name or "conv3x3_thin" in name) else \
         "batchnorm" if ("bn_" in name or "BnStat" in name or "BnBwd" in name) else "other"
     fam[key] += t / n / 1e6
 print("families (ms/step):", ", ".join("%s %.2f" % kv for kv in sorted(fam.items(), key=lambda kv: -kv[1])))
