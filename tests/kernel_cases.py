@@ -1474,6 +1474,9 @@ def check_conv_grouped(dev, B, H, W, C):
     ws = ops._grouped_ws(xh.device)
     check(L.tf_conv3x3_grouped_wgrad_f32(ptr(dyh), ptr(xh), wptr(dw), B, H, W, C, 1, ptr(ws), stream_of(xh)), "grouped wgrad")
     close(dw, gw + 0.25, what="grouped wgrad (accumulate)")
+    dw0 = torch.full_like(wh, 7.0)               # accumulate = 0 overwrites whatever dW held (the atomically accumulating kernel zero-fills first)
+    check(L.tf_conv3x3_grouped_wgrad_f32(ptr(dyh), ptr(xh), wptr(dw0), B, H, W, C, 0, ptr(ws), stream_of(xh)), "grouped wgrad")
+    close(dw0, gw, what="grouped wgrad (store)")
     # and through the public ops (dispatch)
     if groups > 1:
         close(ops.conv_fwd(xh, wh, None, 1, None, groups).permute(0, 3, 1, 2), y - b.view(1, -1, 1, 1), what="ops.conv_fwd -> grouped")

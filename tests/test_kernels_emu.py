@@ -108,6 +108,7 @@ def test_lidar_hist():
     kc.check_hist("cpu", 2, 3000)
     kc.check_hist("cpu", 3, 3001, stride=5)
     kc.check_hist("cpu", 4, 2049, ragged=[2049, 0, 1, 1500])
+    kc.check_hist("cpu", 9, 1100, ragged=[1100, 0, 1, 700, 1100, 64, 65, 1024, 1025])       # more than 8 samples: the slab kernel's second round of sample -> XCD slots, > 1024 points: a second trip
 
 
 def test_lidar_camera_correspondences():

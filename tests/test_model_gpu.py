@@ -637,19 +637,31 @@ def test_bf16_training_trajectory_matches_fp32():
     assert (c16[0, 0] - c16[-1, 0]) >= 0.8 * (c32[0, 0] - c32[-1, 0]) > 0, (c32[:, 0].tolist(), c16[:, 0].tolist())
 
 
-@pytest.mark.parametrize("mode", ["bf16", "fp16"])
-def test_lowp_bench_configuration_parity_B10_H256(mode):
-    """BASELINE configs[2] at ITS size: TransFuser B = 10, 256x704, shipped plans, bf16 (and the fp16 twin) with EVERY 16-bit storage path of the
-    mode on - the GPT linear layers, LayerNorm -> 16-bit copies, the stored-operand 1x1 convolutions of all RegNetY stages 2-4 bottlenecks (not a
-    3-block stage) - against the fp32 CPU oracle: mc.check_lowp_full_size states the tolerances and proves the stored-operand kernels ran."""
-    mc.check_lowp_full_size("transFuser", 10, 256, mode, loss_scale=1024.0 if mode == "fp16" else 1.0)
+def test_lowp_bench_configuration_parity_B10_H256():
+    """BASELINE configs[2] at ITS size: TransFuser B = 10, 256x704, shipped plans, bf16 and the fp16 twin with EVERY 16-bit storage path of the
+    modes on - the GPT linear layers, LayerNorm -> 16-bit copies, the stored-operand 1x1 convolutions of all RegNetY stages 2-4 bottlenecks (not a
+    3-block stage) - against one run of the fp32 CPU oracle (mc.check_lowp_full_size states what the tolerances mean and proves that the
+    stored-operand kernels ran).  Bounds = ~2x what the MI355X measured (bf16: losses 4e-5, waypoints 2e-3, fused 8e-2, grid 4e-1, p2 5e-2, BEV 2e-2,
+    cosine 0.983, median 0.71; fp16: 1e-5, 4e-4, 1.4e-2, 8e-2, 9e-3, 3e-3, 0.996, 0.45).  Last: the deviation scales with the mantissa width -
+    fp16 (11 bits) sits 4-16x below bf16 (8 bits) on every late feature map, as operand rounding must and a defect would not."""
+    res = mc.check_lowp_full_size("transFuser", 10, 256, {
+        "bf16": dict(loss=2e-3, out={"pred_wp": 8e-3, "fused_features": 1.6e-1, "image_features_grid": 7e-1, "p2": 1.1e-1, "pred_bev": 4e-2}, cos=0.96, med=0.9),
+        "fp16": dict(loss=1e-3, out={"pred_wp": 2e-3, "fused_features": 3e-2, "image_features_grid": 1.6e-1, "p2": 2e-2, "pred_bev": 8e-3}, cos=0.99, med=0.65,
+                     loss_scale=1024.0)})
+    for k in ("fused_features", "image_features_grid", "p2", "pred_bev"):
+        ratio = res["bf16"][1][k] / res["fp16"][1][k]
+        print("  %s: bf16 / fp16 deviation ratio %.1f (mantissa ratio 8)" % (k, ratio))
+        assert 3.0 <= ratio <= 20.0, (k, ratio)
 
 
 def test_fp16_full_size_forward_parity():
     """BASELINE configs[4] at ITS size and IN ITS mode (latentTF.py:118-217, bs = 16/GPU, fp16 MFMA): latentTF B = 16, 256x704, half-stored operands,
     backward seeded with the loss scale train.Engine starts from - losses / outputs / gradient direction against the fp32 CPU oracle
-    (mc.check_lowp_full_size)."""
-    mc.check_lowp_full_size("latentTF", 16, 256, "fp16", loss_scale=1024.0)
+    (mc.check_lowp_full_size; bounds ~2x the MI355X measurement: losses 1.5e-5, waypoints 6e-4, fused 2.4e-2, grid 8e-2, p2 3e-2, BEV 1e-2,
+    cosine 0.961, median 0.65)."""
+    mc.check_lowp_full_size("latentTF", 16, 256, {
+        "fp16": dict(loss=1e-3, out={"pred_wp": 3e-3, "fused_features": 5e-2, "image_features_grid": 1.6e-1, "p2": 6e-2, "pred_bev": 2e-2}, cos=0.93, med=0.85,
+                     loss_scale=1024.0)})
 
 
 def test_fp16_training_trajectory_matches_fp32():

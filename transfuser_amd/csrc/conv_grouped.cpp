@@ -25,6 +25,15 @@ constexpr int WP = 36;              // pitch of a weight row (32 output columns 
 
 struct GcGeom { int B, H, W, C, G, tiles_h, tiles_w, ntiles, nb, f16; };   // f16: the bf16 paths use IEEE-half operands instead (tf_set_precision(3))   // C = total channels (pixel stride), nb = blocks per group
 
+// an integer the optimiser may not treat as loop-invariant: index arithmetic derived from it is RE-COMPUTED where it is used instead of being hoisted
+// out of the tile loop into a dozen long-lived registers (round 6: the seven-wave weight gradient needs <= 80 VGPRs without spills)
+__device__ __forceinline__ int opaque(int v) {
+#ifndef TF_EMU
+    asm volatile("" : "+v"(v));
+#endif
+    return v;
+}
+
 template <int TW> struct Tile {
     static constexpr int RW = 32 / TW;            // image rows per wave
     static constexpr int TH = 4 * RW;             // tile rows (4 waves)
@@ -158,14 +167,33 @@ __global__ void __launch_bounds__(256, 2) conv3x3_grouped_kernel(const float* __
                 }
             }
         } else if constexpr (!X3) {
+            // round 6: the NEXT tap's 24 operand reads are issued before the current tap's 12 MFMAs (scheduling fences keep hipcc from sinking every
+            // read to just in front of its MFMA: "read, wait for the LDS round trip, two MFMAs" left the three waves of a SIMD ~50 % MFMA-busy)
+            const float* pa0 = patch + (prow * T::PW + pcol) * PP + hi;
+            const float* pb0 = &wl[hi][l31];
+            auto ldtap = [&](int tap, float (&a)[CG / 2], float (&b)[CG / 2]) {
+                const float* pa = pa0 + ((tap / 3) * T::PW + tap % 3) * PP;
+                const float* pb = pb0 + tap * CG * WP;
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int kh = tap / 3, kw = tap - kh * 3;
-            const float* pa = patch + ((prow + kh) * T::PW + pcol + kw) * PP + hi;
-            const float* pb = &wl[tap * CG + hi][l31];
+                for (int kk = 0; kk < CG / 2; ++kk) { a[kk] = pa[2 * kk]; b[kk] = pb[2 * kk * WP]; }
+            };
+            float a0[CG / 2], b0[CG / 2], a1[CG / 2], b1[CG / 2];
+            ldtap(0, a0, b0);
 #pragma unroll
-            for (int kk = 0; kk < CG / 2; ++kk) mfma_32x32x2(pa[2 * kk], pb[2 * kk * WP], acc);
-        }
+            for (int tap = 0; tap < 9; tap += 2) {
+                if (tap + 1 < 9) ldtap(tap + 1, a1, b1);
+                TF_SCHED_FENCE();
+#pragma unroll
+                for (int kk = 0; kk < CG / 2; ++kk) mfma_32x32x2(a0[kk], b0[kk], acc);
+                TF_SCHED_FENCE();
+                if (tap + 2 < 9) ldtap(tap + 2, a0, b0);
+                TF_SCHED_FENCE();
+                if (tap + 1 < 9) {
+#pragma unroll
+                    for (int kk = 0; kk < CG / 2; ++kk) mfma_32x32x2(a1[kk], b1[kk], acc);
+                }
+                TF_SCHED_FENCE();
+            }
         }
         const int b = tile / (g.tiles_h * g.tiles_w), r = tile - b * (g.tiles_h * g.tiles_w);
         const int h0 = (r / g.tiles_w) * T::TH, w0 = (r % g.tiles_w) * TW;
@@ -345,6 +373,120 @@ __global__ void __launch_bounds__(192) conv3x3_grouped_wgrad_kernel(const float*
             const int i = (e & 3) + 8 * (e >> 2) + 4 * hi;
             pp[kw * 1024 + i * 32] = acc[kw][e];
         }
+}
+
+// ---- round 6: the fp32 weight gradient with the NINE TAPS IN THE MFMA's N dimension.  dW of a group is the (24 x 216) product dY^T . im2col(X):
+// im2col column c = tap * 24 + ci, and c is also the offset of dW[co][tap][ci] inside the row of output channel co - so the group's gradient is ONE
+// row-major (24 x 216) matrix.  SEVEN waves per block, wave j owns the columns [32 j, 32 j + 32): 216 of 224 MFMA columns carry work (the kernel
+// above multiplied 3 x 3 blocks of 24 x 24 inside 32 x 32 tiles: 56 % of the MFMA; this one 24 / 32 x 216 / 224 = 72 %, i.e. 448 instead of 576 MFMAs
+// per 128-pixel tile).  All waves walk the tile's 128 pixels as the K dimension: A[i = co][k = pixel] is the staged dY tile (shared by the seven waves),
+// B[k][j = column] is gathered from the staged patch - a lane's column fixes its tap and input channel, i.e. one constant LDS offset, and every
+// k-step adds a compile-time pixel offset.  One accumulator (16 registers) per wave, ~40 VGPRs, 31 KB of LDS: four blocks = 28 waves per CU.
+// The block's (24 x 216) panel is ADDED to dW with fp32 atomics (64 lanes = two rows x 32 consecutive floats per instruction): no partial-panel
+// workspace (36 KB written and read back per block before: 3.45x the algorithmic traffic), no reduce launch.  Like the k-split GEMM weight
+// gradients the sum order over a group's blocks is not fixed (run-to-run differences at fp32 round-off); accumulate = 0 zero-fills dW first.
+template <int TW>
+__global__ void __launch_bounds__(448, 6) conv3x3_grouped_wgrad7_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw, GcGeom g,
+                                                                     const float* __restrict__ in_coef) {
+    typedef Tile<TW> T;
+    constexpr int NT = 448;
+    constexpr int NVP = (T::NPIX * 6 + NT - 1) / NT, ND = (128 * 6 + NT - 1) / NT;     // float4 slots per thread: patch, dY (6 per pixel)
+    __shared__ float lds[T::NPIX * PP + 128 * PP + 8];
+    __shared__ float cf[2 * CG];
+    float* patch = lds;
+    float* dyt = lds + T::NPIX * PP;               // [pixel][co]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int grp = blockIdx.x / g.nb, sub = blockIdx.x - grp * g.nb, coff = grp * CG;
+    // this lane's im2col column: tap (kh, kw) and input channel; the eight columns 216..223 of wave 6 read tap 8 again (in-bounds) and are never stored
+    const int col = 32 * wave + l31, tapc = col / CG < 9 ? col / CG : 8, ci = col - (col / CG) * CG;
+    const int boff = ((tapc / 3) * T::PW + (tapc % 3)) * PP + ci + hi * PP;       // + the k-step's pixel (2 kk + hi): hi moves one pixel to the right (TW is even)
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float4 pre[NVP], dpre[ND];
+    unsigned okm = 0;              // validity of the pre[] slots (in_coef, see bnrelu4)
+    auto fetch = [&](int t) {      // unconditional loads from clamped addresses; the zero padding is applied to the VALUE
+        const int b = t / (g.tiles_h * g.tiles_w), r = t - b * (g.tiles_h * g.tiles_w);
+        const int h0 = (r / g.tiles_w) * T::TH, w0 = (r % g.tiles_w) * TW;
+        const int tq = opaque(tid);
+        okm = 0;
+#pragma unroll
+        for (int p = 0; p < NVP; ++p) {
+            const int s = tq + p * NT, pix = s / 6, c = (s - pix * 6) * 4;
+            const int ph = pix / T::PW, pw = pix - ph * T::PW, h = h0 - 1 + ph, w = w0 - 1 + pw;
+            const bool ok = pix < T::NPIX && (unsigned)h < (unsigned)g.H && (unsigned)w < (unsigned)g.W;
+            const int hc = h < 0 ? 0 : (h >= g.H ? g.H - 1 : h), wc = w < 0 ? 0 : (w >= g.W ? g.W - 1 : w);
+            const float4 v = *reinterpret_cast<const float4*>(x + (((long)b * g.H + hc) * g.W + wc) * g.C + coff + c);
+            pre[p] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            okm |= ok ? 1u << p : 0u;
+        }
+#pragma unroll
+        for (int p = 0; p < ND; ++p) {
+            const int s = tq + p * NT, pix = s / 6, c = (s - pix * 6) * 4;
+            const int h = h0 + pix / TW, w = w0 + pix % TW;
+            const bool ok = pix < 128 && h < g.H && w < g.W;
+            const int hc = h >= g.H ? g.H - 1 : h, wc = w >= g.W ? g.W - 1 : w;
+            const float4 v = *reinterpret_cast<const float4*>(dy + (((long)b * g.H + hc) * g.W + wc) * g.C + coff + c);
+            dpre[p] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    // the block's tiles: a contiguous, balanced range of the group's tiles (neighbouring tiles share halo rows in L2)
+    const int t0 = (int)((long)sub * g.ntiles / g.nb), t1 = (int)((long)(sub + 1) * g.ntiles / g.nb);
+    int tile = t0;
+    if (tile < t1) fetch(tile);
+    stage_group_coef(cf, in_coef, coff, g.C);
+    for (; tile < t1; ++tile) {
+        __syncthreads();
+        const int ts = opaque(tid);
+#pragma unroll
+        for (int p = 0; p < NVP; ++p) {
+            const int s = ts + p * NT, pix = s / 6, c = (s - pix * 6) * 4;
+            const float4 v = in_coef ? bnrelu4(pre[p], cf, c, (okm >> p) & 1u) : pre[p];
+            if (pix < T::NPIX) { float* q = patch + pix * PP + c; q[0] = v.x; q[1] = v.y; q[2] = v.z; q[3] = v.w; }
+        }
+#pragma unroll
+        for (int p = 0; p < ND; ++p) {
+            const int s = ts + p * NT, pix = s / 6, c = (s - pix * 6) * 4;
+            if (pix < 128) { float* q = dyt + pix * PP + c; q[0] = dpre[p].x; q[1] = dpre[p].y; q[2] = dpre[p].z; q[3] = dpre[p].w; }
+        }
+        __syncthreads();
+        if (tile + 1 < t1) fetch(tile + 1);
+        const float* pa = dyt + hi * PP + l31;
+        const float* pb = patch + boff;
+        // the tile's 64 k-steps (k = pixel 2 kk + hi) in eight chunks of eight: the NEXT chunk's sixteen operand reads are issued before the current
+        // chunk's eight MFMAs, so a wave never sits out an LDS round trip between two MFMAs (one accumulator chain per wave: nothing else to issue)
+        auto kofs_a = [](int kk) { return 2 * kk * PP; };
+        auto kofs_b = [](int kk) { return (((2 * kk) / TW) * T::PW + (2 * kk) % TW) * PP; };
+        float a0[8], b0[8], a1[8], b1[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { a0[u] = pa[kofs_a(u)]; b0[u] = pb[kofs_b(u)]; }
+#pragma unroll
+        for (int ch = 0; ch < 8; ch += 2) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { a1[u] = pa[kofs_a(8 * ch + 8 + u)]; b1[u] = pb[kofs_b(8 * ch + 8 + u)]; }
+            TF_SCHED_FENCE();           // (hipcc's scheduler otherwise sinks every read to just in front of its MFMA: read, wait, two MFMAs, read, wait, ...)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) mfma_32x32x2(a0[u], b0[u], acc);
+            TF_SCHED_FENCE();
+            if (ch + 2 < 8) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { a0[u] = pa[kofs_a(8 * ch + 16 + u)]; b0[u] = pb[kofs_b(8 * ch + 16 + u)]; }
+            }
+            TF_SCHED_FENCE();
+#pragma unroll
+            for (int u = 0; u < 8; ++u) mfma_32x32x2(a1[u], b1[u], acc);
+            TF_SCHED_FENCE();
+        }
+    }
+    // rows co < 24 only (accumulator elements 12..15 are rows 24..31); columns < 216
+    if (col < 9 * CG && t0 < t1) {
+        float* d = dw + (long)grp * CG * 9 * CG + col;
+#pragma unroll
+        for (int e = 0; e < 12; ++e) {
+            const int i = (e & 3) + 8 * (e >> 2) + 4 * hi;
+            atomicAdd(d + i * 9 * CG, acc[e]);
+        }
+    }
 }
 
 __global__ void __launch_bounds__(256) conv3x3_grouped_wgrad_reduce_kernel(const float* __restrict__ part, int nb, float* __restrict__ dw, int accumulate) {
@@ -715,6 +857,13 @@ __global__ void __launch_bounds__(192) conv3x3_grouped_s2_wgrad_kernel(const flo
         }
 }
 
+__global__ void __launch_bounds__(256) fill_f32_kernel(float* __restrict__ p, long n) {
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (i + k < n) p[i + k] = 0.f;
+}
+
 constexpr int kMaxBlocks = 768;     // persistent grid: up to 3 blocks per CU
 
 // compute precision of these kernels; TF_X3_DIRECT=0 keeps them on the exact fp32 MFMA in f32x3 mode (A/B switch)
@@ -824,6 +973,19 @@ static int grouped_wgrad(const char* what, const float* dy, const float* x, cons
     if ((long)g.G * g.nb > kWgradMaxBlocks) g.nb = kWgradMaxBlocks / g.G;
     TF_REQUIRE(g.nb >= 1, "%s: %d groups exceed the workspace", what, g.G);
     const int prec = direct_prec();
+    static const int v7 = [] { const char* e = getenv("TF_GROUPED_WGRAD7"); return e ? atoi(e) : 1; }();     // A/B switch: 0 = the three-wave kernel + partial panels
+    if (prec == 0 && v7) {
+        // seven-wave blocks (conv3x3_grouped_wgrad7_kernel), 31 KB of LDS: up to four per CU.  Every block ends with 5184 atomics on its group's dW, so a
+        // block takes at least two tiles when there are enough; ~3 blocks per CU otherwise (TF_GROUPED_WGRAD7 > 1: that many blocks in all, for the lab)
+        GcGeom g7 = make_geom(B, H, W, C, tw, v7 > 1 ? v7 : 768);
+        int tpb7 = cdiv(g7.ntiles, g7.nb);
+        if (tpb7 < 2 && g7.ntiles >= 2) tpb7 = 2;
+        g7.nb = cdiv(g7.ntiles, tpb7);
+        if (!accumulate) TF_LAUNCH(fill_f32_kernel, dim3(cdiv((long)C * 9 * CG, 1024)), dim3(256), stream, dw, (long)C * 9 * CG);
+        if (tw == 16) TF_LAUNCH((conv3x3_grouped_wgrad7_kernel<16>), dim3(g7.G * g7.nb), dim3(448), stream, x, dy, dw, g7, in_coef);
+        else TF_LAUNCH((conv3x3_grouped_wgrad7_kernel<32>), dim3(g7.G * g7.nb), dim3(448), stream, x, dy, dw, g7, in_coef);
+        return launch_status(what);
+    }
 #define TF_GW(TW_, P_) TF_LAUNCH((conv3x3_grouped_wgrad_kernel<TW_, P_>), dim3(g.G * g.nb), dim3(192), stream, x, dy, ws, g, in_coef)
     if (tw == 16) { if (prec == 2) TF_GW(16, 2); else if (prec == 1 || prec == 3) TF_GW(16, 1); else TF_GW(16, 0); }
     else { if (prec == 2) TF_GW(32, 2); else if (prec == 1 || prec == 3) TF_GW(32, 1); else TF_GW(32, 0); }

@@ -136,6 +136,67 @@ __global__ void __launch_bounds__(256) lidar_hist_count_kernel(const float* __re
     const int cell = hist_cell<float>(x, y, z);
     hist_add(counters + (long)b * 2 * 256 * 256, i < n ? cell : -1);
 }
+
+// ---- round 6: H1 as ONE launch with the counters in LDS ("LDS reduction + coalesced HBM writes", BASELINE north_star).  A 1024-thread block owns a
+// SLAB of one sample's output - 16 grid rows x 256 columns x 2 height bins = 8192 int32 counters = 32 KB of LDS - walks the sample's cloud (512 KB at
+// 32768 points: every slab block of the sample re-reads it, which is why all blocks of a sample are placed on ONE XCD (block b runs on XCD b % 8 on
+// this part; correctness does not depend on it): the cloud leaves HBM once and the 15 re-reads hit that XCD's L2), counts the points of its slab with
+// return-less LDS atomics, and writes its 32 KB of min(count, 5) / 5 as float4 rows.  No global atomics, no counter workspace, the 5 MB output is
+// written exactly once: algorithmic traffic (16 B / point + 512 KB / sample).  Sixteen 16-byte point loads in flight per thread and trip.
+constexpr int kSlabRows = 16, kSlabs = 256 / kSlabRows;
+__global__ void __launch_bounds__(1024) lidar_hist_slab_kernel(const float* __restrict__ pts, const int32_t* __restrict__ npts, int B, int max_pts, int stride,
+                                                                int vec4, float* __restrict__ out) {
+    __shared__ int cnt[2 * kSlabRows * 256];
+    const int tid = threadIdx.x;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int b = xcd + 8 * (j / kSlabs), slab = j % kSlabs;
+    if (b >= B) return;
+    const int n = npts ? (npts[b] < max_pts ? npts[b] : max_pts) : max_pts;
+    const float* base = pts + (long)b * max_pts * stride;
+    constexpr int U = 16;                          // point loads in flight per thread and trip: 32768 points = two round trips of the block
+    bool first = true;
+    for (int i0 = 0; i0 < n || first; i0 += U * 1024) {
+        float px[U], py[U], pz[U];
+        if (n > 0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {          // clamped addresses: the loads are unconditional, the predicate applies to the cell
+                const int i = i0 + tid + 1024 * u;
+                const float* p = base + (long)(i < n ? i : n - 1) * stride;
+                if (vec4) { const float4 v = *reinterpret_cast<const float4*>(p); px[u] = v.x; py[u] = v.y; pz[u] = v.z; }
+                else { px[u] = p[0]; py[u] = p[1]; pz[u] = p[2]; }
+            }
+        }
+        if (first) {                               // the counters are cleared while the first trip's points travel
+#pragma unroll
+            for (int k = 0; k < 2 * kSlabRows * 256 / 1024; ++k) cnt[tid + 1024 * k] = 0;
+            __syncthreads();
+            first = false;
+        }
+        if (n > 0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int cell = hist_cell<float>(px[u], py[u], pz[u]);          // ((bin * 256 + row) * 256 + column) of the sample's output, -1 = outside
+                const int row = (cell >> 8) & 255;
+                if (i0 + tid + 1024 * u < n && cell >= 0 && (row / kSlabRows) == slab)
+                    atomicAdd(&cnt[((cell >> 16) * kSlabRows + (row % kSlabRows)) * 256 + (cell & 255)], 1);
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 2 * kSlabRows * 256 / 4 / 1024; ++k) {
+        const int q = tid + 1024 * k;                       // float4 index inside the slab: [bin][row][64 float4]
+        const int bin = q / (kSlabRows * 64), r = (q / 64) % kSlabRows, c4 = q % 64;
+        const int* c = cnt + q * 4;
+        const float4 v = make_float4((float)(c[0] < 5 ? c[0] : 5) / 5.0f, (float)(c[1] < 5 ? c[1] : 5) / 5.0f, (float)(c[2] < 5 ? c[2] : 5) / 5.0f,
+                                     (float)(c[3] < 5 ? c[3] : 5) / 5.0f);
+        reinterpret_cast<float4*>(out + (((long)b * 2 + bin) * 256 + slab * kSlabRows + r) * 256)[c4] = v;
+    }
+}
+inline bool hist_slab_on() {
+    static const bool on = [] { const char* e = getenv("TF_HIST_SLAB"); return !e || atoi(e) != 0; }();      // A/B switch: 0 = global int32 atomics + finishing pass
+    return on;
+}
 }  // namespace
 
 extern "C" int tf_relu_mask_f32(const float* dy, const float* y, float* out, int64_t n, void* stream) {
@@ -245,6 +306,11 @@ extern "C" int tf_lidar_hist_f32(const float* points, const int32_t* num_points,
     TF_REQUIRE(points && out && B > 0 && max_points >= 0 && point_stride >= 3, "tf_lidar_hist_f32: bad arguments");
     TF_REQUIRE(aligned16(out), "tf_lidar_hist_f32: out must be 16-byte aligned");
     const long n4 = (long)B * 2 * 256 * 256 / 4;
+    if (hist_slab_on()) {
+        const int vec4 = (point_stride == 4 && aligned16(points)) ? 1 : 0;
+        TF_LAUNCH(lidar_hist_slab_kernel, dim3(8 * cdiv(B, 8) * kSlabs), dim3(1024), stream, points, num_points, B, max_points, point_stride, vec4, out);
+        return launch_status("tf_lidar_hist_f32");
+    }
     TF_LAUNCH(hist_clear_kernel, dim3(cdiv(n4, 256)), dim3(256), stream, reinterpret_cast<float4*>(out), n4);
     if (max_points > 0) {
         const int vec4 = (point_stride == 4 && aligned16(points)) ? 1 : 0;
@@ -260,6 +326,11 @@ extern "C" int tf_lidar_hist_ws_f32(const float* points, const int32_t* num_poin
     TF_REQUIRE(points && out && zero_ws && B > 0 && max_points >= 0 && point_stride >= 3, "tf_lidar_hist_ws_f32: bad arguments");
     TF_REQUIRE(aligned16(out) && aligned16(zero_ws), "tf_lidar_hist_ws_f32: out / workspace must be 16-byte aligned");
     const long n4 = (long)B * 2 * 256 * 256 / 4;
+    if (hist_slab_on()) {       // one launch, counters in LDS: the workspace is not touched (it stays all zero)
+        const int vec4 = (point_stride == 4 && aligned16(points)) ? 1 : 0;
+        TF_LAUNCH(lidar_hist_slab_kernel, dim3(8 * cdiv(B, 8) * kSlabs), dim3(1024), stream, points, num_points, B, max_points, point_stride, vec4, out);
+        return launch_status("tf_lidar_hist_ws_f32");
+    }
     if (max_points > 0) {
         const int vec4 = (point_stride == 4 && aligned16(points)) ? 1 : 0;
         TF_LAUNCH(lidar_hist_count_kernel, dim3(cdiv(max_points, 256), B), dim3(256), stream, points, num_points, max_points, point_stride, vec4,
