@@ -71,7 +71,10 @@ __device__ __forceinline__ void store_patch_slot(float* patch, int s, const floa
 }
 
 // y = conv3x3(x, W) (+bias) (relu) (+= when accumulate).  dgrad != 0: x is dY (Ci = W's Cout), y is dX (Co = W's Cin).
-template <bool VEC, int PREC>
+// TRN (round 6, PREC 0 only): the weight panel is the MFMA's A operand and the patch its B operand, i.e. the wave computes the TRANSPOSED tile (rows = output
+// channels, columns = its 32 pixels): a lane then owns 16 channels of ONE pixel as four groups of four consecutive channels - four 16-byte stores per
+// lane and tile instead of sixteen 4-byte ones (in the grouped kernels that form was 8 of 38 us, csrc/conv_grouped.cpp).  Needs Co % 4 == 0 and 16-byte aligned y / bias.
+template <bool VEC, int PREC, bool TRN = false>
 __global__ void __launch_bounds__(256, 2) conv3x3_small_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                                float* __restrict__ y, DcGeom g, int CoW, int CiW, int dgrad, int relu, int accumulate) {
     __shared__ float patch[PH * PW * PP];
@@ -119,11 +122,30 @@ __global__ void __launch_bounds__(256, 2) conv3x3_small_kernel(const float* __re
             const int kh = tap / 3, kw = tap - kh * 3;
             const float* pa = patch + ((wave + kh) * PW + l31 + kw) * PP + hi;
             const float* pb = &wl[tap * 32 + hi][l31];
-            for (int kk = 0; kk < kpairs; ++kk) mfma_32x32x2(pa[2 * kk], pb[2 * kk * WP], acc);
+            for (int kk = 0; kk < kpairs; ++kk) {
+                if constexpr (TRN) mfma_32x32x2(pb[2 * kk * WP], pa[2 * kk], acc);      // D[i = channel][j = pixel]
+                else mfma_32x32x2(pa[2 * kk], pb[2 * kk * WP], acc);
+            }
         }
         }
         const int b = tile / (g.tiles_h * g.tiles_w), r = tile - b * (g.tiles_h * g.tiles_w);
         const int h = (r / g.tiles_w) * TH + wave, w0 = (r % g.tiles_w) * TW;
+        if constexpr (TRN) {
+            if (h < g.H && w0 + l31 < g.W) {                       // this lane's pixel; channels 8 q + 4 hi .. + 3 = accumulator elements 4 q .. 4 q + 3
+                float* dst = y + (((long)b * g.H + h) * g.W + w0 + l31) * g.Co + 4 * hi;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (8 * q + 4 * hi < g.Co) {
+                        float4 v = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+                        if (bias) { const float4 bj = *reinterpret_cast<const float4*>(bias + 8 * q + 4 * hi); v.x += bj.x; v.y += bj.y; v.z += bj.z; v.w += bj.w; }
+                        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                        float4* d4 = reinterpret_cast<float4*>(dst + 8 * q);
+                        if (accumulate) { const float4 o = *d4; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                        *d4 = v;
+                    }
+                }
+            }
+        } else
         if (h < g.H && l31 < g.Co) {
             const float bj = bias ? bias[l31] : 0.f;
 #pragma unroll
@@ -356,6 +378,12 @@ inline int direct_prec() {
     return (p == 2 && !x3) ? 0 : (p == 3 ? 1 : p);      // fp16 mode runs the PREC 1 instantiations with DcGeom.f16 set
 }
 
+// transposed-tile form of the fp32 forward / input gradient (conv3x3_small_kernel<.., TRN>): TF_SMALL_TRN=0 switches it off (A/B)
+inline bool trn_ok(int Co, const float* y, const float* bias) {
+    static const bool on = [] { const char* e = getenv("TF_SMALL_TRN"); return !e || atoi(e) != 0; }();
+    return on && Co % 4 == 0 && aligned16(y) && (!bias || aligned16(bias));
+}
+
 inline bool presplit_enabled() { static const bool on = [] { const char* e = getenv("TF_X3_PRESPLIT"); return !e || atoi(e) != 0; }(); return on; }
 
 inline DcGeom make_geom(int B, int H, int W, int Ci, int Co) {
@@ -380,6 +408,7 @@ extern "C" int tf_conv3x3_small_fwd_f32(const float* x, const float* w, const fl
     }
     if (prec == 2) { if (vec) TF_LAUNCH((conv3x3_small_kernel<true, 2>), dim3(grid), dim3(256), stream, x, w, bias, y, g, Cout, Cin, 0, relu, 0); else TF_LAUNCH((conv3x3_small_kernel<false, 2>), dim3(grid), dim3(256), stream, x, w, bias, y, g, Cout, Cin, 0, relu, 0); }
     else if (prec == 1) { if (vec) TF_LAUNCH((conv3x3_small_kernel<true, 1>), dim3(grid), dim3(256), stream, x, w, bias, y, g, Cout, Cin, 0, relu, 0); else TF_LAUNCH((conv3x3_small_kernel<false, 1>), dim3(grid), dim3(256), stream, x, w, bias, y, g, Cout, Cin, 0, relu, 0); }
+    else if (vec && trn_ok(Cout, y, bias)) TF_LAUNCH((conv3x3_small_kernel<true, 0, true>), dim3(grid), dim3(256), stream, x, w, bias, y, g, Cout, Cin, 0, relu, 0);
     else { if (vec) TF_LAUNCH((conv3x3_small_kernel<true, 0>), dim3(grid), dim3(256), stream, x, w, bias, y, g, Cout, Cin, 0, relu, 0); else TF_LAUNCH((conv3x3_small_kernel<false, 0>), dim3(grid), dim3(256), stream, x, w, bias, y, g, Cout, Cin, 0, relu, 0); }
     return launch_status("tf_conv3x3_small_fwd_f32");
 }
@@ -400,6 +429,7 @@ extern "C" int tf_conv3x3_small_dgrad_f32(const float* dy, const float* w, float
     }
     if (prec == 2) { if (vec) TF_LAUNCH((conv3x3_small_kernel<true, 2>), dim3(grid), dim3(256), stream, dy, w, nob, dx, g, Cout, Cin, 1, 0, accumulate); else TF_LAUNCH((conv3x3_small_kernel<false, 2>), dim3(grid), dim3(256), stream, dy, w, nob, dx, g, Cout, Cin, 1, 0, accumulate); }
     else if (prec == 1) { if (vec) TF_LAUNCH((conv3x3_small_kernel<true, 1>), dim3(grid), dim3(256), stream, dy, w, nob, dx, g, Cout, Cin, 1, 0, accumulate); else TF_LAUNCH((conv3x3_small_kernel<false, 1>), dim3(grid), dim3(256), stream, dy, w, nob, dx, g, Cout, Cin, 1, 0, accumulate); }
+    else if (vec && trn_ok(Cin, dx, nob)) TF_LAUNCH((conv3x3_small_kernel<true, 0, true>), dim3(grid), dim3(256), stream, dy, w, nob, dx, g, Cout, Cin, 1, 0, accumulate);
     else { if (vec) TF_LAUNCH((conv3x3_small_kernel<true, 0>), dim3(grid), dim3(256), stream, dy, w, nob, dx, g, Cout, Cin, 1, 0, accumulate); else TF_LAUNCH((conv3x3_small_kernel<false, 0>), dim3(grid), dim3(256), stream, dy, w, nob, dx, g, Cout, Cin, 1, 0, accumulate); }
     return launch_status("tf_conv3x3_small_dgrad_f32");
 }

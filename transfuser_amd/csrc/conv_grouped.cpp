@@ -12,6 +12,7 @@
 // waves through LDS and over a group's blocks by a second tiny kernel (deterministic, no atomics).
 #include "tf_common.h"
 #include <stdlib.h>
+#include <type_traits>
 #include "../../include/transfuser_hip.h"
 
 using namespace tf;
@@ -23,7 +24,7 @@ constexpr int CG = 24;              // channels per group (in and out)
 constexpr int PP = 25;              // floats per patch pixel: 24 channels + 1 (odd pitch: conflict-free MFMA A fetch)
 constexpr int WP = 36;              // pitch of a weight row (32 output columns + 4)
 
-struct GcGeom { int B, H, W, C, G, tiles_h, tiles_w, ntiles, nb, f16; };   // f16: the bf16 paths use IEEE-half operands instead (tf_set_precision(3))   // C = total channels (pixel stride), nb = blocks per group
+struct GcGeom { int B, H, W, C, G, tiles_h, tiles_w, ntiles, nb, f16, dbg; };   // f16: the bf16 paths use IEEE-half operands instead (tf_set_precision(3))   // C = total channels (pixel stride), nb = blocks per group
 
 // an integer the optimiser may not treat as loop-invariant: index arithmetic derived from it is RE-COMPUTED where it is used instead of being hoisted
 // out of the tile loop into a dozen long-lived registers (round 6: the seven-wave weight gradient needs <= 80 VGPRs without spills)
@@ -40,6 +41,11 @@ template <int TW> struct Tile {
     static constexpr int PH = TH + 2, PW = TW + 2;
     static constexpr int NPIX = PH * PW;
     static constexpr int NV = (NPIX * 6 + 255) / 256;   // float4 patch slots per thread (6 per pixel)
+};
+
+template <int TW> struct Tile2 {
+    static constexpr int RW = 32 / TW, TH = 4 * RW;
+    static constexpr int PH = 2 * TH + 1, PW = 2 * TW + 1, NPIX = PH * PW;
 };
 
 // group panel -> LDS as wl[tap * CG + k][n] (n < 32 zero padded):  fwd   wl[tap][ci][co] = W[g*CG + co][tap][ci]
@@ -99,7 +105,12 @@ __device__ __forceinline__ void stage_group_coef(float* cf, const float* __restr
 // STAT: the forward also produces the BatchNorm statistics of its output (timm ConvBnAct: conv2 is followed by BatchNormAct2d): every wave
 // keeps a running Welford triple (n, mean, M2) per channel over the tiles it computes, the block's 4 waves are merged through LDS at
 // the end and ONE triple per (block, channel) goes to stat[(sub * 3 + {0,1,2}) * C + channel] - plain stores, nb parts per channel.
-template <int TW, bool X3 = false, bool STAT = false>
+// F32T (round 6) = the exact-fp32 instantiation with the TRANSPOSED accumulator: the MFMA takes the weight panel as its A operand (i = output channel) and
+// the patch as B (j = pixel), so a lane ends up with 12 output channels of ONE pixel in three groups of four consecutive channels - three
+// 16-byte stores per lane and tile instead of sixteen 4-byte ones.  (tools/grouped_lab.py with TF_GC_DBG: at (10, 16, 44, 576) the 16 scalar stores were
+// 8 us of a 37.7 us launch, MFMA 22, everything else 8 - and nothing overlaps, the blocks of a CU run in lockstep.)  The statistics of that layout: every
+// lane of a half keeps the running Welford triple of its 12 channels, fed per tile with the count / mean / M2 over the wave's 32 pixels (half_sum).
+template <int TW, bool X3 = false, bool STAT = false, bool F32T = false>
 __global__ void __launch_bounds__(256, 2) conv3x3_grouped_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                                  float* __restrict__ y, GcGeom g, int dgrad, int relu, int accumulate, int prec,
                                                                  float* __restrict__ stat = nullptr, const float* __restrict__ in_coef = nullptr) {
@@ -131,6 +142,9 @@ __global__ void __launch_bounds__(256, 2) conv3x3_grouped_kernel(const float* __
     // this lane's pixel inside the wave's 32: (row, col) of the tile
     const int prow = wave * T::RW + l31 / TW, pcol = l31 % TW;
     float st_n = 0.f, st_mean = 0.f, st_m2 = 0.f;      // STAT: running triple of channel l31 over this wave's pixels (same in both lane halves)
+    float tn = 0.f, tmean[F32T && STAT ? 12 : 1], tm2[F32T && STAT ? 12 : 1];      // F32T + STAT: this lane's triples of channels (e & 3) + 8 (e >> 2) + 4 hi, e < 12
+#pragma unroll
+    for (int e = 0; e < (F32T && STAT ? 12 : 1); ++e) { tmean[e] = 0.f; tm2[e] = 0.f; }
     for (; tile < g.ntiles; tile += g.nb) {
         __syncthreads();                           // previous tile's MFMAs are done with the patch (and the weights / coefficients are staged)
         if (in_coef) {
@@ -142,11 +156,11 @@ __global__ void __launch_bounds__(256, 2) conv3x3_grouped_kernel(const float* __
         }
         __syncthreads();
         const int nxt = tile + g.nb;
-        if (nxt < g.ntiles) fetch(nxt);            // next patch travels while this one is multiplied
+        if (nxt < g.ntiles && !(g.dbg & 4)) fetch(nxt);            // next patch travels while this one is multiplied
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        if (X3 || prec) {
+        if (!F32T && (X3 || prec)) {
             // bf16 MFMA (tf_set_precision(1); X3: bf16x3 split): per tap two 16-deep groups over the 24 (zero-padded to 32) input channels; lane half hi
             // owns channels 16 q + 8 hi .. + 7, so the upper half of the second group is all zeros
 #pragma unroll
@@ -167,50 +181,68 @@ __global__ void __launch_bounds__(256, 2) conv3x3_grouped_kernel(const float* __
                 }
             }
         } else if constexpr (!X3) {
-            // round 6: the NEXT tap's 24 operand reads are issued before the current tap's 12 MFMAs (scheduling fences keep hipcc from sinking every
-            // read to just in front of its MFMA: "read, wait for the LDS round trip, two MFMAs" left the three waves of a SIMD ~50 % MFMA-busy)
-            const float* pa0 = patch + (prow * T::PW + pcol) * PP + hi;
-            const float* pb0 = &wl[hi][l31];
-            auto ldtap = [&](int tap, float (&a)[CG / 2], float (&b)[CG / 2]) {
-                const float* pa = pa0 + ((tap / 3) * T::PW + tap % 3) * PP;
-                const float* pb = pb0 + tap * CG * WP;
+            if (!(g.dbg & 1))
 #pragma unroll
-                for (int kk = 0; kk < CG / 2; ++kk) { a[kk] = pa[2 * kk]; b[kk] = pb[2 * kk * WP]; }
-            };
-            float a0[CG / 2], b0[CG / 2], a1[CG / 2], b1[CG / 2];
-            ldtap(0, a0, b0);
+            for (int tap = 0; tap < 9; ++tap) {
+                const int kh = tap / 3, kw = tap - kh * 3;
+                const float* pa = patch + ((prow + kh) * T::PW + pcol + kw) * PP + hi;
+                const float* pb = &wl[tap * CG + hi][l31];
 #pragma unroll
-            for (int tap = 0; tap < 9; tap += 2) {
-                if (tap + 1 < 9) ldtap(tap + 1, a1, b1);
-                TF_SCHED_FENCE();
-#pragma unroll
-                for (int kk = 0; kk < CG / 2; ++kk) mfma_32x32x2(a0[kk], b0[kk], acc);
-                TF_SCHED_FENCE();
-                if (tap + 2 < 9) ldtap(tap + 2, a0, b0);
-                TF_SCHED_FENCE();
-                if (tap + 1 < 9) {
-#pragma unroll
-                    for (int kk = 0; kk < CG / 2; ++kk) mfma_32x32x2(a1[kk], b1[kk], acc);
+                for (int kk = 0; kk < CG / 2; ++kk) {
+                    if constexpr (F32T) mfma_32x32x2(pb[2 * kk * WP], pa[2 * kk], acc);      // D[i = co][j = pixel]
+                    else mfma_32x32x2(pa[2 * kk], pb[2 * kk * WP], acc);                     // D[i = pixel][j = co]
                 }
-                TF_SCHED_FENCE();
             }
         }
         const int b = tile / (g.tiles_h * g.tiles_w), r = tile - b * (g.tiles_h * g.tiles_w);
         const int h0 = (r / g.tiles_w) * T::TH, w0 = (r % g.tiles_w) * TW;
-        if (l31 < CG) {
-            const float bj = bias ? bias[coff + l31] : 0.f;
+        if constexpr (F32T) {
+            const int hh = h0 + prow, ww = w0 + pcol;                    // this lane's pixel
+            const bool pok = hh < g.H && ww < g.W;
+            if (pok && !(g.dbg & 2)) {
+                float* dst = y + (((long)b * g.H + hh) * g.W + ww) * g.C + coff + 4 * hi;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int i = (e & 3) + 8 * (e >> 2) + 4 * hi;           // pixel index inside the wave's 32
-                const int hh = h0 + wave * T::RW + i / TW, ww = w0 + i % TW;
-                if (hh < g.H && ww < g.W) {
-                    float* dst = y + (((long)b * g.H + hh) * g.W + ww) * g.C + coff + l31;
-                    float v = acc[e] + bj;
-                    if (relu) v = fmaxf(v, 0.f);
-                    *dst = accumulate ? *dst + v : v;
+                for (int q = 0; q < 3; ++q) {                            // channels 8 q + 4 hi .. + 3 = accumulator elements 4 q .. 4 q + 3
+                    float4 v = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+                    if (bias) { const float4 bj = *reinterpret_cast<const float4*>(bias + coff + 8 * q + 4 * hi); v.x += bj.x; v.y += bj.y; v.z += bj.z; v.w += bj.w; }
+                    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    float4* d4 = reinterpret_cast<float4*>(dst + 8 * q);
+                    if (accumulate) { const float4 o = *d4; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                    *d4 = v;
                 }
             }
-        }
+            if constexpr (STAT) {
+                // the wave's 32 pixels of this tile as ONE sample group per channel (as in the pixel-major kernel): count, mean and M2 about that mean over the
+                // 32 lanes of the half (half_sum: four DPP adds + one 16-lane exchange per value), Chan-merged into the running triple every lane of the half keeps identically
+                const float cnt = half_sum(pok ? 1.f : 0.f);
+                if (cnt > 0.f) {                                         // (uniform over the half)
+                    const float inv = 1.f / cnt, n_new = tn + cnt, wb = cnt / n_new, wab = tn * cnt / n_new;
+#pragma unroll
+                    for (int e = 0; e < 12; ++e) {
+                        const float m_t = half_sum(pok ? acc[e] : 0.f) * inv, d0 = acc[e] - m_t;
+                        const float q = half_sum(pok ? d0 * d0 : 0.f);
+                        const float delta = m_t - tmean[e];
+                        tmean[e] += delta * wb;
+                        tm2[e] += q + delta * delta * wab;
+                    }
+                    tn = n_new;
+                }
+            }
+        } else {
+        if (l31 < CG && !(g.dbg & 2)) {
+                const float bj = bias ? bias[coff + l31] : 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int i = (e & 3) + 8 * (e >> 2) + 4 * hi;           // pixel index inside the wave's 32
+                    const int hh = h0 + wave * T::RW + i / TW, ww = w0 + i % TW;
+                    if (hh < g.H && ww < g.W) {
+                        float* dst = y + (((long)b * g.H + hh) * g.W + ww) * g.C + coff + l31;
+                        float v = acc[e] + bj;
+                        if (relu) v = fmaxf(v, 0.f);
+                        *dst = accumulate ? *dst + v : v;
+                    }
+                }
+            }
         if constexpr (STAT) {       // all 64 lanes take part in the shuffles; the padding columns (l31 >= 24) carry zeros and are never stored
             float s = 0.f, cnt = 0.f;
 #pragma unroll
@@ -239,10 +271,21 @@ __global__ void __launch_bounds__(256, 2) conv3x3_grouped_kernel(const float* __
                 st_n = n_new;
             }
         }
+        }   // (F32T / plain epilogue)
     }
     if constexpr (STAT) {
         __syncthreads();                                                 // every wave is done with the patch: its memory carries the 4 triples
         float* red = patch;                                              // [wave][3][32]
+        if constexpr (F32T) {
+            // every lane of a half holds the wave's running triple of its 12 channels
+            if (l31 == 0) {
+#pragma unroll
+                for (int e = 0; e < 12; ++e) {
+                    const int co = (e & 3) + 8 * (e >> 2) + 4 * hi;
+                    red[(wave * 3 + 0) * 32 + co] = tn; red[(wave * 3 + 1) * 32 + co] = tmean[e]; red[(wave * 3 + 2) * 32 + co] = tm2[e];
+                }
+            }
+        } else
         if (hi == 0) { red[(wave * 3 + 0) * 32 + l31] = st_n; red[(wave * 3 + 1) * 32 + l31] = st_mean; red[(wave * 3 + 2) * 32 + l31] = st_m2; }
         __syncthreads();
         if (tid < CG) {
@@ -385,10 +428,13 @@ __global__ void __launch_bounds__(192) conv3x3_grouped_wgrad_kernel(const float*
 // The block's (24 x 216) panel is ADDED to dW with fp32 atomics (64 lanes = two rows x 32 consecutive floats per instruction): no partial-panel
 // workspace (36 KB written and read back per block before: 3.45x the algorithmic traffic), no reduce launch.  Like the k-split GEMM weight
 // gradients the sum order over a group's blocks is not fixed (run-to-run differences at fp32 round-off); accumulate = 0 zero-fills dW first.
-template <int TW>
-__global__ void __launch_bounds__(448, 6) conv3x3_grouped_wgrad7_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw, GcGeom g,
-                                                                     const float* __restrict__ in_coef) {
-    typedef Tile<TW> T;
+// S2: the stride-2 convolution of a stage's first block - tiles over the OUTPUT grid (Ho x Wo, g.H / g.W = the input extent), the staged patch is Tile2's
+// (2 TH + 1) x (2 TW + 1) input pixels and output pixel (i, j), tap (kh, kw) reads patch pixel (2 i + kh, 2 j + kw): every pixel offset below doubles.
+template <int TW, bool S2 = false>
+__global__ void __launch_bounds__(448, S2 ? 3 : 6) conv3x3_grouped_wgrad7_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw, GcGeom g,
+                                                                              const float* __restrict__ in_coef, int Ho, int Wo) {
+    typedef typename std::conditional<S2, Tile2<TW>, Tile<TW> >::type T;
+    constexpr int SS = S2 ? 2 : 1;
     constexpr int NT = 448;
     constexpr int NVP = (T::NPIX * 6 + NT - 1) / NT, ND = (128 * 6 + NT - 1) / NT;     // float4 slots per thread: patch, dY (6 per pixel)
     __shared__ float lds[T::NPIX * PP + 128 * PP + 8];
@@ -399,7 +445,7 @@ __global__ void __launch_bounds__(448, 6) conv3x3_grouped_wgrad7_kernel(const fl
     const int grp = blockIdx.x / g.nb, sub = blockIdx.x - grp * g.nb, coff = grp * CG;
     // this lane's im2col column: tap (kh, kw) and input channel; the eight columns 216..223 of wave 6 read tap 8 again (in-bounds) and are never stored
     const int col = 32 * wave + l31, tapc = col / CG < 9 ? col / CG : 8, ci = col - (col / CG) * CG;
-    const int boff = ((tapc / 3) * T::PW + (tapc % 3)) * PP + ci + hi * PP;       // + the k-step's pixel (2 kk + hi): hi moves one pixel to the right (TW is even)
+    const int boff = ((tapc / 3) * T::PW + (tapc % 3)) * PP + ci + hi * SS * PP;       // + the k-step's pixel (2 kk + hi): hi moves one output pixel to the right (TW is even)
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -413,7 +459,7 @@ __global__ void __launch_bounds__(448, 6) conv3x3_grouped_wgrad7_kernel(const fl
 #pragma unroll
         for (int p = 0; p < NVP; ++p) {
             const int s = tq + p * NT, pix = s / 6, c = (s - pix * 6) * 4;
-            const int ph = pix / T::PW, pw = pix - ph * T::PW, h = h0 - 1 + ph, w = w0 - 1 + pw;
+            const int ph = pix / T::PW, pw = pix - ph * T::PW, h = SS * h0 - 1 + ph, w = SS * w0 - 1 + pw;
             const bool ok = pix < T::NPIX && (unsigned)h < (unsigned)g.H && (unsigned)w < (unsigned)g.W;
             const int hc = h < 0 ? 0 : (h >= g.H ? g.H - 1 : h), wc = w < 0 ? 0 : (w >= g.W ? g.W - 1 : w);
             const float4 v = *reinterpret_cast<const float4*>(x + (((long)b * g.H + hc) * g.W + wc) * g.C + coff + c);
@@ -424,9 +470,9 @@ __global__ void __launch_bounds__(448, 6) conv3x3_grouped_wgrad7_kernel(const fl
         for (int p = 0; p < ND; ++p) {
             const int s = tq + p * NT, pix = s / 6, c = (s - pix * 6) * 4;
             const int h = h0 + pix / TW, w = w0 + pix % TW;
-            const bool ok = pix < 128 && h < g.H && w < g.W;
-            const int hc = h >= g.H ? g.H - 1 : h, wc = w >= g.W ? g.W - 1 : w;
-            const float4 v = *reinterpret_cast<const float4*>(dy + (((long)b * g.H + hc) * g.W + wc) * g.C + coff + c);
+            const bool ok = pix < 128 && h < Ho && w < Wo;
+            const int hc = h >= Ho ? Ho - 1 : h, wc = w >= Wo ? Wo - 1 : w;
+            const float4 v = *reinterpret_cast<const float4*>(dy + (((long)b * Ho + hc) * Wo + wc) * g.C + coff + c);
             dpre[p] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
@@ -456,7 +502,7 @@ __global__ void __launch_bounds__(448, 6) conv3x3_grouped_wgrad7_kernel(const fl
         // the tile's 64 k-steps (k = pixel 2 kk + hi) in eight chunks of eight: the NEXT chunk's sixteen operand reads are issued before the current
         // chunk's eight MFMAs, so a wave never sits out an LDS round trip between two MFMAs (one accumulator chain per wave: nothing else to issue)
         auto kofs_a = [](int kk) { return 2 * kk * PP; };
-        auto kofs_b = [](int kk) { return (((2 * kk) / TW) * T::PW + (2 * kk) % TW) * PP; };
+        auto kofs_b = [](int kk) { return (((2 * kk) / TW) * T::PW + (2 * kk) % TW) * SS * PP; };
         float a0[8], b0[8], a1[8], b1[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) { a0[u] = pa[kofs_a(u)]; b0[u] = pb[kofs_b(u)]; }
@@ -609,10 +655,6 @@ __global__ void __launch_bounds__(256, 2) conv3x3_grouped_s2_dgrad_kernel(const 
 // (2 TH + 1) x (2 TW + 1) pixels (56 KB; with the weight panel 87 KB of LDS: one block per CU, the next patch travels in registers meanwhile);
 // output pixel (i, j), tap (kh, kw) reads patch pixel (2 i + kh, 2 j + kw).  Through the implicit-GEMM engine these 16 launches per step ran at
 // 6-34 TFLOP/s (profiles/r04_census_fp32_final.txt).  OPT-IN (ops: TF_GROUPED_S2=1) until measured on the MI355X.
-template <int TW> struct Tile2 {
-    static constexpr int RW = 32 / TW, TH = 4 * RW;
-    static constexpr int PH = 2 * TH + 1, PW = 2 * TW + 1, NPIX = PH * PW;
-};
 
 template <int TW, bool STAT>
 __global__ void __launch_bounds__(256, 1) conv3x3_grouped_s2_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, GcGeom g, int Ho,
@@ -882,8 +924,14 @@ inline int fwd_prec() {
     return (p == 2 && !x3) ? 0 : p;
 }
 
+inline bool f32t_on() {        // A/B switch: TF_GROUPED_F32T=0 keeps the fp32 forward / input gradient on the pixel-major accumulator (16 scalar stores per lane)
+    static const bool on = [] { const char* e = getenv("TF_GROUPED_F32T"); return !e || atoi(e) != 0; }();
+    return on;
+}
 inline GcGeom make_geom(int B, int H, int W, int C, int TW, int max_blocks = kMaxBlocks) {
     GcGeom g; g.B = B; g.H = H; g.W = W; g.C = C; g.G = C / CG; g.f16 = tf::gemm_precision() == 3 ? 1 : 0;
+    static const int dbg = [] { const char* e = getenv("TF_GC_DBG"); return e ? atoi(e) : 0; }();      // timing diagnosis only (tools/grouped_lab.py): phases of the forward kernel switched off, results are garbage
+    g.dbg = dbg;
     const int th = TW == 16 ? 8 : 4;
     g.tiles_h = cdiv(H, th); g.tiles_w = cdiv(W, TW); g.ntiles = B * g.tiles_h * g.tiles_w;
     int nb = max_blocks / g.G;
@@ -911,6 +959,9 @@ extern "C" int tf_conv3x3_grouped_fwd_f32(const float* x, const float* w, const 
     if (prec == 2) {
         if (tw == 16) TF_LAUNCH((conv3x3_grouped_kernel<16, true>), dim3(g.G * g.nb), dim3(256), stream, x, w, bias, y, g, 0, relu, 0, 2, (float*)nullptr);
         else TF_LAUNCH((conv3x3_grouped_kernel<32, true>), dim3(g.G * g.nb), dim3(256), stream, x, w, bias, y, g, 0, relu, 0, 2, (float*)nullptr);
+    } else if (prec == 0 && f32t_on()) {        // exact fp32: the transposed-accumulator instantiation (16-byte stores)
+        if (tw == 16) TF_LAUNCH((conv3x3_grouped_kernel<16, false, false, true>), dim3(g.G * g.nb), dim3(256), stream, x, w, bias, y, g, 0, relu, 0, 0, (float*)nullptr);
+        else TF_LAUNCH((conv3x3_grouped_kernel<32, false, false, true>), dim3(g.G * g.nb), dim3(256), stream, x, w, bias, y, g, 0, relu, 0, 0, (float*)nullptr);
     } else if (tw == 16) TF_LAUNCH((conv3x3_grouped_kernel<16, false>), dim3(g.G * g.nb), dim3(256), stream, x, w, bias, y, g, 0, relu, 0, prec, (float*)nullptr);
     else TF_LAUNCH((conv3x3_grouped_kernel<32, false>), dim3(g.G * g.nb), dim3(256), stream, x, w, bias, y, g, 0, relu, 0, prec, (float*)nullptr);
     return launch_status("tf_conv3x3_grouped_fwd_f32");
@@ -928,6 +979,9 @@ static int grouped_fwd_colstat(const char* what, const float* x, const float* in
     if (prec == 2) {
         if (tw == 16) TF_LAUNCH((conv3x3_grouped_kernel<16, true, true>), dim3(g.G * g.nb), dim3(256), stream, x, w, nob, y, g, 0, 0, 0, 2, colstat, in_coef);
         else TF_LAUNCH((conv3x3_grouped_kernel<32, true, true>), dim3(g.G * g.nb), dim3(256), stream, x, w, nob, y, g, 0, 0, 0, 2, colstat, in_coef);
+    } else if (prec == 0 && f32t_on()) {
+        if (tw == 16) TF_LAUNCH((conv3x3_grouped_kernel<16, false, true, true>), dim3(g.G * g.nb), dim3(256), stream, x, w, nob, y, g, 0, 0, 0, 0, colstat, in_coef);
+        else TF_LAUNCH((conv3x3_grouped_kernel<32, false, true, true>), dim3(g.G * g.nb), dim3(256), stream, x, w, nob, y, g, 0, 0, 0, 0, colstat, in_coef);
     } else if (tw == 16) TF_LAUNCH((conv3x3_grouped_kernel<16, false, true>), dim3(g.G * g.nb), dim3(256), stream, x, w, nob, y, g, 0, 0, 0, prec, colstat, in_coef);
     else TF_LAUNCH((conv3x3_grouped_kernel<32, false, true>), dim3(g.G * g.nb), dim3(256), stream, x, w, nob, y, g, 0, 0, 0, prec, colstat, in_coef);
     return launch_status(what);
@@ -953,6 +1007,9 @@ extern "C" int tf_conv3x3_grouped_dgrad_f32(const float* dy, const float* w, flo
     if (prec == 2) {
         if (tw == 16) TF_LAUNCH((conv3x3_grouped_kernel<16, true>), dim3(g.G * g.nb), dim3(256), stream, dy, w, nob, dx, g, 1, 0, accumulate, 2, (float*)nullptr);
         else TF_LAUNCH((conv3x3_grouped_kernel<32, true>), dim3(g.G * g.nb), dim3(256), stream, dy, w, nob, dx, g, 1, 0, accumulate, 2, (float*)nullptr);
+    } else if (prec == 0 && f32t_on()) {
+        if (tw == 16) TF_LAUNCH((conv3x3_grouped_kernel<16, false, false, true>), dim3(g.G * g.nb), dim3(256), stream, dy, w, nob, dx, g, 1, 0, accumulate, 0, (float*)nullptr);
+        else TF_LAUNCH((conv3x3_grouped_kernel<32, false, false, true>), dim3(g.G * g.nb), dim3(256), stream, dy, w, nob, dx, g, 1, 0, accumulate, 0, (float*)nullptr);
     } else if (tw == 16) TF_LAUNCH((conv3x3_grouped_kernel<16, false>), dim3(g.G * g.nb), dim3(256), stream, dy, w, nob, dx, g, 1, 0, accumulate, prec, (float*)nullptr);
     else TF_LAUNCH((conv3x3_grouped_kernel<32, false>), dim3(g.G * g.nb), dim3(256), stream, dy, w, nob, dx, g, 1, 0, accumulate, prec, (float*)nullptr);
     return launch_status("tf_conv3x3_grouped_dgrad_f32");
@@ -982,8 +1039,8 @@ static int grouped_wgrad(const char* what, const float* dy, const float* x, cons
         if (tpb7 < 2 && g7.ntiles >= 2) tpb7 = 2;
         g7.nb = cdiv(g7.ntiles, tpb7);
         if (!accumulate) TF_LAUNCH(fill_f32_kernel, dim3(cdiv((long)C * 9 * CG, 1024)), dim3(256), stream, dw, (long)C * 9 * CG);
-        if (tw == 16) TF_LAUNCH((conv3x3_grouped_wgrad7_kernel<16>), dim3(g7.G * g7.nb), dim3(448), stream, x, dy, dw, g7, in_coef);
-        else TF_LAUNCH((conv3x3_grouped_wgrad7_kernel<32>), dim3(g7.G * g7.nb), dim3(448), stream, x, dy, dw, g7, in_coef);
+        if (tw == 16) TF_LAUNCH((conv3x3_grouped_wgrad7_kernel<16>), dim3(g7.G * g7.nb), dim3(448), stream, x, dy, dw, g7, in_coef, H, W);
+        else TF_LAUNCH((conv3x3_grouped_wgrad7_kernel<32>), dim3(g7.G * g7.nb), dim3(448), stream, x, dy, dw, g7, in_coef, H, W);
         return launch_status(what);
     }
 #define TF_GW(TW_, P_) TF_LAUNCH((conv3x3_grouped_wgrad_kernel<TW_, P_>), dim3(g.G * g.nb), dim3(192), stream, x, dy, ws, g, in_coef)
@@ -1035,6 +1092,18 @@ extern "C" int tf_conv3x3_grouped_s2_wgrad_f32(const float* dy, const float* x, 
     TF_REQUIRE(g.nb >= 1, "tf_conv3x3_grouped_s2_wgrad_f32: %d groups exceed the workspace", g.G);
     g.H = Hi; g.W = Wi;
     const int prec = direct_prec();
+    static const int v7 = [] { const char* e = getenv("TF_GROUPED_WGRAD7"); return e ? atoi(e) : 1; }();
+    if (prec == 0 && v7) {      // seven-wave form (69 - 72 KB of LDS: two blocks per CU), atomically accumulated: see grouped_wgrad
+        GcGeom g7 = make_geom(B, Ho, Wo, C, tw, 512);
+        int tpb7 = cdiv(g7.ntiles, g7.nb);
+        if (tpb7 < 2 && g7.ntiles >= 2) tpb7 = 2;
+        g7.nb = cdiv(g7.ntiles, tpb7);
+        g7.H = Hi; g7.W = Wi;
+        if (!accumulate) TF_LAUNCH(fill_f32_kernel, dim3(cdiv((long)C * 9 * CG, 1024)), dim3(256), stream, dw, (long)C * 9 * CG);
+        if (tw == 16) TF_LAUNCH((conv3x3_grouped_wgrad7_kernel<16, true>), dim3(g7.G * g7.nb), dim3(448), stream, x, dy, dw, g7, in_coef, Ho, Wo);
+        else TF_LAUNCH((conv3x3_grouped_wgrad7_kernel<32, true>), dim3(g7.G * g7.nb), dim3(448), stream, x, dy, dw, g7, in_coef, Ho, Wo);
+        return launch_status("tf_conv3x3_grouped_s2_wgrad_f32");
+    }
 #define TF_GW2(TW_, P_) TF_LAUNCH((conv3x3_grouped_s2_wgrad_kernel<TW_, P_>), dim3(g.G * g.nb), dim3(192), stream, x, dy, ws, g, Ho, Wo, in_coef)
     if (tw == 16) { if (prec == 2) TF_GW2(16, 2); else if (prec == 1 || prec == 3) TF_GW2(16, 1); else TF_GW2(16, 0); }
     else { if (prec == 2) TF_GW2(32, 2); else if (prec == 1 || prec == 3) TF_GW2(32, 1); else TF_GW2(32, 0); }

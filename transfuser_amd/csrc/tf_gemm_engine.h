@@ -275,6 +275,7 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[TM][TN], const
     const float* res = ep.res ? ep.res + cz : nullptr;
     const float* bias = ep.bias ? ep.bias + (long)z * ep.sbias : nullptr;
     const bool full = (i0 + BM <= M) && (j0 + BN <= N);
+    if (ep.prec & 0x100) return;
     const uint32_t dseed = ep.drop_seed ? *ep.drop_seed : 0u;
     auto emit = [&](auto mode_c, auto res_c, auto full_c) {
         constexpr int MODE = decltype(mode_c)::value;
@@ -816,6 +817,7 @@ inline CfgGeom cfg_geom(const GemmEpi& ep, int M, int N, int K, int splitk, int 
     c.nsplit = nsplit > 0 ? nsplit : 1;
     c.epg = ep;
     c.epg.prec = gemm_precision();
+    { static const int dbg = [] { const char* e = getenv("TF_GEMM_DBG"); return e ? atoi(e) : 0; }(); c.epg.prec |= dbg << 8; }      // timing diagnosis (tools/pair_lab.py): bit 8 = no epilogue stores, results are garbage
     {
         static const int forced = [] { const char* e = getenv("TF_GROUP_M"); return e ? atoi(e) : 0; }();
         long panel = (long)BM * (kchunk < K ? kchunk : K) * 4;          // bytes of one A panel of this launch

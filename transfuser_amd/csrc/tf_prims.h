@@ -293,6 +293,28 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int m = 32; m >= 1; m >>= 1) v += shfl_xor(v, m);
     return v;
 }
+// Sum over the 32 lanes of a wave HALF (the lanes that share lane >> 5), delivered to every lane of the half.  On the device the first four butterfly
+// steps are DPP adds (quad_perm [1,0,3,2] / [2,3,0,1], row_half_mirror, row_mirror: VALU, no trip through the LDS crossbar) and only the 16-lane
+// exchange is a ds_bpermute; after steps 1..k every group of 2^k lanes is uniform, so the mirrored partner of a lane carries exactly what its xor
+// partner carries and the result is BIT-IDENTICAL to the shfl_xor(1, 2, 4, 8, 16) butterfly the emulator runs.
+#ifdef TF_EMU
+__forceinline__ float half_sum(float v) {
+    for (int m = 1; m <= 16; m <<= 1) v += shfl_xor(v, m);
+    return v;
+}
+#else
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float half_sum(float v) {
+    v += dpp_mov<0xB1>(v);       // quad_perm [1, 0, 3, 2]
+    v += dpp_mov<0x4E>(v);       // quad_perm [2, 3, 0, 1]
+    v += dpp_mov<0x141>(v);      // row_half_mirror
+    v += dpp_mov<0x140>(v);      // row_mirror
+    v += shfl_xor(v, 16);
+    return v;
+}
+#endif
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, shfl_xor(v, m));

@@ -189,8 +189,8 @@ class FlatAdamW:
             return
         gs = getattr(self, "grad_scale", 1.0)
         red = getattr(self, "reducer", None)
-        if red is not None and red.defer_scale and red.world > 1:      # the arena holds the all-reduced SUM: the mean's 1 / world rides on the gradient scale
-            gs = gs / red.world
+        if red is not None:      # defer_scale: the arena holds the all-reduced SUM, the mean's 1 / world rides on the gradient scale (GradReducer.grad_scale)
+            gs = gs * red.grad_scale()
         ops.adamw_(a.params[self.lo:self.hi], a.grads[self.lo:self.hi], self.exp_avg, self.exp_avg_sq, self.state, self.betas[0], self.betas[1],
                    self.eps, self.weight_decay, grad_scale=gs)
 
@@ -283,6 +283,12 @@ class GradReducer:
         self.defer_scale = False       # fp32 buckets: leave the SUM in the arena, the optimizer multiplies by 1 / world (train.Engine sets it when its AdamW can)
         self._wait_events = None       # (before, after) timing events around the optimizer's wait for the side stream: the EXPOSED all-reduce time
         self.time_waits = False        # bench.py --check turns the event pair on
+
+    def grad_scale(self):
+        """The factor that turns the gradient arena (and every ``p.grad`` view of it) into the MEAN gradient after ``train_step``: with ``defer_scale``
+        (fp32 buckets, world > 1, no dynamic loss scale) the arena holds the all-reduced SUM until the optimizer step and FlatAdamW applies 1 / world
+        on its way in - anything ELSE that reads gradients (norm logging / clipping, a user optimizer, a checksum) must multiply by this.  1.0 otherwise."""
+        return 1.0 / self.world if (self.defer_scale and self.world > 1) else 1.0
 
     def broadcast_params(self, src=0):
         """DDP's initial parameter broadcast (rank 0 -> all)."""
