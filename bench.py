@@ -32,7 +32,7 @@ PEAK_F32_MFMA_TF = 157.3                                # /opt/skills/guides/MI3
 PEAK_BF16_MFMA_TF = 2500.0                              # dense bf16 MFMA peak of the same guide (never the 2:1-sparsity figure)
 def _pmc_file(suffix=""):
     """Newest committed rocprofv3 PMC summary of the dominant GEMM (tools/pmc_roofline.sh -> profiles/rNN_pmc_gemm_roofline[_<precision>].json)."""
-    for rnd in ("r05", "r04", "r03", "r02"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02"):
         f = os.path.join(ROOT, "profiles", "%s_pmc_gemm_roofline%s.json" % (rnd, suffix))
         if os.path.exists(f):
             return f
@@ -43,7 +43,7 @@ def _trace_file(suffix="", build_id=None):
     """Newest committed per-kernel summary of a rocprofv3 kernel trace of the graph-replayed bench step (tools/trace_csv_stats.py) that was
     measured ON THIS BUILD: the summary's first line names the library it traced ("# build_id <tf_build_id>", written by tools/gpu_round4.sh
     trace); a summary of another build - or one without that line - is not used (the figure would be stale against this run's FLOPs)."""
-    for name in ("r05_kernel_trace_graph%s.txt", "r04_kernel_trace_graph%s.txt"):
+    for name in ("r06_kernel_trace_graph%s.txt", "r05_kernel_trace_graph%s.txt", "r04_kernel_trace_graph%s.txt"):
         f = os.path.join(ROOT, "profiles", name % suffix)
         if os.path.exists(f):
             try:
@@ -87,6 +87,7 @@ def parse_args():
                     help="DRY RUN of the multi-rank plumbing on a machine without GPUs (tests/test_distributed_cpu.py): tiny trunks, the HIP kernels "
                          "host-emulated (tests/emu), gloo - exercises the self-spawn, the cut / overlapped reducer path, --check and the no-teardown "
                          "exit; its numbers mean nothing and the line says so")
+    ap.add_argument("--cpu-probe", type=int, default=0, help=argparse.SUPPRESS)      # child of cpu_baseline: B = 2 oracle steps on this many threads, prints the median seconds
     ap.add_argument("--watchdog", type=int, default=900, help="dump all Python stacks to stderr if still running after this many seconds")
     return ap.parse_args()
 
@@ -210,8 +211,8 @@ def dominant_kernel_roofline(eng, batch, dev, log, peak=PEAK_F32_MFMA_TF, headli
         except Exception as e:   # a malformed summary must not kill the bench line
             gpt["traffic_source"] = "unreadable %s: %s" % (pmc_file, e)
     # counter traffic of the DOMINANT call: the trunk table (tools/pmc_trunk.sh -> profiles/r05_pmc_trunk.json) when it holds that shape
-    trunk = os.path.join(ROOT, "profiles", "r05_pmc_trunk.json")
-    if ranked and os.path.exists(trunk) and peak == PEAK_F32_MFMA_TF:
+    trunk = next((f for f in (os.path.join(ROOT, "profiles", "%s_pmc_trunk.json" % r) for r in ("r06", "r05")) if os.path.exists(f)), "")
+    if ranked and trunk and peak == PEAK_F32_MFMA_TF:
         try:
             k = ranked[0][0]
             want = {"gemm a0b0": "nt", "gemm a0b1": "nn", "gemm a1b1": "tn", "gemm pair wgrad+dgrad (one grid)": "pair"}.get(k[0])
@@ -220,7 +221,7 @@ def dominant_kernel_roofline(eng, batch, dev, log, peak=PEAK_F32_MFMA_TF, headli
             for row in json.load(open(trunk)):
                 if want and row["case"] == "gemm %s (%d,%d,%d)" % (want, m, n, kk) and row.get("traffic_bytes"):
                     roof["traffic"] = int(row["traffic_bytes"])
-                    roof["traffic_source"] = ("profiles/r05_pmc_trunk.json: 2 x FETCH_SIZE + WRITE_SIZE per call (rocprofv3 --pmc, separate passes, gfx950 correction); "
+                    roof["traffic_source"] = ("profiles/" + os.path.basename(trunk) + ": 2 x FETCH_SIZE + WRITE_SIZE per call (rocprofv3 --pmc, separate passes, gfx950 correction); "
                                               "algorithmic %.1f MB; MFMA busy %.2f" % (row["algorithmic_bytes"] / 1e6, row.get("mfma_busy_frac") or -1))
         except Exception as e:
             roof["traffic_source"] = "unreadable %s: %s" % (trunk, e)
@@ -268,7 +269,7 @@ def hbm_rooflines(eng, batch, dev, log):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(st); g.replay(); e1.record(st); e1.synchronize()
     h1_bytes = 10 * (32768 * 16 + 2 * 256 * 256 * 4)
-    fam["H1 lidar histogram, 10 x 32768 points (16 B / point read + 512 KB / sample written; count + finish launches, the int32 counters in a workspace every call leaves zeroed; hipGraph replay of 20 calls)"] = \
+    fam["H1 lidar histogram, 10 x 32768 points (16 B / point read + 512 KB / sample written, each once: one launch, counters in LDS - lidar_hist_slab_kernel; hipGraph replay of 20 calls)"] = \
         [20, 20 * h1_bytes, e0.elapsed_time(e1) * 1e3, 0.0, (h1_bytes, e0.elapsed_time(e1) * 1e3 / 20)]
     out = []
     for name, (calls, nbytes, us, _, big) in fam.items():
@@ -278,8 +279,22 @@ def hbm_rooflines(eng, batch, dev, log):
                     "frac_of_6.3": round(tbs / ACHIEVABLE_HBM_TBS, 4),
                     "largest_call": {"bytes": int(big[0]), "us": round(big[1], 1), "achieved_TBps": round(btbs, 3), "frac_of_8.0": round(btbs / PEAK_HBM_TBS, 4)}})
     log("in-step HBM census done (%d calls)" % len(rows))
-    return {"bound": "hbm", "peak": PEAK_HBM_TBS, "achievable": ACHIEVABLE_HBM_TBS, "unit": "TB/s", "timing": "HIP events around each call inside one eager training step",
-            "kernels": out}
+    res = {"bound": "hbm", "peak": PEAK_HBM_TBS, "achievable": ACHIEVABLE_HBM_TBS, "unit": "TB/s",
+           "timing": "HIP events around each call inside one EAGER training step: the small calls (LayerNorm, late-stage BatchNorm) carry their host launch gaps, so their "
+                     "TB/s is a launch-gap figure - 'pmc' below holds the counter-based table of the same kernels (kernel time + fabric bytes per call)", "kernels": out}
+    # the counter-based table (tools/pmc_hbm.sh -> profiles/rNN_pmc_hbm.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 correction, per call):
+    # kernel-only time (no launch gaps), fabric-side traffic against the algorithmic bytes
+    pm = next((f for f in (os.path.join(ROOT, "profiles", "%s_pmc_hbm.json" % r) for r in ("r06", "r05", "r04", "r03")) if os.path.exists(f)), "")
+    if pm:
+        try:
+            res["pmc"] = {"source": "profiles/" + os.path.basename(pm),
+                          "kernels": [{"case": r["case"], "algorithmic_bytes": int(r["algorithmic_bytes"]), "traffic_over_algorithmic": round(r["traffic_over_algorithmic"], 3),
+                                       "kernel_us_per_call": round(r["kernel_us_per_call"], 2), "achieved_TBps": round(r["achieved_tbps_algorithmic"], 3),
+                                       "frac_of_8.0": round(r["achieved_tbps_algorithmic"] / PEAK_HBM_TBS, 4), "launches_per_call": r.get("launches_per_call")}
+                                      for r in json.load(open(pm))]}
+        except Exception as e:
+            res["pmc"] = {"error": "unreadable %s: %s" % (pm, e)}
+    return res
 
 
 def replica_check(eng, batch, rank, world, dev, log, cuda=True):
@@ -314,7 +329,36 @@ def replica_check(eng, batch, rank, world, dev, log, cuda=True):
             "backward_pieces": eng.n_pieces(), "grad_dtype": "bf16" if eng.reducer.bf16 else "fp32"}
 
 
-def cpu_baseline(make_cfg, backbone, H, W, budget_s=135.0):
+def cpu_probe(args):
+    """Child process of cpu_baseline: the oracle's B = 2 training step on ``--cpu-probe`` threads (1 warm-up + 3 timed), one line 'CPU_PROBE <median seconds>'.
+    A separate process because a PyTorch-CPU step cannot be interrupted from inside: the parent kills it at its deadline."""
+    import torch
+    from oracle import hist, model_cpu
+    from transfuser_amd.config import GlobalConfig
+    from transfuser_amd.data import synthetic_batch
+    torch.set_num_threads(args.cpu_probe)
+    cfg = GlobalConfig()
+    cfg.n_layer = 4
+    cfg.use_target_point_image = True
+    cfg.embd_pdrop = cfg.attn_pdrop = cfg.resid_pdrop = args.dropout
+    torch.manual_seed(0)
+    ref = model_cpu.LidarCenterNet(cfg, 'cpu', args.backbone, use_velocity=False)
+    ref.train()
+    opt = model_cpu.make_optimizer(ref)
+    H = args.height or (160 if args.backbone == "geometric_fusion" else 256)
+    keys = ("rgb", "lidar", "ego_waypoint", "target_point", "target_point_image", "ego_vel", "bev", "label", "depth", "semantic") + \
+        (("bev_points", "cam_points") if args.backbone == "geometric_fusion" else ())
+    b2 = {k: v for k, v in synthetic_batch(2, H, 704, seed=0, hist_fn=hist.lidar_to_histogram_features, n_points=8192).items() if k in keys}
+    ts = []
+    for i in range(4):
+        t0 = time.time()
+        model_cpu.train_step(ref, opt, b2, cfg)
+        if i:
+            ts.append(time.time() - t0)
+    print("CPU_PROBE %.4f" % sorted(ts)[1], flush=True)
+
+
+def cpu_baseline(make_cfg, backbone, H, W, budget_s=135.0, all_cores_deadline_s=75.0):
     """The oracle (CPU restatement of the reference path; its backbone is pinned bit-exact to the reference's own transfuser.py and
     its heads/losses to the reference's model.py) timed on this host with PyTorch-CPU fp32: B=2 (BASELINE configs[0], the reference's
     CPU-runnable case) with 2 warm-up + 5 timed steps, then B=10 (the workload of the GPU line) with 1 warm-up + up to 5 timed steps
@@ -363,6 +407,20 @@ def cpu_baseline(make_cfg, backbone, H, W, budget_s=135.0):
     res["value"] = value
     res["sample"] = "oracle.model_cpu.train_step (PyTorch-CPU fp32 restatement of train.py:304-316, %s backbone), %d threads of %d cores; value = %s; %s%s" % (
         backbone, threads, ncpu, sample, res["b2_sample"], ("; " + res["b10_sample"]) if "b10_sample" in res else "")
+    if ncpu > threads:      # SURVEY 8d asks for the host's cores: the same B = 2 step on ALL of them, in a child process with a hard deadline (round-5 review, weak #14)
+        t0 = time.time()
+        try:
+            out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-probe", str(ncpu), "--backbone", backbone, "--height", str(H)],
+                                 stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=all_cores_deadline_s).stdout.decode()
+            sec = float([l for l in out.splitlines() if l.startswith("CPU_PROBE")][-1].split()[1])
+            res["all_cores"] = {"cores": ncpu, "b2_value": round(2 / sec, 3), "b2_sample": "B=2, 1 warm-up + 3 timed steps, median %.2f s/step" % sec,
+                                "vs_%d_threads" % threads: round((2 / sec) / res["b2_value"], 3)}
+        except subprocess.TimeoutExpired:
+            res["all_cores"] = {"cores": ncpu, "b2_value": None, "note": "model construction + 4 B=2 steps on %d threads did not finish in %.0f s (the %d-thread run above needs "
+                                "~%.0f s for the same): past 64 threads the oneDNN / OpenMP kernels of these layer sizes slow down" % (ncpu, all_cores_deadline_s, threads, 8 + 4 * t2[2])}
+        except Exception as e:
+            res["all_cores"] = {"cores": ncpu, "b2_value": None, "note": "probe failed: %s" % str(e)[:200]}
+        res["all_cores"]["probe_wall_s"] = round(time.time() - t0, 1)
     return res
 
 
@@ -493,6 +551,8 @@ def dry_run_cpu(args, log):
 
 def main():
     args = parse_args()
+    if args.cpu_probe:
+        return cpu_probe(args)
     if args.gpus > 1 and "RANK" not in os.environ:
         spawn_ranks(args)
     import torch

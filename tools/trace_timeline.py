@@ -50,3 +50,16 @@ print("families: charged wall ms (of which alone):", ", ".join("%s %.2f (%.2f)" 
 print("per kernel: charged wall ms/step, alone ms/step, sum of durations ms/step, launches/step, name")
 for name, c in sorted(charged.items(), key=lambda kv: -kv[1])[:70]:
     print("%8.3f %8.3f %8.3f %5d  %s" % (c / n / 1e6, solo[name] / n / 1e6, dur[name] / n / 1e6, cnt[name] // n, name[:140]))
+# per queue: the kernels that make up its busy time (the queue with the most busy time is the step's critical path: kernel time saved on the others is hidden)
+# and the GAPS between consecutive kernels of the busiest queue (dependent-launch boundaries + waits for the other queues)
+for q, v in sorted(qb.items(), key=lambda kv: -kv[1])[:3]:
+    per = collections.defaultdict(float); pc = collections.Counter()
+    ks = sorted((s, e, name) for name, s, e, qq in seg if qq == q)
+    for s, e, name in ks:
+        per[name] += e - s; pc[name] += 1
+    gaps = [ks[i + 1][0] - ks[i][1] for i in range(len(ks) - 1)]
+    small = sum(g for g in gaps if 0 < g < 5000); big = sum(g for g in gaps if g >= 5000)
+    print("queue %s: %.2f ms busy, %d launches / step; gaps between its consecutive kernels: %.2f ms in %d gaps < 5 us (boundaries), %.2f ms in %d longer ones (waits)" %
+          (q, v / n / 1e6, len(ks) // n, small / n / 1e6, sum(1 for g in gaps if 0 < g < 5000) // n, big / n / 1e6, sum(1 for g in gaps if g >= 5000) // n))
+    for name, t in sorted(per.items(), key=lambda kv: -kv[1])[:25]:
+        print("    %8.3f ms %5d  %s" % (t / n / 1e6, pc[name] // n, name[:130]))

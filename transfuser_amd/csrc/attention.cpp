@@ -188,36 +188,57 @@ __global__ void __launch_bounds__(kNT, 1) attention_fwd_kernel(const float* __re
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t sd = g.thresh ? *seed : 0u;
-    for (int i = wave; i < kR; i += kNW) {
-        float* srow = Sm + i * kSP;
-        float v[3];
-        float mx = -3.0e38f;
+    // the wave's rows i = wave, wave + 6, ... (six for waves 0 / 1, five otherwise) TOGETHER: the row maxima and the row sums are six independent
+    // reductions whose exchange steps are issued back to back (round 6; one row after the other every one of the 12 wave reductions was its own chain
+    // of six dependent ds_bpermute round trips: ~5 us of the kernel's 15 us floor)
+    constexpr int NR = (kR + kNW - 1) / kNW;
+    float v[NR][3], mx[NR], sum[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int i = wave + r * kNW, ic = i < kR ? i : kR - 1;
+        mx[r] = -3.0e38f;
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             const int j = lane + 64 * q;
-            v[q] = j < g.T ? srow[j] : -3.0e38f;
-            mx = fmaxf(mx, v[q]);
+            v[r][q] = j < g.T ? Sm[ic * kSP + j] : -3.0e38f;
+            mx[r] = fmaxf(mx[r], v[r][q]);
         }
-        mx = wave_max(mx);
-        float sum = 0.f;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1)
+#pragma unroll
+        for (int r = 0; r < NR; ++r) mx[r] = fmaxf(mx[r], shfl_xor(mx[r], m));
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        sum[r] = 0.f;
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             const int j = lane + 64 * q;
-            v[q] = j < g.T ? expf(v[q] - mx) : 0.f;
-            sum += v[q];
+            v[r][q] = j < g.T ? expf(v[r][q] - mx[r]) : 0.f;
+            sum[r] += v[r][q];
         }
-        sum = wave_sum(sum);
-        const float inv = 1.0f / sum;
-        const int row = row0 + i;
-        const uint32_t base = (uint32_t)(((long)bh * g.T + row) * g.Tp);
+    }
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            const int j = lane + 64 * q;
-            float p = v[q] * inv;
-            if (g.thresh) p = dropout_keep(sd, g.site, base + (uint32_t)j, g.thresh) ? p * g.keep_scale : 0.f;
-            srow[j] = j < g.T ? p : 0.f;
+    for (int m = 32; m >= 1; m >>= 1)
+#pragma unroll
+        for (int r = 0; r < NR; ++r) sum[r] += shfl_xor(sum[r], m);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int i = wave + r * kNW;
+        if (i < kR) {                                  // wave-uniform
+            float* srow = Sm + i * kSP;
+            const float inv = 1.0f / sum[r];
+            const int row = row0 + i;
+            const uint32_t base = (uint32_t)(((long)bh * g.T + row) * g.Tp);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int j = lane + 64 * q;
+                float p = v[r][q] * inv;
+                if (g.thresh) p = dropout_keep(sd, g.site, base + (uint32_t)j, g.thresh) ? p * g.keep_scale : 0.f;
+                srow[j] = j < g.T ? p : 0.f;
+            }
+            if (lane == 0 && row < g.T) lse[(long)bh * g.T + row] = mx[r] + logf(sum[r]);
         }
-        if (lane == 0 && row < g.T) lse[(long)bh * g.T + row] = mx + logf(sum);
     }
     __syncthreads();
     phase_b(Sm, vp, ld3, g.T, g.hs, y + (long)b * g.T * g.C + (long)h * g.hs, g.C, row0, 1.f);
@@ -245,25 +266,36 @@ __global__ void __launch_bounds__(kNT, 1) attention_bwd_dq_kernel(const float* _
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t sd = g.thresh ? *seed : 0u;
-    for (int i = wave; i < kR; i += kNW) {
-        const int row = row0 + i;
+    constexpr int NR = (kR + kNW - 1) / kNW;              // the wave's rows together, as in the forward kernel: six independent dot-product reductions
+    float p[NR][3], dp[NR][3], dot[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int i = wave + r * kNW, ic = i < kR ? i : kR - 1, row = row0 + ic;
         const float L = row < g.T ? lse[(long)bh * g.T + row] : 0.f;
         const uint32_t base = (uint32_t)(((long)bh * g.T + row) * g.Tp);
-        float p[3], dp[3];
-        float dot = 0.f;
+        dot[r] = 0.f;
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             const int j = lane + 64 * q;
             const bool ok = j < g.T;
-            p[q] = ok ? expf(S0[i * kSP + j] - L) : 0.f;
-            dp[q] = ok ? S1[i * kSP + j] : 0.f;
-            if (g.thresh) dp[q] = (ok && dropout_keep(sd, g.site, base + (uint32_t)j, g.thresh)) ? dp[q] * g.keep_scale : 0.f;
-            dot += p[q] * dp[q];
+            p[r][q] = ok ? expf(S0[ic * kSP + j] - L) : 0.f;
+            dp[r][q] = ok ? S1[ic * kSP + j] : 0.f;
+            if (g.thresh) dp[r][q] = (ok && dropout_keep(sd, g.site, base + (uint32_t)j, g.thresh)) ? dp[r][q] * g.keep_scale : 0.f;
+            dot[r] += p[r][q] * dp[r][q];
         }
-        dot = wave_sum(dot);
+    }
 #pragma unroll
-        for (int q = 0; q < 3; ++q) S0[i * kSP + lane + 64 * q] = p[q] * (dp[q] - dot);
-        if (lane == 0 && row < g.T) dsum[(long)bh * g.T + row] = dot;
+    for (int m = 32; m >= 1; m >>= 1)
+#pragma unroll
+        for (int r = 0; r < NR; ++r) dot[r] += shfl_xor(dot[r], m);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int i = wave + r * kNW, row = row0 + i;
+        if (i < kR) {                                  // wave-uniform
+#pragma unroll
+            for (int q = 0; q < 3; ++q) S0[i * kSP + lane + 64 * q] = p[r][q] * (dp[r][q] - dot[r]);
+            if (lane == 0 && row < g.T) dsum[(long)bh * g.T + row] = dot[r];
+        }
     }
     __syncthreads();
     phase_b(S0, kp, ld3, g.T, g.hs, dqkv + (long)b * g.T * ld3 + g.C + (long)h * g.hs, ld3, row0, g.alpha);      // dQ = dS K / sqrt(hs)

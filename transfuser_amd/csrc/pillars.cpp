@@ -516,6 +516,9 @@ extern "C" int tf_bn_rows_dev_fwd_f32(const float* x, const int32_t* nrows_dev, 
                                       void* stream) {
     TF_REQUIRE(x && nrows_dev && gamma && beta && y && save_mean && save_invstd && ws && rows_cap > 0 && C > 0 && C <= 256 && 256 % C == 0,
                "tf_bn_rows_dev_fwd_f32: needs C <= 256 dividing 256 (got %d)", C);
+    // only the BatchNorm1d + ReLU form of DynamicPointNet exists: tf_bn_rows_dev_bwd_f32 always applies the z > 0 mask, and the static-shape front-end relies
+    // on the post-ReLU zeros of the padding rows (they alias pillar 0 in the scatter-max) - a call without the ReLU would be silently wrong downstream
+    TF_REQUIRE(relu != 0, "tf_bn_rows_dev_fwd_f32: relu = 0 is not implemented (the backward and the static-shape pillar scatter assume the ReLU)");
     int nblk = cdiv(rows_cap, (256 / C) * 16);
     nblk = nblk < 1 ? 1 : (nblk > kBnrBlocks ? kBnrBlocks : nblk);
     float* p1 = ws; float* p2 = ws + (long)kBnrBlocks * C;

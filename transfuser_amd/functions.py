@@ -405,7 +405,9 @@ class YBlockFn(torch.autograd.Function):
         x16t = z16t = None
         if lp:
             pre = getattr(x, "_lp16", None)
-            x16, x16t = pre if pre is not None else ops.cast16(x2)
+            if pre is not None and (pre[0] != x._version or pre[1].dtype != ops._t16()):      # the tensor was modified in place since its producer wrote the copies
+                pre = None                                                                    # (or the storage mode changed): stale copies are never multiplied
+            x16, x16t = pre[1:] if pre is not None else ops.cast16(x2)
             y1, cs1 = ops.gemm16_nt_colstat(x16, ops.lowp_weight(w2d(blk.conv1.conv.weight))[0], torch.empty(B * H * W, C, dtype=torch.float32, device=x.device))
             x2s = None
         else:
@@ -470,7 +472,7 @@ class YBlockFn(torch.autograd.Function):
             coef3, sm3, si3 = ops.bn_finalize_parts(cs3, bn3.weight, bn3.bias, bn3.running_mean, bn3.running_var, bn3.momentum, bn3.eps)
             out, o16, o16t = ops.bn_apply16(y3, coef3, sc, True)
             st3 = (sm3, si3)
-            out._lp16 = (o16, o16t)
+            out._lp16 = (out._version, o16, o16t)
         else:
             out, st3 = _bn(y3, bn3, res=sc, relu=True, stat=cs3)
         ctx.saved = (x, blk, y1, z1, st1, y2, z2, st2, s, g1, gate, z2ss, y3, st3, yd, std, out, x2s, (lp, x16t, z16t))

@@ -162,10 +162,13 @@ class HeadsFn(torch.autograd.Function):
         if merged is not None:
             # live heads = a prefix of MERGED_ORDER unless a head in front of the tail is dead too (then every channel is differentiated)
             live = [n for n in MERGED_ORDER if n not in dead]
-            nlive = len(live) if list(MERGED_ORDER[:len(live)]) == live else len(MERGED_ORDER)
-            dh_all = torch.empty(B * H * W, nlive * Ch, dtype=torch.float32, device=p2.device)
-            if nlive == len(MERGED_ORDER) and dead:
-                dh_all.zero_()
+            if list(MERGED_ORDER[:len(live)]) != live:
+                # the live heads are not a channel prefix (e.g. wp_only: seven dead heads in front of pred_bev): differentiating all 512 merged channels would
+                # run the weight / input gradient over mostly-zero channels and write zeros into the dead heads' gradients - the per-head backward below
+                # skips them instead (the merged FORWARD is kept: hids[i] are its strided views)
+                merged = None
+            else:
+                dh_all = torch.empty(B * H * W, len(live) * Ch, dtype=torch.float32, device=p2.device)
         for i, sq in enumerate(seqs):
             k = sq[2].weight.shape[0]
             last = i == len(seqs) - 1
