@@ -11,6 +11,7 @@ the fused decode_heatmap kernel; not built: the visualisation branch.
 from collections import deque
 
 import numpy as np
+import os
 import torch
 from torch import nn
 
@@ -21,6 +22,8 @@ from .point_pillar import PointPillarNet
 from .transfuser import DepthDecoder, LateFusionBackbone, SegDecoder, TransfuserBackbone, latentTFBackbone, nchw
 
 HEAD_ORDER = ("heatmap_head", "wh_head", "offset_head", "yaw_class_head", "yaw_res_head", "velocity_head", "brake_head")
+_FORK_DECODERS = os.environ.get("TF_FORK_DECODERS", "0") == "1"      # measured experiment of round 6, default off
+
 LOSS_KEYS = ("loss_center_heatmap", "loss_wh", "loss_offset", "loss_yaw_class", "loss_yaw_res", "loss_velocity", "loss_brake")
 
 
@@ -265,6 +268,22 @@ class LidarCenterNet(nn.Module):
             features, grid, fused = self._model.forward_nhwc(rgb, lidar_bev, ego_vel, bev_points, cam_points, **kw)
         else:
             features, grid, fused = self._model.forward_nhwc(rgb, lidar_bev, ego_vel, **kw)
+        # TF_FORK_DECODERS=1 (round-6 experiment): the segmentation and the depth decoder (+ their losses) as two more parallel branches of the step - they only
+        # read the image feature grid and join at the weighted loss sum; their first layers (8 x 22 ... 64 x 176 maps) are latency-sized and can fill the gaps of the
+        # heads' kernels, their last two (256 x 704) fill the chip either way.  Forked BEFORE the heads are enqueued, like the LiDAR trunk in _run.
+        forked = None
+        if cfg.multitask and _FORK_DECODERS and grid.is_cuda:
+            main = torch.cuda.current_stream(grid.device)
+            if getattr(self, "_dec_streams", None) is None or self._dec_streams[0].device != grid.device:
+                self._dec_streams = (torch.cuda.Stream(grid.device), torch.cuda.Stream(grid.device))
+            forked = []
+            for st, dec, tgt, kind in ((self._dec_streams[0], self.seg_decoder, semantic, "sem"), (self._dec_streams[1], self.depth_decoder, depth, "dep")):
+                st.wait_stream(main)
+                with torch.cuda.stream(st):
+                    logits = dec.forward_nhwc(grid)
+                    l = F_.CrossEntropyFn.apply(logits, tgt.contiguous(), None) if kind == "sem" else F_.L1Fn.apply(logits.squeeze(-1), tgt.contiguous(), True)
+                grid.record_stream(st)
+                forked.append((st, l))
         pred_wp, _, _, _, _ = self.forward_gru(fused, target_point)
         p2 = features[0]
         pred, bev_logits = HeadsFn.apply(p2, self, *self.head.parameters(), *self.pred_bev.parameters())
@@ -278,10 +297,17 @@ class LidarCenterNet(nn.Module):
         for i, k in enumerate(LOSS_KEYS):
             loss[k] = det[i]
         if cfg.multitask:
-            seg_logits = self.seg_decoder.forward_nhwc(grid)
-            depth_logits = self.depth_decoder.forward_nhwc(grid)
-            l_sem = F_.CrossEntropyFn.apply(seg_logits, semantic.contiguous(), None)
-            l_dep = F_.L1Fn.apply(depth_logits.squeeze(-1), depth.contiguous(), True)
+            if forked is not None:
+                main = torch.cuda.current_stream(grid.device)
+                for st, l in forked:
+                    main.wait_stream(st)
+                    l.record_stream(main)
+                l_sem, l_dep = forked[0][1], forked[1][1]
+            else:
+                seg_logits = self.seg_decoder.forward_nhwc(grid)
+                depth_logits = self.depth_decoder.forward_nhwc(grid)
+                l_sem = F_.CrossEntropyFn.apply(seg_logits, semantic.contiguous(), None)
+                l_dep = F_.L1Fn.apply(depth_logits.squeeze(-1), depth.contiguous(), True)
             loss["loss_depth"] = l_dep * cfg.ls_depth if cfg.ls_depth != 1.0 else l_dep
             loss["loss_semantic"] = l_sem * cfg.ls_seg if cfg.ls_seg != 1.0 else l_sem
         else:
