@@ -22,7 +22,7 @@ from .point_pillar import PointPillarNet
 from .transfuser import DepthDecoder, LateFusionBackbone, SegDecoder, TransfuserBackbone, latentTFBackbone, nchw
 
 HEAD_ORDER = ("heatmap_head", "wh_head", "offset_head", "yaw_class_head", "yaw_res_head", "velocity_head", "brake_head")
-_FORK_DECODERS = os.environ.get("TF_FORK_DECODERS", "0") == "1"      # measured experiment of round 6, default off
+_FORK_DECODERS = int(os.environ.get("TF_FORK_DECODERS", "2"))      # round 6: 0 = decoders on the main stream, 1 = forked after the backbone, 2 (default) = forked as soon as the image grid exists
 
 LOSS_KEYS = ("loss_center_heatmap", "loss_wh", "loss_offset", "loss_yaw_class", "loss_yaw_res", "loss_velocity", "loss_brake")
 
@@ -268,9 +268,10 @@ class LidarCenterNet(nn.Module):
             features, grid, fused = self._model.forward_nhwc(rgb, lidar_bev, ego_vel, bev_points, cam_points, **kw)
         else:
             features, grid, fused = self._model.forward_nhwc(rgb, lidar_bev, ego_vel, **kw)
-        # TF_FORK_DECODERS=1 (round-6 experiment): the segmentation and the depth decoder (+ their losses) as two more parallel branches of the step - they only
-        # read the image feature grid and join at the weighted loss sum; their first layers (8 x 22 ... 64 x 176 maps) are latency-sized and can fill the gaps of the
-        # heads' kernels, their last two (256 x 704) fill the chip either way.  Forked BEFORE the heads are enqueued, like the LiDAR trunk in _run.
+        # Round 6: the segmentation and the depth decoder (+ their losses) as two more parallel branches of the step (hipGraph: two more graph branches) - they only
+        # read the image feature grid and join at the weighted loss sum; their first layers (8 x 22 ... 64 x 176 maps) are latency-sized and fill the gaps of the FPN's
+        # and the heads' kernels, and autograd replays their backward on the same streams.  Forked BEFORE the heads are enqueued, like the LiDAR trunk in _run.
+        # Same-lease A/B (three rounds): 44.77 -> 43.74 ms/step in fp32, bf16 32.70 -> 31.83, latentTF fp16 B = 16 46.39 -> 45.67, geometric fusion 27.39 -> 26.48.
         forked = None
         if cfg.multitask and _FORK_DECODERS and grid.is_cuda:
             main = torch.cuda.current_stream(grid.device)
@@ -278,7 +279,11 @@ class LidarCenterNet(nn.Module):
                 self._dec_streams = (torch.cuda.Stream(grid.device), torch.cuda.Stream(grid.device))
             forked = []
             for st, dec, tgt, kind in ((self._dec_streams[0], self.seg_decoder, semantic, "sem"), (self._dec_streams[1], self.depth_decoder, depth, "dep")):
-                st.wait_stream(main)
+                ev = getattr(self._model, "_grid_ready", None) if _FORK_DECODERS > 1 else None
+                if ev is not None:
+                    st.wait_event(ev)          # (2: start as soon as the grid exists - beside the LiDAR reducer and the FPN - not after everything enqueued on main)
+                else:
+                    st.wait_stream(main)
                 with torch.cuda.stream(st):
                     logits = dec.forward_nhwc(grid)
                     l = F_.CrossEntropyFn.apply(logits, tgt.contiguous(), None) if kind == "sem" else F_.L1Fn.apply(logits.squeeze(-1), tgt.contiguous(), True)

@@ -318,6 +318,10 @@ class _FusionBackbone(nn.Module):
             if side is not None:
                 y.record_stream(side)
         x = self._conv(getattr(self, self._reducers[0]), x)
+        self._grid_ready = None
+        if main is not None:       # the image feature grid is final here: consumers that only need it (the segmentation / depth decoders, forked by
+            self._grid_ready = torch.cuda.Event()          # LidarCenterNet.forward) may start beside the LiDAR reducer, the pooling and the FPN below
+            self._grid_ready.record(main)
         y = self._conv(getattr(self, self._reducers[1]), y)
         fused = self._pooled(x, y, im, li)
         return self.top_down_nhwc(y), x, fused
