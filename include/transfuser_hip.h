@@ -299,6 +299,10 @@ int tf_attention_fwd_f32(const float* qkv, float* y, float* lse, int B, int T, i
                          void* stream);
 int tf_attention_bwd_f32(const float* qkv, const float* dy, const float* lse, float* dqkv, float* dsum, int B, int T, int C, int nh,
                          const uint32_t* seed_dev, uint32_t site, float pdrop, void* stream);
+/* The same gradients in two launches whose second one holds BOTH halves (round 6): y = tf_attention_fwd_f32's output; D_i = dY_i . Y_i (equal to
+ * sum_j dP_ij P_ij, also under attention dropout) is formed first (written to dsum), then keys and queries run as one grid.  dy / y 8-byte aligned. */
+int tf_attention_bwd_y_f32(const float* qkv, const float* dy, const float* y, const float* lse, float* dqkv, float* dsum, int B, int T, int C, int nh,
+                           const uint32_t* seed_dev, uint32_t site, float pdrop, void* stream);
 
 /* ---- per-channel reductions / BatchNorm / Squeeze-Excite ------------------------------------- */
 
@@ -479,6 +483,24 @@ int tf_pillar_gather_f32(const float* points, int point_stride, const int32_t* k
                          int64_t n_all, int64_t ncells, int P, float* pts4, int32_t* inv, int64_t* sums, int32_t* cellkey, void* stream);
 int tf_pillar_decorate_f32(const float* pts4, const int32_t* inv, const int64_t* sums, const int32_t* cellkey, int64_t N, int GX, int GY,
                            float pixels_per_meter, float min_x, float min_y, float* feat, void* stream);
+/* Round 6: the same index in three launches, no fill, no global atomic (reference: the same lines of point_pillar.py:69-91 + decorate :54-67; results
+ * identical to the sequence above - integer-exact pillar ids, the same fixed-point sums).  Cells carry a PADDED id b * CP + x_idx * GY + y_idx,
+ * CP = tf_pillar_padded_cells(GX, GY) (each sample rounded up to whole LDS slabs; CP % 128 == 0; the order of the ids is torch.unique's row order).
+ *   tf_pillar_mark_f32            keys (B*Nmax padded ids; -1 = dropped), bitmap (B*CP/32 ints, every word written), cellsums (B*CP x 4 int64; only the
+ *                                 occupied cells' entries are written - and later read), blockcnt (B * cdiv(Nmax, 1024) kept-point counts)
+ *   tf_pillar_rank_scan_i32       wordprefix (like bitmap), blockoff (like blockcnt), totals = {kept points N, pillars P} (device memory)
+ *   tf_pillar_gather_decorate_f32 pts4 (N,4), inv (N), feat (N,9), cellkey (P; un-padded (b*GX + x_idx)*GY + y_idx); fill_tail = 1 (static shapes): the buffers
+ *                                 have B*Nmax rows / cell_cap slots, rows >= N are written as zero and cell-key slots >= P as -1 by the same launch
+ * No workspace survives a call; bitmap / wordprefix / cellsums 16-byte aligned; padded cells and points < 2^24. */
+long tf_pillar_padded_cells(int GX, int GY);
+int tf_pillar_mark_f32(const float* points, const int32_t* num_points, int B, int max_points, int point_stride, float min_x, float max_x, float min_y,
+                       float max_y, float pixels_per_meter, int GX, int GY, int32_t* keys, int32_t* bitmap, int64_t* cellsums, int32_t* blockcnt, void* stream);
+int tf_pillar_rank_scan_i32(const int32_t* bitmap, int64_t padded_cells, const int32_t* blockcnt, int nblocks, int32_t* wordprefix, int32_t* blockoff,
+                            int32_t* totals, void* stream);
+int tf_pillar_gather_decorate_f32(const float* points, int point_stride, const int32_t* keys, int B, int max_points, const int32_t* blockoff,
+                                  const int32_t* wordprefix, const int32_t* bitmap, const int64_t* cellsums, const int32_t* totals, int GX, int GY,
+                                  float pixels_per_meter, float min_x, float min_y, float* pts4, int32_t* inv, float* feat, int32_t* cellkey, int64_t cell_cap,
+                                  int fill_tail, void* stream);
 int tf_pillar_scatter_max_f32(const float* z, const int32_t* inv, int64_t N, int C, int P, float* pillar_feat, int32_t* arg, void* stream);
 int tf_pillar_canvas_f32(const float* pillar_feat, const int32_t* cellkey, int P, int C, int B, int H, int W, int GX, int GY,
                          const float* extra_nchw, int Ce, int32_t* owner, float* out_nhwc, void* stream);

@@ -657,6 +657,35 @@ def check_pillars(dev, B, N, npts):
             close(p, q, what=n_, tol=1e-4)
 
 
+def check_pillar_index_forms(dev):
+    """The three-launch pillar index (round 6) against the seven-launch form of rounds 3-5, host-read and static-shape modes: kept points, inverse indices,
+    cell keys and features BITWISE equal; the static-shape tails (zero rows, -1 cell keys) written by the gather launch itself (ragged counts, an empty sample, a
+    cloud with no kept point at all, point stride 5, a cloud concentrated in sixteen pillars)."""
+    cases = [(3, 5000, (5000, 4000, 100), 4), (2, 3000, (0, 3000), 4), (1, 64, (64,), 4), (2, 1030, (1030, 7), 5), (1, 2048, (2048,), 4), (2, 9000, (9000, 8000), 4)]
+    for ci, (B, N, npts, stride) in enumerate(cases):
+        pts = pillar_cloud(B, N, seed=ci + 1)
+        if ci == 4:
+            pts[..., 0] += 100.0                     # nothing inside the range: N = P = 0
+        if ci == 5:                                  # a cloud concentrated in 4 x 4 pillars of ONE slab: the slab kernel's queue overflows (> 4096 points a trip)
+            pts[..., 0] = pts[..., 0].abs() % 0.5 + 1.0
+            pts[..., 1] = -(pts[..., 1].abs() % 0.5) - 3.0
+        if stride != 4:
+            pts = torch.cat((pts, torch.full((B, N, stride - 4), 7.0)), -1)
+        num = torch.tensor(npts, dtype=torch.int32)
+        a = (pts.to(dev), num.to(dev), -16, 16, -32, 0, 8)
+        for static in (False, True):
+            want = ops._pillar_index_v1(*a, static=static)
+            got = ops.pillar_index(*a, static=static)
+            n, p = (int(v) for v in want["totals"].tolist())
+            assert [int(v) for v in got["totals"].tolist()] == [n, p], "totals"
+            assert got["N"] == want["N"] and got["P"] == want["P"]
+            for k in ("points", "inv", "cellkey"):
+                assert torch.equal(got[k], want[k]), "case %d static %d: %s differs between the two forms" % (ci, static, k)
+            assert torch.equal(got["feat"][:n], want["feat"][:n]), "case %d static %d: features" % (ci, static)
+            if static:
+                assert bool((got["feat"][n:] == 0).all()) and bool((got["cellkey"][p:] == -1).all()) and bool((got["points"][n:] == 0).all())
+
+
 SE_EXCITE_CASES = [(10, 576, 144), (2, 72, 8), (16, 1512, 378), (3, 218, 54), (1, 24, 6), (2, 2048, 512), (2, 3072, 64), (12, 216, 54)]
 
 
@@ -1901,7 +1930,8 @@ def check_bn_fused_stats(dev, plans=((0, 64, 64, 16), (0, 128, 32, 16), (0, 128,
 
 
 # ---------------------------------------------------------------- fused attention (csrc/attention.cpp)
-FUSED_ATTENTION_CASES = [(2, 4, 174, 18, 0.1), (1, 4, 174, 54, 0.0), (2, 2, 50, 24, 0.1), (1, 3, 192, 40, 0.1), (2, 1, 33, 6, 0.0)]
+FUSED_ATTENTION_CASES = [(2, 4, 174, 18, 0.1), (1, 4, 174, 54, 0.0), (2, 2, 50, 24, 0.1), (1, 3, 192, 40, 0.1), (2, 1, 33, 6, 0.0),
+                         (1, 1, 40, 258, 0.1), (1, 2, 70, 256, 0.0)]      # head sizes >= 256: the backward kernels stage the row operand in LDS (ragged last chunk / none)
 FUSED_ATTENTION_CASES_GPU = [(10, 4, 174, 378, 0.1), (3, 4, 174, 144, 0.1), (2, 4, 174, 54, 0.0), (2, 4, 174, 18, 0.1), (1, 1, 192, 384, 0.1), (2, 3, 97, 34, 0.1)]
 
 
@@ -1930,10 +1960,11 @@ def check_fused_attention(dev, B, nh, T, hs, p):
     close(yh, y, what="fused attention fwd")
     s = (q @ k.transpose(-2, -1)).detach() * (1.0 / math.sqrt(hs))
     close(lse.view(B, nh, T), torch.logsumexp(s, -1), what="fused attention log-sum-exp")
-    dq = ops.attention_bwd(qd, dy.to(dev), lse, B, T, C, nh, drop)
-    close(dq[:, C:2 * C], g[:, C:2 * C], what="fused attention dQ")
-    close(dq[:, :C], g[:, :C], what="fused attention dK")
-    close(dq[:, 2 * C:], g[:, 2 * C:], what="fused attention dV")
+    for form, kw in (("two dependent launches", {}), ("one grid, D = dY . Y", dict(y=yh))):      # rounds 3-5 / round 6 (tf_attention_bwd_y_f32)
+        dq = ops.attention_bwd(qd, dy.to(dev), lse, B, T, C, nh, drop, **kw)
+        close(dq[:, C:2 * C], g[:, C:2 * C], what="fused attention dQ (%s)" % form)
+        close(dq[:, :C], g[:, :C], what="fused attention dK (%s)" % form)
+        close(dq[:, 2 * C:], g[:, 2 * C:], what="fused attention dV (%s)" % form)
 
 
 # ---------------------------------------------------------------- pair launch (csrc/gemm_pair.cpp)

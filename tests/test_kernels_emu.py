@@ -178,6 +178,10 @@ def test_point_pillars(case):
     kc.check_pillars("cpu", *case)
 
 
+def test_pillar_index_three_launch_form_equals_the_seven_launch_form():
+    kc.check_pillar_index_forms("cpu")
+
+
 @pytest.mark.parametrize("case", kc.SE_EXCITE_CASES, ids=str)
 def test_se_excite_fused(case):
     kc.check_se_excite("cpu", *case)

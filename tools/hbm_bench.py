@@ -84,6 +84,16 @@ raw = torch.zeros(10, 40000, 4, device=dev); raw[:, :32768] = pts
 num = torch.full((10,), 32768, dtype=torch.int32, device=dev)
 row("H2 pillar_index 10 x 40000 points (16 B / point + 4 B / grid cell read)", 10 * (32768 * 16 + 257 * 257 * 4),
     lambda: ops.pillar_index(raw, num, -16, 16, -32, 0, 8), iters=min(10, args.iters))
+# round 6: the same call priced WITH the outputs it has to write (compacted cloud 16 B, inverse index 4 B, nine features 36 B per kept point, 4 B per pillar),
+# its static-shape (hipGraph) mode - no host read, capacity-sized outputs - and the seven-launch form of rounds 3-5 beside it
+_ix = ops.pillar_index(raw, num, -16, 16, -32, 0, 8)
+_h2 = 10 * 32768 * 16 + _ix["N"] * 56 + _ix["P"] * 4
+row("H2 pillar_index, %d kept points / %d pillars (16 B / point read + 56 B / kept point + 4 B / pillar written)" % (_ix["N"], _ix["P"]), _h2,
+    lambda: ops.pillar_index(raw, num, -16, 16, -32, 0, 8), iters=min(10, args.iters))
+row("H2 pillar_index, static shapes (same bytes + the zero tail: 56 B / dropped point, 4 B / unused pillar slot)", 10 * 32768 * 16 + 400000 * 56 + 400000 * 4,
+    lambda: ops.pillar_index(raw, num, -16, 16, -32, 0, 8, static=True), iters=min(10, args.iters))
+row("H2 pillar_index, seven-launch form of rounds 3-5 (TF_PILLAR_V2=0)", _h2,
+    lambda: ops._pillar_index_v1(raw, num, -16, 16, -32, 0, 8), iters=min(10, args.iters))
 n = 168018327
 # ONE allocation cut into 4 arenas, like train.ParamArena / FlatAdamW (4 separate torch.randn(n) tensors were what r02 timed)
 buf = torch.randn(4, (n + 63) // 64 * 64, device=dev) * 0.01

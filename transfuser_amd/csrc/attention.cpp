@@ -18,6 +18,7 @@
 // (B nh, T, Tp) probability tensor (Tp = T rounded up to 4), i.e. the unfused path's mask - parity tests share their masks.
 // Exact fp32 MFMA in every precision mode: the contraction is 1.5 % of the step's FLOPs, its cost was launches and HBM round trips.
 #include "tf_common.h"
+#include <stdlib.h>
 #include "../../include/transfuser_hip.h"
 
 using namespace tf;
@@ -37,6 +38,7 @@ struct AtGeom {
     int B, nh, T, hs, C, Tp;
     float alpha, keep_scale;
     uint32_t site, thresh;
+    int dbg;                       // TF_ATT_DBG (timing diagnosis, results are garbage): 1 no phase A, 2 no phase B, 4 no softmax / dS middle
 };
 
 __device__ __forceinline__ int acc_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
@@ -115,6 +117,84 @@ __device__ __forceinline__ void phase_a(f32x16 (&acc)[NP], const float* const (&
     }
 }
 
+// ---- phase A with the ROW operand staged in LDS (round 6).  The 32 x hs row tile is the same for all six waves - fetched per lane it is half of the
+// phase's load instructions, six times over, and with the column operand's 6 x 32 rows it overflows the 32 KB vector L1 between two chunks of a row's
+// cache line (PMC: the TCP waits on pending misses for half of the kernel, MFMA busy 28 %).  Here the workgroup copies the tile once (8-byte coalesced
+// loads, rows >= T and the channels of the ragged last chunk zero), one barrier, and the A fragments are ds_read_b64 (pitch 386: pitch / 2 odd - the 32
+// rows of a half wave fall into different bank pairs); only the column operand's fragments still come from global memory, double-buffered as before.
+constexpr int kRP = 386;           // row-tile pitch in LDS (floats)
+template <int NP>
+__device__ __forceinline__ void phase_a_lds(f32x16 (&acc)[NP], float* Rl, const float* const (&rsrc)[NP], const long (&rld)[NP], const float* const (&csrc)[NP],
+                                            const long (&cld)[NP], int row0, int T, int hs) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int crow = wave * 32 + l31;
+    const bool cok = crow < T;
+    const float* cp[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        cp[p] = csrc[p] + (long)(cok ? crow : 0) * cld[p];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+    }
+    float2 fb[2][NP][kKH / 2];
+    auto fetch = [&](int buf, int k0) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+            for (int q = 0; q < kKH / 2; ++q) fb[buf][p][q] = *reinterpret_cast<const float2*>(cp[p] + k0 + kKH * hi + 2 * q);
+    };
+    const int nfull = hs / (2 * kKH), npair = nfull >> 1, h2 = hs >> 1, hp2 = (hs + 2 * kKH - 1) / (2 * kKH) * kKH;       // pairs per row incl. the zero padding
+    if (nfull > 0) fetch(0, 0);                                   // the first column fragments travel while the row tile is staged
+    {
+        constexpr int NQ = (kHS / 2 + 63) / 64;                   // float2 per lane and row
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+            for (int i = wave; i < kR; i += kNW) {                // a wave copies whole rows: no index division
+                const int row = row0 + i;
+                const float2* src = reinterpret_cast<const float2*>(rsrc[p] + (long)(row < T ? row : 0) * rld[p]);
+                float2 v[NQ];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) { const int c = lane + 64 * q; v[q] = src[c < h2 ? c : 0]; }
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const int c = lane + 64 * q;
+                    if (c < hp2) *reinterpret_cast<float2*>(Rl + (p * kR + i) * kRP + 2 * c) = (row < T && c < h2) ? v[q] : make_float2(0.f, 0.f);
+                }
+            }
+    }
+    __syncthreads();
+    const float* ap = Rl + l31 * kRP + kKH * hi;
+    auto mma = [&](int buf, int k0) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+            for (int q = 0; q < kKH / 2; ++q) {
+                const float2 a = *reinterpret_cast<const float2*>(ap + p * kR * kRP + k0 + 2 * q);
+                mfma_32x32x2(a.x, fb[buf][p][q].x, acc[p]);
+                mfma_32x32x2(a.y, fb[buf][p][q].y, acc[p]);
+            }
+    };
+    for (int i = 0; i < npair; ++i) {
+        fetch(1, (2 * i + 1) * 2 * kKH);
+        mma(0, 2 * i * 2 * kKH);
+        const int nx = 2 * i + 2 < nfull ? 2 * i + 2 : nfull - 1;
+        fetch(0, nx * 2 * kKH);
+        mma(1, (2 * i + 1) * 2 * kKH);
+    }
+    if (nfull & 1) mma(0, (nfull - 1) * 2 * kKH);             // buffer 0 holds chunk nfull - 1
+    if (hs - nfull * 2 * kKH > 0) {                               // ragged tail: the row tile holds zeros there; the column operand's dead channels read channel 0
+        const int k0 = nfull * 2 * kKH;
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+            for (int q = 0; q < kKH / 2; ++q) {
+                const int k = k0 + kKH * hi + 2 * q;
+                fb[0][p][q] = *reinterpret_cast<const float2*>(cp[p] + (k < hs ? k : 0));
+            }
+        mma(0, k0);
+    }
+}
+
 // the wave's accumulator tile -> score matrix Sm[i][wave * 32 + j] (x scale)
 __device__ __forceinline__ void put_scores(float* Sm, const f32x16& acc, float scale) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
@@ -171,6 +251,7 @@ __device__ __forceinline__ void phase_b(const float* Sm, const float* bsrc, long
 }
 
 // qkv: (B*T, 3C) = [key | query | value] (transfuser.py:500-502 order); head h owns columns h*hs .. of each third
+template <bool RL>
 __global__ void __launch_bounds__(kNT, 1) attention_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ y, float* __restrict__ lse, AtGeom g,
                                                                const uint32_t* __restrict__ seed) {
     __shared__ float Sm[kR * kSP];          // 24.7 KB: several workgroups per CU
@@ -183,7 +264,10 @@ __global__ void __launch_bounds__(kNT, 1) attention_fwd_kernel(const float* __re
     const float* const rs[1] = {qp};
     const float* const cs[1] = {kp};
     const long rl[1] = {ld3}, cl[1] = {ld3};
-    phase_a<1>(acc, rs, rl, cs, cl, row0, g.T, g.hs);
+    __shared__ float Rl[RL ? kR * kRP : 4];
+    if (g.dbg & 1) { for (int r = 0; r < 16; ++r) acc[0][r] = 0.f; }
+    else if (RL) phase_a_lds<1>(acc, Rl, rs, rl, cs, cl, row0, g.T, g.hs);
+    else phase_a<1>(acc, rs, rl, cs, cl, row0, g.T, g.hs);
     put_scores(Sm, acc[0], g.alpha);
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -241,15 +325,13 @@ __global__ void __launch_bounds__(kNT, 1) attention_fwd_kernel(const float* __re
         }
     }
     __syncthreads();
-    phase_b(Sm, vp, ld3, g.T, g.hs, y + (long)b * g.T * g.C + (long)h * g.hs, g.C, row0, 1.f);
+    if (!(g.dbg & 2)) phase_b(Sm, vp, ld3, g.T, g.hs, y + (long)b * g.T * g.C + (long)h * g.hs, g.C, row0, 1.f);
 }
 
-// rows = queries: dQ, and D_i = sum_j dP_ij P_ij for the dkv kernel
-__global__ void __launch_bounds__(kNT, 1) attention_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ dy, const float* __restrict__ lse,
-                                                                  float* __restrict__ dqkv, float* __restrict__ dsum, AtGeom g,
-                                                                  const uint32_t* __restrict__ seed) {
-    __shared__ float S0[kR * kSP];
-    __shared__ float S1[kR * kSP];
+// rows = queries: dQ, and D_i = sum_j dP_ij P_ij for the dkv kernel.  HAVE_D: D_i comes in (attention_dsum_kernel), no reduction and nothing written to dsum
+template <bool HAVE_D, bool RL>
+__device__ __forceinline__ void bwd_dq_body(float* S0, float* S1, float* Rl, const float* __restrict__ qkv, const float* __restrict__ dy, const float* __restrict__ lse,
+                                            float* __restrict__ dqkv, float* __restrict__ dsum, const AtGeom& g, const uint32_t* __restrict__ seed) {
     const int bh = blockIdx.y, b = bh / g.nh, h = bh - b * g.nh, row0 = blockIdx.x * kR;
     const long ld3 = 3L * g.C;
     const float* kp = qkv + (long)b * g.T * ld3 + (long)h * g.hs;
@@ -260,7 +342,9 @@ __global__ void __launch_bounds__(kNT, 1) attention_bwd_dq_kernel(const float* _
     const float* const rs[2] = {qp, dyp};
     const float* const cs[2] = {kp, vp};
     const long rl[2] = {ld3, (long)g.C}, cl[2] = {ld3, ld3};
-    phase_a<2>(acc, rs, rl, cs, cl, row0, g.T, g.hs);       // S = Q K^T, dPd = dY V^T
+    if (g.dbg & 1) { for (int r = 0; r < 16; ++r) acc[0][r] = acc[1][r] = 0.f; }
+    else if (RL) phase_a_lds<2>(acc, Rl, rs, rl, cs, cl, row0, g.T, g.hs);       // S = Q K^T, dPd = dY V^T
+    else phase_a<2>(acc, rs, rl, cs, cl, row0, g.T, g.hs);
     put_scores(S0, acc[0], g.alpha);
     put_scores(S1, acc[1], 1.f);
     __syncthreads();
@@ -273,7 +357,7 @@ __global__ void __launch_bounds__(kNT, 1) attention_bwd_dq_kernel(const float* _
         const int i = wave + r * kNW, ic = i < kR ? i : kR - 1, row = row0 + ic;
         const float L = row < g.T ? lse[(long)bh * g.T + row] : 0.f;
         const uint32_t base = (uint32_t)(((long)bh * g.T + row) * g.Tp);
-        dot[r] = 0.f;
+        dot[r] = (HAVE_D && row < g.T) ? dsum[(long)bh * g.T + row] : 0.f;
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             const int j = lane + 64 * q;
@@ -281,32 +365,41 @@ __global__ void __launch_bounds__(kNT, 1) attention_bwd_dq_kernel(const float* _
             p[r][q] = ok ? expf(S0[ic * kSP + j] - L) : 0.f;
             dp[r][q] = ok ? S1[ic * kSP + j] : 0.f;
             if (g.thresh) dp[r][q] = (ok && dropout_keep(sd, g.site, base + (uint32_t)j, g.thresh)) ? dp[r][q] * g.keep_scale : 0.f;
-            dot[r] += p[r][q] * dp[r][q];
+            if (!HAVE_D) dot[r] += p[r][q] * dp[r][q];
         }
     }
+    if (!HAVE_D) {
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1)
+        for (int m = 32; m >= 1; m >>= 1)
 #pragma unroll
-        for (int r = 0; r < NR; ++r) dot[r] += shfl_xor(dot[r], m);
+            for (int r = 0; r < NR; ++r) dot[r] += shfl_xor(dot[r], m);
+    }
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
         const int i = wave + r * kNW, row = row0 + i;
         if (i < kR) {                                  // wave-uniform
 #pragma unroll
             for (int q = 0; q < 3; ++q) S0[i * kSP + lane + 64 * q] = p[r][q] * (dp[r][q] - dot[r]);
-            if (lane == 0 && row < g.T) dsum[(long)bh * g.T + row] = dot[r];
+            if (!HAVE_D && lane == 0 && row < g.T) dsum[(long)bh * g.T + row] = dot[r];
         }
     }
     __syncthreads();
-    phase_b(S0, kp, ld3, g.T, g.hs, dqkv + (long)b * g.T * ld3 + g.C + (long)h * g.hs, ld3, row0, g.alpha);      // dQ = dS K / sqrt(hs)
+    if (!(g.dbg & 2)) phase_b(S0, kp, ld3, g.T, g.hs, dqkv + (long)b * g.T * ld3 + g.C + (long)h * g.hs, ld3, row0, g.alpha);      // dQ = dS K / sqrt(hs)
+}
+template <bool RL>
+__global__ void __launch_bounds__(kNT, 1) attention_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ dy, const float* __restrict__ lse,
+                                                                  float* __restrict__ dqkv, float* __restrict__ dsum, AtGeom g,
+                                                                  const uint32_t* __restrict__ seed) {
+    __shared__ float S0[kR * kSP];
+    __shared__ float S1[kR * kSP];
+    __shared__ float Rl[RL ? 2 * kR * kRP : 4];
+    bwd_dq_body<false, RL>(S0, S1, Rl, qkv, dy, lse, dqkv, dsum, g, seed);
 }
 
 // rows = keys: dK, dV
-__global__ void __launch_bounds__(kNT, 1) attention_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ dy, const float* __restrict__ lse,
-                                                                   const float* __restrict__ dsum, float* __restrict__ dqkv, AtGeom g,
-                                                                   const uint32_t* __restrict__ seed) {
-    __shared__ float S0[kR * kSP];
-    __shared__ float S1[kR * kSP];
+template <bool RL>
+__device__ __forceinline__ void bwd_dkv_body(float* S0, float* S1, float* Rl, const float* __restrict__ qkv, const float* __restrict__ dy, const float* __restrict__ lse,
+                                             const float* __restrict__ dsum, float* __restrict__ dqkv, const AtGeom& g, const uint32_t* __restrict__ seed) {
     const int bh = blockIdx.y, b = bh / g.nh, h = bh - b * g.nh, row0 = blockIdx.x * kR;
     const long ld3 = 3L * g.C;
     const float* kp = qkv + (long)b * g.T * ld3 + (long)h * g.hs;
@@ -317,7 +410,9 @@ __global__ void __launch_bounds__(kNT, 1) attention_bwd_dkv_kernel(const float* 
     const float* const rs[2] = {kp, vp};
     const float* const cs[2] = {qp, dyp};
     const long rl[2] = {ld3, ld3}, cl[2] = {ld3, (long)g.C};
-    phase_a<2>(acc, rs, rl, cs, cl, row0, g.T, g.hs);       // S^T = K Q^T, dPd^T = V dY^T
+    if (g.dbg & 1) { for (int r = 0; r < 16; ++r) acc[0][r] = acc[1][r] = 0.f; }
+    else if (RL) phase_a_lds<2>(acc, Rl, rs, rl, cs, cl, row0, g.T, g.hs);       // S^T = K Q^T, dPd^T = V dY^T
+    else phase_a<2>(acc, rs, rl, cs, cl, row0, g.T, g.hs);
     put_scores(S0, acc[0], g.alpha);
     put_scores(S1, acc[1], 1.f);
     __syncthreads();
@@ -343,10 +438,63 @@ __global__ void __launch_bounds__(kNT, 1) attention_bwd_dkv_kernel(const float* 
     }
     __syncthreads();
     float* dk = dqkv + (long)b * g.T * ld3 + (long)h * g.hs;
+    if (g.dbg & 2) return;
     phase_b(S0, qp, ld3, g.T, g.hs, dk, ld3, row0, g.alpha);                 // dK = dS^T Q / sqrt(hs)
     phase_b(S1, dyp, g.C, g.T, g.hs, dk + 2 * g.C, ld3, row0, 1.f);          // dV = Pd^T dY
 }
+template <bool RL>
+__global__ void __launch_bounds__(kNT, 1) attention_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ dy, const float* __restrict__ lse,
+                                                                   const float* __restrict__ dsum, float* __restrict__ dqkv, AtGeom g,
+                                                                   const uint32_t* __restrict__ seed) {
+    __shared__ float S0[kR * kSP];
+    __shared__ float S1[kR * kSP];
+    __shared__ float Rl[RL ? 2 * kR * kRP : 4];
+    bwd_dkv_body<RL>(S0, S1, Rl, qkv, dy, lse, dsum, dqkv, g, seed);
+}
 
+// ---- round 6: both backward kernels in ONE grid.  D_i = sum_j dP_ij P_ij = dY_i . Y_i (the rows of the forward output; holds with attention dropout:
+// sum_j Pd_ij (dY_i . V_j) = dY_i . sum_j Pd_ij V_j), so it needs no score matrix: attention_dsum_kernel forms it from dy and y (one wave per row and
+// head), and the dK / dV half no longer waits for the dQ half.  blockIdx.z = 0: keys (the longer half starts first), 1: queries.  A launch of one
+// half is 240 six-wave workgroups on 256 CUs - one per CU, two SIMDs with two waves and two with one; the merged grid puts two workgroups on a CU.
+__global__ void __launch_bounds__(256) attention_dsum_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dsum, int B, int T,
+                                                             int C, int nh) {
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int total = B * T * nh, hs = C / nh;
+    const bool live = wid < total;
+    const int w = live ? wid : 0, h = w % nh, bt = w / nh;
+    const float2* a = reinterpret_cast<const float2*>(dy + (long)bt * C + (long)h * hs);
+    const float2* c = reinterpret_cast<const float2*>(y + (long)bt * C + (long)h * hs);
+    const int n2 = hs >> 1;
+    float2 u[kHS / 128], v[kHS / 128];
+#pragma unroll
+    for (int q = 0; q < kHS / 128; ++q) {
+        const int i = lane + 64 * q, ic = i < n2 ? i : n2 - 1;
+        u[q] = a[ic]; v[q] = c[ic];
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < kHS / 128; ++q) s += (lane + 64 * q < n2) ? u[q].x * v[q].x + u[q].y * v[q].y : 0.f;
+    s = wave_sum(s);
+    if (live && lane == 0) {
+        const int b = bt / T, t = bt - b * T;
+        dsum[((long)b * nh + h) * T + t] = s;
+    }
+}
+template <bool RL>
+__global__ void __launch_bounds__(kNT, 1) attention_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dy, const float* __restrict__ lse,
+                                                               float* __restrict__ dsum, float* __restrict__ dqkv, AtGeom g, const uint32_t* __restrict__ seed) {
+    __shared__ float S0[kR * kSP];
+    __shared__ float S1[kR * kSP];
+    __shared__ float Rl[RL ? 2 * kR * kRP : 4];
+    if (blockIdx.z == 0) bwd_dkv_body<RL>(S0, S1, Rl, qkv, dy, lse, dsum, dqkv, g, seed);
+    else bwd_dq_body<true, RL>(S0, S1, Rl, qkv, dy, lse, dqkv, dsum, g, seed);
+}
+
+// TF_ATT_ROWLDS: 0 never, 1 (default) the backward kernels at head sizes >= 256, 2 everywhere.  Measured in-graph (profiles/r06_attention_lab_row_lds.txt):
+// backward at hs = 378 170.5 -> 145.5 us; at hs <= 144 the staging prologue and its barrier cost 5-7 us per backward and 1-2 us per forward, and the
+// forward kernel does not gain at any size (its phase A is one product).
+inline int row_lds_mode() { static const int m = [] { const char* e = getenv("TF_ATT_ROWLDS"); return e ? atoi(e) : 1; }(); return m; }
+inline bool row_lds(int hs, bool backward) { const int m = row_lds_mode(); return m >= 2 || (m == 1 && backward && hs >= 256); }
 inline int make_geom(AtGeom& g, int B, int T, int C, int nh, uint32_t site, float pdrop, const char* who) {
     TF_REQUIRE(B > 0 && T > 0 && T <= kNC && nh > 0 && C % nh == 0 && C / nh <= kHS && (C / nh) % 2 == 0, "%s: needs T <= %d and an even head size <= %d (got T=%d, hs=%d)",
                who, kNC, kHS, T, nh > 0 ? C / nh : -1);
@@ -356,6 +504,8 @@ inline int make_geom(AtGeom& g, int B, int T, int C, int nh, uint32_t site, floa
     g.site = site;
     g.thresh = (uint32_t)((double)pdrop * 4294967296.0);
     g.keep_scale = 1.f / (1.f - pdrop);
+    static const int dbg = [] { const char* e = getenv("TF_ATT_DBG"); return e ? atoi(e) : 0; }();
+    g.dbg = dbg;
     return 0;
 }
 
@@ -368,8 +518,21 @@ extern "C" int tf_attention_fwd_f32(const float* qkv, float* y, float* lse, int 
     TF_REQUIRE(qkv && y && lse && (pdrop == 0.f || seed_dev), "tf_attention_fwd_f32: null argument");
     AtGeom g;
     if (int e = make_geom(g, B, T, C, nh, site, pdrop, "tf_attention_fwd_f32")) return e;
-    TF_LAUNCH(attention_fwd_kernel, dim3(cdiv(T, kR), B * nh), dim3(kNT), stream, qkv, y, lse, g, seed_dev);
+    if (row_lds(g.hs, false)) TF_LAUNCH(attention_fwd_kernel<true>, dim3(cdiv(T, kR), B * nh), dim3(kNT), stream, qkv, y, lse, g, seed_dev);
+    else TF_LAUNCH(attention_fwd_kernel<false>, dim3(cdiv(T, kR), B * nh), dim3(kNT), stream, qkv, y, lse, g, seed_dev);
     return launch_status("tf_attention_fwd_f32");
+}
+
+extern "C" int tf_attention_bwd_y_f32(const float* qkv, const float* dy, const float* y, const float* lse, float* dqkv, float* dsum, int B, int T, int C, int nh,
+                                      const uint32_t* seed_dev, uint32_t site, float pdrop, void* stream) {
+    TF_REQUIRE(qkv && dy && y && lse && dqkv && dsum && (pdrop == 0.f || seed_dev), "tf_attention_bwd_y_f32: null argument");
+    AtGeom g;
+    if (int e = make_geom(g, B, T, C, nh, site, pdrop, "tf_attention_bwd_y_f32")) return e;
+    TF_REQUIRE((((uintptr_t)dy | (uintptr_t)y) & 7) == 0, "tf_attention_bwd_y_f32: dy / y must be 8-byte aligned");
+    TF_LAUNCH(attention_dsum_kernel, dim3(cdiv((long)B * T * nh, 4)), dim3(256), stream, dy, y, dsum, B, T, C, nh);
+    if (row_lds(g.hs, true)) TF_LAUNCH(attention_bwd_kernel<true>, dim3(cdiv(T, kR), B * nh, 2), dim3(kNT), stream, qkv, dy, lse, dsum, dqkv, g, seed_dev);
+    else TF_LAUNCH(attention_bwd_kernel<false>, dim3(cdiv(T, kR), B * nh, 2), dim3(kNT), stream, qkv, dy, lse, dsum, dqkv, g, seed_dev);
+    return launch_status("tf_attention_bwd_y_f32");
 }
 
 extern "C" int tf_attention_bwd_f32(const float* qkv, const float* dy, const float* lse, float* dqkv, float* dsum, int B, int T, int C, int nh,
@@ -377,7 +540,12 @@ extern "C" int tf_attention_bwd_f32(const float* qkv, const float* dy, const flo
     TF_REQUIRE(qkv && dy && lse && dqkv && dsum && (pdrop == 0.f || seed_dev), "tf_attention_bwd_f32: null argument");
     AtGeom g;
     if (int e = make_geom(g, B, T, C, nh, site, pdrop, "tf_attention_bwd_f32")) return e;
-    TF_LAUNCH(attention_bwd_dq_kernel, dim3(cdiv(T, kR), B * nh), dim3(kNT), stream, qkv, dy, lse, dqkv, dsum, g, seed_dev);
-    TF_LAUNCH(attention_bwd_dkv_kernel, dim3(cdiv(T, kR), B * nh), dim3(kNT), stream, qkv, dy, lse, (const float*)dsum, dqkv, g, seed_dev);
+    if (row_lds(g.hs, true)) {
+        TF_LAUNCH(attention_bwd_dq_kernel<true>, dim3(cdiv(T, kR), B * nh), dim3(kNT), stream, qkv, dy, lse, dqkv, dsum, g, seed_dev);
+        TF_LAUNCH(attention_bwd_dkv_kernel<true>, dim3(cdiv(T, kR), B * nh), dim3(kNT), stream, qkv, dy, lse, (const float*)dsum, dqkv, g, seed_dev);
+    } else {
+        TF_LAUNCH(attention_bwd_dq_kernel<false>, dim3(cdiv(T, kR), B * nh), dim3(kNT), stream, qkv, dy, lse, dqkv, dsum, g, seed_dev);
+        TF_LAUNCH(attention_bwd_dkv_kernel<false>, dim3(cdiv(T, kR), B * nh), dim3(kNT), stream, qkv, dy, lse, (const float*)dsum, dqkv, g, seed_dev);
+    }
     return launch_status("tf_attention_bwd_f32");
 }

@@ -6,6 +6,7 @@
 // its pillar id from the scanned grid - integer-exact by construction, HBM-bound (12 B/point + 4 B/cell), no sort.
 // Everything is fp32 / int32; kept points are compacted in their original order (stable), like points[keep].
 #include "tf_common.h"
+#include <stdlib.h>
 #include "../../include/transfuser_hip.h"
 
 using namespace tf;
@@ -249,6 +250,291 @@ __global__ void __launch_bounds__(256) pillar_decorate_kernel(const float* __res
     }
 }
 
+// ======================================================================================================================================
+// Round 6: the same index in THREE launches, no fill, no global atomic (was: occupancy fill, keys, 2 scan launches, sums fill, gather with four 64-bit
+// global atomics per point run, decorate - and three more fills in the static-shape mode).
+//   pillar_slab_kernel             H1's slab form (misc.cpp): a 1024-thread block owns a SLAB of one sample's grid (<= 4096 cells: [cell][x, y, z sums, count]
+//                                  as 64-bit fixed-point integers = 128 KB of LDS), walks the sample's cloud (all slab blocks of a sample on one XCD: the
+//                                  cloud leaves HBM once) and accumulates its cells with return-less LDS atomics - integer adds, so the sums are the ones
+//                                  the global atomics produced.  It then writes the sums of its OCCUPIED cells to a cell-indexed table (plain stores;
+//                                  never read for an empty cell, so the table needs no initialisation), its words of the occupancy BITMAP (every word
+//                                  written: no zeroed workspace), and - for the 1024-point chunks it owns (chunk % S == slab) - the keys and the chunk's
+//                                  kept-point count.  Cells are numbered with each sample padded to S slabs of SC cells (SC % 128 == 0): the padded id
+//                                  b * S * SC + x_idx * GY + y_idx orders like the (b, x_idx, y_idx) rows torch.unique sorts.
+//   pillar_scan_kernel (1 block)   exclusive scans of the bitmap's per-word popcounts (16-byte loads, 4096 words per block scan) and of the chunk counts
+//   pillar_gather_decorate_kernel  point blocks: row of a kept point = chunk offset + in-block scan of the keep flags, pillar id = word prefix +
+//                                  popcount of the lower bits, the 9 features straight from the cell's sums - compacted cloud, inverse indices and
+//                                  features in ONE pass over the points; in the static-shape mode every dropped point writes one zero row of the tail
+//                                  (the d-th dropped point owns row N + d), so the capacity buffers need no fill either.
+//                                  cell blocks: cellkey[rank] = cell for the set bits (+ the -1 tail in the static-shape mode)
+// Integer results are what the seven-launch form produces (torch.unique's, tests/kernel_cases.py check_pillars / check_pillar_index_forms).
+constexpr int kPlBlock = 1024;      // points per chunk: one block of the gather kernel (256 threads x 4 consecutive points), one trip row of the slab kernel
+constexpr int kPlSlabMax = 4096;    // cells per slab (12 bits of a queue entry)
+constexpr int kPlQueue = 4096;      // queued points per trip of 16 x 1024 points (14 bits of a queue entry); the expected load is 16384 / S
+struct PlGeom { int S, SC, CP; };   // slabs per sample, cells per slab, padded cells per sample
+inline PlGeom pl_geom(int GX, int GY) {
+    const long cs = (long)GX * GY;
+    const int S = cdiv(cs, kPlSlabMax), SC = (cdiv(cs, S) + 127) / 128 * 128;
+    return PlGeom{S, SC, S * SC};
+}
+#ifdef TF_EMU
+static inline int pl_popc(unsigned v) { return __builtin_popcount(v); }
+static inline int wave_count(bool p) { return (int)wave_sum(p ? 1.f : 0.f); }
+#else
+__device__ __forceinline__ int pl_popc(unsigned v) { return __popc(v); }
+__device__ __forceinline__ int wave_count(bool p) { return __popcll(__ballot(p)); }
+#endif
+// exclusive scan of one int per thread over the NW waves of the block (block total < 2^24: the shuffles carry fp32); sm: NW ints
+template <int NW>
+__device__ __forceinline__ int block_excl_scan(int v, int* sm, int& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float x = (float)v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const float y = shfl(x, (lane - off) & 63);
+        if (lane >= off) x += y;
+    }
+    if (lane == 63) sm[wave] = (int)x;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        const int t = sm[w];
+        base += w < wave ? t : 0;
+        tot += t;
+    }
+    __syncthreads();
+    total = tot;
+    return base + (int)x - v;
+}
+__device__ __forceinline__ void pillar_accumulate(unsigned long long* c, float x, float y, float z) {      // LDS; the sums pillar_gather_kernel forms with global atomics
+    atomicAdd(c, (unsigned long long)(long long)llrintf(x * kPillarFix));
+    atomicAdd(c + 1, (unsigned long long)(long long)llrintf(y * kPillarFix));
+    atomicAdd(c + 2, (unsigned long long)(long long)llrintf(z * kPillarFix));
+    atomicAdd(c + 3, 1ull);
+}
+__global__ void __launch_bounds__(1024) pillar_slab_kernel(const float* __restrict__ pts, const int32_t* __restrict__ npts, int B, int Nmax, int F, int vec4,
+                                                           float min_x, float max_x, float min_y, float max_y, float ppm, int GX, int GY, int S, int SC,
+                                                           int32_t* __restrict__ keys, unsigned* __restrict__ bitmap, long long* __restrict__ cellsums,
+                                                           int32_t* __restrict__ blockcnt, int dbg) {
+    __shared__ __attribute__((aligned(16))) unsigned long long acc[kPlSlabMax * 4];
+    __shared__ unsigned char occ[kPlSlabMax];
+    __shared__ unsigned queue[kPlQueue];
+    __shared__ int cnt[64];
+    __shared__ int qn;
+    const int tid = threadIdx.x;
+    // blocks of a sample sit on ONE XCD where they can (the cloud leaves HBM once), but no XCD gets more than its share of the B * S blocks: a block
+    // needs a whole CU's LDS, so 34 blocks on a 32-CU XCD would run in two rounds
+    const int per = (B * S + 7) / 8, lin = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per || lin >= B * S) return;
+    const int b = lin / S, slab = lin - b * S;
+    const int n = npts ? (npts[b] < Nmax ? npts[b] : Nmax) : Nmax;
+    const int CP = S * SC, lo = slab * SC, NCH = (Nmax + kPlBlock - 1) / kPlBlock;
+    const float* base = pts + (long)b * Nmax * F;
+    constexpr int U = 16;
+    bool first = true;
+    int own = slab, ownk = 0;                      // the next 1024-point chunk this block owns (slab, slab + S, ...) and its slot in cnt
+    for (int i0 = 0; i0 < n || first; i0 += U * 1024) {
+        float px[U], py[U];
+        if (i0 < n) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {          // clamped addresses: the loads are unconditional, the predicate applies to the cell
+                const int i = i0 + tid + 1024 * u;
+                const float* p = base + (long)(i < n ? i : n - 1) * F;
+                if (vec4) { const float4 v = *reinterpret_cast<const float4*>(p); px[u] = v.x; py[u] = v.y; }
+                else { px[u] = p[0]; py[u] = p[1]; }
+            }
+        }
+        if (first) {                               // the accumulators are cleared while the first trip's points travel
+            float4* a4 = reinterpret_cast<float4*>(acc);
+            for (int k = tid; k < 2 * SC; k += 1024) a4[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (tid < 64) cnt[tid] = 0;
+            first = false;
+        }
+        if (tid == 0) qn = 0;
+        __syncthreads();
+        // phase A: the cell of every point of the trip; the few that fall into this slab (1 / S of the kept ones) are QUEUED - accumulating them here
+        // would run the fixed-point conversions and the four atomics for two or three live lanes of every wave and every u
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + tid + 1024 * u, chunk = (i0 >> 10) + u;
+            int local = -1;
+            if (dbg & 1) { if (px[u] == 123.f) keys[0] = 1; continue; }
+            if (i < n) {                           // point_pillar.py:70-83, as pillar_keys_kernel
+                const float x = px[u], y = py[u];
+                if (x >= min_x && x < max_x && y >= min_y && y < max_y) {
+                    const float fx = (x - min_x) * ppm, fy = (y - min_y) * ppm;
+                    int cx = (int)fx, cy = (int)fy;
+                    cx = cx < GX ? cx : GX - 1;
+                    cy = cy < GY ? cy : GY - 1;
+                    local = cx * GY + cy;
+                    if (local >= lo && local < lo + SC) {
+                        const int slot = atomicAdd(&qn, 1);
+                        if (slot < kPlQueue) queue[slot] = ((unsigned)(tid + 1024 * u) << 12) | (unsigned)(local - lo);
+                        else pillar_accumulate(acc + (long)(local - lo) * 4, x, y, base[(long)i * F + 2]);      // queue full (a cloud concentrated in one slab): in place
+                    }
+                }
+            }
+            if (!(dbg & 8) && chunk == own) {                // block-uniform: this block owns the chunk's keys and its kept-point count
+                if (i < Nmax) keys[(long)b * Nmax + i] = local >= 0 ? b * CP + local : -1;
+                const int c = wave_count(local >= 0);
+                if ((tid & 63) == 0 && c) atomicAdd(&cnt[ownk], c);
+                own += S; ++ownk;
+            }
+        }
+        __syncthreads();
+        // phase B: dense - one queued point per thread (its coordinates come back from L2)
+        const int nq = qn < kPlQueue ? qn : kPlQueue;
+        for (int e = tid; e < nq && !(dbg & 2); e += 1024) {
+            const unsigned q = queue[e];
+            const float* p = base + (long)(i0 + (int)(q >> 12)) * F;
+            pillar_accumulate(acc + (long)(q & 4095u) * 4, p[0], p[1], p[2]);
+        }
+        __syncthreads();
+    }
+    for (; own < NCH; own += S)                              // owned chunks behind the sample's last point: every key is -1, the count stays 0
+        if (own * kPlBlock + tid < Nmax) keys[(long)b * Nmax + own * kPlBlock + tid] = -1;
+    if (dbg & 4) return;
+    for (int q = tid; q < SC; q += 1024) {
+        const bool on = acc[(long)q * 4 + 3] != 0ull;
+        occ[q] = on ? 1 : 0;
+        if (on) {
+            const float4* a4 = reinterpret_cast<const float4*>(acc + (long)q * 4);
+            float4* o4 = reinterpret_cast<float4*>(cellsums + ((long)b * CP + lo + q) * 4);
+            o4[0] = a4[0];
+            o4[1] = a4[1];
+        }
+    }
+    __syncthreads();
+    if (tid < SC / 32) {
+        unsigned w = 0;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) w |= (unsigned)occ[tid * 32 + k] << k;
+        bitmap[((long)b * CP + lo) / 32 + tid] = w;
+    }
+    if (tid < 64 && slab + S * tid < NCH) blockcnt[b * NCH + slab + S * tid] = cnt[tid];
+}
+__global__ void __launch_bounds__(1024) pillar_scan_kernel(const unsigned* __restrict__ bitmap, int nwords, const int32_t* __restrict__ blockcnt, int nblocks,
+                                                           int32_t* __restrict__ wordprefix, int32_t* __restrict__ blockoff, int32_t* __restrict__ totals) {
+    __shared__ int sm[16];
+    const int t = threadIdx.x;
+    int carry = 0;
+    for (int base = 0; base < nwords; base += 8 * 4096) {        // eight 16-byte loads in flight per thread, then eight block scans (nwords % 4 == 0)
+        int4 v[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int w = base + r * 4096 + 4 * t;
+            v[r] = *reinterpret_cast<const int4*>(bitmap + (w < nwords ? w : 0));
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int w = base + r * 4096 + 4 * t;
+            if (base + r * 4096 >= nwords) break;                // block-uniform
+            const bool in = w < nwords;
+            const int c0 = in ? pl_popc((unsigned)v[r].x) : 0, c1 = in ? pl_popc((unsigned)v[r].y) : 0, c2 = in ? pl_popc((unsigned)v[r].z) : 0,
+                      c3 = in ? pl_popc((unsigned)v[r].w) : 0;
+            int tt;
+            const int ex = carry + block_excl_scan<16>((c0 + c1) + (c2 + c3), sm, tt);
+            if (in) { int4 o; o.x = ex; o.y = ex + c0; o.z = ex + c0 + c1; o.w = ex + c0 + c1 + c2; *reinterpret_cast<int4*>(wordprefix + w) = o; }
+            carry += tt;
+        }
+    }
+    if (t == 0) totals[1] = carry;
+    carry = 0;
+    for (int base = 0; base < nblocks; base += 1024) {
+        const int i = base + t, v = i < nblocks ? blockcnt[i] : 0;
+        int tt;
+        const int ex = block_excl_scan<16>(v, sm, tt);
+        if (i < nblocks) blockoff[i] = carry + ex;
+        carry += tt;
+    }
+    if (t == 0) totals[0] = carry;
+}
+__global__ void __launch_bounds__(256) pillar_gather_decorate_kernel(const float* __restrict__ pts, int F, int vec4, const int32_t* __restrict__ keys, int B, int Nmax,
+                                                                     const int32_t* __restrict__ blockoff, const int32_t* __restrict__ wordprefix,
+                                                                     const unsigned* __restrict__ bm, const long long* __restrict__ cellsums,
+                                                                     const int32_t* __restrict__ totals, int GX, int GY, int CP, float ppm, float min_x,
+                                                                     float min_y, float* __restrict__ pts4, int32_t* __restrict__ inv, float* __restrict__ feat,
+                                                                     int32_t* __restrict__ cellkey, long cell_cap, int fill_tail) {
+    __shared__ int sm[4];
+    __shared__ float lf[kPlBlock * 9];
+    const int NCH = (Nmax + kPlBlock - 1) / kPlBlock, nbA = B * NCH, nwords = (int)((long)B * CP / 32);
+    if ((int)blockIdx.x >= nbA) {          // cell blocks: one bitmap word (32 padded cells) per thread
+        const int w = ((int)blockIdx.x - nbA) * 256 + threadIdx.x;
+        if (w >= nwords) return;
+        const unsigned bits = bm[w];
+        if (bits == 0u && !fill_tail) return;
+        int r = wordprefix[w];
+        const int P = totals[1];
+        const long pc0 = (long)w * 32;
+        const int b = (int)(pc0 / CP), l0 = (int)(pc0 - (long)b * CP);        // CP % 32 == 0: a word never straddles two samples
+        for (int k = 0; k < 32; ++k) {
+            if ((bits >> k) & 1u) cellkey[r++] = b * GX * GY + l0 + k;
+            else if (fill_tail) {                                            // the u-th empty (padded) cell owns tail slot P + u
+                const long slot = (long)P + (pc0 + k - r);
+                if (slot < cell_cap) cellkey[slot] = -1;
+            }
+        }
+        return;
+    }
+    const int b = blockIdx.x / NCH, c = blockIdx.x - b * NCH;
+    const int j0 = c * kPlBlock + threadIdx.x * 4;
+    const long f0 = (long)b * Nmax + j0;                 // flat index of the thread's first point
+    int key[4], kept = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { key[j] = j0 + j < Nmax ? keys[f0 + j] : -1; kept += key[j] >= 0; }
+    float4 p[4];
+    int rk[4];
+    long long s[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {           // every gather of the four points before any store
+        const int k = key[j] >= 0 ? key[j] : b * CP;
+        const long i = j0 + j < Nmax ? f0 + j : (long)b * Nmax + Nmax - 1;
+        if (vec4) p[j] = *reinterpret_cast<const float4*>(pts + i * 4);
+        else p[j] = make_float4(pts[i * F], pts[i * F + 1], pts[i * F + 2], pts[i * F + 3]);
+        rk[j] = wordprefix[k >> 5] + pl_popc(bm[k >> 5] & ((1u << (k & 31)) - 1u));
+        if (key[j] >= 0) {
+            const long long* sr = cellsums + (long)k * 4;
+            s[j][0] = sr[0]; s[j][1] = sr[1]; s[j][2] = sr[2]; s[j][3] = sr[3];
+        } else { s[j][0] = s[j][1] = s[j][2] = s[j][3] = 0; }
+    }
+    int tot;
+    const int ex = block_excl_scan<4>(kept, sm, tot);
+    const long row0 = (long)blockoff[blockIdx.x];        // the block's kept points are rows [row0, row0 + tot): their features leave through LDS as contiguous
+    const long N = totals[0];                            // dwords (nine 4-byte stores per lane at a 36-byte stride are address-rate bound: 15.8 -> measured below)
+    int r = ex;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (key[j] >= 0) {
+            // decorate (:54-67) exactly as pillar_decorate_kernel: the pillar's coordinate SUMS rounded to fp32 once, quirk Q15 kept
+            const double inv_fix = 1.0 / (double)kPillarFix;
+            const float mx = (float)((double)s[j][0] * inv_fix), my = (float)((double)s[j][1] * inv_fix), mz = (float)((double)s[j][2] * inv_fix);
+            const float cw = (float)s[j][3], cnt = cw < 1.f ? 1.f : cw;
+            const int local = key[j] - b * CP;
+            const int cy = local % GY, cx = local / GY;
+            const float xc = (float)cy / ppm + min_x, yc = (float)cx / ppm + min_y;
+            *reinterpret_cast<float4*>(pts4 + (row0 + r) * 4) = p[j];
+            inv[row0 + r] = rk[j];
+            float* f = lf + r * 9;
+            f[0] = p[j].x; f[1] = p[j].y; f[2] = p[j].z; f[3] = p[j].w;
+            f[4] = p[j].x - mx / cnt; f[5] = p[j].y - my / cnt; f[6] = p[j].z - mz / cnt;
+            f[7] = p[j].x - xc; f[8] = p[j].y - yc;
+            ++r;
+        }
+    }
+    __syncthreads();
+    float* fo = feat + row0 * 9;
+    for (int k = threadIdx.x; k < tot * 9; k += 256) fo[k] = lf[k];
+    if (fill_tail) {
+        // static shapes: the block's dropped points own the tail rows [N + d0, N + d0 + nd), d0 = dropped points in front of the block
+        const int npt = Nmax - c * kPlBlock < kPlBlock ? Nmax - c * kPlBlock : kPlBlock, nd = npt - tot;
+        const long t0 = N + ((long)b * Nmax + (long)c * kPlBlock - row0);
+        for (int k = threadIdx.x; k < nd; k += 256) { *reinterpret_cast<float4*>(pts4 + (t0 + k) * 4) = make_float4(0.f, 0.f, 0.f, 0.f); inv[t0 + k] = 0; }
+        float* ft = feat + t0 * 9;
+        for (int k = threadIdx.x; k < nd * 9; k += 256) ft[k] = 0.f;
+    }
+}
+
 __global__ void __launch_bounds__(256) fill_i32_kernel(int32_t* __restrict__ p, long n, int32_t v) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) p[i] = v;
 }
@@ -466,6 +752,46 @@ extern "C" int tf_pillar_gather_f32(const float* points, int point_stride, const
     TF_LAUNCH(pillar_gather_kernel, dim3(pl_blocks((n_all + 3) / 4)), dim3(256), stream, points, point_stride, keys, pos, rank, (long)n_all, pts4, inv,
               reinterpret_cast<long long*>(sums));
     return launch_status("tf_pillar_gather_f32");
+}
+
+/* ---- round 6: the three-launch pillar index (kernels above) ---- */
+static int pl_dbg() { static const int d = [] { const char* e = getenv("TF_PL_DBG"); return e ? atoi(e) : 0; }(); return d; }      // timing diagnosis: phases of the slab kernel off (results are garbage)
+extern "C" long tf_pillar_padded_cells(int GX, int GY) { return GX > 0 && GY > 0 ? (long)pl_geom(GX, GY).CP : -1; }
+extern "C" int tf_pillar_mark_f32(const float* points, const int32_t* num_points, int B, int max_points, int point_stride, float min_x, float max_x, float min_y,
+                                  float max_y, float pixels_per_meter, int GX, int GY, int32_t* keys, int32_t* bitmap, int64_t* cellsums, int32_t* blockcnt,
+                                  void* stream) {
+    TF_REQUIRE(points && keys && bitmap && cellsums && blockcnt && B > 0 && max_points > 0 && point_stride >= 4 && GX > 0 && GY > 0 && aligned16(cellsums) &&
+                   aligned16(bitmap), "tf_pillar_mark_f32: bad arguments (bitmap / cellsums 16-byte aligned)");
+    const PlGeom g = pl_geom(GX, GY);
+    TF_REQUIRE((long)B * g.CP < 16777216L && (long)B * max_points < 16777216L && cdiv(max_points, kPlBlock) <= 64 * g.S,
+               "tf_pillar_mark_f32: padded cells and points must stay below 2^24, max_points below 65536 x slabs");
+    const int vec4 = point_stride == 4 && aligned16(points);
+    TF_LAUNCH(pillar_slab_kernel, dim3(8 * cdiv((long)B * g.S, 8)), dim3(1024), stream, points, num_points, B, max_points, point_stride, vec4, min_x, max_x, min_y, max_y,
+              pixels_per_meter, GX, GY, g.S, g.SC, keys, reinterpret_cast<unsigned*>(bitmap), reinterpret_cast<long long*>(cellsums), blockcnt, pl_dbg());
+    return launch_status("tf_pillar_mark_f32");
+}
+extern "C" int tf_pillar_rank_scan_i32(const int32_t* bitmap, int64_t padded_cells, const int32_t* blockcnt, int nblocks, int32_t* wordprefix, int32_t* blockoff,
+                                       int32_t* totals, void* stream) {
+    TF_REQUIRE(bitmap && blockcnt && wordprefix && blockoff && totals && padded_cells > 0 && padded_cells % 128 == 0 && padded_cells < 16777216L && nblocks > 0 &&
+                   aligned16(bitmap) && aligned16(wordprefix), "tf_pillar_rank_scan_i32: bad arguments (padded_cells = B x tf_pillar_padded_cells(), 16-byte aligned arrays)");
+    TF_LAUNCH(pillar_scan_kernel, dim3(1), dim3(1024), stream, reinterpret_cast<const unsigned*>(bitmap), (int)(padded_cells / 32), blockcnt, nblocks, wordprefix,
+              blockoff, totals);
+    return launch_status("tf_pillar_rank_scan_i32");
+}
+extern "C" int tf_pillar_gather_decorate_f32(const float* points, int point_stride, const int32_t* keys, int B, int max_points, const int32_t* blockoff,
+                                             const int32_t* wordprefix, const int32_t* bitmap, const int64_t* cellsums, const int32_t* totals, int GX, int GY,
+                                             float pixels_per_meter, float min_x, float min_y, float* pts4, int32_t* inv, float* feat, int32_t* cellkey,
+                                             int64_t cell_cap, int fill_tail, void* stream) {
+    TF_REQUIRE(points && keys && blockoff && wordprefix && bitmap && cellsums && totals && pts4 && inv && feat && cellkey && B > 0 && max_points > 0 && GX > 0 &&
+                   GY > 0 && point_stride >= 4 && aligned16(pts4) && cell_cap >= 0, "tf_pillar_gather_decorate_f32: bad arguments");
+    const PlGeom g = pl_geom(GX, GY);
+    TF_REQUIRE(!fill_tail || cell_cap <= (long)B * g.CP, "tf_pillar_gather_decorate_f32: cell_cap exceeds the number of cells");
+    const int nbA = B * cdiv(max_points, kPlBlock), nbB = cdiv((long)B * g.CP / 32, 256);
+    const int vec4 = point_stride == 4 && aligned16(points);
+    TF_LAUNCH(pillar_gather_decorate_kernel, dim3(nbA + nbB), dim3(256), stream, points, point_stride, vec4, keys, B, max_points, blockoff, wordprefix,
+              reinterpret_cast<const unsigned*>(bitmap), reinterpret_cast<const long long*>(cellsums), totals, GX, GY, g.CP, pixels_per_meter, min_x, min_y, pts4, inv,
+              feat, cellkey, (long)cell_cap, fill_tail);
+    return launch_status("tf_pillar_gather_decorate_f32");
 }
 
 extern "C" int tf_pillar_decorate_f32(const float* pts4, const int32_t* inv, const int64_t* sums, const int32_t* cellkey, int64_t N, int GX, int GY,

@@ -795,7 +795,7 @@ def _gpt_block_bwd(gpt, li, saved, dx, B, T, drop):
             dy = ops.linear_dgrad(dres, proj.weight)
     if att_d is None:       # fused attention: att is the log-sum-exp; probabilities are recomputed inside the two backward kernels
         adrop = (gpt.seed, gpt.site(4 * li + 1), gpt.attn_pdrop) if (drop and gpt.attn_pdrop > 0) else None
-        dqkv = ops.attention_bwd(qkv, dy, att, B, T, C, nh, adrop)
+        dqkv = ops.attention_bwd(qkv, dy, att, B, T, C, nh, adrop, y=y_att)
     else:
         dqkv = torch.empty_like(qkv)
         datt = torch.empty_like(att)

@@ -929,11 +929,19 @@ def attention_fwd(qkv, B, T, C, nh, drop=None):
     return y, lse
 
 
-def attention_bwd(qkv, dy, lse, B, T, C, nh, drop=None):
-    """-> dqkv (B*T, 3C): gradients of [key | query | value]; the probabilities are recomputed from qkv and lse."""
+ATT_BWD_ONE = os.environ.get("TF_ATT_BWD_ONE", "1") != "0"      # 0: the two dependent launches (queries, then keys) of rounds 3-5
+
+
+def attention_bwd(qkv, dy, lse, B, T, C, nh, drop=None, y=None):
+    """-> dqkv (B*T, 3C): gradients of [key | query | value]; the probabilities are recomputed from qkv and lse.  y = attention_fwd's output: the row sums
+    D_i = dY_i . Y_i come from it and the key / query halves run as ONE grid (tf_attention_bwd_y_f32)."""
     dqkv = torch.empty_like(qkv)
     dsum = torch.empty_like(lse)
     seed, site, p = drop if drop is not None else (None, 0, 0.0)
+    if y is not None and ATT_BWD_ONE:
+        check(L().tf_attention_bwd_y_f32(ptr(_c(qkv)), ptr(_c(dy)), ptr(_c(y)), ptr(lse), ptr(dqkv), ptr(dsum), B, T, C, nh, ptr(seed), ctypes.c_uint32(site),
+                                         ctypes.c_float(p), stream_of(qkv)), "tf_attention_bwd_y_f32")
+        return dqkv
     check(L().tf_attention_bwd_f32(ptr(_c(qkv)), ptr(_c(dy)), ptr(lse), ptr(dqkv), ptr(dsum), B, T, C, nh, ptr(seed), ctypes.c_uint32(site),
                                    ctypes.c_float(p), stream_of(qkv)), "tf_attention_bwd_f32")
     return dqkv
@@ -1521,7 +1529,52 @@ def _scan(flags):
     return out, total
 
 
+_PILLAR_V2 = os.environ.get("TF_PILLAR_V2", "1") != "0"      # 0: the seven-launch form of rounds 3-5 (A/B, tools/hbm_bench.py)
+
+
 def pillar_index(points, num_points, min_x, max_x, min_y, max_y, ppm, static=False):
+    """point_pillar.py:98-117 without the sort: returns a dict with the compacted points (N,4), 9 decorated features (N,9),
+    inverse indices (N) int32, cellkey (P) int32 [= ((b*GX + x_idx)*GY + y_idx), sorted like torch.unique] and the grid dims.
+    One host read (N, P) - the reference's unique() synchronises at the same place.
+    static=True (hipGraph capture): NO host read - every tensor has its capacity (N -> B * Nmax rows, P -> min(B * Nmax, cells)), ``totals`` =
+    (kept points, pillars) stays on the device, rows / slots beyond the counts are zero (points, inv, features) or -1 (cell keys);
+    the consumers run over the capacity and the point net's BatchNorm reads its row count from ``totals`` (bn_rows_dev_*).
+    Three launches (slab accumulation in LDS, scan, gather + decorate; csrc/pillars.cpp "Round 6"), no fills and no global atomics in either mode."""
+    if not _PILLAR_V2:
+        return _pillar_index_v1(points, num_points, min_x, max_x, min_y, max_y, ppm, static)
+    B, Nmax, Fp = points.shape
+    nx, ny = int((max_x - min_x) * ppm), int((max_y - min_y) * ppm)
+    GX, GY = nx + 1, ny + 1
+    dev = points.device
+    i32 = lambda *s: torch.empty(*s, dtype=torch.int32, device=dev)
+    f, i64 = ctypes.c_float, ctypes.c_int64
+    L().tf_pillar_padded_cells.restype = ctypes.c_long
+    CP = L().tf_pillar_padded_cells(GX, GY)
+    n_all, ncells, nwords, nblk = B * Nmax, B * GX * GY, B * CP // 32, B * ((Nmax + 1023) // 1024)
+    points = _c(points)
+    keys, small = i32(n_all), i32(2 * nwords + 2 * nblk + 4)          # bitmap | wordprefix (16-byte aligned: nwords % 4 == 0) | blockcnt | blockoff | totals
+    bitmap, wordprefix, blockcnt, blockoff, totals = small[:nwords], small[nwords:2 * nwords], small[2 * nwords:2 * nwords + nblk], \
+        small[2 * nwords + nblk:2 * nwords + 2 * nblk], small[2 * nwords + 2 * nblk:2 * nwords + 2 * nblk + 2]
+    cellsums = torch.empty(B * CP, 4, dtype=torch.int64, device=dev)     # written and read for the occupied cells only
+    st = stream_of(points)
+    check(L().tf_pillar_mark_f32(ptr(points), ptr(num_points), B, Nmax, Fp, f(min_x), f(max_x), f(min_y), f(max_y), f(ppm), GX, GY, ptr(keys), ptr(bitmap),
+                                 ptr(cellsums), ptr(blockcnt), st), "tf_pillar_mark_f32")
+    check(L().tf_pillar_rank_scan_i32(ptr(bitmap), i64(B * CP), ptr(blockcnt), nblk, ptr(wordprefix), ptr(blockoff), ptr(totals), st), "tf_pillar_rank_scan_i32")
+    if static:
+        N, P = n_all, min(n_all, ncells)
+    else:
+        N, P = (int(v) for v in totals.tolist())
+    pts4 = torch.empty(N, 4, dtype=torch.float32, device=dev)
+    inv, cellkey = i32(N), i32(P)
+    feat = torch.empty(N, 9, dtype=torch.float32, device=dev)
+    if N:
+        check(L().tf_pillar_gather_decorate_f32(ptr(points), Fp, ptr(keys), B, Nmax, ptr(blockoff), ptr(wordprefix), ptr(bitmap), ptr(cellsums), ptr(totals), GX, GY,
+                                                f(ppm), f(min_x), f(min_y), ptr(pts4), ptr(inv), ptr(feat), ptr(cellkey), i64(P), int(bool(static)), st),
+              "tf_pillar_gather_decorate_f32")
+    return dict(points=pts4, feat=feat, inv=inv, cellkey=cellkey, N=N, P=P, GX=GX, GY=GY, nx=nx, ny=ny, totals=totals, static=bool(static))
+
+
+def _pillar_index_v1(points, num_points, min_x, max_x, min_y, max_y, ppm, static=False):
     """point_pillar.py:98-117 without the sort: returns a dict with the compacted points (N,4), 9 decorated features (N,9),
     inverse indices (N) int32, cellkey (P) int32 [= ((b*GX + x_idx)*GY + y_idx), sorted like torch.unique] and the grid dims.
     One host read (N, P) - the reference's unique() synchronises at the same place.
