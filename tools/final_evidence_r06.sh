@@ -19,9 +19,9 @@ TAG=$TAG timeout 700 bash tools/pmc_roofline.sh fp32 2>&1 | tail -8 | cut -c1-26
 cp $O/${TAG}_pmc_gemm_roofline.json $O/${TAG}_pmc_gemm_roofline.txt profiles/ 2>/dev/null
 ( time timeout 1200 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/${TAG}_bench_n1.json 2> $O/${TAG}_bench_n1.err ) 2>&1 | tail -3
 tail -14 $O/${TAG}_bench_n1.err
-S5="TF_GROUPED_WGRAD7=0 TF_GROUPED_F32T=0 TF_SMALL_TRN=0 TF_HIST_SLAB=0"
+S5="TF_GROUPED_WGRAD7=0 TF_GROUPED_F32T=0 TF_SMALL_TRN=0 TF_HIST_SLAB=0 TF_FORK_DECODERS=0 TF_ATT_BWD_ONE=0 TF_ATT_ROWLDS=0 TF_PILLAR_V2=0"
 for rep in 1 2 3; do
-  env $S5 timeout 200 $B 2>/dev/null | bl "fp32 round-5 behaviour of this library (three-wave grouped wgrad, pixel-major direct kernels)"
+  env $S5 timeout 200 $B 2>/dev/null | bl "fp32 round-5 behaviour of this library (every round-6 switch off)                         "
   timeout 200 $B 2>/dev/null | bl "fp32 round-6 head                                                                         "
 done
 for rep in 1 2; do

@@ -701,7 +701,7 @@ def _gpt_block_fwd(gpt, li, x, B, T, drop):
     rdrop = drop and gpt.resid_pdrop > 0
     if lowp:
         ya_16, ya_t = ops.cast16(y_att)
-        y_att = A16(ya_t)
+        y_att = A16(ya_t, y_att if att_d is None else None)      # fused attention: its backward forms D = dY . Y from the fp32 output
         lin = lambda a16, layer, **kw: _lin16_fwd(a16, layer.weight, layer.bias, **kw)
     else:
         ya_16 = y_att
@@ -795,7 +795,7 @@ def _gpt_block_bwd(gpt, li, saved, dx, B, T, drop):
             dy = ops.linear_dgrad(dres, proj.weight)
     if att_d is None:       # fused attention: att is the log-sum-exp; probabilities are recomputed inside the two backward kernels
         adrop = (gpt.seed, gpt.site(4 * li + 1), gpt.attn_pdrop) if (drop and gpt.attn_pdrop > 0) else None
-        dqkv = ops.attention_bwd(qkv, dy, att, B, T, C, nh, adrop, y=y_att)
+        dqkv = ops.attention_bwd(qkv, dy, att, B, T, C, nh, adrop, y=y_att.f32 if isinstance(y_att, A16) else y_att)
     else:
         dqkv = torch.empty_like(qkv)
         datt = torch.empty_like(att)
