@@ -14,7 +14,7 @@ for pass in "SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA" "SQ_ACTIV
     timeout 200 rocprofv3 --pmc $pass --kernel-trace -d "$OUT" -o "p$i" --output-format csv -- python "$R/tools/attention_lab.py" --pmc > "$OUT/p$i.log" 2>&1
 done
 python - "$OUT" > "$R/gpurun_out/${TAG}_pmc_attention.txt" <<'PY'
-import csv, glob, os, sys, collections
+import csv, glob, os, re, sys, collections
 d = sys.argv[1]
 vals = collections.defaultdict(lambda: collections.defaultdict(list))
 durs = collections.defaultdict(list)
@@ -26,7 +26,7 @@ for cc in sorted(glob.glob(os.path.join(d, "*_counter_collection.csv"))):
         n = r["Kernel_Name"]
         if "attention" not in n:
             continue
-        key = (n.split("(")[0].split("::")[-1], r.get("Grid_Size", ""), r.get("LDS_Block_Size", ""))
+        key = (re.search(r"attention_\w+", n).group(0), r.get("Grid_Size", ""), r.get("LDS_Block_Size", ""))
         vals[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
         if (tag, r["Dispatch_Id"]) not in seen:
             seen.add((tag, r["Dispatch_Id"]))
